@@ -1,0 +1,121 @@
+/*
+ * phylocsf_amd.h -- C-ABI of the MI355X (gfx950) PhyloCSF scoring core.
+ *
+ * Drop-in boundary: the reference (cpockrandt/PhyloCSFpp v1.2.0) has no FFI; its scoring core is
+ * reached through two free functions called from inside the OpenMP job loops:
+ *
+ *   void run_tracks(Data&, const Model&, const alignment_t&, std::vector<double>&)   src/run.hpp:35
+ *        callers: src/phylocsf++build_tracks.hpp:172, src/phylocsf++score_msa.hpp:149
+ *   std::tuple<float,float> run(Data&, const Model&, const alignment_t&, algorithm_t,
+ *                               std::mt19937&, bool)                                src/run.hpp:57
+ *        caller:  src/phylocsf++score_msa.hpp:116
+ *
+ * The entry points below replace exactly those two calls (batched, because one call per
+ * alignment x frame is too fine for a GPU) plus the model set-up they repeat on every call
+ * (PhyloCSFModel_make, src/instance.hpp:687-712).  INTEGRATION.md shows the binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions: plain C types only; every function returns 0 on success or a negative
+ * pcsf_status; no exception crosses the boundary; the caller owns every buffer; a context is
+ * bound to one GPU and may be used by one host thread at a time; outputs are in input order.
+ * There is NO CPU fallback: if no gfx950 device is present pcsf_create fails with
+ * PCSF_ERR_NO_DEVICE.
+ */
+#ifndef PHYLOCSF_AMD_H
+#define PHYLOCSF_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCSF_STATES 64     /* codon states incl. stops (src/ecm.hpp:17-18) */
+#define PCSF_GAP_CODON 64  /* "marginalise" leaf code (src/translation.hpp:80-88) */
+
+typedef enum {
+    PCSF_OK = 0,
+    PCSF_ERR_INVALID_ARG = -1,
+    PCSF_ERR_NO_DEVICE = -2,   /* no HIP device / not gfx950 / extension not usable */
+    PCSF_ERR_HIP = -3,         /* a HIP runtime call failed; see pcsf_last_error */
+    PCSF_ERR_MODEL = -4,       /* P(t) failed the reference's validation (src/instance.hpp:618,635) */
+    PCSF_ERR_UNSUPPORTED = -5
+} pcsf_status;
+
+/* algorithm_t, src/run.hpp:16-21 (same numeric values) */
+typedef enum { PCSF_MLE = 0, PCSF_FIXED = 1, PCSF_OMEGA = 2 } pcsf_algo;
+
+/* What the path reads from `Model` (src/models.hpp:1742-1755):
+ *   phylo_array  -> the flattened tree exactly as newick_flatten numbers it
+ *                   (src/newick.hpp:170-229): ids 0..nl-1 leaves left-to-right, nl..n-1 internal
+ *                   nodes in post-order, root = n-1; child ids -1 for leaves; FLOAT branch lengths
+ *   c_model / nc_model -> empirical_codon_model::matrix (row-major 64x64, symmetric, zero
+ *                   diagonal) and ::codon_freq (src/ecm.hpp:15-19) */
+typedef struct {
+    int32_t n_nodes;
+    const int16_t *child1;     /* [n_nodes] */
+    const int16_t *child2;     /* [n_nodes] */
+    const float *branch_len;   /* [n_nodes] (root entry ignored) */
+    const double *S_coding;    /* [64*64] */
+    const double *pi_coding;   /* [64] */
+    const double *S_noncoding; /* [64*64] */
+    const double *pi_noncoding;/* [64] */
+} pcsf_model_desc;
+
+typedef struct pcsf_ctx pcsf_ctx;
+
+/* Replaces PhyloCSFModel_make x2 (src/run.hpp:38-39): builds Q, its eigen-system and the
+ * 2*(n-1) branch matrices once and keeps them resident in HBM.  device_id: HIP ordinal. */
+int pcsf_create(pcsf_ctx **out, const pcsf_model_desc *model, int device_id);
+void pcsf_destroy(pcsf_ctx *ctx);
+/* message of the last failure on this context (or of the last failed pcsf_create if ctx==NULL) */
+const char *pcsf_last_error(const pcsf_ctx *ctx);
+int pcsf_n_leaves(const pcsf_ctx *ctx);
+
+/* ---- run_tracks (src/run.hpp:35-55): per-codon 10*(ln z_coding - ln z_noncoding)/ln 10 ------
+ * codons: the reference's alignment_t::peptides, leaf-major uint8 [n_leaves][leaf_stride],
+ * values 0..63 or 64 (= marginalise).  Sites of any number of alignments/frames may be
+ * concatenated into one call; every site is independent.  out: [n_sites] fp64. */
+int pcsf_score_sites_fixed(pcsf_ctx *ctx, const uint8_t *codons, size_t n_sites, size_t leaf_stride,
+                           double *out_decibans);
+
+/* Same, but codons/out are DEVICE pointers on ctx's GPU and the work is enqueued on
+ * `hip_stream` (a hipStream_t, NULL = default stream) without synchronising.
+ * out_lnz may be NULL, else device [2][n_sites]: ln z under the coding (row 0) and the
+ * non-coding (row 1) model (the lpr_per_codon vectors of src/fixed_lik.hpp:431-433). */
+int pcsf_score_sites_fixed_dev(pcsf_ctx *ctx, const uint8_t *d_codons, size_t n_sites, size_t leaf_stride,
+                               double *d_out_decibans, double *d_out_lnz, void *hip_stream);
+
+/* ---- run (src/run.hpp:57-211): whole-block scores -----------------------------------------
+ * A batch of blocks in CSR form: block b owns sites [site_offsets[b], site_offsets[b+1]) of the
+ * leaf-major codon matrix.  algo FIXED / MLE / OMEGA; seed is what score-msa passes to
+ * gen.seed() per block (42, src/phylocsf++score_msa.hpp:115).  out_phylo/out_anc: [n_blocks]
+ * float like the reference's std::tuple<float,float>; a block whose model fails validation gets
+ * NaN in both (score-msa swallows the exception, src/phylocsf++score_msa.hpp:124-127); out_anc
+ * may be NULL; it is NaN in OMEGA mode (src/run.hpp:181). */
+int pcsf_score_blocks(pcsf_ctx *ctx, int algo, const uint8_t *codons, const uint64_t *site_offsets,
+                      size_t n_blocks, size_t leaf_stride, int compute_anc, uint32_t seed,
+                      float *out_phylo, float *out_anc);
+
+/* ---- diagnostics ---------------------------------------------------------------------------*/
+/* milliseconds spent in the pruning kernel by the last *_fixed / *_fixed_dev call that was
+ * timed; pcsf_set_timing(ctx,1) brackets each launch with HIP events ON THE LAUNCH STREAM. */
+int pcsf_set_timing(pcsf_ctx *ctx, int enable);
+double pcsf_last_kernel_ms(const pcsf_ctx *ctx);
+/* copies the branch matrices the context holds back to the host: [2][n_nodes-1][64][64],
+ * row = parent state (for parity tests of the P(t) stage) */
+int pcsf_get_branch_matrices(pcsf_ctx *ctx, double *out);
+/* host-only (works without a GPU): the straight-line pruning program the kernel interprets for
+ * a tree, op = code<<28 | a<<14 | b (codes in phylocsfpp_amd/csrc/schedule.hpp), and for every
+ * MATMUL slot the node whose branch matrix it uses.  program_cap >= 4*n_nodes is always enough;
+ * slot_node needs n_nodes entries. */
+int pcsf_build_schedule(int32_t n_nodes, const int16_t *child1, const int16_t *child2, uint32_t *program,
+                        int32_t program_cap, int32_t *slot_node, int32_t *n_ops, int32_t *n_slots,
+                        int32_t *stack_depth);
+const char *pcsf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,203 @@
+"""phylocsfpp_amd -- MI355X (gfx950) PhyloCSF scoring core.
+
+Thin ctypes binding of the C-ABI in include/phylocsf_amd.h (libphylocsf_amd.so, hand-written
+HIP kernels).  Mirrors the two entry points of the reference's scoring core,
+``run_tracks`` (src/run.hpp:35) and ``run`` (src/run.hpp:57).  There is no CPU implementation
+in this package: without the built extension or without a gfx950 device every call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+__all__ = ["ScoringContext", "PcsfError", "library_path", "load_library", "FIXED", "MLE", "OMEGA"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libphylocsf_amd.so")
+
+MLE, FIXED, OMEGA = 0, 1, 2  # algorithm_t, src/run.hpp:16-21
+
+
+class PcsfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("phylocsf_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _ModelDesc(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32),
+                ("child1", C.POINTER(C.c_int16)), ("child2", C.POINTER(C.c_int16)),
+                ("branch_len", C.POINTER(C.c_float)),
+                ("S_coding", C.POINTER(C.c_double)), ("pi_coding", C.POINTER(C.c_double)),
+                ("S_noncoding", C.POINTER(C.c_double)), ("pi_noncoding", C.POINTER(C.c_double))]
+
+
+_lib = None
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Loads the in-tree HIP extension; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError("%s is missing: build it with `python -m phylocsfpp_amd._build` "
+                          "(hipcc, --offload-arch=gfx950); there is no CPU fallback" % _LIB_PATH)
+    lib = C.CDLL(_LIB_PATH)
+    vp, dp, u8p, fp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_float)
+    lib.pcsf_version.restype = C.c_char_p
+    lib.pcsf_create.argtypes = [C.POINTER(vp), C.POINTER(_ModelDesc), C.c_int]
+    lib.pcsf_destroy.argtypes = [vp]
+    lib.pcsf_last_error.restype = C.c_char_p
+    lib.pcsf_last_error.argtypes = [vp]
+    lib.pcsf_n_leaves.argtypes = [vp]
+    lib.pcsf_score_sites_fixed.argtypes = [vp, u8p, C.c_size_t, C.c_size_t, dp]
+    lib.pcsf_score_sites_fixed_dev.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, vp, vp]
+    lib.pcsf_score_blocks.argtypes = [vp, C.c_int, u8p, C.POINTER(C.c_uint64), C.c_size_t, C.c_size_t, C.c_int,
+                                      C.c_uint32, fp, fp]
+    lib.pcsf_set_timing.argtypes = [vp, C.c_int]
+    lib.pcsf_last_kernel_ms.restype = C.c_double
+    lib.pcsf_last_kernel_ms.argtypes = [vp]
+    lib.pcsf_get_branch_matrices.argtypes = [vp, dp]
+    lib.pcsf_build_schedule.argtypes = [C.c_int32, C.POINTER(C.c_int16), C.POINTER(C.c_int16), C.POINTER(C.c_uint32),
+                                        C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32)]
+    _lib = lib
+    return lib
+
+
+def build_schedule(child1, child2):
+    """Host-only: the pruning program the kernel interprets for this tree (no GPU needed).
+    Returns (program uint32[n_ops], slot_node int32[n_slots], stack_depth)."""
+    lib = load_library()
+    c1 = np.ascontiguousarray(child1, dtype=np.int16)
+    c2 = np.ascontiguousarray(child2, dtype=np.int16)
+    n = len(c1)
+    prog = np.zeros(4 * n + 8, dtype=np.uint32)
+    slots = np.zeros(n, dtype=np.int32)
+    n_ops, n_slots, depth = C.c_int32(), C.c_int32(), C.c_int32()
+    rc = lib.pcsf_build_schedule(n, c1.ctypes.data_as(C.POINTER(C.c_int16)), c2.ctypes.data_as(C.POINTER(C.c_int16)),
+                                 prog.ctypes.data_as(C.POINTER(C.c_uint32)), len(prog),
+                                 slots.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n_ops), C.byref(n_slots),
+                                 C.byref(depth))
+    if rc:
+        raise PcsfError(rc, lib.pcsf_last_error(None).decode())
+    return prog[:n_ops.value].copy(), slots[:n_slots.value].copy(), depth.value
+
+
+class ScoringContext:
+    """One model resident on one GPU (replaces the per-call PhyloCSFModel_make of src/run.hpp:38-39).
+
+    child1/child2/branch_len: the flattened tree in newick_flatten order (src/newick.hpp:170-229);
+    S_*/pi_*: empirical_codon_model::matrix / ::codon_freq (src/ecm.hpp:15-19)."""
+
+    def __init__(self, child1, child2, branch_len, S_coding, pi_coding, S_noncoding, pi_noncoding, device=0):
+        lib = load_library()
+        self._lib = lib
+        self._keep = dict(
+            c1=np.ascontiguousarray(child1, dtype=np.int16), c2=np.ascontiguousarray(child2, dtype=np.int16),
+            bl=np.ascontiguousarray(branch_len, dtype=np.float32),
+            sc=np.ascontiguousarray(S_coding, dtype=np.float64).reshape(-1),
+            pc=np.ascontiguousarray(pi_coding, dtype=np.float64),
+            sn=np.ascontiguousarray(S_noncoding, dtype=np.float64).reshape(-1),
+            pn=np.ascontiguousarray(pi_noncoding, dtype=np.float64))
+        k = self._keep
+        n = len(k["c1"])
+        if not (len(k["c2"]) == n == len(k["bl"])) or k["sc"].size != 4096 or k["sn"].size != 4096 \
+                or k["pc"].size != 64 or k["pn"].size != 64:
+            raise ValueError("inconsistent model array sizes")
+        desc = _ModelDesc(n, k["c1"].ctypes.data_as(C.POINTER(C.c_int16)), k["c2"].ctypes.data_as(C.POINTER(C.c_int16)),
+                          k["bl"].ctypes.data_as(C.POINTER(C.c_float)),
+                          k["sc"].ctypes.data_as(C.POINTER(C.c_double)), k["pc"].ctypes.data_as(C.POINTER(C.c_double)),
+                          k["sn"].ctypes.data_as(C.POINTER(C.c_double)), k["pn"].ctypes.data_as(C.POINTER(C.c_double)))
+        h = C.c_void_p()
+        rc = lib.pcsf_create(C.byref(h), C.byref(desc), int(device))
+        if rc:
+            raise PcsfError(rc, lib.pcsf_last_error(None).decode())
+        self._h = h
+        self.device = int(device)
+        self.n_nodes = n
+        self.n_leaves = (n + 1) // 2
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pcsf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise PcsfError(rc, self._lib.pcsf_last_error(self._h).decode())
+
+    # ---- run_tracks ----------------------------------------------------------------------
+    def score_sites_fixed(self, codons):
+        """codons: uint8 ndarray [n_leaves, n_sites] (host) -> float64 ndarray [n_sites] of
+        10*(ln z_c - ln z_nc)/ln 10, the vector run_tracks returns (src/run.hpp:51-54)."""
+        codons = np.asarray(codons)
+        if codons.dtype != np.uint8 or codons.ndim != 2 or codons.shape[0] != self.n_leaves:
+            raise ValueError("codons must be uint8 [n_leaves=%d, n_sites]" % self.n_leaves)
+        n = codons.shape[1]
+        out = np.empty(n, dtype=np.float64)
+        if n == 0:
+            return out
+        if codons.strides[1] != 1:
+            codons = np.ascontiguousarray(codons)
+        self._check(self._lib.pcsf_score_sites_fixed(self._h, codons.ctypes.data_as(C.POINTER(C.c_uint8)), n,
+                                                     codons.strides[0], out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def score_sites_fixed_device(self, d_codons, n_sites, leaf_stride, d_out, d_lnz=0, stream=0):
+        """Raw device-pointer form (ints): enqueues on `stream` (hipStream_t as int) without synchronising."""
+        self._check(self._lib.pcsf_score_sites_fixed_dev(self._h, C.c_void_p(d_codons), n_sites, leaf_stride,
+                                                         C.c_void_p(d_out), C.c_void_p(d_lnz or None),
+                                                         C.c_void_p(stream or None)))
+
+    def score_sites_fixed_torch(self, codons, out=None, lnz=None):
+        """codons: torch.uint8 CUDA tensor [n_leaves, n_sites] on this context's GPU.  Launches on
+        torch's current stream; returns a float64 CUDA tensor [n_sites]."""
+        import torch
+        if codons.dtype != torch.uint8 or codons.dim() != 2 or codons.shape[0] != self.n_leaves or not codons.is_cuda:
+            raise ValueError("codons must be a CUDA uint8 tensor [n_leaves, n_sites]")
+        if codons.stride(1) != 1:
+            codons = codons.contiguous()
+        n = codons.shape[1]
+        if out is None:
+            out = torch.empty(n, dtype=torch.float64, device=codons.device)
+        stream = torch.cuda.current_stream(codons.device).cuda_stream
+        self.score_sites_fixed_device(codons.data_ptr(), n, codons.stride(0), out.data_ptr(),
+                                      lnz.data_ptr() if lnz is not None else 0, stream)
+        return out
+
+    # ---- run -----------------------------------------------------------------------------
+    def score_blocks(self, algo, codons, site_offsets, compute_anc=True, seed=42):
+        codons = np.ascontiguousarray(codons, dtype=np.uint8)
+        off = np.ascontiguousarray(site_offsets, dtype=np.uint64)
+        nb = len(off) - 1
+        phylo = np.full(nb, np.nan, dtype=np.float32)
+        anc = np.full(nb, np.nan, dtype=np.float32)
+        self._check(self._lib.pcsf_score_blocks(self._h, int(algo), codons.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                off.ctypes.data_as(C.POINTER(C.c_uint64)), nb, codons.strides[0],
+                                                int(compute_anc), seed, phylo.ctypes.data_as(C.POINTER(C.c_float)),
+                                                anc.ctypes.data_as(C.POINTER(C.c_float))))
+        return phylo, anc
+
+    # ---- diagnostics -----------------------------------------------------------------------
+    def set_timing(self, enable=True):
+        self._check(self._lib.pcsf_set_timing(self._h, int(enable)))
+
+    def last_kernel_ms(self):
+        return self._lib.pcsf_last_kernel_ms(self._h)
+
+    def branch_matrices(self):
+        out = np.empty((2, self.n_nodes - 1, 64, 64), dtype=np.float64)
+        self._check(self._lib.pcsf_get_branch_matrices(self._h, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out

@@ -1,0 +1,58 @@
+"""Builds libphylocsf_amd.so (HIP kernels + C-ABI) for gfx950 with hipcc, in-tree.
+
+    python -m phylocsfpp_amd._build          # or: from phylocsfpp_amd._build import build; build()
+
+hipcc cross-compiles without a GPU.  The library lands next to this file so that it travels
+with the repository snapshot to the GPU box and is visible as an in-tree native extension.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libphylocsf_amd.so")
+SOURCES = ["kernels.hip", "api.cpp"]
+HEADERS = ["kernels.h", "hostmath.hpp", "schedule.hpp", os.path.join("..", "..", "include", "phylocsf_amd.h")]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (ROCm is required to build phylocsfpp_amd)")
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    if not force and not is_stale():
+        return LIB
+    objs = []
+    build_dir = os.path.join(HERE, "_build")
+    os.makedirs(build_dir, exist_ok=True)
+    common = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-result",
+              "-ffp-contract=off"]
+    for src in SOURCES:
+        obj = os.path.join(build_dir, src + ".o")
+        cmd = [hipcc()] + common + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

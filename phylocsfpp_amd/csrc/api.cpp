@@ -1,0 +1,335 @@
+// api.cpp -- the C-ABI of include/phylocsf_amd.h on top of the gfx950 kernels.
+// Host side of the drop-in boundary: what the reference does in PhyloCSFModel_make /
+// lpr_leaves / run_tracks / run (src/instance.hpp:687-712, src/fixed_lik.hpp:362-449,
+// src/run.hpp:35-211) minus the per-site arithmetic, which runs on the GPU.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/phylocsf_amd.h"
+#include "hostmath.hpp"
+#include "kernels.h"
+#include "schedule.hpp"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    ~DeviceBuffer() { release(); }
+    void release()
+    {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+    hipError_t reserve(size_t n)
+    {
+        if (n <= bytes) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc(&ptr, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    template <class T> T* as() const { return static_cast<T*>(ptr); }
+};
+
+}  // namespace
+
+struct pcsf_ctx {
+    int device = 0;
+    std::string error;
+    pcsf::Schedule schedule;
+    int n_nodes = 0, n_leaves = 0;
+    std::vector<int16_t> child1, child2;
+    std::vector<float> branch_len;
+    pcsf::Mat S[2];
+    pcsf::Vec pi[2];
+    pcsf::EigenSystem eig[2];            // coding, non-coding ECM (tree scale independent)
+    std::vector<double> host_P;          // [2][n-1][64*64] at tree scale 1
+    // device-resident model
+    DeviceBuffer d_program, d_frag, d_leaf_tab, d_prior;
+    // scratch for the host-pointer entry points
+    DeviceBuffer d_codons, d_out, d_lnz;
+    hipStream_t stream = nullptr;        // private stream for host-pointer entry points
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing = false;
+    double last_kernel_ms = 0.0;
+    int variant = 0;
+
+    int fail(int code, const std::string& msg)
+    {
+        error = msg;
+        return code;
+    }
+    int hip_fail(hipError_t e, const char* what)
+    {
+        error = std::string(what) + ": " + hipGetErrorString(e);
+        return PCSF_ERR_HIP;
+    }
+};
+
+namespace {
+
+// uploads fragment images / leaf tables / priors for a set of branch matrices P[2][n-1][4096]
+int upload_model_tables(pcsf_ctx* c, const double* P, const pcsf::Vec prior[2])
+{
+    const int n = c->n_nodes, nl = c->n_leaves;
+    const int ne = static_cast<int>(c->schedule.slot_node.size());
+    std::vector<double> frag(static_cast<size_t>(2) * ne * pcsf::FRAG_DOUBLES);
+    std::vector<double> leaf(static_cast<size_t>(2) * nl * pcsf::LEAF_TABLE_DOUBLES);
+    std::vector<double> pr(2 * 64);
+    for (int m = 0; m < 2; ++m) {
+        const double* Pm = P + static_cast<size_t>(m) * (n - 1) * 4096;
+        for (int s = 0; s < ne; ++s)
+            pcsf::to_fragment_order(Pm + static_cast<size_t>(c->schedule.slot_node[s]) * 4096,
+                                    frag.data() + (static_cast<size_t>(m) * ne + s) * pcsf::FRAG_DOUBLES);
+        for (int l = 0; l < nl; ++l)
+            pcsf::to_leaf_table(Pm + static_cast<size_t>(l) * 4096,
+                                leaf.data() + (static_cast<size_t>(m) * nl + l) * pcsf::LEAF_TABLE_DOUBLES);
+        pcsf::to_lane_order(prior[m].data(), pr.data() + m * 64);
+    }
+    hipError_t e;
+    if ((e = c->d_frag.reserve(std::max<size_t>(frag.size(), 1) * sizeof(double))) != hipSuccess) return c->hip_fail(e, "hipMalloc(frag)");
+    if ((e = c->d_leaf_tab.reserve(leaf.size() * sizeof(double))) != hipSuccess) return c->hip_fail(e, "hipMalloc(leaf_tab)");
+    if ((e = c->d_prior.reserve(pr.size() * sizeof(double))) != hipSuccess) return c->hip_fail(e, "hipMalloc(prior)");
+    if (!frag.empty() && (e = hipMemcpy(c->d_frag.ptr, frag.data(), frag.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess)
+        return c->hip_fail(e, "hipMemcpy(frag)");
+    if ((e = hipMemcpy(c->d_leaf_tab.ptr, leaf.data(), leaf.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess)
+        return c->hip_fail(e, "hipMemcpy(leaf_tab)");
+    if ((e = hipMemcpy(c->d_prior.ptr, pr.data(), pr.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess)
+        return c->hip_fail(e, "hipMemcpy(prior)");
+    return PCSF_OK;
+}
+
+int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t leaf_stride, double* d_out, double* d_lnz,
+                 hipStream_t stream)
+{
+    pcsf::PruneParams p{};
+    p.codons = d_codons;
+    p.n_sites = n_sites;
+    p.leaf_stride = leaf_stride;
+    p.program = c->d_program.as<uint32_t>();
+    p.n_ops = static_cast<int>(c->schedule.program.size());
+    p.n_edges = static_cast<int>(c->schedule.slot_node.size());
+    p.n_leaves = c->n_leaves;
+    p.frag = c->d_frag.as<double>();
+    p.leaf_tab = c->d_leaf_tab.as<double>();
+    p.prior = c->d_prior.as<double>();
+    p.out_score = d_out;
+    p.out_lnz = d_lnz;
+    hipError_t e;
+    if (c->timing && (e = hipEventRecord(c->ev0, stream)) != hipSuccess) return c->hip_fail(e, "hipEventRecord");
+    if ((e = pcsf::launch_prune_fixed(p, c->variant, stream)) != hipSuccess) return c->hip_fail(e, "launch prune_fixed");
+    if (c->timing) {
+        if ((e = hipEventRecord(c->ev1, stream)) != hipSuccess) return c->hip_fail(e, "hipEventRecord");
+        if ((e = hipEventSynchronize(c->ev1)) != hipSuccess) return c->hip_fail(e, "hipEventSynchronize");
+        float ms = 0.f;
+        if ((e = hipEventElapsedTime(&ms, c->ev0, c->ev1)) != hipSuccess) return c->hip_fail(e, "hipEventElapsedTime");
+        c->last_kernel_ms = ms;
+    }
+    return PCSF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pcsf_version(void) { return "phylocsf-amd 0.1.0 (gfx950)"; }
+
+// host-only helper (no device needed): the pruning program for a tree, for tests and tooling
+int pcsf_build_schedule(int32_t n_nodes, const int16_t* child1, const int16_t* child2, uint32_t* program, int32_t program_cap,
+                        int32_t* slot_node, int32_t* n_ops, int32_t* n_slots, int32_t* stack_depth)
+{
+    if (!child1 || !child2 || !program || !slot_node || !n_ops || !n_slots || !stack_depth) return PCSF_ERR_INVALID_ARG;
+    try {
+        const pcsf::Schedule s = pcsf::build_schedule(pcsf::TreeView{n_nodes, child1, child2});
+        if (static_cast<int32_t>(s.program.size()) > program_cap) return PCSF_ERR_INVALID_ARG;
+        std::copy(s.program.begin(), s.program.end(), program);
+        std::copy(s.slot_node.begin(), s.slot_node.end(), slot_node);
+        *n_ops = static_cast<int32_t>(s.program.size());
+        *n_slots = static_cast<int32_t>(s.slot_node.size());
+        *stack_depth = s.stack_depth;
+    } catch (const std::exception& ex) {
+        g_create_error = std::string("pcsf_build_schedule: ") + ex.what();
+        return PCSF_ERR_INVALID_ARG;
+    }
+    return PCSF_OK;
+}
+
+int pcsf_create(pcsf_ctx** out, const pcsf_model_desc* m, int device_id)
+{
+    if (!out || !m || !m->child1 || !m->child2 || !m->branch_len || !m->S_coding || !m->pi_coding || !m->S_noncoding ||
+        !m->pi_noncoding) {
+        g_create_error = "pcsf_create: null argument";
+        return PCSF_ERR_INVALID_ARG;
+    }
+    *out = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        g_create_error = "pcsf_create: no HIP device visible (this library has no CPU path)";
+        return PCSF_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n_dev) {
+        g_create_error = "pcsf_create: device_id out of range";
+        return PCSF_ERR_INVALID_ARG;
+    }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("pcsf_create: device is not gfx950 (") + (e == hipSuccess ? prop.gcnArchName : "?") + ")";
+        return PCSF_ERR_NO_DEVICE;
+    }
+    std::unique_ptr<pcsf_ctx> c(new (std::nothrow) pcsf_ctx);
+    if (!c) return PCSF_ERR_HIP;
+    c->device = device_id;
+    c->n_nodes = m->n_nodes;
+    try {
+        c->schedule = pcsf::build_schedule(pcsf::TreeView{m->n_nodes, m->child1, m->child2});
+    } catch (const std::exception& ex) {
+        g_create_error = std::string("pcsf_create: invalid tree: ") + ex.what();
+        return PCSF_ERR_INVALID_ARG;
+    }
+    const int n = m->n_nodes, nl = (n + 1) / 2;
+    c->n_leaves = nl;
+    c->child1.assign(m->child1, m->child1 + n);
+    c->child2.assign(m->child2, m->child2 + n);
+    c->branch_len.assign(m->branch_len, m->branch_len + n);
+    for (int i = 0; i < n - 1; ++i)
+        if (!(c->branch_len[i] >= 0.0f)) {
+            g_create_error = "pcsf_create: negative or NaN branch length";
+            return PCSF_ERR_INVALID_ARG;
+        }
+    std::memcpy(c->S[0].data(), m->S_coding, sizeof(double) * 4096);
+    std::memcpy(c->S[1].data(), m->S_noncoding, sizeof(double) * 4096);
+    std::memcpy(c->pi[0].data(), m->pi_coding, sizeof(double) * 64);
+    std::memcpy(c->pi[1].data(), m->pi_noncoding, sizeof(double) * 64);
+
+    // PhyloCSFModel_make for both models: Q, eigen-system, P(t_b) at scale 1
+    c->host_P.resize(static_cast<size_t>(2) * (n - 1) * 4096);
+    pcsf::Vec prior[2];
+    for (int k = 0; k < 2; ++k) {
+        pcsf::Mat Q;
+        pcsf::rate_matrix_ecm(c->S[k].data(), c->pi[k].data(), Q);
+        if (!pcsf::eigen_reversible(Q, c->pi[k].data(), c->eig[k])) {
+            g_create_error = "pcsf_create: codon frequencies must be positive";
+            return PCSF_ERR_INVALID_ARG;
+        }
+        prior[k] = c->eig[k].prior;
+        for (int b = 0; b < n - 1; ++b) {
+            const double t = pcsf::scaled_branch(c->branch_len[b], 1.0);
+            if (!pcsf::transition_matrix(c->eig[k], t, c->host_P.data() + (static_cast<size_t>(k) * (n - 1) + b) * 4096)) {
+                g_create_error = "pcsf_create: transition matrix failed validation (branch " + std::to_string(b) + ")";
+                return PCSF_ERR_MODEL;
+            }
+        }
+    }
+
+    if ((e = hipSetDevice(device_id)) != hipSuccess) {
+        g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return PCSF_ERR_HIP;
+    }
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+        g_create_error = std::string("stream/event creation: ") + hipGetErrorString(e);
+        return PCSF_ERR_HIP;
+    }
+    const auto& prog = c->schedule.program;
+    if ((e = c->d_program.reserve(prog.size() * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMemcpy(c->d_program.ptr, prog.data(), prog.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) {
+        g_create_error = std::string("program upload: ") + hipGetErrorString(e);
+        return PCSF_ERR_HIP;
+    }
+    int rc = upload_model_tables(c.get(), c->host_P.data(), prior);
+    if (rc != PCSF_OK) {
+        g_create_error = c->error;
+        return rc;
+    }
+    if (const char* v = std::getenv("PCSF_PRUNE_VARIANT")) {
+        const int vi = std::atoi(v);
+        if (vi >= 0 && vi < pcsf::prune_variant_count()) c->variant = vi;
+    }
+    *out = c.release();
+    return PCSF_OK;
+}
+
+void pcsf_destroy(pcsf_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* pcsf_last_error(const pcsf_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
+
+int pcsf_n_leaves(const pcsf_ctx* c) { return c ? c->n_leaves : PCSF_ERR_INVALID_ARG; }
+
+int pcsf_set_timing(pcsf_ctx* c, int enable)
+{
+    if (!c) return PCSF_ERR_INVALID_ARG;
+    c->timing = enable != 0;
+    return PCSF_OK;
+}
+
+double pcsf_last_kernel_ms(const pcsf_ctx* c) { return c ? c->last_kernel_ms : -1.0; }
+
+int pcsf_get_branch_matrices(pcsf_ctx* c, double* out)
+{
+    if (!c || !out) return PCSF_ERR_INVALID_ARG;
+    std::memcpy(out, c->host_P.data(), c->host_P.size() * sizeof(double));
+    return PCSF_OK;
+}
+
+int pcsf_score_sites_fixed_dev(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t leaf_stride, double* d_out,
+                               double* d_lnz, void* hip_stream)
+{
+    if (!c) return PCSF_ERR_INVALID_ARG;
+    if (n_sites == 0) return PCSF_OK;
+    if (!d_codons || (!d_out && !d_lnz) || leaf_stride < n_sites) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_sites_fixed_dev: bad argument");
+    hipError_t e;
+    if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
+    return launch_fixed(c, d_codons, n_sites, leaf_stride, d_out, d_lnz, static_cast<hipStream_t>(hip_stream));
+}
+
+int pcsf_score_sites_fixed(pcsf_ctx* c, const uint8_t* codons, size_t n_sites, size_t leaf_stride, double* out)
+{
+    if (!c) return PCSF_ERR_INVALID_ARG;
+    if (n_sites == 0) return PCSF_OK;
+    if (!codons || !out || leaf_stride < n_sites) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_sites_fixed: bad argument");
+    hipError_t e;
+    if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
+    const size_t nl = static_cast<size_t>(c->n_leaves);
+    if ((e = c->d_codons.reserve(nl * n_sites)) != hipSuccess) return c->hip_fail(e, "hipMalloc(codons)");
+    if ((e = c->d_out.reserve(n_sites * sizeof(double))) != hipSuccess) return c->hip_fail(e, "hipMalloc(out)");
+    // compact the leaf-major matrix while copying (device stride = n_sites)
+    if ((e = hipMemcpy2DAsync(c->d_codons.ptr, n_sites, codons, leaf_stride, n_sites, nl, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
+        return c->hip_fail(e, "hipMemcpy2DAsync(codons)");
+    int rc = launch_fixed(c, c->d_codons.as<uint8_t>(), n_sites, n_sites, c->d_out.as<double>(), nullptr, c->stream);
+    if (rc != PCSF_OK) return rc;
+    if ((e = hipMemcpyAsync(out, c->d_out.ptr, n_sites * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
+        return c->hip_fail(e, "hipMemcpyAsync(out)");
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return c->hip_fail(e, "hipStreamSynchronize");
+    return PCSF_OK;
+}
+
+int pcsf_score_blocks(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64_t* site_offsets, size_t n_blocks,
+                      size_t leaf_stride, int compute_anc, uint32_t seed, float* out_phylo, float* out_anc)
+{
+    if (!c) return PCSF_ERR_INVALID_ARG;
+    (void)codons; (void)site_offsets; (void)n_blocks; (void)leaf_stride; (void)compute_anc; (void)seed; (void)out_phylo; (void)out_anc;
+    (void)algo;
+    return c->fail(PCSF_ERR_UNSUPPORTED, "pcsf_score_blocks: not implemented yet");
+}
+
+}  // extern "C"

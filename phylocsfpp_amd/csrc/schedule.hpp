@@ -1,0 +1,184 @@
+// schedule.hpp -- turns the flattened tree into the straight-line "pruning program" the kernel
+// interprets, and lays the branch matrices out the way the kernel reads them.
+//
+// The reference walks internal nodes in id order and keeps every node's alpha vector in a
+// (n-nl) x 64 workspace (src/fixed_lik.hpp:125-164, 375-379).  On the GPU the per-node partial
+// likelihoods of a 16-site tile live in registers, so the walk is re-ordered depth-first with
+// the deeper subtree first (Sethi-Ullman): at any time one "current" tile, one accumulator tile
+// and at most `stack_depth` parked tiles are live (<= 3 for every tree the reference ships).
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace pcsf {
+
+enum OpCode : uint32_t {
+    OP_CHERRY = 0,    // cur <- leafmsg(a) * leafmsg(b)                 (both children are leaves)
+    OP_MATMUL = 1,    // acc <- P[slot a] x cur                         (message to the parent)
+    OP_MUL_LEAF = 2,  // cur <- acc * leafmsg(a)
+    OP_PUSH = 3,      // stack[a] <- acc
+    OP_MUL_POP = 4,   // cur <- acc * stack[a]
+    OP_ROOT = 5       // z <- prior . cur ; ln z
+};
+
+inline uint32_t encode_op(OpCode c, int a = 0, int b = 0)
+{
+    return (static_cast<uint32_t>(c) << 28) | (static_cast<uint32_t>(a & 0x3fff) << 14) | static_cast<uint32_t>(b & 0x3fff);
+}
+
+constexpr int MAX_STACK_DEPTH = 3;
+
+struct Schedule {
+    int n_nodes = 0, n_leaves = 0;
+    std::vector<uint32_t> program;
+    std::vector<int> slot_node;  // slot -> node id whose branch matrix the slot holds (internal children)
+    int stack_depth = 0;
+};
+
+struct TreeView {
+    int n_nodes;
+    const int16_t* child1;
+    const int16_t* child2;
+    int n_leaves() const { return (n_nodes + 1) / 2; }
+};
+
+// throws std::invalid_argument on anything that is not a newick_flatten-ordered binary tree
+inline void validate_tree(const TreeView& t)
+{
+    const int n = t.n_nodes, nl = t.n_leaves();
+    if (n < 3 || (n % 2) == 0 || n > 0x3fff) throw std::invalid_argument("n_nodes must be odd, >= 3 and < 16384");
+    std::vector<int> seen(n, 0);
+    for (int i = 0; i < n; ++i) {
+        const int a = t.child1[i], b = t.child2[i];
+        if (i < nl) {
+            if (a != -1 || b != -1) throw std::invalid_argument("node " + std::to_string(i) + " must be a leaf (children -1)");
+        } else {
+            if (a < 0 || b < 0 || a >= i || b >= i || a == b)
+                throw std::invalid_argument("internal node " + std::to_string(i) + " must have two distinct children with smaller ids");
+            if (seen[a]++ || seen[b]++) throw std::invalid_argument("a node has two parents");
+        }
+    }
+    for (int i = 0; i < n - 1; ++i)
+        if (!seen[i]) throw std::invalid_argument("node " + std::to_string(i) + " is not attached to the tree");
+}
+
+inline Schedule build_schedule(const TreeView& t)
+{
+    validate_tree(t);
+    Schedule s;
+    s.n_nodes = t.n_nodes;
+    s.n_leaves = t.n_leaves();
+    const int nl = s.n_leaves;
+    // parked tiles needed to evaluate each subtree (leaves cost nothing: they are table look-ups)
+    std::vector<int> need(t.n_nodes, 0);
+    for (int i = nl; i < t.n_nodes; ++i) {
+        const int a = t.child1[i], b = t.child2[i];
+        const bool la = a < nl, lb = b < nl;
+        if (la && lb) need[i] = 0;
+        else if (la) need[i] = need[b];
+        else if (lb) need[i] = need[a];
+        else {
+            const int hi = std::max(need[a], need[b]), lo = std::min(need[a], need[b]);
+            need[i] = std::max(hi, lo + 1);
+        }
+    }
+    s.stack_depth = need[t.n_nodes - 1];
+    if (s.stack_depth > MAX_STACK_DEPTH)
+        throw std::invalid_argument("tree needs " + std::to_string(s.stack_depth) + " parked tiles; this build supports " +
+                                    std::to_string(MAX_STACK_DEPTH));
+    // iterative post-order emission (explicit stack: caterpillar trees are as deep as they are large)
+    struct Frame { int node, depth, stage; };
+    std::vector<Frame> st;
+    st.push_back({t.n_nodes - 1, 0, 0});
+    auto emit_matmul = [&](int child) {
+        s.program.push_back(encode_op(OP_MATMUL, static_cast<int>(s.slot_node.size())));
+        s.slot_node.push_back(child);
+    };
+    while (!st.empty()) {
+        Frame& f = st.back();
+        const int a = t.child1[f.node], b = t.child2[f.node];
+        const bool la = a < nl, lb = b < nl;
+        if (la && lb) {
+            s.program.push_back(encode_op(OP_CHERRY, a, b));
+            st.pop_back();
+        } else if (la || lb) {
+            const int inner = la ? b : a, leaf = la ? a : b;
+            if (f.stage == 0) {
+                f.stage = 1;
+                st.push_back({inner, f.depth, 0});
+            } else {
+                emit_matmul(inner);
+                s.program.push_back(encode_op(OP_MUL_LEAF, leaf));
+                st.pop_back();
+            }
+        } else {
+            const int first = (need[b] > need[a]) ? b : a, second = (first == a) ? b : a;
+            if (f.stage == 0) {
+                f.stage = 1;
+                st.push_back({first, f.depth, 0});
+            } else if (f.stage == 1) {
+                emit_matmul(first);
+                s.program.push_back(encode_op(OP_PUSH, f.depth));
+                f.stage = 2;
+                st.push_back({second, f.depth + 1, 0});
+            } else {
+                emit_matmul(second);
+                s.program.push_back(encode_op(OP_MUL_POP, f.depth));
+                st.pop_back();
+            }
+        }
+    }
+    s.program.push_back(encode_op(OP_ROOT));
+    return s;
+}
+
+// ---- device table layouts -------------------------------------------------------------------
+// MFMA v_mfma_f64_16x16x4_f64 computes D[16x16] += A[16x4] * B[4x16]; lane l supplies
+// A[l&15][l>>4] and B[l>>4][l&15] and receives D[(l>>4)+4r][l&15] in result register r.
+// With A = a 16x4 piece of P (rows: parent states, k: child states) and B = partial
+// likelihoods (k: child state, column: site) the result registers of output tile t' are
+// exactly the B operands of k-steps 4t'..4t'+3 of the next product, so a tile never moves
+// between lanes.  "fragment order" below is the order in which lanes consume P:
+//   frag[q][h][lane][e] = P[16*(2h+e) + (lane&15)][4q + (lane>>4)],  q<16, h<2, e<2
+constexpr int FRAG_DOUBLES = 64 * 64;
+
+inline void to_fragment_order(const double* P, double* frag)
+{
+    for (int q = 0; q < 16; ++q)
+        for (int h = 0; h < 2; ++h)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 2; ++e)
+                    frag[((q * 2 + h) * 64 + lane) * 2 + e] = P[(16 * (2 * h + e) + (lane & 15)) * 64 + 4 * q + (lane >> 4)];
+}
+
+// leaf messages: table[code][g][q] = P[4q+g][code] for code < 64, and for code 64 (marginalise)
+// the row sum of P accumulated in index order like the reference's loop (src/fixed_lik.hpp:111-117)
+constexpr int LEAF_TABLE_DOUBLES = 65 * 64;
+
+inline void to_leaf_table(const double* P, double* table)
+{
+    for (int code = 0; code < 65; ++code)
+        for (int g = 0; g < 4; ++g)
+            for (int q = 0; q < 16; ++q) {
+                const int a = 4 * q + g;
+                double v;
+                if (code < 64) v = P[a * 64 + code];
+                else {
+                    v = 0.0;
+                    for (int b = 0; b < 64; ++b) v += P[a * 64 + b];
+                }
+                table[(code * 4 + g) * 16 + q] = v;
+            }
+}
+
+inline void to_lane_order(const double* vec64, double* out)  // out[g][q] = vec[4q+g]
+{
+    for (int g = 0; g < 4; ++g)
+        for (int q = 0; q < 16; ++q) out[g * 16 + q] = vec64[4 * q + g];
+}
+
+}  // namespace pcsf
