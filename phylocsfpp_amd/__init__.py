@@ -47,6 +47,12 @@ def load_library():
     if not os.path.exists(_LIB_PATH):
         raise ImportError("%s is missing: build it with `python -m phylocsfpp_amd._build` "
                           "(hipcc, --offload-arch=gfx950); there is no CPU fallback" % _LIB_PATH)
+    # PyTorch-ROCm ships its own HIP runtime; load it first so that this process has ONE runtime
+    # (initialising the system copy first makes torch.cuda report "No HIP GPUs are available").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(_LIB_PATH)
     vp, dp, u8p, fp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_float)
     lib.pcsf_version.restype = C.c_char_p

@@ -11,9 +11,8 @@ constexpr int FRAG_DOUBLES_DEV = 64 * 64;        // one branch matrix in fragmen
 constexpr int LEAF_TABLE_DOUBLES_DEV = 65 * 64;  // one leaf-message table (65 codes x 64 states)
 constexpr int MAX_STACK_DEPTH_DEV = 3;
 
-// op codes of the pruning program (schedule.hpp keeps the host-side twin of this list)
-constexpr uint32_t OP_CHERRY_DEV = 0, OP_MATMUL_DEV = 1, OP_MUL_LEAF_DEV = 2, OP_PUSH_DEV = 3, OP_MUL_POP_DEV = 4,
-                   OP_ROOT_DEV = 5;
+// fused op codes of the pruning program (schedule.hpp FusedOp is the host-side twin of this list)
+constexpr uint32_t F_CHERRY_DEV = 0, F_MM_LEAF_DEV = 1, F_MM_PUSH_CHERRY0_DEV = 2, F_MM_POP0_DEV = 5, F_ROOT_DEV = 8;
 
 struct PruneParams {
     const uint8_t* codons;   // [n_leaves][leaf_stride], 0..63 or 64 = marginalise
@@ -30,7 +29,7 @@ struct PruneParams {
     double* out_lnz;         // [2][n_sites] or null
 };
 
-// variant: 0 = 4 waves x 1 tile, 1 = 8 waves x 1 tile, 2 = 4 waves x 2 tiles, 3 = 8 waves x 2 tiles
+// variant: 0 = 4 waves (64 sites) per work-group, 1 = 8 waves (128 sites) per work-group
 hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t stream);
 int prune_variant_count();
 

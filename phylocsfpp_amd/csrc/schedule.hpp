@@ -16,13 +16,25 @@
 
 namespace pcsf {
 
+// Primitive steps of the walk (used while building; see fuse_program for what the kernel runs)
 enum OpCode : uint32_t {
     OP_CHERRY = 0,    // cur <- leafmsg(a) * leafmsg(b)                 (both children are leaves)
-    OP_MATMUL = 1,    // acc <- P[slot a] x cur                         (message to the parent)
+    OP_MATMUL = 1,    // acc <- P[next slot] x cur                      (message to the parent)
     OP_MUL_LEAF = 2,  // cur <- acc * leafmsg(a)
     OP_PUSH = 3,      // stack[a] <- acc
     OP_MUL_POP = 4,   // cur <- acc * stack[a]
     OP_ROOT = 5       // z <- prior . cur ; ln z
+};
+
+// Fused steps the kernel interprets.  Every product is fused with what follows it so that the
+// leaf-message rows it needs can be fetched while the MFMAs run; the stack slot is part of the
+// op code so that parked tiles are statically indexed registers.
+enum FusedOp : uint32_t {
+    F_CHERRY = 0,           // cur <- leafmsg(a) * leafmsg(b)                     (program start only)
+    F_MM_LEAF = 1,          // acc <- P x cur ; cur <- acc * leafmsg(a)
+    F_MM_PUSH_CHERRY0 = 2,  // acc <- P x cur ; stack[d] <- acc ; cur <- leafmsg(a) * leafmsg(b)   (d = code-2)
+    F_MM_POP0 = 5,          // acc <- P x cur ; cur <- stack[d] * acc                                (d = code-5)
+    F_ROOT = 8              // z <- prior . cur
 };
 
 inline uint32_t encode_op(OpCode c, int a = 0, int b = 0)
@@ -66,6 +78,48 @@ inline void validate_tree(const TreeView& t)
         if (!seen[i]) throw std::invalid_argument("node " + std::to_string(i) + " is not attached to the tree");
 }
 
+// peephole fusion of the primitive walk into the kernel's op set.  A subtree's walk always starts
+// at a cherry (the deepest-first descent ends at a node with two leaf children), so a PUSH is
+// always followed by a CHERRY, and a MATMUL by exactly one of MUL_LEAF / PUSH / MUL_POP.
+inline std::vector<uint32_t> fuse_program(const std::vector<uint32_t>& prim)
+{
+    auto code = [](uint32_t op) { return op >> 28; };
+    auto arg_a = [](uint32_t op) { return static_cast<int>((op >> 14) & 0x3fff); };
+    auto arg_b = [](uint32_t op) { return static_cast<int>(op & 0x3fff); };
+    std::vector<uint32_t> out;
+    size_t i = 0;
+    while (i < prim.size()) {
+        const uint32_t op = prim[i];
+        if (code(op) == OP_CHERRY && i == 0) {
+            out.push_back((F_CHERRY << 28) | (op & 0x0fffffff));
+            i += 1;
+        } else if (code(op) == OP_MATMUL) {
+            if (i + 1 >= prim.size()) throw std::logic_error("dangling MATMUL");
+            const uint32_t nx = prim[i + 1];
+            if (code(nx) == OP_MUL_LEAF) {
+                out.push_back(encode_op(static_cast<OpCode>(F_MM_LEAF), arg_a(nx)));
+                i += 2;
+            } else if (code(nx) == OP_MUL_POP) {
+                out.push_back(encode_op(static_cast<OpCode>(F_MM_POP0 + arg_a(nx))));
+                i += 2;
+            } else if (code(nx) == OP_PUSH) {
+                if (i + 2 >= prim.size() || code(prim[i + 2]) != OP_CHERRY) throw std::logic_error("PUSH not followed by CHERRY");
+                const uint32_t ch = prim[i + 2];
+                out.push_back(encode_op(static_cast<OpCode>(F_MM_PUSH_CHERRY0 + arg_a(nx)), arg_a(ch), arg_b(ch)));
+                i += 3;
+            } else {
+                throw std::logic_error("MATMUL followed by an unexpected step");
+            }
+        } else if (code(op) == OP_ROOT) {
+            out.push_back(static_cast<uint32_t>(F_ROOT) << 28);
+            i += 1;
+        } else {
+            throw std::logic_error("unexpected step in the pruning walk");
+        }
+    }
+    return out;
+}
+
 inline Schedule build_schedule(const TreeView& t)
 {
     validate_tree(t);
@@ -95,7 +149,7 @@ inline Schedule build_schedule(const TreeView& t)
     std::vector<Frame> st;
     st.push_back({t.n_nodes - 1, 0, 0});
     auto emit_matmul = [&](int child) {
-        s.program.push_back(encode_op(OP_MATMUL, static_cast<int>(s.slot_node.size())));
+        s.program.push_back(encode_op(OP_MATMUL));
         s.slot_node.push_back(child);
     };
     while (!st.empty()) {
@@ -133,6 +187,7 @@ inline Schedule build_schedule(const TreeView& t)
         }
     }
     s.program.push_back(encode_op(OP_ROOT));
+    s.program = fuse_program(s.program);
     return s;
 }
 

@@ -1,0 +1,145 @@
+"""Host logic without a GPU: the fused pruning program built by the C-ABI library is interpreted
+here in numpy with the ORACLE's branch matrices and must reproduce the oracle's per-site z."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import phylocsfpp_amd as pa
+from phylocsfpp_amd import synth
+
+F_CHERRY, F_MM_LEAF, F_PUSH0, F_POP0, F_ROOT = 0, 1, 2, 5, 8
+
+
+def interpret(prog, slots, P, prior, cod_col):
+    def leafmsg(l):
+        c = cod_col[l]
+        return P[l][:, c] if c < 64 else np.array([P[l][a, :].sum() for a in range(64)])
+    cur, stk, slot, z = None, {}, 0, None
+    for o in prog:
+        code, a, b = int(o >> 28), int((o >> 14) & 0x3fff), int(o & 0x3fff)
+        if code == F_CHERRY:
+            cur = leafmsg(a) * leafmsg(b)
+            continue
+        if code == F_ROOT:
+            z = float(prior @ cur)
+            continue
+        acc = P[slots[slot]] @ cur
+        slot += 1
+        if code == F_MM_LEAF:
+            cur = acc * leafmsg(a)
+        elif F_PUSH0 <= code < F_POP0:
+            stk[code - F_PUSH0] = acc
+            cur = leafmsg(a) * leafmsg(b)
+        else:
+            cur = stk[code - F_POP0] * acc
+    assert slot == len(slots)
+    return z
+
+
+@pytest.mark.parametrize("model", ["53birds", "58mammals", "100vertebrates"])
+def test_program_reproduces_oracle(model, oracle_models):
+    m = oracle_models(model)
+    prog, slots, depth = pa.build_schedule(m.child1, m.child2)
+    assert depth <= 3
+    assert len(slots) == m.nl - 2                      # one product per internal non-root node
+    assert sorted(slots.tolist()) == list(range(m.nl, m.n - 1))
+    assert int(prog[-1] >> 28) == F_ROOT and int(prog[0] >> 28) == F_CHERRY
+    qd = m.qdiag(True)
+    rc, P = m.all_P(qd, 1.0)
+    assert rc == 0
+    prior = np.array(qd.prior)
+    cod = synth.synthetic_codon_columns(m.child1, m.child2, m.branch_len, m.S_c, m.pi_c, m.S_nc, m.pi_nc, 12, seed=5)
+    lpr, anc = C.c_double(), C.c_double()
+    per = np.empty(cod.shape[1])
+    ob.lib().po_lpr_leaves(C.byref(qd), C.byref(m.m.tree), 1.0, cod.ctypes.data_as(C.POINTER(C.c_uint8)), cod.shape[1],
+                           cod.shape[1], 0, C.byref(lpr), C.byref(anc), per.ctypes.data_as(C.POINTER(C.c_double)))
+    for s in range(cod.shape[1]):
+        z = interpret(prog, slots, P, prior, cod[:, s])
+        assert abs(np.log(z) - per[s]) < 1e-11
+
+
+def _random_tree(nl, rng):
+    """random binary tree in newick_flatten numbering (leaves first, internal nodes in post-order)"""
+    def build(leaves):
+        if len(leaves) == 1:
+            return leaves[0]
+        k = rng.integers(1, len(leaves))
+        return (build(leaves[:k]), build(leaves[k:]))
+    t = build(list(range(nl)))
+    c1, c2 = [-1] * (2 * nl - 1), [-1] * (2 * nl - 1)
+    nxt = [nl]
+
+    def number(node):
+        if not isinstance(node, tuple):
+            return node
+        a, b = number(node[0]), number(node[1])
+        i = nxt[0]
+        nxt[0] += 1
+        c1[i], c2[i] = a, b
+        return i
+    number(t)
+    return np.array(c1, dtype=np.int16), np.array(c2, dtype=np.int16)
+
+
+def test_random_trees_schedule_is_a_valid_walk():
+    rng = np.random.default_rng(7)
+    done = 0
+    for _ in range(200):
+        nl = int(rng.integers(2, 40))
+        c1, c2 = _random_tree(nl, rng)
+        try:
+            prog, slots, depth = pa.build_schedule(c1, c2)
+        except pa.PcsfError:
+            continue                                   # needs more than 3 parked tiles
+        done += 1
+        # symbolic interpretation: every leaf is consumed exactly once, every internal edge once
+        leaves, slot, stk, cur = [], 0, {}, None
+        for o in prog:
+            code, a, b = int(o >> 28), int((o >> 14) & 0x3fff), int(o & 0x3fff)
+            if code == F_CHERRY:
+                leaves += [a, b]
+                cur = {a, b}
+            elif code == F_ROOT:
+                assert cur == set(range(nl))
+            else:
+                node = slots[slot]
+                slot += 1
+                assert c1[node] >= 0
+                if code == F_MM_LEAF:
+                    leaves.append(a)
+                    cur = cur | {a}
+                elif code < F_POP0:
+                    stk[code - F_PUSH0] = cur
+                    leaves += [a, b]
+                    cur = {a, b}
+                else:
+                    cur = cur | stk.pop(code - F_POP0)
+        assert sorted(leaves) == list(range(nl))
+        assert slot == len(slots) == nl - 2
+    assert done > 100
+
+
+def test_invalid_trees_are_rejected():
+    with pytest.raises(pa.PcsfError):
+        pa.build_schedule(np.array([-1, -1, 0, 1], dtype=np.int16), np.array([-1, -1, 1, 2], dtype=np.int16))
+    with pytest.raises(pa.PcsfError):
+        pa.build_schedule(np.array([-1, -1, 0], dtype=np.int16), np.array([-1, -1, 0], dtype=np.int16))
+    # a perfectly balanced 64-leaf tree needs 5 parked tiles
+    c1, c2 = [-1] * 127, [-1] * 127
+    nxt = [64]
+
+    def bal(lo, hi):
+        if hi - lo == 1:
+            return lo
+        mid = (lo + hi) // 2
+        a, b = bal(lo, mid), bal(mid, hi)
+        i = nxt[0]
+        nxt[0] += 1
+        c1[i], c2[i] = a, b
+        return i
+    bal(0, 64)
+    with pytest.raises(pa.PcsfError):
+        pa.build_schedule(np.array(c1, dtype=np.int16), np.array(c2, dtype=np.int16))
