@@ -58,12 +58,15 @@ struct pcsf_ctx {
     // device-resident model
     DeviceBuffer d_program, d_frag, d_leaf_tab, d_prior;
     // scratch for the host-pointer entry points
-    DeviceBuffer d_codons, d_out, d_lnz;
+    DeviceBuffer d_codons, d_out, d_lnz, d_stamps;
+    uint32_t stamp_block = 0;
     hipStream_t stream = nullptr;        // private stream for host-pointer entry points
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false;
     double last_kernel_ms = 0.0;
     int variant = 0;
+    // tuning knobs (speed only; environment overrides are for experiments)
+    size_t extra_lds = 0;
 
     int fail(int code, const std::string& msg)
     {
@@ -126,9 +129,11 @@ int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t le
     p.prior = c->d_prior.as<double>();
     p.out_score = d_out;
     p.out_lnz = d_lnz;
+    p.stamps = c->d_stamps.as<unsigned long long>();
+    p.stamp_block = c->stamp_block;
     hipError_t e;
     if (c->timing && (e = hipEventRecord(c->ev0, stream)) != hipSuccess) return c->hip_fail(e, "hipEventRecord");
-    if ((e = pcsf::launch_prune_fixed(p, c->variant, stream)) != hipSuccess) return c->hip_fail(e, "launch prune_fixed");
+    if ((e = pcsf::launch_prune_fixed(p, c->variant, stream, c->extra_lds)) != hipSuccess) return c->hip_fail(e, "launch prune_fixed");
     if (c->timing) {
         if ((e = hipEventRecord(c->ev1, stream)) != hipSuccess) return c->hip_fail(e, "hipEventRecord");
         if ((e = hipEventSynchronize(c->ev1)) != hipSuccess) return c->hip_fail(e, "hipEventSynchronize");
@@ -253,6 +258,7 @@ int pcsf_create(pcsf_ctx** out, const pcsf_model_desc* m, int device_id)
         g_create_error = c->error;
         return rc;
     }
+    if (const char* v = std::getenv("PCSF_EXTRA_LDS")) c->extra_lds = static_cast<size_t>(std::atoi(v));
     if (const char* v = std::getenv("PCSF_PRUNE_VARIANT")) {
         const int vi = std::atoi(v);
         if (vi >= 0 && vi < pcsf::prune_variant_count()) c->variant = vi;
@@ -283,6 +289,25 @@ int pcsf_set_timing(pcsf_ctx* c, int enable)
 }
 
 double pcsf_last_kernel_ms(const pcsf_ctx* c) { return c ? c->last_kernel_ms : -1.0; }
+
+// diagnostic: arm in-kernel stamps for work-group `block` (needs variant 2) / read them back
+int pcsf_debug_stamps(pcsf_ctx* c, int block, unsigned long long* out, int cap)
+{
+    if (!c) return PCSF_ERR_INVALID_ARG;
+    const size_t n = static_cast<size_t>(2) * c->schedule.program.size() * 4;
+    hipError_t e;
+    if (!out) {  // arm
+        if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
+        if ((e = c->d_stamps.reserve(n * 8)) != hipSuccess) return c->hip_fail(e, "hipMalloc(stamps)");
+        if ((e = hipMemset(c->d_stamps.ptr, 0, n * 8)) != hipSuccess) return c->hip_fail(e, "hipMemset(stamps)");
+        c->stamp_block = static_cast<uint32_t>(block);
+        return static_cast<int>(n);
+    }
+    if (static_cast<size_t>(cap) < n || !c->d_stamps.ptr) return PCSF_ERR_INVALID_ARG;
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return c->hip_fail(e, "hipDeviceSynchronize");
+    if ((e = hipMemcpy(out, c->d_stamps.ptr, n * 8, hipMemcpyDeviceToHost)) != hipSuccess) return c->hip_fail(e, "hipMemcpy(stamps)");
+    return static_cast<int>(n);
+}
 
 int pcsf_get_branch_matrices(pcsf_ctx* c, double* out)
 {

@@ -25,12 +25,15 @@ struct PruneParams {
     const double* frag;      // [2][n_edges][4096]  branch matrices of internal children, fragment order
     const double* leaf_tab;  // [2][n_leaves][65][4][16] leaf-message tables
     const double* prior;     // [2][4][16] equilibrium prior in lane order
+    unsigned long long* stamps;  // diagnostic variant only: [2][n_ops][4] s_memtime values, else null
+    uint32_t stamp_block;
     double* out_score;       // [n_sites] or null
     double* out_lnz;         // [2][n_sites] or null
 };
 
-// variant: 0 = 4 waves (64 sites) per work-group, 1 = 8 waves (128 sites) per work-group
-hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t stream);
+// variant: 0 = 4 waves (64 sites) per work-group, 1 = 8 waves (128 sites) per work-group,
+// 2 = variant 0 with in-kernel stamps (diagnostic only)
+hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t stream, size_t extra_lds = 0);
 int prune_variant_count();
 
 }  // namespace pcsf

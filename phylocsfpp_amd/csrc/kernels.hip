@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace pcsf {
@@ -44,58 +46,75 @@ __device__ __forceinline__ const double2_t* leaf_row_ptr(const double* __restric
 
 // acc[t] (t = 0..3, output states 16t..16t+15) <- P x cur, with P read from its LDS fragment image:
 // 64 x v_mfma_f64_16x16x4_f64 in four independent accumulator chains.
-// Fragments are fetched one k-step ahead of the MFMAs that use them; the scheduling barriers keep
-// the compiler from hoisting all 32 LDS reads (128 VGPRs) to the top.
-// CHERRY: while the product runs, the next subtree's first tile nxt = leafmsg(a)*leafmsg(b) is
-// built a quarter row at a time (loads issued 4 k-steps = 16 MFMAs ahead of their use), so the
-// two 128-byte rows never occupy registers in full.
-template <bool CHERRY>
+//
+// Issue model (measured with in-kernel stamps, tools/stamps.py): one MFMA occupies the matrix
+// pipe for 64 cycles and a wave issues in order, so the next MFMA -- and everything behind it in
+// the instruction stream -- waits for the pipe.  Anything placed AFTER a group of four MFMAs
+// therefore starts ~200 cycles late and, if it takes longer than the 56 idle issue cycles of
+// one MFMA, opens a bubble.  So every non-MFMA instruction of the product is slotted BETWEEN two
+// MFMAs, at most one memory instruction per slot:
+//   slot 0 (after MFMA 0): the two ds_read_b128 of the next k-step's fragments
+//   slot 1..3: per_slot(q, j) -- LDS-DMA piece of the next slot, leaf-row loads, cherry multiplies
+// Scheduling barriers pin this order (and keep the compiler from hoisting all 32 LDS reads).
+template <class PerSlot>
 __device__ __forceinline__ void product(const double2_t* __restrict__ buf, int lane, const double (&cur)[16], double4_t (&acc)[4],
-                                        const double2_t* __restrict__ rowa, const double2_t* __restrict__ rowb, double (&nxt)[16])
+                                        PerSlot&& per_slot)
 {
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
     double2_t n01 = buf[lane], n23 = buf[64 + lane];
-    double2_t xa0, xa1, xb0, xb1;
-    if (CHERRY) {
-        xa0 = rowa[0]; xa1 = rowa[1];
-        xb0 = rowb[0]; xb1 = rowb[1];
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    auto step = [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
         const double2_t f01 = n01, f23 = n23;
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0] = mfma_f64(f01.x, cur[q], acc[0]);
+        __builtin_amdgcn_sched_barrier(0);
         if (q + 1 < 16) {
             n01 = buf[((q + 1) * 2 + 0) * 64 + lane];
             n23 = buf[((q + 1) * 2 + 1) * 64 + lane];
         }
         __builtin_amdgcn_sched_barrier(0);
-        acc[0] = mfma_f64(f01.x, cur[q], acc[0]);
         acc[1] = mfma_f64(f01.y, cur[q], acc[1]);
-        acc[2] = mfma_f64(f23.x, cur[q], acc[2]);
-        acc[3] = mfma_f64(f23.y, cur[q], acc[3]);
-        if (CHERRY && (q & 3) == 3) {
-            const int k = q >> 2;
-            nxt[4 * k + 0] = xa0.x * xb0.x;
-            nxt[4 * k + 1] = xa0.y * xb0.y;
-            nxt[4 * k + 2] = xa1.x * xb1.x;
-            nxt[4 * k + 3] = xa1.y * xb1.y;
-            if (k < 3) {
-                xa0 = rowa[2 * k + 2]; xa1 = rowa[2 * k + 3];
-                xb0 = rowb[2 * k + 2]; xb1 = rowb[2 * k + 3];
-            }
-        }
         __builtin_amdgcn_sched_barrier(0);
-    }
+        per_slot(qc, std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        acc[2] = mfma_f64(f23.x, cur[q], acc[2]);
+        __builtin_amdgcn_sched_barrier(0);
+        per_slot(qc, std::integral_constant<int, 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        acc[3] = mfma_f64(f23.y, cur[q], acc[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        per_slot(qc, std::integral_constant<int, 3>{});
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#define PCSF_STEP(Q) step(std::integral_constant<int, Q>{});
+    PCSF_STEP(0) PCSF_STEP(1) PCSF_STEP(2) PCSF_STEP(3) PCSF_STEP(4) PCSF_STEP(5) PCSF_STEP(6) PCSF_STEP(7)
+    PCSF_STEP(8) PCSF_STEP(9) PCSF_STEP(10) PCSF_STEP(11) PCSF_STEP(12) PCSF_STEP(13) PCSF_STEP(14) PCSF_STEP(15)
+#undef PCSF_STEP
 }
 
 // prune_fixed<NW>: NW waves per work-group, 16 sites per wave.
-// LDS (dynamic, one array): [2][4096] doubles fragment double-buffer, then [n_leaves][NW*16] codon bytes.
-template <int NW>
+// LDS (dynamic, one array): [2][4096] doubles fragment double-buffer, [n_ops] program words,
+// then [n_leaves][NW*16] codon bytes.  The program is read from LDS, not with scalar loads: an
+// s_load in flight makes every lgkmcnt wait of the product a full drain (SMEM returns out of
+// order), which stalls each k-step on the fragment reads it has just issued.
+// STAMP: diagnostic build only (variant 2): wave 0 of one work-group records s_memtime at the
+// start of every op, after its barrier, after its product and after its epilogue into p.stamps.
+// Stamps never touch an output value; the shipped variants are compiled with STAMP = false.
+__device__ __forceinline__ unsigned long long stamp_now()
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+template <int NW, bool STAMP>
 __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double2_t* lfrag = reinterpret_cast<double2_t*>(lds_raw);
-    unsigned char* lcod = lds_raw + 2 * FRAG_DOUBLES_DEV * sizeof(double);
+    uint32_t* lprog = reinterpret_cast<uint32_t*>(lds_raw + 2 * FRAG_DOUBLES_DEV * sizeof(double));
+    unsigned char* lcod = reinterpret_cast<unsigned char*>(lprog + ((p.n_ops + 3) & ~3));
 
     constexpr int SITES = NW * 16;
     const int tid = threadIdx.x;
@@ -116,25 +135,41 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
         }
         lcod[idx] = static_cast<unsigned char>(c);
     }
+    for (int i = tid; i < p.n_ops; i += NW * 64) lprog[i] = p.program[i];
     const unsigned char* my_cod = lcod + wave * 16 + sl;  // + leaf*SITES
+    __syncthreads();
 
     // ---- fragment staging: 32 KiB per slot, moved by LDS-DMA in 1 KiB wave-instructions
     constexpr int CHUNKS_PER_WAVE = 32 / NW;
     const int total_slots = 2 * p.n_edges;  // coding slots, then non-coding slots
+    // each wave moves CHUNKS_PER_WAVE consecutive 1 KiB pieces; the instruction's immediate offset
+    // advances the global and the LDS address together, so one address register serves 4 pieces
+    const unsigned char* src_lane = reinterpret_cast<const unsigned char*>(p.frag) + wave * (CHUNKS_PER_WAVE * 1024) + lane * 16;
+    // stage_piece<J>(slot): J-th of this wave's CHUNKS_PER_WAVE pieces of `slot`
+    auto stage_piece = [&](auto jc, int slot, int buffer) {
+        constexpr int J = decltype(jc)::value;
+        const unsigned char* src = src_lane + static_cast<size_t>(slot) * (FRAG_DOUBLES_DEV * 8) + (J / 4) * 4096;
+        unsigned char* dst = lds_raw + buffer * (FRAG_DOUBLES_DEV * 8) + wave * (CHUNKS_PER_WAVE * 1024) + (J / 4) * 4096;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, (J % 4) * 1024, 0);
+    };
     auto stage_slot = [&](int slot) {
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(p.frag) + static_cast<size_t>(slot) * (FRAG_DOUBLES_DEV * 8);
-        unsigned char* dst = lds_raw + (slot & 1) * (FRAG_DOUBLES_DEV * 8);
-#pragma unroll
-        for (int j = 0; j < CHUNKS_PER_WAVE; ++j) {
-            const int chunk = wave * CHUNKS_PER_WAVE + j;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + chunk * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) void*)(dst + chunk * 1024), 16, 0, 0);
+        stage_piece(std::integral_constant<int, 0>{}, slot, slot & 1);
+        stage_piece(std::integral_constant<int, 1>{}, slot, slot & 1);
+        stage_piece(std::integral_constant<int, 2>{}, slot, slot & 1);
+        stage_piece(std::integral_constant<int, 3>{}, slot, slot & 1);
+        if constexpr (CHUNKS_PER_WAVE > 4) {
+            stage_piece(std::integral_constant<int, 4>{}, slot, slot & 1);
+            stage_piece(std::integral_constant<int, 5>{}, slot, slot & 1);
+            stage_piece(std::integral_constant<int, 6>{}, slot, slot & 1);
+            stage_piece(std::integral_constant<int, 7>{}, slot, slot & 1);
         }
     };
     int slot = 0;
     if (total_slots > 0) stage_slot(0);
-
     double lnz0 = 0.0, lnz1 = 0.0;
+    const bool stamping = STAMP && p.stamps != nullptr && blockIdx.x == p.stamp_block && wave == 0;
+    (void)stamping;
 
     for (int model = 0; model < 2; ++model) {
         const double* __restrict__ leaf_tab = p.leaf_tab + static_cast<size_t>(model) * p.n_leaves * LEAF_TABLE_DOUBLES_DEV;
@@ -144,8 +179,10 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
         double4_t acc[4];
         double stk[MAX_STACK_DEPTH_DEV][16];
 
+        uint32_t next_op = lprog[0];
         for (int ip = 0; ip < p.n_ops; ++ip) {
-            const uint32_t op = p.program[ip];
+            const uint32_t op = __builtin_amdgcn_readfirstlane(next_op);
+            next_op = lprog[ip + 1 < p.n_ops ? ip + 1 : ip];  // fetched one op ahead (LDS broadcast read)
             const uint32_t code = op >> 28;
             const int a = (op >> 14) & 0x3fff, b = op & 0x3fff;
 
@@ -153,33 +190,69 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
             // (a) completes this wave's LDS-DMA of the current slot (vmcnt(0)), (b) publishes all
             // waves' parts, (c) retires all reads of the other buffer, which the next slot's DMA
             // overwrites.  Leaf rows needed after the product are requested before the MFMAs.
+#define PCSF_STAMP(K)                                                                \
+    if constexpr (STAMP) {                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        const unsigned long long ts_ = stamp_now();                                  \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        if (stamping && lane == 0) p.stamps[(static_cast<size_t>(model) * p.n_ops + ip) * 4 + (K)] = ts_; \
+    }
 #define PCSF_PRODUCT_PROLOGUE()                                                      \
+    PCSF_STAMP(0)                                                                    \
     __syncthreads();                                                                 \
-    const double2_t* buf = lfrag + (slot & 1) * (FRAG_DOUBLES_DEV / 2);
-#define PCSF_PRODUCT_BODY(CH, RA, RB)                                                \
-    if (slot + 1 < total_slots) stage_slot(slot + 1);                                \
-    ++slot;                                                                          \
-    product<CH>(buf, lane, cur, acc, RA, RB, nxt);
+    PCSF_STAMP(1)                                                                    \
+    const double2_t* buf = lfrag + (slot & 1) * (FRAG_DOUBLES_DEV / 2);              \
+    const int this_slot = slot;                                                      \
+    /* branch-free: the last product re-stages its own slot into the idle buffer (never read) */ \
+    const int stage_next = this_slot + 1 < total_slots ? this_slot + 1 : this_slot;  \
+    ++slot;
+// slot 1 of k-steps 0..CHUNKS_PER_WAVE-1: one LDS-DMA piece of the next slot each
+#define PCSF_STAGE_SLOT(q, j)                                                        \
+    if constexpr (j == 1 && q < CHUNKS_PER_WAVE) {                                   \
+        stage_piece(std::integral_constant<int, (q < CHUNKS_PER_WAVE ? q : 0)>{}, stage_next, (this_slot + 1) & 1); \
+    }
+// cherry rows arrive a quarter (4 states per lane = 2 x 16 B per row) at a time: quarter k is
+// requested in k-steps 3k (row a: slots 2,3) and 3k+1 (row b: slots 2,3) and multiplied into nxt
+// in k-step 3k+5 (slots 2,3), so at most two quarters are in registers
 #define PCSF_PUSH_CHERRY(D)                                                          \
     {                                                                                \
         PCSF_PRODUCT_PROLOGUE()                                                      \
         const double2_t* pa = leaf_row_ptr(leaf_tab, a, my_cod[a * SITES], g4);      \
         const double2_t* pb = leaf_row_ptr(leaf_tab, b, my_cod[b * SITES], g4);      \
-        PCSF_PRODUCT_BODY(true, pa, pb)                                              \
+        double2_t xa[2][2], xb[2][2];                                                \
+        product(buf, lane, cur, acc, [&](auto qc, auto jc) {                         \
+            constexpr int q = decltype(qc)::value;                                   \
+            constexpr int j = decltype(jc)::value;                                   \
+            PCSF_STAGE_SLOT(q, j)                                                    \
+            if constexpr (j >= 2 && q % 3 == 0 && q / 3 < 4) xa[(q / 3) & 1][j - 2] = pa[2 * (q / 3) + (j - 2)]; \
+            if constexpr (j >= 2 && q % 3 == 1 && q / 3 < 4) xb[(q / 3) & 1][j - 2] = pb[2 * (q / 3) + (j - 2)]; \
+            if constexpr (j >= 2 && q >= 5 && (q - 5) % 3 == 0 && (q - 5) / 3 < 4) {  \
+                constexpr int k = (q - 5) / 3;                                       \
+                nxt[4 * k + 2 * (j - 2) + 0] = xa[k & 1][j - 2].x * xb[k & 1][j - 2].x; \
+                nxt[4 * k + 2 * (j - 2) + 1] = xa[k & 1][j - 2].y * xb[k & 1][j - 2].y; \
+            }                                                                        \
+        });                                                                          \
+        PCSF_STAMP(2)                                                                \
         _Pragma("unroll") for (int q = 0; q < 16; ++q) {                             \
             stk[D][q] = acc[q >> 2][q & 3];                                          \
             cur[q] = nxt[q];                                                         \
         }                                                                            \
+        PCSF_STAMP(3)                                                                \
     }
 #define PCSF_POP(D)                                                                  \
     {                                                                                \
         PCSF_PRODUCT_PROLOGUE()                                                      \
-        PCSF_PRODUCT_BODY(false, nullptr, nullptr)                                   \
+        product(buf, lane, cur, acc, [&](auto qc, auto jc) {                         \
+            constexpr int q = decltype(qc)::value;                                   \
+            constexpr int j = decltype(jc)::value;                                   \
+            PCSF_STAGE_SLOT(q, j)                                                    \
+        });                                                                          \
+        PCSF_STAMP(2)                                                                \
         _Pragma("unroll") for (int q = 0; q < 16; ++q) cur[q] = stk[D][q] * acc[q >> 2][q & 3]; \
+        PCSF_STAMP(3)                                                                \
     }
             switch (code) {
                 case F_CHERRY_DEV: {
-                    __syncthreads();  // codon bytes staged above are visible
                     const LeafRow ra = load_leaf_row(leaf_tab, a, my_cod[a * SITES], g4);
                     const LeafRow rb = load_leaf_row(leaf_tab, b, my_cod[b * SITES], g4);
 #pragma unroll
@@ -191,13 +264,21 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
                 }
                 case F_MM_LEAF_DEV: {
                     PCSF_PRODUCT_PROLOGUE()
-                    const LeafRow ra = load_leaf_row(leaf_tab, a, my_cod[a * SITES], g4);
-                    PCSF_PRODUCT_BODY(false, nullptr, nullptr)
+                    const double2_t* pa = leaf_row_ptr(leaf_tab, a, my_cod[a * SITES], g4);
+                    LeafRow ra;
+                    product(buf, lane, cur, acc, [&](auto qc, auto jc) {
+                        constexpr int q = decltype(qc)::value;
+                        constexpr int j = decltype(jc)::value;
+                        PCSF_STAGE_SLOT(q, j)
+                        if constexpr (j == 2 && q >= 4 && q < 12) ra.v[q - 4] = pa[q - 4];  // one 16-byte piece per k-step
+                    });
+                    PCSF_STAMP(2)
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         cur[2 * i] = acc[(2 * i) >> 2][(2 * i) & 3] * ra.v[i].x;
                         cur[2 * i + 1] = acc[(2 * i + 1) >> 2][(2 * i + 1) & 3] * ra.v[i].y;
                     }
+                    PCSF_STAMP(3)
                     break;
                 }
                 case F_MM_PUSH_CHERRY0_DEV + 0: PCSF_PUSH_CHERRY(0) break;
@@ -219,7 +300,8 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
                 }
             }
 #undef PCSF_PRODUCT_PROLOGUE
-#undef PCSF_PRODUCT_BODY
+#undef PCSF_STAMP
+#undef PCSF_STAGE_SLOT
 #undef PCSF_PUSH_CHERRY
 #undef PCSF_POP
         }
@@ -234,34 +316,36 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     }
 }
 
-template <int NW>
-static hipError_t launch_impl(const PruneParams& p, hipStream_t stream)
+template <int NW, bool STAMP>
+static hipError_t launch_impl(const PruneParams& p, hipStream_t stream, size_t extra_lds)
 {
     const size_t sites_per_block = static_cast<size_t>(NW) * 16;
     const size_t blocks = (p.n_sites + sites_per_block - 1) / sites_per_block;
     if (blocks == 0) return hipSuccess;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
-    const size_t lds = 2 * FRAG_DOUBLES_DEV * sizeof(double) + static_cast<size_t>(p.n_leaves) * sites_per_block;
+    const size_t lds = 2 * FRAG_DOUBLES_DEV * sizeof(double) + ((static_cast<size_t>(p.n_ops) + 3) & ~size_t(3)) * 4 +
+                       static_cast<size_t>(p.n_leaves) * sites_per_block + extra_lds;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prune_fixed<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prune_fixed<NW, STAMP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((prune_fixed<NW>), dim3(static_cast<unsigned>(blocks)), dim3(NW * 64), lds, stream, p);
+    hipLaunchKernelGGL((prune_fixed<NW, STAMP>), dim3(static_cast<unsigned>(blocks)), dim3(NW * 64), lds, stream, p);
     return hipGetLastError();
 }
 
-hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t stream)
+hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t stream, size_t extra_lds)
 {
     switch (variant) {
-        case 0: return launch_impl<4>(p, stream);
-        case 1: return launch_impl<8>(p, stream);
+        case 0: return launch_impl<4, false>(p, stream, extra_lds);
+        case 1: return launch_impl<8, false>(p, stream, extra_lds);
+        case 2: return launch_impl<4, true>(p, stream, extra_lds);  // diagnostic: in-kernel stamps
         default: return hipErrorInvalidValue;
     }
 }
 
-int prune_variant_count() { return 2; }
+int prune_variant_count() { return 3; }
 
 }  // namespace pcsf
