@@ -1,0 +1,101 @@
+// cli_common.hpp -- argument handling shared by the product CLI and the oracle's test CLI.
+// Same sub-commands, option names and defaults as the reference (`phylocsf++ build-tracks`,
+// `phylocsf++ score-msa`: src/phylocsf++build_tracks.hpp:367-507, src/phylocsf++score_msa.hpp:245-385)
+// for the options that reach the scoring path; options must precede the positionals.
+#pragma once
+
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "drivers.hpp"
+
+namespace pcsf_host {
+
+inline bool parse_bool(const std::string& v) { return v == "1" || v == "true" || v == "one"; }
+
+inline int usage(const char* prog)
+{
+    fprintf(stderr,
+            "usage:\n"
+            "  %s build-tracks [--output DIR] [--power-threshold 0|1] [--output-raw-phylo 0|1] [--output-power 0|1]\n"
+            "                  [--species-aliases FILE] [--device N] <model prefix> <alignment.maf>...\n"
+            "  %s score-msa    [--strategy fixed|mle|omega] [--comp-phylo 0|1] [--comp-anc 0|1] [--comp-bls 0|1]\n"
+            "                  [--output DIR] [--species-aliases FILE] [--device N] <model prefix> <alignment.maf>...\n"
+            "<model prefix> names <prefix>_coding.ECM, <prefix>_noncoding.ECM and <prefix>.nh\n",
+            prog, prog);
+    return 2;
+}
+
+using BackendFactory = std::function<std::unique_ptr<ScoringBackend>(const Model&, int device)>;
+
+inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
+{
+    if (argc < 2) return usage(argv[0]);
+    const std::string cmd = argv[1];
+    if (cmd != "build-tracks" && cmd != "score-msa") return usage(argv[0]);
+    BuildTracksParams bt;
+    ScoreMsaParams sm;
+    std::string aliases;
+    int device = 0;
+    int i = 2;
+    for (; i < argc && strncmp(argv[i], "--", 2) == 0; i += 2) {
+        if (i + 1 >= argc) return usage(argv[0]);
+        const std::string k = argv[i], v = argv[i + 1];
+        if (k == "--output") bt.output_dir = sm.output_dir = v;
+        // the reference reads this option with get_bool: anything but 1/true/one means 0.0
+        else if (k == "--power-threshold") bt.power_threshold = parse_bool(v) ? 1.0f : 0.0f;
+        else if (k == "--output-raw-phylo") bt.write_raw = parse_bool(v);
+        else if (k == "--output-power") bt.write_power = parse_bool(v);
+        else if (k == "--species-aliases") aliases = v;
+        else if (k == "--device") device = atoi(v.c_str());
+        else if (k == "--verbose") bt.verbose = sm.verbose = parse_bool(v);
+        else if (k == "--strategy") {
+            const std::string s = lower(v);
+            if (s == "fixed") sm.strategy = ALGO_FIXED;
+            else if (s == "mle") sm.strategy = ALGO_MLE;
+            else if (s == "omega") sm.strategy = ALGO_OMEGA;
+            else return usage(argv[0]);
+        } else if (k == "--comp-phylo") sm.comp_phylo = parse_bool(v);
+        else if (k == "--comp-anc") sm.comp_anc = parse_bool(v);
+        else if (k == "--comp-bls") sm.comp_bls = parse_bool(v);
+        else {
+            fprintf(stderr, "unknown option %s\n", k.c_str());
+            return usage(argv[0]);
+        }
+    }
+    if (argc - i < 2) return usage(argv[0]);
+    try {
+        const std::string prefix = argv[i++];
+        if (aliases.empty()) {  // convention: species_aliases.tsv next to the model files
+            const std::string cand = dirname_of(prefix) + "/species_aliases.tsv";
+            if (FILE* f = fopen(cand.c_str(), "r")) {
+                fclose(f);
+                aliases = cand;
+            }
+        }
+        const Model model = load_model(prefix, aliases);
+        std::unique_ptr<ScoringBackend> backend = make_backend(model, device);
+        bool first = true;
+        for (; i < argc; ++i) {
+            if (cmd == "build-tracks") {
+                const BuildTracksStats st = build_tracks(model, argv[i], bt, *backend, !first);
+                fprintf(stderr, "%s: %zu alignments, %zu reference bases, %zu codon-frames, %zu backend calls (%.3f s)\n", argv[i],
+                        st.alignments, st.ref_bases, st.codon_frames, st.backend_calls, st.backend_seconds);
+            } else {
+                const std::string out = score_msa(model, argv[i], sm, *backend);
+                fprintf(stderr, "%s -> %s\n", argv[i], out.c_str());
+            }
+            first = false;
+        }
+    } catch (const std::exception& e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
+
+}  // namespace pcsf_host

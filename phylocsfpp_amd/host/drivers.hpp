@@ -1,0 +1,235 @@
+// drivers.hpp -- build-tracks and score-msa on top of a scoring backend.
+//
+// The reference calls run_tracks() once per alignment x frame and run() once per block from
+// inside an OpenMP loop (src/phylocsf++build_tracks.hpp:88-232, src/phylocsf++score_msa.hpp:94-220).
+// Here the host gathers many alignment-frames / blocks into one leaf-major codon matrix and hands
+// it to the backend in one call (the C-ABI of include/phylocsf_amd.h); output text and file
+// layout follow the reference (PhyloCSFpower.wig, PhyloCSFRaw{+,-}{1,2,3}.wig, <maf>.scores).
+#pragma once
+
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cinttypes>
+#include <cmath>
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "maf_reader.hpp"
+#include "model_io.hpp"
+#include "tracks.hpp"
+
+namespace pcsf_host {
+
+enum Algorithm { ALGO_MLE = 0, ALGO_FIXED = 1, ALGO_OMEGA = 2 };  // algorithm_t, src/run.hpp:16-21
+
+// What the drivers need from a scoring implementation; HipBackend (backend_hip.hpp) forwards to
+// the C-ABI, the test-only OracleBackend (oracle/oracle_cli.cpp) to the CPU oracle.
+struct ScoringBackend {
+    virtual ~ScoringBackend() = default;
+    // run_tracks: leaf-major codons -> per-codon decibans
+    virtual void score_sites_fixed(const uint8_t* codons, size_t n_sites, size_t leaf_stride, double* out) = 0;
+    // run: CSR batch of blocks -> (phylo, anc) floats, NaN on model failure
+    virtual void score_blocks(int algo, const uint8_t* codons, const uint64_t* offsets, size_t n_blocks, size_t leaf_stride,
+                              bool compute_anc, uint32_t seed, float* phylo, float* anc) = 0;
+};
+
+struct BuildTracksParams {
+    std::string output_dir;          // empty: next to the alignment file
+    float power_threshold = 0.1f;    // TrackCLIParams::phylo_threshold
+    bool write_raw = true, write_power = true;
+    size_t batch_sites = 4u << 20;   // codon-frames gathered per backend call
+    bool verbose = false;
+};
+
+inline std::string dirname_of(const std::string& path)
+{
+    const size_t p = path.find_last_of('/');
+    return p == std::string::npos ? "./" : path.substr(0, p);
+}
+
+inline FILE* open_out(const std::string& path, const char* mode)
+{
+    FILE* f = fopen(path.c_str(), mode);
+    if (!f) throw std::runtime_error("cannot create file '" + path + "'");
+    return f;
+}
+
+struct BuildTracksStats {
+    size_t alignments = 0, ref_bases = 0, codon_frames = 0, backend_calls = 0;
+    double backend_seconds = 0.0;
+};
+
+// build-tracks for one MAF file.  append: later files of a multi-file run append to the wigs.
+inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_path, const BuildTracksParams& prm,
+                                     ScoringBackend& backend, bool append = false)
+{
+    const std::string out_dir = prm.output_dir.empty() ? dirname_of(maf_path) : prm.output_dir;
+    mkdir(out_dir.c_str(), 0764);
+    const char* mode = append ? "a" : "w";
+    FILE* f_power = prm.write_power ? open_out(out_dir + "/PhyloCSFpower.wig", mode) : nullptr;
+    FILE* f_raw[6] = {nullptr};
+    if (prm.write_raw)
+        for (int i = 0; i < 6; ++i)
+            f_raw[i] = open_out(out_dir + "/PhyloCSFRaw" + std::string(1, i < 3 ? '+' : '-') + std::to_string(i % 3 + 1) + ".wig", mode);
+
+    struct Pending {  // one alignment waiting for its scores
+        std::string chrom;
+        uint64_t start_pos;
+        std::vector<double> bls;
+        FrameView frame[6];
+        size_t offset[6];
+    };
+    const size_t nl = static_cast<size_t>(model.n_leaves);
+    size_t cap = prm.batch_sites;
+    std::vector<uint8_t> codons(nl * cap);
+    std::vector<double> scores;
+    std::vector<Pending> pending;
+    size_t used = 0;
+    BuildTracksStats st;
+    BranchLengthScore bls(model);
+    const float threshold3 = prm.power_threshold * 3;
+
+    auto flush = [&]() {
+        if (pending.empty()) return;
+        scores.resize(used);
+        if (used > 0 && prm.write_raw) {
+            const auto t0 = std::chrono::steady_clock::now();
+            backend.score_sites_fixed(codons.data(), used, cap, scores.data());
+            st.backend_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            ++st.backend_calls;
+        }
+        for (const Pending& p : pending) {
+            for (int fi = 0; fi < 6 && prm.write_raw; ++fi) {
+                const FrameView& v = p.frame[fi];
+                const bool minus = fi >= 3;
+                int64_t prev = -4;
+                size_t bpos = v.bls_offset;
+                for (size_t xx = 0; xx < v.n_codons; ++xx, bpos += 3) {
+                    const float bsum = static_cast<float>(p.bls[bpos] + p.bls[bpos + 1] + p.bls[bpos + 2]);
+                    if (bsum < threshold3) continue;
+                    const int64_t pos = static_cast<int64_t>(v.start_pos + xx * 3);
+                    if (prev + 3 != pos) fprintf(f_raw[fi], "fixedStep chrom=%s start=%" PRId64 " step=3 span=3\n", p.chrom.c_str(), pos);
+                    prev = pos;
+                    // '-' strand codons were scored right-to-left: score xx of the forward track is the mirrored one
+                    const size_t idx = minus ? (v.n_codons - 1 - xx) : xx;
+                    print_trimmed(f_raw[fi], "%.3f", static_cast<float>(scores[p.offset[fi] + idx]));
+                }
+            }
+        }
+        pending.clear();
+        used = 0;
+    };
+
+    MafReader reader(maf_path, model.name_to_leaf, model.n_leaves, /*concatenate=*/true, prm.verbose);
+    Alignment aln;
+    while (reader.next(aln)) {
+        ++st.alignments;
+        const size_t len = aln.length();
+        st.ref_bases += len;
+        Pending p;
+        p.chrom = aln.chrom;
+        p.start_pos = aln.start_pos;
+        bls.per_base(aln, &p.bls);
+
+        if (f_power) {  // power track: frame 3 of the + strand, mean of the three per-base scores
+            int64_t skip = static_cast<int64_t>(3 - static_cast<int64_t>(aln.start_pos)) % 3;
+            if (skip < 0) skip += 3;
+            if (static_cast<uint64_t>(skip) + 2 < p.bls.size())
+                fprintf(f_power, "fixedStep chrom=%s start=%" PRId64 " step=3 span=3\n", aln.chrom.c_str(),
+                        static_cast<int64_t>(aln.start_pos) + skip);
+            for (size_t pos = static_cast<size_t>(skip); pos + 2 < p.bls.size(); pos += 3)
+                print_trimmed(f_power, "%.4f", static_cast<float>((p.bls[pos] + p.bls[pos + 1] + p.bls[pos + 2]) / 3.0));
+        }
+        if (prm.write_raw) {
+            size_t need = 0;
+            for (int fi = 0; fi < 6; ++fi) {
+                p.frame[fi] = frame_view(aln.start_pos, aln.chrom_len, len, fi < 3 ? '+' : '-', static_cast<unsigned>(fi % 3 + 1));
+                need += p.frame[fi].n_codons;
+            }
+            if (used + need > cap) flush();
+            if (need > cap) {  // one alignment larger than the batch buffer
+                cap = need;
+                codons.assign(nl * cap, 0);
+            }
+            for (int fi = 0; fi < 6; ++fi) {
+                if (fi == 3) reverse_complement(aln.seqs);
+                p.offset[fi] = used;
+                extract_codons(aln.seqs, p.frame[fi].skip, p.frame[fi].n_codons, codons.data(), cap, used);
+                used += p.frame[fi].n_codons;
+                st.codon_frames += p.frame[fi].n_codons;
+            }
+        }
+        pending.push_back(std::move(p));
+    }
+    flush();
+    if (f_power) fclose(f_power);
+    for (FILE* f : f_raw)
+        if (f) fclose(f);
+    return st;
+}
+
+struct ScoreMsaParams {
+    std::string output_dir;  // empty: <maf>.scores next to the alignment
+    int strategy = ALGO_MLE;
+    bool comp_phylo = true, comp_anc = false, comp_bls = true;
+    bool verbose = false;
+    std::string version_line = "# PhyloCSF scores computed with phylocsf-amd (MI355X)";
+};
+
+inline std::string score_msa(const Model& model, const std::string& maf_path, const ScoreMsaParams& prm, ScoringBackend& backend)
+{
+    std::string out_path = prm.output_dir.empty() ? maf_path + ".scores" : prm.output_dir + "/" + maf_path.substr(maf_path.find_last_of('/') == std::string::npos ? 0 : maf_path.find_last_of('/') + 1) + ".scores";
+    FILE* out = open_out(out_path, "w");
+    fprintf(out, "%s\n", prm.version_line.c_str());
+    fprintf(out, "seq\tstart\tend\tstrand");
+    if (prm.comp_phylo) fprintf(out, "\tphylocsf-score");
+    if (prm.comp_anc) fprintf(out, "\tanc-score");
+    if (prm.comp_bls) fprintf(out, "\tbls-score");
+    fprintf(out, "\n");
+
+    struct Row { std::string chrom; uint64_t start, end; char strand; float bls; };
+    std::vector<Row> rows;
+    const size_t nl = static_cast<size_t>(model.n_leaves);
+    std::vector<std::vector<uint8_t>> per_leaf(nl);
+    std::vector<uint64_t> offsets{0};
+    BranchLengthScore bls(model);
+    MafReader reader(maf_path, model.name_to_leaf, model.n_leaves, /*concatenate=*/false, prm.verbose);
+    Alignment aln;
+    while (reader.next(aln)) {
+        const size_t len = aln.length();
+        Row r{aln.chrom, aln.start_pos, aln.start_pos + len - 1, aln.strand, NAN};
+        if (prm.comp_bls) r.bls = static_cast<float>(bls.per_base(aln, nullptr));
+        const size_t nc = len / 3;  // translate(): frame +1 from column 0
+        for (size_t l = 0; l < nl; ++l) {
+            const size_t at = per_leaf[l].size();
+            per_leaf[l].resize(at + nc);
+            const char* s = aln.seqs[l].data();
+            for (size_t c = 0; c < nc; ++c) per_leaf[l][at + c] = codon_id(s[3 * c], s[3 * c + 1], s[3 * c + 2]);
+        }
+        offsets.push_back(offsets.back() + nc);
+        rows.push_back(std::move(r));
+    }
+    const size_t total = offsets.back(), stride = std::max<size_t>(total, 1);
+    std::vector<uint8_t> codons(nl * stride);
+    for (size_t l = 0; l < nl; ++l) std::copy(per_leaf[l].begin(), per_leaf[l].end(), codons.begin() + l * stride);
+    std::vector<float> phylo(rows.size(), NAN), anc(rows.size(), NAN);
+    if ((prm.comp_phylo || prm.comp_anc) && !rows.empty())
+        backend.score_blocks(prm.strategy, codons.data(), offsets.data(), rows.size(), stride, prm.comp_anc, 42u, phylo.data(), anc.data());
+    for (size_t i = 0; i < rows.size(); ++i) {
+        const Row& r = rows[i];
+        fprintf(out, "%s\t%" PRIu64 "\t%" PRIu64 "\t%c", r.chrom.c_str(), r.start, r.end, r.strand);
+        if (prm.comp_phylo) fprintf(out, "\t%.6f", static_cast<double>(phylo[i]));
+        if (prm.comp_anc) fprintf(out, "\t%.6f", static_cast<double>(anc[i]));
+        if (prm.comp_bls) fprintf(out, "\t%.6f", static_cast<double>(r.bls));
+        fprintf(out, "\n");
+    }
+    fclose(out);
+    return out_path;
+}
+
+}  // namespace pcsf_host

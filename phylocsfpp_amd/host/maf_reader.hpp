@@ -1,0 +1,235 @@
+// maf_reader.hpp -- sequential MAF reader with the column-indexing semantics of the reference's
+// parallel_maf_reader::get_next_alignment (src/parallel_file_reader.hpp:430-685), restated:
+//   * only "a" and "s" lines matter; species = text before the first '.', lower-cased, looked up
+//     in the model's name map; unknown rows are skipped with a one-time warning
+//   * the first mapped row of a block is the reference row
+//   * build-tracks mode (concatenate): the next block is appended while its reference row
+//     continues exactly where the running alignment ends (same chromosome, start0 == start-1 +
+//     sum of reference sizes); species missing from a block are padded with 'N'
+//   * a block whose reference interval crosses a multiple of 1,000,000 marks a break point:
+//     reading continues until >= 2 more reference bases are available, the alignment is cut to
+//     (length at the end of the break-point block + 2) and the NEXT alignment restarts at the
+//     block after the break-point block
+//   * afterwards every column where the reference row has '-' is removed from all rows
+//   * score-msa mode: every block alone, any strand
+// The reference splits the file into byte-range jobs for OpenMP; the result does not depend on
+// the split (its CI checks that), so this reader is the one-job case.
+#pragma once
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "model_io.hpp"
+
+namespace pcsf_host {
+
+constexpr uint64_t BREAKPOINT_INTERVAL = 1000000;
+
+struct Alignment {
+    std::string chrom;
+    uint64_t start_pos = 0;  // 1-based
+    uint64_t chrom_len = 0;
+    char strand = '+';
+    std::vector<std::string> seqs;  // one row per leaf, equal lengths, reference gaps removed
+    size_t length() const { return seqs.empty() ? 0 : seqs[0].size(); }
+};
+
+class MafReader {
+public:
+    MafReader(const std::string& path, const std::unordered_map<std::string, int>& name_to_leaf, int n_leaves, bool concatenate,
+              bool verbose = true)
+        : names_(name_to_leaf), n_leaves_(n_leaves), concatenate_(concatenate), verbose_(verbose)
+    {
+        fd_ = ::open(path.c_str(), O_RDONLY);
+        if (fd_ < 0) throw std::runtime_error("cannot open " + path);
+        struct stat st;
+        if (fstat(fd_, &st) != 0) throw std::runtime_error("cannot stat " + path);
+        size_ = static_cast<size_t>(st.st_size);
+        if (size_ > 0) {
+            void* p = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
+            if (p == MAP_FAILED) throw std::runtime_error("cannot mmap " + path);
+            data_ = static_cast<const char*>(p);
+        }
+        // first alignment block: the file starts with "a " or we look for "\na "
+        if (!(size_ >= 2 && data_[0] == 'a' && data_[1] == ' ')) {
+            const char* hit = size_ ? static_cast<const char*>(memmem(data_, size_, "\na ", 3)) : nullptr;
+            pos_ = hit ? static_cast<size_t>(hit - data_) + 1 : size_;
+        }
+    }
+    ~MafReader()
+    {
+        if (data_) munmap(const_cast<char*>(data_), size_);
+        if (fd_ >= 0) ::close(fd_);
+    }
+    MafReader(const MafReader&) = delete;
+    MafReader& operator=(const MafReader&) = delete;
+
+    size_t bytes_total() const { return size_; }
+    size_t bytes_done() const { return pos_; }
+
+    bool next(Alignment& aln)
+    {
+        if (pos_ >= size_) return false;
+        aln.seqs.assign(n_leaves_, std::string());
+        bool first_block = true, stop = !concatenate_, reached_bp = false, freeze_restart = false;
+        size_t restart_pos = pos_;
+        int ref_leaf = -1;
+        uint64_t ref_bases = 0, ref_bases_at_bp = 0;
+
+        while ((!stop || first_block) && pos_ < size_) {
+            if (!freeze_restart) {
+                if (reached_bp) freeze_restart = true;
+                restart_pos = pos_;
+            }
+            skip_line();  // the "a ..." line
+            int block_ref = -1;
+            if (reached_bp && ref_bases >= ref_bases_at_bp + 2) stop = true;
+
+            while ((!stop || first_block) && pos_ < size_ && data_[pos_] != 'a') {
+                if (data_[pos_] != 's') {
+                    skip_line();
+                    continue;
+                }
+                SLine s = parse_s_line();
+                if (!first_block && block_ref == -1 && !((aln.start_pos - 1) + ref_bases == s.start && s.chrom == aln.chrom)) {
+                    stop = true;  // not contiguous: this block starts the next alignment
+                    break;
+                }
+                auto it = names_.find(s.species);
+                if (it == names_.end()) {
+                    if (unknown_.insert(s.species).second && verbose_)
+                        fprintf(stderr, "WARNING: species %s in the alignment file is not part of the model\n", s.species.c_str());
+                    continue;
+                }
+                const int leaf = it->second;
+                if (first_block && ref_leaf == -1) {
+                    aln.start_pos = s.start + 1;
+                    aln.chrom = s.chrom;
+                    aln.chrom_len = s.src_size;
+                    aln.strand = s.strand;
+                    ref_leaf = leaf;
+                    ref_bases = s.size;
+                    check_strand(s);
+                    if (!reached_bp && aln.start_pos / BREAKPOINT_INTERVAL < (aln.start_pos + s.size) / BREAKPOINT_INTERVAL) {
+                        reached_bp = true;
+                        ref_bases_at_bp = ref_bases;
+                    }
+                } else if (!first_block && block_ref == -1) {
+                    block_ref = leaf;
+                    const uint64_t prev_end = aln.start_pos + ref_bases;
+                    ref_bases += s.size;
+                    if (!reached_bp && prev_end / BREAKPOINT_INTERVAL < (prev_end + s.size) / BREAKPOINT_INTERVAL) {
+                        reached_bp = true;
+                        ref_bases_at_bp = ref_bases;
+                    }
+                    if (block_ref != ref_leaf)
+                        throw std::runtime_error("alignment block does not start with the reference species: " + s.species + "." + s.chrom);
+                    check_strand(s);
+                }
+                aln.seqs[leaf].append(s.text, s.text_len);
+            }
+            if (ref_leaf < 0) throw std::runtime_error("alignment block without any species of the model");
+            const size_t L = aln.seqs[ref_leaf].size();
+            for (auto& row : aln.seqs)
+                if (row.size() != L) row.append(L - row.size(), 'N');
+            first_block = false;
+        }
+        if (reached_bp && ref_bases >= ref_bases_at_bp + 2) stop = true;
+        if (stop && concatenate_) pos_ = restart_pos;
+
+        // remove the columns where the reference row is a gap
+        const std::string& ref = aln.seqs[ref_leaf];
+        keep_.clear();
+        for (size_t i = 0; i < ref.size(); ++i)
+            if (ref[i] != '-') keep_.push_back(static_cast<uint32_t>(i));
+        if (keep_.size() != ref.size()) {
+            for (auto& row : aln.seqs) {
+                for (size_t w = 0; w < keep_.size(); ++w) row[w] = row[keep_[w]];
+                row.resize(keep_.size());
+            }
+        }
+        if (reached_bp && ref_bases > ref_bases_at_bp + 2)
+            for (auto& row : aln.seqs) row.resize(ref_bases_at_bp + 2);
+        return true;
+    }
+
+private:
+    struct SLine {
+        std::string species, chrom;
+        uint64_t start = 0, size = 0, src_size = 0;
+        char strand = '.';
+        const char* text = nullptr;
+        size_t text_len = 0;
+    };
+
+    void skip_line()
+    {
+        const void* nl = memchr(data_ + pos_, '\n', size_ - pos_);
+        pos_ = nl ? static_cast<size_t>(static_cast<const char*>(nl) - data_) + 1 : size_;
+    }
+
+    // "s <src> <start> <size> <strand> <srcSize> <text>", fields separated by runs of spaces
+    SLine parse_s_line()
+    {
+        const void* nl = memchr(data_ + pos_, '\n', size_ - pos_);
+        const size_t end = nl ? static_cast<size_t>(static_cast<const char*>(nl) - data_) : size_;
+        const char* p = data_ + pos_;
+        const char* e = data_ + end;
+        const char* tok[7] = {nullptr};
+        size_t len[7] = {0};
+        int k = 0;
+        while (p < e && k < 7) {
+            while (p < e && *p == ' ') ++p;
+            if (p >= e) break;
+            const char* b = p;
+            while (p < e && *p != ' ') ++p;
+            tok[k] = b;
+            len[k] = static_cast<size_t>(p - b);
+            ++k;
+        }
+        if (k < 7) throw std::runtime_error("malformed 's' line in MAF at byte " + std::to_string(pos_));
+        SLine s;
+        std::string src(tok[1], len[1]);
+        const size_t dot = src.find('.');
+        if (dot == std::string::npos) throw std::runtime_error("MAF source '" + src + "' is not of the form species.chrom");
+        s.species = lower(src.substr(0, dot));
+        s.chrom = src.substr(dot + 1);
+        s.start = static_cast<uint64_t>(atoi(std::string(tok[2], len[2]).c_str()));
+        s.size = static_cast<uint64_t>(atoi(std::string(tok[3], len[3]).c_str()));
+        s.strand = tok[4][0];
+        s.src_size = static_cast<uint64_t>(atoi(std::string(tok[5], len[5]).c_str()));
+        s.text = tok[6];
+        s.text_len = len[6];
+        if (s.text_len && s.text[s.text_len - 1] == '\r') --s.text_len;
+        pos_ = nl ? end + 1 : size_;
+        return s;
+    }
+
+    void check_strand(const SLine& s) const
+    {
+        if (concatenate_ && s.strand != '+')
+            throw std::runtime_error("reference sequence is not on the + strand (" + s.species + "." + s.chrom + " at " + std::to_string(s.start) + ")");
+    }
+
+    const std::unordered_map<std::string, int>& names_;
+    int n_leaves_;
+    bool concatenate_, verbose_;
+    int fd_ = -1;
+    const char* data_ = nullptr;
+    size_t size_ = 0, pos_ = 0;
+    std::unordered_set<std::string> unknown_;
+    std::vector<uint32_t> keep_;
+};
+
+}  // namespace pcsf_host

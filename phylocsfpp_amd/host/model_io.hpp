@@ -1,0 +1,216 @@
+// model_io.hpp -- host-side model input: ECM rate files, newick tree, species-name map.
+// Mirrors what load_model() hands to the scoring core (reference src/models.hpp:1757-1857,
+// src/ecm.hpp:20-67, src/newick.hpp:31-229); written from scratch.
+#pragma once
+
+#include <algorithm>
+#include <cctype>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace pcsf_host {
+
+struct Model {
+    int n_nodes = 0, n_leaves = 0;
+    // newick_flatten numbering: leaves 0..nl-1 in left-to-right order, internal nodes in post-order
+    std::vector<int16_t> child1, child2, parent;
+    std::vector<float> branch_len;     // what the likelihood uses (newick_elem::branch_length is float)
+    std::vector<double> branch_len_d;  // what the branch-length score uses (newick_node, double)
+    std::vector<std::string> label;    // lower-cased; empty for internal nodes
+    std::vector<double> S_c, pi_c, S_nc, pi_nc;  // 64x64 row-major, 64
+    std::unordered_map<std::string, int> name_to_leaf;  // labels + aliases, lower case
+};
+
+// ---- ECM file: 63 lower-triangle rows, a blank line, 64 frequencies (then codon names) --------
+inline void read_ecm(const std::string& path, std::vector<double>& S, std::vector<double>& pi)
+{
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error("cannot open model file '" + path + "' (pass the prefix without file endings)");
+    S.assign(64 * 64, 0.0);
+    pi.assign(64, 0.0);
+    std::string line;
+    int row = 1;  // the first line of the file is row 1 of the triangle (row 0 would be empty)
+    bool have_freq = false;
+    while (std::getline(in, line)) {
+        const char* p = line.c_str();
+        char* end = nullptr;
+        int col = 0;
+        if (row <= 63) {
+            for (double v = std::strtod(p, &end); p != end; v = std::strtod(p, &end)) {
+                p = end;
+                if (col < row) S[col * 64 + row] = S[row * 64 + col] = v;
+                ++col;
+            }
+            if (col != row) throw std::runtime_error(path + ": triangle row " + std::to_string(row) + " has " + std::to_string(col) + " values");
+        } else if (row == 65) {
+            for (double v = std::strtod(p, &end); p != end; v = std::strtod(p, &end)) {
+                p = end;
+                if (col < 64) pi[col] = v;
+                ++col;
+            }
+            if (col != 64) throw std::runtime_error(path + ": expected 64 codon frequencies");
+            have_freq = true;
+        }
+        ++row;
+    }
+    if (!have_freq) throw std::runtime_error(path + ": codon frequency line missing");
+}
+
+// ---- newick ---------------------------------------------------------------------------------
+namespace detail {
+struct Node {
+    int left = -1, right = -1, parent = -1;
+    double len = 0.0;
+    std::string label;
+    int id = -1;
+};
+
+struct NewickParser {
+    const std::string& s;
+    size_t pos = 0;
+    std::vector<Node> nodes;
+    explicit NewickParser(const std::string& text) : s(text) {}
+
+    int parse(int parent)
+    {
+        const int me = static_cast<int>(nodes.size());
+        nodes.emplace_back();
+        nodes[me].parent = parent;
+        if (pos < s.size() && s[pos] == '(') {
+            ++pos;
+            const int l = parse(me);
+            expect(',');
+            const int r = parse(me);
+            expect(')');  // strictly binary, like the reference
+            nodes[me].left = l;
+            nodes[me].right = r;
+        } else {
+            std::string lab;
+            while (pos < s.size() && s[pos] != '(' && s[pos] != ',' && s[pos] != ')' && s[pos] != ':' && s[pos] != ';')
+                lab += static_cast<char>(std::tolower(static_cast<unsigned char>(s[pos++])));
+            if (lab.empty()) fail("empty leaf label");
+            nodes[me].label = lab;
+        }
+        if (pos < s.size() && s[pos] == ':') {
+            ++pos;
+            std::string num;
+            while (pos < s.size() && (std::isdigit(static_cast<unsigned char>(s[pos])) || s[pos] == '.')) num += s[pos++];
+            if (num.empty()) fail("branch length expected");
+            nodes[me].len = std::stod(num);
+        }
+        return me;
+    }
+    void expect(char c)
+    {
+        if (pos >= s.size() || s[pos] != c) fail(std::string("'") + c + "' expected");
+        ++pos;
+    }
+    [[noreturn]] void fail(const std::string& what) { throw std::runtime_error("newick: " + what + " at offset " + std::to_string(pos)); }
+};
+}  // namespace detail
+
+inline void parse_newick(const std::string& text, Model& m)
+{
+    std::string s;
+    for (char c : text)
+        if (!std::isspace(static_cast<unsigned char>(c))) s += c;
+    detail::NewickParser P(s);
+    const int root = P.parse(-1);
+    if (P.pos < s.size() && s[P.pos] != ';') P.fail("trailing characters");
+    auto& nd = P.nodes;
+    int nl = 0;
+    for (auto& x : nd) nl += x.left < 0;
+    const int n = static_cast<int>(nd.size());
+    if (n != 2 * nl - 1 || nl < 2) throw std::runtime_error("newick: not a binary tree with >= 2 leaves");
+    // ids: leaves left-to-right, internal nodes in post-order starting at nl
+    int next_leaf = 0, next_inner = nl;
+    std::vector<std::pair<int, int>> stack{{root, 0}};
+    while (!stack.empty()) {
+        auto& [v, stage] = stack.back();
+        if (nd[v].left < 0) {
+            nd[v].id = next_leaf++;
+            stack.pop_back();
+        } else if (stage == 0) {
+            stage = 1;
+            stack.push_back({nd[v].left, 0});
+        } else if (stage == 1) {
+            stage = 2;
+            stack.push_back({nd[v].right, 0});
+        } else {
+            nd[v].id = next_inner++;
+            stack.pop_back();
+        }
+    }
+    m.n_nodes = n;
+    m.n_leaves = nl;
+    m.child1.assign(n, -1);
+    m.child2.assign(n, -1);
+    m.parent.assign(n, -1);
+    m.branch_len.assign(n, 0.f);
+    m.branch_len_d.assign(n, 0.0);
+    m.label.assign(n, "");
+    for (auto& x : nd) {
+        const int i = x.id;
+        if (x.left >= 0) {
+            m.child1[i] = static_cast<int16_t>(nd[x.left].id);
+            m.child2[i] = static_cast<int16_t>(nd[x.right].id);
+        }
+        m.parent[i] = x.parent >= 0 ? static_cast<int16_t>(nd[x.parent].id) : -1;
+        m.branch_len[i] = static_cast<float>(x.len);
+        m.branch_len_d[i] = x.len;
+        m.label[i] = x.label;
+    }
+}
+
+inline std::string slurp(const std::string& path)
+{
+    std::ifstream in(path, std::ios::binary);
+    if (!in) throw std::runtime_error("cannot open '" + path + "'");
+    std::ostringstream ss;
+    ss << in.rdbuf();
+    return ss.str();
+}
+
+inline std::string lower(std::string s)
+{
+    for (char& c : s) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+    return s;
+}
+
+// alias table: "<tree label>\t<alias> <alias> ...", one species per line (all matched lower-cased)
+inline void add_aliases(Model& m, const std::string& path)
+{
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error("cannot open species alias file '" + path + "'");
+    std::string line;
+    while (std::getline(in, line)) {
+        const size_t tab = line.find('\t');
+        if (tab == std::string::npos) continue;
+        auto it = m.name_to_leaf.find(lower(line.substr(0, tab)));
+        if (it == m.name_to_leaf.end()) continue;
+        std::istringstream al(line.substr(tab + 1));
+        std::string a;
+        while (al >> a) m.name_to_leaf.emplace(lower(a), it->second);
+    }
+}
+
+// <prefix>_coding.ECM, <prefix>_noncoding.ECM, <prefix>.nh  (reference src/models.hpp:1773-1775)
+inline Model load_model(const std::string& prefix, const std::string& alias_file = "")
+{
+    Model m;
+    read_ecm(prefix + "_coding.ECM", m.S_c, m.pi_c);
+    read_ecm(prefix + "_noncoding.ECM", m.S_nc, m.pi_nc);
+    parse_newick(slurp(prefix + ".nh"), m);
+    for (int i = 0; i < m.n_leaves; ++i) m.name_to_leaf.emplace(m.label[i], i);
+    if (!alias_file.empty()) add_aliases(m, alias_file);
+    return m;
+}
+
+}  // namespace pcsf_host

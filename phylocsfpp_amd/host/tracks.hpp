@@ -1,0 +1,199 @@
+// tracks.hpp -- everything between an Alignment and the text the reference writes:
+// branch-length score, six-frame codon extraction, wig / .scores formatting.
+// Restates (from scratch) the behaviour of the reference's
+//   compute_bls_score / newick_sum_branch_lengths   src/additional_scores.hpp:5-84
+//   alignment_t::update_seqs / translate            src/parallel_file_reader.hpp:46-113
+//   get_amino_acid_id / complement                  src/translation.hpp:29-88
+//   the per-frame output loop                       src/phylocsf++build_tracks.hpp:139-227
+//   my_fprintf                                      src/common.hpp:48-68
+#pragma once
+
+#include <cinttypes>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "maf_reader.hpp"
+#include "model_io.hpp"
+
+namespace pcsf_host {
+
+// ---- nucleotides and codons ------------------------------------------------------------------
+// 0..3 = A C G T (either case), 4 = N n - . ; anything else is an input error (the reference exits)
+inline int nucleotide_id(char c)
+{
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+        case 'N': case 'n': case '-': case '.': return 4;
+        default: throw std::runtime_error(std::string("unexpected character '") + c + "' in alignment");
+    }
+}
+
+inline uint8_t codon_id(char a, char b, char c)
+{
+    const int x = nucleotide_id(a), y = nucleotide_id(b), z = nucleotide_id(c);
+    if (x == 4 || y == 4 || z == 4) return 64;  // marginalise
+    return static_cast<uint8_t>(16 * x + 4 * y + z);
+}
+
+inline char complement(char c)
+{
+    switch (c) {
+        case 'A': return 'T'; case 'a': return 't';
+        case 'C': return 'G'; case 'c': return 'g';
+        case 'G': return 'C'; case 'g': return 'c';
+        case 'T': return 'A'; case 't': return 'a';
+        default: return c;
+    }
+}
+
+inline void reverse_complement(std::vector<std::string>& rows)
+{
+    for (auto& r : rows) {
+        std::string out(r.size(), ' ');
+        for (size_t i = 0; i < r.size(); ++i) out[r.size() - 1 - i] = complement(r[i]);
+        r.swap(out);
+    }
+}
+
+// Frame arithmetic of update_seqs.  `rows` must already be reverse-complemented for strand '-'.
+struct FrameView {
+    unsigned skip = 0;       // leading columns (of the rows as given) before the first codon
+    size_t n_codons = 0;
+    uint64_t start_pos = 0;  // genome position (1-based) of the first emitted score
+    size_t bls_offset = 0;   // index into the forward per-base BLS vector of the first score
+};
+
+inline FrameView frame_view(uint64_t orig_start, uint64_t chrom_len, size_t len, char strand, unsigned frame)
+{
+    FrameView v;
+    int64_t skip;
+    if (strand == '+') {
+        skip = (static_cast<int64_t>(frame) - static_cast<int64_t>(orig_start)) % 3;
+    } else {
+        skip = (static_cast<int64_t>(frame) - static_cast<int64_t>(chrom_len - (orig_start + len) + 2)) % 3;
+    }
+    if (skip < 0) skip += 3;
+    if (static_cast<uint64_t>(skip) > len) skip = static_cast<int64_t>(len);
+    v.skip = static_cast<unsigned>(skip);
+    v.n_codons = (len - v.skip) / 3;
+    if (strand == '+') {
+        v.start_pos = orig_start + v.skip;
+        v.bls_offset = v.skip;
+    } else {
+        // codons are read right-to-left; the 0-2 left-over bases sit at the left end of the forward strand
+        v.start_pos = orig_start + (len - v.skip) % 3;
+        v.bls_offset = (len - v.skip) % 3;
+    }
+    return v;
+}
+
+// appends the codons of one frame, leaf-major, into dst[leaf*stride + offset ...]
+inline void extract_codons(const std::vector<std::string>& rows, unsigned skip, size_t n_codons, uint8_t* dst, size_t stride, size_t offset)
+{
+    for (size_t leaf = 0; leaf < rows.size(); ++leaf) {
+        const char* s = rows[leaf].data() + skip;
+        uint8_t* d = dst + leaf * stride + offset;
+        for (size_t c = 0; c < n_codons; ++c) d[c] = codon_id(s[3 * c], s[3 * c + 1], s[3 * c + 2]);
+    }
+}
+
+// ---- branch-length score ---------------------------------------------------------------------
+// For a column, S = leaves showing A/C/G/T.  bl(S) = sum of the branch lengths below the last
+// common ancestor of S that lead to at least one member of S, accumulated in the order
+// (own branch, left subtree, right subtree) in double precision -- the order matters because the
+// result feeds a float threshold.  Leaves are numbered left to right, so a subtree is a range.
+class BranchLengthScore {
+public:
+    explicit BranchLengthScore(const Model& m) : m_(m), lo_(m.n_nodes), hi_(m.n_nodes), prefix_(m.n_leaves + 1)
+    {
+        for (int i = 0; i < m.n_nodes; ++i) {
+            if (i < m.n_leaves) { lo_[i] = i; hi_[i] = i + 1; }
+            else { lo_[i] = lo_[m.child1[i]]; hi_[i] = hi_[m.child2[i]]; }
+        }
+        std::vector<char> all(m.n_leaves, 1);
+        total_ = subtree_sum(all);
+    }
+    double total() const { return total_; }
+
+    // present[leaf] != 0 for members of S; requires |S| >= 1
+    double subtree_sum(const std::vector<char>& present)
+    {
+        prefix_[0] = 0;
+        for (int l = 0; l < m_.n_leaves; ++l) prefix_[l + 1] = prefix_[l] + (present[l] ? 1 : 0);
+        return walk(m_.n_nodes - 1, false);
+    }
+
+    // per-base scores bl(S)/bl(all) (0 when fewer than two species have a base); returns the mean
+    double per_base(const Alignment& aln, std::vector<double>* out)
+    {
+        const size_t L = aln.length();
+        std::vector<char> present(m_.n_leaves), last(m_.n_leaves, 2);
+        double last_val = 0.0, sum = 0.0;
+        if (out) out->clear();
+        for (size_t i = 0; i < L; ++i) {
+            int cnt = 0;
+            for (int l = 0; l < m_.n_leaves; ++l) {
+                present[l] = nucleotide_id(aln.seqs[l][i]) <= 3;
+                cnt += present[l];
+            }
+            double v = 0.0;
+            if (cnt >= 2) {
+                if (present != last) {
+                    last_val = subtree_sum(present);
+                    last = present;
+                }
+                v = last_val;
+                sum += v;
+            }
+            if (out) out->push_back(cnt >= 2 ? v / total_ : 0.0);
+        }
+        return sum / (total_ * static_cast<double>(L));
+    }
+
+private:
+    int overlap(int node) const { return prefix_[hi_[node]] - prefix_[lo_[node]]; }
+    double walk(int node, bool below_lca) const
+    {
+        if (node < m_.n_leaves) return m_.branch_len_d[node];
+        const int l = m_.child1[node], r = m_.child2[node];
+        const int ol = overlap(l), orr = overlap(node) - ol;
+        double bl = below_lca ? m_.branch_len_d[node] : 0.0;
+        if (ol > 0 && orr > 0) below_lca = true;
+        if (ol > 0) bl += walk(l, below_lca);
+        if (orr > 0) bl += walk(r, below_lca);
+        return bl;
+    }
+    const Model& m_;
+    std::vector<int> lo_, hi_, prefix_;
+    double total_ = 0.0;
+};
+
+// ---- text output -----------------------------------------------------------------------------
+// "%.3f"-style formatting of a float with trailing zeros removed but one decimal kept
+inline void print_trimmed(FILE* f, const char* fmt, float v)
+{
+    char buf[64];
+    snprintf(buf, sizeof buf, fmt, static_cast<double>(v));
+    for (int i = static_cast<int>(strlen(buf)); i >= 0; --i) {
+        if (buf[i] == '.') {
+            buf[i + 1] = '0';
+            break;
+        }
+        if (buf[i] >= '0' && buf[i] <= '9') {
+            if (buf[i] != '0') break;
+            buf[i] = 0;
+        }
+    }
+    fputs(buf, f);
+    fputc('\n', f);
+}
+
+}  // namespace pcsf_host

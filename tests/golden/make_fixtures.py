@@ -62,7 +62,7 @@ for model in ("58mammals", "100vertebrates"):
 labels = set()
 for model in ("53birds", "58mammals", "100vertebrates"):
     t = open(os.path.join(OUT, "models", model + ".nh")).read()
-    labels |= {x.lower() for x in re.findall(r"[(,]\s*([A-Za-z_0-9]+)\s*:", t)}
+    labels |= {x.lower() for x in re.findall(r"[(,]\s*([^:,()\s]+)\s*:", t)}
 block = src[src.index("sequence_name_mapping = {"):]
 block = block[:block.index("};")]
 rows = re.findall(r'\{\s*"([^"]+)"\s*,\s*\{([^}]*)\}\s*\}', block)

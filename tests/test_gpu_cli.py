@@ -1,0 +1,51 @@
+"""End to end on the GPU: the host driver (phylocsfpp_amd/host/phylocsf-amd) calling the HIP path
+through the C-ABI must regenerate the reference's golden files (tests/golden/)."""
+import gzip
+import os
+import shutil
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+CLI = os.path.join(ROOT, "phylocsfpp_amd", "host", "phylocsf-amd")
+
+
+def _cli():
+    if not os.path.exists(CLI):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(CLI)])
+    return CLI
+
+
+def test_build_tracks_golden_wigs_on_gpu(tmp_path):
+    maf = tmp_path / "galGal6.maf"
+    with gzip.open(os.path.join(GOLD, "build-tracks", "galGal6_chr22_25_28_each_30k_bases.maf.gz"), "rb") as fi, open(maf, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    out = tmp_path / "out"
+    subprocess.check_call([_cli(), "build-tracks", "--output", str(out), os.path.join(GOLD, "models", "53birds"), str(maf)])
+    for n in ["PhyloCSFpower"] + ["PhyloCSFRaw%s%d" % (s, f) for s in "+-" for f in (1, 2, 3)]:
+        want = gzip.open(os.path.join(GOLD, "build-tracks", n + ".wig.gz"), "rb").read()
+        got = open(out / (n + ".wig"), "rb").read()
+        assert got == want, n                      # the reference's own test is `diff -r`
+
+
+def _scores(path):
+    return [l.rstrip("\n").split("\t") for l in open(path) if not l.startswith("#")][1:]
+
+
+@pytest.mark.parametrize("maf,gold", [("chr22.50alignments.maf", "chr22.50alignments.fixed.scores"),
+                                      ("chr22.516alignments.maf.gz", "chr22.516alignments.fixed.scores")])
+def test_score_msa_fixed_golden_on_gpu(tmp_path, maf, gold):
+    src = os.path.join(GOLD, "score-msa", maf)
+    dst = tmp_path / maf.replace(".gz", "")
+    if maf.endswith(".gz"):
+        with gzip.open(src, "rb") as fi, open(dst, "wb") as fo:
+            shutil.copyfileobj(fi, fo)
+    else:
+        shutil.copyfile(src, dst)
+    subprocess.check_call([_cli(), "score-msa", "--strategy", "fixed", "--comp-anc", "1",
+                           os.path.join(GOLD, "models", "100vertebrates"), str(dst)])
+    assert _scores(str(dst) + ".scores") == _scores(os.path.join(GOLD, "score-msa", gold))

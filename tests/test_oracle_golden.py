@@ -1,0 +1,119 @@
+"""Pins the CPU oracle (and the host driver it is run under) against the reference's OWN golden
+outputs (tests/golden/, copied from /root/reference/test by tests/golden/make_fixtures.py):
+
+  * build-tracks, 53birds file model, galGal6 example  -> 7 raw/power wigs, byte-identical
+    (reference test/tests.sh:15-19, `diff -r`)
+  * score-msa 100vertebrates FIXED, 50 and 516 blocks   -> identical text (tests.sh:35-37)
+  * score-msa MLE   -> |delta|^2 <= 0.001 on score and anc (tests.sh:40-42)
+  * score-msa OMEGA -> |delta|^2 <= 0.1 (tests.sh:45-48), NaN rows for blocks without a codon
+"""
+import gzip
+import math
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+CLI = os.path.join(ROOT, "oracle", "_build", "oracle_cli")
+
+
+@pytest.fixture(scope="module")
+def oracle_cli():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert os.path.exists(CLI)
+    return CLI
+
+
+def gunzip_to(src, dst):
+    with gzip.open(src, "rb") as fi, open(dst, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+
+
+def read_scores(path):
+    rows = [l.rstrip("\n").split("\t") for l in open(path) if not l.startswith("#")]
+    return rows[0], rows[1:]
+
+
+def test_build_tracks_wigs_byte_identical(oracle_cli, tmp_path):
+    maf = tmp_path / "galGal6.maf"
+    gunzip_to(os.path.join(GOLD, "build-tracks", "galGal6_chr22_25_28_each_30k_bases.maf.gz"), maf)
+    out = tmp_path / "out"
+    subprocess.check_call([oracle_cli, "build-tracks", "--output", str(out), os.path.join(GOLD, "models", "53birds"), str(maf)],
+                          stderr=subprocess.DEVNULL)
+    names = ["PhyloCSFpower"] + ["PhyloCSFRaw%s%d" % (s, f) for s in "+-" for f in (1, 2, 3)]
+    for n in names:
+        want = gzip.open(os.path.join(GOLD, "build-tracks", n + ".wig.gz"), "rb").read()
+        got = open(out / (n + ".wig"), "rb").read()
+        assert got == want, n
+
+
+@pytest.mark.parametrize("maf,gold,n", [("chr22.50alignments.maf", "chr22.50alignments.fixed.scores", 50),
+                                        ("chr22.516alignments.maf.gz", "chr22.516alignments.fixed.scores", 516)])
+def test_score_msa_fixed_identical(oracle_cli, tmp_path, maf, gold, n):
+    src = os.path.join(GOLD, "score-msa", maf)
+    dst = tmp_path / maf.replace(".gz", "")
+    gunzip_to(src, dst) if maf.endswith(".gz") else shutil.copyfile(src, dst)
+    subprocess.check_call([oracle_cli, "score-msa", "--strategy", "fixed", "--comp-anc", "1",
+                           os.path.join(GOLD, "models", "100vertebrates"), str(dst)], stderr=subprocess.DEVNULL)
+    _, got = read_scores(str(dst) + ".scores")
+    _, want = read_scores(os.path.join(GOLD, "score-msa", gold))
+    assert len(got) == len(want) == n
+    assert got == want          # coordinates, strand, %.6f scores, anc and bls: all text-identical
+
+
+def _first_blocks(src, dst, n_blocks):
+    out, n = [], 0
+    for line in open(src):
+        if line.startswith("a"):
+            n += 1
+            if n > n_blocks:
+                break
+        out.append(line)
+    open(dst, "w").writelines(out)
+
+
+def test_score_msa_mle_within_reference_tolerance(oracle_cli, tmp_path):
+    dst = tmp_path / "small.maf"
+    shutil.copyfile(os.path.join(GOLD, "score-msa", "chr22.50alignments.maf"), dst)
+    subprocess.check_call([oracle_cli, "score-msa", "--strategy", "mle", "--comp-anc", "1",
+                           os.path.join(GOLD, "models", "100vertebrates"), str(dst)], stderr=subprocess.DEVNULL)
+    _, got = read_scores(str(dst) + ".scores")
+    _, want = read_scores(os.path.join(GOLD, "score-msa", "chr22.50alignments.mle.scores"))
+    assert len(got) == len(want) == 50
+    tight = 0
+    for g, w in zip(got, want):
+        assert g[:4] == w[:4] and g[6] == w[6]
+        dp, da = float(g[4]) - float(w[4]), float(g[5]) - float(w[5])
+        assert dp * dp <= 0.001 and da * da <= 0.001            # the reference's own acceptance test
+        tight += abs(dp) <= 5e-6 and abs(da) <= 5e-6
+    # GSL-Brent restatement: 48 of 50 rows reproduce to print precision (rows 5 and 48 take a
+    # different branch at a near-tie inside Brent, 1.5e-4 away -- SURVEY.md 8a14)
+    assert tight >= 48
+
+
+def test_score_msa_omega_within_reference_tolerance(oracle_cli, tmp_path):
+    dst = tmp_path / "small.maf"
+    _first_blocks(os.path.join(GOLD, "score-msa", "chr22.50alignments.maf"), dst, 30)
+    subprocess.check_call([oracle_cli, "score-msa", "--strategy", "omega", "--comp-anc", "0",
+                           os.path.join(GOLD, "models", "100vertebrates"), str(dst)], stderr=subprocess.DEVNULL)
+    _, got = read_scores(str(dst) + ".scores")
+    _, want = read_scores(os.path.join(GOLD, "score-msa", "chr22.50alignments.omega.scores"))
+    assert len(got) == 30
+    finite = 0
+    for g, w in zip(got, want):
+        assert g[:4] == w[:4] and g[5] == w[5]
+        n_codons = (int(g[2]) - int(g[1]) + 1) // 3
+        if n_codons == 0:
+            assert g[4] == "nan" and w[4] == "nan"             # policy: blocks without a codon are NaN like the goldens
+        elif w[4] != "nan":
+            d = float(g[4]) - float(w[4])
+            assert d * d <= 0.1                                 # tests.sh:46
+            finite += 1
+        else:
+            # short-block NaN rows of the reference come from GSL's non-symmetric solver degrading;
+            # the symmetric solver returns a finite score there (parity unpinned)
+            assert math.isfinite(float(g[4]))
+    assert finite >= 20
