@@ -98,6 +98,16 @@ int pcsf_score_blocks(pcsf_ctx *ctx, int algo, const uint8_t *codons, const uint
                       size_t n_blocks, size_t leaf_stride, int compute_anc, uint32_t seed,
                       float *out_phylo, float *out_anc);
 
+/* One objective evaluation of the MLE / OMEGA strategies per block at caller-chosen parameters, without
+ * the prior term: sum over the block's sites of ln z with the branch matrices at tree scale
+ * tree_scale[b] (minimizer_lpr_leaves, src/fixed_lik.hpp:460-467; lpr_leaves_omega, src/omega.hpp:151-202).
+ * model 0 = coding ECM, 1 = non-coding ECM, 2 = the kappa/omega F3x4 model with
+ * q_settings[n_blocks][12] = kappa, omega, sigma and the nine ratios (src/run.hpp:75-79, else NULL).
+ * out_failed[b] (may be NULL) = 1 where a branch matrix fails the reference's validation. */
+int pcsf_block_loglik(pcsf_ctx *ctx, int model, const double *q_settings, const double *tree_scale,
+                      const uint8_t *codons, const uint64_t *site_offsets, size_t n_blocks, size_t leaf_stride,
+                      double *out_lpr, int32_t *out_failed);
+
 /* ---- diagnostics ---------------------------------------------------------------------------*/
 /* milliseconds spent in the pruning kernel by the last *_fixed / *_fixed_dev call that was
  * timed; pcsf_set_timing(ctx,1) brackets each launch with HIP events ON THE LAUNCH STREAM. */
@@ -113,6 +123,11 @@ int pcsf_get_branch_matrices(pcsf_ctx *ctx, double *out);
 int pcsf_build_schedule(int32_t n_nodes, const int16_t *child1, const int16_t *child2, uint32_t *program,
                         int32_t program_cap, int32_t *slot_node, int32_t *n_ops, int32_t *n_slots,
                         int32_t *stack_depth);
+/* host-only: runs the lock-step optimiser (fit_find_init + Brent, src/fixed_lik.hpp:469-544) on a
+ * caller-supplied objective (to be MAXIMISED), mt19937 seeded with `seed` and advanced by
+ * `skip_draws` 32-bit draws; returns the evaluation points in order and the value of the LAST one. */
+int pcsf_debug_maxlik(double (*objective)(double x, void *user), void *user, double init, double lo, double hi,
+                      uint32_t seed, int skip_draws, double *xs_out, int cap, int *n_evals, double *last_lpr);
 const char *pcsf_version(void);
 
 #ifdef __cplusplus

@@ -718,6 +718,35 @@ static void max_lik(objective *o, double init, double lo, double hi, po_mt19937 
     if (elpr_anc) *elpr_anc = o->elpr_anc;
 }
 
+/* test hook: max_lik on a caller-supplied objective (to be maximised); records evaluation points */
+typedef struct { double (*fn)(double, void *); void *user; double *xs; int cap, n; } dbg_ctx;
+static dbg_ctx *g_dbg;
+static double obj_debug(double x, objective *o)
+{
+    o->x = x;
+    if (g_dbg->xs && g_dbg->n < g_dbg->cap) g_dbg->xs[g_dbg->n] = x;
+    g_dbg->n++;
+    o->lpr = g_dbg->fn(x, g_dbg->user);
+    return -o->lpr;
+}
+int po_debug_max_lik(double (*fn)(double, void *), void *user, double init, double lo, double hi, uint32_t seed,
+                     int skip_draws, double *xs_out, int cap, int *n_evals, double *last_lpr)
+{
+    po_mt19937 gen;
+    po_mt_seed(&gen, seed);
+    for (int i = 0; i < skip_draws; ++i) (void)po_mt_next(&gen);
+    dbg_ctx d = {fn, user, xs_out, cap, 0};
+    g_dbg = &d;
+    objective o;
+    memset(&o, 0, sizeof o);
+    o.f = obj_debug;
+    double lpr = 0;
+    max_lik(&o, init, lo, hi, &gen, &lpr, NULL);
+    *n_evals = d.n;
+    *last_lpr = lpr;
+    return 0;
+}
+
 /* minimizer_lpr_leaves, src/fixed_lik.hpp:460-467 */
 static double obj_tree_scale(double x, objective *o)
 {
@@ -777,6 +806,7 @@ static double obj_rho(double x, objective *o)
         return NAN;
     }
     o->lpr += po_lpr_rho(x);
+    if (getenv("PO_TRACE")) fprintf(stderr, "TRACE omega rho x %.17g lpr %.17g\n", x, o->lpr);
     return -o->lpr;
 }
 
@@ -791,6 +821,7 @@ static double obj_kappa(double x, objective *o)
         return NAN;
     }
     o->lpr += po_lpr_kappa(x);
+    if (getenv("PO_TRACE")) fprintf(stderr, "TRACE omega kappa x %.17g lpr %.17g\n", x, o->lpr);
     return -o->lpr;
 }
 

@@ -110,6 +110,9 @@ int po_run_blocks(const po_model *m, int algo, const uint8_t *codons, const uint
 long po_last_eval_count(void);
 
 /* --- small pieces exposed for unit tests --- */
+/* max_lik_lpr_leaves (fit_find_init + GSL Brent) on a caller-supplied objective to be maximised */
+int po_debug_max_lik(double (*fn)(double, void *), void *user, double init, double lo, double hi, uint32_t seed,
+                     int skip_draws, double *xs_out, int cap, int *n_evals, double *last_lpr);
 typedef struct { uint32_t mt[624]; int idx; } po_mt19937;
 void po_mt_seed(po_mt19937 *g, uint32_t seed);
 uint32_t po_mt_next(po_mt19937 *g);

@@ -65,6 +65,8 @@ def load_library():
     lib.pcsf_score_sites_fixed_dev.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, vp, vp]
     lib.pcsf_score_blocks.argtypes = [vp, C.c_int, u8p, C.POINTER(C.c_uint64), C.c_size_t, C.c_size_t, C.c_int,
                                       C.c_uint32, fp, fp]
+    lib.pcsf_block_loglik.argtypes = [vp, C.c_int, dp, dp, u8p, C.POINTER(C.c_uint64), C.c_size_t, C.c_size_t, dp,
+                                      C.POINTER(C.c_int32)]
     lib.pcsf_set_timing.argtypes = [vp, C.c_int]
     lib.pcsf_last_kernel_ms.restype = C.c_double
     lib.pcsf_last_kernel_ms.argtypes = [vp]
@@ -195,6 +197,25 @@ class ScoringContext:
                                                 int(compute_anc), seed, phylo.ctypes.data_as(C.POINTER(C.c_float)),
                                                 anc.ctypes.data_as(C.POINTER(C.c_float))))
         return phylo, anc
+
+    def block_loglik(self, model, codons, site_offsets, tree_scale, q_settings=None):
+        """One objective evaluation per block (no prior term): model 0/1 = coding/non-coding ECM,
+        2 = kappa/omega model with q_settings [n_blocks, 12].  Returns (lpr float64[n_blocks], failed)."""
+        codons = np.ascontiguousarray(codons, dtype=np.uint8)
+        off = np.ascontiguousarray(site_offsets, dtype=np.uint64)
+        nb = len(off) - 1
+        ts = np.ascontiguousarray(np.broadcast_to(np.asarray(tree_scale, dtype=np.float64), (nb,)))
+        qs = None
+        if q_settings is not None:
+            qs = np.ascontiguousarray(np.broadcast_to(np.asarray(q_settings, dtype=np.float64), (nb, 12)))
+        out = np.empty(nb, dtype=np.float64)
+        failed = np.zeros(nb, dtype=np.int32)
+        self._check(self._lib.pcsf_block_loglik(
+            self._h, int(model), qs.ctypes.data_as(C.POINTER(C.c_double)) if qs is not None else None,
+            ts.ctypes.data_as(C.POINTER(C.c_double)), codons.ctypes.data_as(C.POINTER(C.c_uint8)),
+            off.ctypes.data_as(C.POINTER(C.c_uint64)), nb, codons.strides[0], out.ctypes.data_as(C.POINTER(C.c_double)),
+            failed.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out, failed
 
     # ---- diagnostics -----------------------------------------------------------------------
     def set_timing(self, enable=True):

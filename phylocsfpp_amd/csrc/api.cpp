@@ -12,73 +12,14 @@
 #include <string>
 #include <vector>
 
-#include "../../include/phylocsf_amd.h"
-#include "hostmath.hpp"
-#include "kernels.h"
-#include "schedule.hpp"
+#include "ctx.hpp"
+#include "optimizer.hpp"
 
 namespace {
-
 thread_local std::string g_create_error;
-
-struct DeviceBuffer {
-    void* ptr = nullptr;
-    size_t bytes = 0;
-    ~DeviceBuffer() { release(); }
-    void release()
-    {
-        if (ptr) (void)hipFree(ptr);
-        ptr = nullptr;
-        bytes = 0;
-    }
-    hipError_t reserve(size_t n)
-    {
-        if (n <= bytes) return hipSuccess;
-        release();
-        hipError_t e = hipMalloc(&ptr, n);
-        if (e == hipSuccess) bytes = n;
-        return e;
-    }
-    template <class T> T* as() const { return static_cast<T*>(ptr); }
-};
-
 }  // namespace
 
-struct pcsf_ctx {
-    int device = 0;
-    std::string error;
-    pcsf::Schedule schedule;
-    int n_nodes = 0, n_leaves = 0;
-    std::vector<int16_t> child1, child2;
-    std::vector<float> branch_len;
-    pcsf::Mat S[2];
-    pcsf::Vec pi[2];
-    pcsf::EigenSystem eig[2];            // coding, non-coding ECM (tree scale independent)
-    std::vector<double> host_P;          // [2][n-1][64*64] at tree scale 1
-    // device-resident model
-    DeviceBuffer d_program, d_frag, d_leaf_tab, d_prior;
-    // scratch for the host-pointer entry points
-    DeviceBuffer d_codons, d_out, d_lnz, d_stamps;
-    uint32_t stamp_block = 0;
-    hipStream_t stream = nullptr;        // private stream for host-pointer entry points
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timing = false;
-    double last_kernel_ms = 0.0;
-    int variant = 0;
-    // tuning knobs (speed only; environment overrides are for experiments)
-    size_t extra_lds = 0;
-
-    int fail(int code, const std::string& msg)
-    {
-        error = msg;
-        return code;
-    }
-    int hip_fail(hipError_t e, const char* what)
-    {
-        error = std::string(what) + ": " + hipGetErrorString(e);
-        return PCSF_ERR_HIP;
-    }
-};
+using pcsf::DeviceBuffer;
 
 namespace {
 
@@ -89,7 +30,7 @@ int upload_model_tables(pcsf_ctx* c, const double* P, const pcsf::Vec prior[2])
     const int ne = static_cast<int>(c->schedule.slot_node.size());
     std::vector<double> frag(static_cast<size_t>(2) * ne * pcsf::FRAG_DOUBLES);
     std::vector<double> leaf(static_cast<size_t>(2) * nl * pcsf::LEAF_TABLE_DOUBLES);
-    std::vector<double> pr(2 * 64);
+    std::vector<double> pr(2 * 64), aw(2 * 64);
     for (int m = 0; m < 2; ++m) {
         const double* Pm = P + static_cast<size_t>(m) * (n - 1) * 4096;
         for (int s = 0; s < ne; ++s)
@@ -99,11 +40,17 @@ int upload_model_tables(pcsf_ctx* c, const double* P, const pcsf::Vec prior[2])
             pcsf::to_leaf_table(Pm + static_cast<size_t>(l) * 4096,
                                 leaf.data() + (static_cast<size_t>(m) * nl + l) * pcsf::LEAF_TABLE_DOUBLES);
         pcsf::to_lane_order(prior[m].data(), pr.data() + m * 64);
+        pcsf::Vec w;
+        for (int x = 0; x < 64; ++x) w[x] = std::log(prior[m][x]) * prior[m][x];
+        pcsf::to_lane_order(w.data(), aw.data() + m * 64);
     }
     hipError_t e;
     if ((e = c->d_frag.reserve(std::max<size_t>(frag.size(), 1) * sizeof(double))) != hipSuccess) return c->hip_fail(e, "hipMalloc(frag)");
     if ((e = c->d_leaf_tab.reserve(leaf.size() * sizeof(double))) != hipSuccess) return c->hip_fail(e, "hipMalloc(leaf_tab)");
     if ((e = c->d_prior.reserve(pr.size() * sizeof(double))) != hipSuccess) return c->hip_fail(e, "hipMalloc(prior)");
+    if ((e = c->d_anc_weight.reserve(aw.size() * sizeof(double))) != hipSuccess) return c->hip_fail(e, "hipMalloc(anc_weight)");
+    if ((e = hipMemcpy(c->d_anc_weight.ptr, aw.data(), aw.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess)
+        return c->hip_fail(e, "hipMemcpy(anc_weight)");
     if (!frag.empty() && (e = hipMemcpy(c->d_frag.ptr, frag.data(), frag.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess)
         return c->hip_fail(e, "hipMemcpy(frag)");
     if ((e = hipMemcpy(c->d_leaf_tab.ptr, leaf.data(), leaf.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess)
@@ -113,27 +60,40 @@ int upload_model_tables(pcsf_ctx* c, const double* P, const pcsf::Vec prior[2])
     return PCSF_OK;
 }
 
-int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t leaf_stride, double* d_out, double* d_lnz,
-                 hipStream_t stream)
+}  // namespace
+
+namespace pcsf {
+
+PruneParams base_prune_params(const pcsf_ctx* c)
 {
-    pcsf::PruneParams p{};
-    p.codons = d_codons;
-    p.n_sites = n_sites;
-    p.leaf_stride = leaf_stride;
+    PruneParams p{};
     p.program = c->d_program.as<uint32_t>();
     p.n_ops = static_cast<int>(c->schedule.program.size());
     p.n_edges = static_cast<int>(c->schedule.slot_node.size());
     p.n_leaves = c->n_leaves;
+    p.n_passes = 2;
     p.frag = c->d_frag.as<double>();
     p.leaf_tab = c->d_leaf_tab.as<double>();
     p.prior = c->d_prior.as<double>();
-    p.out_score = d_out;
-    p.out_lnz = d_lnz;
+    p.anc_weight = c->d_anc_weight.as<double>();
     p.stamps = c->d_stamps.as<unsigned long long>();
     p.stamp_block = c->stamp_block;
+    return p;
+}
+
+int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t leaf_stride, double* d_out, double* d_lnz,
+                 double* d_anc, hipStream_t stream)
+{
+    PruneParams p = base_prune_params(c);
+    p.codons = d_codons;
+    p.n_sites = n_sites;
+    p.leaf_stride = leaf_stride;
+    p.out_score = d_out;
+    p.out_lnz = d_lnz;
+    p.out_anc = d_anc;
     hipError_t e;
     if (c->timing && (e = hipEventRecord(c->ev0, stream)) != hipSuccess) return c->hip_fail(e, "hipEventRecord");
-    if ((e = pcsf::launch_prune_fixed(p, c->variant, stream, c->extra_lds)) != hipSuccess) return c->hip_fail(e, "launch prune_fixed");
+    if ((e = launch_prune_fixed(p, c->variant, stream, c->extra_lds)) != hipSuccess) return c->hip_fail(e, "launch prune_fixed");
     if (c->timing) {
         if ((e = hipEventRecord(c->ev1, stream)) != hipSuccess) return c->hip_fail(e, "hipEventRecord");
         if ((e = hipEventSynchronize(c->ev1)) != hipSuccess) return c->hip_fail(e, "hipEventSynchronize");
@@ -144,11 +104,34 @@ int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t le
     return PCSF_OK;
 }
 
-}  // namespace
+}  // namespace pcsf
 
 extern "C" {
 
 const char* pcsf_version(void) { return "phylocsf-amd 0.1.0 (gfx950)"; }
+
+// host-only helper: drives the lock-step optimiser's state machine (optimizer.hpp) with a caller-supplied
+// objective; records the evaluation points.  Lets the tests check that it takes exactly the decisions
+// of the reference's fit_find_init + GSL Brent without a GPU in the loop.
+int pcsf_debug_maxlik(double (*objective)(double x, void* user), void* user, double init, double lo, double hi, uint32_t seed,
+                      int skip_draws, double* xs_out, int cap, int* n_evals, double* last_lpr)
+{
+    if (!objective || !n_evals || !last_lpr) return PCSF_ERR_INVALID_ARG;
+    std::mt19937 gen(seed);
+    for (int i = 0; i < skip_draws; ++i) (void)gen();
+    pcsf::MaxLik1D opt;
+    opt.start(init, lo, hi, &gen);
+    int n = 0;
+    while (!opt.done()) {
+        const double x = opt.request();
+        if (xs_out && n < cap) xs_out[n] = x;
+        ++n;
+        opt.supply(objective(x, user), 0.0);
+    }
+    *n_evals = n;
+    *last_lpr = opt.last_lpr();
+    return PCSF_OK;
+}
 
 // host-only helper (no device needed): the pruning program for a tree, for tests and tooling
 int pcsf_build_schedule(int32_t n_nodes, const int16_t* child1, const int16_t* child2, uint32_t* program, int32_t program_cap,
@@ -247,6 +230,8 @@ int pcsf_create(pcsf_ctx** out, const pcsf_model_desc* m, int device_id)
         g_create_error = std::string("stream/event creation: ") + hipGetErrorString(e);
         return PCSF_ERR_HIP;
     }
+    c->branch_slot.assign(n, -1);
+    for (size_t sl = 0; sl < c->schedule.slot_node.size(); ++sl) c->branch_slot[c->schedule.slot_node[sl]] = static_cast<int>(sl);
     const auto& prog = c->schedule.program;
     if ((e = c->d_program.reserve(prog.size() * sizeof(uint32_t))) != hipSuccess ||
         (e = hipMemcpy(c->d_program.ptr, prog.data(), prog.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) {
@@ -271,9 +256,6 @@ void pcsf_destroy(pcsf_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -324,7 +306,7 @@ int pcsf_score_sites_fixed_dev(pcsf_ctx* c, const uint8_t* d_codons, size_t n_si
     if (!d_codons || (!d_out && !d_lnz) || leaf_stride < n_sites) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_sites_fixed_dev: bad argument");
     hipError_t e;
     if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
-    return launch_fixed(c, d_codons, n_sites, leaf_stride, d_out, d_lnz, static_cast<hipStream_t>(hip_stream));
+    return pcsf::launch_fixed(c, d_codons, n_sites, leaf_stride, d_out, d_lnz, nullptr, static_cast<hipStream_t>(hip_stream));
 }
 
 int pcsf_score_sites_fixed(pcsf_ctx* c, const uint8_t* codons, size_t n_sites, size_t leaf_stride, double* out)
@@ -340,7 +322,7 @@ int pcsf_score_sites_fixed(pcsf_ctx* c, const uint8_t* codons, size_t n_sites, s
     // compact the leaf-major matrix while copying (device stride = n_sites)
     if ((e = hipMemcpy2DAsync(c->d_codons.ptr, n_sites, codons, leaf_stride, n_sites, nl, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
         return c->hip_fail(e, "hipMemcpy2DAsync(codons)");
-    int rc = launch_fixed(c, c->d_codons.as<uint8_t>(), n_sites, n_sites, c->d_out.as<double>(), nullptr, c->stream);
+    int rc = pcsf::launch_fixed(c, c->d_codons.as<uint8_t>(), n_sites, n_sites, c->d_out.as<double>(), nullptr, nullptr, c->stream);
     if (rc != PCSF_OK) return rc;
     if ((e = hipMemcpyAsync(out, c->d_out.ptr, n_sites * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
         return c->hip_fail(e, "hipMemcpyAsync(out)");
@@ -352,9 +334,42 @@ int pcsf_score_blocks(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
                       size_t leaf_stride, int compute_anc, uint32_t seed, float* out_phylo, float* out_anc)
 {
     if (!c) return PCSF_ERR_INVALID_ARG;
-    (void)codons; (void)site_offsets; (void)n_blocks; (void)leaf_stride; (void)compute_anc; (void)seed; (void)out_phylo; (void)out_anc;
-    (void)algo;
-    return c->fail(PCSF_ERR_UNSUPPORTED, "pcsf_score_blocks: not implemented yet");
+    if (n_blocks == 0) return PCSF_OK;
+    if (!site_offsets || !out_phylo || (algo != PCSF_MLE && algo != PCSF_FIXED && algo != PCSF_OMEGA))
+        return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_blocks: bad argument");
+    for (size_t b = 0; b < n_blocks; ++b)
+        if (site_offsets[b + 1] < site_offsets[b]) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_blocks: site_offsets must be non-decreasing");
+    const size_t n_sites = site_offsets[n_blocks] - site_offsets[0];
+    if (n_sites > 0 && (!codons || leaf_stride < site_offsets[n_blocks])) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_blocks: bad codon matrix");
+    hipError_t e;
+    if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
+    try {
+        return pcsf::score_blocks_impl(c, algo, codons, site_offsets, n_blocks, leaf_stride, compute_anc, seed, out_phylo, out_anc);
+    } catch (const std::exception& ex) {
+        return c->fail(PCSF_ERR_HIP, std::string("pcsf_score_blocks: ") + ex.what());
+    }
+}
+
+// log-likelihood of every block at caller-chosen parameters: ONE objective evaluation of the MLE / OMEGA
+// strategies without the prior term (minimizer_lpr_leaves, src/fixed_lik.hpp:460-467; lpr_leaves_omega,
+// src/omega.hpp:151-202).  model: 0 coding ECM, 1 non-coding ECM, 2 kappa/omega F3x4 model with
+// q_settings[n_blocks][12] = kappa, omega, sigma, nine nucleotide-frequency ratios (src/run.hpp:75-79).
+int pcsf_block_loglik(pcsf_ctx* c, int model, const double* q_settings, const double* tree_scale, const uint8_t* codons,
+                      const uint64_t* site_offsets, size_t n_blocks, size_t leaf_stride, double* out_lpr, int32_t* out_failed)
+{
+    if (!c) return PCSF_ERR_INVALID_ARG;
+    if (n_blocks == 0) return PCSF_OK;
+    if (model < 0 || model > 2 || !tree_scale || !site_offsets || !out_lpr || (model == 2 && !q_settings))
+        return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_block_loglik: bad argument");
+    for (size_t b = 0; b < n_blocks; ++b)
+        if (site_offsets[b + 1] < site_offsets[b] || !(tree_scale[b] >= 0.0)) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_block_loglik: bad block");
+    hipError_t e;
+    if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
+    try {
+        return pcsf::block_loglik_impl(c, model, q_settings, tree_scale, codons, site_offsets, n_blocks, leaf_stride, out_lpr, out_failed);
+    } catch (const std::exception& ex) {
+        return c->fail(PCSF_ERR_HIP, std::string("pcsf_block_loglik: ") + ex.what());
+    }
 }
 
 }  // extern "C"

@@ -1,0 +1,98 @@
+// ctx.hpp -- the context object behind the C-ABI handle (shared by api.cpp and blocks.cpp)
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/phylocsf_amd.h"
+#include "hostmath.hpp"
+#include "kernels.h"
+#include "schedule.hpp"
+
+namespace pcsf {
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    ~DeviceBuffer() { release(); }
+    void release()
+    {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+    hipError_t reserve(size_t n)
+    {
+        if (n <= bytes) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc(&ptr, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    template <class T> T* as() const { return static_cast<T*>(ptr); }
+};
+
+}  // namespace pcsf
+
+struct pcsf_ctx {
+    int device = 0;
+    std::string error;
+    pcsf::Schedule schedule;
+    int n_nodes = 0, n_leaves = 0;
+    std::vector<int16_t> child1, child2;
+    std::vector<float> branch_len;
+    std::vector<int> branch_slot;        // branch (node id) -> fragment slot of the schedule, -1 for leaves
+    pcsf::Mat S[2];
+    pcsf::Vec pi[2];
+    pcsf::EigenSystem eig[2];            // coding, non-coding ECM (tree scale independent)
+    std::vector<double> host_P;          // [2][n-1][64*64] at tree scale 1
+    // device-resident model (table sets 0 = coding, 1 = non-coding at tree scale 1)
+    pcsf::DeviceBuffer d_program, d_frag, d_leaf_tab, d_prior, d_anc_weight;
+    // scratch for the host-pointer entry points
+    pcsf::DeviceBuffer d_codons, d_out, d_lnz, d_anc, d_stamps;
+    uint32_t stamp_block = 0;
+    hipStream_t stream = nullptr;        // private stream for host-pointer entry points
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing = false;
+    double last_kernel_ms = 0.0;
+    int variant = 0;
+    size_t extra_lds = 0;                // experiment knob (PCSF_EXTRA_LDS): lowers occupancy
+
+    ~pcsf_ctx()
+    {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    int fail(int code, const std::string& msg)
+    {
+        error = msg;
+        return code;
+    }
+    int hip_fail(hipError_t e, const char* what)
+    {
+        error = std::string(what) + ": " + hipGetErrorString(e);
+        return PCSF_ERR_HIP;
+    }
+};
+
+namespace pcsf {
+// fills the kernel parameters that describe the resident model (tables of sets 0 and 1)
+PruneParams base_prune_params(const pcsf_ctx* c);
+// launches the tracks-mode kernel over `n_sites` device-resident sites (both models)
+int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t leaf_stride, double* d_out, double* d_lnz,
+                 double* d_anc, hipStream_t stream);
+// run() for a batch of blocks (blocks.cpp)
+int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64_t* site_offsets, size_t n_blocks,
+                      size_t leaf_stride, int compute_anc, uint32_t seed, float* out_phylo, float* out_anc);
+int block_loglik_impl(pcsf_ctx* c, int model, const double* q_settings, const double* tree_scale, const uint8_t* codons,
+                      const uint64_t* site_offsets, size_t n_blocks, size_t leaf_stride, double* out_lpr, int32_t* out_failed);
+int block_loglik_impl(pcsf_ctx* c, int model, const double* q_settings, const double* tree_scale, const uint8_t* codons,
+                      const uint64_t* site_offsets, size_t n_blocks, size_t leaf_stride, double* out_lpr, int32_t* out_failed);
+}  // namespace pcsf

@@ -22,18 +22,56 @@ struct PruneParams {
     int n_ops;
     int n_edges;             // MATMUL ops per model (= internal non-root nodes)
     int n_leaves;
-    const double* frag;      // [2][n_edges][4096]  branch matrices of internal children, fragment order
-    const double* leaf_tab;  // [2][n_leaves][65][4][16] leaf-message tables
-    const double* prior;     // [2][4][16] equilibrium prior in lane order
+    int n_passes;            // table sets walked per site: 2 = coding then non-coding (tracks / FIXED), 1 = one model
+    const double* frag;      // [table][n_edges][4096]  branch matrices of internal children, fragment order
+    const double* leaf_tab;  // [table][n_leaves][65][4][16] leaf-message tables
+    const double* prior;     // [table][4][16] equilibrium prior in lane order
+    const double* anc_weight;// [table][4][16] ln(prior)*prior in lane order (only read if out_anc)
+    // block mode (variant 16): work-group w scores sites [wg_site0[w], wg_site_end[w]) (at most 64)
+    // with table sets wg_table[w] .. wg_table[w]+n_passes-1
+    const uint64_t* wg_site0;
+    const uint64_t* wg_site_end;
+    const uint32_t* wg_table;
+    size_t n_wgs;
     unsigned long long* stamps;  // diagnostic variant only: [2][n_ops][4] s_memtime values, else null
     uint32_t stamp_block;
     double* out_score;       // [n_sites] or null
-    double* out_lnz;         // [2][n_sites] or null
+    double* out_lnz;         // [n_passes][n_sites] or null
+    double* out_anc;         // [n_passes][n_sites] or null: ancestral-composition term per site
 };
 
 // variant: 0 = 4 waves (64 sites) per work-group, 1 = 8 waves (128 sites) per work-group,
-// 2 = variant 0 with in-kernel stamps (diagnostic only)
+// 2 = variant 0 with in-kernel stamps (diagnostic only), 16 = block mode (per-work-group windows and tables)
 hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t stream, size_t extra_lds = 0);
 int prune_variant_count();
+
+}  // namespace pcsf
+
+namespace pcsf {
+
+// ---- batched P(t) = S * diag(exp(lambda t)) * S^-1 with the reference's post-processing -------
+// (src/instance.hpp:529-549, 602-640).  One job = one branch matrix of one table set.
+struct ExpmJob {
+    uint32_t eig;      // eigen-system index: S at eig_right + eig*4096, S^-1 at eig_left + eig*4096, lambda at eig_lambda + eig*64
+    uint32_t table;    // destination table set
+    int32_t slot;      // >= 0: internal child -> fragment image `slot` of the table set
+    int32_t leaf;      // >= 0: leaf -> leaf-message table `leaf` of the table set
+    double t;          // branch length at the current tree scale
+};
+
+struct ExpmParams {
+    const ExpmJob* jobs;
+    uint32_t n_jobs;
+    int n_edges, n_leaves;
+    const double* eig_right;   // [n_eig][64*64] row-major, right eigenvectors in columns
+    const double* eig_left;    // [n_eig][64*64] row-major, left eigenvectors in rows
+    const double* eig_lambda;  // [n_eig][64]
+    double* frag;              // [table][n_edges][4096]
+    double* leaf_tab;          // [table][n_leaves][65*64]
+    uint32_t* fail;            // [table]: set to 1 when a matrix fails validation
+    double* raw_out;           // optional [n_jobs][4096]: validated P, row-major (diagnostics/tests)
+};
+
+hipError_t launch_expm(const ExpmParams& p, hipStream_t stream);
 
 }  // namespace pcsf

@@ -108,7 +108,10 @@ __device__ __forceinline__ unsigned long long stamp_now()
     return t;
 }
 
-template <int NW, bool STAMP>
+// BLOCKS: per-work-group site window and table set (whole-block scoring with per-block branch
+// matrices, MLE / OMEGA); otherwise work-group b owns sites [b*SITES, (b+1)*SITES) and passes
+// 0..n_passes-1 use table sets 0..n_passes-1 (coding, non-coding).
+template <int NW, bool STAMP, bool BLOCKS>
 __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -120,16 +123,18 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int sl = lane & 15, g4 = lane >> 4;
-    const size_t block_site0 = static_cast<size_t>(blockIdx.x) * SITES;
+    const size_t block_site0 = BLOCKS ? p.wg_site0[blockIdx.x] : static_cast<size_t>(blockIdx.x) * SITES;
+    const size_t site_end = BLOCKS ? p.wg_site_end[blockIdx.x] : p.n_sites;
+    const int table0 = BLOCKS ? static_cast<int>(p.wg_table[blockIdx.x]) : 0;
     const size_t my_site = block_site0 + wave * 16 + sl;
-    const bool valid = my_site < p.n_sites;
+    const bool valid = my_site < site_end;
 
     // ---- stage this work-group's codon columns into LDS (clamped to 0..64; 64 beyond the end)
     for (int idx = tid; idx < p.n_leaves * SITES; idx += NW * 64) {
         const int leaf = idx / SITES, s = idx - leaf * SITES;
         const size_t site = block_site0 + s;
         unsigned c = 64u;
-        if (site < p.n_sites) {
+        if (site < site_end) {
             c = p.codons[static_cast<size_t>(leaf) * p.leaf_stride + site];
             c = c > 64u ? 64u : c;
         }
@@ -141,10 +146,11 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
 
     // ---- fragment staging: 32 KiB per slot, moved by LDS-DMA in 1 KiB wave-instructions
     constexpr int CHUNKS_PER_WAVE = 32 / NW;
-    const int total_slots = 2 * p.n_edges;  // coding slots, then non-coding slots
+    const int total_slots = p.n_passes * p.n_edges;  // pass 0 slots, then pass 1 slots (consecutive table sets)
     // each wave moves CHUNKS_PER_WAVE consecutive 1 KiB pieces; the instruction's immediate offset
     // advances the global and the LDS address together, so one address register serves 4 pieces
-    const unsigned char* src_lane = reinterpret_cast<const unsigned char*>(p.frag) + wave * (CHUNKS_PER_WAVE * 1024) + lane * 16;
+    const unsigned char* src_lane = reinterpret_cast<const unsigned char*>(p.frag) +
+                                    static_cast<size_t>(table0) * p.n_edges * (FRAG_DOUBLES_DEV * 8) + wave * (CHUNKS_PER_WAVE * 1024) + lane * 16;
     // stage_piece<J>(slot): J-th of this wave's CHUNKS_PER_WAVE pieces of `slot`
     auto stage_piece = [&](auto jc, int slot, int buffer) {
         constexpr int J = decltype(jc)::value;
@@ -167,13 +173,13 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     };
     int slot = 0;
     if (total_slots > 0) stage_slot(0);
-    double lnz0 = 0.0, lnz1 = 0.0;
+    double lnz0 = 0.0, lnz1 = 0.0, anc0 = 0.0, anc1 = 0.0;
     const bool stamping = STAMP && p.stamps != nullptr && blockIdx.x == p.stamp_block && wave == 0;
     (void)stamping;
 
-    for (int model = 0; model < 2; ++model) {
-        const double* __restrict__ leaf_tab = p.leaf_tab + static_cast<size_t>(model) * p.n_leaves * LEAF_TABLE_DOUBLES_DEV;
-        const double* __restrict__ prior = p.prior + model * 64 + g4 * 16;
+    for (int model = 0; model < p.n_passes; ++model) {
+        const double* __restrict__ leaf_tab = p.leaf_tab + static_cast<size_t>(table0 + model) * p.n_leaves * LEAF_TABLE_DOUBLES_DEV;
+        const double* __restrict__ prior = p.prior + static_cast<size_t>(table0 + model) * 64 + g4 * 16;
 
         double cur[16], nxt[16];
         double4_t acc[4];
@@ -296,6 +302,17 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
                     const double lz = log(z);
                     if (model == 0) lnz0 = lz;
                     else lnz1 = lz;
+                    if (p.out_anc) {  // sum_x ln(prior_x) * prior_x * alpha_root[x] / z  (root posterior term)
+                        const double* __restrict__ w = p.anc_weight + static_cast<size_t>(table0 + model) * 64 + g4 * 16;
+                        double t = 0.0;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) t += w[q] * cur[q];
+                        t += __shfl_xor(t, 16);
+                        t += __shfl_xor(t, 32);
+                        t = (z == 0.0) ? 0.0 : t / z;
+                        if (model == 0) anc0 = t;
+                        else anc1 = t;
+                    }
                     break;
                 }
             }
@@ -311,37 +328,42 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
         if (p.out_score) p.out_score[my_site] = 10.0 * (lnz0 - lnz1) / log(10.0);
         if (p.out_lnz) {
             p.out_lnz[my_site] = lnz0;
-            p.out_lnz[p.n_sites + my_site] = lnz1;
+            if (p.n_passes > 1) p.out_lnz[p.n_sites + my_site] = lnz1;
+        }
+        if (p.out_anc) {
+            p.out_anc[my_site] = anc0;
+            if (p.n_passes > 1) p.out_anc[p.n_sites + my_site] = anc1;
         }
     }
 }
 
-template <int NW, bool STAMP>
+template <int NW, bool STAMP, bool BLOCKS>
 static hipError_t launch_impl(const PruneParams& p, hipStream_t stream, size_t extra_lds)
 {
     const size_t sites_per_block = static_cast<size_t>(NW) * 16;
-    const size_t blocks = (p.n_sites + sites_per_block - 1) / sites_per_block;
+    const size_t blocks = BLOCKS ? p.n_wgs : (p.n_sites + sites_per_block - 1) / sites_per_block;
     if (blocks == 0) return hipSuccess;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     const size_t lds = 2 * FRAG_DOUBLES_DEV * sizeof(double) + ((static_cast<size_t>(p.n_ops) + 3) & ~size_t(3)) * 4 +
                        static_cast<size_t>(p.n_leaves) * sites_per_block + extra_lds;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_set = false;
+    static bool attr_set = false;  // one flag per template instantiation
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prune_fixed<NW, STAMP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prune_fixed<NW, STAMP, BLOCKS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((prune_fixed<NW, STAMP>), dim3(static_cast<unsigned>(blocks)), dim3(NW * 64), lds, stream, p);
+    hipLaunchKernelGGL((prune_fixed<NW, STAMP, BLOCKS>), dim3(static_cast<unsigned>(blocks)), dim3(NW * 64), lds, stream, p);
     return hipGetLastError();
 }
 
 hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t stream, size_t extra_lds)
 {
     switch (variant) {
-        case 0: return launch_impl<4, false>(p, stream, extra_lds);
-        case 1: return launch_impl<8, false>(p, stream, extra_lds);
-        case 2: return launch_impl<4, true>(p, stream, extra_lds);  // diagnostic: in-kernel stamps
+        case 0: return launch_impl<4, false, false>(p, stream, extra_lds);
+        case 1: return launch_impl<8, false, false>(p, stream, extra_lds);
+        case 2: return launch_impl<4, true, false>(p, stream, extra_lds);  // diagnostic: in-kernel stamps
+        case 16: return launch_impl<4, false, true>(p, stream, extra_lds); // per-work-group windows/tables
         default: return hipErrorInvalidValue;
     }
 }

@@ -1,0 +1,155 @@
+"""GPU parity of whole-block scoring (run, src/run.hpp:57-211) through the C-ABI: FIXED, MLE, OMEGA
+against the CPU oracle on the same blocks, and against the reference's golden .scores files."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import maf_blocks
+import oracle_binding as ob
+import phylocsfpp_amd as pa
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SMALL = os.path.join(GOLD, "score-msa", "chr22.50alignments.maf")
+ALIASES = os.path.join(GOLD, "models", "species_aliases.tsv")
+
+
+def _gold(name):
+    rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(GOLD, "score-msa", name))][1:]
+    return rows
+
+
+def _oracle_blocks(m, algo, cod, off, compute_anc=True):
+    nb = len(off) - 1
+    ph = np.full(nb, np.nan, np.float32)
+    an = np.full(nb, np.nan, np.float32)
+    lib = ob.lib()
+    lib.po_run_blocks.argtypes = [C.POINTER(ob.PoModel), C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.c_size_t,
+                                  C.c_size_t, C.c_int, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
+    lib.po_run_blocks(C.byref(m.m), algo, cod.ctypes.data_as(C.POINTER(C.c_uint8)), off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                      nb, cod.shape[1], int(compute_anc), 42, ph.ctypes.data_as(C.POINTER(C.c_float)),
+                      an.ctypes.data_as(C.POINTER(C.c_float)), 0)
+    return ph, an
+
+
+@pytest.fixture(scope="module")
+def small_blocks(oracle_models):
+    m = oracle_models("100vertebrates")
+    cod, off = maf_blocks.block_codons(SMALL, m.labels, ALIASES)
+    return m, cod, off
+
+
+def test_fixed_blocks_match_golden_and_oracle(small_blocks, gpu_contexts):
+    m, cod, off = small_blocks
+    ctx = gpu_contexts("100vertebrates")
+    ph, an = ctx.score_blocks(pa.FIXED, cod, off, compute_anc=True)
+    gold = _gold("chr22.50alignments.fixed.scores")
+    assert ["%.6f" % v for v in ph] == [g[4] for g in gold]         # the reference's test is an exact diff
+    assert ["%.6f" % v for v in an] == [g[5] for g in gold]
+    oph, oan = _oracle_blocks(m, ob.FIXED, cod, off)
+    np.testing.assert_allclose(ph, oph, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(an, oan, rtol=1e-6, atol=1e-6)
+
+
+def test_mle_blocks(small_blocks, gpu_contexts):
+    m, cod, off = small_blocks
+    ctx = gpu_contexts("100vertebrates")
+    ph, an = ctx.score_blocks(pa.MLE, cod, off, compute_anc=True)
+    gold = _gold("chr22.50alignments.mle.scores")
+    gp = np.array([float(g[4]) for g in gold])
+    ga = np.array([float(g[5]) for g in gold])
+    assert np.all((ph - gp) ** 2 <= 0.001) and np.all((an - ga) ** 2 <= 0.001)   # reference test/tests.sh:41
+    assert np.sum((np.abs(ph - gp) <= 5e-6) & (np.abs(an - ga) <= 5e-6)) >= 48
+    print("MLE rows equal to the golden at print precision:", int(np.sum((np.abs(ph - gp) <= 5e-6) & (np.abs(an - ga) <= 5e-6))))
+    # against the oracle (same optimiser, same evaluation order): 1e-6 relative.  Blocks 5 and 48 sit on a
+    # near-tie inside Brent (the oracle itself differs from the GSL golden there by 1.5e-4): a 1e-13
+    # difference in f re-routes them, so up to three rows may take the other branch.
+    oph, oan = _oracle_blocks(m, ob.MLE, cod, off)
+    close = np.isclose(ph, oph, rtol=1e-6, atol=2e-6) & np.isclose(an, oan, rtol=1e-6, atol=2e-6)
+    assert close.sum() >= 47, (ph - oph, an - oan)
+    assert np.all((ph - oph) ** 2 <= 0.001)
+
+
+def test_omega_blocks(small_blocks, gpu_contexts):
+    m, cod, off = small_blocks
+    ctx = gpu_contexts("100vertebrates")
+    ph, an = ctx.score_blocks(pa.OMEGA, cod, off, compute_anc=False)
+    assert np.all(np.isnan(an))
+    gold = _gold("chr22.50alignments.omega.scores")
+    n_cod = np.diff(off.astype(np.int64))
+    for i, g in enumerate(gold):
+        if n_cod[i] == 0:
+            assert np.isnan(ph[i]) and g[4] == "nan"
+        elif g[4] != "nan":
+            assert (ph[i] - float(g[4])) ** 2 <= 0.1                 # reference test/tests.sh:46
+        else:
+            assert np.isfinite(ph[i])                                 # GSL-degradation NaN rows: parity unpinned
+    sel = np.nonzero(n_cod > 0)[0][:16]
+    sub_off = np.concatenate([[0], np.cumsum(n_cod[sel])]).astype(np.uint64)
+    sub = np.concatenate([cod[:, int(off[i]):int(off[i + 1])] for i in sel], axis=1)
+    sub = np.ascontiguousarray(sub)
+    gph, _ = ctx.score_blocks(pa.OMEGA, sub, sub_off, compute_anc=False)
+    np.testing.assert_array_equal(gph, ph[sel])                       # batching must not change a block's result
+    # GPU vs oracle: same optimiser logic (tests/test_optimizer.py pins it bit for bit) and objective values
+    # equal to ~1e-12 (test_objective_values_match_oracle), but twelve chained 1-%-bracket Brent runs that
+    # each report their LAST probe amplify that to the reference's own reproducibility level (tests.sh:46)
+    oph, _ = _oracle_blocks(m, ob.OMEGA, sub, sub_off, compute_anc=False)
+    assert np.all((gph - oph) ** 2 <= 0.1)
+
+
+def _oracle_lpr(m, qd, cod, x):
+    lpr, anc = C.c_double(), C.c_double()
+    rc = ob.lib().po_lpr_leaves(C.byref(qd), C.byref(m.m.tree), x, cod.ctypes.data_as(C.POINTER(C.c_uint8)), cod.shape[1],
+                                cod.shape[1], 0, C.byref(lpr), C.byref(anc), None)
+    assert rc == 0
+    return lpr.value
+
+
+def test_objective_values_match_oracle(small_blocks, gpu_contexts):
+    """One objective evaluation (batched expm on the GPU + block-mode pruning) against the oracle at fixed
+    parameters: this is where the 1e-6 target of north_star is meaningful for MLE / OMEGA."""
+    m, cod, off = small_blocks
+    ctx = gpu_contexts("100vertebrates")
+    n_cod = np.diff(off.astype(np.int64))
+    sel = [i for i in np.argsort(-n_cod)[:6]] + [int(np.nonzero(n_cod == 1)[0][0])]
+    subs = [np.ascontiguousarray(cod[:, int(off[i]):int(off[i + 1])]) for i in sel]
+    sub = np.ascontiguousarray(np.concatenate(subs, axis=1))
+    sub_off = np.concatenate([[0], np.cumsum([s.shape[1] for s in subs])]).astype(np.uint64)
+    for model, coding in ((0, True), (1, False)):
+        qd = m.qdiag(coding)
+        for x in (0.01, 0.37, 1.0, 2.5, 10.0):
+            got, failed = ctx.block_loglik(model, sub, sub_off, x)
+            assert not failed.any()
+            want = np.array([_oracle_lpr(m, qd, s, x) for s in subs])
+            np.testing.assert_allclose(got, want, rtol=1e-9 if x >= 0.05 else 1e-6)
+    # kappa/omega model at several (kappa, omega, sigma, ratios, rho)
+    rng = np.random.default_rng(4)
+    for kappa, omega, sigma, rho in ((2.5, 1.0, 1.0, 1.0), (1.0, 0.2, 0.01, 0.3), (7.3, 0.2, 0.01, 5.9), (2.8, 1.0, 1.0, 0.02)):
+        qs = np.concatenate([[kappa, omega, sigma], rng.uniform(0.5, 1.5, 9)])
+        Q, pi = np.empty((64, 64)), np.empty(64)
+        dp = C.POINTER(C.c_double)
+        ob.lib().po_q_from_omega(qs.ctypes.data_as(dp), Q.ctypes.data_as(dp), pi.ctypes.data_as(dp))
+        qd = ob.PoQdiag()
+        ob.lib().po_eig(Q.ctypes.data_as(dp), pi.ctypes.data_as(dp), C.byref(qd))
+        got, failed = ctx.block_loglik(2, sub, sub_off, rho, q_settings=qs)
+        assert not failed.any()
+        want = np.array([_oracle_lpr(m, qd, s, rho) for s in subs])
+        np.testing.assert_allclose(got, want, rtol=1e-9 if rho >= 0.05 else 1e-6)
+
+
+def test_random_blocks_fixed_with_empty_and_ragged(oracle_models, gpu_contexts):
+    from phylocsfpp_amd import synth
+    m = oracle_models("58mammals")
+    ctx = gpu_contexts("58mammals")
+    cod = synth.synthetic_codon_columns(m.child1, m.child2, m.branch_len, m.S_c, m.pi_c, m.S_nc, m.pi_nc, 700, seed=21)
+    off = np.array([0, 0, 1, 17, 17, 81, 145, 146, 700], dtype=np.uint64)
+    ph, an = ctx.score_blocks(pa.FIXED, cod, off)
+    oph, oan = _oracle_blocks(m, ob.FIXED, cod, off)
+    np.testing.assert_allclose(ph, oph, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(an, oan, rtol=1e-6, atol=1e-6)
+    assert ph[0] == 0.0 and ph[3] == 0.0
+    with pytest.raises(pa.PcsfError):
+        ctx.score_blocks(pa.FIXED, cod, np.array([0, 5, 3], dtype=np.uint64))

@@ -49,3 +49,21 @@ def test_score_msa_fixed_golden_on_gpu(tmp_path, maf, gold):
     subprocess.check_call([_cli(), "score-msa", "--strategy", "fixed", "--comp-anc", "1",
                            os.path.join(GOLD, "models", "100vertebrates"), str(dst)])
     assert _scores(str(dst) + ".scores") == _scores(os.path.join(GOLD, "score-msa", gold))
+
+
+def test_score_msa_mle_and_omega_golden_on_gpu(tmp_path):
+    src = os.path.join(GOLD, "score-msa", "chr22.50alignments.maf")
+    for strategy, anc, tol in (("mle", "1", 0.001), ("omega", "0", 0.1)):
+        dst = tmp_path / ("small_%s.maf" % strategy)
+        shutil.copyfile(src, dst)
+        subprocess.check_call([_cli(), "score-msa", "--strategy", strategy, "--comp-anc", anc,
+                               os.path.join(GOLD, "models", "100vertebrates"), str(dst)])
+        got = _scores(str(dst) + ".scores")
+        want = _scores(os.path.join(GOLD, "score-msa", "chr22.50alignments.%s.scores" % strategy))
+        assert len(got) == len(want) == 50
+        for g, w in zip(got, want):
+            assert g[:4] == w[:4] and g[-1] == w[-1]                  # coordinates, strand, bls: exact
+            for gv, wv in zip(g[4:-1], w[4:-1]):
+                if wv == "nan":
+                    continue                                          # see test_gpu_blocks.test_omega_blocks
+                assert (float(gv) - float(wv)) ** 2 <= tol            # reference test/tests.sh:41,46
