@@ -59,6 +59,19 @@ def make_batch(m, n_sites, seed):
     return np.ascontiguousarray(pool[:, idx])
 
 
+def effective_cpus():
+    """CPUs this process may actually use: affinity mask capped by the cgroup quota (the GPU box
+    shows 256 hardware threads but its container is limited by cpu.max)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(m, codons, budget_sites):
     """Times the oracle's reference-structured run_tracks loop (model re-instantiated per
     alignment x frame, scalar pruning per codon, OpenMP schedule(dynamic,1) over alignments)."""
@@ -67,13 +80,14 @@ def cpu_baseline(m, codons, budget_sites):
     n_units = max(1, int(round(ALIGNMENT_FRAMES * n / SITES_PER_GPU)))
     off = np.linspace(0, n, n_units + 1).astype(np.uint64)
     sample = np.ascontiguousarray(codons[:, :n])
-    threads = os.cpu_count() or 1
+    threads = effective_cpus()
     t0 = time.perf_counter()
     m.baseline_run_tracks(sample, off, threads=threads)
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "codon-frames/s", "cores": threads, "kind": "port",
-            "sample": "%d codon-frames in %d alignment-frames of the same batch, %.1f s, OpenMP over alignments"
-                      % (n, n_units, dt)}
+            "sample": "%d codon-frames in %d alignment-frames of the same batch, %.1f s; reference-structured port "
+                      "(model re-instantiated per alignment-frame, scalar pruning), OpenMP schedule(dynamic,1) over "
+                      "alignment-frames on %d threads (cgroup CPU quota of this host)" % (n, n_units, dt, threads)}
 
 
 def main():
@@ -174,8 +188,8 @@ def main():
         if world == 1:
             budget = args.cpu_baseline_sites
             if budget < 0:
-                # ~2.7 k codon-frames/s/core + 0.1 s of model set-up per alignment-frame -> aim for 10-30 s
-                budget = int(min(n_sites, max(20_000, 600 * (os.cpu_count() or 1) * 15)))
+                # ~2.5 k codon-frames/s/core incl. the per-alignment model set-up -> aim for ~15 s
+                budget = int(min(n_sites, max(20_000, 2500 * effective_cpus() * 15)))
             if budget > 0:
                 out["cpu_baseline"] = cpu_baseline(m, codons_host, budget)
         print(json.dumps(out), flush=True)

@@ -1,0 +1,103 @@
+"""Multi-GPU sharding of the scoring path: one process per GPU (torch.distributed, backend "nccl" =
+RCCL over xGMI on MI355X; "gloo" on CPU for tests).
+
+Every alignment column is independent given the (replicated, ~7 MB) model, so the reference's
+OpenMP loop over byte-range jobs (src/phylocsf++build_tracks.hpp:88) becomes: rank r scores a
+CONTIGUOUS range of the site stream in file order, and the only exchange is one gather of the
+per-codon scores to rank 0, which owns the wig writers.  Concatenating the rank outputs restores
+file order without a sort.  Whole-block strategies (MLE / OMEGA) shard by contiguous block ranges
+balanced by site count; two floats per block come back.
+"""
+import numpy as np
+
+
+def shard_bounds(n_items, world, align=1):
+    """Contiguous, balanced [lo, hi) per rank; boundaries are multiples of `align` (64 = one
+    work-group of the pruning kernel) except the last."""
+    units = (n_items + align - 1) // align
+    base, extra = divmod(units, world)
+    bounds, lo = [], 0
+    for r in range(world):
+        hi = lo + (base + (1 if r < extra else 0)) * align
+        bounds.append((min(lo, n_items), min(hi, n_items)))
+        lo = hi
+    return bounds
+
+
+def shard_blocks(site_offsets, world):
+    """Contiguous block ranges [b_lo, b_hi) per rank with roughly equal site counts (each block also
+    costs a constant: its branch matrices are rebuilt at every optimiser step)."""
+    off = np.asarray(site_offsets, dtype=np.int64)
+    nb = len(off) - 1
+    cost = np.diff(off) + 16          # ~16 site-equivalents of expm work per block and step
+    cum = np.concatenate([[0], np.cumsum(cost)])
+    cuts = [0]
+    for r in range(1, world):
+        target = cum[-1] * r / world
+        cuts.append(int(np.searchsorted(cum, target, side="left")))
+    cuts.append(nb)
+    cuts = np.maximum.accumulate(np.clip(cuts, 0, nb))
+    return [(int(cuts[r]), int(cuts[r + 1])) for r in range(world)]
+
+
+def gather_to_root(local, counts, dst=0, group=None):
+    """Gathers ragged 1-D tensors to rank `dst` in rank order.  local: this rank's tensor (length
+    counts[rank]); counts: per-rank lengths known to every rank.  Returns the concatenation on
+    `dst`, None elsewhere.  One padded dist.gather: on xGMI every peer has its own link to the root."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    width = max(int(max(counts)), 1)
+    buf = torch.zeros(width, dtype=local.dtype, device=local.device)
+    buf[:local.numel()] = local
+    recv = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, recv, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([recv[r][:int(counts[r])] for r in range(world)])
+
+
+def score_sites_sharded(score_fn, codons, group=None, align=64, to_device=None):
+    """run_tracks over `codons` (uint8 [n_leaves, n_sites], the same array on every rank or at least
+    this rank's columns valid) sharded across the process group.
+    score_fn(codons_slice ndarray) -> 1-D torch tensor of per-codon scores for that slice.
+    Returns the full score vector (torch tensor) on rank 0, None on the other ranks."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n = codons.shape[1]
+    bounds = shard_bounds(n, world, align)
+    lo, hi = bounds[rank]
+    local = score_fn(np.ascontiguousarray(codons[:, lo:hi]))
+    if to_device is not None:
+        local = local.to(to_device)
+    return gather_to_root(local, [b[1] - b[0] for b in bounds], dst=0, group=group)
+
+
+def score_blocks_sharded(score_fn, codons, site_offsets, group=None):
+    """run() over a CSR batch of blocks sharded by contiguous block ranges.
+    score_fn(codons_slice, offsets_slice) -> (phylo float32 ndarray, anc float32 ndarray).
+    Returns (phylo, anc) ndarrays on rank 0, (None, None) elsewhere."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    off = np.asarray(site_offsets, dtype=np.uint64)
+    ranges = shard_blocks(off, world)
+    b_lo, b_hi = ranges[rank]
+    s_lo, s_hi = int(off[b_lo]), int(off[b_hi])
+    sub = np.ascontiguousarray(codons[:, s_lo:max(s_hi, s_lo + 1)]) if s_hi > s_lo else np.full((codons.shape[0], 1), 64, np.uint8)
+    ph, an = score_fn(sub, (off[b_lo:b_hi + 1] - off[b_lo]).astype(np.uint64))
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    both = torch.from_numpy(np.concatenate([np.asarray(ph, np.float32), np.asarray(an, np.float32)])).to(dev)
+    counts = [2 * (r[1] - r[0]) for r in ranges]
+    allv = gather_to_root(both, counts, dst=0, group=group)
+    if rank != 0:
+        return None, None
+    allv = allv.cpu().numpy()
+    phs, ans, pos = [], [], 0
+    for r in ranges:
+        k = r[1] - r[0]
+        phs.append(allv[pos:pos + k])
+        ans.append(allv[pos + k:pos + 2 * k])
+        pos += 2 * k
+    return np.concatenate(phs), np.concatenate(ans)

@@ -1,0 +1,79 @@
+"""N > 1 path on CPU: world_size-2 (and 3) gloo process groups exercise the sharding + gather of
+phylocsfpp_amd/dist.py with the CPU oracle standing in for the per-rank GPU scorer."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from phylocsfpp_amd import dist as pdist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_sites, out_path):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    import oracle_binding as ob
+    from phylocsfpp_amd import synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = ob.OracleModel(os.path.join(ROOT, "tests", "golden", "models", "53birds"))
+    cod = synth.synthetic_codon_columns(m.child1, m.child2, m.branch_len, m.S_c, m.pi_c, m.S_nc, m.pi_nc, max(n_sites, 1), seed=9)[:, :n_sites]
+    full = pdist.score_sites_sharded(lambda c: torch.from_numpy(m.run_tracks(c)), cod, align=64)
+    # whole-block FIXED scores through the block sharding
+    off = np.unique(np.concatenate([[0, n_sites], np.random.default_rng(1).integers(0, n_sites + 1, 7)])).astype(np.uint64)
+
+    def blocks(c, o):
+        ph, an = [], []
+        for b in range(len(o) - 1):
+            p, a = m.run(ob.FIXED, np.ascontiguousarray(c[:, int(o[b]):int(o[b + 1])]))
+            ph.append(p)
+            an.append(a)
+        return np.array(ph, np.float32), np.array(an, np.float32)
+    ph, an = pdist.score_blocks_sharded(blocks, cod, off)
+    if rank == 0:
+        want = m.run_tracks(cod)
+        wph, wan = blocks(cod, off)
+        np.save(out_path, np.array([float(np.array_equal(full.numpy(), want)), float(np.array_equal(ph, wph) and np.array_equal(an, wan)),
+                                    float(len(full))]))
+    else:
+        assert full is None and ph is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_sites", [(2, 333), (2, 1), (3, 200), (2, 64)])
+def test_sharded_scores_equal_unsharded(tmp_path, world, n_sites):
+    out = str(tmp_path / "res.npy")
+    mp.spawn(_worker, args=(world, _free_port(), n_sites, out), nprocs=world, join=True)
+    res = np.load(out)
+    assert res[0] == 1.0 and res[1] == 1.0 and res[2] == n_sites
+
+
+def test_shard_bounds_properties():
+    for n in (0, 1, 63, 64, 65, 1000, 2_000_000):
+        for w in (1, 2, 4, 8):
+            b = pdist.shard_bounds(n, w, 64)
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert all(lo % 64 == 0 or lo == n for lo, _ in b)
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 64 or n < 64 * w
+    off = np.array([0, 5, 5, 900, 910, 1500, 1501, 4000], dtype=np.uint64)
+    for w in (1, 2, 3, 8):
+        r = pdist.shard_blocks(off, w)
+        assert r[0][0] == 0 and r[-1][1] == 7 and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
