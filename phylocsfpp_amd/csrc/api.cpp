@@ -78,6 +78,8 @@ PruneParams base_prune_params(const pcsf_ctx* c)
     p.anc_weight = c->d_anc_weight.as<double>();
     p.stamps = c->d_stamps.as<unsigned long long>();
     p.stamp_block = c->stamp_block;
+    p.stagger_sleep = c->stagger_sleep;
+    p.stagger_first_blocks = c->stagger_first_blocks;
     return p;
 }
 
@@ -243,6 +245,8 @@ int pcsf_create(pcsf_ctx** out, const pcsf_model_desc* m, int device_id)
         g_create_error = c->error;
         return rc;
     }
+    c->stagger_first_blocks = 2u * static_cast<uint32_t>(prop.multiProcessorCount);
+    if (const char* v = std::getenv("PCSF_STAGGER")) c->stagger_sleep = std::atoi(v);
     if (const char* v = std::getenv("PCSF_EXTRA_LDS")) c->extra_lds = static_cast<size_t>(std::atoi(v));
     if (const char* v = std::getenv("PCSF_PRUNE_VARIANT")) {
         const int vi = std::atoi(v);
@@ -276,7 +280,7 @@ double pcsf_last_kernel_ms(const pcsf_ctx* c) { return c ? c->last_kernel_ms : -
 int pcsf_debug_stamps(pcsf_ctx* c, int block, unsigned long long* out, int cap)
 {
     if (!c) return PCSF_ERR_INVALID_ARG;
-    const size_t n = static_cast<size_t>(2) * c->schedule.program.size() * 4;
+    const size_t n = static_cast<size_t>(2) * c->schedule.program.size() * 4 + 1024 * 16;  // per-op stamps + residency census
     hipError_t e;
     if (!out) {  // arm
         if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");

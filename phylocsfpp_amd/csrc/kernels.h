@@ -33,6 +33,8 @@ struct PruneParams {
     const uint64_t* wg_site_end;
     const uint32_t* wg_table;
     size_t n_wgs;
+    int stagger_sleep;           // first-generation stagger of co-resident work-groups, x 1024 cycles (0 = off)
+    uint32_t stagger_first_blocks;
     unsigned long long* stamps;  // diagnostic variant only: [2][n_ops][4] s_memtime values, else null
     uint32_t stamp_block;
     double* out_score;       // [n_sites] or null

@@ -173,6 +173,16 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     };
     int slot = 0;
     if (total_slots > 0) stage_slot(0);
+    // Two work-groups share a CU (one wave each per SIMD), run the same program and start together,
+    // so they would reach their matrix phases and their between-product gaps at the same time and
+    // leave the pipe idle in every gap.  The first generation of work-groups is staggered by
+    // their hardware wave slot (HW_ID.WAVE_ID): the group in the odd slot starts half a product
+    // late.  Later work-groups inherit the phase of the group they replace.  Speed only.
+    if (p.stagger_sleep > 0 && blockIdx.x < p.stagger_first_blocks && wave == 0) {
+        const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID[3:0]
+        if (wave_slot & 1)
+            for (int i = 0; i < p.stagger_sleep; ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles
+    }
     double lnz0 = 0.0, lnz1 = 0.0, anc0 = 0.0, anc1 = 0.0;
     const bool stamping = STAMP && p.stamps != nullptr && blockIdx.x == p.stamp_block && wave == 0;
     (void)stamping;
@@ -205,6 +215,13 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     }
 #define PCSF_PRODUCT_PROLOGUE()                                                      \
     PCSF_STAMP(0)                                                                    \
+    if constexpr (STAMP) { /* residency census: HW_ID and op start times of the first 1024 work-groups */ \
+        if (p.stamps && blockIdx.x < 1024 && wave == 0 && lane == 0 && (ip == 10 || ip == 40 || ip == 70 || ip == 100)) {  \
+            unsigned long long* cz = p.stamps + static_cast<size_t>(2) * p.n_ops * 4 + static_cast<size_t>(blockIdx.x) * 16; \
+            if (ip == 10 && model == 0) cz[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);  \
+            cz[1 + model * 4 + (ip - 10) / 30] = stamp_now();                        \
+        }                                                                            \
+    }                                                                                \
     __syncthreads();                                                                 \
     PCSF_STAMP(1)                                                                    \
     const double2_t* buf = lfrag + (slot & 1) * (FRAG_DOUBLES_DEV / 2);              \

@@ -17,10 +17,13 @@ out = torch.empty(n_sites, dtype=torch.float64, device="cuda")
 want = m.run_tracks(pool[:, idx[:256]])
 configs = [("v0", dict(PCSF_PRUNE_VARIANT="0")), ("v1", dict(PCSF_PRUNE_VARIANT="1")),
            ("v0 1WG/CU", dict(PCSF_PRUNE_VARIANT="0", PCSF_EXTRA_LDS="30000")),
+           ("v0 stagger2", dict(PCSF_PRUNE_VARIANT="0", PCSF_STAGGER="2")),
+           ("v0 stagger4", dict(PCSF_PRUNE_VARIANT="0", PCSF_STAGGER="4")),
+           ("v0 stagger6", dict(PCSF_PRUNE_VARIANT="0", PCSF_STAGGER="6")),
            ]
 ctxs = []
 for name, env in configs:
-    for k in ("PCSF_PRUNE_VARIANT", "PCSF_EXTRA_LDS", "PCSF_STAGGER_SLEEPS"):
+    for k in ("PCSF_PRUNE_VARIANT", "PCSF_EXTRA_LDS", "PCSF_STAGGER"):
         os.environ.pop(k, None)
     os.environ.update(env)
     c = pa.ScoringContext(m.child1, m.child2, m.branch_len, m.S_c, m.pi_c, m.S_nc, m.pi_nc)
