@@ -46,6 +46,7 @@ struct PruneParams {
 // 2 = variant 0 with in-kernel stamps (diagnostic only), 16 = block mode (per-work-group windows and tables)
 hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t stream, size_t extra_lds = 0);
 int prune_variant_count();
+hipError_t launch_prune_ring(const PruneParams& p, int variant, hipStream_t stream, size_t extra_lds);
 
 }  // namespace pcsf
 

@@ -1,3 +1,7 @@
+// kernels_ring.hip -- EXPERIMENTAL variant of prune_fixed (kernels.hip) with a 3-slot LDS ring.
+// Differences: the branch matrix of product j+1 is published by a barrier in k-step 2 of product j
+// (not at the product boundary), so the first fragments of the next product are fetched in the last
+// k-step of the current one and no barrier, LDS latency or DMA wait sits between two products.
 // kernels.hip -- gfx950 (CDNA4) kernels of the PhyloCSF scoring core.
 //
 // prune_fixed<NW,G>: Felsenstein pruning + log-likelihood ratio for the FIXED strategy
@@ -16,6 +20,7 @@
 #include "kernels.h"
 
 namespace pcsf {
+namespace ring {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
@@ -57,12 +62,11 @@ __device__ __forceinline__ const double2_t* leaf_row_ptr(const double* __restric
 //   slot 1..3: per_slot(q, j) -- LDS-DMA piece of the next slot, leaf-row loads, cherry multiplies
 // Scheduling barriers pin this order (and keep the compiler from hoisting all 32 LDS reads).
 template <class PerSlot>
-__device__ __forceinline__ void product(const double2_t* __restrict__ buf, int lane, const double (&cur)[16], double4_t (&acc)[4],
-                                        PerSlot&& per_slot)
+__device__ __forceinline__ void product(const double2_t* __restrict__ buf, const double2_t* __restrict__ next_buf, bool has_next, int lane,
+                                        double2_t& n01, double2_t& n23, const double (&cur)[16], double4_t (&acc)[4], PerSlot&& per_slot)
 {
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
-    double2_t n01 = buf[lane], n23 = buf[64 + lane];
     auto step = [&](auto qc) {
         constexpr int q = decltype(qc)::value;
         const double2_t f01 = n01, f23 = n23;
@@ -72,6 +76,9 @@ __device__ __forceinline__ void product(const double2_t* __restrict__ buf, int l
         if (q + 1 < 16) {
             n01 = buf[((q + 1) * 2 + 0) * 64 + lane];
             n23 = buf[((q + 1) * 2 + 1) * 64 + lane];
+        } else if (has_next) {  // first fragments of the NEXT product (its buffer was published in k-step 2)
+            n01 = next_buf[lane];
+            n23 = next_buf[64 + lane];
         }
         __builtin_amdgcn_sched_barrier(0);
         acc[1] = mfma_f64(f01.y, cur[q], acc[1]);
@@ -112,11 +119,11 @@ __device__ __forceinline__ unsigned long long stamp_now()
 // matrices, MLE / OMEGA); otherwise work-group b owns sites [b*SITES, (b+1)*SITES) and passes
 // 0..n_passes-1 use table sets 0..n_passes-1 (coding, non-coding).
 template <int NW, bool STAMP, bool BLOCKS>
-__global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void prune_ring(const PruneParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double2_t* lfrag = reinterpret_cast<double2_t*>(lds_raw);
-    uint32_t* lprog = reinterpret_cast<uint32_t*>(lds_raw + 2 * FRAG_DOUBLES_DEV * sizeof(double));
+    uint32_t* lprog = reinterpret_cast<uint32_t*>(lds_raw + 3 * FRAG_DOUBLES_DEV * sizeof(double));
     unsigned char* lcod = reinterpret_cast<unsigned char*>(lprog + ((p.n_ops + 3) & ~3));
 
     constexpr int SITES = NW * 16;
@@ -142,7 +149,6 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     }
     for (int i = tid; i < p.n_ops; i += NW * 64) lprog[i] = p.program[i];
     const unsigned char* my_cod = lcod + wave * 16 + sl;  // + leaf*SITES
-    __syncthreads();
 
     // ---- fragment staging: 32 KiB per slot, moved by LDS-DMA in 1 KiB wave-instructions
     constexpr int CHUNKS_PER_WAVE = 32 / NW;
@@ -160,28 +166,25 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
                                          (__attribute__((address_space(3))) void*)dst, 16, (J % 4) * 1024, 0);
     };
     auto stage_slot = [&](int slot) {
-        stage_piece(std::integral_constant<int, 0>{}, slot, slot & 1);
-        stage_piece(std::integral_constant<int, 1>{}, slot, slot & 1);
-        stage_piece(std::integral_constant<int, 2>{}, slot, slot & 1);
-        stage_piece(std::integral_constant<int, 3>{}, slot, slot & 1);
+        stage_piece(std::integral_constant<int, 0>{}, slot, slot % 3);
+        stage_piece(std::integral_constant<int, 1>{}, slot, slot % 3);
+        stage_piece(std::integral_constant<int, 2>{}, slot, slot % 3);
+        stage_piece(std::integral_constant<int, 3>{}, slot, slot % 3);
         if constexpr (CHUNKS_PER_WAVE > 4) {
-            stage_piece(std::integral_constant<int, 4>{}, slot, slot & 1);
-            stage_piece(std::integral_constant<int, 5>{}, slot, slot & 1);
-            stage_piece(std::integral_constant<int, 6>{}, slot, slot & 1);
-            stage_piece(std::integral_constant<int, 7>{}, slot, slot & 1);
+            stage_piece(std::integral_constant<int, 4>{}, slot, slot % 3);
+            stage_piece(std::integral_constant<int, 5>{}, slot, slot % 3);
+            stage_piece(std::integral_constant<int, 6>{}, slot, slot % 3);
+            stage_piece(std::integral_constant<int, 7>{}, slot, slot % 3);
         }
     };
     int slot = 0;
     if (total_slots > 0) stage_slot(0);
-    // Two work-groups share a CU (one wave each per SIMD), run the same program and start together,
-    // so they would reach their matrix phases and their between-product gaps at the same time and
-    // leave the pipe idle in every gap.  The first generation of work-groups is staggered by
-    // their hardware wave slot (HW_ID.WAVE_ID): the group in the odd slot starts half a product
-    // late.  Later work-groups inherit the phase of the group they replace.  Speed only.
-    if (p.stagger_sleep > 0 && blockIdx.x < p.stagger_first_blocks && wave == 0) {
-        const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID[3:0]
-        if (wave_slot & 1)
-            for (int i = 0; i < p.stagger_sleep; ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles
+    if (total_slots > 1) stage_slot(1);
+    __syncthreads();  // codons, program and (vmcnt(0)) the first two slots are in LDS
+    double2_t n01 = double2_t{0.0, 0.0}, n23 = double2_t{0.0, 0.0};
+    if (total_slots > 0) {
+        n01 = lfrag[lane];
+        n23 = lfrag[64 + lane];
     }
     double lnz0 = 0.0, lnz1 = 0.0, anc0 = 0.0, anc1 = 0.0;
     const bool stamping = STAMP && p.stamps != nullptr && blockIdx.x == p.stamp_block && wave == 0;
@@ -195,27 +198,12 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
         double4_t acc[4];
         double stk[MAX_STACK_DEPTH_DEV][16];
 
-        // The op word and the codon bytes of op i+1 are fetched from LDS while op i runs, so that no LDS
-        // round trip (op word -> leaf index -> codon byte) sits between two products.
-        uint32_t op = __builtin_amdgcn_readfirstlane(lprog[0]);
-        uint32_t word_ahead = lprog[p.n_ops > 1 ? 1 : 0];
-        uint32_t ca = my_cod[((op >> 14) & 0x3fff) * SITES], cb = my_cod[(op & 0x3fff) * SITES];
+        uint32_t next_op = lprog[0];
         for (int ip = 0; ip < p.n_ops; ++ip) {
+            const uint32_t op = __builtin_amdgcn_readfirstlane(next_op);
+            next_op = lprog[ip + 1 < p.n_ops ? ip + 1 : ip];  // fetched one op ahead (LDS broadcast read)
             const uint32_t code = op >> 28;
             const int a = (op >> 14) & 0x3fff, b = op & 0x3fff;
-            const uint32_t cod_a = ca, cod_b = cb;
-            (void)cod_b;
-            // issue next iteration's LDS reads now; they are consumed after this op's product
-            op = __builtin_amdgcn_readfirstlane(word_ahead);
-            word_ahead = lprog[ip + 2 < p.n_ops ? ip + 2 : p.n_ops - 1];
-            ca = my_cod[((op >> 14) & 0x3fff) * SITES];
-            cb = my_cod[(op & 0x3fff) * SITES];
-            if constexpr (STAMP) {
-                __builtin_amdgcn_sched_barrier(0);
-                const unsigned long long ts_ = stamp_now();
-                __builtin_amdgcn_sched_barrier(0);
-                if (stamping && lane == 0) p.stamps[(static_cast<size_t>(model) * p.n_ops + ip) * 8 + 5] = ts_;
-            }
 
             // Every op except the first cherry and the root starts with a product.  Its barrier
             // (a) completes this wave's LDS-DMA of the current slot (vmcnt(0)), (b) publishes all
@@ -226,28 +214,26 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
         __builtin_amdgcn_sched_barrier(0);                                           \
         const unsigned long long ts_ = stamp_now();                                  \
         __builtin_amdgcn_sched_barrier(0);                                           \
-        if (stamping && lane == 0) p.stamps[(static_cast<size_t>(model) * p.n_ops + ip) * 8 + (K)] = ts_; \
+        if (stamping && lane == 0) p.stamps[(static_cast<size_t>(model) * p.n_ops + ip) * 4 + (K)] = ts_; \
     }
 #define PCSF_PRODUCT_PROLOGUE()                                                      \
     PCSF_STAMP(0)                                                                    \
-    if constexpr (STAMP) { /* residency census: HW_ID and op start times of the first 1024 work-groups */ \
-        if (p.stamps && blockIdx.x < 1024 && wave == 0 && lane == 0 && (ip == 10 || ip == 40 || ip == 70 || ip == 100)) {  \
-            unsigned long long* cz = p.stamps + static_cast<size_t>(2) * p.n_ops * 8 + static_cast<size_t>(blockIdx.x) * 16; \
-            if (ip == 10 && model == 0) cz[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);  \
-            cz[1 + model * 4 + (ip - 10) / 30] = stamp_now();                        \
-        }                                                                            \
-    }                                                                                \
-    __syncthreads();                                                                 \
     PCSF_STAMP(1)                                                                    \
-    const double2_t* buf = lfrag + (slot & 1) * (FRAG_DOUBLES_DEV / 2);              \
     const int this_slot = slot;                                                      \
-    /* branch-free: the last product re-stages its own slot into the idle buffer (never read) */ \
-    const int stage_next = this_slot + 1 < total_slots ? this_slot + 1 : this_slot;  \
+    const double2_t* buf = lfrag + (this_slot % 3) * (FRAG_DOUBLES_DEV / 2);         \
+    const double2_t* next_buf = lfrag + ((this_slot + 1) % 3) * (FRAG_DOUBLES_DEV / 2); \
+    const bool has_next = this_slot + 1 < total_slots;                               \
+    /* branch-free: near the end an already staged slot is re-staged into the idle buffer (never read) */ \
+    const int stage_next = this_slot + 2 < total_slots ? this_slot + 2 : total_slots - 1;  \
+    const int stage_buf = (this_slot + 2) % 3;                                       \
     ++slot;
-// slot 1 of k-steps 0..CHUNKS_PER_WAVE-1: one LDS-DMA piece of the next slot each
+// k-step 2, slot 1: the barrier that (a) completes and publishes slot j+1 (staged during product j-1) and
+// (b) proves every wave has left product j-1, whose buffer the pieces below overwrite.
+// k-steps 3..: one LDS-DMA piece of slot j+2 each.
 #define PCSF_STAGE_SLOT(q, j)                                                        \
-    if constexpr (j == 1 && q < CHUNKS_PER_WAVE) {                                   \
-        stage_piece(std::integral_constant<int, (q < CHUNKS_PER_WAVE ? q : 0)>{}, stage_next, (this_slot + 1) & 1); \
+    if constexpr (j == 1 && q == 2) __syncthreads();                                 \
+    if constexpr (j == 1 && q >= 3 && q - 3 < CHUNKS_PER_WAVE) {                     \
+        stage_piece(std::integral_constant<int, (q >= 3 && q - 3 < CHUNKS_PER_WAVE ? q - 3 : 0)>{}, stage_next, stage_buf); \
     }
 // cherry rows arrive a quarter (4 states per lane = 2 x 16 B per row) at a time: quarter k is
 // requested in k-steps 3k (row a: slots 2,3) and 3k+1 (row b: slots 2,3) and multiplied into nxt
@@ -255,22 +241,27 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
 #define PCSF_PUSH_CHERRY(D)                                                          \
     {                                                                                \
         PCSF_PRODUCT_PROLOGUE()                                                      \
-        const double2_t* pa = leaf_row_ptr(leaf_tab, a, cod_a, g4);      \
-        const double2_t* pb = leaf_row_ptr(leaf_tab, b, cod_b, g4);      \
+        const double2_t* pa = leaf_row_ptr(leaf_tab, a, my_cod[a * SITES], g4);      \
+        const double2_t* pb = leaf_row_ptr(leaf_tab, b, my_cod[b * SITES], g4);      \
         double2_t xa[2][2], xb[2][2];                                                \
-        product(buf, lane, cur, acc, [&](auto qc, auto jc) {                         \
+        product(buf, next_buf, has_next, lane, n01, n23, cur, acc, [&](auto qc, auto jc) {                         \
             constexpr int q = decltype(qc)::value;                                   \
             constexpr int j = decltype(jc)::value;                                   \
             PCSF_STAGE_SLOT(q, j)                                                    \
-            if constexpr (j >= 2 && q % 3 == 0 && q / 3 < 4) xa[(q / 3) & 1][j - 2] = pa[2 * (q / 3) + (j - 2)]; \
-            if constexpr (j >= 2 && q % 3 == 1 && q / 3 < 4) xb[(q / 3) & 1][j - 2] = pb[2 * (q / 3) + (j - 2)]; \
-            if constexpr (j >= 2 && q >= 5 && (q - 5) % 3 == 0 && (q - 5) / 3 < 4) {  \
-                constexpr int k = (q - 5) / 3;                                       \
+            /* quarter k: row a at k-step 3+3k, row b at 4+3k (slots 2,3), product at 8+3k; the last one after the loop */ \
+            if constexpr (j >= 2 && q >= 3 && (q - 3) % 3 == 0 && (q - 3) / 3 < 4) xa[((q - 3) / 3) & 1][j - 2] = pa[2 * ((q - 3) / 3) + (j - 2)]; \
+            if constexpr (j >= 2 && q >= 4 && (q - 4) % 3 == 0 && (q - 4) / 3 < 4) xb[((q - 4) / 3) & 1][j - 2] = pb[2 * ((q - 4) / 3) + (j - 2)]; \
+            if constexpr (j >= 2 && q >= 8 && (q - 8) % 3 == 0 && (q - 8) / 3 < 3) {  \
+                constexpr int k = (q - 8) / 3;                                       \
                 nxt[4 * k + 2 * (j - 2) + 0] = xa[k & 1][j - 2].x * xb[k & 1][j - 2].x; \
                 nxt[4 * k + 2 * (j - 2) + 1] = xa[k & 1][j - 2].y * xb[k & 1][j - 2].y; \
             }                                                                        \
         });                                                                          \
         PCSF_STAMP(2)                                                                \
+        nxt[12] = xa[1][0].x * xb[1][0].x;                                           \
+        nxt[13] = xa[1][0].y * xb[1][0].y;                                           \
+        nxt[14] = xa[1][1].x * xb[1][1].x;                                           \
+        nxt[15] = xa[1][1].y * xb[1][1].y;                                           \
         _Pragma("unroll") for (int q = 0; q < 16; ++q) {                             \
             stk[D][q] = acc[q >> 2][q & 3];                                          \
             cur[q] = nxt[q];                                                         \
@@ -280,7 +271,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
 #define PCSF_POP(D)                                                                  \
     {                                                                                \
         PCSF_PRODUCT_PROLOGUE()                                                      \
-        product(buf, lane, cur, acc, [&](auto qc, auto jc) {                         \
+        product(buf, next_buf, has_next, lane, n01, n23, cur, acc, [&](auto qc, auto jc) {                         \
             constexpr int q = decltype(qc)::value;                                   \
             constexpr int j = decltype(jc)::value;                                   \
             PCSF_STAGE_SLOT(q, j)                                                    \
@@ -291,8 +282,8 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     }
             switch (code) {
                 case F_CHERRY_DEV: {
-                    const LeafRow ra = load_leaf_row(leaf_tab, a, cod_a, g4);
-                    const LeafRow rb = load_leaf_row(leaf_tab, b, cod_b, g4);
+                    const LeafRow ra = load_leaf_row(leaf_tab, a, my_cod[a * SITES], g4);
+                    const LeafRow rb = load_leaf_row(leaf_tab, b, my_cod[b * SITES], g4);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         cur[2 * i] = ra.v[i].x * rb.v[i].x;
@@ -302,9 +293,9 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
                 }
                 case F_MM_LEAF_DEV: {
                     PCSF_PRODUCT_PROLOGUE()
-                    const double2_t* pa = leaf_row_ptr(leaf_tab, a, cod_a, g4);
+                    const double2_t* pa = leaf_row_ptr(leaf_tab, a, my_cod[a * SITES], g4);
                     LeafRow ra;
-                    product(buf, lane, cur, acc, [&](auto qc, auto jc) {
+                    product(buf, next_buf, has_next, lane, n01, n23, cur, acc, [&](auto qc, auto jc) {
                         constexpr int q = decltype(qc)::value;
                         constexpr int j = decltype(jc)::value;
                         PCSF_STAGE_SLOT(q, j)
@@ -317,7 +308,6 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
                         cur[2 * i + 1] = acc[(2 * i + 1) >> 2][(2 * i + 1) & 3] * ra.v[i].y;
                     }
                     PCSF_STAMP(3)
-                    PCSF_STAMP(4)
                     break;
                 }
                 case F_MM_PUSH_CHERRY0_DEV + 0: PCSF_PUSH_CHERRY(0) break;
@@ -377,31 +367,30 @@ static hipError_t launch_impl(const PruneParams& p, hipStream_t stream, size_t e
     const size_t blocks = BLOCKS ? p.n_wgs : (p.n_sites + sites_per_block - 1) / sites_per_block;
     if (blocks == 0) return hipSuccess;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
-    const size_t lds = 2 * FRAG_DOUBLES_DEV * sizeof(double) + ((static_cast<size_t>(p.n_ops) + 3) & ~size_t(3)) * 4 +
+    const size_t lds = 3 * FRAG_DOUBLES_DEV * sizeof(double) + ((static_cast<size_t>(p.n_ops) + 3) & ~size_t(3)) * 4 +
                        static_cast<size_t>(p.n_leaves) * sites_per_block + extra_lds;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     static bool attr_set = false;  // one flag per template instantiation
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prune_fixed<NW, STAMP, BLOCKS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prune_ring<NW, STAMP, BLOCKS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((prune_fixed<NW, STAMP, BLOCKS>), dim3(static_cast<unsigned>(blocks)), dim3(NW * 64), lds, stream, p);
+    hipLaunchKernelGGL((prune_ring<NW, STAMP, BLOCKS>), dim3(static_cast<unsigned>(blocks)), dim3(NW * 64), lds, stream, p);
     return hipGetLastError();
 }
 
-hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t stream, size_t extra_lds)
+}  // namespace ring
+
+hipError_t launch_prune_ring(const PruneParams& p, int variant, hipStream_t stream, size_t extra_lds)
 {
     switch (variant) {
-        case 0: return launch_impl<4, false, false>(p, stream, extra_lds);
-        case 1: return launch_impl<8, false, false>(p, stream, extra_lds);
-        case 2: return launch_impl<4, true, false>(p, stream, extra_lds);  // diagnostic: in-kernel stamps
-        case 16: return launch_impl<4, false, true>(p, stream, extra_lds); // per-work-group windows/tables
-        case 8: case 9: case 10: case 24: return launch_prune_ring(p, variant, stream, extra_lds);  // 3-slot LDS ring (kernels_ring.hip)
+        case 8: return ring::launch_impl<4, false, false>(p, stream, extra_lds);
+        case 9: return ring::launch_impl<8, false, false>(p, stream, extra_lds);
+        case 10: return ring::launch_impl<4, true, false>(p, stream, extra_lds);  // stamps
+        case 24: return ring::launch_impl<4, false, true>(p, stream, extra_lds);  // block mode
         default: return hipErrorInvalidValue;
     }
 }
-
-int prune_variant_count() { return 11; }
 
 }  // namespace pcsf

@@ -12,8 +12,9 @@ pool = synth.synthetic_codon_columns(m.child1, m.child2, m.branch_len, m.S_c, m.
 idx = np.random.default_rng(2).integers(0, 16384, size=n_sites)
 d = torch.from_numpy(np.ascontiguousarray(pool[:, idx])).cuda()
 out = torch.empty(n_sites, dtype=torch.float64, device="cuda")
-for extra in ("0", "30000"):
-    os.environ["PCSF_PRUNE_VARIANT"] = "2"; os.environ["PCSF_EXTRA_LDS"] = extra
+VAR = os.environ.get("STAMP_VARIANT", "2")
+for extra in (("0", "30000") if VAR == "2" else ("0",)):
+    os.environ["PCSF_PRUNE_VARIANT"] = VAR; os.environ["PCSF_EXTRA_LDS"] = extra
     c = pa.ScoringContext(m.child1, m.child2, m.branch_len, m.S_c, m.pi_c, m.S_nc, m.pi_nc)
     lib = pa.load_library()
     lib.pcsf_debug_stamps.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.c_int]
@@ -22,7 +23,8 @@ for extra in ("0", "30000"):
         c.score_sites_fixed_torch(d, out=out); torch.cuda.synchronize()
         buf = np.zeros(n, dtype=np.uint64)
         lib.pcsf_debug_stamps(c._h, block, buf.ctypes.data_as(C.POINTER(C.c_uint64)), n)
-        st = buf.reshape(2, -1, 4).astype(np.int64)
+        n_ops = len(pa.build_schedule(m.child1, m.child2)[0])
+        st = buf[:2 * n_ops * 8].reshape(2, -1, 8).astype(np.int64)
         ops = st[:, 1:-1, :]                      # ops with a product (skip first cherry and root)
         wait_bar = ops[:, :, 1] - ops[:, :, 0]
         prod = ops[:, :, 2] - ops[:, :, 1]
@@ -38,6 +40,11 @@ for extra in ("0", "30000"):
                 print("   %-15s n=%2d  barrier %.0f  product %.0f  epilogue %.0f  gap-after %.0f" % (
                     cname, sel.sum(), wait_bar[:, sel].mean(), prod[:, sel].mean(), epi[:, sel].mean(),
                     gap[:, sel[:-1]].mean()))
+        leaf = codes == 1
+        cal = (ops[:, :, 4] - ops[:, :, 3])[:, leaf]
+        top = ops[:, 1:, 5] - ops[:, :-1, 3]          # epilogue end -> next loop top (after decode + LDS issue)
+        disp = ops[:, :, 0] - ops[:, :, 5]            # loop top -> arm start (switch dispatch)
+        print("   stamp cost (back-to-back) %.0f ; arm-exit+latch+decode %.0f ; switch dispatch %.0f" % (cal.mean(), top.mean(), disp.mean()))
         print("   first 12 ops product:", prod[0, :12].tolist(), "codes", codes[:12].tolist())
         print("   product min/max %d/%d  barrier min/max %d/%d  total %d" % (prod.min(), prod.max(), wait_bar.min(), wait_bar.max(), st[1, -1, 0] - st[0, 1, 0]))
     c.close()
