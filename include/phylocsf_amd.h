@@ -87,6 +87,26 @@ int pcsf_score_sites_fixed(pcsf_ctx *ctx, const uint8_t *codons, size_t n_sites,
 int pcsf_score_sites_fixed_dev(pcsf_ctx *ctx, const uint8_t *d_codons, size_t n_sites, size_t leaf_stride,
                                double *d_out_decibans, double *d_out_lnz, void *hip_stream);
 
+/* ---- build-tracks front end: the six frames of whole alignments ------------------------------
+ * Replaces, per alignment, the loop of src/phylocsf++build_tracks.hpp:162-227: for strand in {+,-}, frame 1..3:
+ * alignment_t::update_seqs (frame offset + translation, src/parallel_file_reader.hpp:61-113), run_tracks,
+ * reversal of the '-' strand scores, reverse complement between the strands.
+ * nucleotides: the rows of alignment_t::seqs (reference gaps already removed), ASCII, leaf-major
+ * [n_leaves][row_stride]; alignment k occupies columns [col_offset, col_offset+len) of every row, start_pos is
+ * its 1-based reference position and chrom_len the reference chromosome length (alignment_t::start_pos /
+ * ::chrom_len).  Characters other than ACGTacgt count as N (the reference exits on anything but ACGTNacgtn-.).
+ * Output: for alignment k and frame index f = 0..5 (+1,+2,+3,-1,-2,-3) n_codons[6k+f] scores at
+ * out_scores[out_offsets[6k+f] ...] in FORWARD genome order; skip_bases (may be NULL) = alignment_t::skip_bases. */
+typedef struct {
+    uint64_t col_offset;
+    uint32_t len;
+    uint64_t start_pos;
+    uint64_t chrom_len;
+} pcsf_alignment_desc;
+int pcsf_score_alignments_6frames(pcsf_ctx *ctx, const char *nucleotides, size_t row_stride,
+                                  const pcsf_alignment_desc *alignments, size_t n_alignments, double *out_scores,
+                                  size_t out_capacity, uint64_t *out_offsets, uint32_t *n_codons, uint32_t *skip_bases);
+
 /* ---- run (src/run.hpp:57-211): whole-block scores -----------------------------------------
  * A batch of blocks in CSR form: block b owns sites [site_offsets[b], site_offsets[b+1]) of the
  * leaf-major codon matrix.  algo FIXED / MLE / OMEGA; seed is what score-msa passes to

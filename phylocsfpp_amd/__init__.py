@@ -24,6 +24,10 @@ class PcsfError(RuntimeError):
         self.code = code
 
 
+class _AlignmentDesc(C.Structure):
+    _fields_ = [("col_offset", C.c_uint64), ("len", C.c_uint32), ("start_pos", C.c_uint64), ("chrom_len", C.c_uint64)]
+
+
 class _ModelDesc(C.Structure):
     _fields_ = [("n_nodes", C.c_int32),
                 ("child1", C.POINTER(C.c_int16)), ("child2", C.POINTER(C.c_int16)),
@@ -65,6 +69,8 @@ def load_library():
     lib.pcsf_score_sites_fixed_dev.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, vp, vp]
     lib.pcsf_score_blocks.argtypes = [vp, C.c_int, u8p, C.POINTER(C.c_uint64), C.c_size_t, C.c_size_t, C.c_int,
                                       C.c_uint32, fp, fp]
+    lib.pcsf_score_alignments_6frames.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(_AlignmentDesc), C.c_size_t, dp, C.c_size_t,
+                                                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.pcsf_block_loglik.argtypes = [vp, C.c_int, dp, dp, u8p, C.POINTER(C.c_uint64), C.c_size_t, C.c_size_t, dp,
                                       C.POINTER(C.c_int32)]
     lib.pcsf_set_timing.argtypes = [vp, C.c_int]
@@ -184,6 +190,27 @@ class ScoringContext:
         self.score_sites_fixed_device(codons.data_ptr(), n, codons.stride(0), out.data_ptr(),
                                       lnz.data_ptr() if lnz is not None else 0, stream)
         return out
+
+    def score_alignments_6frames(self, nucleotides, alignments):
+        """Six-frame front end (device translation + run_tracks).  nucleotides: uint8/bytes ndarray
+        [n_leaves, n_cols] of ASCII rows (reference gaps removed); alignments: list of
+        (col_offset, len, start_pos, chrom_len).  Returns a list (per alignment) of 6 float64 arrays in
+        forward genome order (+1,+2,+3,-1,-2,-3) and the skip_bases array [n, 6]."""
+        nuc = np.ascontiguousarray(nucleotides, dtype=np.uint8)
+        assert nuc.ndim == 2 and nuc.shape[0] == self.n_leaves
+        n = len(alignments)
+        desc = (_AlignmentDesc * n)(*[_AlignmentDesc(int(a), int(b), int(c), int(d)) for a, b, c, d in alignments])
+        cap = int(sum(2 * int(a[1]) for a in alignments)) + 1
+        out = np.empty(cap, dtype=np.float64)
+        offs = np.zeros(n * 6, dtype=np.uint64)
+        ncod = np.zeros(n * 6, dtype=np.uint32)
+        skip = np.zeros(n * 6, dtype=np.uint32)
+        self._check(self._lib.pcsf_score_alignments_6frames(
+            self._h, nuc.ctypes.data_as(C.c_char_p), nuc.strides[0], desc, n, out.ctypes.data_as(C.POINTER(C.c_double)), cap,
+            offs.ctypes.data_as(C.POINTER(C.c_uint64)), ncod.ctypes.data_as(C.POINTER(C.c_uint32)),
+            skip.ctypes.data_as(C.POINTER(C.c_uint32))))
+        res = [[out[int(offs[k * 6 + f]):int(offs[k * 6 + f]) + int(ncod[k * 6 + f])].copy() for f in range(6)] for k in range(n)]
+        return res, skip.reshape(n, 6)
 
     # ---- run -----------------------------------------------------------------------------
     def score_blocks(self, algo, codons, site_offsets, compute_anc=True, seed=42):

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "ctx.hpp"
+#include "frames.hpp"
 #include "optimizer.hpp"
 
 namespace {
@@ -329,6 +330,65 @@ int pcsf_score_sites_fixed(pcsf_ctx* c, const uint8_t* codons, size_t n_sites, s
     int rc = pcsf::launch_fixed(c, c->d_codons.as<uint8_t>(), n_sites, n_sites, c->d_out.as<double>(), nullptr, nullptr, c->stream);
     if (rc != PCSF_OK) return rc;
     if ((e = hipMemcpyAsync(out, c->d_out.ptr, n_sites * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
+        return c->hip_fail(e, "hipMemcpyAsync(out)");
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return c->hip_fail(e, "hipStreamSynchronize");
+    return PCSF_OK;
+}
+
+int pcsf_score_alignments_6frames(pcsf_ctx* c, const char* nucleotides, size_t row_stride, const pcsf_alignment_desc* alns, size_t n_alns,
+                                  double* out_scores, size_t out_capacity, uint64_t* out_offsets, uint32_t* n_codons, uint32_t* skip_bases)
+{
+    if (!c) return PCSF_ERR_INVALID_ARG;
+    if (n_alns == 0) return PCSF_OK;
+    if (!nucleotides || !alns || !out_scores || !out_offsets || !n_codons) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_alignments_6frames: null argument");
+    std::vector<pcsf::FrameSegment> seg;
+    seg.reserve(n_alns * 6);
+    uint64_t total = 0, max_col = 0;
+    uint32_t max_codons = 0;
+    for (size_t k = 0; k < n_alns; ++k) {
+        const pcsf_alignment_desc& a = alns[k];
+        if (a.col_offset + a.len > row_stride) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_alignments_6frames: alignment exceeds row_stride");
+        max_col = std::max<uint64_t>(max_col, a.col_offset + a.len);
+        for (int f = 0; f < 6; ++f) {
+            const pcsf::FrameView v = pcsf::frame_view(a.start_pos, a.chrom_len, a.len, f < 3 ? '+' : '-', static_cast<unsigned>(f % 3 + 1));
+            pcsf::FrameSegment s{};
+            s.col0 = a.col_offset;
+            s.dst0 = total;
+            s.len = a.len;
+            s.skip = v.skip;
+            s.n_codons = static_cast<uint32_t>(v.n_codons);
+            s.minus = f >= 3;
+            out_offsets[k * 6 + f] = total;
+            n_codons[k * 6 + f] = s.n_codons;
+            if (skip_bases) skip_bases[k * 6 + f] = v.skip;
+            total += s.n_codons;
+            max_codons = std::max(max_codons, s.n_codons);
+            if (s.n_codons) seg.push_back(s);
+        }
+    }
+    if (total > out_capacity) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_alignments_6frames: out_capacity too small");
+    if (total == 0) return PCSF_OK;
+    hipError_t e;
+    if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
+    const size_t nl = static_cast<size_t>(c->n_leaves);
+    if ((e = c->d_nucl.reserve(nl * max_col)) != hipSuccess) return c->hip_fail(e, "hipMalloc(nucleotides)");
+    if ((e = c->d_segments.reserve(seg.size() * sizeof(pcsf::FrameSegment))) != hipSuccess) return c->hip_fail(e, "hipMalloc(segments)");
+    if ((e = c->d_codons.reserve(nl * total)) != hipSuccess) return c->hip_fail(e, "hipMalloc(codons)");
+    if ((e = c->d_out.reserve(total * sizeof(double))) != hipSuccess) return c->hip_fail(e, "hipMalloc(out)");
+    if ((e = hipMemcpy2DAsync(c->d_nucl.ptr, max_col, nucleotides, row_stride, max_col, nl, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
+        return c->hip_fail(e, "hipMemcpy2DAsync(nucleotides)");
+    if ((e = hipMemcpyAsync(c->d_segments.ptr, seg.data(), seg.size() * sizeof(pcsf::FrameSegment), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
+        return c->hip_fail(e, "hipMemcpyAsync(segments)");
+    // at most 65535 segments per launch (grid.y)
+    for (size_t s0 = 0; s0 < seg.size(); s0 += 65535) {
+        const uint32_t ns = static_cast<uint32_t>(std::min<size_t>(65535, seg.size() - s0));
+        if ((e = pcsf::launch_extract_frames(c->d_segments.as<pcsf::FrameSegment>() + s0, ns, max_codons, c->d_nucl.as<unsigned char>(), max_col,
+                                             c->n_leaves, c->d_codons.as<unsigned char>(), total, c->stream)) != hipSuccess)
+            return c->hip_fail(e, "launch extract_frames");
+    }
+    int rc = pcsf::launch_fixed(c, c->d_codons.as<uint8_t>(), total, total, c->d_out.as<double>(), nullptr, nullptr, c->stream);
+    if (rc != PCSF_OK) return rc;
+    if ((e = hipMemcpyAsync(out_scores, c->d_out.ptr, total * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
         return c->hip_fail(e, "hipMemcpyAsync(out)");
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return c->hip_fail(e, "hipStreamSynchronize");
     return PCSF_OK;

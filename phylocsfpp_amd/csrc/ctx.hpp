@@ -55,7 +55,7 @@ struct pcsf_ctx {
     // device-resident model (table sets 0 = coding, 1 = non-coding at tree scale 1)
     pcsf::DeviceBuffer d_program, d_frag, d_leaf_tab, d_prior, d_anc_weight;
     // scratch for the host-pointer entry points
-    pcsf::DeviceBuffer d_codons, d_out, d_lnz, d_anc, d_stamps;
+    pcsf::DeviceBuffer d_codons, d_out, d_lnz, d_anc, d_stamps, d_nucl, d_segments;
     uint32_t stamp_block = 0;
     hipStream_t stream = nullptr;        // private stream for host-pointer entry points
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

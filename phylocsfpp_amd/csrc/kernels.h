@@ -78,3 +78,20 @@ struct ExpmParams {
 hipError_t launch_expm(const ExpmParams& p, hipStream_t stream);
 
 }  // namespace pcsf
+
+namespace pcsf {
+
+// one (alignment, strand, frame) segment of the six-frame front end
+struct FrameSegment {
+    uint64_t col0;      // first column of the alignment in the nucleotide matrix
+    uint64_t dst0;      // first site of the segment in the codon matrix
+    uint32_t len;       // alignment length in columns
+    uint32_t skip;      // columns skipped before the first codon (in the strand's own orientation)
+    uint32_t n_codons;
+    uint32_t minus;     // 0 = '+' strand, 1 = '-' strand (reverse complement, codons stored mirrored)
+};
+
+hipError_t launch_extract_frames(const FrameSegment* d_seg, uint32_t n_segments, uint32_t max_codons, const unsigned char* d_nucl,
+                                 size_t row_stride, int n_leaves, unsigned char* d_codons, size_t leaf_stride, hipStream_t stream);
+
+}  // namespace pcsf

@@ -83,8 +83,10 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
         for (; i < argc; ++i) {
             if (cmd == "build-tracks") {
                 const BuildTracksStats st = build_tracks(model, argv[i], bt, *backend, !first);
-                fprintf(stderr, "%s: %zu alignments, %zu reference bases, %zu codon-frames, %zu backend calls (%.3f s)\n", argv[i],
-                        st.alignments, st.ref_bases, st.codon_frames, st.backend_calls, st.backend_seconds);
+                fprintf(stderr, "%s: %zu alignments, %zu reference bases, %zu codon-frames, %zu backend calls\n", argv[i], st.alignments,
+                        st.ref_bases, st.codon_frames, st.backend_calls);
+                fprintf(stderr, "  seconds: total %.3f = MAF read %.3f + BLS %.3f + codon extraction/power wig %.3f + scoring backend %.3f + raw wig output %.3f\n",
+                        st.total_seconds, st.read_seconds, st.bls_seconds, st.extract_seconds, st.backend_seconds, st.write_seconds - st.backend_seconds);
             } else {
                 const std::string out = score_msa(model, argv[i], sm, *backend);
                 fprintf(stderr, "%s -> %s\n", argv[i], out.c_str());

@@ -36,6 +36,42 @@ struct ScoringBackend {
     // run: CSR batch of blocks -> (phylo, anc) floats, NaN on model failure
     virtual void score_blocks(int algo, const uint8_t* codons, const uint64_t* offsets, size_t n_blocks, size_t leaf_stride,
                               bool compute_anc, uint32_t seed, float* phylo, float* anc) = 0;
+    // the six frames of a batch of alignments: nucleotide rows [n_leaves][row_stride], alignment k in columns
+    // [col0[k], col0[k]+len[k]); frame f of alignment k gets n_codons[6k+f] scores at out[offsets[6k+f]...] in FORWARD
+    // genome order.  Default: translate on the host and call score_sites_fixed (what the CPU oracle backend uses);
+    // the HIP backend overrides it with the device front end.
+    virtual void score_alignments_6frames(int n_leaves, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0,
+                                          const std::vector<uint32_t>& len, const std::vector<uint64_t>& start_pos,
+                                          const std::vector<uint64_t>& chrom_len, std::vector<double>& out, std::vector<uint64_t>& offsets,
+                                          std::vector<uint32_t>& n_codons)
+    {
+        const size_t n = col0.size();
+        offsets.assign(n * 6, 0);
+        n_codons.assign(n * 6, 0);
+        uint64_t total = 0;
+        for (size_t k = 0; k < n; ++k)
+            for (int f = 0; f < 6; ++f) {
+                const FrameView v = frame_view(start_pos[k], chrom_len[k], len[k], f < 3 ? '+' : '-', static_cast<unsigned>(f % 3 + 1));
+                offsets[k * 6 + f] = total;
+                n_codons[k * 6 + f] = static_cast<uint32_t>(v.n_codons);
+                total += v.n_codons;
+            }
+        out.assign(total, 0.0);
+        if (total == 0) return;
+        std::vector<uint8_t> codons(static_cast<size_t>(n_leaves) * total);
+        std::vector<std::string> rows(n_leaves);
+        for (size_t k = 0; k < n; ++k) {
+            for (int l = 0; l < n_leaves; ++l) rows[l].assign(nucl + static_cast<size_t>(l) * row_stride + col0[k], len[k]);
+            for (int f = 0; f < 6; ++f) {
+                if (f == 3) reverse_complement(rows);
+                const FrameView v = frame_view(start_pos[k], chrom_len[k], len[k], f < 3 ? '+' : '-', static_cast<unsigned>(f % 3 + 1));
+                extract_codons(rows, v.skip, v.n_codons, codons.data(), total, offsets[k * 6 + f]);
+            }
+        }
+        score_sites_fixed(codons.data(), total, total, out.data());
+        for (size_t k = 0; k < n; ++k)  // '-' strand codons were scored right-to-left
+            for (int f = 3; f < 6; ++f) std::reverse(out.begin() + offsets[k * 6 + f], out.begin() + offsets[k * 6 + f] + n_codons[k * 6 + f]);
+    }
 };
 
 struct BuildTracksParams {
@@ -61,7 +97,19 @@ inline FILE* open_out(const std::string& path, const char* mode)
 
 struct BuildTracksStats {
     size_t alignments = 0, ref_bases = 0, codon_frames = 0, backend_calls = 0;
-    double backend_seconds = 0.0;
+    double backend_seconds = 0.0;                       // inside ScoringBackend::score_sites_fixed (H2D + kernel + D2H)
+    double read_seconds = 0.0, bls_seconds = 0.0, extract_seconds = 0.0, write_seconds = 0.0, total_seconds = 0.0;
+};
+
+struct StopWatch {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double lap()
+    {
+        const auto t1 = std::chrono::steady_clock::now();
+        const double d = std::chrono::duration<double>(t1 - t0).count();
+        t0 = t1;
+        return d;
+    }
 };
 
 // build-tracks for one MAF file.  append: later files of a multi-file run append to the wigs.
@@ -79,15 +127,17 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
 
     struct Pending {  // one alignment waiting for its scores
         std::string chrom;
-        uint64_t start_pos;
+        uint64_t start_pos, chrom_len;
+        uint32_t len;
+        uint64_t col0;
         std::vector<double> bls;
-        FrameView frame[6];
-        size_t offset[6];
     };
     const size_t nl = static_cast<size_t>(model.n_leaves);
-    size_t cap = prm.batch_sites;
-    std::vector<uint8_t> codons(nl * cap);
+    size_t cap = prm.batch_sites / 2;  // columns per batch: one column yields two codon-frames
+    std::vector<char> nucl(nl * cap);
     std::vector<double> scores;
+    std::vector<uint64_t> offsets;
+    std::vector<uint32_t> n_codons;
     std::vector<Pending> pending;
     size_t used = 0;
     BuildTracksStats st;
@@ -96,17 +146,26 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
 
     auto flush = [&]() {
         if (pending.empty()) return;
-        scores.resize(used);
-        if (used > 0 && prm.write_raw) {
-            const auto t0 = std::chrono::steady_clock::now();
-            backend.score_sites_fixed(codons.data(), used, cap, scores.data());
-            st.backend_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        StopWatch fw;
+        if (prm.write_raw) {
+            std::vector<uint64_t> col0, start_pos, chrom_len;
+            std::vector<uint32_t> len;
+            for (const Pending& p : pending) {
+                col0.push_back(p.col0);
+                len.push_back(p.len);
+                start_pos.push_back(p.start_pos);
+                chrom_len.push_back(p.chrom_len);
+            }
+            backend.score_alignments_6frames(model.n_leaves, nucl.data(), cap, col0, len, start_pos, chrom_len, scores, offsets, n_codons);
+            st.backend_seconds += fw.lap();
             ++st.backend_calls;
+            st.codon_frames += scores.size();
         }
-        for (const Pending& p : pending) {
-            for (int fi = 0; fi < 6 && prm.write_raw; ++fi) {
-                const FrameView& v = p.frame[fi];
-                const bool minus = fi >= 3;
+        for (size_t k = 0; k < pending.size() && prm.write_raw; ++k) {
+            const Pending& p = pending[k];
+            for (int fi = 0; fi < 6; ++fi) {
+                const FrameView v = frame_view(p.start_pos, p.chrom_len, p.len, fi < 3 ? '+' : '-', static_cast<unsigned>(fi % 3 + 1));
+                const double* sc = scores.data() + offsets[k * 6 + fi];
                 int64_t prev = -4;
                 size_t bpos = v.bls_offset;
                 for (size_t xx = 0; xx < v.n_codons; ++xx, bpos += 3) {
@@ -115,26 +174,30 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
                     const int64_t pos = static_cast<int64_t>(v.start_pos + xx * 3);
                     if (prev + 3 != pos) fprintf(f_raw[fi], "fixedStep chrom=%s start=%" PRId64 " step=3 span=3\n", p.chrom.c_str(), pos);
                     prev = pos;
-                    // '-' strand codons were scored right-to-left: score xx of the forward track is the mirrored one
-                    const size_t idx = minus ? (v.n_codons - 1 - xx) : xx;
-                    print_trimmed(f_raw[fi], "%.3f", static_cast<float>(scores[p.offset[fi] + idx]));
+                    print_trimmed(f_raw[fi], "%.3f", static_cast<float>(sc[xx]));
                 }
             }
         }
         pending.clear();
         used = 0;
+        st.write_seconds += fw.lap();
     };
 
     MafReader reader(maf_path, model.name_to_leaf, model.n_leaves, /*concatenate=*/true, prm.verbose);
     Alignment aln;
+    StopWatch total, sw;
     while (reader.next(aln)) {
+        st.read_seconds += sw.lap();
         ++st.alignments;
         const size_t len = aln.length();
         st.ref_bases += len;
         Pending p;
         p.chrom = aln.chrom;
         p.start_pos = aln.start_pos;
-        bls.per_base(aln, &p.bls);
+        p.chrom_len = aln.chrom_len;
+        p.len = static_cast<uint32_t>(len);
+        bls.per_base(aln, &p.bls);  // also validates every character (the reference exits on anything but ACGTNacgtn-.)
+        st.bls_seconds += sw.lap();
 
         if (f_power) {  // power track: frame 3 of the + strand, mean of the three per-base scores
             int64_t skip = static_cast<int64_t>(3 - static_cast<int64_t>(aln.start_pos)) % 3;
@@ -146,27 +209,20 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
                 print_trimmed(f_power, "%.4f", static_cast<float>((p.bls[pos] + p.bls[pos + 1] + p.bls[pos + 2]) / 3.0));
         }
         if (prm.write_raw) {
-            size_t need = 0;
-            for (int fi = 0; fi < 6; ++fi) {
-                p.frame[fi] = frame_view(aln.start_pos, aln.chrom_len, len, fi < 3 ? '+' : '-', static_cast<unsigned>(fi % 3 + 1));
-                need += p.frame[fi].n_codons;
+            if (used + len > cap) flush();
+            if (len > cap) {  // one alignment larger than the batch buffer
+                cap = len;
+                nucl.assign(nl * cap, 'N');
             }
-            if (used + need > cap) flush();
-            if (need > cap) {  // one alignment larger than the batch buffer
-                cap = need;
-                codons.assign(nl * cap, 0);
-            }
-            for (int fi = 0; fi < 6; ++fi) {
-                if (fi == 3) reverse_complement(aln.seqs);
-                p.offset[fi] = used;
-                extract_codons(aln.seqs, p.frame[fi].skip, p.frame[fi].n_codons, codons.data(), cap, used);
-                used += p.frame[fi].n_codons;
-                st.codon_frames += p.frame[fi].n_codons;
-            }
+            p.col0 = used;
+            for (size_t l = 0; l < nl; ++l) memcpy(nucl.data() + l * cap + used, aln.seqs[l].data(), len);
+            used += len;
         }
         pending.push_back(std::move(p));
+        st.extract_seconds += sw.lap();
     }
     flush();
+    st.total_seconds = total.lap();
     if (f_power) fclose(f_power);
     for (FILE* f : f_raw)
         if (f) fclose(f);

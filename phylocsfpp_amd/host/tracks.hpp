@@ -17,6 +17,7 @@
 #include <string>
 #include <vector>
 
+#include "../csrc/frames.hpp"
 #include "maf_reader.hpp"
 #include "model_io.hpp"
 
@@ -63,37 +64,9 @@ inline void reverse_complement(std::vector<std::string>& rows)
     }
 }
 
-// Frame arithmetic of update_seqs.  `rows` must already be reverse-complemented for strand '-'.
-struct FrameView {
-    unsigned skip = 0;       // leading columns (of the rows as given) before the first codon
-    size_t n_codons = 0;
-    uint64_t start_pos = 0;  // genome position (1-based) of the first emitted score
-    size_t bls_offset = 0;   // index into the forward per-base BLS vector of the first score
-};
-
-inline FrameView frame_view(uint64_t orig_start, uint64_t chrom_len, size_t len, char strand, unsigned frame)
-{
-    FrameView v;
-    int64_t skip;
-    if (strand == '+') {
-        skip = (static_cast<int64_t>(frame) - static_cast<int64_t>(orig_start)) % 3;
-    } else {
-        skip = (static_cast<int64_t>(frame) - static_cast<int64_t>(chrom_len - (orig_start + len) + 2)) % 3;
-    }
-    if (skip < 0) skip += 3;
-    if (static_cast<uint64_t>(skip) > len) skip = static_cast<int64_t>(len);
-    v.skip = static_cast<unsigned>(skip);
-    v.n_codons = (len - v.skip) / 3;
-    if (strand == '+') {
-        v.start_pos = orig_start + v.skip;
-        v.bls_offset = v.skip;
-    } else {
-        // codons are read right-to-left; the 0-2 left-over bases sit at the left end of the forward strand
-        v.start_pos = orig_start + (len - v.skip) % 3;
-        v.bls_offset = (len - v.skip) % 3;
-    }
-    return v;
-}
+// Frame arithmetic of update_seqs: shared with the device front end (csrc/frames.hpp)
+using pcsf::FrameView;
+using pcsf::frame_view;
 
 // appends the codons of one frame, leaf-major, into dst[leaf*stride + offset ...]
 inline void extract_codons(const std::vector<std::string>& rows, unsigned skip, size_t n_codons, uint8_t* dst, size_t stride, size_t offset)
