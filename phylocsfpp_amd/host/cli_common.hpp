@@ -36,6 +36,33 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
 {
     if (argc < 2) return usage(argv[0]);
     const std::string cmd = argv[1];
+    if (cmd == "dump-alignments") {  // diagnostics/tests: what the MAF reader yields (build-tracks semantics unless --blocks 1)
+        bool blocks = false;
+        int j = 2;
+        if (j + 1 < argc && std::string(argv[j]) == "--blocks") {
+            blocks = parse_bool(argv[j + 1]);
+            j += 2;
+        }
+        if (argc - j < 2) return usage(argv[0]);
+        try {
+            const std::string prefix = argv[j];
+            std::string al = dirname_of(prefix) + "/species_aliases.tsv";
+            if (FILE* f = fopen(al.c_str(), "r")) fclose(f);
+            else al.clear();
+            const Model model = load_model(prefix, al);
+            MafReader rd(argv[j + 1], model.name_to_leaf, model.n_leaves, !blocks, false);
+            Alignment aln;
+            while (rd.next(aln)) {
+                printf("%s\t%" PRIu64 "\t%zu\t%c\t%" PRIu64, aln.chrom.c_str(), aln.start_pos, aln.length(), aln.strand, aln.chrom_len);
+                for (const auto& r : aln.seqs) printf("\t%s", r.c_str());
+                printf("\n");
+            }
+        } catch (const std::exception& e) {
+            fprintf(stderr, "error: %s\n", e.what());
+            return 1;
+        }
+        return 0;
+    }
     if (cmd != "build-tracks" && cmd != "score-msa") return usage(argv[0]);
     BuildTracksParams bt;
     ScoreMsaParams sm;

@@ -1,0 +1,116 @@
+"""CPU: the C++ host layer (phylocsfpp_amd/host/: MAF reader, frames, BLS, formatting) on crafted inputs,
+through the oracle-backed test CLI.  The golden-file tests pin the common path; these pin the corner
+cases the goldens do not reach: block concatenation rules, N padding, reference
+gap removal, the 1 Mb break point, '-' strand frames, trimming of printed numbers."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "oracle", "_build", "oracle_cli")
+MODEL = os.path.join(ROOT, "tests", "golden", "models", "53birds")   # first leaves: chicken, japanese_quail, turkey
+
+
+@pytest.fixture(scope="module")
+def cli():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return CLI
+
+
+def _dump(cli, path, blocks=False):
+    out = subprocess.check_output([cli, "dump-alignments"] + (["--blocks", "1"] if blocks else []) + [MODEL, path], text=True)
+    rows = []
+    for line in out.splitlines():
+        f = line.split("\t")
+        rows.append(dict(chrom=f[0], start=int(f[1]), length=int(f[2]), strand=f[3], chrom_len=int(f[4]), seqs=f[5:]))
+    return rows
+
+
+def _write(tmp_path, text, name="t.maf"):
+    p = tmp_path / name
+    p.write_text(text)
+    return str(p)
+
+
+def test_concatenation_padding_and_reference_gaps(cli, tmp_path):
+    maf = """##maf version=1
+a score=1
+s chicken.chr1 99 6 + 1000 AC-GTA-A
+s turkey.chrX 5 8 + 500 ACTGTACA
+s unknownSpecies.chr1 0 8 + 9 AAAAAAAA
+
+a score=2
+s chicken.chr1 105 3 + 1000 GGG
+s japanese_quail.c 7 3 - 50 ccc
+
+a score=3
+s chicken.chr1 200 2 + 1000 TT
+"""
+    rows = _dump(cli, _write(tmp_path, maf))
+    assert len(rows) == 2                                   # blocks 1+2 are contiguous (99+6 == 105), block 3 is not
+    a = rows[0]
+    assert (a["chrom"], a["start"], a["length"], a["strand"], a["chrom_len"]) == ("chr1", 100, 9, "+", 1000)
+    assert a["seqs"][0] == "ACGTAAGGG"                      # chicken: gap columns removed
+    assert a["seqs"][2] == "ACGTAANNN"                      # turkey: reference-gap columns dropped, missing block -> N
+    assert a["seqs"][1] == "NNNNNNccc"                      # quail: absent from block 1 -> N padding
+    assert all(s == "N" * 9 for s in a["seqs"][3:])
+    assert rows[1]["start"] == 201 and rows[1]["seqs"][0] == "TT"
+    # score-msa mode: every block alone
+    rows = _dump(cli, _write(tmp_path, maf), blocks=True)
+    assert [r["length"] for r in rows] == [6, 3, 2]
+
+
+def test_break_point_at_one_megabase(cli, tmp_path):
+    # block B crosses 1,000,000 (1-based 999,996..1,000,003); C and D supply the two extra bases; E would follow
+    def s(start, seq):
+        return "a score=0\ns chicken.chr2 %d %d + 5000000 %s\n\n" % (start, len(seq), seq)
+    maf = "##maf\n" + s(999990, "AAAAA") + s(999995, "CCCCCCCC") + s(1000003, "G") + s(1000004, "TTT") + s(1000007, "ACAC")
+    rows = _dump(cli, _write(tmp_path, maf))
+    # first alignment: A + B (break-point block) + exactly two more reference bases, truncated there
+    assert rows[0]["start"] == 999991 and rows[0]["seqs"][0] == "AAAAA" + "CCCCCCCC" + "G" + "T"
+    # the next alignment restarts at the block AFTER the break-point block (blocks C, D are read twice)
+    assert rows[1]["start"] == 1000004 and rows[1]["seqs"][0] == "G" + "TTT" + "ACAC"
+    assert len(rows) == 2
+
+
+def test_minus_strand_reference_is_rejected_in_build_tracks_mode(cli, tmp_path):
+    maf = "a score=0\ns chicken.chr1 10 4 - 1000 ACGT\n"
+    path = _write(tmp_path, maf)
+    r = subprocess.run([cli, "dump-alignments", MODEL, path], capture_output=True, text=True)
+    assert r.returncode != 0 and "+ strand" in r.stderr
+    assert _dump(cli, path, blocks=True)[0]["strand"] == "-"
+
+
+def test_frames_and_wig_text_on_a_tiny_alignment(cli, tmp_path):
+    # 14 columns at 1-based position 101 on a chromosome of length 1000, three species with bases everywhere
+    seq = "ATGGCCAAGTTTGA"
+    maf = "a score=0\n" + "".join("s %s.chrZ 100 14 + 1000 %s\n" % (sp, seq) for sp in ("chicken", "turkey", "japanese_quail", "barn_owl"))
+    out = tmp_path / "out"
+    subprocess.check_call([cli, "build-tracks", "--power-threshold", "0", "--output", str(out), MODEL, _write(tmp_path, maf)],
+                          stderr=subprocess.DEVNULL)
+    def starts(name):
+        lines = open(out / name).read().splitlines()
+        return [l for l in lines if l.startswith("fixedStep")], [l for l in lines if not l.startswith("fixedStep")]
+    # '+' frame f: skip = (f - 101) mod 3 -> f=1: 2, f=2: 0, f=3: 1 ; positions 101+skip
+    for f, skip in ((1, 2), (2, 0), (3, 1)):
+        hdr, vals = starts("PhyloCSFRaw+%d.wig" % f)
+        assert hdr == ["fixedStep chrom=chrZ start=%d step=3 span=3" % (101 + skip)]
+        assert len(vals) == (14 - skip) // 3
+    # '-' frame f: skip = (f - (1000 - (101+14) + 2)) mod 3 = (f - 887) mod 3 -> f=1: 2, f=2: 0, f=3: 1 ; start = 101 + (14-skip)%3
+    for f, skip in ((1, 2), (2, 0), (3, 1)):
+        hdr, vals = starts("PhyloCSFRaw-%d.wig" % f)
+        assert hdr == ["fixedStep chrom=chrZ start=%d step=3 span=3" % (101 + (14 - skip) % 3)]
+        assert len(vals) == (14 - skip) // 3
+    hdr, vals = starts("PhyloCSFpower.wig")
+    assert hdr == ["fixedStep chrom=chrZ start=%d step=3 span=3" % (101 + (3 - 101) % 3)]
+    # number formatting: at least one decimal, no trailing zeros beyond it
+    for v in vals:
+        assert "." in v and not (v.endswith("0") and not v.endswith(".0"))
+
+
+def test_invalid_character_is_an_error(cli, tmp_path):
+    maf = "a score=0\ns chicken.chr1 10 4 + 1000 ACXT\ns turkey.chr1 10 4 + 1000 ACGT\n"
+    r = subprocess.run([cli, "build-tracks", "--output", str(tmp_path / "o"), MODEL, _write(tmp_path, maf)], capture_output=True, text=True)
+    assert r.returncode != 0 and "unexpected character" in r.stderr
