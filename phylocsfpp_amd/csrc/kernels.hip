@@ -186,6 +186,10 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     double lnz0 = 0.0, lnz1 = 0.0, anc0 = 0.0, anc1 = 0.0;
     const bool stamping = STAMP && p.stamps != nullptr && blockIdx.x == p.stamp_block && wave == 0;
     (void)stamping;
+    // diagnostic build: per-segment cycle sums, kept in scalar registers until the end of the kernel
+    unsigned long long seg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = STAMP ? stamp_now() : 0ull;
+    unsigned seg_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)seg_sum; (void)seg_cnt; (void)stamp_prev;
 
     for (int model = 0; model < p.n_passes; ++model) {
         const double* __restrict__ leaf_tab = p.leaf_tab + static_cast<size_t>(table0 + model) * p.n_leaves * LEAF_TABLE_DOUBLES_DEV;
@@ -197,10 +201,20 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
 
         // The op word and the codon bytes of op i+1 are fetched from LDS while op i runs, so that no LDS
         // round trip (op word -> leaf index -> codon byte) sits between two products.
+#define PCSF_STAMP_RAW(K)                                                            \
+    if constexpr (STAMP) {                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        const unsigned long long ts_ = stamp_now();                                  \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        seg_sum[K] += ts_ - stamp_prev;                                              \
+        seg_cnt[K] += 1;                                                             \
+        stamp_prev = ts_;                                                            \
+    }
         uint32_t op = __builtin_amdgcn_readfirstlane(lprog[0]);
         uint32_t word_ahead = lprog[p.n_ops > 1 ? 1 : 0];
         uint32_t ca = my_cod[((op >> 14) & 0x3fff) * SITES], cb = my_cod[(op & 0x3fff) * SITES];
         for (int ip = 0; ip < p.n_ops; ++ip) {
+            PCSF_STAMP_RAW(7)
             const uint32_t code = op >> 28;
             const int a = (op >> 14) & 0x3fff, b = op & 0x3fff;
             const uint32_t cod_a = ca, cod_b = cb;
@@ -210,33 +224,25 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
             word_ahead = lprog[ip + 2 < p.n_ops ? ip + 2 : p.n_ops - 1];
             ca = my_cod[((op >> 14) & 0x3fff) * SITES];
             cb = my_cod[(op & 0x3fff) * SITES];
-            if constexpr (STAMP) {
-                __builtin_amdgcn_sched_barrier(0);
-                const unsigned long long ts_ = stamp_now();
-                __builtin_amdgcn_sched_barrier(0);
-                if (stamping && lane == 0) p.stamps[(static_cast<size_t>(model) * p.n_ops + ip) * 8 + 5] = ts_;
-            }
+            PCSF_STAMP_RAW(5)
 
             // Every op except the first cherry and the root starts with a product.  Its barrier
             // (a) completes this wave's LDS-DMA of the current slot (vmcnt(0)), (b) publishes all
             // waves' parts, (c) retires all reads of the other buffer, which the next slot's DMA
             // overwrites.  Leaf rows needed after the product are requested before the MFMAs.
+// segment K ends here: add (now - previous stamp) to its scalar sum; nothing is stored inside the loop
+// (a store would put its own latency behind the next vmcnt wait and distort what is measured)
 #define PCSF_STAMP(K)                                                                \
     if constexpr (STAMP) {                                                           \
         __builtin_amdgcn_sched_barrier(0);                                           \
         const unsigned long long ts_ = stamp_now();                                  \
         __builtin_amdgcn_sched_barrier(0);                                           \
-        if (stamping && lane == 0) p.stamps[(static_cast<size_t>(model) * p.n_ops + ip) * 8 + (K)] = ts_; \
+        seg_sum[K] += ts_ - stamp_prev;                                              \
+        seg_cnt[K] += 1;                                                             \
+        stamp_prev = ts_;                                                            \
     }
 #define PCSF_PRODUCT_PROLOGUE()                                                      \
     PCSF_STAMP(0)                                                                    \
-    if constexpr (STAMP) { /* residency census: HW_ID and op start times of the first 1024 work-groups */ \
-        if (p.stamps && blockIdx.x < 1024 && wave == 0 && lane == 0 && (ip == 10 || ip == 40 || ip == 70 || ip == 100)) {  \
-            unsigned long long* cz = p.stamps + static_cast<size_t>(2) * p.n_ops * 8 + static_cast<size_t>(blockIdx.x) * 16; \
-            if (ip == 10 && model == 0) cz[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);  \
-            cz[1 + model * 4 + (ip - 10) / 30] = stamp_now();                        \
-        }                                                                            \
-    }                                                                                \
     __syncthreads();                                                                 \
     PCSF_STAMP(1)                                                                    \
     const double2_t* buf = lfrag + (slot & 1) * (FRAG_DOUBLES_DEV / 2);              \
@@ -317,7 +323,6 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
                         cur[2 * i + 1] = acc[(2 * i + 1) >> 2][(2 * i + 1) & 3] * ra.v[i].y;
                     }
                     PCSF_STAMP(3)
-                    PCSF_STAMP(4)
                     break;
                 }
                 case F_MM_PUSH_CHERRY0_DEV + 0: PCSF_PUSH_CHERRY(0) break;
@@ -342,7 +347,8 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
                         for (int q = 0; q < 16; ++q) t += w[q] * cur[q];
                         t += __shfl_xor(t, 16);
                         t += __shfl_xor(t, 32);
-                        t = (z == 0.0) ? 0.0 : t / z;
+                        const double ratio = t / ((z == 0.0) ? 1.0 : z);  // select, not a branch: keeps the op loop uniform
+                        t = (z == 0.0) ? 0.0 : ratio;
                         if (model == 0) anc0 = t;
                         else anc1 = t;
                     }
@@ -351,12 +357,20 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
             }
 #undef PCSF_PRODUCT_PROLOGUE
 #undef PCSF_STAMP
+#undef PCSF_STAMP_RAW
 #undef PCSF_STAGE_SLOT
 #undef PCSF_PUSH_CHERRY
 #undef PCSF_POP
         }
     }
 
+    if constexpr (STAMP) {
+        if (stamping && lane == 0)
+            for (int k = 0; k < 8; ++k) {
+                p.stamps[k] = seg_sum[k];
+                p.stamps[8 + k] = seg_cnt[k];
+            }
+    }
     if (g4 == 0 && valid) {
         if (p.out_score) p.out_score[my_site] = 10.0 * (lnz0 - lnz1) / log(10.0);
         if (p.out_lnz) {
