@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libphylocsf_amd.so")
-SOURCES = ["kernels.hip", "kernels_ring.hip", "expm.hip", "frontend.hip", "api.cpp", "blocks.cpp"]
+SOURCES = ["kernels.hip", "expm.hip", "frontend.hip", "api.cpp", "blocks.cpp"]
 HEADERS = ["kernels.h", "hostmath.hpp", "schedule.hpp", "ctx.hpp", "optimizer.hpp", "frames.hpp", os.path.join("..", "..", "include", "phylocsf_amd.h")]
 
 
@@ -44,8 +44,7 @@ def build(force=False, verbose=False):
     # structurises even uniform regions, which turns the switch into a chain of "Flow" blocks whose phi copies
     # cost ~80 v_mov_b64 per op (and 26 spilled VGPRs).  Leaving uniform regions as plain scalar branches
     # removes both (233 VGPRs, no spills).
-    per_source = {"kernels.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"],
-                  "kernels_ring.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"]}
+    per_source = {"kernels.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"]}
     for src in SOURCES:
         obj = os.path.join(build_dir, src + ".o")
         cmd = [hipcc()] + common + per_source.get(src, []) + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]

@@ -81,11 +81,11 @@ __global__ __launch_bounds__(256) void expm_kernel(const ExpmParams p)
         }
     }
     if (job.leaf >= 0) {
-        // leaf table: tab[(code*4 + g)*16 + q] = P[4q+g][code], code 64 = row sum
+        // leaf table: tab[((code*8 + q2)*4 + g)*2 + e] = P[4(2 q2 + e) + g][code], code 64 = row sum
         double* dst = p.leaf_tab + (static_cast<size_t>(job.table) * p.n_leaves + job.leaf) * LEAF_TABLE_DOUBLES_DEV;
         for (int idx = tid; idx < LEAF_TABLE_DOUBLES_DEV; idx += 256) {
-            const int q = idx & 15, g = (idx >> 4) & 3, code = idx >> 6;
-            const int a = 4 * q + g;
+            const int e = idx & 1, g = (idx >> 1) & 3, q2 = (idx >> 3) & 7, code = idx >> 6;
+            const int a = 4 * (2 * q2 + e) + g;
             dst[idx] = code < 64 ? P[a * 65 + code] : rowsum[a];
         }
     }

@@ -24,7 +24,7 @@ struct PruneParams {
     int n_leaves;
     int n_passes;            // table sets walked per site: 2 = coding then non-coding (tracks / FIXED), 1 = one model
     const double* frag;      // [table][n_edges][4096]  branch matrices of internal children, fragment order
-    const double* leaf_tab;  // [table][n_leaves][65][4][16] leaf-message tables
+    const double* leaf_tab;  // [table][n_leaves][65 codes][8 q2][4 g][2 e] leaf-message tables
     const double* prior;     // [table][4][16] equilibrium prior in lane order
     const double* anc_weight;// [table][4][16] ln(prior)*prior in lane order (only read if out_anc)
     // block mode (variant 16): work-group w scores sites [wg_site0[w], wg_site_end[w]) (at most 64)
@@ -46,7 +46,6 @@ struct PruneParams {
 // 2 = variant 0 with in-kernel stamps (diagnostic only), 16 = block mode (per-work-group windows and tables)
 hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t stream, size_t extra_lds = 0);
 int prune_variant_count();
-hipError_t launch_prune_ring(const PruneParams& p, int variant, hipStream_t stream, size_t extra_lds);
 
 }  // namespace pcsf
 

@@ -25,23 +25,28 @@ __device__ __forceinline__ double4_t mfma_f64(double a, double b, double4_t c)
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-// One lane's 128-byte segment of a leaf-message row: table[leaf][code][g4][0..15]
+// Leaf-message rows: table[leaf][code][q2][g][e] = P[4(2 q2 + e) + g][code].  A lane (site sl, group g) needs
+// the sixteen states 4q+g; piece i (q = 2i, 2i+1) is 16 bytes at row + (i*4 + g)*16, so the four lanes of a site
+// read 64 contiguous bytes per instruction and one wave-instruction touches 16 half cache lines.  (With the
+// lane's 128 bytes stored contiguously every instruction touched 64 different lines and the L1 tag pipe, not
+// the matrix pipe, set the pace of the leaf arms.)
 struct LeafRow {
     double2_t v[8];
 };
-
-__device__ __forceinline__ LeafRow load_leaf_row(const double* __restrict__ leaf_tab, int leaf, uint32_t code, int g4)
-{
-    const double2_t* r2 = reinterpret_cast<const double2_t*>(leaf_tab + ((static_cast<size_t>(leaf) * 65 + code) * 4 + g4) * 16);
-    LeafRow r;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r.v[i] = r2[i];
-    return r;
-}
+constexpr int ROW_PIECE_STRIDE = 4;  // in 16-byte units
 
 __device__ __forceinline__ const double2_t* leaf_row_ptr(const double* __restrict__ leaf_tab, int leaf, uint32_t code, int g4)
 {
-    return reinterpret_cast<const double2_t*>(leaf_tab + ((static_cast<size_t>(leaf) * 65 + code) * 4 + g4) * 16);
+    return reinterpret_cast<const double2_t*>(leaf_tab + (static_cast<size_t>(leaf) * 65 + code) * 64) + g4;
+}
+
+__device__ __forceinline__ LeafRow load_leaf_row(const double* __restrict__ leaf_tab, int leaf, uint32_t code, int g4)
+{
+    const double2_t* r2 = leaf_row_ptr(leaf_tab, leaf, code, g4);
+    LeafRow r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = r2[i * ROW_PIECE_STRIDE];
+    return r;
 }
 
 // acc[t] (t = 0..3, output states 16t..16t+15) <- P x cur, with P read from its LDS fragment image:
@@ -128,17 +133,37 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     const int table0 = BLOCKS ? static_cast<int>(p.wg_table[blockIdx.x]) : 0;
     const size_t my_site = block_site0 + wave * 16 + sl;
     const bool valid = my_site < site_end;
+    const unsigned long long stamp_t0 = STAMP ? stamp_now() : 0ull;
+    (void)stamp_t0;
 
     // ---- stage this work-group's codon columns into LDS (clamped to 0..64; 64 beyond the end)
-    for (int idx = tid; idx < p.n_leaves * SITES; idx += NW * 64) {
-        const int leaf = idx / SITES, s = idx - leaf * SITES;
-        const size_t site = block_site0 + s;
-        unsigned c = 64u;
-        if (site < site_end) {
-            c = p.codons[static_cast<size_t>(leaf) * p.leaf_stride + site];
-            c = c > 64u ? 64u : c;
+    // A full, 16-byte aligned window moves as one 16-byte load per thread (58 leaves x 64 sites = 232 pieces):
+    // the byte-wise loop below costs ~15 dependent round trips per work-group while the CU's other group runs alone.
+    const bool whole_window = block_site0 + SITES <= site_end && ((block_site0 | p.leaf_stride | reinterpret_cast<size_t>(p.codons)) & 15) == 0;
+    if (whole_window) {
+        constexpr int PIECES = SITES / 16;
+        for (int idx = tid; idx < p.n_leaves * PIECES; idx += NW * 64) {
+            const int leaf = idx / PIECES, piece = idx % PIECES;
+            uint4 v = *reinterpret_cast<const uint4*>(p.codons + static_cast<size_t>(leaf) * p.leaf_stride + block_site0 + piece * 16);
+            auto clamp64 = [](uint32_t x) {  // per byte: min(x, 64)
+                const uint32_t over = (((x & 0x7f7f7f7fu) + 0x3f3f3f3fu) | x) & 0x80808080u;  // bit 7 of each byte > 64
+                const uint32_t mask = (over >> 7) * 0xffu;
+                return (x & ~mask) | (0x40404040u & mask);
+            };
+            v.x = clamp64(v.x); v.y = clamp64(v.y); v.z = clamp64(v.z); v.w = clamp64(v.w);
+            *reinterpret_cast<uint4*>(lcod + leaf * SITES + piece * 16) = v;
         }
-        lcod[idx] = static_cast<unsigned char>(c);
+    } else {
+        for (int idx = tid; idx < p.n_leaves * SITES; idx += NW * 64) {
+            const int leaf = idx / SITES, s = idx - leaf * SITES;
+            const size_t site = block_site0 + s;
+            unsigned c = 64u;
+            if (site < site_end) {
+                c = p.codons[static_cast<size_t>(leaf) * p.leaf_stride + site];
+                c = c > 64u ? 64u : c;
+            }
+            lcod[idx] = static_cast<unsigned char>(c);
+        }
     }
     for (int i = tid; i < p.n_ops; i += NW * 64) lprog[i] = p.program[i];
     const unsigned char* my_cod = lcod + wave * 16 + sl;  // + leaf*SITES
@@ -187,15 +212,20 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     const bool stamping = STAMP && p.stamps != nullptr && blockIdx.x == p.stamp_block && wave == 0;
     (void)stamping;
     // diagnostic build: per-segment cycle sums, kept in scalar registers until the end of the kernel
-    unsigned long long seg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = STAMP ? stamp_now() : 0ull;
+    unsigned long long seg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = stamp_t0;
     unsigned seg_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)seg_sum; (void)seg_cnt; (void)stamp_prev;
 
+    if constexpr (STAMP) {  // segment 6: work-group prologue (codons + program into LDS, first slot requested)
+        seg_sum[6] = stamp_now() - stamp_prev;
+        seg_cnt[6] = 1;
+        stamp_prev += seg_sum[6];
+    }
     for (int model = 0; model < p.n_passes; ++model) {
         const double* __restrict__ leaf_tab = p.leaf_tab + static_cast<size_t>(table0 + model) * p.n_leaves * LEAF_TABLE_DOUBLES_DEV;
         const double* __restrict__ prior = p.prior + static_cast<size_t>(table0 + model) * 64 + g4 * 16;
 
-        double cur[16], nxt[16];
+        double cur[16];
         double4_t acc[4];
         double stk[MAX_STACK_DEPTH_DEV][16];
 
@@ -255,31 +285,26 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     if constexpr (j == 1 && q < CHUNKS_PER_WAVE) {                                   \
         stage_piece(std::integral_constant<int, (q < CHUNKS_PER_WAVE ? q : 0)>{}, stage_next, (this_slot + 1) & 1); \
     }
-// cherry rows arrive a quarter (4 states per lane = 2 x 16 B per row) at a time: quarter k is
-// requested in k-steps 3k (row a: slots 2,3) and 3k+1 (row b: slots 2,3) and multiplied into nxt
-// in k-step 3k+5 (slots 2,3), so at most two quarters are in registers
+// Cherry rows: piece i of row a in k-step i slot 2, of row b in k-step i slot 3 (i = 0..7); multiplied after the
+// product, by which time the last piece has been on its way for eight k-steps.
 #define PCSF_PUSH_CHERRY(D)                                                          \
     {                                                                                \
         PCSF_PRODUCT_PROLOGUE()                                                      \
-        const double2_t* pa = leaf_row_ptr(leaf_tab, a, cod_a, g4);      \
-        const double2_t* pb = leaf_row_ptr(leaf_tab, b, cod_b, g4);      \
-        double2_t xa[2][2], xb[2][2];                                                \
+        const double2_t* pa = leaf_row_ptr(leaf_tab, a, cod_a, g4);                  \
+        const double2_t* pb = leaf_row_ptr(leaf_tab, b, cod_b, g4);                  \
+        LeafRow ra, rb;                                                              \
         product(buf, lane, cur, acc, [&](auto qc, auto jc) {                         \
             constexpr int q = decltype(qc)::value;                                   \
             constexpr int j = decltype(jc)::value;                                   \
             PCSF_STAGE_SLOT(q, j)                                                    \
-            if constexpr (j >= 2 && q % 3 == 0 && q / 3 < 4) xa[(q / 3) & 1][j - 2] = pa[2 * (q / 3) + (j - 2)]; \
-            if constexpr (j >= 2 && q % 3 == 1 && q / 3 < 4) xb[(q / 3) & 1][j - 2] = pb[2 * (q / 3) + (j - 2)]; \
-            if constexpr (j >= 2 && q >= 5 && (q - 5) % 3 == 0 && (q - 5) / 3 < 4) {  \
-                constexpr int k = (q - 5) / 3;                                       \
-                nxt[4 * k + 2 * (j - 2) + 0] = xa[k & 1][j - 2].x * xb[k & 1][j - 2].x; \
-                nxt[4 * k + 2 * (j - 2) + 1] = xa[k & 1][j - 2].y * xb[k & 1][j - 2].y; \
-            }                                                                        \
+            if constexpr (j == 2 && q < 8) ra.v[q] = pa[q * ROW_PIECE_STRIDE];       \
+            if constexpr (j == 3 && q < 8) rb.v[q] = pb[q * ROW_PIECE_STRIDE];       \
         });                                                                          \
-        PCSF_STAMP(2)                                                                \
-        _Pragma("unroll") for (int q = 0; q < 16; ++q) {                             \
-            stk[D][q] = acc[q >> 2][q & 3];                                          \
-            cur[q] = nxt[q];                                                         \
+        PCSF_STAMP(4)                                                                \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) stk[D][q] = acc[q >> 2][q & 3]; \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                              \
+            cur[2 * i] = ra.v[i].x * rb.v[i].x;                                      \
+            cur[2 * i + 1] = ra.v[i].y * rb.v[i].y;                                  \
         }                                                                            \
         PCSF_STAMP(3)                                                                \
     }
@@ -314,7 +339,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
                         constexpr int q = decltype(qc)::value;
                         constexpr int j = decltype(jc)::value;
                         PCSF_STAGE_SLOT(q, j)
-                        if constexpr (j == 2 && q >= 4 && q < 12) ra.v[q - 4] = pa[q - 4];  // one 16-byte piece per k-step
+                        if constexpr (j == 2 && q >= 4 && q < 12) ra.v[q - 4] = pa[(q - 4) * ROW_PIECE_STRIDE];  // one 16-byte piece per k-step
                     });
                     PCSF_STAMP(2)
 #pragma unroll
@@ -411,11 +436,10 @@ hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t str
         case 1: return launch_impl<8, false, false>(p, stream, extra_lds);
         case 2: return launch_impl<4, true, false>(p, stream, extra_lds);  // diagnostic: in-kernel stamps
         case 16: return launch_impl<4, false, true>(p, stream, extra_lds); // per-work-group windows/tables
-        case 8: case 9: case 10: case 24: return launch_prune_ring(p, variant, stream, extra_lds);  // 3-slot LDS ring (kernels_ring.hip)
         default: return hipErrorInvalidValue;
     }
 }
 
-int prune_variant_count() { return 11; }
+int prune_variant_count() { return 3; }
 
 }  // namespace pcsf

@@ -210,8 +210,10 @@ inline void to_fragment_order(const double* P, double* frag)
                     frag[((q * 2 + h) * 64 + lane) * 2 + e] = P[(16 * (2 * h + e) + (lane & 15)) * 64 + 4 * q + (lane >> 4)];
 }
 
-// leaf messages: table[code][g][q] = P[4q+g][code] for code < 64, and for code 64 (marginalise)
-// the row sum of P accumulated in index order like the reference's loop (src/fixed_lik.hpp:111-117)
+// leaf messages: table[code][q2][g][e] = P[4(2 q2 + e) + g][code] for code < 64, and for code 64
+// (marginalise) the row sum of P accumulated in index order like the reference's loop
+// (src/fixed_lik.hpp:111-117).  Lane (site, g) of a tile reads the 16-byte pieces (q2, g, 0..1), q2 = 0..7,
+// so the four lanes of a site read 64 contiguous bytes.
 constexpr int LEAF_TABLE_DOUBLES = 65 * 64;
 
 inline void to_leaf_table(const double* P, double* table)
@@ -226,7 +228,7 @@ inline void to_leaf_table(const double* P, double* table)
                     v = 0.0;
                     for (int b = 0; b < 64; ++b) v += P[a * 64 + b];
                 }
-                table[(code * 4 + g) * 16 + q] = v;
+                table[((code * 8 + (q >> 1)) * 4 + g) * 2 + (q & 1)] = v;
             }
 }
 

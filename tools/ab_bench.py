@@ -15,8 +15,7 @@ idx = np.random.default_rng(2).integers(0, 16384, size=n_sites)
 d = torch.from_numpy(np.ascontiguousarray(pool[:, idx])).cuda()
 out = torch.empty(n_sites, dtype=torch.float64, device="cuda")
 want = m.run_tracks(pool[:, idx[:256]])
-configs = [("v0", dict(PCSF_PRUNE_VARIANT="0")), ("v1 8w", dict(PCSF_PRUNE_VARIANT="1")),
-           ("v8 ring 4w", dict(PCSF_PRUNE_VARIANT="8")), ("v9 ring 8w", dict(PCSF_PRUNE_VARIANT="9"))]
+configs = [("v0", dict(PCSF_PRUNE_VARIANT="0")), ("v1 8w", dict(PCSF_PRUNE_VARIANT="1"))]
 if len(sys.argv) > 3:
     configs = [c for c in configs if c[0].split()[0] in sys.argv[3].split(",")]
 ctxs = []
