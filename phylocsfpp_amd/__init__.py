@@ -13,7 +13,8 @@ import numpy as np
 __all__ = ["ScoringContext", "PcsfError", "library_path", "load_library", "FIXED", "MLE", "OMEGA"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libphylocsf_amd.so")
+# PCSF_LIBRARY: load another build of the same HIP library (kernel experiments); never a CPU implementation
+_LIB_PATH = os.environ.get("PCSF_LIBRARY") or os.path.join(_HERE, "libphylocsf_amd.so")
 
 MLE, FIXED, OMEGA = 0, 1, 2  # algorithm_t, src/run.hpp:16-21
 

@@ -15,7 +15,8 @@ idx = np.random.default_rng(2).integers(0, 16384, size=n_sites)
 d = torch.from_numpy(np.ascontiguousarray(pool[:, idx])).cuda()
 out = torch.empty(n_sites, dtype=torch.float64, device="cuda")
 want = m.run_tracks(pool[:, idx[:256]])
-configs = [("v0", dict(PCSF_PRUNE_VARIANT="0")), ("v1 8w", dict(PCSF_PRUNE_VARIANT="1"))]
+configs = [("v0", dict(PCSF_PRUNE_VARIANT="0")), ("v1 8w", dict(PCSF_PRUNE_VARIANT="1")),
+           ("v0x1 one WG/CU", dict(PCSF_PRUNE_VARIANT="0", PCSF_EXTRA_LDS="30000"))]
 if len(sys.argv) > 3:
     configs = [c for c in configs if c[0].split()[0] in sys.argv[3].split(",")]
 ctxs = []

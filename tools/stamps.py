@@ -16,7 +16,7 @@ out = torch.empty(n_sites, dtype=torch.float64, device="cuda")
 names = {0: "dispatch (loop top -> arm start)", 1: "barrier (+vmcnt) wait", 2: "product (leaf / pop arms)", 4: "product (push+cherry arms)", 3: "epilogue", 5: "decode + LDS issue",
          7: "arm exit + loop latch"}
 for extra in ("0", "30000"):
-    os.environ["PCSF_PRUNE_VARIANT"] = "2"; os.environ["PCSF_EXTRA_LDS"] = extra
+    os.environ["PCSF_PRUNE_VARIANT"] = os.environ.get("STAMP_VARIANT", "2"); os.environ["PCSF_EXTRA_LDS"] = extra
     c = pa.ScoringContext(m.child1, m.child2, m.branch_len, m.S_c, m.pi_c, m.S_nc, m.pi_nc)
     lib = pa.load_library()
     lib.pcsf_debug_stamps.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.c_int]
