@@ -22,9 +22,11 @@ inline int usage(const char* prog)
     fprintf(stderr,
             "usage:\n"
             "  %s build-tracks [--output DIR] [--power-threshold 0|1] [--output-raw-phylo 0|1] [--output-power 0|1]\n"
-            "                  [--species-aliases FILE] [--device N] <model prefix> <alignment.maf>...\n"
+            "                  [--species A,B,...] [--mapping FILE] [--species-aliases FILE] [--device N] <model prefix> <alignment.maf>...\n"
             "  %s score-msa    [--strategy fixed|mle|omega] [--comp-phylo 0|1] [--comp-anc 0|1] [--comp-bls 0|1]\n"
-            "                  [--output DIR] [--species-aliases FILE] [--device N] <model prefix> <alignment.maf>...\n"
+            "                  [--output DIR] [--species A,B,...] [--mapping FILE] [--species-aliases FILE] [--device N]\n"
+            "                  <model prefix> <alignment.maf>...\n"
+            "--species reduces the model's tree to the named species (tree labels or their other names)\n"
             "<model prefix> names <prefix>_coding.ECM, <prefix>_noncoding.ECM and <prefix>.nh\n",
             prog, prog);
     return 2;
@@ -63,10 +65,34 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
         }
         return 0;
     }
+    if (cmd == "dump-model") {  // diagnostics/tests: the flattened tree the scoring core receives
+        std::string species, mapping;
+        int j = 2;
+        for (; j + 1 < argc && strncmp(argv[j], "--", 2) == 0; j += 2) {
+            if (std::string(argv[j]) == "--species") species = argv[j + 1];
+            else if (std::string(argv[j]) == "--mapping") mapping = argv[j + 1];
+            else return usage(argv[0]);
+        }
+        if (argc - j < 1) return usage(argv[0]);
+        try {
+            const std::string prefix = argv[j];
+            std::string al = dirname_of(prefix) + "/species_aliases.tsv";
+            if (FILE* f = fopen(al.c_str(), "r")) fclose(f);
+            else al.clear();
+            const Model model = load_model(prefix, al, species, mapping);
+            for (int v = 0; v < model.n_nodes; ++v)
+                printf("%d\t%d\t%d\t%d\t%.17g\t%.9g\t%s\n", v, model.child1[v], model.child2[v], model.parent[v], model.branch_len_d[v],
+                       static_cast<double>(model.branch_len[v]), model.label[v].c_str());
+        } catch (const std::exception& e) {
+            fprintf(stderr, "error: %s\n", e.what());
+            return 1;
+        }
+        return 0;
+    }
     if (cmd != "build-tracks" && cmd != "score-msa") return usage(argv[0]);
     BuildTracksParams bt;
     ScoreMsaParams sm;
-    std::string aliases;
+    std::string aliases, species, mapping;
     int device = 0;
     int i = 2;
     for (; i < argc && strncmp(argv[i], "--", 2) == 0; i += 2) {
@@ -78,6 +104,8 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
         else if (k == "--output-raw-phylo") bt.write_raw = parse_bool(v);
         else if (k == "--output-power") bt.write_power = parse_bool(v);
         else if (k == "--species-aliases") aliases = v;
+        else if (k == "--species") species = v;
+        else if (k == "--mapping") mapping = v;
         else if (k == "--device") device = atoi(v.c_str());
         else if (k == "--verbose") bt.verbose = sm.verbose = parse_bool(v);
         else if (k == "--strategy") {
@@ -104,7 +132,8 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
                 aliases = cand;
             }
         }
-        const Model model = load_model(prefix, aliases);
+        const Model model = load_model(prefix, aliases, species, mapping);
+        if (!species.empty()) fprintf(stderr, "model reduced to %d species\n", model.n_leaves);
         std::unique_ptr<ScoringBackend> backend = make_backend(model, device);
         bool first = true;
         for (; i < argc; ++i) {
@@ -113,7 +142,7 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
                 fprintf(stderr, "%s: %zu alignments, %zu reference bases, %zu codon-frames, %zu backend calls\n", argv[i], st.alignments,
                         st.ref_bases, st.codon_frames, st.backend_calls);
                 fprintf(stderr, "  seconds: total %.3f = MAF read %.3f + BLS %.3f + codon extraction/power wig %.3f + scoring backend %.3f + raw wig output %.3f\n",
-                        st.total_seconds, st.read_seconds, st.bls_seconds, st.extract_seconds, st.backend_seconds, st.write_seconds - st.backend_seconds);
+                        st.total_seconds, st.read_seconds, st.bls_seconds, st.extract_seconds, st.backend_seconds, st.write_seconds);
             } else {
                 const std::string out = score_msa(model, argv[i], sm, *backend);
                 fprintf(stderr, "%s -> %s\n", argv[i], out.c_str());

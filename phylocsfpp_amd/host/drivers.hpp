@@ -209,7 +209,11 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
                 print_trimmed(f_power, "%.4f", static_cast<float>((p.bls[pos] + p.bls[pos + 1] + p.bls[pos + 2]) / 3.0));
         }
         if (prm.write_raw) {
-            if (used + len > cap) flush();
+            if (used + len > cap) {
+                st.extract_seconds += sw.lap();
+                flush();
+                sw.lap();  // the flush is accounted as backend + write time
+            }
             if (len > cap) {  // one alignment larger than the batch buffer
                 cap = len;
                 nucl.assign(nl * cap, 'N');

@@ -1,6 +1,7 @@
 // model_io.hpp -- host-side model input: ECM rate files, newick tree, species-name map.
 // Mirrors what load_model() hands to the scoring core (reference src/models.hpp:1757-1857,
-// src/ecm.hpp:20-67, src/newick.hpp:31-229); written from scratch.
+// src/ecm.hpp:20-67, src/newick.hpp:31-229), including the --species tree reduction
+// (src/newick.hpp:286-363) and the --mapping name table (src/models.hpp:1709-1740); written from scratch.
 #pragma once
 
 #include <algorithm>
@@ -13,6 +14,7 @@
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 namespace pcsf_host {
@@ -116,7 +118,43 @@ struct NewickParser {
 };
 }  // namespace detail
 
-inline void parse_newick(const std::string& text, Model& m)
+namespace detail {
+inline int selected_below(const std::vector<Node>& nd, int v, const std::unordered_set<std::string>& keep)
+{
+    if (nd[v].left < 0) return keep.count(nd[v].label) ? 1 : 0;
+    return selected_below(nd, nd[v].left, keep) + selected_below(nd, nd[v].right, keep);
+}
+
+// --species: drop every subtree without a selected leaf.  A node that loses a child is merged with the
+// surviving child: it takes over that child's children (or its label, if the child is a leaf) and, unless it
+// is the root, the child's branch length is ADDED to its own (double, before the float narrowing); the root
+// never carries a length.  Same result as the reference's newick_reduce for any selection.
+inline void reduce_to(std::vector<Node>& nd, int v, const std::unordered_set<std::string>& keep)
+{
+    while (nd[v].left >= 0) {
+        const int l = nd[v].left, r = nd[v].right;
+        const int nl = selected_below(nd, l, keep), nr = selected_below(nd, r, keep);
+        if (nl > 0 && nr > 0) {
+            reduce_to(nd, l, keep);
+            reduce_to(nd, r, keep);
+            return;
+        }
+        const int stay = nl == 0 ? r : l;
+        nd[v].left = nd[stay].left;
+        nd[v].right = nd[stay].right;
+        if (nd[v].left >= 0) {
+            nd[nd[v].left].parent = v;
+            nd[nd[v].right].parent = v;
+        } else {
+            nd[v].label = nd[stay].label;
+        }
+        if (nd[v].parent >= 0) nd[v].len += nd[stay].len;
+    }
+}
+}  // namespace detail
+
+// keep: lower-cased tree labels to reduce the tree to (nullptr or empty = the whole tree)
+inline void parse_newick(const std::string& text, Model& m, const std::unordered_set<std::string>* keep = nullptr)
 {
     std::string s;
     for (char c : text)
@@ -124,14 +162,39 @@ inline void parse_newick(const std::string& text, Model& m)
     detail::NewickParser P(s);
     const int root = P.parse(-1);
     if (P.pos < s.size() && s[P.pos] != ';') P.fail("trailing characters");
+    if (P.nodes.size() % 2 == 0) throw std::runtime_error("newick: not a binary tree");
+    if (keep && !keep->empty()) {
+        detail::reduce_to(P.nodes, root, *keep);
+        std::vector<detail::Node> live;  // compact to the reachable nodes
+        std::vector<int> remap(P.nodes.size(), -1), order{root};
+        for (size_t i = 0; i < order.size(); ++i) {
+            const detail::Node& x = P.nodes[order[i]];
+            if (x.left >= 0) {
+                order.push_back(x.left);
+                order.push_back(x.right);
+            }
+        }
+        for (size_t i = 0; i < order.size(); ++i) remap[order[i]] = static_cast<int>(i);
+        for (int old : order) {
+            detail::Node x = P.nodes[old];
+            x.left = x.left >= 0 ? remap[x.left] : -1;
+            x.right = x.right >= 0 ? remap[x.right] : -1;
+            x.parent = x.parent >= 0 ? remap[x.parent] : -1;
+            live.push_back(x);
+        }
+        live[0].parent = -1;
+        live[0].len = 0.0;
+        P.nodes.swap(live);
+    }
+    const int root_ix = (keep && !keep->empty()) ? 0 : root;
     auto& nd = P.nodes;
     int nl = 0;
     for (auto& x : nd) nl += x.left < 0;
     const int n = static_cast<int>(nd.size());
-    if (n != 2 * nl - 1 || nl < 2) throw std::runtime_error("newick: not a binary tree with >= 2 leaves");
+    if (n != 2 * nl - 1 || nl < 2) throw std::runtime_error("newick: not a binary tree with >= 2 leaves (after --species reduction)");
     // ids: leaves left-to-right, internal nodes in post-order starting at nl
     int next_leaf = 0, next_inner = nl;
-    std::vector<std::pair<int, int>> stack{{root, 0}};
+    std::vector<std::pair<int, int>> stack{{root_ix, 0}};
     while (!stack.empty()) {
         auto& [v, stage] = stack.back();
         if (nd[v].left < 0) {
@@ -184,8 +247,11 @@ inline std::string lower(std::string s)
     return s;
 }
 
-// alias table: "<tree label>\t<alias> <alias> ...", one species per line (all matched lower-cased)
-inline void add_aliases(Model& m, const std::string& path)
+// alias table: "<tree label>\t<alias> <alias> ...", one species per line (all matched lower-cased).  This file
+// stands in for the name table compiled into the reference (src/models.hpp:1240-1706).
+using AliasTable = std::unordered_map<std::string, std::vector<std::string>>;  // tree label -> other names
+
+inline void read_alias_table(const std::string& path, AliasTable& t)
 {
     std::ifstream in(path);
     if (!in) throw std::runtime_error("cannot open species alias file '" + path + "'");
@@ -193,23 +259,92 @@ inline void add_aliases(Model& m, const std::string& path)
     while (std::getline(in, line)) {
         const size_t tab = line.find('\t');
         if (tab == std::string::npos) continue;
-        auto it = m.name_to_leaf.find(lower(line.substr(0, tab)));
-        if (it == m.name_to_leaf.end()) continue;
+        auto& names = t[lower(line.substr(0, tab))];
         std::istringstream al(line.substr(tab + 1));
         std::string a;
-        while (al >> a) m.name_to_leaf.emplace(lower(a), it->second);
+        while (al >> a) {
+            a = lower(a);
+            if (std::find(names.begin(), names.end(), a) == names.end()) names.push_back(a);
+        }
     }
 }
 
+// --mapping: two columns "<common name>\t<name used in the alignments>" per line (reference
+// update_sequence_name_mapping).  Both columns are lower-cased here; the reference keeps the first column's
+// case, which makes a capitalised common name unreachable from the (lower-cased) tree labels.
+inline void read_mapping_file(const std::string& path, AliasTable& t)
+{
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error("cannot open mapping file '" + path + "'");
+    std::string line;
+    while (std::getline(in, line)) {
+        std::istringstream ls(line);
+        std::string common, other;
+        if (!(ls >> common >> other)) continue;
+        auto& names = t[lower(common)];
+        other = lower(other);
+        if (std::find(names.begin(), names.end(), other) == names.end()) names.push_back(other);
+    }
+}
+
+// --species "a,b,c": each name is a tree label or one of its other names; returns tree labels
+inline std::unordered_set<std::string> resolve_species(const std::string& csv, const std::vector<std::string>& tree_labels, const AliasTable& t)
+{
+    std::unordered_set<std::string> keep;
+    std::vector<std::string> missing;
+    std::istringstream ss(csv);
+    std::string tok;
+    while (std::getline(ss, tok, ',')) {
+        tok = lower(tok);
+        if (tok.empty()) continue;
+        if (std::find(tree_labels.begin(), tree_labels.end(), tok) != tree_labels.end()) {
+            keep.insert(tok);
+            continue;
+        }
+        bool found = false;
+        for (const auto& row : t)
+            if (std::find(row.second.begin(), row.second.end(), tok) != row.second.end() &&
+                std::find(tree_labels.begin(), tree_labels.end(), row.first) != tree_labels.end()) {
+                keep.insert(row.first);
+                found = true;
+            }
+        if (!found) missing.push_back(tok);
+    }
+    if (!missing.empty()) {
+        std::string msg = "the following selected species are missing in the phylogenetic tree:";
+        for (const auto& x : missing) msg += " " + x;
+        throw std::runtime_error(msg);
+    }
+    return keep;
+}
+
 // <prefix>_coding.ECM, <prefix>_noncoding.ECM, <prefix>.nh  (reference src/models.hpp:1773-1775)
-inline Model load_model(const std::string& prefix, const std::string& alias_file = "")
+inline Model load_model(const std::string& prefix, const std::string& alias_file = "", const std::string& species_csv = "",
+                        const std::string& mapping_file = "")
 {
     Model m;
     read_ecm(prefix + "_coding.ECM", m.S_c, m.pi_c);
     read_ecm(prefix + "_noncoding.ECM", m.S_nc, m.pi_nc);
-    parse_newick(slurp(prefix + ".nh"), m);
-    for (int i = 0; i < m.n_leaves; ++i) m.name_to_leaf.emplace(m.label[i], i);
-    if (!alias_file.empty()) add_aliases(m, alias_file);
+    AliasTable aliases;
+    if (!alias_file.empty()) read_alias_table(alias_file, aliases);
+    if (!mapping_file.empty()) read_mapping_file(mapping_file, aliases);
+    const std::string text = slurp(prefix + ".nh");
+    if (species_csv.empty()) {
+        parse_newick(text, m);
+    } else {
+        Model full;
+        parse_newick(text, full);
+        const std::vector<std::string> leaves(full.label.begin(), full.label.begin() + full.n_leaves);
+        const std::unordered_set<std::string> keep = resolve_species(species_csv, leaves, aliases);
+        if (keep.size() < 2) throw std::runtime_error("--species must select at least two species of the tree");
+        parse_newick(text, m, &keep);
+    }
+    for (int i = 0; i < m.n_leaves; ++i) {
+        m.name_to_leaf.emplace(m.label[i], i);
+        auto it = aliases.find(m.label[i]);
+        if (it != aliases.end())
+            for (const auto& a : it->second) m.name_to_leaf.emplace(a, i);
+    }
     return m;
 }
 

@@ -67,3 +67,26 @@ def test_score_msa_mle_and_omega_golden_on_gpu(tmp_path):
                 if wv == "nan":
                     continue                                          # see test_gpu_blocks.test_omega_blocks
                 assert (float(gv) - float(wv)) ** 2 <= tol            # reference test/tests.sh:41,46
+
+
+def test_species_reduced_model_on_gpu_matches_oracle_driver(tmp_path):
+    """--species (tree reduced to 20 of the 53 birds; kernel program, tables and leaf count change at run time):
+    the GPU driver must write the same seven wig files as the oracle-backed driver on the same input."""
+    oracle_cli = os.path.join(ROOT, "oracle", "_build", "oracle_cli")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    maf = tmp_path / "galGal6.maf"
+    with gzip.open(os.path.join(GOLD, "build-tracks", "galGal6_chr22_25_28_each_30k_bases.maf.gz"), "rb") as fi, open(maf, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    labels = [l.split("\t")[0] for l in open(os.path.join(GOLD, "models", "species_aliases.tsv")) if l.strip()]
+    tree = open(os.path.join(GOLD, "models", "53birds.nh")).read().lower()
+    birds = [l for l in labels if (l.lower() + ":") in tree][:40:2]
+    assert len(birds) == 20
+    outs = []
+    for cli, name in ((_cli(), "gpu"), (oracle_cli, "cpu")):
+        out = tmp_path / name
+        subprocess.check_call([cli, "build-tracks", "--output", str(out), "--species", ",".join(birds + ["Chicken"]),
+                               os.path.join(GOLD, "models", "53birds"), str(maf)])
+        outs.append(out)
+    for n in ["PhyloCSFpower"] + ["PhyloCSFRaw%s%d" % (s, f) for s in "+-" for f in (1, 2, 3)]:
+        got, want = open(outs[0] / (n + ".wig"), "rb").read(), open(outs[1] / (n + ".wig"), "rb").read()
+        assert len(want) > 10000 and got == want, n

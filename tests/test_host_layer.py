@@ -114,3 +114,87 @@ def test_invalid_character_is_an_error(cli, tmp_path):
     maf = "a score=0\ns chicken.chr1 10 4 + 1000 ACXT\ns turkey.chr1 10 4 + 1000 ACGT\n"
     r = subprocess.run([cli, "build-tracks", "--output", str(tmp_path / "o"), MODEL, _write(tmp_path, maf)], capture_output=True, text=True)
     assert r.returncode != 0 and "unexpected character" in r.stderr
+
+
+# ---- --species: tree reduction and name mapping (reference src/newick.hpp:286-363, src/models.hpp:1780-1857) ----
+def _model_dir(tmp_path, newick):
+    import shutil
+    for kind in ("coding", "noncoding"):
+        shutil.copy(MODEL + "_%s.ECM" % kind, tmp_path / ("t_%s.ECM" % kind))
+    (tmp_path / "t.nh").write_text(newick)
+    return str(tmp_path / "t")
+
+
+def _dump_model(cli, prefix, species=None, mapping=None):
+    cmd = [cli, "dump-model"]
+    if species:
+        cmd += ["--species", species]
+    if mapping:
+        cmd += ["--mapping", mapping]
+    out = subprocess.check_output(cmd + [prefix], text=True)
+    rows = []
+    for line in out.splitlines():
+        f = line.split("\t")
+        rows.append((int(f[0]), int(f[1]), int(f[2]), int(f[3]), float(f[4]), f[6] if len(f) > 6 else ""))
+    return rows
+
+
+def test_species_reduction_merges_branches_like_the_reference(cli, tmp_path):
+    prefix = _model_dir(tmp_path, "((A:1,b:2):3,(c:4,(d:5,e:6):7):8);")
+    full = _dump_model(cli, prefix)
+    assert [r[5] for r in full[:5]] == ["a", "b", "c", "d", "e"] and len(full) == 9
+    # (a,b):3 loses b -> leaf a with 3+1; (c,(d,e):7):8 loses c -> (d,e) with 8+7
+    red = _dump_model(cli, prefix, "a,D,e")
+    assert red == [(0, -1, -1, 4, 4.0, "a"), (1, -1, -1, 3, 5.0, "d"), (2, -1, -1, 3, 6.0, "e"), (3, 1, 2, 4, 15.0, ""), (4, 0, 3, -1, 0.0, "")]
+    # the root never accumulates a length: it becomes the (d,e) node
+    assert _dump_model(cli, prefix, "d,e") == [(0, -1, -1, 2, 5.0, "d"), (1, -1, -1, 2, 6.0, "e"), (2, 0, 1, -1, 0.0, "")]
+    # selecting everything changes nothing
+    assert _dump_model(cli, prefix, "a,b,c,d,e") == full
+    # unknown names are an error that lists them; fewer than two species too
+    r = subprocess.run([cli, "dump-model", "--species", "a,zzz", prefix], capture_output=True, text=True)
+    assert r.returncode != 0 and "zzz" in r.stderr
+    assert subprocess.run([cli, "dump-model", "--species", "a", prefix], capture_output=True, text=True).returncode != 0
+
+
+def test_species_accepts_other_names_and_mapping_file(cli, tmp_path):
+    prefix100 = os.path.join(ROOT, "tests", "golden", "models", "100vertebrates")
+    red = _dump_model(cli, prefix100, "hg38,Mouse,galGal6")        # assembly names resolve through the alias table
+    assert [r[5] for r in red[:3]] == ["human", "mouse", "chicken"] and len(red) == 5
+    # sum of the merged path lengths is preserved: human's branch in the 3-species tree = path to the human/mouse ancestor
+    prefix = _model_dir(tmp_path, "((A:1,b:2):3,(c:4,(d:5,e:6):7):8);")
+    mapping = tmp_path / "map.tsv"
+    mapping.write_text("A\tasm1\nE\tasm5\n")
+    red = _dump_model(cli, prefix, "asm1,asm5,d", str(mapping))
+    assert [r[5] for r in red[:3]] == ["a", "d", "e"]
+
+
+def test_reduced_model_scores_like_the_full_model_on_the_same_rows(cli, tmp_path):
+    """Removing a species from the tree == marginalising it: FIXED scores of the reduced model equal those of the
+    full model when the alignment only holds the selected species (up to the float narrowing of merged branches)."""
+    import gzip
+    prefix100 = os.path.join(ROOT, "tests", "golden", "models", "100vertebrates")
+    keep = ["hg19", "pantro4", "ponabe2", "turtru2", "mondom5", "anocar2", "gasacu1"]   # 7 of the 11 species in the file
+    src = os.path.join(ROOT, "tests", "golden", "score-msa", "chr22.50alignments.maf")
+    lines = []
+    opener = gzip.open if src.endswith(".gz") else open
+    with opener(src, "rt") as f:
+        for line in f:
+            if line.startswith("s "):
+                if line.split()[1].split(".")[0].lower() not in keep:
+                    continue
+            lines.append(line)
+    maf = tmp_path / "sub.maf"
+    maf.write_text("".join(lines))
+    outs = []
+    for i, extra in enumerate(([], ["--species", ",".join(keep)])):
+        d = tmp_path / ("o%d" % i)
+        d.mkdir()
+        subprocess.check_call([cli, "score-msa", "--strategy", "fixed", "--comp-anc", "1", "--comp-bls", "0", "--output", str(d)] + extra +
+                              [prefix100, str(maf)], stderr=subprocess.DEVNULL)
+        rows = [l.split("\t") for l in open(d / "sub.maf.scores").read().splitlines() if not l.startswith("#")][1:]  # header row
+        outs.append(np.array([[float(x) for x in r[-2:]] for r in rows]))
+    assert outs[0].shape == outs[1].shape and outs[0].shape[0] == 50
+    # the likelihood ratio is root-invariant; the ancestral-composition score is a statement about the ROOT, which
+    # moves to the selected species' last common ancestor, so it legitimately changes
+    np.testing.assert_allclose(outs[1][:, 0], outs[0][:, 0], rtol=2e-5, atol=2e-5)
+    assert np.abs(outs[0][:, 0]).max() > 1.0 and np.abs(outs[1][:, 1] - outs[0][:, 1]).max() > 1e-3
