@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <limits>
 #include <memory>
 #include <string>
 #include <vector>
@@ -38,12 +39,44 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
 {
     if (argc < 2) return usage(argv[0]);
     const std::string cmd = argv[1];
+    if (cmd == "selftest-format") {  // tests: format_trimmed<3|4> against snprintf-based print_trimmed on n random floats
+        const size_t n = argc > 2 ? static_cast<size_t>(atoll(argv[2])) : 1000000;
+        uint64_t state = 0x9e3779b97f4a7c15ull;
+        size_t bad = 0;
+        auto check = [&](float v) {
+            for (int d = 3; d <= 4; ++d) {
+                char want[80], got[80];
+                snprintf(want, sizeof want, d == 3 ? "%.3f" : "%.4f", static_cast<double>(v));
+                for (int i = static_cast<int>(strlen(want)); i >= 0; --i) {
+                    if (want[i] == '.') { want[i + 1] = '0'; break; }
+                    if (want[i] >= '0' && want[i] <= '9') { if (want[i] != '0') break; want[i] = 0; }
+                }
+                if (d == 3) format_trimmed<3>(got, v); else format_trimmed<4>(got, v);
+                if (strcmp(want, got) != 0 && bad++ < 10) fprintf(stderr, "mismatch %.9g (%%.%df): want %s got %s\n", static_cast<double>(v), d, want, got);
+            }
+        };
+        const float edge[] = {0.f, -0.f, 0.0005f, -0.0005f, 0.0015f, 0.00049999f, 1e-10f, -1e-10f, 0.125f, 0.0625f, 2.5e-4f, 9.9995f, 99999.9995f, 1e14f, 1e15f, 3e38f, -3e38f,
+                              std::numeric_limits<float>::infinity(), -std::numeric_limits<float>::infinity(), std::numeric_limits<float>::quiet_NaN(), 1.0f, -1.0f, 123456.789f};
+        for (float v : edge) check(v);
+        for (size_t i = 0; i < n; ++i) {
+            state ^= state << 13; state ^= state >> 7; state ^= state << 17;
+            float v;
+            if (i % 3 == 0) { const uint32_t bits = static_cast<uint32_t>(state); memcpy(&v, &bits, 4); }        // any bit pattern
+            else if (i % 3 == 1) v = static_cast<float>(static_cast<int64_t>(state % 2000001) - 1000000) / 8000.f;  // many exact ties (k/8000)
+            else v = static_cast<float>((static_cast<double>(state >> 11) / 9007199254740992.0 - 0.5) * 200.0);   // typical score range
+            check(v);
+        }
+        printf("%zu values checked, %zu mismatches\n", n + sizeof edge / sizeof edge[0], bad);
+        return bad ? 1 : 0;
+    }
     if (cmd == "dump-alignments") {  // diagnostics/tests: what the MAF reader yields (build-tracks semantics unless --blocks 1)
         bool blocks = false;
+        size_t jobs = 1;
         int j = 2;
-        if (j + 1 < argc && std::string(argv[j]) == "--blocks") {
-            blocks = parse_bool(argv[j + 1]);
-            j += 2;
+        for (; j + 1 < argc && strncmp(argv[j], "--", 2) == 0; j += 2) {
+            if (std::string(argv[j]) == "--blocks") blocks = parse_bool(argv[j + 1]);
+            else if (std::string(argv[j]) == "--jobs") jobs = static_cast<size_t>(atoll(argv[j + 1]));  // byte-range jobs, concatenated in order
+            else return usage(argv[0]);
         }
         if (argc - j < 2) return usage(argv[0]);
         try {
@@ -52,12 +85,16 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
             if (FILE* f = fopen(al.c_str(), "r")) fclose(f);
             else al.clear();
             const Model model = load_model(prefix, al);
-            MafReader rd(argv[j + 1], model.name_to_leaf, model.n_leaves, !blocks, false);
-            Alignment aln;
-            while (rd.next(aln)) {
-                printf("%s\t%" PRIu64 "\t%zu\t%c\t%" PRIu64, aln.chrom.c_str(), aln.start_pos, aln.length(), aln.strand, aln.chrom_len);
-                for (const auto& r : aln.seqs) printf("\t%s", r.c_str());
-                printf("\n");
+            MafFile file(argv[j + 1]);
+            for (size_t job = 0; job < std::max<size_t>(jobs, 1); ++job) {
+                const size_t nj = std::max<size_t>(jobs, 1);
+                MafReader rd(file, file.size() * job / nj, file.size() * (job + 1) / nj, model.name_to_leaf, model.n_leaves, !blocks, false);
+                Alignment aln;
+                while (rd.next(aln)) {
+                    printf("%s\t%" PRIu64 "\t%zu\t%c\t%" PRIu64, aln.chrom.c_str(), aln.start_pos, aln.length(), aln.strand, aln.chrom_len);
+                    for (const auto& r : aln.seqs) printf("\t%s", r.c_str());
+                    printf("\n");
+                }
             }
         } catch (const std::exception& e) {
             fprintf(stderr, "error: %s\n", e.what());

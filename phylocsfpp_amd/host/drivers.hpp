@@ -10,13 +10,19 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cinttypes>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "maf_reader.hpp"
@@ -80,7 +86,60 @@ struct BuildTracksParams {
     bool write_raw = true, write_power = true;
     size_t batch_sites = 4u << 20;   // codon-frames gathered per backend call
     bool verbose = false;
+    int threads = 0;                 // host threads for ingest / BLS / text output (0 = all the process may use)
+    size_t window_bytes = size_t(256) << 20;  // MAF bytes parsed (in parallel) before their alignments are scored
 };
+
+// CPUs this process may actually use: hardware threads, capped by the cgroup CPU quota (a container on a
+// 256-thread host may own 16) and by PCSF_THREADS
+inline int effective_threads()
+{
+    int n = static_cast<int>(std::thread::hardware_concurrency());
+    if (n <= 0) n = 1;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        long period = 0;
+        if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+            const long q = (atol(quota) + period - 1) / period;
+            if (q >= 1 && q < n) n = static_cast<int>(q);
+        }
+        fclose(f);
+    }
+    if (const char* e = getenv("PCSF_THREADS")) {
+        const int v = atoi(e);
+        if (v >= 1) n = v;
+    }
+    return n;
+}
+
+// fn(i) for i in [0, n) on up to `threads` threads (dynamic schedule); the first exception is rethrown
+template <class Fn>
+inline void parallel_for(size_t n, int threads, Fn&& fn)
+{
+    if (n == 0) return;
+    const size_t nt = std::min<size_t>(n, static_cast<size_t>(std::max(threads, 1)));
+    if (nt == 1) {
+        for (size_t i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    std::exception_ptr error;
+    std::mutex error_lock;
+    auto work = [&]() {
+        try {
+            for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
+        } catch (...) {
+            std::lock_guard<std::mutex> g(error_lock);
+            if (!error) error = std::current_exception();
+            next.store(n);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    if (error) std::rethrow_exception(error);
+}
 
 inline std::string dirname_of(const std::string& path)
 {
@@ -112,7 +171,46 @@ struct StopWatch {
     }
 };
 
+// appends text to a file through a large buffer
+struct WigSink {
+    FILE* f;
+    std::vector<char> buf;
+    explicit WigSink(FILE* file) : f(file) { buf.reserve(1 << 20); }
+    char* room(size_t n)
+    {
+        if (buf.size() + n > buf.capacity()) flush();
+        const size_t at = buf.size();
+        buf.resize(at + n);
+        return buf.data() + at;
+    }
+    void shrink(size_t unused) { buf.resize(buf.size() - unused); }
+    void flush()
+    {
+        if (!buf.empty() && fwrite(buf.data(), 1, buf.size(), f) != buf.size()) throw std::runtime_error("write failed");
+        buf.clear();
+    }
+    void header(const std::string& chrom, int64_t pos)
+    {
+        char* p = room(chrom.size() + 64);
+        const int n = snprintf(p, chrom.size() + 64, "fixedStep chrom=%s start=%" PRId64 " step=3 span=3\n", chrom.c_str(), pos);
+        shrink(chrom.size() + 64 - static_cast<size_t>(n));
+    }
+    template <int D>
+    void value(float v)
+    {
+        char* p = room(72);
+        const size_t n = format_trimmed<D>(p, v);
+        p[n] = '\n';
+        shrink(72 - (n + 1));
+    }
+};
+
+
 // build-tracks for one MAF file.  append: later files of a multi-file run append to the wigs.
+// Stages per window of the file: (1) byte-range jobs parse the MAF and compute the per-base branch-length
+// scores on all host threads; (2) the alignments, in file order, are packed into nucleotide batches and
+// scored by the backend (six frames per alignment, one call per batch); (3) seven writers -- the power
+// track and the six frames -- format their text in parallel and append it to their files.
 inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_path, const BuildTracksParams& prm,
                                      ScoringBackend& backend, bool append = false)
 {
@@ -125,107 +223,149 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         for (int i = 0; i < 6; ++i)
             f_raw[i] = open_out(out_dir + "/PhyloCSFRaw" + std::string(1, i < 3 ? '+' : '-') + std::to_string(i % 3 + 1) + ".wig", mode);
 
-    struct Pending {  // one alignment waiting for its scores
+    struct Item {  // one alignment
         std::string chrom;
-        uint64_t start_pos, chrom_len;
-        uint32_t len;
-        uint64_t col0;
+        uint64_t start_pos = 0, chrom_len = 0, col0 = 0;
+        uint32_t len = 0;
+        std::vector<std::string> seqs;
         std::vector<double> bls;
     };
     const size_t nl = static_cast<size_t>(model.n_leaves);
-    size_t cap = prm.batch_sites / 2;  // columns per batch: one column yields two codon-frames
-    std::vector<char> nucl(nl * cap);
+    const int threads = prm.threads > 0 ? prm.threads : effective_threads();
+    size_t cap = std::max<size_t>(prm.batch_sites / 2, 1);  // columns per batch: one column yields two codon-frames
+    std::vector<char> nucl;
     std::vector<double> scores;
     std::vector<uint64_t> offsets;
     std::vector<uint32_t> n_codons;
-    std::vector<Pending> pending;
-    size_t used = 0;
     BuildTracksStats st;
-    BranchLengthScore bls(model);
     const float threshold3 = prm.power_threshold * 3;
+    StopWatch total, sw;
 
-    auto flush = [&]() {
-        if (pending.empty()) return;
-        StopWatch fw;
+    auto write_power = [&](const std::vector<Item*>& items) {  // frame 3 of the + strand, mean of the three per-base scores
+        WigSink out(f_power);
+        for (const Item* it : items) {
+            int64_t skip = static_cast<int64_t>(3 - static_cast<int64_t>(it->start_pos)) % 3;
+            if (skip < 0) skip += 3;
+            if (static_cast<uint64_t>(skip) + 2 < it->bls.size()) out.header(it->chrom, static_cast<int64_t>(it->start_pos) + skip);
+            for (size_t pos = static_cast<size_t>(skip); pos + 2 < it->bls.size(); pos += 3)
+                out.value<4>(static_cast<float>((it->bls[pos] + it->bls[pos + 1] + it->bls[pos + 2]) / 3.0));
+        }
+        out.flush();
+    };
+    auto write_frame = [&](const std::vector<Item*>& items, int fi) {
+        WigSink out(f_raw[fi]);
+        for (size_t k = 0; k < items.size(); ++k) {
+            const Item& p = *items[k];
+            const FrameView v = frame_view(p.start_pos, p.chrom_len, p.len, fi < 3 ? '+' : '-', static_cast<unsigned>(fi % 3 + 1));
+            const double* sc = scores.data() + offsets[k * 6 + fi];
+            int64_t prev = -4;
+            size_t bpos = v.bls_offset;
+            for (size_t xx = 0; xx < v.n_codons; ++xx, bpos += 3) {
+                const float bsum = static_cast<float>(p.bls[bpos] + p.bls[bpos + 1] + p.bls[bpos + 2]);
+                if (bsum < threshold3) continue;
+                const int64_t pos = static_cast<int64_t>(v.start_pos + xx * 3);
+                if (prev + 3 != pos) out.header(p.chrom, pos);
+                prev = pos;
+                out.value<3>(static_cast<float>(sc[xx]));
+            }
+        }
+        out.flush();
+    };
+
+    // one batch: pack, score, write
+    auto run_batch = [&](const std::vector<Item*>& items, size_t columns) {
+        if (items.empty()) return;
+        StopWatch bw;
         if (prm.write_raw) {
+            const size_t stride = std::max(columns, size_t(1));
+            if (nucl.size() < nl * stride) nucl.resize(nl * stride);
             std::vector<uint64_t> col0, start_pos, chrom_len;
             std::vector<uint32_t> len;
-            for (const Pending& p : pending) {
-                col0.push_back(p.col0);
-                len.push_back(p.len);
-                start_pos.push_back(p.start_pos);
-                chrom_len.push_back(p.chrom_len);
+            for (const Item* p : items) {
+                col0.push_back(p->col0);
+                len.push_back(p->len);
+                start_pos.push_back(p->start_pos);
+                chrom_len.push_back(p->chrom_len);
             }
-            backend.score_alignments_6frames(model.n_leaves, nucl.data(), cap, col0, len, start_pos, chrom_len, scores, offsets, n_codons);
-            st.backend_seconds += fw.lap();
+            parallel_for(items.size() * nl, threads, [&](size_t j) {
+                const Item& p = *items[j / nl];
+                const size_t l = j % nl;
+                memcpy(nucl.data() + l * stride + p.col0, p.seqs[l].data(), p.len);
+            });
+            st.extract_seconds += bw.lap();
+            backend.score_alignments_6frames(model.n_leaves, nucl.data(), stride, col0, len, start_pos, chrom_len, scores, offsets, n_codons);
+            st.backend_seconds += bw.lap();
             ++st.backend_calls;
             st.codon_frames += scores.size();
         }
-        for (size_t k = 0; k < pending.size() && prm.write_raw; ++k) {
-            const Pending& p = pending[k];
-            for (int fi = 0; fi < 6; ++fi) {
-                const FrameView v = frame_view(p.start_pos, p.chrom_len, p.len, fi < 3 ? '+' : '-', static_cast<unsigned>(fi % 3 + 1));
-                const double* sc = scores.data() + offsets[k * 6 + fi];
-                int64_t prev = -4;
-                size_t bpos = v.bls_offset;
-                for (size_t xx = 0; xx < v.n_codons; ++xx, bpos += 3) {
-                    const float bsum = static_cast<float>(p.bls[bpos] + p.bls[bpos + 1] + p.bls[bpos + 2]);
-                    if (bsum < threshold3) continue;
-                    const int64_t pos = static_cast<int64_t>(v.start_pos + xx * 3);
-                    if (prev + 3 != pos) fprintf(f_raw[fi], "fixedStep chrom=%s start=%" PRId64 " step=3 span=3\n", p.chrom.c_str(), pos);
-                    prev = pos;
-                    print_trimmed(f_raw[fi], "%.3f", static_cast<float>(sc[xx]));
-                }
+        parallel_for(7, threads, [&](size_t t) {
+            if (t == 0) {
+                if (f_power) write_power(items);
+            } else if (prm.write_raw) {
+                write_frame(items, static_cast<int>(t) - 1);
             }
-        }
-        pending.clear();
-        used = 0;
-        st.write_seconds += fw.lap();
+        });
+        st.write_seconds += bw.lap();
     };
 
-    MafReader reader(maf_path, model.name_to_leaf, model.n_leaves, /*concatenate=*/true, prm.verbose);
-    Alignment aln;
-    StopWatch total, sw;
-    while (reader.next(aln)) {
-        st.read_seconds += sw.lap();
-        ++st.alignments;
-        const size_t len = aln.length();
-        st.ref_bases += len;
-        Pending p;
-        p.chrom = aln.chrom;
-        p.start_pos = aln.start_pos;
-        p.chrom_len = aln.chrom_len;
-        p.len = static_cast<uint32_t>(len);
-        bls.per_base(aln, &p.bls);  // also validates every character (the reference exits on anything but ACGTNacgtn-.)
-        st.bls_seconds += sw.lap();
-
-        if (f_power) {  // power track: frame 3 of the + strand, mean of the three per-base scores
-            int64_t skip = static_cast<int64_t>(3 - static_cast<int64_t>(aln.start_pos)) % 3;
-            if (skip < 0) skip += 3;
-            if (static_cast<uint64_t>(skip) + 2 < p.bls.size())
-                fprintf(f_power, "fixedStep chrom=%s start=%" PRId64 " step=3 span=3\n", aln.chrom.c_str(),
-                        static_cast<int64_t>(aln.start_pos) + skip);
-            for (size_t pos = static_cast<size_t>(skip); pos + 2 < p.bls.size(); pos += 3)
-                print_trimmed(f_power, "%.4f", static_cast<float>((p.bls[pos] + p.bls[pos + 1] + p.bls[pos + 2]) / 3.0));
-        }
-        if (prm.write_raw) {
-            if (used + len > cap) {
-                st.extract_seconds += sw.lap();
-                flush();
-                sw.lap();  // the flush is accounted as backend + write time
+    MafFile file(maf_path);
+    const size_t window = std::max<size_t>(prm.window_bytes, 1 << 16);
+    for (size_t w0 = 0; w0 < file.size() || (w0 == 0 && file.size() == 0); w0 += window) {
+        if (file.size() == 0) break;
+        const size_t w1 = std::min(file.size(), w0 + window);
+        // (1) parse + branch-length scores, one job per byte range; ranges are cut at arbitrary bytes
+        const size_t n_jobs = std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(threads) * 4, (w1 - w0 + (1 << 16) - 1) >> 16));
+        std::vector<std::vector<Item>> parsed(n_jobs);
+        std::vector<double> job_read(n_jobs, 0.0), job_bls(n_jobs, 0.0);
+        sw.lap();
+        parallel_for(n_jobs, threads, [&](size_t j) {
+            const size_t b = w0 + (w1 - w0) * j / n_jobs, e = w0 + (w1 - w0) * (j + 1) / n_jobs;
+            MafReader reader(file, b, e, model.name_to_leaf, model.n_leaves, /*concatenate=*/true, prm.verbose && j == 0 && w0 == 0);
+            BranchLengthScore bls(model);
+            Alignment aln;
+            StopWatch jw;
+            while (reader.next(aln)) {
+                job_read[j] += jw.lap();
+                Item it;
+                it.chrom = aln.chrom;
+                it.start_pos = aln.start_pos;
+                it.chrom_len = aln.chrom_len;
+                it.len = static_cast<uint32_t>(aln.length());
+                bls.per_base(aln, &it.bls);  // also validates every character (the reference exits on anything but ACGTNacgtn-.)
+                it.seqs.swap(aln.seqs);
+                parsed[j].push_back(std::move(it));
+                job_bls[j] += jw.lap();
             }
-            if (len > cap) {  // one alignment larger than the batch buffer
-                cap = len;
-                nucl.assign(nl * cap, 'N');
+        });
+        {  // wall time of the stage, split in proportion to the summed thread times
+            const double wall = sw.lap();
+            double r = 0.0, b = 0.0;
+            for (size_t j = 0; j < n_jobs; ++j) {
+                r += job_read[j];
+                b += job_bls[j];
             }
-            p.col0 = used;
-            for (size_t l = 0; l < nl; ++l) memcpy(nucl.data() + l * cap + used, aln.seqs[l].data(), len);
-            used += len;
+            const double tot = r + b > 0 ? r + b : 1.0;
+            st.read_seconds += wall * r / tot;
+            st.bls_seconds += wall * b / tot;
         }
-        pending.push_back(std::move(p));
-        st.extract_seconds += sw.lap();
+        // (2)+(3) batches in file order
+        std::vector<Item*> batch;
+        size_t used = 0;
+        for (auto& job : parsed)
+            for (Item& it : job) {
+                ++st.alignments;
+                st.ref_bases += it.len;
+                if (!batch.empty() && used + it.len > cap) {
+                    run_batch(batch, used);
+                    batch.clear();
+                    used = 0;
+                }
+                it.col0 = used;
+                used += it.len;
+                batch.push_back(&it);
+            }
+        run_batch(batch, used);
     }
-    flush();
     st.total_seconds = total.lap();
     if (f_power) fclose(f_power);
     for (FILE* f : f_raw)

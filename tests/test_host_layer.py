@@ -198,3 +198,35 @@ def test_reduced_model_scores_like_the_full_model_on_the_same_rows(cli, tmp_path
     # moves to the selected species' last common ancestor, so it legitimately changes
     np.testing.assert_allclose(outs[1][:, 0], outs[0][:, 0], rtol=2e-5, atol=2e-5)
     assert np.abs(outs[0][:, 0]).max() > 1.0 and np.abs(outs[1][:, 1] - outs[0][:, 1]).max() > 1e-3
+
+
+# ---- parallel ingest: byte-range jobs (reference src/parallel_file_reader.hpp:283-350,396-425) and fast text ----
+def _dump_text(cli, model, path, jobs):
+    return subprocess.check_output([cli, "dump-alignments", "--jobs", str(jobs), model, path], text=True)
+
+
+def test_byte_range_jobs_do_not_change_the_alignments(cli, tmp_path):
+    import gzip
+    import sys
+    # (a) the reference's example (10 097 blocks, 9 alignments), cut into 1..97 byte ranges
+    maf = tmp_path / "g.maf"
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "build-tracks", "galGal6_chr22_25_28_each_30k_bases.maf.gz"), "rb") as fi:
+        maf.write_bytes(fi.read())
+    one = _dump_text(cli, MODEL, str(maf), 1)
+    assert one.count("\n") == 9
+    for jobs in (2, 3, 16, 97):
+        assert _dump_text(cli, MODEL, str(maf), jobs) == one, jobs
+    # (b) a synthetic 30 kb alignment that crosses the 1 Mb break point, discontinuities included
+    syn = tmp_path / "syn.maf"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_synthetic_maf.py"), str(syn), "--bases", "30000", "--start", "985000",
+                           "--seed", "7"], stdout=subprocess.DEVNULL)
+    model100 = os.path.join(ROOT, "tests", "golden", "models", "100vertebrates")
+    one = _dump_text(cli, model100, str(syn), 1)
+    assert one.count("\n") >= 3
+    for jobs in (2, 5, 33, 200):
+        assert _dump_text(cli, model100, str(syn), jobs) == one, jobs
+
+
+def test_fast_number_formatting_matches_printf(cli):
+    out = subprocess.check_output([cli, "selftest-format", "600000"], text=True)
+    assert out.strip().endswith("0 mismatches"), out
