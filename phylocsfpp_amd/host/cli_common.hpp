@@ -23,13 +23,16 @@ inline int usage(const char* prog)
     fprintf(stderr,
             "usage:\n"
             "  %s build-tracks [--output DIR] [--power-threshold 0|1] [--output-raw-phylo 0|1] [--output-power 0|1]\n"
+            "                  [--output-phylo 0|1] [--output-regions 0|1] [--genome-length N --coding-exons FILE | --hmm-params P]\n"
             "                  [--species A,B,...] [--mapping FILE] [--species-aliases FILE] [--device N] <model prefix> <alignment.maf>...\n"
             "  %s score-msa    [--strategy fixed|mle|omega] [--comp-phylo 0|1] [--comp-anc 0|1] [--comp-bls 0|1]\n"
             "                  [--output DIR] [--species A,B,...] [--mapping FILE] [--species-aliases FILE] [--device N]\n"
             "                  <model prefix> <alignment.maf>...\n"
+            "  %s smooth-tracks [--output-phylo 0|1] [--output-regions 0|1] (--genome-length N --coding-exons FILE | --hmm-params P) DIR\n"
+            "--hmm-params: coding prior, mean coding length (codons), 3 non-coding weights, 3 non-coding mean lengths (codons)\n"
             "--species reduces the model's tree to the named species (tree labels or their other names)\n"
             "<model prefix> names <prefix>_coding.ECM, <prefix>_noncoding.ECM and <prefix>.nh\n",
-            prog, prog);
+            prog, prog, prog);
     return 2;
 }
 
@@ -126,8 +129,10 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
         }
         return 0;
     }
-    if (cmd != "build-tracks" && cmd != "score-msa") return usage(argv[0]);
+    if (cmd != "build-tracks" && cmd != "score-msa" && cmd != "smooth-tracks") return usage(argv[0]);
     BuildTracksParams bt;
+    std::string coding_exons, hmm_params, hmm_matrix;
+    uint64_t genome_length = 0;
     ScoreMsaParams sm;
     std::string aliases, species, mapping;
     int device = 0;
@@ -140,6 +145,13 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
         else if (k == "--power-threshold") bt.power_threshold = parse_bool(v) ? 1.0f : 0.0f;
         else if (k == "--output-raw-phylo") bt.write_raw = parse_bool(v);
         else if (k == "--output-power") bt.write_power = parse_bool(v);
+        else if (k == "--output-phylo") bt.write_smooth = parse_bool(v);
+        else if (k == "--output-regions") bt.write_regions = parse_bool(v);
+        else if (k == "--genome-length") genome_length = strtoull(v.c_str(), nullptr, 10);
+        else if (k == "--coding-exons") coding_exons = v;
+        else if (k == "--hmm-params") hmm_params = v;
+        else if (k == "--hmm-matrix") hmm_matrix = v;
+        else if (k == "--threads") bt.threads = atoi(v.c_str());
         else if (k == "--species-aliases") aliases = v;
         else if (k == "--species") species = v;
         else if (k == "--mapping") mapping = v;
@@ -159,8 +171,50 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
             return usage(argv[0]);
         }
     }
-    if (argc - i < 2) return usage(argv[0]);
+    if (cmd == "smooth-tracks" && !bt.write_smooth && !bt.write_regions) bt.write_smooth = true;
+    if (argc - i < (cmd == "smooth-tracks" ? 1 : 2)) return usage(argv[0]);
     try {
+        if (cmd == "build-tracks" || cmd == "smooth-tracks") {
+            if (bt.write_smooth || bt.write_regions) {
+                HmmParams hp;
+                bool have_matrix = false;
+                if (!hmm_matrix.empty()) {  // 4 initial + 16 row-major transition probabilities of a hand-made HMM
+                    std::vector<double> v;
+                    const char* q = hmm_matrix.c_str();
+                    char* end = nullptr;
+                    for (double x = strtod(q, &end); q != end; x = strtod(q, &end)) {
+                        v.push_back(x);
+                        q = *end == ',' ? end + 1 : end;
+                    }
+                    if (v.size() != 20) throw std::runtime_error("--hmm-matrix expects 20 comma-separated numbers");
+                    for (int a = 0; a < 4; ++a) bt.hmm.init[a] = v[a];
+                    for (int a = 0; a < 16; ++a) bt.hmm.trans[a / 4][a % 4] = v[4 + a];
+                    have_matrix = true;
+                } else if (!hmm_params.empty()) {
+                    double v[8];
+                    if (sscanf(hmm_params.c_str(), "%lf,%lf,%lf,%lf,%lf,%lf,%lf,%lf", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7) != 8)
+                        throw std::runtime_error("--hmm-params expects eight comma-separated numbers");
+                    hp.coding_prior = v[0];
+                    hp.coding_length_in_codons = v[1];
+                    for (int q = 0; q < 3; ++q) {
+                        hp.non_coding_weights[q] = v[2 + q];
+                        hp.non_coding_lengths_in_codons[q] = v[5 + q];
+                    }
+                } else if (genome_length != 0 && !coding_exons.empty()) {
+                    hp = estimate_hmm_params(coding_exons, static_cast<uint32_t>(genome_length));  // uint32_t like the reference
+                    fprintf(stderr, "HMM parameters: %.17g,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g\n", hp.coding_prior, hp.coding_length_in_codons,
+                            hp.non_coding_weights[0], hp.non_coding_weights[1], hp.non_coding_weights[2], hp.non_coding_lengths_in_codons[0],
+                            hp.non_coding_lengths_in_codons[1], hp.non_coding_lengths_in_codons[2]);
+                } else {
+                    throw std::runtime_error("for smoothened tracks / regions (--output-phylo, --output-regions) provide --genome-length and --coding-exons (or --hmm-params)");
+                }
+                if (!have_matrix) bt.hmm = make_coding_hmm(hp);
+            }
+            if (cmd == "smooth-tracks") {
+                smooth_tracks(argv[i], bt.hmm, bt.write_smooth, bt.write_regions, /*keep_raw=*/true, bt.threads > 0 ? bt.threads : effective_threads());
+                return 0;
+            }
+        }
         const std::string prefix = argv[i++];
         if (aliases.empty()) {  // convention: species_aliases.tsv next to the model files
             const std::string cand = dirname_of(prefix) + "/species_aliases.tsv";
@@ -178,8 +232,8 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
                 const BuildTracksStats st = build_tracks(model, argv[i], bt, *backend, !first);
                 fprintf(stderr, "%s: %zu alignments, %zu reference bases, %zu codon-frames, %zu backend calls\n", argv[i], st.alignments,
                         st.ref_bases, st.codon_frames, st.backend_calls);
-                fprintf(stderr, "  seconds: total %.3f = MAF read %.3f + BLS %.3f + codon extraction/power wig %.3f + scoring backend %.3f + raw wig output %.3f\n",
-                        st.total_seconds, st.read_seconds, st.bls_seconds, st.extract_seconds, st.backend_seconds, st.write_seconds);
+                fprintf(stderr, "  seconds: total %.3f = MAF read %.3f + BLS %.3f + batch packing %.3f + scoring backend %.3f + wig output %.3f + smoothing %.3f\n",
+                        st.total_seconds, st.read_seconds, st.bls_seconds, st.extract_seconds, st.backend_seconds, st.write_seconds, st.smooth_seconds);
             } else {
                 const std::string out = score_msa(model, argv[i], sm, *backend);
                 fprintf(stderr, "%s -> %s\n", argv[i], out.c_str());

@@ -8,6 +8,7 @@
 #pragma once
 
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -25,6 +26,7 @@
 #include <thread>
 #include <vector>
 
+#include "hmm.hpp"
 #include "maf_reader.hpp"
 #include "model_io.hpp"
 #include "tracks.hpp"
@@ -84,6 +86,8 @@ struct BuildTracksParams {
     std::string output_dir;          // empty: next to the alignment file
     float power_threshold = 0.1f;    // TrackCLIParams::phylo_threshold
     bool write_raw = true, write_power = true;
+    bool write_smooth = false, write_regions = false;  // --output-phylo, --output-regions (both need `hmm`)
+    Hmm hmm;
     size_t batch_sites = 4u << 20;   // codon-frames gathered per backend call
     bool verbose = false;
     int threads = 0;                 // host threads for ingest / BLS / text output (0 = all the process may use)
@@ -157,7 +161,7 @@ inline FILE* open_out(const std::string& path, const char* mode)
 struct BuildTracksStats {
     size_t alignments = 0, ref_bases = 0, codon_frames = 0, backend_calls = 0;
     double backend_seconds = 0.0;                       // inside ScoringBackend::score_sites_fixed (H2D + kernel + D2H)
-    double read_seconds = 0.0, bls_seconds = 0.0, extract_seconds = 0.0, write_seconds = 0.0, total_seconds = 0.0;
+    double read_seconds = 0.0, bls_seconds = 0.0, extract_seconds = 0.0, write_seconds = 0.0, smooth_seconds = 0.0, total_seconds = 0.0;
 };
 
 struct StopWatch {
@@ -206,6 +210,44 @@ struct WigSink {
 };
 
 
+// The smoothing pass (reference src/phylocsf++build_tracks.hpp:262-366): every PhyloCSFRaw<strand><frame>.wig of
+// out_dir is read back as text, cut into maximal contiguous runs, and each run goes through the HMM:
+// PhyloCSF<strand><frame>.wig gets the log-odds of the coding posterior per codon ("%.3f", trimmed),
+// PhyloCSF<strand><frame>Regions.bed the coding stretches of the Viterbi path.  Six frames, six threads.
+inline void smooth_tracks(const std::string& out_dir, const Hmm& hmm, bool write_smooth, bool write_regions, bool keep_raw, int threads)
+{
+    parallel_for(6, threads, [&](size_t fi) {
+        const char strand = fi < 3 ? '+' : '-';
+        const std::string tag = std::string(1, strand) + std::to_string(fi % 3 + 1);
+        const std::string raw = out_dir + "/PhyloCSFRaw" + tag + ".wig";
+        FILE* f_wig = write_smooth ? open_out(out_dir + "/PhyloCSF" + tag + ".wig", "w") : nullptr;
+        FILE* f_bed = write_regions ? open_out(out_dir + "/PhyloCSF" + tag + "Regions.bed", "w") : nullptr;
+        std::vector<double> post, work;
+        std::vector<BedRegion> regions;
+        {
+            std::unique_ptr<WigSink> out(f_wig ? new WigSink(f_wig) : nullptr);
+            for_each_wig_run(raw, [&](const WigRun& run) {
+                hmm_coding_posterior(hmm, run.scores, post, work);
+                if (out) {
+                    out->header(run.chrom, static_cast<int64_t>(run.start));
+                    for (double p : post) out->value<3>(static_cast<float>(hmm_log_odds(p)));
+                }
+                if (f_bed) {
+                    regions.clear();
+                    hmm_regions(hmm_viterbi(hmm, run.scores), post, static_cast<uint32_t>(run.start), regions);
+                    for (const BedRegion& r : regions)
+                        fprintf(f_bed, "%s\t%" PRIu32 "\t%" PRIu32 "\t%s:%" PRIu32 "-%" PRIu32 "\t0\t%c\t%" PRIu32 "\t%" PRIu32 "\t%" PRIu32 ",%" PRIu32 ",%" PRIu32 "\n",
+                                run.chrom.c_str(), r.start, r.end, run.chrom.c_str(), r.start + 1, r.end, strand, r.start, r.end, r.color, r.color, r.color);
+                }
+            });
+            if (out) out->flush();
+        }
+        if (f_wig) fclose(f_wig);
+        if (f_bed) fclose(f_bed);
+        if (!keep_raw) unlink(raw.c_str());
+    });
+}
+
 // build-tracks for one MAF file.  append: later files of a multi-file run append to the wigs.
 // Stages per window of the file: (1) byte-range jobs parse the MAF and compute the per-base branch-length
 // scores on all host threads; (2) the alignments, in file order, are packed into nucleotide batches and
@@ -219,7 +261,10 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     const char* mode = append ? "a" : "w";
     FILE* f_power = prm.write_power ? open_out(out_dir + "/PhyloCSFpower.wig", mode) : nullptr;
     FILE* f_raw[6] = {nullptr};
-    if (prm.write_raw)
+    // the smoothing pass reads the raw tracks back (as text, like the reference), so they are written even when
+    // they were not asked for, and removed afterwards
+    const bool need_raw = prm.write_raw || prm.write_smooth || prm.write_regions;
+    if (need_raw)
         for (int i = 0; i < 6; ++i)
             f_raw[i] = open_out(out_dir + "/PhyloCSFRaw" + std::string(1, i < 3 ? '+' : '-') + std::to_string(i % 3 + 1) + ".wig", mode);
 
@@ -276,7 +321,7 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     auto run_batch = [&](const std::vector<Item*>& items, size_t columns) {
         if (items.empty()) return;
         StopWatch bw;
-        if (prm.write_raw) {
+        if (need_raw) {
             const size_t stride = std::max(columns, size_t(1));
             if (nucl.size() < nl * stride) nucl.resize(nl * stride);
             std::vector<uint64_t> col0, start_pos, chrom_len;
@@ -301,7 +346,7 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         parallel_for(7, threads, [&](size_t t) {
             if (t == 0) {
                 if (f_power) write_power(items);
-            } else if (prm.write_raw) {
+            } else if (need_raw) {
                 write_frame(items, static_cast<int>(t) - 1);
             }
         });
@@ -366,10 +411,15 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             }
         run_batch(batch, used);
     }
-    st.total_seconds = total.lap();
     if (f_power) fclose(f_power);
     for (FILE* f : f_raw)
         if (f) fclose(f);
+    if (prm.write_smooth || prm.write_regions) {
+        sw.lap();
+        smooth_tracks(out_dir, prm.hmm, prm.write_smooth, prm.write_regions, /*keep_raw=*/prm.write_raw, threads);
+        st.smooth_seconds += sw.lap();
+    }
+    st.total_seconds = total.lap();
     return st;
 }
 

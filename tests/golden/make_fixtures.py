@@ -82,9 +82,12 @@ with open(os.path.join(REF, "test/maf-file-medium/chr22.516alignments.maf"), "rb
         gzip.GzipFile(os.path.join(OUT, "score-msa/chr22.516alignments.maf.gz"), "wb", mtime=0) as fo:
     fo.write(fi.read())
 
-# (5) build-tracks fixtures (test/tests.sh:15-19): input MAF (kept gzipped) + the 7 raw/power wigs
+# (5) build-tracks fixtures (test/tests.sh:15-19): input MAF (kept gzipped) + the 7 raw/power wigs + the 6 smoothed
+# wigs (their HMM parameters came from example/galGal6_coding_exons.txt, which the checkout does not hold:
+# tests/golden/build-tracks/hmm_params_backsolved.json holds parameters fitted to these files, see fit_hmm_params.py)
 copy("example/galGal6_chr22_25_28_each_30k_bases.maf.gz", "build-tracks/galGal6_chr22_25_28_each_30k_bases.maf.gz")
-for w in ["PhyloCSFpower.wig"] + ["PhyloCSFRaw%s%d.wig" % (s, f) for s in "+-" for f in (1, 2, 3)]:
+for w in ["PhyloCSFpower.wig"] + ["PhyloCSFRaw%s%d.wig" % (s, f) for s in "+-" for f in (1, 2, 3)] + \
+        ["PhyloCSF%s%d.wig" % (s, f) for s in "+-" for f in (1, 2, 3)]:
     with open(os.path.join(REF, "test/expected_results/build-tracks", w), "rb") as fi, \
             gzip.GzipFile(os.path.join(OUT, "build-tracks", w + ".gz"), "wb", mtime=0) as fo:
         fo.write(fi.read())

@@ -90,3 +90,31 @@ def test_species_reduced_model_on_gpu_matches_oracle_driver(tmp_path):
     for n in ["PhyloCSFpower"] + ["PhyloCSFRaw%s%d" % (s, f) for s in "+-" for f in (1, 2, 3)]:
         got, want = open(outs[0] / (n + ".wig"), "rb").read(), open(outs[1] / (n + ".wig"), "rb").read()
         assert len(want) > 10000 and got == want, n
+
+
+def test_build_tracks_smoothed_tracks_on_gpu(tmp_path):
+    """--output-phylo 1: raw tracks byte-identical to the goldens, smoothed tracks within the back-solved-parameter
+    tolerance of the reference's (tests/test_hmm.py, tests/golden/fit_hmm_params.py)."""
+    import json
+    maf = tmp_path / "galGal6.maf"
+    with gzip.open(os.path.join(GOLD, "build-tracks", "galGal6_chr22_25_28_each_30k_bases.maf.gz"), "rb") as fi, open(maf, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    prm = json.load(open(os.path.join(GOLD, "build-tracks", "hmm_params_backsolved.json")))["hmm_params"]
+    out = tmp_path / "out"
+    subprocess.check_call([_cli(), "build-tracks", "--output", str(out), "--output-phylo", "1", "--hmm-params", ",".join("%.17g" % x for x in prm),
+                           os.path.join(GOLD, "models", "53birds"), str(maf)])
+    worst, n = 0.0, 0
+    for s in "+-":
+        for f in (1, 2, 3):
+            tag = "%s%d" % (s, f)
+            assert open(out / ("PhyloCSFRaw%s.wig" % tag), "rb").read() == gzip.open(os.path.join(GOLD, "build-tracks", "PhyloCSFRaw%s.wig.gz" % tag), "rb").read()
+            got = open(out / ("PhyloCSF%s.wig" % tag)).read().splitlines()
+            want = gzip.open(os.path.join(GOLD, "build-tracks", "PhyloCSF%s.wig.gz" % tag), "rt").read().splitlines()
+            assert len(got) == len(want)
+            for g, w in zip(got, want):
+                if w[0] == "f":
+                    assert g == w
+                else:
+                    worst = max(worst, abs(float(g) - float(w)))
+                    n += 1
+    assert n == 174648 and worst <= 0.1001
