@@ -252,6 +252,20 @@ class ScoringContext:
     def last_kernel_ms(self):
         return self._lib.pcsf_last_kernel_ms(self._h)
 
+    def debug_eigen_omega(self, q_settings):
+        """Eigen-systems of kappa/omega rate matrices from the device solver: q_settings [n, 12] ->
+        (right [n,64,64], left [n,64,64], lambda [n,64], prior [n,64], failed [n])."""
+        qs = np.ascontiguousarray(np.asarray(q_settings, dtype=np.float64).reshape(-1, 12))
+        n = qs.shape[0]
+        right, left = np.empty((n, 64, 64)), np.empty((n, 64, 64))
+        lam, prior = np.empty((n, 64)), np.empty((n, 64))
+        failed = np.zeros(n, dtype=np.int32)
+        dp = C.POINTER(C.c_double)
+        self._lib.pcsf_debug_eigen_omega.argtypes = [C.c_void_p, dp, C.c_size_t, dp, dp, dp, dp, C.POINTER(C.c_int32)]
+        self._check(self._lib.pcsf_debug_eigen_omega(self._h, qs.ctypes.data_as(dp), n, right.ctypes.data_as(dp), left.ctypes.data_as(dp),
+                                                     lam.ctypes.data_as(dp), prior.ctypes.data_as(dp), failed.ctypes.data_as(C.POINTER(C.c_int32))))
+        return right, left, lam, prior, failed
+
     def branch_matrices(self):
         out = np.empty((2, self.n_nodes - 1, 64, 64), dtype=np.float64)
         self._check(self._lib.pcsf_get_branch_matrices(self._h, out.ctypes.data_as(C.POINTER(C.c_double))))

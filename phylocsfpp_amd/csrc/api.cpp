@@ -436,4 +436,20 @@ int pcsf_block_loglik(pcsf_ctx* c, int model, const double* q_settings, const do
     }
 }
 
+// diagnostics/tests: the device eigen-solver of the kappa/omega rate matrix (eigen.hip)
+int pcsf_debug_eigen_omega(pcsf_ctx* c, const double* q_settings, size_t n, double* right, double* left, double* lambda, double* prior,
+                           int32_t* failed)
+{
+    if (!c) return PCSF_ERR_INVALID_ARG;
+    if (n == 0) return PCSF_OK;
+    if (!q_settings || !right || !left || !lambda || !prior || !failed) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_debug_eigen_omega: bad argument");
+    hipError_t e;
+    if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
+    try {
+        return pcsf::debug_eigen_omega_impl(c, q_settings, n, right, left, lambda, prior, failed);
+    } catch (const std::exception& ex) {
+        return c->fail(PCSF_ERR_HIP, std::string("pcsf_debug_eigen_omega: ") + ex.what());
+    }
+}
+
 }  // extern "C"

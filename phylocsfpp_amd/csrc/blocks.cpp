@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <random>
@@ -62,8 +63,9 @@ struct BlockEngine {
     DeviceBuffer d_codons;                 // [nl][leaf_stride] compact copy
     DeviceBuffer d_frag, d_leaf, d_prior, d_ancw, d_fail;  // table sets, one per block slot
     DeviceBuffer d_eig_r, d_eig_l, d_eig_lam;              // eigen systems
-    DeviceBuffer d_jobs, d_wg0, d_wg1, d_wgt, d_lnz, d_anc;
+    DeviceBuffer d_jobs, d_eig_jobs, d_wg0, d_wg1, d_wgt, d_lnz, d_anc;
     std::vector<ExpmJob> jobs;
+    std::vector<EigenJob> eig_jobs;
     std::vector<uint64_t> wg0, wg1;
     std::vector<uint32_t> wgt;
     std::vector<double> lnz, anc;
@@ -123,6 +125,16 @@ struct BlockEngine {
         priors_dirty = true;
     }
 
+    // queue the eigen-system `eig` (and root prior of table set `table`) of the kappa/omega rate matrix with
+    // settings qs[12]; computed on the device before the branch matrices of the same run()
+    void add_eigen_job(uint32_t eig, uint32_t table, const double* qs)
+    {
+        EigenJob j;
+        j.eig = eig;
+        j.table = table;
+        for (int i = 0; i < 12; ++i) j.qs[i] = qs[i];
+        eig_jobs.push_back(j);
+    }
     // queue the n-1 branch matrices of table set `table` from eigen system `eig` at tree scale x
     void add_expm_jobs(uint32_t table, uint32_t eig, double x)
     {
@@ -155,6 +167,20 @@ struct BlockEngine {
             HIP_TRY(hipMemcpyAsync(d_prior.ptr, h_prior.data(), h_prior.size() * sizeof(double), hipMemcpyHostToDevice, stream));
             HIP_TRY(hipMemcpyAsync(d_ancw.ptr, h_ancw.data(), h_ancw.size() * sizeof(double), hipMemcpyHostToDevice, stream));
             priors_dirty = false;
+        }
+        if (!eig_jobs.empty()) {
+            HIP_TRY(d_eig_jobs.reserve(eig_jobs.size() * sizeof(EigenJob)));
+            HIP_TRY(hipMemcpyAsync(d_eig_jobs.ptr, eig_jobs.data(), eig_jobs.size() * sizeof(EigenJob), hipMemcpyHostToDevice, stream));
+            EigenParams gp{};
+            gp.jobs = d_eig_jobs.as<EigenJob>();
+            gp.n_jobs = static_cast<uint32_t>(eig_jobs.size());
+            gp.eig_right = d_eig_r.as<double>();
+            gp.eig_left = d_eig_l.as<double>();
+            gp.eig_lambda = d_eig_lam.as<double>();
+            gp.prior = d_prior.as<double>();
+            gp.anc_weight = d_ancw.as<double>();
+            gp.fail = d_fail.as<uint32_t>();
+            HIP_TRY(launch_eigen_omega(gp, stream));
         }
         if (!jobs.empty()) {
             HIP_TRY(d_jobs.reserve(jobs.size() * sizeof(ExpmJob)));
@@ -209,6 +235,7 @@ struct BlockEngine {
         HIP_TRY(hipMemcpyAsync(fail.data(), d_fail.ptr, tables * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         jobs.clear();
+        eig_jobs.clear();
         wg0.clear();
         wg1.clear();
         wgt.clear();
@@ -318,7 +345,6 @@ int run_mle(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_bl
 struct OmegaBlock {
     double q_settings[12];
     double tree_scale = 1.0;
-    EigenSystem es;
     std::mt19937 gen;
     MaxLik1D opt;
     int stage = 0;  // 0..5: H0 (rho,kappa)x3 ; 6..11: H1 (rho,kappa)x3 ; 12 = finished
@@ -336,16 +362,13 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
     const long trace_block = std::getenv("PCSF_TRACE_BLOCK") ? std::atol(std::getenv("PCSF_TRACE_BLOCK")) : -1;  // diagnostics
     const size_t nl = static_cast<size_t>(c->n_leaves);
 
-    auto rebuild_eigen = [&](OmegaBlock& ob) {
-        Mat Q;
-        Vec pi;
-        rate_matrix_omega(ob.q_settings, Q, pi);
-        if (!eigen_reversible(Q, pi.data(), ob.es)) ob.failed = true;
-    };
-    // validation-only pass (PhyloModel_make can throw): build every active block's matrices and read the flags
+    // Rate matrix -> eigen-system -> root prior are (re)built on the device (eigen.hip) whenever a block's
+    // q_settings change; block b owns eigen-system b and table set b.
+    // validation-only pass (PhyloModel_make can throw): build every listed block's eigen-system and matrices
+    // and read the flags
     auto validate_all = [&](const std::vector<size_t>& which) {
         for (size_t b : which) {
-            eng.upload_eig(b, blk[b]->es);
+            eng.add_eigen_job(static_cast<uint32_t>(b), static_cast<uint32_t>(b), blk[b]->q_settings);
             eng.add_expm_jobs(static_cast<uint32_t>(b), static_cast<uint32_t>(b), blk[b]->tree_scale);
         }
         eng.run(n_blocks, false);
@@ -370,7 +393,6 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
         ob.q_settings[2] = 1.0;
         for (int i = 3; i < 12; ++i) ob.q_settings[i] = 1.0;
     }
-    parallel_for(live.size(), [&](size_t i) { rebuild_eigen(*blk[live[i]]); });
     validate_all(live);
     // F3x4 nucleotide counts over every non-gap codon of every row (src/run.hpp:105-134)
     parallel_for(live.size(), [&](size_t i) {
@@ -391,7 +413,6 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
             }
         for (int p = 0; p < 3; ++p)
             for (int j = 0; j < 3; ++j) ob.q_settings[3 + 3 * p + j] = cnt[p][j] / cnt[p][3];
-        rebuild_eigen(ob);
     });
     {
         std::vector<size_t> ok;
@@ -408,30 +429,37 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
     for (size_t b : live)
         if (!blk[b]->failed) start_stage(*blk[b]);
 
+    const bool timing = std::getenv("PCSF_TIME_BLOCKS") != nullptr;  // diagnostics: where the rounds spend their time
+    double t_eig = 0.0, t_queue = 0.0, t_run = 0.0, t_opt = 0.0;
+    size_t rounds = 0, evals = 0, eig_evals = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     for (;;) {
         std::vector<size_t> act;
         for (size_t b : live)
             if (!blk[b]->failed && !blk[b]->done) act.push_back(b);
         if (act.empty()) break;
-        // apply each block's request: rho -> tree scale; kappa -> new rate matrix + eigen-system
-        parallel_for(act.size(), [&](size_t i) {
-            OmegaBlock& ob = *blk[act[i]];
+        const auto t0 = now();
+        ++rounds;
+        evals += act.size();
+        for (size_t b : act) eig_evals += (blk[b]->stage % 2) == 1;
+        // apply each block's request: rho -> tree scale; kappa -> new rate matrix + eigen-system (device)
+        const auto t1 = now();
+        for (size_t b : act) {
+            OmegaBlock& ob = *blk[b];
+            if (ob.failed) continue;
             const double x = ob.opt.request();
             if ((ob.stage % 2) == 0) ob.tree_scale = x;
             else {
                 ob.q_settings[0] = x;
-                rebuild_eigen(ob);
+                eng.add_eigen_job(static_cast<uint32_t>(b), static_cast<uint32_t>(b), ob.q_settings);
             }
-        });
-        for (size_t b : act) {
-            OmegaBlock& ob = *blk[b];
-            if (ob.failed) continue;
-            if ((ob.stage % 2) == 1) eng.upload_eig(b, ob.es);
-            eng.set_prior(b, ob.es.prior);
             eng.add_expm_jobs(static_cast<uint32_t>(b), static_cast<uint32_t>(b), ob.tree_scale);
             eng.add_prune(b, static_cast<uint32_t>(b));
         }
+        const auto t2 = now();
         eng.run(n_blocks, false);
+        const auto t3 = now();
         std::vector<size_t> entering_h1;
         for (size_t b : act) {
             OmegaBlock& ob = *blk[b];
@@ -455,12 +483,10 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
             else start_stage(ob);
         }
         if (!entering_h1.empty()) {  // omega_H1 = 0.2, sigma_H1 = 0.01, keep rho and kappa (src/run.hpp:161-166)
-            parallel_for(entering_h1.size(), [&](size_t i) {
-                OmegaBlock& ob = *blk[entering_h1[i]];
-                ob.q_settings[1] = 0.2;
-                ob.q_settings[2] = 0.01;
-                rebuild_eigen(ob);
-            });
+            for (size_t b : entering_h1) {
+                blk[b]->q_settings[1] = 0.2;
+                blk[b]->q_settings[2] = 0.01;
+            }
             std::vector<size_t> ok;
             for (size_t b : entering_h1)
                 if (!blk[b]->failed) ok.push_back(b);
@@ -468,7 +494,15 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
             for (size_t b : ok)
                 if (!blk[b]->failed) start_stage(*blk[b]);
         }
+        const auto t4 = now();
+        t_eig += secs(t0, t1);
+        t_queue += secs(t1, t2);
+        t_run += secs(t2, t3);
+        t_opt += secs(t3, t4);
     }
+    if (timing)
+        fprintf(stderr, "run_omega: %zu blocks, %zu rounds, %zu evaluations (%zu with a new eigen-system): bookkeeping %.3f s, queue %.3f s, device rounds %.3f s, optimiser %.3f s\n",
+                n_blocks, rounds, evals, eig_evals, t_eig, t_queue, t_run, t_opt);
     for (size_t b = 0; b < n_blocks; ++b) {
         const OmegaBlock& ob = *blk[b];
         out_phylo[b] = ob.failed ? NAN : decibans(ob.lpr_h1, ob.lpr_h0);
@@ -487,24 +521,16 @@ int block_loglik_impl(pcsf_ctx* c, int model, const double* q_settings, const do
     for (size_t b = 0; b <= n_blocks; ++b) off[b] = site_offsets[b] - site_offsets[0];
     BlockEngine eng(c, codons ? codons + site_offsets[0] : nullptr, off.data(), n_blocks, leaf_stride);
     eng.reserve_tables(n_blocks);
-    std::vector<EigenSystem> es(model == 2 ? n_blocks : 0);
     std::vector<char> bad(n_blocks, 0);
     if (model == 2) {
-        eng.reserve_eig(n_blocks);
-        parallel_for(n_blocks, [&](size_t b) {
-            Mat Q;
-            Vec pi;
-            rate_matrix_omega(q_settings + 12 * b, Q, pi);
-            if (!eigen_reversible(Q, pi.data(), es[b])) bad[b] = 1;
-        });
+        eng.reserve_eig(n_blocks);  // eigen-systems and root priors come from the device solver (eigen.hip)
     } else {
         eng.reserve_eig(1);
         eng.upload_eig(0, c->eig[model]);
     }
     for (size_t b = 0; b < n_blocks; ++b) {
-        if (bad[b]) continue;
-        if (model == 2) eng.upload_eig(b, es[b]);
-        eng.set_prior(b, model == 2 ? es[b].prior : c->eig[model].prior);
+        if (model == 2) eng.add_eigen_job(static_cast<uint32_t>(b), static_cast<uint32_t>(b), q_settings + 12 * b);
+        else eng.set_prior(b, c->eig[model].prior);
         eng.add_expm_jobs(static_cast<uint32_t>(b), model == 2 ? static_cast<uint32_t>(b) : 0u, tree_scale[b]);
         eng.add_prune(b, static_cast<uint32_t>(b));
     }
@@ -514,6 +540,44 @@ int block_loglik_impl(pcsf_ctx* c, int model, const double* q_settings, const do
         if (out_failed) out_failed[b] = f;
         out_lpr[b] = f ? NAN : (off[b + 1] > off[b] ? eng.block_sum(eng.lnz, b) : 0.0);
     }
+    return PCSF_OK;
+}
+
+// diagnostics/tests: eigen-systems of n kappa/omega rate matrices from the device solver
+int debug_eigen_omega_impl(pcsf_ctx* c, const double* q_settings, size_t n, double* right, double* left, double* lambda, double* prior,
+                           int32_t* failed)
+{
+    DeviceBuffer d_jobs, d_r, d_l, d_lam, d_prior, d_fail;
+    std::vector<EigenJob> jobs(n);
+    for (size_t i = 0; i < n; ++i) {
+        jobs[i].eig = jobs[i].table = static_cast<uint32_t>(i);
+        for (int k = 0; k < 12; ++k) jobs[i].qs[k] = q_settings[12 * i + k];
+    }
+    HIP_TRY(d_jobs.reserve(n * sizeof(EigenJob)));
+    HIP_TRY(d_r.reserve(n * 4096 * 8));
+    HIP_TRY(d_l.reserve(n * 4096 * 8));
+    HIP_TRY(d_lam.reserve(n * 64 * 8));
+    HIP_TRY(d_prior.reserve(n * 64 * 8));
+    HIP_TRY(d_fail.reserve(n * 4));
+    HIP_TRY(hipMemsetAsync(d_fail.ptr, 0, n * 4, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_jobs.ptr, jobs.data(), n * sizeof(EigenJob), hipMemcpyHostToDevice, c->stream));
+    EigenParams gp{};
+    gp.jobs = d_jobs.as<EigenJob>();
+    gp.n_jobs = static_cast<uint32_t>(n);
+    gp.eig_right = d_r.as<double>();
+    gp.eig_left = d_l.as<double>();
+    gp.eig_lambda = d_lam.as<double>();
+    gp.prior_plain = d_prior.as<double>();  // state order; the lane-order copies are not wanted here
+    gp.fail = d_fail.as<uint32_t>();
+    HIP_TRY(launch_eigen_omega(gp, c->stream));
+    std::vector<uint32_t> f(n);
+    HIP_TRY(hipMemcpyAsync(right, d_r.ptr, n * 4096 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(left, d_l.ptr, n * 4096 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(lambda, d_lam.ptr, n * 64 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(prior, d_prior.ptr, n * 64 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(f.data(), d_fail.ptr, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; ++i) failed[i] = static_cast<int32_t>(f[i]);
     return PCSF_OK;
 }
 

@@ -1,0 +1,243 @@
+// eigen.hip -- batched eigen-systems of the kappa/omega F3x4 codon rate matrix on gfx950.
+//
+// OMEGA re-derives the rate matrix and its eigen-system at every kappa evaluation of every block
+// (reference src/omega.hpp:38-128 + src/instance.hpp:309-434: gsl_eigen_nonsymmv and a complex LU inverse;
+// ~170-200 evaluations per block, half of them with a new matrix).  Here one work-group per job
+//   1. builds pi and Q from the twelve q_settings exactly like hostmath.hpp::rate_matrix_omega
+//      (same per-element arithmetic and the same summation order for the diagonal and the normaliser),
+//   2. symmetrises B = D^1/2 Q D^-1/2 (Q is reversible w.r.t. pi),
+//   3. diagonalises B with a PARALLEL-ORDER cyclic Jacobi iteration in LDS: 63 steps per sweep, each
+//      applying 32 disjoint plane rotations (round-robin tournament pairing) as B <- J^T B J, V <- V J.
+//      Only rotations, so the near-zero eigenvalue keeps its relative accuracy (the equilibrium prior is read
+//      off its eigenvector), same stopping rule as the host solver (off^2 <= 1e-58 * diag^2),
+//   4. writes right = D^-1/2 V, left = V^T D^1/2, lambda, and the root prior (+ ln(prior)*prior) of the job's
+//      table set in the lane order the pruning kernel reads.
+// The host solver (hostmath.hpp::eigen_reversible, sequential row-cyclic order) stays the reference for tests:
+// the two agree to rounding (tests/test_gpu_blocks.py), not bit for bit -- rotation order differs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace pcsf {
+
+namespace {
+constexpr int LD = 65;  // padded row length: column walks hit 32 different banks
+
+// genetic code in A,C,G,T order, '*' = stop (as hostmath.hpp::amino_acid)
+__device__ __forceinline__ char amino_acid_dev(int codon)
+{
+    const char* code = "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF";
+    return code[codon];
+}
+
+__device__ __forceinline__ double f3x4_weight(const double* qs, int codon)
+{
+    const int d0 = codon >> 4, d1 = (codon >> 2) & 3, d2 = codon & 3;
+    const double f1 = ((d0 == 3) ? 1.0 : qs[3 + d0]) / (1.0 + qs[3] + qs[4] + qs[5]);
+    const double f2 = ((d1 == 3) ? 1.0 : qs[6 + d1]) / (1.0 + qs[6] + qs[7] + qs[8]);
+    const double f3 = ((d2 == 3) ? 1.0 : qs[9 + d2]) / (1.0 + qs[9] + qs[10] + qs[11]);
+    return f1 * f2 * f3;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_eig[];  // 2 x 64 x 65 doubles = 66,560 B
+    double* A = lds_eig;
+    double* V = lds_eig + 64 * LD;
+    __shared__ double pi[64], root[64], iroot[64], cs[32], sn[32], red[8];
+    __shared__ int pp[32], qq[32];
+    __shared__ double norm_s;
+    __shared__ int flag;
+
+    const EigenJob job = p.jobs[blockIdx.x];
+    const double* qs = job.qs;
+    const int tid = threadIdx.x;
+    if (tid == 0) flag = 0;
+    if (tid < 64) {
+        const double stop_mass = f3x4_weight(qs, 48) + f3x4_weight(qs, 50) + f3x4_weight(qs, 56);  // TAA, TAG, TGA
+        const double denom = 1.0 - ((1.0 - qs[2]) * stop_mass);
+        pi[tid] = f3x4_weight(qs, tid) / denom;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        if (!(pi[tid] > 0.0)) flag = 1;
+        root[tid] = sqrt(pi[tid]);
+        iroot[tid] = 1.0 / root[tid];
+    }
+    const double kappa = qs[0], omega = qs[1];
+    for (int idx = tid; idx < 4096; idx += 256) {
+        const int i = idx >> 6, j = idx & 63;
+        double rate = 0.0;
+        const int x = i ^ j;
+        const int ndiff = ((x & 0x30) != 0) + ((x & 0x0c) != 0) + ((x & 0x03) != 0);
+        if (ndiff == 1) {
+            const int shift = (x & 0x30) ? 4 : ((x & 0x0c) ? 2 : 0);
+            const int a = (i >> shift) & 3, b = (j >> shift) & 3;
+            const bool transition = (a + b == 2) || (a + b == 4);
+            rate = transition ? kappa : 1.0;
+            const char ai = amino_acid_dev(i), aj = amino_acid_dev(j);
+            rate *= (ai != '*' && aj != '*' && ai != aj) ? omega : 1.0;
+            rate *= pi[j];
+        }
+        A[i * LD + j] = rate;
+        V[i * LD + j] = i == j ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (flag) {  // pi has a non-positive entry: the model is invalid (host: eigen_reversible returns false)
+        if (tid == 0) p.fail[job.table] = 1u;
+        return;
+    }
+    if (tid < 64) {
+        double diag = 0.0;
+        for (int j = 0; j < 64; ++j)
+            if (j != tid) diag -= A[tid * LD + j];
+        A[tid * LD + tid] = diag;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double norm = 0.0;
+        for (int i = 0; i < 64; ++i) norm -= pi[i] * A[i * LD + i];
+        norm_s = norm;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 4096; idx += 256) {
+        const int i = idx >> 6, j = idx & 63;
+        A[i * LD + j] = root[i] * (A[i * LD + j] / norm_s) * iroot[j];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 4096; idx += 256) {
+        const int i = idx >> 6, j = idx & 63;
+        if (i < j) {
+            const double m = 0.5 * (A[i * LD + j] + A[j * LD + i]);
+            A[i * LD + j] = m;
+            A[j * LD + i] = m;
+        }
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        // convergence: squared off-diagonal mass against squared diagonal mass
+        double off = 0.0, total = 0.0;
+        for (int idx = tid; idx < 4096; idx += 256) {
+            const int i = idx >> 6, j = idx & 63;
+            const double v = A[i * LD + j];
+            if (i == j) total += v * v;
+            else off += v * v;
+        }
+        for (int s = 32; s > 0; s >>= 1) {
+            off += __shfl_xor(off, s);
+            total += __shfl_xor(total, s);
+        }
+        if (lane == 0) {
+            red[wave] = off;
+            red[4 + wave] = total;
+        }
+        __syncthreads();
+        off = red[0] + red[1] + red[2] + red[3];
+        total = red[4] + red[5] + red[6] + red[7];
+        __syncthreads();
+        if (off <= 1e-58 * total) break;
+
+        for (int step = 0; step < 63; ++step) {
+            if (tid < 32) {  // tournament pairing of 0..63: 63 stays, the others rotate
+                int a, b;
+                if (tid == 0) {
+                    a = step;
+                    b = 63;
+                } else {
+                    a = (step + tid) % 63;
+                    b = (step - tid + 63) % 63;
+                }
+                const int pi_ = a < b ? a : b, qi = a < b ? b : a;
+                const double g = A[pi_ * LD + qi];
+                double c = 1.0, s = 0.0;
+                if (!(fabs(g) < 1e-290)) {
+                    const double zeta = (A[qi * LD + qi] - A[pi_ * LD + pi_]) / (2.0 * g);
+                    const double t = (fabs(zeta) > 1e150) ? 0.5 / zeta : copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    c = 1.0 / sqrt(1.0 + t * t);
+                    s = t * c;
+                }
+                cs[tid] = c;
+                sn[tid] = s;
+                pp[tid] = pi_;
+                qq[tid] = qi;
+            }
+            __syncthreads();
+            // columns p,q of A and of V (item = pair m x row k)
+            for (int item = tid; item < 2048; item += 256) {
+                const int m = item >> 6, k = item & 63;
+                const int pc = pp[m], qc = qq[m];
+                const double c = cs[m], s = sn[m];
+                const double x = A[k * LD + pc], y = A[k * LD + qc];
+                A[k * LD + pc] = c * x - s * y;
+                A[k * LD + qc] = s * x + c * y;
+                const double vx = V[k * LD + pc], vy = V[k * LD + qc];
+                V[k * LD + pc] = c * vx - s * vy;
+                V[k * LD + qc] = s * vx + c * vy;
+            }
+            __syncthreads();
+            // rows p,q of A; the rotated pair itself becomes exactly zero
+            for (int item = tid; item < 2048; item += 256) {
+                const int m = item >> 6, k = item & 63;
+                const int pr = pp[m], qr = qq[m];
+                const double c = cs[m], s = sn[m];
+                const double x = A[pr * LD + k], y = A[qr * LD + k];
+                double nx = c * x - s * y, ny = s * x + c * y;
+                if (k == qr) nx = 0.0;  // a_pq and a_qp: annihilated by the rotation (or already below 1e-290)
+                if (k == pr) ny = 0.0;
+                A[pr * LD + k] = nx;
+                A[qr * LD + k] = ny;
+            }
+            __syncthreads();
+        }
+    }
+
+    // eigen-system of Q: right = D^-1/2 V (eigenvectors in columns), left = V^T D^1/2 (in rows)
+    double* __restrict__ R = p.eig_right + static_cast<size_t>(job.eig) * 4096;
+    double* __restrict__ L = p.eig_left + static_cast<size_t>(job.eig) * 4096;
+    double* __restrict__ lam = p.eig_lambda + static_cast<size_t>(job.eig) * 64;
+    for (int idx = tid; idx < 4096; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        R[idx] = iroot[r] * V[r * LD + c];   // right[i][k], i = r, k = c
+        L[idx] = V[c * LD + r] * root[c];    // left[k][i],  k = r, i = c
+    }
+    if (tid < 64) lam[tid] = A[tid * LD + tid];
+    // equilibrium: left eigenvector of the eigenvalue closest to zero, scaled to sum 1 (index order)
+    if (tid == 0) {
+        int z = 0;
+        for (int k = 1; k < 64; ++k)
+            if (fabs(A[k * LD + k]) < fabs(A[z * LD + z])) z = k;
+        double mass = 0.0;
+        for (int j = 0; j < 64; ++j) mass += V[j * LD + z] * root[j];
+        norm_s = mass;
+        pp[0] = z;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int z = pp[0];
+        const double pr = (V[tid * LD + z] * root[tid]) / norm_s;
+        const int lane_pos = (tid & 3) * 16 + (tid >> 2);  // lane order: [g][q] = state 4q+g
+        if (p.prior) p.prior[static_cast<size_t>(job.table) * 64 + lane_pos] = pr;
+        if (p.anc_weight) p.anc_weight[static_cast<size_t>(job.table) * 64 + lane_pos] = log(pr) * pr;
+        if (p.prior_plain) p.prior_plain[static_cast<size_t>(job.eig) * 64 + tid] = pr;
+    }
+}
+
+hipError_t launch_eigen_omega(const EigenParams& p, hipStream_t stream)
+{
+    if (p.n_jobs == 0) return hipSuccess;
+    constexpr size_t lds = 2 * 64 * LD * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eigen_omega_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(eigen_omega_kernel, dim3(p.n_jobs), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace pcsf

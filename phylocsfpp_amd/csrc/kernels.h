@@ -76,6 +76,27 @@ struct ExpmParams {
 
 hipError_t launch_expm(const ExpmParams& p, hipStream_t stream);
 
+// Batched eigen-systems of the kappa/omega F3x4 rate matrix (eigen.hip): one job = one rate matrix.
+struct EigenJob {
+    uint32_t eig;      // destination eigen-system index
+    uint32_t table;    // table set whose root prior this eigen-system defines
+    double qs[12];     // kappa, omega, sigma, nine nucleotide-frequency ratios (src/run.hpp:75-79)
+};
+
+struct EigenParams {
+    const EigenJob* jobs;
+    uint32_t n_jobs;
+    double* eig_right;    // [n_eig][64*64]
+    double* eig_left;     // [n_eig][64*64]
+    double* eig_lambda;   // [n_eig][64]
+    double* prior;        // [table][64] equilibrium prior in lane order (may be null)
+    double* anc_weight;   // [table][64] ln(prior)*prior in lane order (may be null)
+    double* prior_plain;  // optional [n_eig][64] prior in state order (diagnostics/tests)
+    uint32_t* fail;       // [table]: set to 1 when pi has a non-positive entry
+};
+
+hipError_t launch_eigen_omega(const EigenParams& p, hipStream_t stream);
+
 }  // namespace pcsf
 
 namespace pcsf {

@@ -137,7 +137,41 @@ def test_objective_values_match_oracle(small_blocks, gpu_contexts):
         got, failed = ctx.block_loglik(2, sub, sub_off, rho, q_settings=qs)
         assert not failed.any()
         want = np.array([_oracle_lpr(m, qd, s, rho) for s in subs])
-        np.testing.assert_allclose(got, want, rtol=1e-9 if rho >= 0.05 else 1e-6)
+        # Here the eigen-systems come from two different solvers (device: parallel-order Jacobi, oracle: row-cyclic
+        # Jacobi).  The objective itself is only defined to that level: the reference clamps noise-level negative
+        # entries of P to zero and rebuilds the diagonal, so columns that need an a-priori impossible double change
+        # see the solver's rounding -- the oracle's Jacobi and LAPACK's eigh differ by 3e-9 (rho = 0.3, sigma = 0.01)
+        # and 2e-6 (rho = 0.02) on these very blocks.
+        np.testing.assert_allclose(got, want, rtol=2e-8 if rho >= 0.05 else 1e-5)
+
+
+def test_device_eigen_solver_of_the_omega_rate_matrix(gpu_contexts):
+    """eigen.hip (parallel-order Jacobi, one work-group per matrix) against the oracle's rate matrix: Q = R diag(lambda) L,
+    L R = I, the spectrum of the symmetrised matrix, and the equilibrium prior pi / sum(pi)."""
+    ctx = gpu_contexts("100vertebrates")
+    rng = np.random.default_rng(12)
+    qs = np.empty((97, 12))
+    qs[:, 0] = rng.uniform(1.0, 10.0, 97)                 # kappa
+    qs[:, 1] = rng.choice([1.0, 0.2, 0.05, 3.0], 97)       # omega
+    qs[:, 2] = rng.choice([1.0, 0.01, 0.5], 97)            # sigma
+    qs[:, 3:] = np.exp(rng.uniform(np.log(0.05), np.log(20.0), (97, 9)))
+    qs[0] = [2.5, 1.0, 1.0] + [1.0] * 9                    # the uniform starting point of every block
+    qs[1] = [1.0, 0.2, 0.01] + [1.0] * 9
+    qs[96, 5] = -0.5                                       # a negative frequency ratio: invalid model
+    right, left, lam, prior, failed = ctx.debug_eigen_omega(qs)
+    assert failed[96] == 1 and not failed[:96].any()
+    dp = C.POINTER(C.c_double)
+    for i in range(96):
+        Q, pi = np.empty((64, 64)), np.empty(64)
+        ob.lib().po_q_from_omega(np.ascontiguousarray(qs[i]).ctypes.data_as(dp), Q.ctypes.data_as(dp), pi.ctypes.data_as(dp))
+        scale = np.abs(Q).max()
+        assert np.abs((right[i] * lam[i]) @ left[i] - Q).max() <= 2e-13 * scale
+        assert np.abs(left[i] @ right[i] - np.eye(64)).max() <= 1e-12
+        B = np.sqrt(pi)[:, None] * Q / np.sqrt(pi)[None, :]
+        want = np.linalg.eigvalsh(0.5 * (B + B.T))
+        np.testing.assert_allclose(np.sort(lam[i]), want, rtol=1e-11, atol=1e-14 * scale)
+        np.testing.assert_allclose(prior[i], pi / pi.sum(), rtol=1e-11)
+        assert abs(prior[i].sum() - 1.0) < 1e-14
 
 
 def test_random_blocks_fixed_with_empty_and_ragged(oracle_models, gpu_contexts):
