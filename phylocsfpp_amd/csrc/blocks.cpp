@@ -64,10 +64,16 @@ struct BlockEngine {
     DeviceBuffer d_frag, d_leaf, d_prior, d_ancw, d_fail;  // table sets, one per block slot
     DeviceBuffer d_eig_r, d_eig_l, d_eig_lam;              // eigen systems
     DeviceBuffer d_jobs, d_eig_jobs, d_wg0, d_wg1, d_wgt, d_lnz, d_anc;
-    std::vector<ExpmJob> jobs;
+    // Work of one run() is kept in two sets: tables whose eigen-system is rebuilt in this run (set 1: eigen ->
+    // expm -> prune on the side stream) and all others (set 0: expm -> prune on the main stream), so that the
+    // latency-bound eigen kernel of one half of the blocks overlaps the matrix work of the other half.
+    std::vector<ExpmJob> jobs[2];
     std::vector<EigenJob> eig_jobs;
-    std::vector<uint64_t> wg0, wg1;
-    std::vector<uint32_t> wgt;
+    std::vector<uint64_t> wg0[2], wg1[2];
+    std::vector<uint32_t> wgt[2];
+    std::vector<uint8_t> table_set;   // [table] -> 0 / 1 for the current run()
+    hipStream_t side = nullptr;
+    hipEvent_t ev_start = nullptr, ev_side = nullptr;
     std::vector<double> lnz, anc;
     std::vector<uint32_t> fail;
     size_t cap_tables = 0, cap_eig = 0;
@@ -79,14 +85,30 @@ struct BlockEngine {
         nl = c->n_leaves;
         n = c->n_nodes;
         n_sites_total = offsets[nb];
+        HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
         if (n_sites_total > 0) {
             HIP_TRY(d_codons.reserve(static_cast<size_t>(nl) * n_sites_total));
             HIP_TRY(hipMemcpy2DAsync(d_codons.ptr, n_sites_total, codons, stride, n_sites_total, nl, hipMemcpyHostToDevice, stream));
         }
     }
 
+    ~BlockEngine()
+    {
+        if (side) {
+            (void)hipStreamSynchronize(side);
+            (void)hipStreamDestroy(side);
+        }
+        if (ev_start) (void)hipEventDestroy(ev_start);
+        if (ev_side) (void)hipEventDestroy(ev_side);
+    }
+    BlockEngine(const BlockEngine&) = delete;
+    BlockEngine& operator=(const BlockEngine&) = delete;
+
     void reserve_tables(size_t tables)
     {
+        if (table_set.size() < tables) table_set.resize(tables, 0);
         if (tables <= cap_tables) return;
         HIP_TRY(d_frag.reserve(std::max<size_t>(1, tables * ne) * 4096 * sizeof(double)));
         HIP_TRY(d_leaf.reserve(tables * nl * LEAF_TABLE_DOUBLES_DEV * sizeof(double)));
@@ -134,6 +156,7 @@ struct BlockEngine {
         j.table = table;
         for (int i = 0; i < 12; ++i) j.qs[i] = qs[i];
         eig_jobs.push_back(j);
+        table_set[table] = 1;
     }
     // queue the n-1 branch matrices of table set `table` from eigen system `eig` at tree scale x
     void add_expm_jobs(uint32_t table, uint32_t eig, double x)
@@ -145,16 +168,17 @@ struct BlockEngine {
             j.slot = c->branch_slot[b];
             j.leaf = b < nl ? b : -1;
             j.t = scaled_branch(c->branch_len[b], x);
-            jobs.push_back(j);
+            jobs[table_set[table]].push_back(j);
         }
     }
     // queue the work-groups that prune block `blk` with table set `table`
     void add_prune(size_t blk, uint32_t table)
     {
+        const int set = table_set[table];
         for (uint64_t s = off[blk]; s < off[blk + 1]; s += 64) {
-            wg0.push_back(s);
-            wg1.push_back(std::min<uint64_t>(s + 64, off[blk + 1]));
-            wgt.push_back(table);
+            wg0[set].push_back(s);
+            wg1[set].push_back(std::min<uint64_t>(s + 64, off[blk + 1]));
+            wgt[set].push_back(table);
         }
     }
 
@@ -168,62 +192,91 @@ struct BlockEngine {
             HIP_TRY(hipMemcpyAsync(d_ancw.ptr, h_ancw.data(), h_ancw.size() * sizeof(double), hipMemcpyHostToDevice, stream));
             priors_dirty = false;
         }
+        // uploads (main stream), then the two sets on their streams
+        const size_t nj0 = jobs[0].size(), nj1 = jobs[1].size(), nw0 = wg0[0].size(), nw1 = wg0[1].size();
         if (!eig_jobs.empty()) {
             HIP_TRY(d_eig_jobs.reserve(eig_jobs.size() * sizeof(EigenJob)));
             HIP_TRY(hipMemcpyAsync(d_eig_jobs.ptr, eig_jobs.data(), eig_jobs.size() * sizeof(EigenJob), hipMemcpyHostToDevice, stream));
-            EigenParams gp{};
-            gp.jobs = d_eig_jobs.as<EigenJob>();
-            gp.n_jobs = static_cast<uint32_t>(eig_jobs.size());
-            gp.eig_right = d_eig_r.as<double>();
-            gp.eig_left = d_eig_l.as<double>();
-            gp.eig_lambda = d_eig_lam.as<double>();
-            gp.prior = d_prior.as<double>();
-            gp.anc_weight = d_ancw.as<double>();
-            gp.fail = d_fail.as<uint32_t>();
-            HIP_TRY(launch_eigen_omega(gp, stream));
         }
-        if (!jobs.empty()) {
-            HIP_TRY(d_jobs.reserve(jobs.size() * sizeof(ExpmJob)));
-            HIP_TRY(hipMemcpyAsync(d_jobs.ptr, jobs.data(), jobs.size() * sizeof(ExpmJob), hipMemcpyHostToDevice, stream));
-            ExpmParams ep{};
-            ep.jobs = d_jobs.as<ExpmJob>();
-            ep.n_jobs = static_cast<uint32_t>(jobs.size());
-            ep.n_edges = ne;
-            ep.n_leaves = nl;
-            ep.eig_right = d_eig_r.as<double>();
-            ep.eig_left = d_eig_l.as<double>();
-            ep.eig_lambda = d_eig_lam.as<double>();
-            ep.frag = d_frag.as<double>();
-            ep.leaf_tab = d_leaf.as<double>();
-            ep.fail = d_fail.as<uint32_t>();
-            HIP_TRY(launch_expm(ep, stream));
+        if (nj0 + nj1) {
+            HIP_TRY(d_jobs.reserve((nj0 + nj1) * sizeof(ExpmJob)));
+            if (nj0) HIP_TRY(hipMemcpyAsync(d_jobs.as<ExpmJob>(), jobs[0].data(), nj0 * sizeof(ExpmJob), hipMemcpyHostToDevice, stream));
+            if (nj1) HIP_TRY(hipMemcpyAsync(d_jobs.as<ExpmJob>() + nj0, jobs[1].data(), nj1 * sizeof(ExpmJob), hipMemcpyHostToDevice, stream));
         }
-        if (!wg0.empty()) {
-            const size_t nw = wg0.size();
+        if (nw0 + nw1) {
+            const size_t nw = nw0 + nw1;
             HIP_TRY(d_wg0.reserve(nw * 8));
             HIP_TRY(d_wg1.reserve(nw * 8));
             HIP_TRY(d_wgt.reserve(nw * 4));
             HIP_TRY(d_lnz.reserve(n_sites_total * 8));
             HIP_TRY(d_anc.reserve(n_sites_total * 8));
-            HIP_TRY(hipMemcpyAsync(d_wg0.ptr, wg0.data(), nw * 8, hipMemcpyHostToDevice, stream));
-            HIP_TRY(hipMemcpyAsync(d_wg1.ptr, wg1.data(), nw * 8, hipMemcpyHostToDevice, stream));
-            HIP_TRY(hipMemcpyAsync(d_wgt.ptr, wgt.data(), nw * 4, hipMemcpyHostToDevice, stream));
-            PruneParams p = base_prune_params(c);
-            p.codons = d_codons.as<uint8_t>();
-            p.n_sites = n_sites_total;
-            p.leaf_stride = n_sites_total;
-            p.n_passes = 1;
-            p.frag = d_frag.as<double>();
-            p.leaf_tab = d_leaf.as<double>();
-            p.prior = d_prior.as<double>();
-            p.anc_weight = d_ancw.as<double>();
-            p.wg_site0 = d_wg0.as<uint64_t>();
-            p.wg_site_end = d_wg1.as<uint64_t>();
-            p.wg_table = d_wgt.as<uint32_t>();
-            p.n_wgs = nw;
-            p.out_lnz = d_lnz.as<double>();
-            p.out_anc = want_anc ? d_anc.as<double>() : nullptr;
-            HIP_TRY(launch_prune_fixed(p, 16, stream, 0));
+            for (int set = 0; set < 2; ++set) {
+                const size_t at = set ? nw0 : 0, cnt = wg0[set].size();
+                if (!cnt) continue;
+                HIP_TRY(hipMemcpyAsync(d_wg0.as<uint64_t>() + at, wg0[set].data(), cnt * 8, hipMemcpyHostToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(d_wg1.as<uint64_t>() + at, wg1[set].data(), cnt * 8, hipMemcpyHostToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(d_wgt.as<uint32_t>() + at, wgt[set].data(), cnt * 4, hipMemcpyHostToDevice, stream));
+            }
+        }
+        const bool use_side = !eig_jobs.empty() || nj1 || nw1;
+        if (use_side) {
+            HIP_TRY(hipEventRecord(ev_start, stream));
+            HIP_TRY(hipStreamWaitEvent(side, ev_start, 0));
+        }
+        auto expm_and_prune = [&](int set, hipStream_t st) {
+            const size_t nj = set ? nj1 : nj0, j_at = set ? nj0 : 0, nw = set ? nw1 : nw0, w_at = set ? nw0 : 0;
+            if (nj) {
+                ExpmParams ep{};
+                ep.jobs = d_jobs.as<ExpmJob>() + j_at;
+                ep.n_jobs = static_cast<uint32_t>(nj);
+                ep.n_edges = ne;
+                ep.n_leaves = nl;
+                ep.eig_right = d_eig_r.as<double>();
+                ep.eig_left = d_eig_l.as<double>();
+                ep.eig_lambda = d_eig_lam.as<double>();
+                ep.frag = d_frag.as<double>();
+                ep.leaf_tab = d_leaf.as<double>();
+                ep.fail = d_fail.as<uint32_t>();
+                HIP_TRY(launch_expm(ep, st));
+            }
+            if (nw) {
+                PruneParams p = base_prune_params(c);
+                p.codons = d_codons.as<uint8_t>();
+                p.n_sites = n_sites_total;
+                p.leaf_stride = n_sites_total;
+                p.n_passes = 1;
+                p.frag = d_frag.as<double>();
+                p.leaf_tab = d_leaf.as<double>();
+                p.prior = d_prior.as<double>();
+                p.anc_weight = d_ancw.as<double>();
+                p.wg_site0 = d_wg0.as<uint64_t>() + w_at;
+                p.wg_site_end = d_wg1.as<uint64_t>() + w_at;
+                p.wg_table = d_wgt.as<uint32_t>() + w_at;
+                p.n_wgs = nw;
+                p.out_lnz = d_lnz.as<double>();
+                p.out_anc = want_anc ? d_anc.as<double>() : nullptr;
+                HIP_TRY(launch_prune_fixed(p, 16, st, 0));
+            }
+        };
+        if (use_side) {
+            if (!eig_jobs.empty()) {
+                EigenParams gp{};
+                gp.jobs = d_eig_jobs.as<EigenJob>();
+                gp.n_jobs = static_cast<uint32_t>(eig_jobs.size());
+                gp.eig_right = d_eig_r.as<double>();
+                gp.eig_left = d_eig_l.as<double>();
+                gp.eig_lambda = d_eig_lam.as<double>();
+                gp.prior = d_prior.as<double>();
+                gp.anc_weight = d_ancw.as<double>();
+                gp.fail = d_fail.as<uint32_t>();
+                HIP_TRY(launch_eigen_omega(gp, side));
+            }
+            expm_and_prune(1, side);
+            HIP_TRY(hipEventRecord(ev_side, side));
+        }
+        expm_and_prune(0, stream);
+        if (use_side) HIP_TRY(hipStreamWaitEvent(stream, ev_side, 0));
+        if (nw0 + nw1) {
             lnz.resize(n_sites_total);
             HIP_TRY(hipMemcpyAsync(lnz.data(), d_lnz.ptr, n_sites_total * 8, hipMemcpyDeviceToHost, stream));
             if (want_anc) {
@@ -234,11 +287,14 @@ struct BlockEngine {
         fail.resize(tables);
         HIP_TRY(hipMemcpyAsync(fail.data(), d_fail.ptr, tables * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        jobs.clear();
+        for (int set = 0; set < 2; ++set) {
+            jobs[set].clear();
+            wg0[set].clear();
+            wg1[set].clear();
+            wgt[set].clear();
+        }
+        for (const EigenJob& j : eig_jobs) table_set[j.table] = 0;
         eig_jobs.clear();
-        wg0.clear();
-        wg1.clear();
-        wgt.clear();
     }
 
     double block_sum(const std::vector<double>& v, size_t blk) const

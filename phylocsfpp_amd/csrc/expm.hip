@@ -12,93 +12,131 @@
 namespace pcsf {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256) void expm_kernel(const ExpmParams p)
+// jobs per work-group: consecutive jobs nearly always share an eigen-system (a block queues its n-1 branches
+// back to back), so a work-group keeps S as MFMA operand fragments in registers (16 doubles per lane) and
+// S^-1 in LDS (32 KiB) and only re-reads them when the eigen-system index changes.  One job per work-group re-read 64 KiB of
+// eigenvectors per 0.5 MFLOP product and left the kernel at ~6 TFLOP/s (79 % of the OMEGA run).
+constexpr int EXPM_CHUNK = 9;
+
+__global__ __launch_bounds__(256, 2) void expm_kernel(const ExpmParams p)
 {
-    __shared__ double P[64 * 65];      // padded rows: the row pass reads along rows, the scatter along columns
-    __shared__ double rowsum[64];
+    extern __shared__ __attribute__((aligned(16))) double lds_expm[];
+    double* P = lds_expm;               // [64][65] padded rows: the row pass reads along rows, the scatter along columns
+    double* Ls = lds_expm + 64 * 65;    // [64][64] S^-1 of the current eigen-system
+    __shared__ double rowsum[64], lam_s[64], scale_s[64];
     __shared__ int bad;
 
-    const ExpmJob job = p.jobs[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double* __restrict__ R = p.eig_right + static_cast<size_t>(job.eig) * 4096;
-    const double* __restrict__ L = p.eig_left + static_cast<size_t>(job.eig) * 4096;
-    const double* __restrict__ lam = p.eig_lambda + static_cast<size_t>(job.eig) * 64;
-    if (tid == 0) bad = 0;
+    const uint32_t job0 = blockIdx.x * EXPM_CHUNK;
+    const uint32_t job1 = min(p.n_jobs, job0 + EXPM_CHUNK);
+    const int i = 16 * wave + (lane & 15);  // wave w computes rows 16w..16w+15 of P, all four 16-column tiles
+    double r_frag[16];
+    uint32_t have_eig = 0xffffffffu;
 
-    // wave w computes rows 16w..16w+15 of P, all four 16-column tiles
-    double4_t acc[4];
+    for (uint32_t jx = job0; jx < job1; ++jx) {
+        const ExpmJob job = p.jobs[jx];
+        if (job.eig != have_eig) {
+            const double* __restrict__ R = p.eig_right + static_cast<size_t>(job.eig) * 4096;
+            const double* __restrict__ L = p.eig_left + static_cast<size_t>(job.eig) * 4096;
+            const double* __restrict__ lam = p.eig_lambda + static_cast<size_t>(job.eig) * 64;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = double4_t{0.0, 0.0, 0.0, 0.0};
-    const int i = 16 * wave + (lane & 15);
-#pragma unroll 4
-    for (int q = 0; q < 16; ++q) {
-        const int k = 4 * q + (lane >> 4);
-        const double a = R[i * 64 + k];
-        const double e = exp(lam[k] * job.t);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const double b = L[k * 64 + 16 * c + (lane & 15)] * e;
-            acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+            for (int q = 0; q < 16; ++q) r_frag[q] = R[i * 64 + 4 * q + (lane >> 4)];
+            have_eig = job.eig;
+            __syncthreads();  // lam_s / Ls may still be read by the previous job
+            if (tid < 64) lam_s[tid] = lam[tid];
+            for (int idx = tid; idx < 2048; idx += 256)
+                reinterpret_cast<double2_t*>(Ls)[idx] = reinterpret_cast<const double2_t*>(L)[idx];
+            __syncthreads();
         }
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) P[(16 * wave + (lane >> 4) + 4 * r) * 65 + 16 * c + (lane & 15)] = acc[c][r];
-    __syncthreads();
+        if (tid == 0) bad = 0;
+        if (tid < 64) scale_s[tid] = exp(lam_s[tid] * job.t);  // one exponential per eigenvalue and job
+        __syncthreads();
 
-    // row post-processing, one thread per row, in index order like the reference
-    if (tid < 64) {
-        double* row = P + tid * 65;
-        double total = 0.0, diag = 1.0;
-        bool ok = true;
-        for (int j = 0; j < 64; ++j) {
-            const double v = row[j];
-            total += v;
-            if (v < 0.0) {
-                if (fabs(v) > 1e-6) ok = false;
-                row[j] = 0.0;
+        double4_t acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const double e = scale_s[4 * q + (lane >> 4)];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_frag[q], Ls[(4 * q + (lane >> 4)) * 64 + 16 * c + (lane & 15)] * e, acc[c], 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[(16 * wave + (lane >> 4) + 4 * r) * 65 + 16 * c + (lane & 15)] = acc[c][r];
+        __syncthreads();
+
+        // row post-processing, one thread per row, in index order like the reference
+        if (tid < 64) {
+            double* row = P + tid * 65;
+            double total = 0.0, diag = 1.0;
+            bool ok = true;
+            // `lead` = the row sum as far as the columns before the diagonal: the gap-leaf message is the sum of the
+            // FINAL row in index order (src/fixed_lik.hpp:111-117), whose diagonal is only known after this pass
+            double lead = 0.0;
+#pragma unroll 8
+            for (int j = 0; j < 64; ++j) {
+                const double v = row[j];
+                total += v;
+                double vz = v;
+                if (v < 0.0) {
+                    if (fabs(v) > 1e-6) ok = false;
+                    vz = 0.0;
+                    row[j] = 0.0;
+                }
+                if (j != tid) diag -= vz;
+                if (j < tid) lead += vz;
             }
-            if (j != tid) diag -= row[j];
+            if (!(fabs(total - 1.0) <= 1e-6)) ok = false;
+            row[tid] = diag;
+            double s = lead + diag;
+            for (int j = tid + 1; j < 64; ++j) s += row[j];
+            rowsum[tid] = s;
+            if (!ok) bad = 1;
         }
-        if (!(fabs(total - 1.0) <= 1e-6)) ok = false;
-        row[tid] = diag;
-        double s = 0.0;  // message of a gap leaf: sum of the final row, in index order (src/fixed_lik.hpp:111-117)
-        for (int j = 0; j < 64; ++j) s += row[j];
-        rowsum[tid] = s;
-        if (!ok) bad = 1;
-    }
-    __syncthreads();
-    if (tid == 0 && bad) p.fail[job.table] = 1u;
+        __syncthreads();
+        if (tid == 0 && bad) p.fail[job.table] = 1u;
 
-    if (job.slot >= 0) {
-        // fragment order: frag[((q*2+h)*64 + l)*2 + e] = P[16*(2h+e) + (l&15)][4q + (l>>4)]
-        double* dst = p.frag + (static_cast<size_t>(job.table) * p.n_edges + job.slot) * 4096;
-        for (int idx = tid; idx < 4096; idx += 256) {
-            const int e = idx & 1, l = (idx >> 1) & 63, h = (idx >> 7) & 1, q = idx >> 8;
-            dst[idx] = P[(16 * (2 * h + e) + (l & 15)) * 65 + 4 * q + (l >> 4)];
+        if (job.slot >= 0) {
+            // fragment order: frag[((q*2+h)*64 + l)*2 + e] = P[16*(2h+e) + (l&15)][4q + (l>>4)]
+            double* dst = p.frag + (static_cast<size_t>(job.table) * p.n_edges + job.slot) * 4096;
+            for (int idx = tid; idx < 4096; idx += 256) {
+                const int e = idx & 1, l = (idx >> 1) & 63, h = (idx >> 7) & 1, q = idx >> 8;
+                dst[idx] = P[(16 * (2 * h + e) + (l & 15)) * 65 + 4 * q + (l >> 4)];
+            }
         }
-    }
-    if (job.leaf >= 0) {
-        // leaf table: tab[((code*8 + q2)*4 + g)*2 + e] = P[4(2 q2 + e) + g][code], code 64 = row sum
-        double* dst = p.leaf_tab + (static_cast<size_t>(job.table) * p.n_leaves + job.leaf) * LEAF_TABLE_DOUBLES_DEV;
-        for (int idx = tid; idx < LEAF_TABLE_DOUBLES_DEV; idx += 256) {
-            const int e = idx & 1, g = (idx >> 1) & 3, q2 = (idx >> 3) & 7, code = idx >> 6;
-            const int a = 4 * (2 * q2 + e) + g;
-            dst[idx] = code < 64 ? P[a * 65 + code] : rowsum[a];
+        if (job.leaf >= 0) {
+            // leaf table: tab[((code*8 + q2)*4 + g)*2 + e] = P[4(2 q2 + e) + g][code], code 64 = row sum
+            double* dst = p.leaf_tab + (static_cast<size_t>(job.table) * p.n_leaves + job.leaf) * LEAF_TABLE_DOUBLES_DEV;
+            for (int idx = tid; idx < LEAF_TABLE_DOUBLES_DEV; idx += 256) {
+                const int e = idx & 1, g = (idx >> 1) & 3, q2 = (idx >> 3) & 7, code = idx >> 6;
+                const int a = 4 * (2 * q2 + e) + g;
+                dst[idx] = code < 64 ? P[a * 65 + code] : rowsum[a];
+            }
         }
-    }
-    if (p.raw_out) {
-        double* dst = p.raw_out + static_cast<size_t>(blockIdx.x) * 4096;
-        for (int idx = tid; idx < 4096; idx += 256) dst[idx] = P[(idx >> 6) * 65 + (idx & 63)];
+        if (p.raw_out) {
+            double* dst = p.raw_out + static_cast<size_t>(jx) * 4096;
+            for (int idx = tid; idx < 4096; idx += 256) dst[idx] = P[(idx >> 6) * 65 + (idx & 63)];
+        }
+        __syncthreads();  // P is rewritten by the next job
     }
 }
 
 hipError_t launch_expm(const ExpmParams& p, hipStream_t stream)
 {
     if (p.n_jobs == 0) return hipSuccess;
-    hipLaunchKernelGGL(expm_kernel, dim3(p.n_jobs), dim3(256), 0, stream, p);
+    constexpr size_t lds = (64 * 65 + 64 * 64) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&expm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(expm_kernel, dim3((p.n_jobs + EXPM_CHUNK - 1) / EXPM_CHUNK), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
