@@ -640,16 +640,31 @@ int debug_eigen_omega_impl(pcsf_ctx* c, const double* q_settings, size_t n, doub
 int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64_t* site_offsets, size_t n_blocks,
                       size_t leaf_stride, int compute_anc, uint32_t seed, float* out_phylo, float* out_anc)
 {
-    // re-base the CSR offsets at zero
-    std::vector<uint64_t> off(n_blocks + 1);
-    for (size_t b = 0; b <= n_blocks; ++b) off[b] = site_offsets[b] - site_offsets[0];
-    const uint8_t* cod = codons ? codons + site_offsets[0] : nullptr;
-    switch (algo) {
-        case PCSF_FIXED: return run_fixed(c, cod, off.data(), n_blocks, leaf_stride, compute_anc, out_phylo, out_anc);
-        case PCSF_MLE: return run_mle(c, cod, off.data(), n_blocks, leaf_stride, compute_anc, seed, out_phylo, out_anc);
-        case PCSF_OMEGA: return run_omega(c, cod, off.data(), n_blocks, leaf_stride, seed, out_phylo, out_anc);
-        default: return c->fail(PCSF_ERR_INVALID_ARG, "unknown algorithm");
+    // MLE / OMEGA keep one set of branch-matrix tables per block in HBM (9.6 MB for a 100-leaf tree): blocks are
+    // independent, so a long list is processed in chunks that bound that footprint to ~32 GB
+    size_t chunk = n_blocks;
+    if (algo != PCSF_FIXED) {
+        const size_t ne = c->schedule.slot_node.size();
+        const size_t per_table = (ne * 4096 + static_cast<size_t>(c->n_leaves) * LEAF_TABLE_DOUBLES_DEV) * sizeof(double);
+        chunk = std::max<size_t>(64, (size_t(32) << 30) / std::max<size_t>(per_table, 1));
     }
+    for (size_t b0 = 0; b0 < n_blocks; b0 += chunk) {
+        const size_t nb = std::min(chunk, n_blocks - b0);
+        std::vector<uint64_t> off(nb + 1);  // CSR offsets re-based at the chunk's first site
+        for (size_t b = 0; b <= nb; ++b) off[b] = site_offsets[b0 + b] - site_offsets[b0];
+        const uint8_t* cod = codons ? codons + site_offsets[b0] : nullptr;
+        float* ph = out_phylo + b0;
+        float* an = out_anc ? out_anc + b0 : nullptr;
+        int rc;
+        switch (algo) {
+            case PCSF_FIXED: rc = run_fixed(c, cod, off.data(), nb, leaf_stride, compute_anc, ph, an); break;
+            case PCSF_MLE: rc = run_mle(c, cod, off.data(), nb, leaf_stride, compute_anc, seed, ph, an); break;
+            case PCSF_OMEGA: rc = run_omega(c, cod, off.data(), nb, leaf_stride, seed, ph, an); break;
+            default: return c->fail(PCSF_ERR_INVALID_ARG, "unknown algorithm");
+        }
+        if (rc != PCSF_OK) return rc;
+    }
+    return PCSF_OK;
 }
 
 }  // namespace pcsf

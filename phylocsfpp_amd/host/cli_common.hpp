@@ -25,7 +25,7 @@ inline int usage(const char* prog)
             "  %s build-tracks [--output DIR] [--power-threshold 0|1] [--output-raw-phylo 0|1] [--output-power 0|1]\n"
             "                  [--output-phylo 0|1] [--output-regions 0|1] [--genome-length N --coding-exons FILE | --hmm-params P]\n"
             "                  [--species A,B,...] [--mapping FILE] [--species-aliases FILE] [--device N] <model prefix> <alignment.maf>...\n"
-            "  %s score-msa    [--strategy fixed|mle|omega] [--comp-phylo 0|1] [--comp-anc 0|1] [--comp-bls 0|1]\n"
+            "  %s score-msa    [--strategy fixed|mle|omega|fixed_mean] [--comp-phylo 0|1] [--comp-anc 0|1] [--comp-bls 0|1]\n"
             "                  [--output DIR] [--species A,B,...] [--mapping FILE] [--species-aliases FILE] [--device N]\n"
             "                  <model prefix> <alignment.maf>...\n"
             "  %s smooth-tracks [--output-phylo 0|1] [--output-regions 0|1] (--genome-length N --coding-exons FILE | --hmm-params P) DIR\n"
@@ -162,6 +162,7 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
             if (s == "fixed") sm.strategy = ALGO_FIXED;
             else if (s == "mle") sm.strategy = ALGO_MLE;
             else if (s == "omega") sm.strategy = ALGO_OMEGA;
+            else if (s == "fixed_mean") sm.strategy = ALGO_FIXED_MEAN;
             else return usage(argv[0]);
         } else if (k == "--comp-phylo") sm.comp_phylo = parse_bool(v);
         else if (k == "--comp-anc") sm.comp_anc = parse_bool(v);
@@ -174,8 +175,8 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
     if (cmd == "smooth-tracks" && !bt.write_smooth && !bt.write_regions) bt.write_smooth = true;
     if (argc - i < (cmd == "smooth-tracks" ? 1 : 2)) return usage(argv[0]);
     try {
-        if (cmd == "build-tracks" || cmd == "smooth-tracks") {
-            if (bt.write_smooth || bt.write_regions) {
+        {
+            if (cmd == "score-msa" ? sm.strategy == ALGO_FIXED_MEAN : (bt.write_smooth || bt.write_regions)) {
                 HmmParams hp;
                 bool have_matrix = false;
                 if (!hmm_matrix.empty()) {  // 4 initial + 16 row-major transition probabilities of a hand-made HMM
@@ -206,9 +207,10 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
                             hp.non_coding_weights[0], hp.non_coding_weights[1], hp.non_coding_weights[2], hp.non_coding_lengths_in_codons[0],
                             hp.non_coding_lengths_in_codons[1], hp.non_coding_lengths_in_codons[2]);
                 } else {
-                    throw std::runtime_error("for smoothened tracks / regions (--output-phylo, --output-regions) provide --genome-length and --coding-exons (or --hmm-params)");
+                    throw std::runtime_error("for smoothened tracks / regions (--output-phylo, --output-regions) and --strategy fixed_mean provide --genome-length and --coding-exons (or --hmm-params)");
                 }
                 if (!have_matrix) bt.hmm = make_coding_hmm(hp);
+                sm.hmm = bt.hmm;
             }
             if (cmd == "smooth-tracks") {
                 smooth_tracks(argv[i], bt.hmm, bt.write_smooth, bt.write_regions, /*keep_raw=*/true, bt.threads > 0 ? bt.threads : effective_threads());

@@ -34,6 +34,7 @@
 namespace pcsf_host {
 
 enum Algorithm { ALGO_MLE = 0, ALGO_FIXED = 1, ALGO_OMEGA = 2 };  // algorithm_t, src/run.hpp:16-21
+constexpr int ALGO_FIXED_MEAN = 3;  // score-msa --strategy FIXED_MEAN: mean of the HMM-smoothed per-codon FIXED scores
 
 // What the drivers need from a scoring implementation; HipBackend (backend_hip.hpp) forwards to
 // the C-ABI, the test-only OracleBackend (oracle/oracle_cli.cpp) to the CPU oracle.
@@ -428,6 +429,7 @@ struct ScoreMsaParams {
     int strategy = ALGO_MLE;
     bool comp_phylo = true, comp_anc = false, comp_bls = true;
     bool verbose = false;
+    Hmm hmm;  // FIXED_MEAN only
     std::string version_line = "# PhyloCSF scores computed with phylocsf-amd (MI355X)";
 };
 
@@ -468,7 +470,19 @@ inline std::string score_msa(const Model& model, const std::string& maf_path, co
     std::vector<uint8_t> codons(nl * stride);
     for (size_t l = 0; l < nl; ++l) std::copy(per_leaf[l].begin(), per_leaf[l].end(), codons.begin() + l * stride);
     std::vector<float> phylo(rows.size(), NAN), anc(rows.size(), NAN);
-    if ((prm.comp_phylo || prm.comp_anc) && !rows.empty())
+    if (prm.strategy == ALGO_FIXED_MEAN) {
+        // src/phylocsf++score_msa.hpp:133-212: per-codon FIXED scores of the block (run_tracks), smoothed by the HMM as
+        // ONE run, and the mean log-odds -- accumulated in float like the reference -- reported as the score; no anc score
+        std::vector<double> per_codon(total), post, work;
+        if (total) backend.score_sites_fixed(codons.data(), total, stride, per_codon.data());
+        for (size_t i = 0; i < rows.size(); ++i) {
+            const std::vector<double> scores(per_codon.begin() + offsets[i], per_codon.begin() + offsets[i + 1]);
+            hmm_coding_posterior(prm.hmm, scores, post, work);
+            float sum = 0.0f;
+            for (double q : post) sum += hmm_log_odds(q);
+            phylo[i] = sum / static_cast<uint64_t>(post.size());
+        }
+    } else if ((prm.comp_phylo || prm.comp_anc) && !rows.empty())
         backend.score_blocks(prm.strategy, codons.data(), offsets.data(), rows.size(), stride, prm.comp_anc, 42u, phylo.data(), anc.data());
     for (size_t i = 0; i < rows.size(); ++i) {
         const Row& r = rows[i];

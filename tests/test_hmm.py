@@ -152,3 +152,36 @@ def test_build_tracks_writes_smoothed_tracks_and_drops_unwanted_raw_ones(cli, tm
     r = subprocess.run([cli, "build-tracks", "--output", str(out), "--output-phylo", "1", os.path.join(ROOT, "tests", "golden", "models", "53birds"), str(maf)],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "--genome-length" in r.stderr
+
+
+def test_score_msa_fixed_mean_matches_the_python_restatement(cli, tmp_path):
+    """--strategy FIXED_MEAN (reference src/phylocsf++score_msa.hpp:133-212): per-codon FIXED scores of a block, smoothed as
+    one run, float-accumulated mean of the log-odds."""
+    import shutil
+    import maf_blocks
+    import oracle_binding as ob
+    src = os.path.join(ROOT, "tests", "golden", "score-msa", "chr22.50alignments.maf")
+    maf = tmp_path / "small.maf"
+    shutil.copyfile(src, maf)
+    prefix = os.path.join(ROOT, "tests", "golden", "models", "100vertebrates")
+    p = [0.004, 55.0, 0.45, 0.45, 0.10, 800.0, 9000.0, 60.0]
+    subprocess.check_call([cli, "score-msa", "--strategy", "fixed_mean", "--comp-bls", "0", "--hmm-params", _pstr(p), prefix, str(maf)], stderr=subprocess.DEVNULL)
+    rows = [l.split("\t") for l in open(str(maf) + ".scores").read().splitlines() if not l.startswith("#")][1:]
+    assert len(rows) == 50
+    m = ob.OracleModel(prefix)
+    cod, off = maf_blocks.block_codons(src, m.labels, os.path.join(ROOT, "tests", "golden", "models", "species_aliases.tsv"))
+    init, trans = ho.make_hmm(p)
+    n_checked = 0
+    for b, row in enumerate(rows):
+        sub = np.ascontiguousarray(cod[:, int(off[b]):int(off[b + 1])])
+        if sub.shape[1] == 0:
+            assert row[4] in ("nan", "-nan")
+            continue
+        post = ho.coding_posterior(init, trans, list(m.run_tracks(sub)))
+        acc = np.float32(0.0)
+        for q in post:
+            acc = np.float32(float(acc) + ho.log_odds(q))
+        want = np.float32(acc / np.float32(len(post)))
+        assert abs(float(row[4]) - float(want)) <= 1e-6 * max(1.0, abs(float(want))), (b, row[4], want)
+        n_checked += 1
+    assert n_checked >= 40
