@@ -3,12 +3,17 @@
 // FIXED : one tracks-mode launch over all sites (ln z and the ancestral term per site and model),
 //         per-block sums on the host in site order.
 // MLE   : every block maximises over the tree scale, coding model first, then non-coding, sharing
-//         one mt19937 per block like the reference.  All blocks advance in lock-step: per round
-//         the host collects one scale per active block, the GPU builds that block's 2*(n-1)... (n-1)
-//         branch matrices (expm.hip) into the block's table set and prunes the block's sites with
-//         them (block-mode kernel), and the per-site ln z come back for the optimisers.
-// OMEGA : same machinery with the kappa/omega F3x4 rate matrix; rho rounds only re-exponentiate,
-//         kappa rounds rebuild Q and its eigen-system (host, one thread per block).
+//         one mt19937 per block like the reference.  All blocks advance in lock-step rounds.  Per round the
+//         host asks every active block's optimiser for the points it will or may need next (optimizer.hpp:
+//         upcoming()), queues one EVALUATION per point not seen before -- the n-1 branch matrices at that
+//         scale (expm.hip) into a table set, then the block's sites pruned with them (block-mode kernel) --
+//         runs the whole batch, stores the values, and feeds each optimiser from its store until it asks for
+//         a point that is not there.  The sequence of values an optimiser sees is the one it would see
+//         evaluating one point at a time (a re-evaluation of the same point returns the same bits), so
+//         results do not change; the rounds drop from ~250 per stage for blocks that exhaust the random
+//         restarts to a few tens.
+// OMEGA : same machinery with the kappa/omega F3x4 rate matrix; rho evaluations only re-exponentiate,
+//         kappa evaluations rebuild Q and its eigen-system on the device (eigen.hip).
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -53,7 +58,9 @@ void parallel_for(size_t n, F&& f)
     for (auto& t : th) t.join();
 }
 
-// Device state shared by the lock-step strategies
+// Device state shared by the lock-step strategies.  One EVALUATION = (block, eigen-system, tree scale): its
+// branch matrices go to a table set of its own, its per-site ln z to an output segment of its own, so any
+// number of evaluations -- also of the same block -- can share a run().
 struct BlockEngine {
     pcsf_ctx* c;
     size_t n_blocks, leaf_stride, n_sites_total;
@@ -61,22 +68,26 @@ struct BlockEngine {
     hipStream_t stream;
     int ne, nl, n;
     DeviceBuffer d_codons;                 // [nl][leaf_stride] compact copy
-    DeviceBuffer d_frag, d_leaf, d_prior, d_ancw, d_fail;  // table sets, one per block slot
-    DeviceBuffer d_eig_r, d_eig_l, d_eig_lam;              // eigen systems
-    DeviceBuffer d_jobs, d_eig_jobs, d_wg0, d_wg1, d_wgt, d_lnz, d_anc;
-    // Work of one run() is kept in two sets: tables whose eigen-system is rebuilt in this run (set 1: eigen ->
+    DeviceBuffer d_frag, d_leaf, d_fail;   // table sets, one per evaluation of a run
+    DeviceBuffer d_eig_r, d_eig_l, d_eig_lam, d_prior, d_ancw;  // eigen-systems and their root priors
+    DeviceBuffer d_jobs, d_eig_jobs, d_wg0, d_wg1, d_wgt, d_wgp, d_wgo, d_lnz, d_anc;
+    // Work of one run() is kept in two sets: evaluations whose eigen-system is rebuilt in this run (set 1: eigen ->
     // expm -> prune on the side stream) and all others (set 0: expm -> prune on the main stream), so that the
-    // latency-bound eigen kernel of one half of the blocks overlaps the matrix work of the other half.
+    // latency-bound eigen kernel overlaps the matrix work of the other evaluations.
     std::vector<ExpmJob> jobs[2];
     std::vector<EigenJob> eig_jobs;
-    std::vector<uint64_t> wg0[2], wg1[2];
-    std::vector<uint32_t> wgt[2];
-    std::vector<uint8_t> table_set;   // [table] -> 0 / 1 for the current run()
-    hipStream_t side = nullptr;
-    hipEvent_t ev_start = nullptr, ev_side = nullptr;
+    std::vector<uint64_t> wg0[2], wg1[2], wgo[2];
+    std::vector<uint32_t> wgt[2], wgp[2];
+    struct Eval {
+        uint32_t block, table;
+        size_t out0;
+    };
+    std::vector<Eval> evals;
     std::vector<double> lnz, anc;
     std::vector<uint32_t> fail;
-    size_t cap_tables = 0, cap_eig = 0;
+    size_t cap_tables = 0, cap_eig = 0, out_used = 0;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_start = nullptr, ev_side = nullptr;
 
     BlockEngine(pcsf_ctx* ctx, const uint8_t* codons, const uint64_t* offsets, size_t nb, size_t stride)
         : c(ctx), n_blocks(nb), leaf_stride(stride), off(offsets), stream(ctx->stream)
@@ -93,7 +104,6 @@ struct BlockEngine {
             HIP_TRY(hipMemcpy2DAsync(d_codons.ptr, n_sites_total, codons, stride, n_sites_total, nl, hipMemcpyHostToDevice, stream));
         }
     }
-
     ~BlockEngine()
     {
         if (side) {
@@ -106,14 +116,12 @@ struct BlockEngine {
     BlockEngine(const BlockEngine&) = delete;
     BlockEngine& operator=(const BlockEngine&) = delete;
 
+    // capacity: evaluations per run() / eigen-systems alive at a time
     void reserve_tables(size_t tables)
     {
-        if (table_set.size() < tables) table_set.resize(tables, 0);
         if (tables <= cap_tables) return;
         HIP_TRY(d_frag.reserve(std::max<size_t>(1, tables * ne) * 4096 * sizeof(double)));
         HIP_TRY(d_leaf.reserve(tables * nl * LEAF_TABLE_DOUBLES_DEV * sizeof(double)));
-        HIP_TRY(d_prior.reserve(tables * 64 * sizeof(double)));
-        HIP_TRY(d_ancw.reserve(tables * 64 * sizeof(double)));
         HIP_TRY(d_fail.reserve(tables * sizeof(uint32_t)));
         cap_tables = tables;
     }
@@ -123,44 +131,42 @@ struct BlockEngine {
         HIP_TRY(d_eig_r.reserve(count * 4096 * sizeof(double)));
         HIP_TRY(d_eig_l.reserve(count * 4096 * sizeof(double)));
         HIP_TRY(d_eig_lam.reserve(count * 64 * sizeof(double)));
+        HIP_TRY(d_prior.reserve(count * 64 * sizeof(double)));
+        HIP_TRY(d_ancw.reserve(count * 64 * sizeof(double)));
         cap_eig = count;
     }
+    // a host-side eigen-system (the ECM models of the context) and its root prior into slot idx
     void upload_eig(size_t idx, const EigenSystem& es)
     {
         HIP_TRY(hipMemcpyAsync(d_eig_r.as<double>() + idx * 4096, es.right.data(), 4096 * sizeof(double), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(d_eig_l.as<double>() + idx * 4096, es.left.data(), 4096 * sizeof(double), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(d_eig_lam.as<double>() + idx * 64, es.lambda.data(), 64 * sizeof(double), hipMemcpyHostToDevice, stream));
-    }
-    // root prior (and ln(prior)*prior) of a table set: staged on the host, uploaded once per run()
-    std::vector<double> h_prior, h_ancw;
-    bool priors_dirty = false;
-    void set_prior(size_t table, const Vec& prior)
-    {
-        if (h_prior.size() < cap_tables * 64) {
-            h_prior.resize(cap_tables * 64, 0.0);
-            h_ancw.resize(cap_tables * 64, 0.0);
-        }
-        Vec w;
-        for (int x = 0; x < 64; ++x) w[x] = std::log(prior[x]) * prior[x];
-        to_lane_order(prior.data(), h_prior.data() + table * 64);
-        to_lane_order(w.data(), h_ancw.data() + table * 64);
-        priors_dirty = true;
+        Vec w, pl, wl;
+        for (int x = 0; x < 64; ++x) w[x] = std::log(es.prior[x]) * es.prior[x];
+        to_lane_order(es.prior.data(), pl.data());
+        to_lane_order(w.data(), wl.data());
+        HIP_TRY(hipMemcpyAsync(d_prior.as<double>() + idx * 64, pl.data(), 64 * sizeof(double), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(d_ancw.as<double>() + idx * 64, wl.data(), 64 * sizeof(double), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));  // pl / wl are stack temporaries
     }
 
-    // queue the eigen-system `eig` (and root prior of table set `table`) of the kappa/omega rate matrix with
-    // settings qs[12]; computed on the device before the branch matrices of the same run()
-    void add_eigen_job(uint32_t eig, uint32_t table, const double* qs)
+    size_t free_evaluations() const { return cap_tables - evals.size(); }
+
+    // queue one evaluation of block `blk` at tree scale x with eigen-system slot `eig`.  new_qs != null: slot
+    // `eig` is (re)built first from these kappa/omega settings; after_eigen: the slot is rebuilt by ANOTHER
+    // evaluation of this run, so this one has to run behind it.  Returns the evaluation's index in this run.
+    size_t queue(size_t blk, uint32_t eig, double x, const double* new_qs, bool after_eigen = false)
     {
-        EigenJob j;
-        j.eig = eig;
-        j.table = table;
-        for (int i = 0; i < 12; ++i) j.qs[i] = qs[i];
-        eig_jobs.push_back(j);
-        table_set[table] = 1;
-    }
-    // queue the n-1 branch matrices of table set `table` from eigen system `eig` at tree scale x
-    void add_expm_jobs(uint32_t table, uint32_t eig, double x)
-    {
+        const uint32_t table = static_cast<uint32_t>(evals.size());
+        if (table >= cap_tables) throw std::runtime_error("BlockEngine: more evaluations queued than table sets reserved");
+        const int set = (new_qs || after_eigen) ? 1 : 0;
+        if (new_qs) {
+            EigenJob j;
+            j.eig = eig;
+            j.table = table;
+            for (int i = 0; i < 12; ++i) j.qs[i] = new_qs[i];
+            eig_jobs.push_back(j);
+        }
         for (int b = 0; b < n - 1; ++b) {
             ExpmJob j;
             j.eig = eig;
@@ -168,54 +174,51 @@ struct BlockEngine {
             j.slot = c->branch_slot[b];
             j.leaf = b < nl ? b : -1;
             j.t = scaled_branch(c->branch_len[b], x);
-            jobs[table_set[table]].push_back(j);
+            jobs[set].push_back(j);
         }
-    }
-    // queue the work-groups that prune block `blk` with table set `table`
-    void add_prune(size_t blk, uint32_t table)
-    {
-        const int set = table_set[table];
         for (uint64_t s = off[blk]; s < off[blk + 1]; s += 64) {
             wg0[set].push_back(s);
             wg1[set].push_back(std::min<uint64_t>(s + 64, off[blk + 1]));
             wgt[set].push_back(table);
+            wgp[set].push_back(eig);
+            wgo[set].push_back(out_used + (s - off[blk]));
         }
+        evals.push_back({static_cast<uint32_t>(blk), table, out_used});
+        out_used += off[blk + 1] - off[blk];
+        return evals.size() - 1;
     }
 
-    // runs the queued expm jobs and prune work-groups (one pass per work-group); afterwards
-    // lnz[site] (and anc[site] if wanted) hold the per-site values and fail[table] the validation flags
-    void run(size_t tables, bool want_anc)
+    // runs everything queued; afterwards value(k) / failed(k) describe evaluation k
+    void run(bool want_anc)
     {
+        const size_t tables = evals.size();
+        if (tables == 0) return;
         HIP_TRY(hipMemsetAsync(d_fail.ptr, 0, tables * sizeof(uint32_t), stream));
-        if (priors_dirty) {
-            HIP_TRY(hipMemcpyAsync(d_prior.ptr, h_prior.data(), h_prior.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-            HIP_TRY(hipMemcpyAsync(d_ancw.ptr, h_ancw.data(), h_ancw.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-            priors_dirty = false;
-        }
-        // uploads (main stream), then the two sets on their streams
         const size_t nj0 = jobs[0].size(), nj1 = jobs[1].size(), nw0 = wg0[0].size(), nw1 = wg0[1].size();
         if (!eig_jobs.empty()) {
             HIP_TRY(d_eig_jobs.reserve(eig_jobs.size() * sizeof(EigenJob)));
             HIP_TRY(hipMemcpyAsync(d_eig_jobs.ptr, eig_jobs.data(), eig_jobs.size() * sizeof(EigenJob), hipMemcpyHostToDevice, stream));
         }
-        if (nj0 + nj1) {
-            HIP_TRY(d_jobs.reserve((nj0 + nj1) * sizeof(ExpmJob)));
-            if (nj0) HIP_TRY(hipMemcpyAsync(d_jobs.as<ExpmJob>(), jobs[0].data(), nj0 * sizeof(ExpmJob), hipMemcpyHostToDevice, stream));
-            if (nj1) HIP_TRY(hipMemcpyAsync(d_jobs.as<ExpmJob>() + nj0, jobs[1].data(), nj1 * sizeof(ExpmJob), hipMemcpyHostToDevice, stream));
-        }
+        HIP_TRY(d_jobs.reserve((nj0 + nj1) * sizeof(ExpmJob)));
+        if (nj0) HIP_TRY(hipMemcpyAsync(d_jobs.as<ExpmJob>(), jobs[0].data(), nj0 * sizeof(ExpmJob), hipMemcpyHostToDevice, stream));
+        if (nj1) HIP_TRY(hipMemcpyAsync(d_jobs.as<ExpmJob>() + nj0, jobs[1].data(), nj1 * sizeof(ExpmJob), hipMemcpyHostToDevice, stream));
         if (nw0 + nw1) {
             const size_t nw = nw0 + nw1;
             HIP_TRY(d_wg0.reserve(nw * 8));
             HIP_TRY(d_wg1.reserve(nw * 8));
+            HIP_TRY(d_wgo.reserve(nw * 8));
             HIP_TRY(d_wgt.reserve(nw * 4));
-            HIP_TRY(d_lnz.reserve(n_sites_total * 8));
-            HIP_TRY(d_anc.reserve(n_sites_total * 8));
+            HIP_TRY(d_wgp.reserve(nw * 4));
+            HIP_TRY(d_lnz.reserve(out_used * 8));
+            HIP_TRY(d_anc.reserve(out_used * 8));
             for (int set = 0; set < 2; ++set) {
                 const size_t at = set ? nw0 : 0, cnt = wg0[set].size();
                 if (!cnt) continue;
                 HIP_TRY(hipMemcpyAsync(d_wg0.as<uint64_t>() + at, wg0[set].data(), cnt * 8, hipMemcpyHostToDevice, stream));
                 HIP_TRY(hipMemcpyAsync(d_wg1.as<uint64_t>() + at, wg1[set].data(), cnt * 8, hipMemcpyHostToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(d_wgo.as<uint64_t>() + at, wgo[set].data(), cnt * 8, hipMemcpyHostToDevice, stream));
                 HIP_TRY(hipMemcpyAsync(d_wgt.as<uint32_t>() + at, wgt[set].data(), cnt * 4, hipMemcpyHostToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(d_wgp.as<uint32_t>() + at, wgp[set].data(), cnt * 4, hipMemcpyHostToDevice, stream));
             }
         }
         const bool use_side = !eig_jobs.empty() || nj1 || nw1;
@@ -242,7 +245,7 @@ struct BlockEngine {
             if (nw) {
                 PruneParams p = base_prune_params(c);
                 p.codons = d_codons.as<uint8_t>();
-                p.n_sites = n_sites_total;
+                p.n_sites = out_used;  // rows of the output arrays (one pass)
                 p.leaf_stride = n_sites_total;
                 p.n_passes = 1;
                 p.frag = d_frag.as<double>();
@@ -252,6 +255,8 @@ struct BlockEngine {
                 p.wg_site0 = d_wg0.as<uint64_t>() + w_at;
                 p.wg_site_end = d_wg1.as<uint64_t>() + w_at;
                 p.wg_table = d_wgt.as<uint32_t>() + w_at;
+                p.wg_prior = d_wgp.as<uint32_t>() + w_at;
+                p.wg_out = d_wgo.as<uint64_t>() + w_at;
                 p.n_wgs = nw;
                 p.out_lnz = d_lnz.as<double>();
                 p.out_anc = want_anc ? d_anc.as<double>() : nullptr;
@@ -276,32 +281,71 @@ struct BlockEngine {
         }
         expm_and_prune(0, stream);
         if (use_side) HIP_TRY(hipStreamWaitEvent(stream, ev_side, 0));
-        if (nw0 + nw1) {
-            lnz.resize(n_sites_total);
-            HIP_TRY(hipMemcpyAsync(lnz.data(), d_lnz.ptr, n_sites_total * 8, hipMemcpyDeviceToHost, stream));
+        if (out_used) {
+            lnz.resize(out_used);
+            HIP_TRY(hipMemcpyAsync(lnz.data(), d_lnz.ptr, out_used * 8, hipMemcpyDeviceToHost, stream));
             if (want_anc) {
-                anc.resize(n_sites_total);
-                HIP_TRY(hipMemcpyAsync(anc.data(), d_anc.ptr, n_sites_total * 8, hipMemcpyDeviceToHost, stream));
+                anc.resize(out_used);
+                HIP_TRY(hipMemcpyAsync(anc.data(), d_anc.ptr, out_used * 8, hipMemcpyDeviceToHost, stream));
             }
         }
         fail.resize(tables);
         HIP_TRY(hipMemcpyAsync(fail.data(), d_fail.ptr, tables * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        done_evals.swap(evals);
+        evals.clear();
         for (int set = 0; set < 2; ++set) {
             jobs[set].clear();
             wg0[set].clear();
             wg1[set].clear();
+            wgo[set].clear();
             wgt[set].clear();
+            wgp[set].clear();
         }
-        for (const EigenJob& j : eig_jobs) table_set[j.table] = 0;
         eig_jobs.clear();
+        out_used = 0;
     }
+    std::vector<Eval> done_evals;  // the evaluations of the last run()
 
-    double block_sum(const std::vector<double>& v, size_t blk) const
+    bool failed(size_t k) const { return fail[done_evals[k].table] != 0; }
+    // sum over the block's sites in site order, like lpr += log_z (src/fixed_lik.hpp:431-432)
+    double value(size_t k, const std::vector<double>& v) const
     {
-        double s = 0.0;  // in site order, like lpr += log_z (src/fixed_lik.hpp:431-432)
-        for (uint64_t i = off[blk]; i < off[blk + 1]; ++i) s += v[i];
+        const Eval& e = done_evals[k];
+        double s = 0.0;
+        for (uint64_t i = 0, cnt = off[e.block + 1] - off[e.block]; i < cnt; ++i) s += v[e.out0 + i];
         return s;
+    }
+};
+
+// values an optimiser stage has seen: the objective is a pure function of the point, so a point asked for
+// again (the reference re-evaluates lo, hi and the chosen start when it sets up Brent) is served from here
+struct EvalStore {
+    struct Entry {
+        double x, lpr, anc;
+        bool failed;
+    };
+    std::vector<Entry> entries;
+    const Entry* find(double x) const
+    {
+        for (const Entry& e : entries)
+            if (e.x == x) return &e;
+        return nullptr;
+    }
+    void clear() { entries.clear(); }
+};
+
+constexpr int MAX_POINTS_PER_ROUND = 12;   // per block: certain points first, then speculative restarts
+constexpr int MAX_SPECULATIVE_RESTARTS = 8;
+
+struct Lookahead {  // MaxLik1D::upcoming() of one block for the current round
+    int n = 0;
+    double x[MAX_POINTS_PER_ROUND];
+    bool seen_before(int rank) const  // the same point earlier in the list (lo, hi, chosen recur when Brent is set up)
+    {
+        for (int i = 0; i < rank; ++i)
+            if (x[i] == x[rank]) return true;
+        return false;
     }
 };
 
@@ -344,41 +388,66 @@ int run_mle(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_bl
             uint32_t seed, float* out_phylo, float* out_anc)
 {
     BlockEngine eng(c, codons, off, n_blocks, leaf_stride);
-    eng.reserve_tables(n_blocks);
+    eng.reserve_tables(std::max<size_t>(64, 2 * n_blocks));
     eng.reserve_eig(2);
     eng.upload_eig(0, c->eig[0]);
     eng.upload_eig(1, c->eig[1]);
     std::vector<std::mt19937> gen(n_blocks);
     std::vector<MaxLik1D> opt(n_blocks);
+    std::vector<EvalStore> store(n_blocks);
     std::vector<double> res_lpr(2 * n_blocks, 0.0), res_anc(2 * n_blocks, 0.0);
     std::vector<char> failed(n_blocks, 0);
     for (size_t b = 0; b < n_blocks; ++b) gen[b].seed(seed);
+    struct Pending {
+        size_t block, eval;
+        double x;
+    };
 
     for (int model = 0; model < 2; ++model) {  // coding first, then non-coding (src/run.hpp:193-194)
-        for (size_t b = 0; b < n_blocks; ++b) eng.set_prior(b, c->eig[model].prior);
-        for (size_t b = 0; b < n_blocks; ++b)
+        for (size_t b = 0; b < n_blocks; ++b) {
+            store[b].clear();
             if (!failed[b]) opt[b].start(1.0, 1e-2, 10.0, &gen[b]);
+        }
         for (;;) {
+            // feed every optimiser from its store; blocks without a codon have lpr = 0 at every scale
             size_t active = 0;
             for (size_t b = 0; b < n_blocks; ++b) {
-                if (failed[b] || opt[b].done()) continue;
-                ++active;
-                if (off[b + 1] > off[b]) {  // blocks without a codon have lpr = 0 at every scale
-                    eng.add_expm_jobs(static_cast<uint32_t>(b), static_cast<uint32_t>(model), opt[b].request());
-                    eng.add_prune(b, static_cast<uint32_t>(b));
+                if (failed[b]) continue;
+                while (!opt[b].done()) {
+                    if (off[b + 1] == off[b]) {
+                        opt[b].supply(0.0, 0.0);
+                        continue;
+                    }
+                    const EvalStore::Entry* e = store[b].find(opt[b].request());
+                    if (!e) break;
+                    if (e->failed) {  // std::runtime_error in PhyloModel_make -> NaN row
+                        failed[b] = 1;
+                        break;
+                    }
+                    opt[b].supply(e->lpr, e->anc);
                 }
+                if (!failed[b] && !opt[b].done()) ++active;
             }
             if (!active) break;
-            eng.run(n_blocks, compute_anc != 0);
-            for (size_t b = 0; b < n_blocks; ++b) {
-                if (failed[b] || opt[b].done()) continue;
-                if (off[b + 1] > off[b] && eng.fail[b]) {
-                    failed[b] = 1;  // std::runtime_error in PhyloModel_make -> NaN row
-                    continue;
+            // queue the points the active optimisers will or may need: rank 0 (certain) for everybody first
+            std::vector<Pending> pending;
+            std::vector<Lookahead> ahead(n_blocks);
+            for (size_t b = 0; b < n_blocks; ++b)
+                if (!failed[b] && !opt[b].done()) ahead[b].n = opt[b].upcoming(ahead[b].x, MAX_POINTS_PER_ROUND, MAX_SPECULATIVE_RESTARTS);
+            for (int rank = 0; rank < MAX_POINTS_PER_ROUND && eng.free_evaluations() > 0; ++rank) {
+                bool any = false;
+                for (size_t b = 0; b < n_blocks && eng.free_evaluations() > 0; ++b) {
+                    if (rank >= ahead[b].n) continue;
+                    any = true;
+                    const double x = ahead[b].x[rank];
+                    if (store[b].find(x) || ahead[b].seen_before(rank)) continue;
+                    pending.push_back({b, eng.queue(b, static_cast<uint32_t>(model), x, nullptr), x});
                 }
-                const bool has = off[b + 1] > off[b];
-                opt[b].supply(has ? eng.block_sum(eng.lnz, b) : 0.0, (has && compute_anc) ? eng.block_sum(eng.anc, b) : 0.0);
+                if (!any) break;
             }
+            eng.run(compute_anc != 0);
+            for (const Pending& q : pending)
+                store[q.block].entries.push_back({q.x, eng.value(q.eval, eng.lnz), compute_anc ? eng.value(q.eval, eng.anc) : 0.0, eng.failed(q.eval)});
         }
         for (size_t b = 0; b < n_blocks; ++b) {
             res_lpr[model * n_blocks + b] = opt[b].last_lpr();
@@ -399,37 +468,45 @@ int run_mle(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_bl
 
 // ---- OMEGA -------------------------------------------------------------------------------------
 struct OmegaBlock {
-    double q_settings[12];
+    double q_settings[12];      // kappa, omega, sigma, nine ratios: the model the block is AT (src/run.hpp:75-79)
+    double eig_settings[12];    // settings the block's own eigen-system slot currently holds
+    bool eig_valid = false;
     double tree_scale = 1.0;
     std::mt19937 gen;
     MaxLik1D opt;
+    EvalStore store;
     int stage = 0;  // 0..5: H0 (rho,kappa)x3 ; 6..11: H1 (rho,kappa)x3 ; 12 = finished
     double lpr_h0 = 0.0, lpr_h1 = 0.0;
     bool failed = false, done = false;
+    bool needs_validation = false;  // the model was re-instantiated (PhyloModel_make can throw) and must be checked
 };
 
 int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_blocks, size_t leaf_stride, uint32_t seed,
               float* out_phylo, float* out_anc)
 {
     BlockEngine eng(c, codons, off, n_blocks, leaf_stride);
-    eng.reserve_tables(n_blocks);
-    eng.reserve_eig(n_blocks);
+    const size_t cap = std::max<size_t>(64, 2 * n_blocks);
+    eng.reserve_tables(cap);
+    eng.reserve_eig(n_blocks + cap);  // slot b: block b's current model; slots n_blocks + k: kappa probes of a round
     std::vector<std::unique_ptr<OmegaBlock>> blk(n_blocks);
     const long trace_block = std::getenv("PCSF_TRACE_BLOCK") ? std::atol(std::getenv("PCSF_TRACE_BLOCK")) : -1;  // diagnostics
     const size_t nl = static_cast<size_t>(c->n_leaves);
 
-    // Rate matrix -> eigen-system -> root prior are (re)built on the device (eigen.hip) whenever a block's
-    // q_settings change; block b owns eigen-system b and table set b.
-    // validation-only pass (PhyloModel_make can throw): build every listed block's eigen-system and matrices
-    // and read the flags
+    // Validation-only pass (PhyloModel_make can throw): rebuild the listed blocks' eigen-systems from their
+    // q_settings, build their matrices at their tree scale and read the flags.
     auto validate_all = [&](const std::vector<size_t>& which) {
-        for (size_t b : which) {
-            eng.add_eigen_job(static_cast<uint32_t>(b), static_cast<uint32_t>(b), blk[b]->q_settings);
-            eng.add_expm_jobs(static_cast<uint32_t>(b), static_cast<uint32_t>(b), blk[b]->tree_scale);
+        for (size_t at = 0; at < which.size();) {
+            std::vector<std::pair<size_t, size_t>> queued;
+            for (; at < which.size() && eng.free_evaluations() > 0; ++at) {
+                OmegaBlock& ob = *blk[which[at]];
+                queued.push_back({which[at], eng.queue(which[at], static_cast<uint32_t>(which[at]), ob.tree_scale, ob.q_settings)});
+                std::memcpy(ob.eig_settings, ob.q_settings, sizeof ob.q_settings);
+                ob.eig_valid = true;
+            }
+            eng.run(false);
+            for (const auto& q : queued)
+                if (eng.failed(q.second)) blk[q.first]->failed = true;
         }
-        eng.run(n_blocks, false);
-        for (size_t b : which)
-            if (eng.fail[b]) blk[b]->failed = true;
     };
 
     std::vector<size_t> live;
@@ -478,87 +555,126 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
     }
 
     auto start_stage = [&](OmegaBlock& ob) {
-        const bool rho = (ob.stage % 2) == 0;
-        if (rho) ob.opt.start(ob.tree_scale, 0.001, 10.0, &ob.gen);
+        ob.store.clear();
+        if ((ob.stage % 2) == 0) ob.opt.start(ob.tree_scale, 0.001, 10.0, &ob.gen);
         else ob.opt.start(ob.q_settings[0], 1.0, 10.0, &ob.gen);
     };
     for (size_t b : live)
         if (!blk[b]->failed) start_stage(*blk[b]);
 
     const bool timing = std::getenv("PCSF_TIME_BLOCKS") != nullptr;  // diagnostics: where the rounds spend their time
-    double t_eig = 0.0, t_queue = 0.0, t_run = 0.0, t_opt = 0.0;
+    double t_host = 0.0, t_run = 0.0;
     size_t rounds = 0, evals = 0, eig_evals = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    struct Pending {
+        size_t block, eval;
+        double x;
+    };
     for (;;) {
-        std::vector<size_t> act;
-        for (size_t b : live)
-            if (!blk[b]->failed && !blk[b]->done) act.push_back(b);
-        if (act.empty()) break;
         const auto t0 = now();
-        ++rounds;
-        evals += act.size();
-        for (size_t b : act) eig_evals += (blk[b]->stage % 2) == 1;
-        // apply each block's request: rho -> tree scale; kappa -> new rate matrix + eigen-system (device)
-        const auto t1 = now();
-        for (size_t b : act) {
-            OmegaBlock& ob = *blk[b];
-            if (ob.failed) continue;
-            const double x = ob.opt.request();
-            if ((ob.stage % 2) == 0) ob.tree_scale = x;
-            else {
-                ob.q_settings[0] = x;
-                eng.add_eigen_job(static_cast<uint32_t>(b), static_cast<uint32_t>(b), ob.q_settings);
-            }
-            eng.add_expm_jobs(static_cast<uint32_t>(b), static_cast<uint32_t>(b), ob.tree_scale);
-            eng.add_prune(b, static_cast<uint32_t>(b));
-        }
-        const auto t2 = now();
-        eng.run(n_blocks, false);
-        const auto t3 = now();
+        // (1) feed every optimiser from its store; finished stages move the block on
         std::vector<size_t> entering_h1;
-        for (size_t b : act) {
+        size_t active = 0;
+        for (size_t b : live) {
             OmegaBlock& ob = *blk[b];
-            if (ob.failed) continue;
-            if (eng.fail[b]) {
-                ob.failed = true;
-                continue;
+            while (!ob.failed && !ob.done && !ob.needs_validation) {
+                if (ob.opt.done()) {
+                    // max_lik_lpr_leaves returned: the model stays at the LAST evaluated point
+                    if ((ob.stage % 2) == 0) ob.tree_scale = ob.opt.last_x();
+                    else ob.q_settings[0] = ob.opt.last_x();
+                    (ob.stage < 6 ? ob.lpr_h0 : ob.lpr_h1) = ob.opt.last_lpr();
+                    ++ob.stage;
+                    if (ob.stage == 12) {
+                        ob.done = true;
+                    } else if (ob.stage == 6) {  // omega_H1 = 0.2, sigma_H1 = 0.01, keep rho and kappa (src/run.hpp:161-166)
+                        ob.q_settings[1] = 0.2;
+                        ob.q_settings[2] = 0.01;
+                        ob.needs_validation = true;
+                        entering_h1.push_back(b);
+                    } else {
+                        start_stage(ob);
+                    }
+                    continue;
+                }
+                const EvalStore::Entry* e = ob.store.find(ob.opt.request());
+                if (!e) break;
+                if (e->failed) {
+                    ob.failed = true;
+                    break;
+                }
+                if (trace_block >= 0 && static_cast<size_t>(trace_block) == b)
+                    fprintf(stderr, "TRACE omega stage %d x %.17g lpr %.17g\n", ob.stage, e->x, e->lpr);
+                ob.opt.supply(e->lpr, 0.0);
             }
-            const double x = ob.opt.request();
-            double lpr = eng.block_sum(eng.lnz, b);
-            lpr += ((ob.stage % 2) == 0) ? log_prior_rho(x) : log_prior_kappa(x);
-            if (trace_block >= 0 && static_cast<size_t>(trace_block) == b)
-                fprintf(stderr, "TRACE omega stage %d x %.17g lpr %.17g\n", ob.stage, x, lpr);
-            ob.opt.supply(lpr, 0.0);
-            if (!ob.opt.done()) continue;
-            // max_lik_lpr_leaves returned: the instance stays at the last evaluated point
-            (ob.stage < 6 ? ob.lpr_h0 : ob.lpr_h1) = ob.opt.last_lpr();
-            ++ob.stage;
-            if (ob.stage == 6) entering_h1.push_back(b);
-            else if (ob.stage == 12) ob.done = true;
-            else start_stage(ob);
+            if (!ob.failed && !ob.done) ++active;
         }
-        if (!entering_h1.empty()) {  // omega_H1 = 0.2, sigma_H1 = 0.01, keep rho and kappa (src/run.hpp:161-166)
+        if (!entering_h1.empty()) {
+            validate_all(entering_h1);
             for (size_t b : entering_h1) {
-                blk[b]->q_settings[1] = 0.2;
-                blk[b]->q_settings[2] = 0.01;
-            }
-            std::vector<size_t> ok;
-            for (size_t b : entering_h1)
-                if (!blk[b]->failed) ok.push_back(b);
-            validate_all(ok);
-            for (size_t b : ok)
+                blk[b]->needs_validation = false;
                 if (!blk[b]->failed) start_stage(*blk[b]);
+            }
+            continue;  // their first points join the next round
         }
-        const auto t4 = now();
-        t_eig += secs(t0, t1);
-        t_queue += secs(t1, t2);
-        t_run += secs(t2, t3);
-        t_opt += secs(t3, t4);
+        if (!active) break;
+        // (2) queue the points the optimisers will or may need next: rank 0 (certain) for every block first
+        std::vector<Pending> pending;
+        std::vector<Lookahead> ahead(n_blocks);
+        std::vector<char> rebuilt(n_blocks, 0);  // block's own eigen-system slot is rebuilt in this run
+        for (size_t b : live) {
+            OmegaBlock& ob = *blk[b];
+            if (!ob.failed && !ob.done) ahead[b].n = ob.opt.upcoming(ahead[b].x, MAX_POINTS_PER_ROUND, MAX_SPECULATIVE_RESTARTS);
+        }
+        for (int rank = 0; rank < MAX_POINTS_PER_ROUND && eng.free_evaluations() > 0; ++rank) {
+            bool any = false;
+            for (size_t b : live) {
+                if (eng.free_evaluations() == 0) break;
+                if (rank >= ahead[b].n) continue;
+                any = true;
+                OmegaBlock& ob = *blk[b];
+                const double x = ahead[b].x[rank];
+                if (ob.store.find(x) || ahead[b].seen_before(rank)) continue;
+                size_t k;
+                if ((ob.stage % 2) == 0) {  // rho: the block's own eigen-system, brought up to date if need be
+                    const bool stale = !ob.eig_valid || std::memcmp(ob.eig_settings, ob.q_settings, sizeof ob.q_settings) != 0;
+                    if (stale && !rebuilt[b]) {
+                        k = eng.queue(b, static_cast<uint32_t>(b), x, ob.q_settings);
+                        std::memcpy(ob.eig_settings, ob.q_settings, sizeof ob.q_settings);
+                        ob.eig_valid = true;
+                        rebuilt[b] = 1;
+                        ++eig_evals;
+                    } else {
+                        k = eng.queue(b, static_cast<uint32_t>(b), x, nullptr, rebuilt[b] != 0);
+                    }
+                } else {  // kappa: a probe model in a slot of its own
+                    double qs[12];
+                    std::memcpy(qs, ob.q_settings, sizeof qs);
+                    qs[0] = x;
+                    k = eng.queue(b, static_cast<uint32_t>(n_blocks + eng.evals.size()), ob.tree_scale, qs);
+                    ++eig_evals;
+                }
+                pending.push_back({b, k, x});
+            }
+            if (!any) break;
+        }
+        ++rounds;
+        evals += pending.size();
+        const auto t1 = now();
+        eng.run(false);
+        const auto t2 = now();
+        for (const Pending& q : pending) {
+            const OmegaBlock& ob = *blk[q.block];
+            double lpr = eng.value(q.eval, eng.lnz);
+            lpr += ((ob.stage % 2) == 0) ? log_prior_rho(q.x) : log_prior_kappa(q.x);
+            blk[q.block]->store.entries.push_back({q.x, lpr, 0.0, eng.failed(q.eval)});
+        }
+        t_host += secs(t0, t1) + secs(t2, now());
+        t_run += secs(t1, t2);
     }
     if (timing)
-        fprintf(stderr, "run_omega: %zu blocks, %zu rounds, %zu evaluations (%zu with a new eigen-system): bookkeeping %.3f s, queue %.3f s, device rounds %.3f s, optimiser %.3f s\n",
-                n_blocks, rounds, evals, eig_evals, t_eig, t_queue, t_run, t_opt);
+        fprintf(stderr, "run_omega: %zu blocks, %zu rounds, %zu evaluations (%zu with a new eigen-system): host %.3f s, device rounds %.3f s\n",
+                n_blocks, rounds, evals, eig_evals, t_host, t_run);
     for (size_t b = 0; b < n_blocks; ++b) {
         const OmegaBlock& ob = *blk[b];
         out_phylo[b] = ob.failed ? NAN : decibans(ob.lpr_h1, ob.lpr_h0);
@@ -569,6 +685,7 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
 
 }  // namespace
 
+
 // one objective evaluation per block at caller-chosen parameters (no prior term)
 int block_loglik_impl(pcsf_ctx* c, int model, const double* q_settings, const double* tree_scale, const uint8_t* codons,
                       const uint64_t* site_offsets, size_t n_blocks, size_t leaf_stride, double* out_lpr, int32_t* out_failed)
@@ -577,24 +694,19 @@ int block_loglik_impl(pcsf_ctx* c, int model, const double* q_settings, const do
     for (size_t b = 0; b <= n_blocks; ++b) off[b] = site_offsets[b] - site_offsets[0];
     BlockEngine eng(c, codons ? codons + site_offsets[0] : nullptr, off.data(), n_blocks, leaf_stride);
     eng.reserve_tables(n_blocks);
-    std::vector<char> bad(n_blocks, 0);
     if (model == 2) {
         eng.reserve_eig(n_blocks);  // eigen-systems and root priors come from the device solver (eigen.hip)
     } else {
         eng.reserve_eig(1);
         eng.upload_eig(0, c->eig[model]);
     }
+    for (size_t b = 0; b < n_blocks; ++b)
+        eng.queue(b, model == 2 ? static_cast<uint32_t>(b) : 0u, tree_scale[b], model == 2 ? q_settings + 12 * b : nullptr);
+    eng.run(false);
     for (size_t b = 0; b < n_blocks; ++b) {
-        if (model == 2) eng.add_eigen_job(static_cast<uint32_t>(b), static_cast<uint32_t>(b), q_settings + 12 * b);
-        else eng.set_prior(b, c->eig[model].prior);
-        eng.add_expm_jobs(static_cast<uint32_t>(b), model == 2 ? static_cast<uint32_t>(b) : 0u, tree_scale[b]);
-        eng.add_prune(b, static_cast<uint32_t>(b));
-    }
-    eng.run(n_blocks, false);
-    for (size_t b = 0; b < n_blocks; ++b) {
-        const bool f = bad[b] || eng.fail[b];
+        const bool f = eng.failed(b);
         if (out_failed) out_failed[b] = f;
-        out_lpr[b] = f ? NAN : (off[b + 1] > off[b] ? eng.block_sum(eng.lnz, b) : 0.0);
+        out_lpr[b] = f ? NAN : (off[b + 1] > off[b] ? eng.value(b, eng.lnz) : 0.0);
     }
     return PCSF_OK;
 }

@@ -10,8 +10,8 @@
 //      applying 32 disjoint plane rotations (round-robin tournament pairing) as B <- J^T B J, V <- V J.
 //      Only rotations, so the near-zero eigenvalue keeps its relative accuracy (the equilibrium prior is read
 //      off its eigenvector), same stopping rule as the host solver (off^2 <= 1e-58 * diag^2),
-//   4. writes right = D^-1/2 V, left = V^T D^1/2, lambda, and the root prior (+ ln(prior)*prior) of the job's
-//      table set in the lane order the pruning kernel reads.
+//   4. writes right = D^-1/2 V, left = V^T D^1/2, lambda, and the root prior (+ ln(prior)*prior) of the
+//      eigen-system in the lane order the pruning kernel reads.
 // The host solver (hostmath.hpp::eigen_reversible, sequential row-cyclic order) stays the reference for tests:
 // the two agree to rounding (tests/test_gpu_blocks.py), not bit for bit -- rotation order differs.
 #include <hip/hip_runtime.h>
@@ -220,8 +220,9 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
         const int z = pp[0];
         const double pr = (V[tid * LD + z] * root[tid]) / norm_s;
         const int lane_pos = (tid & 3) * 16 + (tid >> 2);  // lane order: [g][q] = state 4q+g
-        if (p.prior) p.prior[static_cast<size_t>(job.table) * 64 + lane_pos] = pr;
-        if (p.anc_weight) p.anc_weight[static_cast<size_t>(job.table) * 64 + lane_pos] = log(pr) * pr;
+        // the root prior belongs to the eigen-system: row job.eig (the pruning kernel finds it through wg_prior)
+        if (p.prior) p.prior[static_cast<size_t>(job.eig) * 64 + lane_pos] = pr;
+        if (p.anc_weight) p.anc_weight[static_cast<size_t>(job.eig) * 64 + lane_pos] = log(pr) * pr;
         if (p.prior_plain) p.prior_plain[static_cast<size_t>(job.eig) * 64 + tid] = pr;
     }
 }

@@ -32,6 +32,9 @@ struct PruneParams {
     const uint64_t* wg_site0;
     const uint64_t* wg_site_end;
     const uint32_t* wg_table;
+    const uint32_t* wg_prior;    // optional: row of prior / anc_weight per work-group (else the table index)
+    const uint64_t* wg_out;      // optional: output index of the work-group's first site (else the site index), so
+                                 // that several evaluations of the same block can run in one launch
     size_t n_wgs;
     int stagger_sleep;           // first-generation stagger of co-resident work-groups, x 1024 cycles (0 = off)
     uint32_t stagger_first_blocks;
@@ -79,7 +82,7 @@ hipError_t launch_expm(const ExpmParams& p, hipStream_t stream);
 // Batched eigen-systems of the kappa/omega F3x4 rate matrix (eigen.hip): one job = one rate matrix.
 struct EigenJob {
     uint32_t eig;      // destination eigen-system index
-    uint32_t table;    // table set whose root prior this eigen-system defines
+    uint32_t table;    // table set whose validation flag reports an invalid model (fail[table])
     double qs[12];     // kappa, omega, sigma, nine nucleotide-frequency ratios (src/run.hpp:75-79)
 };
 
@@ -89,8 +92,8 @@ struct EigenParams {
     double* eig_right;    // [n_eig][64*64]
     double* eig_left;     // [n_eig][64*64]
     double* eig_lambda;   // [n_eig][64]
-    double* prior;        // [table][64] equilibrium prior in lane order (may be null)
-    double* anc_weight;   // [table][64] ln(prior)*prior in lane order (may be null)
+    double* prior;        // [n_eig][64] equilibrium prior in lane order (may be null)
+    double* anc_weight;   // [n_eig][64] ln(prior)*prior in lane order (may be null)
     double* prior_plain;  // optional [n_eig][64] prior in state order (diagnostics/tests)
     uint32_t* fail;       // [table]: set to 1 when pi has a non-positive entry
 };

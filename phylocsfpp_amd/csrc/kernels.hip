@@ -131,6 +131,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     const size_t block_site0 = BLOCKS ? p.wg_site0[blockIdx.x] : static_cast<size_t>(blockIdx.x) * SITES;
     const size_t site_end = BLOCKS ? p.wg_site_end[blockIdx.x] : p.n_sites;
     const int table0 = BLOCKS ? static_cast<int>(p.wg_table[blockIdx.x]) : 0;
+    const int prior0 = (BLOCKS && p.wg_prior) ? static_cast<int>(p.wg_prior[blockIdx.x]) : table0;
     const size_t my_site = block_site0 + wave * 16 + sl;
     const bool valid = my_site < site_end;
     const unsigned long long stamp_t0 = STAMP ? stamp_now() : 0ull;
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     }
     for (int model = 0; model < p.n_passes; ++model) {
         const double* __restrict__ leaf_tab = p.leaf_tab + static_cast<size_t>(table0 + model) * p.n_leaves * LEAF_TABLE_DOUBLES_DEV;
-        const double* __restrict__ prior = p.prior + static_cast<size_t>(table0 + model) * 64 + g4 * 16;
+        const double* __restrict__ prior = p.prior + static_cast<size_t>(prior0 + model) * 64 + g4 * 16;
 
         double cur[16];
         double4_t acc[4];
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
                     if (model == 0) lnz0 = lz;
                     else lnz1 = lz;
                     if (p.out_anc) {  // sum_x ln(prior_x) * prior_x * alpha_root[x] / z  (root posterior term)
-                        const double* __restrict__ w = p.anc_weight + static_cast<size_t>(table0 + model) * 64 + g4 * 16;
+                        const double* __restrict__ w = p.anc_weight + static_cast<size_t>(prior0 + model) * 64 + g4 * 16;
                         double t = 0.0;
 #pragma unroll
                         for (int q = 0; q < 16; ++q) t += w[q] * cur[q];
@@ -397,14 +398,15 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
             }
     }
     if (g4 == 0 && valid) {
-        if (p.out_score) p.out_score[my_site] = 10.0 * (lnz0 - lnz1) / log(10.0);
+        const size_t out_at = (BLOCKS && p.wg_out) ? p.wg_out[blockIdx.x] + (my_site - block_site0) : my_site;
+        if (p.out_score) p.out_score[out_at] = 10.0 * (lnz0 - lnz1) / log(10.0);
         if (p.out_lnz) {
-            p.out_lnz[my_site] = lnz0;
-            if (p.n_passes > 1) p.out_lnz[p.n_sites + my_site] = lnz1;
+            p.out_lnz[out_at] = lnz0;
+            if (p.n_passes > 1) p.out_lnz[p.n_sites + out_at] = lnz1;
         }
         if (p.out_anc) {
-            p.out_anc[my_site] = anc0;
-            if (p.n_passes > 1) p.out_anc[p.n_sites + my_site] = anc1;
+            p.out_anc[out_at] = anc0;
+            if (p.n_passes > 1) p.out_anc[p.n_sites + out_at] = anc1;
         }
     }
 }

@@ -39,6 +39,79 @@ public:
     double last_anc() const { return last_anc_; }
     int evaluations() const { return evals_; }
 
+    // Points whose objective value the search will or may ask for next, in the order it would ask, WITHOUT
+    // depending on values not yet supplied: xs[0] == request() (certain); the rest is certain up to the next
+    // data-dependent decision (lo, hi, init at the start; chosen, lo, hi, chosen, v when Brent is set up) or
+    // speculative (the next random restarts, drawn from a COPY of the generator: the restart sequence does not
+    // depend on the values, only its length does).  A driver may evaluate all of them in one batch, keep the
+    // results and feed supply() from that store: the sequence of supply() calls -- hence every decision and the
+    // result -- is the same as when evaluating one point at a time.  Returns the number of points written.
+    int upcoming(double* xs, int max_points, int max_restarts) const
+    {
+        int n = 0;
+        auto push = [&](double x) {
+            if (n < max_points) xs[n++] = x;
+        };
+        if (done_ || max_points <= 0) return 0;
+        auto restarts = [&](int already) {  // the next random starting points
+            if (!gen_ || max_restarts <= 0) return;
+            std::mt19937 g = *gen_;
+            for (int t = already, k = 0; t < 250 && k < max_restarts && n < max_points; ++t, ++k) {
+                std::uniform_real_distribution<> dis(0.0, width_);
+                push(std::exp(std::log(lo_) + dis(g)));
+            }
+        };
+        switch (state_) {
+            case S_LO:
+                push(lo_);
+                push(hi_);
+                push(init_);
+                restarts(0);
+                break;
+            case S_HI:
+                push(hi_);
+                push(init_);
+                restarts(0);
+                break;
+            case S_INIT:
+                push(init_);
+                restarts(0);
+                break;
+            case S_RESTART:
+                push(request_);
+                restarts(tries_ + 1);
+                break;
+            case S_FINAL:
+                push(chosen_);
+                if (lo_ < chosen_ && chosen_ < hi_) {
+                    push(lo_);
+                    push(hi_);
+                    push(chosen_);
+                    push(lo_ + GOLDEN * (hi_ - lo_));
+                }
+                break;
+            case B_LO:
+                push(lo_);
+                push(hi_);
+                push(b_min_);
+                push(b_lo_ + GOLDEN * (b_up_ - b_lo_));
+                break;
+            case B_HI:
+                push(hi_);
+                push(b_min_);
+                push(b_lo_ + GOLDEN * (b_up_ - b_lo_));
+                break;
+            case B_MIN:
+                push(b_min_);
+                push(b_lo_ + GOLDEN * (b_up_ - b_lo_));
+                break;
+            default:
+                push(request_);
+                break;
+        }
+        return n;
+    }
+
     void supply(double lpr, double anc)
     {
         last_x_ = request_;
