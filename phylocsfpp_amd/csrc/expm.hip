@@ -35,8 +35,10 @@ __global__ __launch_bounds__(256, 2) void expm_kernel(const ExpmParams p)
     double r_frag[16];
     uint32_t have_eig = 0xffffffffu;
 
+    ExpmJob ahead = p.jobs[job0 < job1 ? job0 : 0];
     for (uint32_t jx = job0; jx < job1; ++jx) {
-        const ExpmJob job = p.jobs[jx];
+        const ExpmJob job = ahead;
+        ahead = p.jobs[jx + 1 < job1 ? jx + 1 : jx];  // the next job's 24 bytes travel while this one computes
         if (job.eig != have_eig) {
             const double* __restrict__ R = p.eig_right + static_cast<size_t>(job.eig) * 4096;
             const double* __restrict__ L = p.eig_left + static_cast<size_t>(job.eig) * 4096;
@@ -70,7 +72,9 @@ __global__ __launch_bounds__(256, 2) void expm_kernel(const ExpmParams p)
             for (int r = 0; r < 4; ++r) P[(16 * wave + (lane >> 4) + 4 * r) * 65 + 16 * c + (lane & 15)] = acc[c][r];
         __syncthreads();
 
-        // row post-processing, one thread per row, in index order like the reference
+        // Row post-processing, one thread per row, in index order like the reference.  Branch-free and with the LDS
+        // reads issued eight at a time: written as one load, test and branch per entry this pass was a chain of 64
+        // LDS round trips and took three quarters of the whole kernel.
         if (tid < 64) {
             double* row = P + tid * 65;
             double total = 0.0, diag = 1.0;
@@ -78,23 +82,34 @@ __global__ __launch_bounds__(256, 2) void expm_kernel(const ExpmParams p)
             // `lead` = the row sum as far as the columns before the diagonal: the gap-leaf message is the sum of the
             // FINAL row in index order (src/fixed_lik.hpp:111-117), whose diagonal is only known after this pass
             double lead = 0.0;
-#pragma unroll 8
-            for (int j = 0; j < 64; ++j) {
-                const double v = row[j];
-                total += v;
-                double vz = v;
-                if (v < 0.0) {
-                    if (fabs(v) > 1e-6) ok = false;
-                    vz = 0.0;
-                    row[j] = 0.0;
+#pragma unroll 1  // (fully unrolled, the 3 x 64 loop-invariant lane masks of `j <> tid` are hoisted and spill)
+            for (int j0 = 0; j0 < 64; j0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = row[j0 + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u;
+                    total += v[u];
+                    const bool neg = v[u] < 0.0;
+                    ok = ok && !(neg && fabs(v[u]) > 1e-6);
+                    const double vz = neg ? 0.0 : v[u];
+                    row[j] = vz;
+                    diag = (j != tid) ? diag - vz : diag;
+                    lead = (j < tid) ? lead + vz : lead;
                 }
-                if (j != tid) diag -= vz;
-                if (j < tid) lead += vz;
             }
             if (!(fabs(total - 1.0) <= 1e-6)) ok = false;
             row[tid] = diag;
             double s = lead + diag;
-            for (int j = tid + 1; j < 64; ++j) s += row[j];
+#pragma unroll 1
+            for (int j0 = 0; j0 < 64; j0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = row[j0 + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s = (j0 + u > tid) ? s + v[u] : s;
+            }
             rowsum[tid] = s;
             if (!ok) bad = 1;
         }
