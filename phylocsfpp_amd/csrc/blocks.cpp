@@ -752,13 +752,14 @@ int debug_eigen_omega_impl(pcsf_ctx* c, const double* q_settings, size_t n, doub
 int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64_t* site_offsets, size_t n_blocks,
                       size_t leaf_stride, int compute_anc, uint32_t seed, float* out_phylo, float* out_anc)
 {
-    // MLE / OMEGA keep one set of branch-matrix tables per block in HBM (9.6 MB for a 100-leaf tree): blocks are
-    // independent, so a long list is processed in chunks that bound that footprint to ~32 GB
+    // MLE / OMEGA keep one set of branch-matrix tables per evaluation in HBM (9.6 MB for a 100-leaf tree), up to two
+    // evaluations per block and round: blocks are independent, so a long list is processed in chunks that bound
+    // that footprint to ~32 GB
     size_t chunk = n_blocks;
     if (algo != PCSF_FIXED) {
         const size_t ne = c->schedule.slot_node.size();
         const size_t per_table = (ne * 4096 + static_cast<size_t>(c->n_leaves) * LEAF_TABLE_DOUBLES_DEV) * sizeof(double);
-        chunk = std::max<size_t>(64, (size_t(32) << 30) / std::max<size_t>(per_table, 1));
+        chunk = std::max<size_t>(64, (size_t(16) << 30) / std::max<size_t>(per_table, 1));
     }
     for (size_t b0 = 0; b0 < n_blocks; b0 += chunk) {
         const size_t nb = std::min(chunk, n_blocks - b0);
