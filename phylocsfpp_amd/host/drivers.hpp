@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -92,7 +93,7 @@ struct BuildTracksParams {
     size_t batch_sites = 4u << 20;   // codon-frames gathered per backend call
     bool verbose = false;
     int threads = 0;                 // host threads for ingest / BLS / text output (0 = all the process may use)
-    size_t window_bytes = size_t(256) << 20;  // MAF bytes parsed (in parallel) before their alignments are scored
+    size_t window_bytes = size_t(32) << 20;   // MAF bytes parsed (in parallel) per pipeline step
 };
 
 // CPUs this process may actually use: hardware threads, capped by the cgroup CPU quota (a container on a
@@ -356,14 +357,18 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
 
     MafFile file(maf_path);
     const size_t window = std::max<size_t>(prm.window_bytes, 1 << 16);
-    for (size_t w0 = 0; w0 < file.size() || (w0 == 0 && file.size() == 0); w0 += window) {
-        if (file.size() == 0) break;
+    struct ParsedWindow {
+        std::vector<std::vector<Item>> jobs;
+        double wall = 0.0, read = 0.0, bls = 0.0;  // stage wall time; thread-seconds inside the reader / the branch-length score
+    };
+    // (1) parse + branch-length scores of one window, one job per byte range; ranges are cut at arbitrary bytes
+    auto parse_window = [&](size_t w0) {
+        ParsedWindow pw;
+        StopWatch wall;
         const size_t w1 = std::min(file.size(), w0 + window);
-        // (1) parse + branch-length scores, one job per byte range; ranges are cut at arbitrary bytes
         const size_t n_jobs = std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(threads) * 4, (w1 - w0 + (1 << 16) - 1) >> 16));
-        std::vector<std::vector<Item>> parsed(n_jobs);
+        pw.jobs.resize(n_jobs);
         std::vector<double> job_read(n_jobs, 0.0), job_bls(n_jobs, 0.0);
-        sw.lap();
         parallel_for(n_jobs, threads, [&](size_t j) {
             const size_t b = w0 + (w1 - w0) * j / n_jobs, e = w0 + (w1 - w0) * (j + 1) / n_jobs;
             MafReader reader(file, b, e, model.name_to_leaf, model.n_leaves, /*concatenate=*/true, prm.verbose && j == 0 && w0 == 0);
@@ -379,25 +384,35 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
                 it.len = static_cast<uint32_t>(aln.length());
                 bls.per_base(aln, &it.bls);  // also validates every character (the reference exits on anything but ACGTNacgtn-.)
                 it.seqs.swap(aln.seqs);
-                parsed[j].push_back(std::move(it));
+                pw.jobs[j].push_back(std::move(it));
                 job_bls[j] += jw.lap();
             }
         });
-        {  // wall time of the stage, split in proportion to the summed thread times
-            const double wall = sw.lap();
-            double r = 0.0, b = 0.0;
-            for (size_t j = 0; j < n_jobs; ++j) {
-                r += job_read[j];
-                b += job_bls[j];
-            }
-            const double tot = r + b > 0 ? r + b : 1.0;
-            st.read_seconds += wall * r / tot;
-            st.bls_seconds += wall * b / tot;
+        for (size_t j = 0; j < n_jobs; ++j) {
+            pw.read += job_read[j];
+            pw.bls += job_bls[j];
+        }
+        pw.wall = wall.lap();
+        return pw;
+    };
+    // Windows are pipelined: while the alignments of window k are packed, scored and written, window k+1 is being
+    // parsed (its own threads; the two stages share the host cores for the short overlap).
+    std::future<ParsedWindow> next;
+    if (file.size() > 0) next = std::async(std::launch::async, parse_window, size_t(0));
+    for (size_t w0 = 0; w0 < file.size(); w0 += window) {
+        sw.lap();
+        ParsedWindow pw = next.get();
+        const double waited = sw.lap();  // only the time the pipeline actually stalled on parsing counts
+        if (w0 + window < file.size()) next = std::async(std::launch::async, parse_window, w0 + window);
+        {
+            const double tot = pw.read + pw.bls > 0 ? pw.read + pw.bls : 1.0;
+            st.read_seconds += waited * pw.read / tot;
+            st.bls_seconds += waited * pw.bls / tot;
         }
         // (2)+(3) batches in file order
         std::vector<Item*> batch;
         size_t used = 0;
-        for (auto& job : parsed)
+        for (auto& job : pw.jobs)
             for (Item& it : job) {
                 ++st.alignments;
                 st.ref_bases += it.len;
