@@ -156,6 +156,12 @@ int pcsf_debug_maxlik(double (*objective)(double x, void *user), void *user, dou
                       uint32_t seed, int skip_draws, double *xs_out, int cap, int *n_evals, double *last_lpr);
 const char *pcsf_version(void);
 
+/* Optional: page-locked host memory for the buffers handed to the scoring calls.  Transfers from/to such buffers
+ * run at DMA speed and do not occupy host threads (a pageable 58 MB nucleotide matrix costs ~6 ms of CPU-driven
+ * staging per call); any other memory works too.  NULL on failure. */
+void *pcsf_host_alloc(size_t bytes);
+void pcsf_host_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

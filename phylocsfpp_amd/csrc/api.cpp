@@ -113,6 +113,18 @@ extern "C" {
 
 const char* pcsf_version(void) { return "phylocsf-amd 0.1.0 (gfx950)"; }
 
+void* pcsf_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void pcsf_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 // host-only helper: drives the lock-step optimiser's state machine (optimizer.hpp) with a caller-supplied
 // objective; records the evaluation points.  Lets the tests check that it takes exactly the decisions
 // of the reference's fit_find_init + GSL Brent without a GPU in the loop.

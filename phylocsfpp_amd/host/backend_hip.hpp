@@ -57,6 +57,14 @@ public:
         out.resize(total);
     }
 
+    char* staging_alloc(size_t bytes) override
+    {
+        char* p = static_cast<char*>(pcsf_host_alloc(bytes));
+        if (!p) throw std::runtime_error("pcsf_host_alloc failed");
+        return p;
+    }
+    void staging_free(char* p) override { pcsf_host_free(p); }
+
 private:
     void check(int rc)
     {

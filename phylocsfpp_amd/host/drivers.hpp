@@ -41,6 +41,9 @@ constexpr int ALGO_FIXED_MEAN = 3;  // score-msa --strategy FIXED_MEAN: mean of 
 // the C-ABI, the test-only OracleBackend (oracle/oracle_cli.cpp) to the CPU oracle.
 struct ScoringBackend {
     virtual ~ScoringBackend() = default;
+    // memory for the batch matrices handed to score_alignments_6frames (the HIP backend returns page-locked memory)
+    virtual char* staging_alloc(size_t bytes) { return new char[bytes]; }
+    virtual void staging_free(char* p) { delete[] p; }
     // run_tracks: leaf-major codons -> per-codon decibans
     virtual void score_sites_fixed(const uint8_t* codons, size_t n_sites, size_t leaf_stride, double* out) = 0;
     // run: CSR batch of blocks -> (phylo, anc) floats, NaN on model failure
@@ -280,7 +283,6 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     const size_t nl = static_cast<size_t>(model.n_leaves);
     const int threads = prm.threads > 0 ? prm.threads : effective_threads();
     size_t cap = std::max<size_t>(prm.batch_sites / 2, 1);  // columns per batch: one column yields two codon-frames
-    std::vector<char> nucl;
     std::vector<double> scores;
     std::vector<uint64_t> offsets;
     std::vector<uint32_t> n_codons;
@@ -319,55 +321,57 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         out.flush();
     };
 
-    // one batch: pack, score, write
-    auto run_batch = [&](const std::vector<Item*>& items, size_t columns) {
-        if (items.empty()) return;
-        StopWatch bw;
-        if (need_raw) {
-            const size_t stride = std::max(columns, size_t(1));
-            if (nucl.size() < nl * stride) nucl.resize(nl * stride);
-            std::vector<uint64_t> col0, start_pos, chrom_len;
-            std::vector<uint32_t> len;
-            for (const Item* p : items) {
-                col0.push_back(p->col0);
-                len.push_back(p->len);
-                start_pos.push_back(p->start_pos);
-                chrom_len.push_back(p->chrom_len);
-            }
-            parallel_for(items.size() * nl, threads, [&](size_t j) {
-                const Item& p = *items[j / nl];
-                const size_t l = j % nl;
-                memcpy(nucl.data() + l * stride + p.col0, p.seqs[l].data(), p.len);
-            });
-            st.extract_seconds += bw.lap();
-            backend.score_alignments_6frames(model.n_leaves, nucl.data(), stride, col0, len, start_pos, chrom_len, scores, offsets, n_codons);
-            st.backend_seconds += bw.lap();
-            ++st.backend_calls;
-            st.codon_frames += scores.size();
-        }
-        parallel_for(7, threads, [&](size_t t) {
-            if (t == 0) {
-                if (f_power) write_power(items);
-            } else if (need_raw) {
-                write_frame(items, static_cast<int>(t) - 1);
-            }
-        });
-        st.write_seconds += bw.lap();
-    };
-
     MafFile file(maf_path);
     const size_t window = std::max<size_t>(prm.window_bytes, 1 << 16);
-    struct ParsedWindow {
-        std::vector<std::vector<Item>> jobs;
-        double wall = 0.0, read = 0.0, bls = 0.0;  // stage wall time; thread-seconds inside the reader / the branch-length score
+    // batch matrices come from the backend (page-locked for the GPU) and are recycled: allocating them is slow
+    struct StagingPool {
+        ScoringBackend& backend;
+        std::mutex lock;
+        std::vector<std::pair<char*, size_t>> free_list;
+        explicit StagingPool(ScoringBackend& b) : backend(b) {}
+        ~StagingPool()
+        {
+            for (auto& f : free_list) backend.staging_free(f.first);
+        }
+        std::pair<char*, size_t> get(size_t bytes)
+        {
+            {
+                std::lock_guard<std::mutex> g(lock);
+                for (size_t i = 0; i < free_list.size(); ++i)
+                    if (free_list[i].second >= bytes) {
+                        auto f = free_list[i];
+                        free_list.erase(free_list.begin() + static_cast<long>(i));
+                        return f;
+                    }
+            }
+            const size_t cap_bytes = bytes + bytes / 4;  // head room so that the next, slightly larger batch fits too
+            return {backend.staging_alloc(cap_bytes), cap_bytes};
+        }
+        void put(std::pair<char*, size_t> f)
+        {
+            std::lock_guard<std::mutex> g(lock);
+            free_list.push_back(f);
+        }
+    } pool(backend);
+    struct Batch {  // alignments scored by one backend call, their nucleotides packed leaf-major
+        std::vector<Item*> items;
+        size_t stride = 0;
+        std::pair<char*, size_t> nucl{nullptr, 0};  // [nl][stride], uninitialised outside the alignments' columns
+        std::vector<uint64_t> col0, start_pos, chrom_len;
+        std::vector<uint32_t> len;
     };
-    // (1) parse + branch-length scores of one window, one job per byte range; ranges are cut at arbitrary bytes
-    auto parse_window = [&](size_t w0) {
-        ParsedWindow pw;
-        StopWatch wall;
+    struct PreparedWindow {
+        std::vector<std::vector<Item>> jobs;
+        std::vector<Batch> batches;
+        double read = 0.0, bls = 0.0, pack = 0.0;  // thread-seconds in the reader / the branch-length score; wall seconds packing
+    };
+    // Stage 1 (runs one window ahead of the scoring): byte-range jobs parse the MAF and compute the branch-length
+    // scores; then the alignments, in file order, are cut into batches and their rows copied into the batch matrix.
+    auto prepare_window = [&](size_t w0) {
+        std::unique_ptr<PreparedWindow> pw(new PreparedWindow);
         const size_t w1 = std::min(file.size(), w0 + window);
         const size_t n_jobs = std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(threads) * 4, (w1 - w0 + (1 << 16) - 1) >> 16));
-        pw.jobs.resize(n_jobs);
+        pw->jobs.resize(n_jobs);
         std::vector<double> job_read(n_jobs, 0.0), job_bls(n_jobs, 0.0);
         parallel_for(n_jobs, threads, [&](size_t j) {
             const size_t b = w0 + (w1 - w0) * j / n_jobs, e = w0 + (w1 - w0) * (j + 1) / n_jobs;
@@ -384,48 +388,85 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
                 it.len = static_cast<uint32_t>(aln.length());
                 bls.per_base(aln, &it.bls);  // also validates every character (the reference exits on anything but ACGTNacgtn-.)
                 it.seqs.swap(aln.seqs);
-                pw.jobs[j].push_back(std::move(it));
+                pw->jobs[j].push_back(std::move(it));
                 job_bls[j] += jw.lap();
             }
         });
         for (size_t j = 0; j < n_jobs; ++j) {
-            pw.read += job_read[j];
-            pw.bls += job_bls[j];
+            pw->read += job_read[j];
+            pw->bls += job_bls[j];
         }
-        pw.wall = wall.lap();
+        StopWatch pack;
+        pw->batches.emplace_back();
+        for (auto& job : pw->jobs)
+            for (Item& it : job) {
+                if (!pw->batches.back().items.empty() && pw->batches.back().stride + it.len > cap) pw->batches.emplace_back();
+                Batch& bt = pw->batches.back();
+                it.col0 = bt.stride;
+                bt.stride += it.len;
+                bt.items.push_back(&it);
+            }
+        if (pw->batches.back().items.empty()) pw->batches.pop_back();
+        for (Batch& bt : pw->batches) {
+            bt.stride = std::max(bt.stride, size_t(1));
+            for (const Item* p : bt.items) {
+                bt.col0.push_back(p->col0);
+                bt.len.push_back(p->len);
+                bt.start_pos.push_back(p->start_pos);
+                bt.chrom_len.push_back(p->chrom_len);
+            }
+            if (!need_raw) continue;
+            bt.nucl = pool.get(nl * bt.stride);
+            parallel_for(bt.items.size() * nl, threads, [&](size_t j) {
+                const Item& p = *bt.items[j / nl];
+                const size_t l = j % nl;
+                memcpy(bt.nucl.first + l * bt.stride + p.col0, p.seqs[l].data(), p.len);
+            });
+            for (Item* p : bt.items) std::vector<std::string>().swap(p->seqs);  // the rows now live in the batch matrix
+        }
+        pw->pack = pack.lap();
         return pw;
     };
-    // Windows are pipelined: while the alignments of window k are packed, scored and written, window k+1 is being
-    // parsed (its own threads; the two stages share the host cores for the short overlap).
-    std::future<ParsedWindow> next;
-    if (file.size() > 0) next = std::async(std::launch::async, parse_window, size_t(0));
+    // Stage 2 (this thread): one backend call per batch, then seven writers -- the power track and the six frames.
+    auto run_batch = [&](Batch& bt) {
+        StopWatch bw;
+        if (need_raw) {
+            backend.score_alignments_6frames(model.n_leaves, bt.nucl.first, bt.stride, bt.col0, bt.len, bt.start_pos, bt.chrom_len, scores, offsets, n_codons);
+            st.backend_seconds += bw.lap();
+            ++st.backend_calls;
+            st.codon_frames += scores.size();
+            pool.put(bt.nucl);
+            bt.nucl = {nullptr, 0};
+        }
+        parallel_for(7, threads, [&](size_t t) {
+            if (t == 0) {
+                if (f_power) write_power(bt.items);
+            } else if (need_raw) {
+                write_frame(bt.items, static_cast<int>(t) - 1);
+            }
+        });
+        st.write_seconds += bw.lap();
+    };
+    std::future<std::unique_ptr<PreparedWindow>> next;
+    if (file.size() > 0) next = std::async(std::launch::async, prepare_window, size_t(0));
     for (size_t w0 = 0; w0 < file.size(); w0 += window) {
         sw.lap();
-        ParsedWindow pw = next.get();
-        const double waited = sw.lap();  // only the time the pipeline actually stalled on parsing counts
-        if (w0 + window < file.size()) next = std::async(std::launch::async, parse_window, w0 + window);
+        std::unique_ptr<PreparedWindow> pw = next.get();
+        const double waited = sw.lap();  // only the time this thread actually stalled on stage 1 counts
+        if (w0 + window < file.size()) next = std::async(std::launch::async, prepare_window, w0 + window);
         {
-            const double tot = pw.read + pw.bls > 0 ? pw.read + pw.bls : 1.0;
-            st.read_seconds += waited * pw.read / tot;
-            st.bls_seconds += waited * pw.bls / tot;
+            const double cpu = pw->read + pw->bls, tot = (cpu > 0 ? cpu : 1.0);
+            const double parse_share = waited > pw->pack ? waited - pw->pack : 0.0;
+            st.read_seconds += parse_share * pw->read / tot;
+            st.bls_seconds += parse_share * pw->bls / tot;
+            st.extract_seconds += std::min(waited, pw->pack);
         }
-        // (2)+(3) batches in file order
-        std::vector<Item*> batch;
-        size_t used = 0;
-        for (auto& job : pw.jobs)
-            for (Item& it : job) {
+        for (auto& job : pw->jobs)
+            for (const Item& it : job) {
                 ++st.alignments;
                 st.ref_bases += it.len;
-                if (!batch.empty() && used + it.len > cap) {
-                    run_batch(batch, used);
-                    batch.clear();
-                    used = 0;
-                }
-                it.col0 = used;
-                used += it.len;
-                batch.push_back(&it);
             }
-        run_batch(batch, used);
+        for (Batch& bt : pw->batches) run_batch(bt);
     }
     if (f_power) fclose(f_power);
     for (FILE* f : f_raw)
