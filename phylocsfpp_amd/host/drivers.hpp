@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <exception>
 #include <future>
 #include <memory>
@@ -283,9 +284,6 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     const size_t nl = static_cast<size_t>(model.n_leaves);
     const int threads = prm.threads > 0 ? prm.threads : effective_threads();
     size_t cap = std::max<size_t>(prm.batch_sites / 2, 1);  // columns per batch: one column yields two codon-frames
-    std::vector<double> scores;
-    std::vector<uint64_t> offsets;
-    std::vector<uint32_t> n_codons;
     BuildTracksStats st;
     const float threshold3 = prm.power_threshold * 3;
     StopWatch total, sw;
@@ -301,7 +299,7 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         }
         out.flush();
     };
-    auto write_frame = [&](const std::vector<Item*>& items, int fi) {
+    auto write_frame = [&](const std::vector<Item*>& items, const std::vector<double>& scores, const std::vector<uint64_t>& offsets, int fi) {
         WigSink out(f_raw[fi]);
         for (size_t k = 0; k < items.size(); ++k) {
             const Item& p = *items[k];
@@ -359,6 +357,9 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         std::pair<char*, size_t> nucl{nullptr, 0};  // [nl][stride], uninitialised outside the alignments' columns
         std::vector<uint64_t> col0, start_pos, chrom_len;
         std::vector<uint32_t> len;
+        std::vector<double> scores;        // filled by the backend
+        std::vector<uint64_t> offsets;
+        std::vector<uint32_t> n_codons;
     };
     struct PreparedWindow {
         std::vector<std::vector<Item>> jobs;
@@ -427,28 +428,41 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         pw->pack = pack.lap();
         return pw;
     };
-    // Stage 2 (this thread): one backend call per batch, then seven writers -- the power track and the six frames.
+    // Stage 2 (this thread): one backend call per batch.  Stage 3 (one batch behind): seven writers -- the power
+    // track and the six frames -- format the batch's text and append it to their files, in batch order.
+    std::future<double> writer;  // seconds the previous batch's writers took
+    auto finish_writer = [&]() {
+        if (writer.valid()) st.write_seconds += writer.get();
+    };
     auto run_batch = [&](Batch& bt) {
         StopWatch bw;
         if (need_raw) {
-            backend.score_alignments_6frames(model.n_leaves, bt.nucl.first, bt.stride, bt.col0, bt.len, bt.start_pos, bt.chrom_len, scores, offsets, n_codons);
+            backend.score_alignments_6frames(model.n_leaves, bt.nucl.first, bt.stride, bt.col0, bt.len, bt.start_pos, bt.chrom_len, bt.scores, bt.offsets,
+                                             bt.n_codons);
             st.backend_seconds += bw.lap();
             ++st.backend_calls;
-            st.codon_frames += scores.size();
+            st.codon_frames += bt.scores.size();
             pool.put(bt.nucl);
             bt.nucl = {nullptr, 0};
         }
-        parallel_for(7, threads, [&](size_t t) {
-            if (t == 0) {
-                if (f_power) write_power(bt.items);
-            } else if (need_raw) {
-                write_frame(bt.items, static_cast<int>(t) - 1);
-            }
+        finish_writer();  // files are appended in batch order
+        writer = std::async(std::launch::async, [&, batch = &bt]() {
+            StopWatch ww;
+            parallel_for(7, threads, [&](size_t t) {
+                if (t == 0) {
+                    if (f_power) write_power(batch->items);
+                } else if (need_raw) {
+                    write_frame(batch->items, batch->scores, batch->offsets, static_cast<int>(t) - 1);
+                }
+            });
+            std::vector<double>().swap(batch->scores);
+            return ww.lap();
         });
-        st.write_seconds += bw.lap();
     };
+    std::deque<std::unique_ptr<PreparedWindow>> alive;
     std::future<std::unique_ptr<PreparedWindow>> next;
     if (file.size() > 0) next = std::async(std::launch::async, prepare_window, size_t(0));
+    try {
     for (size_t w0 = 0; w0 < file.size(); w0 += window) {
         sw.lap();
         std::unique_ptr<PreparedWindow> pw = next.get();
@@ -466,8 +480,22 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
                 ++st.alignments;
                 st.ref_bases += it.len;
             }
-        for (Batch& bt : pw->batches) run_batch(bt);
+
+        // a window stays alive until the writers of its last batch are done, i.e. until the first batch of a later
+        // window has passed finish_writer() inside run_batch
+        alive.push_back(std::move(pw));
+        for (Batch& bt : alive.back()->batches) {
+            run_batch(bt);
+            while (alive.size() > 1) alive.pop_front();
+        }
     }
+    finish_writer();
+    } catch (...) {  // the background stages reference this frame: let them finish before it unwinds
+        if (writer.valid()) writer.wait();
+        if (next.valid()) next.wait();
+        throw;
+    }
+    alive.clear();
     if (f_power) fclose(f_power);
     for (FILE* f : f_raw)
         if (f) fclose(f);
