@@ -228,7 +228,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
 
         double cur[16];
         double4_t acc[4];
-        double stk[MAX_STACK_DEPTH_DEV][16];
+        double4_t stk[MAX_STACK_DEPTH_DEV][4];  // parked messages, in accumulator layout: a push accumulates in place
 
         // The op word and the codon bytes of op i+1 are fetched from LDS while op i runs, so that no LDS
         // round trip (op word -> leaf index -> codon byte) sits between two products.
@@ -250,11 +250,16 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
             const int a = (op >> 14) & 0x3fff, b = op & 0x3fff;
             const uint32_t cod_a = ca, cod_b = cb;
             (void)cod_b;
-            // issue next iteration's LDS reads now; they are consumed after this op's product
-            op = __builtin_amdgcn_readfirstlane(word_ahead);
-            word_ahead = lprog[ip + 2 < p.n_ops ? ip + 2 : p.n_ops - 1];
-            ca = my_cod[((op >> 14) & 0x3fff) * SITES];
-            cb = my_cod[(op & 0x3fff) * SITES];
+            // The next op's word and codon bytes are fetched from LDS while this op runs: inside its product (slot 3 of
+            // k-step 13, PCSF_STAGE_SLOT) for the product arms, right here for the two arms without a product
+#define PCSF_FETCH_NEXT_OP()                                                         \
+    {                                                                                \
+        op = __builtin_amdgcn_readfirstlane(word_ahead);                             \
+        word_ahead = lprog[ip + 2 < p.n_ops ? ip + 2 : p.n_ops - 1];                 \
+        ca = my_cod[((op >> 14) & 0x3fff) * SITES];                                  \
+        cb = my_cod[(op & 0x3fff) * SITES];                                          \
+    }
+            if (code == F_CHERRY_DEV || code >= F_ROOT_DEV) PCSF_FETCH_NEXT_OP()
             PCSF_STAMP_RAW(5)
 
             // Every op except the first cherry and the root starts with a product.  Its barrier
@@ -285,7 +290,8 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
 #define PCSF_STAGE_SLOT(q, j)                                                        \
     if constexpr (j == 1 && q < CHUNKS_PER_WAVE) {                                   \
         stage_piece(std::integral_constant<int, (q < CHUNKS_PER_WAVE ? q : 0)>{}, stage_next, (this_slot + 1) & 1); \
-    }
+    }                                                                                \
+    if constexpr (j == 3 && q == 13) PCSF_FETCH_NEXT_OP()
 // Cherry rows: piece i of row a in k-step i slot 2, of row b in k-step i slot 3 (i = 0..7); multiplied after the
 // product, by which time the last piece has been on its way for eight k-steps.
 #define PCSF_PUSH_CHERRY(D)                                                          \
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
         const double2_t* pa = leaf_row_ptr(leaf_tab, a, cod_a, g4);                  \
         const double2_t* pb = leaf_row_ptr(leaf_tab, b, cod_b, g4);                  \
         LeafRow ra, rb;                                                              \
-        product(buf, lane, cur, acc, [&](auto qc, auto jc) {                         \
+        product(buf, lane, cur, stk[D], [&](auto qc, auto jc) {                         \
             constexpr int q = decltype(qc)::value;                                   \
             constexpr int j = decltype(jc)::value;                                   \
             PCSF_STAGE_SLOT(q, j)                                                    \
@@ -302,7 +308,6 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
             if constexpr (j == 3 && q < 8) rb.v[q] = pb[q * ROW_PIECE_STRIDE];       \
         });                                                                          \
         PCSF_STAMP(4)                                                                \
-        _Pragma("unroll") for (int q = 0; q < 16; ++q) stk[D][q] = acc[q >> 2][q & 3]; \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) {                              \
             cur[2 * i] = ra.v[i].x * rb.v[i].x;                                      \
             cur[2 * i + 1] = ra.v[i].y * rb.v[i].y;                                  \
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
             PCSF_STAGE_SLOT(q, j)                                                    \
         });                                                                          \
         PCSF_STAMP(2)                                                                \
-        _Pragma("unroll") for (int q = 0; q < 16; ++q) cur[q] = stk[D][q] * acc[q >> 2][q & 3]; \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) cur[q] = stk[D][q >> 2][q & 3] * acc[q >> 2][q & 3]; \
         PCSF_STAMP(3)                                                                \
     }
             switch (code) {
@@ -385,6 +390,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
 #undef PCSF_STAMP
 #undef PCSF_STAMP_RAW
 #undef PCSF_STAGE_SLOT
+#undef PCSF_FETCH_NEXT_OP
 #undef PCSF_PUSH_CHERRY
 #undef PCSF_POP
         }
