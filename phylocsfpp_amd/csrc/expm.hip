@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void expm_kernel(const ExpmParams p)
             __syncthreads();
         }
         if (tid == 0) bad = 0;
-        if (tid < 64) scale_s[tid] = exp(lam_s[tid] * job.t);  // one exponential per eigenvalue and job
+        if (wave == static_cast<int>((jx + 2) & 3)) scale_s[lane] = exp(lam_s[lane] * job.t);  // one exponential per eigenvalue and job
         __syncthreads();
 
         double4_t acc[4];
@@ -72,65 +72,71 @@ __global__ __launch_bounds__(256, 2) void expm_kernel(const ExpmParams p)
             for (int r = 0; r < 4; ++r) P[(16 * wave + (lane >> 4) + 4 * r) * 65 + 16 * c + (lane & 15)] = acc[c][r];
         __syncthreads();
 
-        // Row post-processing, one thread per row, in index order like the reference.  Branch-free and with the LDS
-        // reads issued eight at a time: written as one load, test and branch per entry this pass was a chain of 64
-        // LDS round trips and took three quarters of the whole kernel.
-        if (tid < 64) {
-            double* row = P + tid * 65;
-            double total = 0.0, diag = 1.0;
-            bool ok = true;
-            // `lead` = the row sum as far as the columns before the diagonal: the gap-leaf message is the sum of the
-            // FINAL row in index order (src/fixed_lik.hpp:111-117), whose diagonal is only known after this pass
-            double lead = 0.0;
-#pragma unroll 1  // (fully unrolled, the 3 x 64 loop-invariant lane masks of `j <> tid` are hoisted and spill)
-            for (int j0 = 0; j0 < 64; j0 += 8) {
-                double v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = row[j0 + u];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int j = j0 + u;
-                    total += v[u];
-                    const bool neg = v[u] < 0.0;
-                    ok = ok && !(neg && fabs(v[u]) > 1e-6);
-                    const double vz = neg ? 0.0 : v[u];
-                    row[j] = vz;
-                    diag = (j != tid) ? diag - vz : diag;
-                    lead = (j < tid) ? lead + vz : lead;
-                }
-            }
-            if (!(fabs(total - 1.0) <= 1e-6)) ok = false;
-            row[tid] = diag;
-            double s = lead + diag;
+        // Row post-processing, one thread per row, sums in index order like the reference; three sweeps over the row
+        // so that no sweep needs a per-entry select: (1) raw row sum, most negative entry, clamp negatives to zero;
+        // (2) with a zero parked on the diagonal, diag = 1 - (sum of the row); (3) the final row's sum (the message of
+        // a gap leaf, src/fixed_lik.hpp:111-117).  Vector-ALU instructions are time taken from the matrix pipe
+        // (DESIGN.md 3.1), so the wave that does this -- and the one that computes the exponentials -- changes with
+        // every job: with one work-group per SIMD-pair of waves, a fixed wave would load one SIMD only.
+        if (wave == static_cast<int>(jx & 3)) {
+            double* row = P + lane * 65;
+            double total = 0.0, most_negative = 0.0;
 #pragma unroll 1
             for (int j0 = 0; j0 < 64; j0 += 8) {
                 double v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) v[u] = row[j0 + u];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) s = (j0 + u > tid) ? s + v[u] : s;
+                for (int u = 0; u < 8; ++u) {
+                    total += v[u];
+                    most_negative = fmin(most_negative, v[u]);
+                    row[j0 + u] = fmax(v[u], 0.0);
+                }
             }
-            rowsum[tid] = s;
+            const bool ok = (fabs(total - 1.0) <= 1e-6) && !(most_negative < -1e-6);
+            row[lane] = 0.0;
+            double diag = 1.0;
+#pragma unroll 1
+            for (int j0 = 0; j0 < 64; j0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = row[j0 + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) diag -= v[u];
+            }
+            row[lane] = diag;
+            double s = 0.0;
+#pragma unroll 1
+            for (int j0 = 0; j0 < 64; j0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = row[j0 + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            rowsum[lane] = s;
             if (!ok) bad = 1;
         }
         __syncthreads();
         if (tid == 0 && bad) p.fail[job.table] = 1u;
 
         if (job.slot >= 0) {
-            // fragment order: frag[((q*2+h)*64 + l)*2 + e] = P[16*(2h+e) + (l&15)][4q + (l>>4)]
-            double* dst = p.frag + (static_cast<size_t>(job.table) * p.n_edges + job.slot) * 4096;
-            for (int idx = tid; idx < 4096; idx += 256) {
-                const int e = idx & 1, l = (idx >> 1) & 63, h = (idx >> 7) & 1, q = idx >> 8;
-                dst[idx] = P[(16 * (2 * h + e) + (l & 15)) * 65 + 4 * q + (l >> 4)];
+            // fragment order: frag[((q*2+h)*64 + l)*2 + e] = P[16*(2h+e) + (l&15)][4q + (l>>4)]; the two e of a lane
+            // leave as one 16-byte store
+            double2_t* dst = reinterpret_cast<double2_t*>(p.frag + (static_cast<size_t>(job.table) * p.n_edges + job.slot) * 4096);
+            for (int idx = tid; idx < 2048; idx += 256) {
+                const int l = idx & 63, h = (idx >> 6) & 1, q = idx >> 7;
+                const double* src = P + (32 * h + (l & 15)) * 65 + 4 * q + (l >> 4);
+                dst[idx] = double2_t{src[0], src[16 * 65]};
             }
         }
         if (job.leaf >= 0) {
             // leaf table: tab[((code*8 + q2)*4 + g)*2 + e] = P[4(2 q2 + e) + g][code], code 64 = row sum
-            double* dst = p.leaf_tab + (static_cast<size_t>(job.table) * p.n_leaves + job.leaf) * LEAF_TABLE_DOUBLES_DEV;
-            for (int idx = tid; idx < LEAF_TABLE_DOUBLES_DEV; idx += 256) {
-                const int e = idx & 1, g = (idx >> 1) & 3, q2 = (idx >> 3) & 7, code = idx >> 6;
-                const int a = 4 * (2 * q2 + e) + g;
-                dst[idx] = code < 64 ? P[a * 65 + code] : rowsum[a];
+            double2_t* dst = reinterpret_cast<double2_t*>(p.leaf_tab + (static_cast<size_t>(job.table) * p.n_leaves + job.leaf) * LEAF_TABLE_DOUBLES_DEV);
+            for (int idx = tid; idx < LEAF_TABLE_DOUBLES_DEV / 2; idx += 256) {
+                const int g = idx & 3, q2 = (idx >> 2) & 7, code = idx >> 5;
+                const int a = 8 * q2 + g;  // e = 0; e = 1 is state a + 4
+                dst[idx] = code < 64 ? double2_t{P[a * 65 + code], P[(a + 4) * 65 + code]} : double2_t{rowsum[a], rowsum[a + 4]};
             }
         }
         if (p.raw_out) {
