@@ -59,12 +59,28 @@ __global__ __launch_bounds__(256, 2) void expm_kernel(const ExpmParams p)
         double4_t acc[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = double4_t{0.0, 0.0, 0.0, 0.0};
+        // operands of k-step q+1 are requested from LDS before the MFMAs of k-step q are issued
+        const double* lrow = Ls + (lane >> 4) * 64 + (lane & 15);
+        double ln[4], en;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ln[c] = lrow[16 * c];
+        en = scale_s[lane >> 4];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const double e = scale_s[4 * q + (lane >> 4)];
+            double lc[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_frag[q], Ls[(4 * q + (lane >> 4)) * 64 + 16 * c + (lane & 15)] * e, acc[c], 0, 0, 0);
+            for (int c = 0; c < 4; ++c) lc[c] = ln[c];
+            const double e = en;
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < 16) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ln[c] = lrow[(q + 1) * 256 + 16 * c];
+                en = scale_s[4 * (q + 1) + (lane >> 4)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_frag[q], lc[c] * e, acc[c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c)
