@@ -166,30 +166,52 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
                 qq[tid] = qi;
             }
             __syncthreads();
-            // columns p,q of A and of V (item = pair m x row k)
-            for (int item = tid; item < 2048; item += 256) {
-                const int m = item >> 6, k = item & 63;
-                const int pc = pp[m], qc = qq[m];
-                const double c = cs[m], s = sn[m];
-                const double x = A[k * LD + pc], y = A[k * LD + qc];
-                A[k * LD + pc] = c * x - s * y;
-                A[k * LD + qc] = s * x + c * y;
-                const double vx = V[k * LD + pc], vy = V[k * LD + qc];
-                V[k * LD + pc] = c * vx - s * vy;
-                V[k * LD + qc] = s * vx + c * vy;
+            // Wave w applies rotations m = w, w+4, ..., w+28 to row / column k = lane.  All operands of a phase are
+            // read before any result is written: the items of a phase are disjoint, but the compiler cannot know that
+            // for two accesses to the same LDS array and would otherwise wait for one LDS round trip per item.
+            int pm[8], qm[8];
+            double cm[8], sm[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = wave + 4 * i;
+                pm[i] = pp[m];
+                qm[i] = qq[m];
+                cm[i] = cs[m];
+                sm[i] = sn[m];
+            }
+            {  // columns p,q of A and of V
+                double x[8], y[8], vx[8], vy[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    x[i] = A[lane * LD + pm[i]];
+                    y[i] = A[lane * LD + qm[i]];
+                    vx[i] = V[lane * LD + pm[i]];
+                    vy[i] = V[lane * LD + qm[i]];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    A[lane * LD + pm[i]] = cm[i] * x[i] - sm[i] * y[i];
+                    A[lane * LD + qm[i]] = sm[i] * x[i] + cm[i] * y[i];
+                    V[lane * LD + pm[i]] = cm[i] * vx[i] - sm[i] * vy[i];
+                    V[lane * LD + qm[i]] = sm[i] * vx[i] + cm[i] * vy[i];
+                }
             }
             __syncthreads();
-            // rows p,q of A; the rotated pair itself becomes exactly zero
-            for (int item = tid; item < 2048; item += 256) {
-                const int m = item >> 6, k = item & 63;
-                const int pr = pp[m], qr = qq[m];
-                const double c = cs[m], s = sn[m];
-                const double x = A[pr * LD + k], y = A[qr * LD + k];
-                double nx = c * x - s * y, ny = s * x + c * y;
-                if (k == qr) nx = 0.0;  // a_pq and a_qp: annihilated by the rotation (or already below 1e-290)
-                if (k == pr) ny = 0.0;
-                A[pr * LD + k] = nx;
-                A[qr * LD + k] = ny;
+            {  // rows p,q of A; the rotated pair itself becomes exactly zero
+                double x[8], y[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    x[i] = A[pm[i] * LD + lane];
+                    y[i] = A[qm[i] * LD + lane];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    double nx = cm[i] * x[i] - sm[i] * y[i], ny = sm[i] * x[i] + cm[i] * y[i];
+                    if (lane == qm[i]) nx = 0.0;  // a_pq and a_qp: annihilated by the rotation (or already below 1e-290)
+                    if (lane == pm[i]) ny = 0.0;
+                    A[pm[i] * LD + lane] = nx;
+                    A[qm[i] * LD + lane] = ny;
+                }
             }
             __syncthreads();
         }
