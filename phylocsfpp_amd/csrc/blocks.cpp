@@ -71,10 +71,11 @@ struct BlockEngine {
     DeviceBuffer d_frag, d_leaf, d_fail;   // table sets, one per evaluation of a run
     DeviceBuffer d_eig_r, d_eig_l, d_eig_lam, d_prior, d_ancw;  // eigen-systems and their root priors
     DeviceBuffer d_jobs, d_eig_jobs, d_wg0, d_wg1, d_wgt, d_wgp, d_wgo, d_lnz, d_anc;
+    DeviceBuffer d_branch_slot, d_branch_len, d_leaf_codes;  // per-branch constants; per (block, leaf) row masks
     // Work of one run() is kept in two sets: evaluations whose eigen-system is rebuilt in this run (set 1: eigen ->
     // expm -> prune on the side stream) and all others (set 0: expm -> prune on the main stream), so that the
     // latency-bound eigen kernel overlaps the matrix work of the other evaluations.
-    std::vector<ExpmJob> jobs[2];
+    std::vector<ExpmEval> jobs[2];
     std::vector<EigenJob> eig_jobs;
     std::vector<uint64_t> wg0[2], wg1[2], wgo[2];
     std::vector<uint32_t> wgt[2], wgp[2];
@@ -103,7 +104,32 @@ struct BlockEngine {
             HIP_TRY(d_codons.reserve(static_cast<size_t>(nl) * n_sites_total));
             HIP_TRY(hipMemcpy2DAsync(d_codons.ptr, n_sites_total, codons, stride, n_sites_total, nl, hipMemcpyHostToDevice, stream));
         }
+        // which rows of each leaf's message table the block's sites read (values above 64 count as 64, like the kernel)
+        leaf_codes.assign(nb * static_cast<size_t>(nl) * 2, 0);
+        for (size_t b = 0; b < nb; ++b)
+            for (int l = 0; l < nl; ++l) {
+                uint64_t lo = 0, hi = 0;
+                const uint8_t* row = codons + static_cast<size_t>(l) * stride;
+                for (uint64_t s = offsets[b]; s < offsets[b + 1]; ++s) {
+                    const unsigned cd = row[s] > 64 ? 64u : row[s];
+                    if (cd < 64) lo |= uint64_t(1) << cd;
+                    else hi |= 1;
+                }
+                leaf_codes[(b * nl + l) * 2] = lo;
+                leaf_codes[(b * nl + l) * 2 + 1] = hi;
+            }
+        std::vector<int32_t> slots(static_cast<size_t>(n - 1));
+        for (int b = 0; b < n - 1; ++b) slots[b] = c->branch_slot[b];
+        HIP_TRY(d_branch_slot.reserve(slots.size() * sizeof(int32_t)));
+        HIP_TRY(d_branch_len.reserve(slots.size() * sizeof(float)));
+        HIP_TRY(d_leaf_codes.reserve(std::max<size_t>(leaf_codes.size(), 2) * sizeof(uint64_t)));
+        HIP_TRY(hipMemcpyAsync(d_branch_slot.ptr, slots.data(), slots.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(d_branch_len.ptr, c->branch_len.data(), slots.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+        if (!leaf_codes.empty())
+            HIP_TRY(hipMemcpyAsync(d_leaf_codes.ptr, leaf_codes.data(), leaf_codes.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));  // `slots` is a stack temporary
     }
+    std::vector<uint64_t> leaf_codes;  // [block][leaf][2]
     ~BlockEngine()
     {
         if (side) {
@@ -167,15 +193,12 @@ struct BlockEngine {
             for (int i = 0; i < 12; ++i) j.qs[i] = new_qs[i];
             eig_jobs.push_back(j);
         }
-        for (int b = 0; b < n - 1; ++b) {
-            ExpmJob j;
-            j.eig = eig;
-            j.table = table;
-            j.slot = c->branch_slot[b];
-            j.leaf = b < nl ? b : -1;
-            j.t = scaled_branch(c->branch_len[b], x);
-            jobs[set].push_back(j);
-        }
+        ExpmEval ev{};
+        ev.eig = eig;
+        ev.table = table;
+        ev.block = static_cast<uint32_t>(blk);
+        ev.x = x;
+        jobs[set].push_back(ev);
         for (uint64_t s = off[blk]; s < off[blk + 1]; s += 64) {
             wg0[set].push_back(s);
             wg1[set].push_back(std::min<uint64_t>(s + 64, off[blk + 1]));
@@ -199,9 +222,9 @@ struct BlockEngine {
             HIP_TRY(d_eig_jobs.reserve(eig_jobs.size() * sizeof(EigenJob)));
             HIP_TRY(hipMemcpyAsync(d_eig_jobs.ptr, eig_jobs.data(), eig_jobs.size() * sizeof(EigenJob), hipMemcpyHostToDevice, stream));
         }
-        HIP_TRY(d_jobs.reserve((nj0 + nj1) * sizeof(ExpmJob)));
-        if (nj0) HIP_TRY(hipMemcpyAsync(d_jobs.as<ExpmJob>(), jobs[0].data(), nj0 * sizeof(ExpmJob), hipMemcpyHostToDevice, stream));
-        if (nj1) HIP_TRY(hipMemcpyAsync(d_jobs.as<ExpmJob>() + nj0, jobs[1].data(), nj1 * sizeof(ExpmJob), hipMemcpyHostToDevice, stream));
+        HIP_TRY(d_jobs.reserve((nj0 + nj1) * sizeof(ExpmEval)));
+        if (nj0) HIP_TRY(hipMemcpyAsync(d_jobs.as<ExpmEval>(), jobs[0].data(), nj0 * sizeof(ExpmEval), hipMemcpyHostToDevice, stream));
+        if (nj1) HIP_TRY(hipMemcpyAsync(d_jobs.as<ExpmEval>() + nj0, jobs[1].data(), nj1 * sizeof(ExpmEval), hipMemcpyHostToDevice, stream));
         if (nw0 + nw1) {
             const size_t nw = nw0 + nw1;
             HIP_TRY(d_wg0.reserve(nw * 8));
@@ -230,10 +253,14 @@ struct BlockEngine {
             const size_t nj = set ? nj1 : nj0, j_at = set ? nj0 : 0, nw = set ? nw1 : nw0, w_at = set ? nw0 : 0;
             if (nj) {
                 ExpmParams ep{};
-                ep.jobs = d_jobs.as<ExpmJob>() + j_at;
-                ep.n_jobs = static_cast<uint32_t>(nj);
+                ep.evals = d_jobs.as<ExpmEval>() + j_at;
+                ep.n_evals = static_cast<uint32_t>(nj);
+                ep.n_branches = static_cast<uint32_t>(n - 1);
                 ep.n_edges = ne;
                 ep.n_leaves = nl;
+                ep.branch_slot = d_branch_slot.as<int32_t>();
+                ep.branch_len = d_branch_len.as<float>();
+                ep.leaf_codes = d_leaf_codes.as<uint64_t>();
                 ep.eig_right = d_eig_r.as<double>();
                 ep.eig_left = d_eig_l.as<double>();
                 ep.eig_lambda = d_eig_lam.as<double>();

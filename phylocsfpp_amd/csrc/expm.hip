@@ -29,16 +29,40 @@ __global__ __launch_bounds__(256, 2) void expm_kernel(const ExpmParams p)
     __shared__ int bad;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n_jobs = p.n_evals * p.n_branches;
     const uint32_t job0 = blockIdx.x * EXPM_CHUNK;
-    const uint32_t job1 = min(p.n_jobs, job0 + EXPM_CHUNK);
+    const uint32_t job1 = min(n_jobs, job0 + EXPM_CHUNK);
+    struct Job {
+        uint32_t eig, table;
+        int32_t slot, leaf;
+        double t;
+        uint64_t codes[2];
+    };
+    auto fetch = [&](uint32_t jx) {  // evaluation record + per-branch constants -> one job
+        const uint32_t e = jx / p.n_branches, b = jx - e * p.n_branches;
+        const ExpmEval ev = p.evals[e];
+        Job j;
+        j.eig = ev.eig;
+        j.table = ev.table;
+        j.slot = p.branch_slot[b];
+        j.leaf = static_cast<int>(b) < p.n_leaves ? static_cast<int>(b) : -1;
+        j.t = static_cast<double>(static_cast<float>(static_cast<double>(p.branch_len[b]) * ev.x));
+        j.codes[0] = j.codes[1] = ~uint64_t(0);
+        if (j.leaf >= 0 && p.leaf_codes) {
+            const uint64_t* m = p.leaf_codes + (static_cast<size_t>(ev.block) * p.n_leaves + j.leaf) * 2;
+            j.codes[0] = m[0];
+            j.codes[1] = m[1];
+        }
+        return j;
+    };
     const int i = 16 * wave + (lane & 15);  // wave w computes rows 16w..16w+15 of P, all four 16-column tiles
     double r_frag[16];
     uint32_t have_eig = 0xffffffffu;
 
-    ExpmJob ahead = p.jobs[job0 < job1 ? job0 : 0];
+    Job ahead = fetch(job0 < job1 ? job0 : 0);
     for (uint32_t jx = job0; jx < job1; ++jx) {
-        const ExpmJob job = ahead;
-        ahead = p.jobs[jx + 1 < job1 ? jx + 1 : jx];  // the next job's 24 bytes travel while this one computes
+        const Job job = ahead;
+        ahead = fetch(jx + 1 < job1 ? jx + 1 : jx);  // the next job's parameters travel while this one computes
         if (job.eig != have_eig) {
             const double* __restrict__ R = p.eig_right + static_cast<size_t>(job.eig) * 4096;
             const double* __restrict__ L = p.eig_left + static_cast<size_t>(job.eig) * 4096;
@@ -151,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void expm_kernel(const ExpmParams p)
             double2_t* dst = reinterpret_cast<double2_t*>(p.leaf_tab + (static_cast<size_t>(job.table) * p.n_leaves + job.leaf) * LEAF_TABLE_DOUBLES_DEV);
             for (int idx = tid; idx < LEAF_TABLE_DOUBLES_DEV / 2; idx += 256) {
                 const int g = idx & 3, q2 = (idx >> 2) & 7, code = idx >> 5;
+                if (!((job.codes[code >> 6] >> (code & 63)) & 1)) continue;  // row not read by this block
                 const int a = 8 * q2 + g;  // e = 0; e = 1 is state a + 4
                 dst[idx] = code < 64 ? double2_t{P[a * 65 + code], P[(a + 4) * 65 + code]} : double2_t{rowsum[a], rowsum[a + 4]};
             }
@@ -165,7 +190,9 @@ __global__ __launch_bounds__(256, 2) void expm_kernel(const ExpmParams p)
 
 hipError_t launch_expm(const ExpmParams& p, hipStream_t stream)
 {
-    if (p.n_jobs == 0) return hipSuccess;
+    const uint64_t n_jobs = static_cast<uint64_t>(p.n_evals) * p.n_branches;
+    if (n_jobs == 0) return hipSuccess;
+    if (n_jobs > 0x7fffffffULL) return hipErrorInvalidValue;
     constexpr size_t lds = (64 * 65 + 64 * 64) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
@@ -173,7 +200,7 @@ hipError_t launch_expm(const ExpmParams& p, hipStream_t stream)
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(expm_kernel, dim3((p.n_jobs + EXPM_CHUNK - 1) / EXPM_CHUNK), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(expm_kernel, dim3(static_cast<unsigned>((n_jobs + EXPM_CHUNK - 1) / EXPM_CHUNK)), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 

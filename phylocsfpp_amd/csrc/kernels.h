@@ -56,18 +56,26 @@ namespace pcsf {
 
 // ---- batched P(t) = S * diag(exp(lambda t)) * S^-1 with the reference's post-processing -------
 // (src/instance.hpp:529-549, 602-640).  One job = one branch matrix of one table set.
-struct ExpmJob {
+// One EVALUATION = all n-1 branch matrices of one table set at one tree scale; job jx of a launch is branch
+// jx % n_branches of evaluation jx / n_branches.  (Per-branch job records built on the host cost more host time and
+// PCIe traffic than the kernel took.)
+struct ExpmEval {
     uint32_t eig;      // eigen-system index: S at eig_right + eig*4096, S^-1 at eig_left + eig*4096, lambda at eig_lambda + eig*64
     uint32_t table;    // destination table set
-    int32_t slot;      // >= 0: internal child -> fragment image `slot` of the table set
-    int32_t leaf;      // >= 0: leaf -> leaf-message table `leaf` of the table set
-    double t;          // branch length at the current tree scale
+    uint32_t block;    // block whose sites will read the tables (selects the leaf-table rows that are written)
+    uint32_t pad;
+    double x;          // tree scale: branch b gets t = (double)(float)(branch_len[b] * x), like the reference's float tree
 };
 
 struct ExpmParams {
-    const ExpmJob* jobs;
-    uint32_t n_jobs;
+    const ExpmEval* evals;
+    uint32_t n_evals;
+    uint32_t n_branches;       // n_nodes - 1
     int n_edges, n_leaves;
+    const int32_t* branch_slot;  // [n_branches] >= 0: internal child -> fragment image `slot` of the table set; -1: leaf b
+    const float* branch_len;     // [n_branches]
+    const uint64_t* leaf_codes;  // [block][n_leaves][2] bit c = row c (codon 0..63, 64 = gap) of the leaf's table is read by
+                                 // the block's sites; only those rows are written (null: all rows)
     const double* eig_right;   // [n_eig][64*64] row-major, right eigenvectors in columns
     const double* eig_left;    // [n_eig][64*64] row-major, left eigenvectors in rows
     const double* eig_lambda;  // [n_eig][64]
