@@ -187,3 +187,35 @@ def test_random_blocks_fixed_with_empty_and_ragged(oracle_models, gpu_contexts):
     assert ph[0] == 0.0 and ph[3] == 0.0
     with pytest.raises(pa.PcsfError):
         ctx.score_blocks(pa.FIXED, cod, np.array([0, 5, 3], dtype=np.uint64))
+
+
+def test_mle_and_omega_on_trees_whose_branch_count_is_not_a_chunk_multiple(oracle_models, gpu_contexts):
+    """53birds (104 branches) and 58mammals (114): the batched P(t) kernel's nine-job chunks straddle evaluations, so a
+    work-group changes eigen-system in mid-chunk (100vertebrates' 198 branches never do)."""
+    from phylocsfpp_amd import synth
+    for name in ("53birds", "58mammals"):
+        m = oracle_models(name)
+        ctx = gpu_contexts(name)
+        lens = [7, 1, 30, 12, 3]
+        cols = synth.synthetic_codon_columns(m.child1, m.child2, m.branch_len, m.S_c, m.pi_c, m.S_nc, m.pi_nc, sum(lens), seed=21, dropout=0.2, gap_rate=0.05)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        # objective level, kappa/omega model: every block its own rate matrix -> one eigen-system per evaluation
+        rng = np.random.default_rng(8)
+        qs = np.column_stack([rng.uniform(1.5, 6.0, len(lens)), np.full(len(lens), 0.2), np.full(len(lens), 0.5), rng.uniform(0.6, 1.6, (len(lens), 9))])
+        got, failed = ctx.block_loglik(2, cols, off, np.array([0.4, 1.0, 2.2, 0.9, 1.7]), q_settings=qs)
+        assert not failed.any()
+        dp = C.POINTER(C.c_double)
+        for b in range(len(lens)):
+            Q, pi = np.empty((64, 64)), np.empty(64)
+            ob.lib().po_q_from_omega(np.ascontiguousarray(qs[b]).ctypes.data_as(dp), Q.ctypes.data_as(dp), pi.ctypes.data_as(dp))
+            qd = ob.PoQdiag()
+            ob.lib().po_eig(Q.ctypes.data_as(dp), pi.ctypes.data_as(dp), C.byref(qd))
+            want = _oracle_lpr(m, qd, np.ascontiguousarray(cols[:, int(off[b]):int(off[b + 1])]), [0.4, 1.0, 2.2, 0.9, 1.7][b])
+            assert abs(got[b] - want) <= 2e-8 * abs(want)
+        # end to end against the oracle's own optimiser runs
+        for algo, tol in ((pa.MLE, 0.001), (pa.OMEGA, 0.1)):
+            ph, _ = ctx.score_blocks(algo, cols, off, compute_anc=False)
+            oph, _ = _oracle_blocks(m, algo, cols, off, compute_anc=False)
+            assert np.all(np.isfinite(ph) == np.isfinite(oph))
+            ok = np.isfinite(oph)
+            assert np.all((ph[ok] - oph[ok]) ** 2 <= tol), (name, algo, ph, oph)
