@@ -166,51 +166,64 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
                 qq[tid] = qi;
             }
             __syncthreads();
-            // Wave w applies rotations m = w, w+4, ..., w+28 to row / column k = lane.  All operands of a phase are
-            // read before any result is written: the items of a phase are disjoint, but the compiler cannot know that
-            // for two accesses to the same LDS array and would otherwise wait for one LDS round trip per item.
-            int pm[8], qm[8];
-            double cm[8], sm[8];
+            // B <- J^T B J in ONE pass over 2x2 blocks: block (m, m') = rows {p,q} of pair m x columns {p',q'} of pair
+            // m' is first rotated from the right by pair m', then from the left by pair m -- the same arithmetic as a
+            // column pass followed by a row pass, with every entry read and written once.  V <- V J on the side.  All
+            // operands are read before any result is written (the items are disjoint, but the compiler cannot know
+            // that for accesses to one LDS array and would otherwise wait for an LDS round trip per item).
+            {
+                double b00[4], b01[4], b10[4], b11[4], cl[4], sl[4], cr[4], sr[4];
+                int pl[4], ql[4], pr[4], qr[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = wave + 4 * i;
-                pm[i] = pp[m];
-                qm[i] = qq[m];
-                cm[i] = cs[m];
-                sm[i] = sn[m];
-            }
-            {  // columns p,q of A and of V
-                double x[8], y[8], vx[8], vy[8];
+                for (int i = 0; i < 4; ++i) {
+                    const int blk = tid + 256 * i, m = blk >> 5, mr = blk & 31;
+                    pl[i] = pp[m];
+                    ql[i] = qq[m];
+                    cl[i] = cs[m];
+                    sl[i] = sn[m];
+                    pr[i] = pp[mr];
+                    qr[i] = qq[mr];
+                    cr[i] = cs[mr];
+                    sr[i] = sn[mr];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    b00[i] = A[pl[i] * LD + pr[i]];
+                    b01[i] = A[pl[i] * LD + qr[i]];
+                    b10[i] = A[ql[i] * LD + pr[i]];
+                    b11[i] = A[ql[i] * LD + qr[i]];
+                }
+                int pm[8], qm[8];
+                double cm[8], sm[8], vx[8], vy[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    x[i] = A[lane * LD + pm[i]];
-                    y[i] = A[lane * LD + qm[i]];
+                    const int m = wave + 4 * i;
+                    pm[i] = pp[m];
+                    qm[i] = qq[m];
+                    cm[i] = cs[m];
+                    sm[i] = sn[m];
                     vx[i] = V[lane * LD + pm[i]];
                     vy[i] = V[lane * LD + qm[i]];
                 }
 #pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int blk = tid + 256 * i;
+                    // columns p', q' (right rotation) of both rows ...
+                    const double t1 = cr[i] * b00[i] - sr[i] * b01[i], t2 = sr[i] * b00[i] + cr[i] * b01[i];
+                    const double u1 = cr[i] * b10[i] - sr[i] * b11[i], u2 = sr[i] * b10[i] + cr[i] * b11[i];
+                    // ... then rows p, q (left rotation)
+                    double n00 = cl[i] * t1 - sl[i] * u1, n01 = cl[i] * t2 - sl[i] * u2;
+                    double n10 = sl[i] * t1 + cl[i] * u1, n11 = sl[i] * t2 + cl[i] * u2;
+                    if ((blk >> 5) == (blk & 31)) n01 = n10 = 0.0;  // the rotated pair itself: annihilated (or already below 1e-290)
+                    A[pl[i] * LD + pr[i]] = n00;
+                    A[pl[i] * LD + qr[i]] = n01;
+                    A[ql[i] * LD + pr[i]] = n10;
+                    A[ql[i] * LD + qr[i]] = n11;
+                }
+#pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    A[lane * LD + pm[i]] = cm[i] * x[i] - sm[i] * y[i];
-                    A[lane * LD + qm[i]] = sm[i] * x[i] + cm[i] * y[i];
                     V[lane * LD + pm[i]] = cm[i] * vx[i] - sm[i] * vy[i];
                     V[lane * LD + qm[i]] = sm[i] * vx[i] + cm[i] * vy[i];
-                }
-            }
-            __syncthreads();
-            {  // rows p,q of A; the rotated pair itself becomes exactly zero
-                double x[8], y[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    x[i] = A[pm[i] * LD + lane];
-                    y[i] = A[qm[i] * LD + lane];
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    double nx = cm[i] * x[i] - sm[i] * y[i], ny = sm[i] * x[i] + cm[i] * y[i];
-                    if (lane == qm[i]) nx = 0.0;  // a_pq and a_qp: annihilated by the rotation (or already below 1e-290)
-                    if (lane == pm[i]) ny = 0.0;
-                    A[pm[i] * LD + lane] = nx;
-                    A[qm[i] * LD + lane] = ny;
                 }
             }
             __syncthreads();
