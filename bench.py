@@ -123,15 +123,22 @@ def main():
     codons_host = make_batch(m, n_sites, seed=20261002 + rank)
     codons = torch.from_numpy(codons_host).to(dev)
     scores = torch.empty(n_sites, dtype=torch.float64, device=dev)
-    gathered = [torch.empty(n_sites, dtype=torch.float64, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # N > 1: two score buffers per rank; the gather of step k (RCCL, its own stream) runs while step k+1 is scored
+    pipe = None
+    if world > 1:
+        from phylocsfpp_amd import dist as pdist
+        pipe = pdist.ScoreGatherPipeline(n_sites, torch.float64, dev, depth=2, dst=0)
 
     def step():
-        ctx.score_sites_fixed_torch(codons, out=scores)
-        if world > 1:
-            dist.gather(scores, gathered, dst=0)
+        if pipe is None:
+            ctx.score_sites_fixed_torch(codons, out=scores)
+        else:
+            ctx.score_sites_fixed_torch(codons, out=pipe.acquire())
+            pipe.submit()
 
     def fence():
-        if world > 1:
+        if pipe is not None:
+            pipe.drain()       # every rank's scores of every step have arrived on rank 0
             dist.barrier()
         torch.cuda.synchronize()
 

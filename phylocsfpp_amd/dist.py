@@ -57,6 +57,53 @@ def gather_to_root(local, counts, dst=0, group=None):
     return torch.cat([recv[r][:int(counts[r])] for r in range(world)])
 
 
+class ScoreGatherPipeline:
+    """Steady-state form of the gather: `depth` score buffers per rank, the gather of step k runs (async, on the
+    collective's own stream) while step k+1 is being scored into the next buffer.
+
+        buf = pipe.acquire()      # the buffer to score into; waits for the gather that last read it
+        ... launch the scoring kernel writing `buf` on the current stream ...
+        pipe.submit()             # starts the gather of `buf` to rank 0
+        ...
+        pipe.drain()              # all gathers done; on rank 0 pipe.result(i) = list of the ranks' buffers of slot i
+    """
+
+    def __init__(self, n_items, dtype, device, depth=2, dst=0, group=None):
+        import torch
+        import torch.distributed as dist
+        self._dist, self.group, self.dst, self.depth = dist, group, dst, depth
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.bufs = [torch.empty(n_items, dtype=dtype, device=device) for _ in range(depth)]
+        self.recv = [[torch.empty(n_items, dtype=dtype, device=device) for _ in range(self.world)] if self.rank == dst else None
+                     for _ in range(depth)]
+        self.pending = [None] * depth
+        self.k = 0
+        self._cur = None
+
+    def acquire(self):
+        slot = self.k % self.depth
+        if self.pending[slot] is not None:
+            self.pending[slot].wait()   # orders the current stream behind that gather; no host block on GPU streams
+            self.pending[slot] = None
+        self._cur = slot
+        return self.bufs[slot]
+
+    def submit(self):
+        slot = self._cur
+        self.pending[slot] = self._dist.gather(self.bufs[slot], self.recv[slot], dst=self.dst, group=self.group, async_op=True)
+        self.k += 1
+        return slot
+
+    def drain(self):
+        for slot in range(self.depth):
+            if self.pending[slot] is not None:
+                self.pending[slot].wait()
+                self.pending[slot] = None
+
+    def result(self, slot):
+        return self.recv[slot]
+
+
 def score_sites_sharded(score_fn, codons, group=None, align=64, to_device=None):
     """run_tracks over `codons` (uint8 [n_leaves, n_sites], the same array on every rank or at least
     this rank's columns valid) sharded across the process group.

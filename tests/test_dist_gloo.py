@@ -77,3 +77,37 @@ def test_shard_bounds_properties():
     for w in (1, 2, 3, 8):
         r = pdist.shard_blocks(off, w)
         assert r[0][0] == 0 and r[-1][1] == 7 and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+
+
+def _pipeline_worker(rank, world, port, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pipe = pdist.ScoreGatherPipeline(1000, torch.float64, torch.device("cpu"), depth=2)
+    ok = True
+    seen = {}
+    for step in range(7):
+        buf = pipe.acquire()
+        if rank == 0 and step >= 2:     # the gather that used this slot two steps ago has completed by now
+            got = pipe.result(step % 2)
+            ok = ok and all(bool((got[r] == 100.0 * (step - 2) + r).all()) for r in range(world))
+        buf.fill_(100.0 * step + rank)
+        seen[step] = pipe.submit()
+    pipe.drain()
+    if rank == 0:
+        for step in (5, 6):
+            got = pipe.result(seen[step])
+            ok = ok and all(bool((got[r] == 100.0 * step + r).all()) for r in range(world))
+        np.save(out_path, np.array([float(ok)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_overlapped_gather_pipeline(tmp_path, world):
+    """bench.py's N > 1 steady state: the gather of step k overlaps the scoring of step k+1 (two buffers per rank)."""
+    out = str(tmp_path / "pipe.npy")
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert np.load(out)[0] == 1.0
