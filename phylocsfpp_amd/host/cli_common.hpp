@@ -24,9 +24,10 @@ inline int usage(const char* prog)
             "usage:\n"
             "  %s build-tracks [--output DIR] [--power-threshold 0|1] [--output-raw-phylo 0|1] [--output-power 0|1]\n"
             "                  [--output-phylo 0|1] [--output-regions 0|1] [--genome-length N --coding-exons FILE | --hmm-params P]\n"
-            "                  [--species A,B,...] [--mapping FILE] [--species-aliases FILE] [--device N] <model prefix> <alignment.maf>...\n"
+            "                  [--species A,B,...] [--mapping FILE] [--species-aliases FILE] [--device N | --devices N,M,...]\n"
+            "                  <model prefix> <alignment.maf>...\n"
             "  %s score-msa    [--strategy fixed|mle|omega|fixed_mean] [--comp-phylo 0|1] [--comp-anc 0|1] [--comp-bls 0|1]\n"
-            "                  [--output DIR] [--species A,B,...] [--mapping FILE] [--species-aliases FILE] [--device N]\n"
+            "                  [--output DIR] [--species A,B,...] [--mapping FILE] [--species-aliases FILE] [--device N | --devices N,M,...]\n"
             "                  <model prefix> <alignment.maf>...\n"
             "  %s smooth-tracks [--output-phylo 0|1] [--output-regions 0|1] (--genome-length N --coding-exons FILE | --hmm-params P) DIR\n"
             "--hmm-params: coding prior, mean coding length (codons), 3 non-coding weights, 3 non-coding mean lengths (codons)\n"
@@ -135,7 +136,7 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
     uint64_t genome_length = 0;
     ScoreMsaParams sm;
     std::string aliases, species, mapping;
-    int device = 0;
+    std::vector<int> devices{0};
     int i = 2;
     for (; i < argc && strncmp(argv[i], "--", 2) == 0; i += 2) {
         if (i + 1 >= argc) return usage(argv[0]);
@@ -152,10 +153,22 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
         else if (k == "--hmm-params") hmm_params = v;
         else if (k == "--hmm-matrix") hmm_matrix = v;
         else if (k == "--threads") bt.threads = atoi(v.c_str());
+        else if (k == "--batch-sites") bt.batch_sites = static_cast<size_t>(strtoull(v.c_str(), nullptr, 10));    // codon-frames per backend call
+        else if (k == "--window-bytes") bt.window_bytes = static_cast<size_t>(strtoull(v.c_str(), nullptr, 10));  // MAF bytes per pipeline step
         else if (k == "--species-aliases") aliases = v;
         else if (k == "--species") species = v;
         else if (k == "--mapping") mapping = v;
-        else if (k == "--device") device = atoi(v.c_str());
+        else if (k == "--device") devices = {atoi(v.c_str())};
+        else if (k == "--devices") {  // one scoring context per listed GPU; batches / block ranges are dealt to them
+            devices.clear();
+            const char* q = v.c_str();
+            char* end = nullptr;
+            for (long x = strtol(q, &end, 10); q != end; x = strtol(q, &end, 10)) {
+                devices.push_back(static_cast<int>(x));
+                q = *end == ',' ? end + 1 : end;
+            }
+            if (devices.empty()) return usage(argv[0]);
+        }
         else if (k == "--verbose") bt.verbose = sm.verbose = parse_bool(v);
         else if (k == "--strategy") {
             const std::string s = lower(v);
@@ -227,17 +240,22 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
         }
         const Model model = load_model(prefix, aliases, species, mapping);
         if (!species.empty()) fprintf(stderr, "model reduced to %d species\n", model.n_leaves);
-        std::unique_ptr<ScoringBackend> backend = make_backend(model, device);
+        std::vector<std::unique_ptr<ScoringBackend>> owned;
+        std::vector<ScoringBackend*> backends;
+        for (int d : devices) {
+            owned.push_back(make_backend(model, d));
+            backends.push_back(owned.back().get());
+        }
         bool first = true;
         for (; i < argc; ++i) {
             if (cmd == "build-tracks") {
-                const BuildTracksStats st = build_tracks(model, argv[i], bt, *backend, !first);
+                const BuildTracksStats st = build_tracks(model, argv[i], bt, backends, !first);
                 fprintf(stderr, "%s: %zu alignments, %zu reference bases, %zu codon-frames, %zu backend calls\n", argv[i], st.alignments,
                         st.ref_bases, st.codon_frames, st.backend_calls);
                 fprintf(stderr, "  seconds: total %.3f = MAF read %.3f + BLS %.3f + batch packing %.3f + scoring backend %.3f + wig output %.3f + smoothing %.3f\n",
                         st.total_seconds, st.read_seconds, st.bls_seconds, st.extract_seconds, st.backend_seconds, st.write_seconds, st.smooth_seconds);
             } else {
-                const std::string out = score_msa(model, argv[i], sm, *backend);
+                const std::string out = score_msa(model, argv[i], sm, backends);
                 fprintf(stderr, "%s -> %s\n", argv[i], out.c_str());
             }
             first = false;

@@ -260,8 +260,10 @@ inline void smooth_tracks(const std::string& out_dir, const Hmm& hmm, bool write
 // scored by the backend (six frames per alignment, one call per batch); (3) seven writers -- the power
 // track and the six frames -- format their text in parallel and append it to their files.
 inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_path, const BuildTracksParams& prm,
-                                     ScoringBackend& backend, bool append = false)
+                                     const std::vector<ScoringBackend*>& backends, bool append = false)
 {
+    if (backends.empty()) throw std::runtime_error("build_tracks: no scoring backend");
+    ScoringBackend& backend = *backends[0];  // owner of the staging memory
     const std::string out_dir = prm.output_dir.empty() ? dirname_of(maf_path) : prm.output_dir;
     mkdir(out_dir.c_str(), 0764);
     const char* mode = append ? "a" : "w";
@@ -364,6 +366,7 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     struct PreparedWindow {
         std::vector<std::vector<Item>> jobs;
         std::vector<Batch> batches;
+        size_t submitted = 0;  // batches handed to stage 2
         double read = 0.0, bls = 0.0, pack = 0.0;  // thread-seconds in the reader / the branch-length score; wall seconds packing
     };
     // Stage 1 (runs one window ahead of the scoring): byte-range jobs parse the MAF and compute the branch-length
@@ -428,25 +431,42 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         pw->pack = pack.lap();
         return pw;
     };
-    // Stage 2 (this thread): one backend call per batch.  Stage 3 (one batch behind): seven writers -- the power
-    // track and the six frames -- format the batch's text and append it to their files, in batch order.
-    std::future<double> writer;  // seconds the previous batch's writers took
-    auto finish_writer = [&]() {
-        if (writer.valid()) st.write_seconds += writer.get();
+    // Stage 2: one backend call per batch, batches dealt round-robin to the backends (one per GPU; a backend takes
+    // its batches in order, different backends run concurrently).  Stage 3 (behind stage 2, in batch order): seven
+    // writers -- the power track and the six frames -- format the batch's text and append it to their files.
+    struct WindowSlot {
+        std::unique_ptr<PreparedWindow> pw;
+        size_t unwritten = 0;  // batches whose text is not on file yet: the window (items, batches) must stay alive
     };
-    auto run_batch = [&](Batch& bt) {
-        StopWatch bw;
+    struct InFlight {
+        Batch* bt = nullptr;
+        WindowSlot* ws = nullptr;
+        std::shared_future<double> scored;  // seconds inside the backend call
+    };
+    std::deque<WindowSlot> alive;  // references to deque elements survive push_back / pop_front of other elements
+    std::deque<InFlight> inflight;
+    InFlight writing;
+    std::future<double> writer;  // seconds the writers of `writing` took
+    const size_t n_dev = backends.size();
+    std::vector<std::shared_future<double>> dev_last(n_dev);
+    size_t next_dev = 0;
+    auto finish_writer = [&]() {
+        if (!writer.valid()) return;
+        st.write_seconds += writer.get();
+        --writing.ws->unwritten;
+        while (!alive.empty() && alive.front().unwritten == 0 && alive.front().pw->batches.size() == alive.front().pw->submitted) alive.pop_front();
+    };
+    auto retire_front = [&]() {  // oldest scored batch -> writers
+        InFlight f = inflight.front();
+        inflight.pop_front();
+        st.backend_seconds += f.scored.get();
         if (need_raw) {
-            backend.score_alignments_6frames(model.n_leaves, bt.nucl.first, bt.stride, bt.col0, bt.len, bt.start_pos, bt.chrom_len, bt.scores, bt.offsets,
-                                             bt.n_codons);
-            st.backend_seconds += bw.lap();
             ++st.backend_calls;
-            st.codon_frames += bt.scores.size();
-            pool.put(bt.nucl);
-            bt.nucl = {nullptr, 0};
+            st.codon_frames += f.bt->scores.size();
         }
         finish_writer();  // files are appended in batch order
-        writer = std::async(std::launch::async, [&, batch = &bt]() {
+        writing = f;
+        writer = std::async(std::launch::async, [&, batch = f.bt]() {
             StopWatch ww;
             parallel_for(7, threads, [&](size_t t) {
                 if (t == 0) {
@@ -459,7 +479,25 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             return ww.lap();
         });
     };
-    std::deque<std::unique_ptr<PreparedWindow>> alive;
+    auto submit = [&](Batch& bt, WindowSlot* ws) {
+        const size_t d = next_dev++ % n_dev;
+        const std::shared_future<double> prev = dev_last[d];
+        std::shared_future<double> task = std::async(std::launch::async, [&, b = &bt, d, prev]() -> double {
+            if (prev.valid()) prev.wait();
+            StopWatch bw;
+            if (need_raw) {
+                backends[d]->score_alignments_6frames(model.n_leaves, b->nucl.first, b->stride, b->col0, b->len, b->start_pos, b->chrom_len, b->scores,
+                                                      b->offsets, b->n_codons);
+                pool.put(b->nucl);
+                b->nucl = {nullptr, 0};
+            }
+            return bw.lap();
+        }).share();
+        dev_last[d] = task;
+        ++ws->pw->submitted;
+        inflight.push_back({&bt, ws, task});
+        while (inflight.size() > n_dev) retire_front();
+    };
     std::future<std::unique_ptr<PreparedWindow>> next;
     if (file.size() > 0) next = std::async(std::launch::async, prepare_window, size_t(0));
     try {
@@ -480,17 +518,20 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
                 ++st.alignments;
                 st.ref_bases += it.len;
             }
-
-        // a window stays alive until the writers of its last batch are done, i.e. until the first batch of a later
-        // window has passed finish_writer() inside run_batch
-        alive.push_back(std::move(pw));
-        for (Batch& bt : alive.back()->batches) {
-            run_batch(bt);
-            while (alive.size() > 1) alive.pop_front();
-        }
+        if (pw->batches.empty()) continue;
+        alive.emplace_back();
+        WindowSlot* ws = &alive.back();
+        ws->pw = std::move(pw);
+        ws->unwritten = ws->pw->batches.size();
+        for (Batch& bt : ws->pw->batches) submit(bt, ws);
     }
+    while (!inflight.empty()) retire_front();
     finish_writer();
     } catch (...) {  // the background stages reference this frame: let them finish before it unwinds
+        for (auto& f : inflight)
+            if (f.scored.valid()) f.scored.wait();
+        for (auto& f : dev_last)
+            if (f.valid()) f.wait();
         if (writer.valid()) writer.wait();
         if (next.valid()) next.wait();
         throw;
@@ -508,6 +549,12 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     return st;
 }
 
+inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_path, const BuildTracksParams& prm, ScoringBackend& backend,
+                                     bool append = false)
+{
+    return build_tracks(model, maf_path, prm, std::vector<ScoringBackend*>{&backend}, append);
+}
+
 struct ScoreMsaParams {
     std::string output_dir;  // empty: <maf>.scores next to the alignment
     int strategy = ALGO_MLE;
@@ -517,8 +564,10 @@ struct ScoreMsaParams {
     std::string version_line = "# PhyloCSF scores computed with phylocsf-amd (MI355X)";
 };
 
-inline std::string score_msa(const Model& model, const std::string& maf_path, const ScoreMsaParams& prm, ScoringBackend& backend)
+inline std::string score_msa(const Model& model, const std::string& maf_path, const ScoreMsaParams& prm, const std::vector<ScoringBackend*>& backends)
 {
+    if (backends.empty()) throw std::runtime_error("score_msa: no scoring backend");
+    ScoringBackend& backend = *backends[0];
     std::string out_path = prm.output_dir.empty() ? maf_path + ".scores" : prm.output_dir + "/" + maf_path.substr(maf_path.find_last_of('/') == std::string::npos ? 0 : maf_path.find_last_of('/') + 1) + ".scores";
     FILE* out = open_out(out_path, "w");
     fprintf(out, "%s\n", prm.version_line.c_str());
@@ -566,8 +615,28 @@ inline std::string score_msa(const Model& model, const std::string& maf_path, co
             for (double q : post) sum += hmm_log_odds(q);
             phylo[i] = sum / static_cast<uint64_t>(post.size());
         }
-    } else if ((prm.comp_phylo || prm.comp_anc) && !rows.empty())
-        backend.score_blocks(prm.strategy, codons.data(), offsets.data(), rows.size(), stride, prm.comp_anc, 42u, phylo.data(), anc.data());
+    } else if ((prm.comp_phylo || prm.comp_anc) && !rows.empty()) {
+        // blocks are independent: contiguous ranges with about equal site counts (+ a constant per block for its branch
+        // matrices) go to the backends, one thread each; CSR offsets are absolute, so every backend sees the same matrix
+        const size_t n_dev = std::min(backends.size(), rows.size());
+        std::vector<size_t> cut(n_dev + 1, rows.size());
+        cut[0] = 0;
+        const double total_cost = static_cast<double>(total) + 16.0 * static_cast<double>(rows.size());
+        size_t b = 0;
+        double acc_cost = 0.0;
+        for (size_t d = 1; d < n_dev; ++d) {
+            while (b < rows.size() && acc_cost < total_cost * static_cast<double>(d) / static_cast<double>(n_dev)) {
+                acc_cost += static_cast<double>(offsets[b + 1] - offsets[b]) + 16.0;
+                ++b;
+            }
+            cut[d] = b;
+        }
+        parallel_for(n_dev, static_cast<int>(n_dev), [&](size_t d) {
+            const size_t b0 = cut[d], b1 = cut[d + 1];
+            if (b1 > b0)
+                backends[d]->score_blocks(prm.strategy, codons.data(), offsets.data() + b0, b1 - b0, stride, prm.comp_anc, 42u, phylo.data() + b0, anc.data() + b0);
+        });
+    }
     for (size_t i = 0; i < rows.size(); ++i) {
         const Row& r = rows[i];
         fprintf(out, "%s\t%" PRIu64 "\t%" PRIu64 "\t%c", r.chrom.c_str(), r.start, r.end, r.strand);
@@ -578,6 +647,11 @@ inline std::string score_msa(const Model& model, const std::string& maf_path, co
     }
     fclose(out);
     return out_path;
+}
+
+inline std::string score_msa(const Model& model, const std::string& maf_path, const ScoreMsaParams& prm, ScoringBackend& backend)
+{
+    return score_msa(model, maf_path, prm, std::vector<ScoringBackend*>{&backend});
 }
 
 }  // namespace pcsf_host

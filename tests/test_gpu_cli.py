@@ -146,3 +146,23 @@ def test_synthetic_maf_across_the_break_point_matches_oracle_driver(tmp_path):
             assert got == want, n
         else:  # smoothed: the raw text is identical, so the HMM input is, and so is its output
             assert got == want, n
+
+
+def test_two_scoring_contexts_give_the_same_files(tmp_path):
+    """--devices 0,0: two contexts (two host threads, two streams) share the batches of build-tracks and the block ranges
+    of score-msa -- the multi-GPU code path of the driver, exercised on one GPU; outputs must not change."""
+    maf = tmp_path / "galGal6.maf"
+    with gzip.open(os.path.join(GOLD, "build-tracks", "galGal6_chr22_25_28_each_30k_bases.maf.gz"), "rb") as fi, open(maf, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    out = tmp_path / "out"
+    subprocess.check_call([_cli(), "build-tracks", "--output", str(out), "--devices", "0,0", "--batch-sites", "30000", "--window-bytes", "1000000",
+                           os.path.join(GOLD, "models", "53birds"), str(maf)])
+    for n in ["PhyloCSFpower"] + ["PhyloCSFRaw%s%d" % (s, f) for s in "+-" for f in (1, 2, 3)]:
+        assert open(out / (n + ".wig"), "rb").read() == gzip.open(os.path.join(GOLD, "build-tracks", n + ".wig.gz"), "rb").read(), n
+    res = []
+    for i, extra in enumerate(([], ["--devices", "0,0"])):
+        m = tmp_path / ("s%d.maf" % i)
+        shutil.copyfile(os.path.join(GOLD, "score-msa", "chr22.50alignments.maf"), m)
+        subprocess.check_call([_cli(), "score-msa", "--strategy", "omega"] + extra + [os.path.join(GOLD, "models", "100vertebrates"), str(m)])
+        res.append(_scores(str(m) + ".scores"))
+    assert res[0] == res[1] and len(res[0]) == 50

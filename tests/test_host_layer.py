@@ -230,3 +230,33 @@ def test_byte_range_jobs_do_not_change_the_alignments(cli, tmp_path):
 def test_fast_number_formatting_matches_printf(cli):
     out = subprocess.check_output([cli, "selftest-format", "600000"], text=True)
     assert out.strip().endswith("0 mismatches"), out
+
+
+def test_several_backends_small_batches_and_windows_do_not_change_the_output(cli, tmp_path):
+    """build-tracks with three scoring backends (--devices; one per GPU in production), batches of ~2,000 columns and
+    100 kB windows -- dozens of batches retired in order behind concurrent backends -- against the one-batch run; and
+    score-msa with its block list cut into three ranges."""
+    import gzip
+    import shutil
+    maf = tmp_path / "g.maf"
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "build-tracks", "galGal6_chr22_25_28_each_30k_bases.maf.gz"), "rt") as fi:
+        blocks = fi.read().split("\n\n")
+    maf.write_text("\n\n".join(blocks[:1500]) + "\n\n")
+    outs = []
+    for extra in ([], ["--devices", "0,0,0", "--batch-sites", "4000", "--window-bytes", "100000", "--threads", "3"]):
+        out = tmp_path / ("o%d" % len(outs))
+        subprocess.check_call([cli, "build-tracks", "--output", str(out)] + extra + [MODEL, str(maf)], stderr=subprocess.DEVNULL)
+        outs.append(out)
+    names = sorted(os.listdir(outs[0]))
+    assert len(names) == 7
+    for n in names:
+        assert open(outs[0] / n, "rb").read() == open(outs[1] / n, "rb").read(), n
+    src = os.path.join(ROOT, "tests", "golden", "score-msa", "chr22.50alignments.maf")
+    res = []
+    for i, extra in enumerate(([], ["--devices", "0,0,0"])):
+        m = tmp_path / ("s%d.maf" % i)
+        shutil.copyfile(src, m)
+        subprocess.check_call([cli, "score-msa", "--strategy", "mle", "--comp-anc", "1"] + extra +
+                              [os.path.join(ROOT, "tests", "golden", "models", "100vertebrates"), str(m)], stderr=subprocess.DEVNULL)
+        res.append(open(str(m) + ".scores").read().splitlines()[1:])
+    assert res[0] == res[1] and len(res[0]) == 51
