@@ -293,7 +293,7 @@ double pcsf_last_kernel_ms(const pcsf_ctx* c) { return c ? c->last_kernel_ms : -
 int pcsf_debug_stamps(pcsf_ctx* c, int block, unsigned long long* out, int cap)
 {
     if (!c) return PCSF_ERR_INVALID_ARG;
-    const size_t n = static_cast<size_t>(2) * c->schedule.program.size() * 8 + 1024 * 16;  // per-op stamps + residency census
+    const size_t n = 16;  // eight per-segment cycle sums and eight counts (kernels.hip, STAMP build)
     hipError_t e;
     if (!out) {  // arm
         if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
