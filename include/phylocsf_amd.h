@@ -139,6 +139,10 @@ int pcsf_debug_eigen_omega(pcsf_ctx *ctx, const double *q_settings, size_t n, do
  * timed; pcsf_set_timing(ctx,1) brackets each launch with HIP events ON THE LAUNCH STREAM. */
 int pcsf_set_timing(pcsf_ctx *ctx, int enable);
 double pcsf_last_kernel_ms(const pcsf_ctx *ctx);
+/* in-kernel cycle stamps of one work-group (needs the diagnostic kernel build, PCSF_PRUNE_VARIANT=2; tools/stamps.py):
+ * out == NULL arms the stamps for work-group `block` and returns the number of values; otherwise copies them out
+ * (eight per-segment cycle sums, then eight counts). */
+int pcsf_debug_stamps(pcsf_ctx *ctx, int block, unsigned long long *out, int cap);
 /* copies the branch matrices the context holds back to the host: [2][n_nodes-1][64][64],
  * row = parent state (for parity tests of the P(t) stage) */
 int pcsf_get_branch_matrices(pcsf_ctx *ctx, double *out);
