@@ -37,24 +37,19 @@ public:
         check(pcsf_score_blocks(ctx_, algo, codons, offsets, n_blocks, leaf_stride, compute_anc ? 1 : 0, seed, phylo, anc));
     }
 
-    void score_alignments_6frames(int, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0, const std::vector<uint32_t>& len,
-                                  const std::vector<uint64_t>& start_pos, const std::vector<uint64_t>& chrom_len, std::vector<double>& out,
-                                  std::vector<uint64_t>& offsets, std::vector<uint32_t>& n_codons) override
+    size_t score_alignments_6frames(int, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0, const std::vector<uint32_t>& len,
+                                    const std::vector<uint64_t>& start_pos, const std::vector<uint64_t>& chrom_len, double* out, size_t out_capacity,
+                                    std::vector<uint64_t>& offsets, std::vector<uint32_t>& n_codons) override
     {
         const size_t n = col0.size();
         std::vector<pcsf_alignment_desc> d(n);
-        size_t cap = 0;
-        for (size_t k = 0; k < n; ++k) {
-            d[k] = pcsf_alignment_desc{col0[k], len[k], start_pos[k], chrom_len[k]};
-            cap += 2 * static_cast<size_t>(len[k]);
-        }
-        out.resize(cap);
+        for (size_t k = 0; k < n; ++k) d[k] = pcsf_alignment_desc{col0[k], len[k], start_pos[k], chrom_len[k]};
         offsets.assign(n * 6, 0);
         n_codons.assign(n * 6, 0);
-        check(pcsf_score_alignments_6frames(ctx_, nucl, row_stride, d.data(), n, out.data(), cap, offsets.data(), n_codons.data(), nullptr));
+        check(pcsf_score_alignments_6frames(ctx_, nucl, row_stride, d.data(), n, out, out_capacity, offsets.data(), n_codons.data(), nullptr));
         size_t total = 0;
         for (size_t i = 0; i < n * 6; ++i) total += n_codons[i];
-        out.resize(total);
+        return total;
     }
 
     char* staging_alloc(size_t bytes) override

@@ -252,7 +252,7 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
                 const BuildTracksStats st = build_tracks(model, argv[i], bt, backends, !first);
                 fprintf(stderr, "%s: %zu alignments, %zu reference bases, %zu codon-frames, %zu backend calls\n", argv[i], st.alignments,
                         st.ref_bases, st.codon_frames, st.backend_calls);
-                fprintf(stderr, "  seconds: total %.3f = MAF read %.3f + BLS %.3f + batch packing %.3f + scoring backend %.3f + wig output %.3f + smoothing %.3f\n",
+                fprintf(stderr, "  seconds: total %.3f; busy per stage (the stages overlap): MAF read %.3f, BLS %.3f, batch packing %.3f | scoring backend %.3f | wig output %.3f | smoothing %.3f\n",
                         st.total_seconds, st.read_seconds, st.bls_seconds, st.extract_seconds, st.backend_seconds, st.write_seconds, st.smooth_seconds);
             } else {
                 const std::string out = score_msa(model, argv[i], sm, backends);

@@ -54,10 +54,12 @@ struct ScoringBackend {
     // [col0[k], col0[k]+len[k]); frame f of alignment k gets n_codons[6k+f] scores at out[offsets[6k+f]...] in FORWARD
     // genome order.  Default: translate on the host and call score_sites_fixed (what the CPU oracle backend uses);
     // the HIP backend overrides it with the device front end.
-    virtual void score_alignments_6frames(int n_leaves, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0,
-                                          const std::vector<uint32_t>& len, const std::vector<uint64_t>& start_pos,
-                                          const std::vector<uint64_t>& chrom_len, std::vector<double>& out, std::vector<uint64_t>& offsets,
-                                          std::vector<uint32_t>& n_codons)
+    // `out` has room for out_capacity values (2 per column is always enough) and, like `nucl`, preferably comes from
+    // staging_alloc; returns the number of values written.
+    virtual size_t score_alignments_6frames(int n_leaves, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0,
+                                            const std::vector<uint32_t>& len, const std::vector<uint64_t>& start_pos,
+                                            const std::vector<uint64_t>& chrom_len, double* out, size_t out_capacity, std::vector<uint64_t>& offsets,
+                                            std::vector<uint32_t>& n_codons)
     {
         const size_t n = col0.size();
         offsets.assign(n * 6, 0);
@@ -70,8 +72,8 @@ struct ScoringBackend {
                 n_codons[k * 6 + f] = static_cast<uint32_t>(v.n_codons);
                 total += v.n_codons;
             }
-        out.assign(total, 0.0);
-        if (total == 0) return;
+        if (total > out_capacity) throw std::runtime_error("score_alignments_6frames: output buffer too small");
+        if (total == 0) return 0;
         std::vector<uint8_t> codons(static_cast<size_t>(n_leaves) * total);
         std::vector<std::string> rows(n_leaves);
         for (size_t k = 0; k < n; ++k) {
@@ -82,9 +84,10 @@ struct ScoringBackend {
                 extract_codons(rows, v.skip, v.n_codons, codons.data(), total, offsets[k * 6 + f]);
             }
         }
-        score_sites_fixed(codons.data(), total, total, out.data());
+        score_sites_fixed(codons.data(), total, total, out);
         for (size_t k = 0; k < n; ++k)  // '-' strand codons were scored right-to-left
-            for (int f = 3; f < 6; ++f) std::reverse(out.begin() + offsets[k * 6 + f], out.begin() + offsets[k * 6 + f] + n_codons[k * 6 + f]);
+            for (int f = 3; f < 6; ++f) std::reverse(out + offsets[k * 6 + f], out + offsets[k * 6 + f] + n_codons[k * 6 + f]);
+        return total;
     }
 };
 
@@ -301,12 +304,12 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         }
         out.flush();
     };
-    auto write_frame = [&](const std::vector<Item*>& items, const std::vector<double>& scores, const std::vector<uint64_t>& offsets, int fi) {
+    auto write_frame = [&](const std::vector<Item*>& items, const double* scores, const std::vector<uint64_t>& offsets, int fi) {
         WigSink out(f_raw[fi]);
         for (size_t k = 0; k < items.size(); ++k) {
             const Item& p = *items[k];
             const FrameView v = frame_view(p.start_pos, p.chrom_len, p.len, fi < 3 ? '+' : '-', static_cast<unsigned>(fi % 3 + 1));
-            const double* sc = scores.data() + offsets[k * 6 + fi];
+            const double* sc = scores + offsets[k * 6 + fi];
             int64_t prev = -4;
             size_t bpos = v.bls_offset;
             for (size_t xx = 0; xx < v.n_codons; ++xx, bpos += 3) {
@@ -352,14 +355,16 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             std::lock_guard<std::mutex> g(lock);
             free_list.push_back(f);
         }
-    } pool(backend);
+    } pool(backend), score_pool(backend);  // batch matrices; score vectors (different sizes: kept apart)
     struct Batch {  // alignments scored by one backend call, their nucleotides packed leaf-major
         std::vector<Item*> items;
         size_t stride = 0;
         std::pair<char*, size_t> nucl{nullptr, 0};  // [nl][stride], uninitialised outside the alignments' columns
         std::vector<uint64_t> col0, start_pos, chrom_len;
         std::vector<uint32_t> len;
-        std::vector<double> scores;        // filled by the backend
+        std::pair<char*, size_t> score_mem{nullptr, 0};  // page-locked, from the pool
+        const double* scores = nullptr;    // filled by the backend
+        size_t n_scores = 0;
         std::vector<uint64_t> offsets;
         std::vector<uint32_t> n_codons;
     };
@@ -368,11 +373,13 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         std::vector<Batch> batches;
         size_t submitted = 0;  // batches handed to stage 2
         double read = 0.0, bls = 0.0, pack = 0.0;  // thread-seconds in the reader / the branch-length score; wall seconds packing
+        double parse_wall = 0.0;                   // wall seconds of the parallel parse
     };
     // Stage 1 (runs one window ahead of the scoring): byte-range jobs parse the MAF and compute the branch-length
     // scores; then the alignments, in file order, are cut into batches and their rows copied into the batch matrix.
     auto prepare_window = [&](size_t w0) {
         std::unique_ptr<PreparedWindow> pw(new PreparedWindow);
+        StopWatch parse_clock;
         const size_t w1 = std::min(file.size(), w0 + window);
         const size_t n_jobs = std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(threads) * 4, (w1 - w0 + (1 << 16) - 1) >> 16));
         pw->jobs.resize(n_jobs);
@@ -400,6 +407,7 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             pw->read += job_read[j];
             pw->bls += job_bls[j];
         }
+        pw->parse_wall = parse_clock.lap();
         StopWatch pack;
         pw->batches.emplace_back();
         for (auto& job : pw->jobs)
@@ -462,7 +470,7 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         st.backend_seconds += f.scored.get();
         if (need_raw) {
             ++st.backend_calls;
-            st.codon_frames += f.bt->scores.size();
+            st.codon_frames += f.bt->n_scores;
         }
         finish_writer();  // files are appended in batch order
         writing = f;
@@ -475,7 +483,9 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
                     write_frame(batch->items, batch->scores, batch->offsets, static_cast<int>(t) - 1);
                 }
             });
-            std::vector<double>().swap(batch->scores);
+            if (batch->score_mem.first) score_pool.put(batch->score_mem);
+            batch->score_mem = {nullptr, 0};
+            batch->scores = nullptr;
             return ww.lap();
         });
     };
@@ -486,8 +496,12 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             if (prev.valid()) prev.wait();
             StopWatch bw;
             if (need_raw) {
-                backends[d]->score_alignments_6frames(model.n_leaves, b->nucl.first, b->stride, b->col0, b->len, b->start_pos, b->chrom_len, b->scores,
-                                                      b->offsets, b->n_codons);
+                const size_t cap_scores = 2 * b->stride;  // six frames of len/3 codons each
+                b->score_mem = score_pool.get(cap_scores * sizeof(double));
+                double* out = reinterpret_cast<double*>(b->score_mem.first);
+                b->n_scores = backends[d]->score_alignments_6frames(model.n_leaves, b->nucl.first, b->stride, b->col0, b->len, b->start_pos, b->chrom_len,
+                                                                    out, cap_scores, b->offsets, b->n_codons);
+                b->scores = out;
                 pool.put(b->nucl);
                 b->nucl = {nullptr, 0};
             }
@@ -502,16 +516,13 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     if (file.size() > 0) next = std::async(std::launch::async, prepare_window, size_t(0));
     try {
     for (size_t w0 = 0; w0 < file.size(); w0 += window) {
-        sw.lap();
         std::unique_ptr<PreparedWindow> pw = next.get();
-        const double waited = sw.lap();  // only the time this thread actually stalled on stage 1 counts
         if (w0 + window < file.size()) next = std::async(std::launch::async, prepare_window, w0 + window);
-        {
+        {  // busy seconds of stage 1 (it runs concurrently with the other stages): the parallel parse split by thread time
             const double cpu = pw->read + pw->bls, tot = (cpu > 0 ? cpu : 1.0);
-            const double parse_share = waited > pw->pack ? waited - pw->pack : 0.0;
-            st.read_seconds += parse_share * pw->read / tot;
-            st.bls_seconds += parse_share * pw->bls / tot;
-            st.extract_seconds += std::min(waited, pw->pack);
+            st.read_seconds += pw->parse_wall * pw->read / tot;
+            st.bls_seconds += pw->parse_wall * pw->bls / tot;
+            st.extract_seconds += pw->pack;
         }
         for (auto& job : pw->jobs)
             for (const Item& it : job) {
