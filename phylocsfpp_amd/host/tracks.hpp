@@ -104,24 +104,51 @@ public:
         return walk(m_.n_nodes - 1, false);
     }
 
-    // per-base scores bl(S)/bl(all) (0 when fewer than two species have a base); returns the mean
+    // per-base scores bl(S)/bl(all) (0 when fewer than two species have a base); returns the mean.
+    // The species set of a column is a bit mask built row by row (sequential reads of each species' row, one table
+    // look-up per character); the tree is walked only when the mask differs from the previous column's.
     double per_base(const Alignment& aln, std::vector<double>* out)
     {
         const size_t L = aln.length();
-        std::vector<char> present(m_.n_leaves), last(m_.n_leaves, 2);
-        double last_val = 0.0, sum = 0.0;
-        if (out) out->clear();
-        for (size_t i = 0; i < L; ++i) {
-            int cnt = 0;
-            for (int l = 0; l < m_.n_leaves; ++l) {
-                present[l] = nucleotide_id(aln.seqs[l][i]) <= 3;
-                cnt += present[l];
+        const int nl = m_.n_leaves;
+        const size_t words = (static_cast<size_t>(nl) + 63) / 64;
+        masks_.assign(L * words, 0);
+        static const CharClass cls;
+        for (int l = 0; l < nl; ++l) {
+            const unsigned char* row = reinterpret_cast<const unsigned char*>(aln.seqs[l].data());
+            uint64_t* mw = masks_.data() + (l >> 6);
+            const uint64_t bit = uint64_t(1) << (l & 63);
+            unsigned bad = 0;
+            for (size_t i = 0; i < L; ++i) {
+                const unsigned c = cls.id[row[i]];
+                bad |= c;
+                if (c <= 3) mw[i * words] |= bit;
             }
+            if (bad & 8) {  // report the first offending character like nucleotide_id() does
+                for (size_t i = 0; i < L; ++i) nucleotide_id(static_cast<char>(row[i]));
+            }
+        }
+        std::vector<char> present(nl);
+        std::vector<uint64_t> last(words, ~uint64_t(0));
+        bool have_last = false;
+        double last_val = 0.0, sum = 0.0;
+        if (out) {
+            out->clear();
+            out->reserve(L);
+        }
+        for (size_t i = 0; i < L; ++i) {
+            const uint64_t* mk = masks_.data() + i * words;
+            int cnt = 0;
+            for (size_t w = 0; w < words; ++w) cnt += __builtin_popcountll(mk[w]);
             double v = 0.0;
             if (cnt >= 2) {
-                if (present != last) {
+                bool same = have_last;
+                for (size_t w = 0; w < words && same; ++w) same = mk[w] == last[w];
+                if (!same) {
+                    for (int l = 0; l < nl; ++l) present[l] = (mk[l >> 6] >> (l & 63)) & 1;
                     last_val = subtree_sum(present);
-                    last = present;
+                    for (size_t w = 0; w < words; ++w) last[w] = mk[w];
+                    have_last = true;
                 }
                 v = last_val;
                 sum += v;
@@ -132,6 +159,19 @@ public:
     }
 
 private:
+    struct CharClass {  // 0..3 = A C G T (either case), 4 = N n - . , 8 = not allowed in an alignment
+        unsigned char id[256];
+        CharClass()
+        {
+            for (int c = 0; c < 256; ++c) id[c] = 8;
+            id['A'] = id['a'] = 0;
+            id['C'] = id['c'] = 1;
+            id['G'] = id['g'] = 2;
+            id['T'] = id['t'] = 3;
+            id['N'] = id['n'] = id['-'] = id['.'] = 4;
+        }
+    };
+    std::vector<uint64_t> masks_;
     int overlap(int node) const { return prefix_[hi_[node]] - prefix_[lo_[node]]; }
     double walk(int node, bool below_lca) const
     {
