@@ -129,20 +129,20 @@ public:
                     continue;
                 }
                 SLine s = parse_s_line();
-                if (!first_block && block_ref == -1 && !((aln.start_pos - 1) + ref_bases == s.start && s.chrom == aln.chrom)) {
+                if (!first_block && block_ref == -1 && !((aln.start_pos - 1) + ref_bases == s.start && s.chrom_is(aln.chrom))) {
                     stop = true;  // not contiguous: this block starts the next alignment
                     break;
                 }
-                auto it = names_.find(s.species);
+                auto it = names_.find(*s.species_key);
                 if (it == names_.end()) {
-                    if (unknown_.insert(s.species).second && verbose_)
-                        fprintf(stderr, "WARNING: species %s in the alignment file is not part of the model\n", s.species.c_str());
+                    if (unknown_.insert(*s.species_key).second && verbose_)
+                        fprintf(stderr, "WARNING: species %s in the alignment file is not part of the model\n", s.species_key->c_str());
                     continue;
                 }
                 const int leaf = it->second;
                 if (first_block && ref_leaf == -1) {
                     aln.start_pos = s.start + 1;
-                    aln.chrom = s.chrom;
+                    aln.chrom = s.chrom_str();
                     aln.chrom_len = s.src_size;
                     aln.strand = s.strand;
                     ref_leaf = leaf;
@@ -161,7 +161,7 @@ public:
                         ref_bases_at_bp = ref_bases;
                     }
                     if (block_ref != ref_leaf)
-                        throw std::runtime_error("alignment block does not start with the reference species: " + s.species + "." + s.chrom);
+                        throw std::runtime_error("alignment block does not start with the reference species: " + s.species_str() + "." + s.chrom_str());
                     check_strand(s);
                 }
                 aln.seqs[leaf].append(s.text, s.text_len);
@@ -230,8 +230,13 @@ private:
         end_ = keep_end;
     }
 
-    struct SLine {
-        std::string species, chrom;
+    struct SLine {  // views into the mapped file, except `species` (lower-cased copy in a buffer that is reused)
+        const std::string* species_key = nullptr;
+        const char* chrom = nullptr;
+        size_t chrom_len = 0;
+        std::string species_str() const { return *species_key; }
+        std::string chrom_str() const { return std::string(chrom, chrom_len); }
+        bool chrom_is(const std::string& c) const { return c.size() == chrom_len && memcmp(c.data(), chrom, chrom_len) == 0; }
         uint64_t start = 0, size = 0, src_size = 0;
         char strand = '.';
         const char* text = nullptr;
@@ -265,15 +270,25 @@ private:
         }
         if (k < 7) throw std::runtime_error("malformed 's' line in MAF at byte " + std::to_string(pos_));
         SLine s;
-        std::string src(tok[1], len[1]);
-        const size_t dot = src.find('.');
-        if (dot == std::string::npos) throw std::runtime_error("MAF source '" + src + "' is not of the form species.chrom");
-        s.species = lower(src.substr(0, dot));
-        s.chrom = src.substr(dot + 1);
-        s.start = static_cast<uint64_t>(atoi(std::string(tok[2], len[2]).c_str()));
-        s.size = static_cast<uint64_t>(atoi(std::string(tok[3], len[3]).c_str()));
+        const char* dot = static_cast<const char*>(memchr(tok[1], '.', len[1]));
+        if (!dot) throw std::runtime_error("MAF source '" + std::string(tok[1], len[1]) + "' is not of the form species.chrom");
+        key_.assign(tok[1], static_cast<size_t>(dot - tok[1]));  // no allocation once the buffer has grown
+        for (char& c : key_) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+        s.species_key = &key_;
+        s.chrom = dot + 1;
+        s.chrom_len = len[1] - static_cast<size_t>(dot + 1 - tok[1]);
+        auto number = [](const char* p, size_t n) {  // atoi semantics for the plain non-negative integers of a MAF
+            uint64_t v = 0;
+            size_t i = 0;
+            bool neg = false;
+            if (i < n && (p[i] == '-' || p[i] == '+')) neg = p[i++] == '-';
+            for (; i < n && p[i] >= '0' && p[i] <= '9'; ++i) v = v * 10 + static_cast<uint64_t>(p[i] - '0');
+            return neg ? static_cast<uint64_t>(-static_cast<int64_t>(v)) : v;
+        };
+        s.start = number(tok[2], len[2]);
+        s.size = number(tok[3], len[3]);
         s.strand = tok[4][0];
-        s.src_size = static_cast<uint64_t>(atoi(std::string(tok[5], len[5]).c_str()));
+        s.src_size = number(tok[5], len[5]);
         s.text = tok[6];
         s.text_len = len[6];
         if (s.text_len && s.text[s.text_len - 1] == '\r') --s.text_len;
@@ -284,7 +299,7 @@ private:
     void check_strand(const SLine& s) const
     {
         if (concatenate_ && s.strand != '+')
-            throw std::runtime_error("reference sequence is not on the + strand (" + s.species + "." + s.chrom + " at " + std::to_string(s.start) + ")");
+            throw std::runtime_error("reference sequence is not on the + strand (" + s.species_str() + "." + s.chrom_str() + " at " + std::to_string(s.start) + ")");
     }
 
     const std::unordered_map<std::string, int>& names_;
@@ -294,6 +309,7 @@ private:
     const char* data_ = nullptr;
     size_t size_ = 0, pos_ = 0, end_ = 0;
     std::unordered_set<std::string> unknown_;
+    std::string key_;  // lower-cased species name of the line being parsed
     std::vector<uint32_t> keep_;
 };
 

@@ -8,6 +8,7 @@
 //   my_fprintf                                      src/common.hpp:48-68
 #pragma once
 
+#include <algorithm>
 #include <cinttypes>
 #include <cmath>
 #include <cstdint>
@@ -114,18 +115,22 @@ public:
         const size_t words = (static_cast<size_t>(nl) + 63) / 64;
         masks_.assign(L * words, 0);
         static const CharClass cls;
-        for (int l = 0; l < nl; ++l) {
-            const unsigned char* row = reinterpret_cast<const unsigned char*>(aln.seqs[l].data());
-            uint64_t* mw = masks_.data() + (l >> 6);
-            const uint64_t bit = uint64_t(1) << (l & 63);
-            unsigned bad = 0;
-            for (size_t i = 0; i < L; ++i) {
-                const unsigned c = cls.id[row[i]];
-                bad |= c;
-                if (c <= 3) mw[i * words] |= bit;
-            }
-            if (bad & 8) {  // report the first offending character like nucleotide_id() does
-                for (size_t i = 0; i < L; ++i) nucleotide_id(static_cast<char>(row[i]));
+        constexpr size_t CHUNK = 2048;  // columns per pass: the chunk's masks stay in L1 while every species' row streams by
+        for (size_t i0 = 0; i0 < L; i0 += CHUNK) {
+            const size_t i1 = std::min(L, i0 + CHUNK);
+            for (int l = 0; l < nl; ++l) {
+                const unsigned char* row = reinterpret_cast<const unsigned char*>(aln.seqs[l].data());
+                uint64_t* mw = masks_.data() + (l >> 6);
+                const uint64_t bit = uint64_t(1) << (l & 63);
+                unsigned bad = 0;
+                for (size_t i = i0; i < i1; ++i) {
+                    const unsigned c = cls.id[row[i]];
+                    bad |= c;
+                    mw[i * words] |= c <= 3 ? bit : 0;
+                }
+                if (bad & 8) {  // report the first offending character like nucleotide_id() does
+                    for (size_t i = i0; i < i1; ++i) nucleotide_id(static_cast<char>(row[i]));
+                }
             }
         }
         std::vector<char> present(nl);
