@@ -16,6 +16,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../csrc/frames.hpp"
@@ -92,6 +93,10 @@ public:
             if (i < m.n_leaves) { lo_[i] = i; hi_[i] = i + 1; }
             else { lo_[i] = lo_[m.child1[i]]; hi_[i] = hi_[m.child2[i]]; }
         }
+        words_ = (static_cast<size_t>(m.n_leaves) + 63) / 64;
+        range_.assign(static_cast<size_t>(m.n_nodes) * words_, 0);
+        for (int i = 0; i < m.n_nodes; ++i)
+            for (int l = lo_[i]; l < hi_[i]; ++l) range_[i * words_ + (l >> 6)] |= uint64_t(1) << (l & 63);
         std::vector<char> all(m.n_leaves, 1);
         total_ = subtree_sum(all);
     }
@@ -133,7 +138,6 @@ public:
                 }
             }
         }
-        std::vector<char> present(nl);
         std::vector<uint64_t> last(words, ~uint64_t(0));
         bool have_last = false;
         double last_val = 0.0, sum = 0.0;
@@ -150,8 +154,7 @@ public:
                 bool same = have_last;
                 for (size_t w = 0; w < words && same; ++w) same = mk[w] == last[w];
                 if (!same) {
-                    for (int l = 0; l < nl; ++l) present[l] = (mk[l >> 6] >> (l & 63)) & 1;
-                    last_val = subtree_sum(present);
+                    last_val = sum_for_mask(mk);
                     for (size_t w = 0; w < words; ++w) last[w] = mk[w];
                     have_last = true;
                 }
@@ -164,6 +167,51 @@ public:
     }
 
 private:
+    // bl(S) for a species set given as a bit mask: the same walk (own branch, left, right) with the overlaps taken
+    // from popcounts, and a memo of the sets seen so far (alignments repeat a small number of presence patterns)
+    int overlap_mask(int node, const uint64_t* mk) const
+    {
+        int c = 0;
+        for (size_t w = 0; w < words_; ++w) c += __builtin_popcountll(mk[w] & range_[static_cast<size_t>(node) * words_ + w]);
+        return c;
+    }
+    double walk_mask(int node, bool below_lca, const uint64_t* mk, int here) const
+    {
+        if (node < m_.n_leaves) return m_.branch_len_d[node];
+        const int l = m_.child1[node], r = m_.child2[node];
+        const int ol = overlap_mask(l, mk), orr = here - ol;
+        double bl = below_lca ? m_.branch_len_d[node] : 0.0;
+        if (ol > 0 && orr > 0) below_lca = true;
+        if (ol > 0) bl += walk_mask(l, below_lca, mk, ol);
+        if (orr > 0) bl += walk_mask(r, below_lca, mk, orr);
+        return bl;
+    }
+    double sum_for_mask(const uint64_t* mk)
+    {
+        if (words_ <= 2) {
+            const Key k{mk[0], words_ > 1 ? mk[1] : 0};
+            auto it = memo_.find(k);
+            if (it != memo_.end()) return it->second;
+            const double v = walk_mask(m_.n_nodes - 1, false, mk, overlap_mask(m_.n_nodes - 1, mk));
+            if (memo_.size() < (size_t(1) << 20)) memo_.emplace(k, v);
+            return v;
+        }
+        return walk_mask(m_.n_nodes - 1, false, mk, overlap_mask(m_.n_nodes - 1, mk));
+    }
+    struct Key {
+        uint64_t lo, hi;
+        bool operator==(const Key& o) const { return lo == o.lo && hi == o.hi; }
+    };
+    struct KeyHash {
+        size_t operator()(const Key& k) const
+        {
+            uint64_t x = k.lo * 0x9e3779b97f4a7c15ull ^ (k.hi + 0x7f4a7c159e3779b9ull) * 0xc2b2ae3d27d4eb4full;
+            return static_cast<size_t>(x ^ (x >> 29));
+        }
+    };
+    std::unordered_map<Key, double, KeyHash> memo_;
+    size_t words_ = 1;
+    std::vector<uint64_t> range_;  // [node][words_] leaves below the node
     struct CharClass {  // 0..3 = A C G T (either case), 4 = N n - . , 8 = not allowed in an alignment
         unsigned char id[256];
         CharClass()
