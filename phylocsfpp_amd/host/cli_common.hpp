@@ -71,7 +71,9 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
             check(v);
         }
         printf("%zu values checked, %zu mismatches\n", n + sizeof edge / sizeof edge[0], bad);
-        return bad ? 1 : 0;
+        const size_t bad_rows = BranchLengthScore::selftest_presence_bits(20000);
+        printf("20000 character rows classified, %zu mismatches between the vector and the scalar path\n", bad_rows);
+        return (bad || bad_rows) ? 1 : 0;
     }
     if (cmd == "dump-alignments") {  // diagnostics/tests: what the MAF reader yields (build-tracks semantics unless --blocks 1)
         bool blocks = false;

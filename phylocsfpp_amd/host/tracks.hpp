@@ -10,6 +10,9 @@
 
 #include <algorithm>
 #include <cinttypes>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -102,6 +105,28 @@ public:
     }
     double total() const { return total_; }
 
+    // tests: the vector and the scalar character classifiers agree on n random rows (returns the number of mismatches)
+    static size_t selftest_presence_bits(size_t n_rows)
+    {
+        size_t bad = 0;
+        uint64_t state = 0x2545f4914f6cdd1dull;
+        const char alphabet[] = "ACGTacgtNn-.ACGTacgt";
+        for (size_t r = 0; r < n_rows; ++r) {
+            state ^= state << 13; state ^= state >> 7; state ^= state << 17;
+            const size_t len = 1 + state % 300;
+            std::vector<unsigned char> row(len);
+            for (size_t i = 0; i < len; ++i) {
+                state ^= state << 13; state ^= state >> 7; state ^= state << 17;
+                row[i] = static_cast<unsigned char>(alphabet[state % 20]);
+            }
+            if (r % 7 == 0) row[state % len] = static_cast<unsigned char>("XRY*@m "[state % 7]);  // not allowed
+            std::vector<uint64_t> a((len + 63) / 64, 0), b((len + 63) / 64, 0);
+            const bool oka = presence_bits(row.data(), len, a.data()), okb = presence_bits_scalar(row.data(), len, b.data());
+            if (oka != okb || a != b) ++bad;
+        }
+        return bad;
+    }
+
     // present[leaf] != 0 for members of S; requires |S| >= 1
     double subtree_sum(const std::vector<char>& present)
     {
@@ -120,22 +145,25 @@ public:
         const size_t words = (static_cast<size_t>(nl) + 63) / 64;
         masks_.assign(L * words, 0);
         static const CharClass cls;
-        constexpr size_t CHUNK = 2048;  // columns per pass: the chunk's masks stay in L1 while every species' row streams by
-        for (size_t i0 = 0; i0 < L; i0 += CHUNK) {
-            const size_t i1 = std::min(L, i0 + CHUNK);
-            for (int l = 0; l < nl; ++l) {
-                const unsigned char* row = reinterpret_cast<const unsigned char*>(aln.seqs[l].data());
-                uint64_t* mw = masks_.data() + (l >> 6);
-                const uint64_t bit = uint64_t(1) << (l & 63);
-                unsigned bad = 0;
-                for (size_t i = i0; i < i1; ++i) {
-                    const unsigned c = cls.id[row[i]];
-                    bad |= c;
-                    mw[i * words] |= c <= 3 ? bit : 0;
+        // (1) per species, one presence bit per column (64 columns per word): 32 characters per step with AVX2
+        const size_t col_words = (L + 63) / 64;
+        bits_.assign(static_cast<size_t>(nl) * col_words, 0);
+        for (int l = 0; l < nl; ++l) {
+            const unsigned char* row = reinterpret_cast<const unsigned char*>(aln.seqs[l].data());
+            if (!presence_bits(row, L, bits_.data() + static_cast<size_t>(l) * col_words))
+                for (size_t i = 0; i < L; ++i) nucleotide_id(static_cast<char>(row[i]));  // throws at the first offending character
+        }
+        // (2) 64 x 64 bit transposes turn 64 species words into 64 column masks
+        for (size_t cw = 0; cw < col_words; ++cw) {
+            for (size_t w = 0; w < words; ++w) {
+                uint64_t blk[64];
+                for (int r = 0; r < 64; ++r) {
+                    const size_t l = w * 64 + static_cast<size_t>(r);
+                    blk[r] = l < static_cast<size_t>(nl) ? bits_[l * col_words + cw] : 0;
                 }
-                if (bad & 8) {  // report the first offending character like nucleotide_id() does
-                    for (size_t i = i0; i < i1; ++i) nucleotide_id(static_cast<char>(row[i]));
-                }
+                transpose64(blk);
+                const size_t n_cols = std::min<size_t>(64, L - cw * 64);
+                for (size_t c = 0; c < n_cols; ++c) masks_[(cw * 64 + c) * words + w] = blk[c];
             }
         }
         std::vector<uint64_t> last(words, ~uint64_t(0));
@@ -224,7 +252,71 @@ private:
             id['N'] = id['n'] = id['-'] = id['.'] = 4;
         }
     };
-    std::vector<uint64_t> masks_;
+    std::vector<uint64_t> masks_, bits_;
+
+    // out bit i = row[i] is one of ACGTacgt; returns false if a character outside ACGTNacgtn-. occurs
+    static bool presence_bits_scalar(const unsigned char* row, size_t n, uint64_t* out)
+    {
+        static const CharClass cls;
+        unsigned bad = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const unsigned c = cls.id[row[i]];
+            bad |= c;
+            if (c <= 3) out[i >> 6] |= uint64_t(1) << (i & 63);
+        }
+        return !(bad & 8);
+    }
+#if defined(__x86_64__)
+    __attribute__((target("avx2"))) static bool presence_bits_avx2(const unsigned char* row, size_t n, uint64_t* out)
+    {
+        const __m256i up = _mm256_set1_epi8(static_cast<char>(0xDF));
+        const __m256i cA = _mm256_set1_epi8('A'), cC = _mm256_set1_epi8('C'), cG = _mm256_set1_epi8('G'), cT = _mm256_set1_epi8('T');
+        const __m256i cN = _mm256_set1_epi8('N'), cDash = _mm256_set1_epi8('-'), cDot = _mm256_set1_epi8('.');
+        uint32_t all_ok = 0xffffffffu;
+        size_t i = 0;
+        for (; i + 32 <= n; i += 32) {
+            const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(row + i));
+            const __m256i u = _mm256_and_si256(x, up);  // letters to upper case (other characters change, they are tested on x)
+            const __m256i acgt = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(u, cA), _mm256_cmpeq_epi8(u, cC)),
+                                                 _mm256_or_si256(_mm256_cmpeq_epi8(u, cG), _mm256_cmpeq_epi8(u, cT)));
+            const __m256i other = _mm256_or_si256(_mm256_cmpeq_epi8(u, cN), _mm256_or_si256(_mm256_cmpeq_epi8(x, cDash), _mm256_cmpeq_epi8(x, cDot)));
+            const uint32_t m = static_cast<uint32_t>(_mm256_movemask_epi8(acgt));
+            all_ok &= m | static_cast<uint32_t>(_mm256_movemask_epi8(other));
+            out[i >> 6] |= static_cast<uint64_t>(m) << (i & 63);
+        }
+        bool ok = all_ok == 0xffffffffu;
+        if (i < n) {  // tail; bit positions continue at i
+            static const CharClass cls;
+            unsigned bad = 0;
+            for (; i < n; ++i) {
+                const unsigned c = cls.id[row[i]];
+                bad |= c;
+                if (c <= 3) out[i >> 6] |= uint64_t(1) << (i & 63);
+            }
+            ok = ok && !(bad & 8);
+        }
+        return ok;
+    }
+#endif
+    static bool presence_bits(const unsigned char* row, size_t n, uint64_t* out)
+    {
+#if defined(__x86_64__)
+        static const bool avx2 = __builtin_cpu_supports("avx2");
+        if (avx2) return presence_bits_avx2(row, n, out);
+#endif
+        return presence_bits_scalar(row, n, out);
+    }
+    // in-place transpose of a 64 x 64 bit matrix (row r = a[r], column c = bit c): six butterfly stages
+    static void transpose64(uint64_t a[64])
+    {
+        uint64_t m = 0x00000000ffffffffull;
+        for (int j = 32; j != 0; j >>= 1, m ^= m << j)
+            for (int k = 0; k < 64; k = (k + j + 1) & ~j) {
+                const uint64_t t = ((a[k] >> j) ^ a[k + j]) & m;
+                a[k] ^= t << j;
+                a[k + j] ^= t;
+            }
+    }
     int overlap(int node) const { return prefix_[hi_[node]] - prefix_[lo_[node]]; }
     double walk(int node, bool below_lca) const
     {
