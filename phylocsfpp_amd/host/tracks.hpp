@@ -216,28 +216,24 @@ private:
     }
     double sum_for_mask(const uint64_t* mk)
     {
-        if (words_ <= 2) {
-            const Key k{mk[0], words_ > 1 ? mk[1] : 0};
-            auto it = memo_.find(k);
-            if (it != memo_.end()) return it->second;
-            const double v = walk_mask(m_.n_nodes - 1, false, mk, overlap_mask(m_.n_nodes - 1, mk));
-            if (memo_.size() < (size_t(1) << 20)) memo_.emplace(k, v);
-            return v;
-        }
-        return walk_mask(m_.n_nodes - 1, false, mk, overlap_mask(m_.n_nodes - 1, mk));
+        if (words_ > 2) return walk_mask(m_.n_nodes - 1, false, mk, overlap_mask(m_.n_nodes - 1, mk));
+        const uint64_t lo = mk[0], hi = words_ > 1 ? mk[1] : 0;
+        uint64_t x = lo * 0x9e3779b97f4a7c15ull ^ (hi + 0x7f4a7c159e3779b9ull) * 0xc2b2ae3d27d4eb4full;
+        x ^= x >> 29;
+        if (memo_.empty()) memo_.resize(MEMO_SLOTS);
+        MemoSlot& slot = memo_[x & (MEMO_SLOTS - 1)];  // direct-mapped: a set seen recently is found with one probe
+        if (slot.used && slot.lo == lo && slot.hi == hi) return slot.value;
+        const double v = walk_mask(m_.n_nodes - 1, false, mk, overlap_mask(m_.n_nodes - 1, mk));
+        slot = MemoSlot{lo, hi, v, true};
+        return v;
     }
-    struct Key {
-        uint64_t lo, hi;
-        bool operator==(const Key& o) const { return lo == o.lo && hi == o.hi; }
+    struct MemoSlot {
+        uint64_t lo = 0, hi = 0;
+        double value = 0.0;
+        bool used = false;
     };
-    struct KeyHash {
-        size_t operator()(const Key& k) const
-        {
-            uint64_t x = k.lo * 0x9e3779b97f4a7c15ull ^ (k.hi + 0x7f4a7c159e3779b9ull) * 0xc2b2ae3d27d4eb4full;
-            return static_cast<size_t>(x ^ (x >> 29));
-        }
-    };
-    std::unordered_map<Key, double, KeyHash> memo_;
+    static constexpr size_t MEMO_SLOTS = 1 << 13;
+    std::vector<MemoSlot> memo_;
     size_t words_ = 1;
     std::vector<uint64_t> range_;  // [node][words_] leaves below the node
     struct CharClass {  // 0..3 = A C G T (either case), 4 = N n - . , 8 = not allowed in an alignment
