@@ -15,8 +15,7 @@ CLI = os.path.join(ROOT, "phylocsfpp_amd", "host", "phylocsf-amd")
 
 
 def _cli():
-    if not os.path.exists(CLI):
-        subprocess.check_call(["make", "-s", "-C", os.path.dirname(CLI)])
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(CLI)])   # no-op when the driver is up to date
     return CLI
 
 
