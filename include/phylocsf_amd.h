@@ -132,9 +132,10 @@ int pcsf_block_loglik(pcsf_ctx *ctx, int model, const double *q_settings, const 
 /* eigen-systems of n kappa/omega F3x4 rate matrices (q_settings[n][12]) from the device solver that OMEGA uses at
  * every kappa evaluation (replaces gsl_eigen_nonsymmv + complex LU of src/instance.hpp:309-434):
  * right[n][64][64] (eigenvectors in columns), left[n][64][64] (= right^-1, in rows), lambda[n][64],
- * prior[n][64] (equilibrium, sums to 1), failed[n] = 1 where a codon frequency is not positive. */
-int pcsf_debug_eigen_omega(pcsf_ctx *ctx, const double *q_settings, size_t n, double *right, double *left,
-                           double *lambda, double *prior, int32_t *failed);
+ * prior[n][64] (equilibrium, sums to 1), failed[n] = 1 where a codon frequency is not positive.
+ * warm_settings (may be NULL): [n][12] settings whose eigenbasis the iteration starts from, as OMEGA does for its probes. */
+int pcsf_debug_eigen_omega(pcsf_ctx *ctx, const double *q_settings, const double *warm_settings, size_t n, double *right,
+                           double *left, double *lambda, double *prior, int32_t *failed);
 /* milliseconds spent in the pruning kernel by the last *_fixed / *_fixed_dev call that was
  * timed; pcsf_set_timing(ctx,1) brackets each launch with HIP events ON THE LAUNCH STREAM. */
 int pcsf_set_timing(pcsf_ctx *ctx, int enable);

@@ -252,7 +252,7 @@ class ScoringContext:
     def last_kernel_ms(self):
         return self._lib.pcsf_last_kernel_ms(self._h)
 
-    def debug_eigen_omega(self, q_settings):
+    def debug_eigen_omega(self, q_settings, warm_settings=None):
         """Eigen-systems of kappa/omega rate matrices from the device solver: q_settings [n, 12] ->
         (right [n,64,64], left [n,64,64], lambda [n,64], prior [n,64], failed [n])."""
         qs = np.ascontiguousarray(np.asarray(q_settings, dtype=np.float64).reshape(-1, 12))
@@ -261,8 +261,10 @@ class ScoringContext:
         lam, prior = np.empty((n, 64)), np.empty((n, 64))
         failed = np.zeros(n, dtype=np.int32)
         dp = C.POINTER(C.c_double)
-        self._lib.pcsf_debug_eigen_omega.argtypes = [C.c_void_p, dp, C.c_size_t, dp, dp, dp, dp, C.POINTER(C.c_int32)]
-        self._check(self._lib.pcsf_debug_eigen_omega(self._h, qs.ctypes.data_as(dp), n, right.ctypes.data_as(dp), left.ctypes.data_as(dp),
+        ws = None if warm_settings is None else np.ascontiguousarray(np.asarray(warm_settings, dtype=np.float64).reshape(-1, 12))
+        self._lib.pcsf_debug_eigen_omega.argtypes = [C.c_void_p, dp, dp, C.c_size_t, dp, dp, dp, dp, C.POINTER(C.c_int32)]
+        self._check(self._lib.pcsf_debug_eigen_omega(self._h, qs.ctypes.data_as(dp), None if ws is None else ws.ctypes.data_as(dp), n,
+                                                     right.ctypes.data_as(dp), left.ctypes.data_as(dp),
                                                      lam.ctypes.data_as(dp), prior.ctypes.data_as(dp), failed.ctypes.data_as(C.POINTER(C.c_int32))))
         return right, left, lam, prior, failed
 

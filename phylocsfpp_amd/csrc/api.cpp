@@ -449,8 +449,8 @@ int pcsf_block_loglik(pcsf_ctx* c, int model, const double* q_settings, const do
 }
 
 // diagnostics/tests: the device eigen-solver of the kappa/omega rate matrix (eigen.hip)
-int pcsf_debug_eigen_omega(pcsf_ctx* c, const double* q_settings, size_t n, double* right, double* left, double* lambda, double* prior,
-                           int32_t* failed)
+int pcsf_debug_eigen_omega(pcsf_ctx* c, const double* q_settings, const double* warm_settings, size_t n, double* right, double* left,
+                           double* lambda, double* prior, int32_t* failed)
 {
     if (!c) return PCSF_ERR_INVALID_ARG;
     if (n == 0) return PCSF_OK;
@@ -458,7 +458,7 @@ int pcsf_debug_eigen_omega(pcsf_ctx* c, const double* q_settings, size_t n, doub
     hipError_t e;
     if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
     try {
-        return pcsf::debug_eigen_omega_impl(c, q_settings, n, right, left, lambda, prior, failed);
+        return pcsf::debug_eigen_omega_impl(c, q_settings, warm_settings, n, right, left, lambda, prior, failed);
     } catch (const std::exception& ex) {
         return c->fail(PCSF_ERR_HIP, std::string("pcsf_debug_eigen_omega: ") + ex.what());
     }

@@ -69,7 +69,7 @@ struct BlockEngine {
     int ne, nl, n;
     DeviceBuffer d_codons;                 // [nl][leaf_stride] compact copy
     DeviceBuffer d_frag, d_leaf, d_fail;   // table sets, one per evaluation of a run
-    DeviceBuffer d_eig_r, d_eig_l, d_eig_lam, d_prior, d_ancw;  // eigen-systems and their root priors
+    DeviceBuffer d_eig_r, d_eig_l, d_eig_lam, d_eig_basis, d_prior, d_ancw;  // eigen-systems and their root priors
     DeviceBuffer d_jobs, d_eig_jobs, d_wg0, d_wg1, d_wgt, d_wgp, d_wgo, d_lnz, d_anc;
     DeviceBuffer d_branch_slot, d_branch_len, d_leaf_codes;  // per-branch constants; per (block, leaf) row masks
     // Work of one run() is kept in two sets: evaluations whose eigen-system is rebuilt in this run (set 1: eigen ->
@@ -157,6 +157,7 @@ struct BlockEngine {
         HIP_TRY(d_eig_r.reserve(count * 4096 * sizeof(double)));
         HIP_TRY(d_eig_l.reserve(count * 4096 * sizeof(double)));
         HIP_TRY(d_eig_lam.reserve(count * 64 * sizeof(double)));
+        HIP_TRY(d_eig_basis.reserve(count * 4096 * sizeof(double)));
         HIP_TRY(d_prior.reserve(count * 64 * sizeof(double)));
         HIP_TRY(d_ancw.reserve(count * 64 * sizeof(double)));
         cap_eig = count;
@@ -181,7 +182,8 @@ struct BlockEngine {
     // queue one evaluation of block `blk` at tree scale x with eigen-system slot `eig`.  new_qs != null: slot
     // `eig` is (re)built first from these kappa/omega settings; after_eigen: the slot is rebuilt by ANOTHER
     // evaluation of this run, so this one has to run behind it.  Returns the evaluation's index in this run.
-    size_t queue(size_t blk, uint32_t eig, double x, const double* new_qs, bool after_eigen = false)
+    // warm >= 0: the rebuilt eigen-system starts its Jacobi iteration from the eigenbasis held in slot `warm`.
+    size_t queue(size_t blk, uint32_t eig, double x, const double* new_qs, bool after_eigen = false, int32_t warm = -1)
     {
         const uint32_t table = static_cast<uint32_t>(evals.size());
         if (table >= cap_tables) throw std::runtime_error("BlockEngine: more evaluations queued than table sets reserved");
@@ -190,6 +192,8 @@ struct BlockEngine {
             EigenJob j;
             j.eig = eig;
             j.table = table;
+            j.warm = warm;
+            j.pad = 0;
             for (int i = 0; i < 12; ++i) j.qs[i] = new_qs[i];
             eig_jobs.push_back(j);
         }
@@ -298,6 +302,7 @@ struct BlockEngine {
                 gp.eig_right = d_eig_r.as<double>();
                 gp.eig_left = d_eig_l.as<double>();
                 gp.eig_lambda = d_eig_lam.as<double>();
+                gp.eig_basis = d_eig_basis.as<double>();
                 gp.prior = d_prior.as<double>();
                 gp.anc_weight = d_ancw.as<double>();
                 gp.fail = d_fail.as<uint32_t>();
@@ -526,7 +531,8 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
             std::vector<std::pair<size_t, size_t>> queued;
             for (; at < which.size() && eng.free_evaluations() > 0; ++at) {
                 OmegaBlock& ob = *blk[which[at]];
-                queued.push_back({which[at], eng.queue(which[at], static_cast<uint32_t>(which[at]), ob.tree_scale, ob.q_settings)});
+                queued.push_back({which[at], eng.queue(which[at], static_cast<uint32_t>(which[at]), ob.tree_scale, ob.q_settings, false,
+                                                       ob.eig_valid ? static_cast<int32_t>(which[at]) : -1)});
                 std::memcpy(ob.eig_settings, ob.q_settings, sizeof ob.q_settings);
                 ob.eig_valid = true;
             }
@@ -666,7 +672,7 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
                 if ((ob.stage % 2) == 0) {  // rho: the block's own eigen-system, brought up to date if need be
                     const bool stale = !ob.eig_valid || std::memcmp(ob.eig_settings, ob.q_settings, sizeof ob.q_settings) != 0;
                     if (stale && !rebuilt[b]) {
-                        k = eng.queue(b, static_cast<uint32_t>(b), x, ob.q_settings);
+                        k = eng.queue(b, static_cast<uint32_t>(b), x, ob.q_settings, false, ob.eig_valid ? static_cast<int32_t>(b) : -1);
                         std::memcpy(ob.eig_settings, ob.q_settings, sizeof ob.q_settings);
                         ob.eig_valid = true;
                         rebuilt[b] = 1;
@@ -678,7 +684,8 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
                     double qs[12];
                     std::memcpy(qs, ob.q_settings, sizeof qs);
                     qs[0] = x;
-                    k = eng.queue(b, static_cast<uint32_t>(n_blocks + eng.evals.size()), ob.tree_scale, qs);
+                    k = eng.queue(b, static_cast<uint32_t>(n_blocks + eng.evals.size()), ob.tree_scale, qs, false,
+                                  (ob.eig_valid && !rebuilt[b]) ? static_cast<int32_t>(b) : -1);
                     ++eig_evals;
                 }
                 pending.push_back({b, k, x});
@@ -738,33 +745,45 @@ int block_loglik_impl(pcsf_ctx* c, int model, const double* q_settings, const do
     return PCSF_OK;
 }
 
-// diagnostics/tests: eigen-systems of n kappa/omega rate matrices from the device solver
-int debug_eigen_omega_impl(pcsf_ctx* c, const double* q_settings, size_t n, double* right, double* left, double* lambda, double* prior,
-                           int32_t* failed)
+// diagnostics/tests: eigen-systems of n kappa/omega rate matrices from the device solver.  warm_settings != null: the
+// solver is first run (cold) on warm_settings[i], then on q_settings[i] starting from that eigenbasis -- the path OMEGA
+// takes for every kappa probe; the results returned are those of the second run.
+int debug_eigen_omega_impl(pcsf_ctx* c, const double* q_settings, const double* warm_settings, size_t n, double* right, double* left,
+                           double* lambda, double* prior, int32_t* failed)
 {
-    DeviceBuffer d_jobs, d_r, d_l, d_lam, d_prior, d_fail;
-    std::vector<EigenJob> jobs(n);
-    for (size_t i = 0; i < n; ++i) {
-        jobs[i].eig = jobs[i].table = static_cast<uint32_t>(i);
-        for (int k = 0; k < 12; ++k) jobs[i].qs[k] = q_settings[12 * i + k];
-    }
+    const size_t slots = warm_settings ? 2 * n : n;
+    DeviceBuffer d_jobs, d_r, d_l, d_lam, d_basis, d_prior, d_fail;
     HIP_TRY(d_jobs.reserve(n * sizeof(EigenJob)));
-    HIP_TRY(d_r.reserve(n * 4096 * 8));
-    HIP_TRY(d_l.reserve(n * 4096 * 8));
-    HIP_TRY(d_lam.reserve(n * 64 * 8));
-    HIP_TRY(d_prior.reserve(n * 64 * 8));
+    HIP_TRY(d_r.reserve(slots * 4096 * 8));
+    HIP_TRY(d_l.reserve(slots * 4096 * 8));
+    HIP_TRY(d_lam.reserve(slots * 64 * 8));
+    HIP_TRY(d_basis.reserve(slots * 4096 * 8));
+    HIP_TRY(d_prior.reserve(slots * 64 * 8));
     HIP_TRY(d_fail.reserve(n * 4));
     HIP_TRY(hipMemsetAsync(d_fail.ptr, 0, n * 4, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_jobs.ptr, jobs.data(), n * sizeof(EigenJob), hipMemcpyHostToDevice, c->stream));
     EigenParams gp{};
     gp.jobs = d_jobs.as<EigenJob>();
     gp.n_jobs = static_cast<uint32_t>(n);
     gp.eig_right = d_r.as<double>();
     gp.eig_left = d_l.as<double>();
     gp.eig_lambda = d_lam.as<double>();
+    gp.eig_basis = d_basis.as<double>();
     gp.prior_plain = d_prior.as<double>();  // state order; the lane-order copies are not wanted here
     gp.fail = d_fail.as<uint32_t>();
-    HIP_TRY(launch_eigen_omega(gp, c->stream));
+    std::vector<EigenJob> jobs(n);
+    for (int pass = warm_settings ? 0 : 1; pass < 2; ++pass) {
+        const double* qs = pass == 0 ? warm_settings : q_settings;
+        for (size_t i = 0; i < n; ++i) {
+            jobs[i].eig = static_cast<uint32_t>(pass == 0 ? n + i : i);
+            jobs[i].table = static_cast<uint32_t>(i);
+            jobs[i].warm = (pass == 1 && warm_settings) ? static_cast<int32_t>(n + i) : -1;
+            jobs[i].pad = 0;
+            for (int k = 0; k < 12; ++k) jobs[i].qs[k] = qs[12 * i + k];
+        }
+        HIP_TRY(hipMemcpyAsync(d_jobs.ptr, jobs.data(), n * sizeof(EigenJob), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(launch_eigen_omega(gp, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // `jobs` is rewritten for the second pass
+    }
     std::vector<uint32_t> f(n);
     HIP_TRY(hipMemcpyAsync(right, d_r.ptr, n * 4096 * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(left, d_l.ptr, n * 4096 * 8, hipMemcpyDeviceToHost, c->stream));

@@ -95,6 +95,6 @@ int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
                       size_t leaf_stride, int compute_anc, uint32_t seed, float* out_phylo, float* out_anc);
 int block_loglik_impl(pcsf_ctx* c, int model, const double* q_settings, const double* tree_scale, const uint8_t* codons,
                       const uint64_t* site_offsets, size_t n_blocks, size_t leaf_stride, double* out_lpr, int32_t* out_failed);
-int debug_eigen_omega_impl(pcsf_ctx* c, const double* q_settings, size_t n, double* right, double* left, double* lambda, double* prior,
-                           int32_t* failed);
+int debug_eigen_omega_impl(pcsf_ctx* c, const double* q_settings, const double* warm_settings, size_t n, double* right, double* left,
+                           double* lambda, double* prior, int32_t* failed);
 }  // namespace pcsf

@@ -91,6 +91,8 @@ hipError_t launch_expm(const ExpmParams& p, hipStream_t stream);
 struct EigenJob {
     uint32_t eig;      // destination eigen-system index
     uint32_t table;    // table set whose validation flag reports an invalid model (fail[table])
+    int32_t warm;      // >= 0: start the Jacobi iteration in the eigenbasis stored in slot `warm` (may equal eig); -1: cold
+    int32_t pad;
     double qs[12];     // kappa, omega, sigma, nine nucleotide-frequency ratios (src/run.hpp:75-79)
 };
 
@@ -100,6 +102,7 @@ struct EigenParams {
     double* eig_right;    // [n_eig][64*64]
     double* eig_left;     // [n_eig][64*64]
     double* eig_lambda;   // [n_eig][64]
+    double* eig_basis;    // [n_eig][64*64] orthogonal eigenvector matrix of the symmetrised rate matrix (warm starts; may be null)
     double* prior;        // [n_eig][64] equilibrium prior in lane order (may be null)
     double* anc_weight;   // [n_eig][64] ln(prior)*prior in lane order (may be null)
     double* prior_plain;  // optional [n_eig][64] prior in state order (diagnostics/tests)

@@ -172,6 +172,23 @@ def test_device_eigen_solver_of_the_omega_rate_matrix(gpu_contexts):
         np.testing.assert_allclose(np.sort(lam[i]), want, rtol=1e-11, atol=1e-14 * scale)
         np.testing.assert_allclose(prior[i], pi / pi.sum(), rtol=1e-11)
         assert abs(prior[i].sum() - 1.0) < 1e-14
+    # warm start (what every kappa probe of OMEGA does): the iteration begins in the eigenbasis of a neighbouring -- or,
+    # for random restarts and the H0 -> H1 switch, a distant -- matrix and must end at the same eigen-system
+    ws = qs[:96].copy()
+    ws[:48, 0] *= rng.uniform(0.97, 1.03, 48)              # kappa moved by a Brent step
+    ws[48:, 0] = rng.uniform(1.0, 10.0, 48)                # kappa anywhere
+    ws[80:, 1:3] = [1.0, 1.0]                              # and omega / sigma as under H0
+    ws[:, 0] = np.clip(ws[:, 0], 1.0, 10.0)
+    r2, l2, lam2, prior2, failed2 = ctx.debug_eigen_omega(qs[:96], warm_settings=ws)
+    assert not failed2.any()
+    for i in range(96):
+        Q, pi = np.empty((64, 64)), np.empty(64)
+        ob.lib().po_q_from_omega(np.ascontiguousarray(qs[i]).ctypes.data_as(dp), Q.ctypes.data_as(dp), pi.ctypes.data_as(dp))
+        scale = np.abs(Q).max()
+        assert np.abs((r2[i] * lam2[i]) @ l2[i] - Q).max() <= 2e-13 * scale
+        assert np.abs(l2[i] @ r2[i] - np.eye(64)).max() <= 1e-12
+        np.testing.assert_allclose(np.sort(lam2[i]), np.sort(lam[i]), rtol=1e-11, atol=1e-14 * scale)
+        np.testing.assert_allclose(prior2[i], prior[i], rtol=1e-11)
 
 
 def test_random_blocks_fixed_with_empty_and_ragged(oracle_models, gpu_contexts):
