@@ -107,6 +107,26 @@ int pcsf_score_alignments_6frames(pcsf_ctx *ctx, const char *nucleotides, size_t
                                   const pcsf_alignment_desc *alignments, size_t n_alignments, double *out_scores,
                                   size_t out_capacity, uint64_t *out_offsets, uint32_t *n_codons, uint32_t *skip_bases);
 
+/* ---- branch-length score (compute_bls_score, src/additional_scores.hpp:44-84) ---------------------
+ * Per alignment column: the branch lengths of the subtree spanned by the species that have one of
+ * ACGTacgt there (newick_sum_branch_lengths, src/additional_scores.hpp:5-41: own branch, then left, then
+ * right subtree, in double) over the same sum for all species; 0 when fewer than two species have a base.
+ * The reference works on newick_node's DOUBLE branch lengths (the likelihood uses the float ones), so they
+ * are handed over separately: branch_len[n_nodes] in the node order of pcsf_model_desc.  Up to 128 species.
+ * A character outside ACGTNacgtn-. fails the call ("unexpected character", the reference exits on it,
+ * src/translation.hpp:29-88). */
+int pcsf_set_bls_branch_lengths(pcsf_ctx *ctx, const double *branch_len);
+/* out_bls[n_columns] for the leaf-major rows nucleotides[n_leaves][row_stride] */
+int pcsf_branch_length_scores(pcsf_ctx *ctx, const char *nucleotides, size_t row_stride, size_t n_columns,
+                              double *out_bls);
+/* pcsf_score_alignments_6frames plus, from the same uploaded rows, out_bls[max(col_offset + len)]: the per-base
+ * branch-length scores build-tracks thresholds the codons with and writes to PhyloCSFpower.wig
+ * (src/phylocsf++build_tracks.hpp:139-158,201-205); columns outside every alignment get 0.  out_bls may be NULL. */
+int pcsf_score_alignments_6frames_bls(pcsf_ctx *ctx, const char *nucleotides, size_t row_stride,
+                                      const pcsf_alignment_desc *alignments, size_t n_alignments, double *out_scores,
+                                      size_t out_capacity, uint64_t *out_offsets, uint32_t *n_codons,
+                                      uint32_t *skip_bases, double *out_bls);
+
 /* ---- run (src/run.hpp:57-211): whole-block scores -----------------------------------------
  * A batch of blocks in CSR form: block b owns sites [site_offsets[b], site_offsets[b+1]) of the
  * leaf-major codon matrix.  algo FIXED / MLE / OMEGA; seed is what score-msa passes to

@@ -955,6 +955,63 @@ int po_run_blocks(const po_model *m, int algo, const uint8_t *codons, const uint
 }
 
 /* ------------------------------------------------------------------------------------------
+ * branch-length score (src/additional_scores.hpp:5-84) */
+static int po_overlap_size(const po_tree *t, int node, const unsigned char *in_set)
+{
+    if (node < t->nl) return in_set[node] ? 1 : 0;
+    return po_overlap_size(t, t->child1[node], in_set) + po_overlap_size(t, t->child2[node], in_set);
+}
+
+/* newick_sum_branch_lengths (src/additional_scores.hpp:5-41) */
+static double po_sum_branch_lengths(const po_tree *t, int node, const unsigned char *in_set, int arrived_at_lca, int overlap_parent)
+{
+    if (node < t->nl) return t->branch_len_d[node];
+    if (overlap_parent == -1) overlap_parent = po_overlap_size(t, node, in_set);
+    const int overlap_left = po_overlap_size(t, t->child1[node], in_set);
+    const int overlap_right = overlap_parent - overlap_left;
+    double bl = 0.0;
+    if (arrived_at_lca) bl = t->branch_len_d[node];
+    if (overlap_left > 0 && overlap_right > 0) arrived_at_lca = 1;
+    if (overlap_left > 0) bl += po_sum_branch_lengths(t, t->child1[node], in_set, arrived_at_lca, overlap_left);
+    if (overlap_right > 0) bl += po_sum_branch_lengths(t, t->child2[node], in_set, arrived_at_lca, overlap_right);
+    return bl;
+}
+
+/* compute_bls_score (src/additional_scores.hpp:44-84) */
+double po_bls(const po_tree *t, const char *nucl, size_t row_stride, size_t n_cols, double *per_base)
+{
+    unsigned char in_set[PO_MAX_NODES];
+    for (int l = 0; l < t->nl; ++l) in_set[l] = 1;
+    const double all = po_sum_branch_lengths(t, t->n - 1, in_set, 0, -1);
+    double total = 0.0;
+    for (size_t i = 0; i < n_cols; ++i) {
+        int cnt = 0;
+        for (int l = 0; l < t->nl; ++l) {
+            const char ch = nucl[(size_t)l * row_stride + i];
+            int id;
+            switch (ch) { /* get_dna_id, src/translation.hpp:29-88 */
+                case 'A': case 'a': id = 0; break;
+                case 'C': case 'c': id = 1; break;
+                case 'G': case 'g': id = 2; break;
+                case 'T': case 't': id = 3; break;
+                case 'N': case 'n': case '-': case '.': id = 4; break;
+                default: return -1.0;
+            }
+            in_set[l] = id <= 3;
+            cnt += id <= 3;
+        }
+        if (cnt >= 2) {
+            const double bl = po_sum_branch_lengths(t, t->n - 1, in_set, 0, -1);
+            total += bl;
+            if (per_base) per_base[i] = bl / all;
+        } else if (per_base) {
+            per_base[i] = 0.0;
+        }
+    }
+    return total / (all * (double)n_cols);
+}
+
+/* ------------------------------------------------------------------------------------------
  * reference-structured CPU baseline for bench.py
  * ---------------------------------------------------------------------------------------- */
 int po_baseline_run_tracks(const po_model *m, const uint8_t *codons, const uint64_t *off, size_t n_aln,

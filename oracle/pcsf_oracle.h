@@ -120,6 +120,13 @@ double po_uniform_real(po_mt19937 *g, double a, double b); /* libstdc++ uniform_
 double po_lpr_rho(double rho);     /* src/omega.hpp:130-141 */
 double po_lpr_kappa(double kappa); /* src/omega.hpp:143-149 */
 
+/* --- branch-length score (src/additional_scores.hpp:5-84) ---
+ * compute_bls_score<true>: per column of the leaf-major ASCII rows nucl[nl][row_stride], S = the species with
+ * one of ACGTacgt; per_base[col] = bl(S) / bl(all species), 0 when |S| < 2 (per_base may be NULL); returns the
+ * block score sum bl(S) / (bl(all) * n_cols).  bl is newick_sum_branch_lengths, as a recursion over the
+ * flattened tree with the reference's order of additions.  -1.0 on a character outside ACGTNacgtn-. */
+double po_bls(const po_tree *t, const char *nucl, size_t row_stride, size_t n_cols, double *per_base);
+
 /* reference-structured CPU baseline used by bench.py (cpu_baseline.kind = "port"):
  * scores n_aln independent alignments exactly like the OpenMP loop of build-tracks does --
  * the model is re-instantiated for every alignment x model (src/run.hpp:38-49,

@@ -72,6 +72,9 @@ def load_library():
                                       C.c_uint32, fp, fp]
     lib.pcsf_score_alignments_6frames.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(_AlignmentDesc), C.c_size_t, dp, C.c_size_t,
                                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.pcsf_score_alignments_6frames_bls.argtypes = lib.pcsf_score_alignments_6frames.argtypes + [dp]
+    lib.pcsf_set_bls_branch_lengths.argtypes = [vp, dp]
+    lib.pcsf_branch_length_scores.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_size_t, dp]
     lib.pcsf_block_loglik.argtypes = [vp, C.c_int, dp, dp, u8p, C.POINTER(C.c_uint64), C.c_size_t, C.c_size_t, dp,
                                       C.POINTER(C.c_int32)]
     lib.pcsf_set_timing.argtypes = [vp, C.c_int]
@@ -192,11 +195,27 @@ class ScoringContext:
                                       lnz.data_ptr() if lnz is not None else 0, stream)
         return out
 
-    def score_alignments_6frames(self, nucleotides, alignments):
+    # ---- branch-length score ----------------------------------------------------------------
+    def set_bls_branch_lengths(self, branch_len):
+        """Double-precision branch lengths [n_nodes] for the branch-length score (the reference's newick_node)."""
+        bl = np.ascontiguousarray(branch_len, dtype=np.float64)
+        self._check(self._lib.pcsf_set_bls_branch_lengths(self._h, bl.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def branch_length_scores(self, nucleotides):
+        """compute_bls_score per column of the ASCII rows nucleotides[n_leaves, n_cols] -> float64[n_cols]."""
+        nuc = np.ascontiguousarray(nucleotides, dtype=np.uint8)
+        assert nuc.ndim == 2 and nuc.shape[0] == self.n_leaves
+        out = np.empty(nuc.shape[1], dtype=np.float64)
+        self._check(self._lib.pcsf_branch_length_scores(self._h, nuc.ctypes.data_as(C.c_char_p), nuc.strides[0], nuc.shape[1],
+                                                        out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def score_alignments_6frames(self, nucleotides, alignments, with_bls=False):
         """Six-frame front end (device translation + run_tracks).  nucleotides: uint8/bytes ndarray
         [n_leaves, n_cols] of ASCII rows (reference gaps removed); alignments: list of
         (col_offset, len, start_pos, chrom_len).  Returns a list (per alignment) of 6 float64 arrays in
-        forward genome order (+1,+2,+3,-1,-2,-3) and the skip_bases array [n, 6]."""
+        forward genome order (+1,+2,+3,-1,-2,-3) and the skip_bases array [n, 6]; with_bls adds the per-column
+        branch-length scores float64[n_cols] as a third value."""
         nuc = np.ascontiguousarray(nucleotides, dtype=np.uint8)
         assert nuc.ndim == 2 and nuc.shape[0] == self.n_leaves
         n = len(alignments)
@@ -206,11 +225,14 @@ class ScoringContext:
         offs = np.zeros(n * 6, dtype=np.uint64)
         ncod = np.zeros(n * 6, dtype=np.uint32)
         skip = np.zeros(n * 6, dtype=np.uint32)
-        self._check(self._lib.pcsf_score_alignments_6frames(
+        bls = np.zeros(nuc.shape[1], dtype=np.float64) if with_bls else None
+        self._check(self._lib.pcsf_score_alignments_6frames_bls(
             self._h, nuc.ctypes.data_as(C.c_char_p), nuc.strides[0], desc, n, out.ctypes.data_as(C.POINTER(C.c_double)), cap,
             offs.ctypes.data_as(C.POINTER(C.c_uint64)), ncod.ctypes.data_as(C.POINTER(C.c_uint32)),
-            skip.ctypes.data_as(C.POINTER(C.c_uint32))))
+            skip.ctypes.data_as(C.POINTER(C.c_uint32)), bls.ctypes.data_as(C.POINTER(C.c_double)) if with_bls else None))
         res = [[out[int(offs[k * 6 + f]):int(offs[k * 6 + f]) + int(ncod[k * 6 + f])].copy() for f in range(6)] for k in range(n)]
+        if with_bls:
+            return res, skip.reshape(n, 6), bls
         return res, skip.reshape(n, 6)
 
     # ---- run -----------------------------------------------------------------------------

@@ -109,6 +109,60 @@ int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t le
 
 }  // namespace pcsf
 
+namespace pcsf {
+// Branch-length scores of the columns in `spans` of the DEVICE-resident rows d_nucl[n_leaves][d_stride]: enqueues
+// the kernel and the copy of columns [0, n_cols) to host_out on the context's stream (no synchronisation).
+static int bls_enqueue(pcsf_ctx* c, const unsigned char* d_nucl, size_t d_stride, size_t n_cols, const std::vector<BlsSpan>& spans, double* host_out)
+{
+    hipError_t e;
+    if ((e = c->d_bls_out.reserve(n_cols * sizeof(double))) != hipSuccess) return c->hip_fail(e, "hipMalloc(bls out)");
+    if ((e = c->d_bls_spans.reserve(spans.size() * sizeof(BlsSpan))) != hipSuccess) return c->hip_fail(e, "hipMalloc(bls spans)");
+    // columns outside every span are reported as 0
+    if ((e = hipMemsetAsync(c->d_bls_out.ptr, 0, n_cols * sizeof(double), c->stream)) != hipSuccess) return c->hip_fail(e, "hipMemsetAsync(bls out)");
+    if ((e = hipMemsetAsync(c->d_bls_flag.ptr, 0xff, sizeof(unsigned long long), c->stream)) != hipSuccess) return c->hip_fail(e, "hipMemsetAsync(bls flag)");
+    if ((e = hipMemcpyAsync(c->d_bls_spans.ptr, spans.data(), spans.size() * sizeof(BlsSpan), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
+        return c->hip_fail(e, "hipMemcpyAsync(bls spans)");
+    for (size_t s0 = 0; s0 < spans.size(); s0 += 65535) {
+        const uint32_t ns = static_cast<uint32_t>(std::min<size_t>(65535, spans.size() - s0));
+        uint64_t max_len = 0;
+        for (uint32_t k = 0; k < ns; ++k) max_len = std::max<uint64_t>(max_len, spans[s0 + k].len);
+        if ((e = launch_bls(c->bls_tree, c->d_bls_spans.as<BlsSpan>() + s0, ns, max_len, d_nucl, d_stride, c->d_bls_out.as<double>(),
+                            c->d_bls_flag.as<unsigned long long>(), c->stream)) != hipSuccess)
+            return c->hip_fail(e, "launch bls");
+    }
+    if ((e = hipMemcpyAsync(host_out, c->d_bls_out.ptr, n_cols * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
+        return c->hip_fail(e, "hipMemcpyAsync(bls out)");
+    c->bls_first_bad = BLS_NO_BAD;
+    if ((e = hipMemcpyAsync(&c->bls_first_bad, c->d_bls_flag.ptr, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
+        return c->hip_fail(e, "hipMemcpyAsync(bls flag)");
+    return PCSF_OK;
+}
+
+// after the stream has been synchronised: was a character outside ACGTNacgtn-. seen?  (the reference exits on
+// one, src/translation.hpp:29-88); host_nucl/host_stride locate the character for the message
+static int bls_check(pcsf_ctx* c, const char* host_nucl, size_t host_stride, size_t d_stride)
+{
+    const unsigned long long bad = c->bls_first_bad;  // copied out behind the kernel by bls_enqueue
+    if (bad == BLS_NO_BAD) return PCSF_OK;
+    const size_t row = bad / d_stride, col = bad % d_stride;
+    return c->fail(PCSF_ERR_INVALID_ARG, std::string("unexpected character '") + host_nucl[row * host_stride + col] + "' in alignment");
+}
+
+// host rows in, host scores out (uploads the rows, synchronises)
+static int bls_columns(pcsf_ctx* c, const char* nucleotides, size_t row_stride, size_t n_cols, const std::vector<BlsSpan>& spans, double* out)
+{
+    hipError_t e;
+    const size_t nl = static_cast<size_t>(c->n_leaves);
+    if ((e = c->d_nucl.reserve(nl * n_cols)) != hipSuccess) return c->hip_fail(e, "hipMalloc(nucleotides)");
+    if ((e = hipMemcpy2DAsync(c->d_nucl.ptr, n_cols, nucleotides, row_stride, n_cols, nl, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
+        return c->hip_fail(e, "hipMemcpy2DAsync(nucleotides)");
+    const int rc = bls_enqueue(c, c->d_nucl.as<unsigned char>(), n_cols, n_cols, spans, out);
+    if (rc != PCSF_OK) return rc;
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return c->hip_fail(e, "hipStreamSynchronize");
+    return bls_check(c, nucleotides, row_stride, n_cols);
+}
+}  // namespace pcsf
+
 extern "C" {
 
 const char* pcsf_version(void) { return "phylocsf-amd 0.1.0 (gfx950)"; }
@@ -350,10 +404,20 @@ int pcsf_score_sites_fixed(pcsf_ctx* c, const uint8_t* codons, size_t n_sites, s
 int pcsf_score_alignments_6frames(pcsf_ctx* c, const char* nucleotides, size_t row_stride, const pcsf_alignment_desc* alns, size_t n_alns,
                                   double* out_scores, size_t out_capacity, uint64_t* out_offsets, uint32_t* n_codons, uint32_t* skip_bases)
 {
+    return pcsf_score_alignments_6frames_bls(c, nucleotides, row_stride, alns, n_alns, out_scores, out_capacity, out_offsets, n_codons, skip_bases,
+                                             nullptr);
+}
+
+int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size_t row_stride, const pcsf_alignment_desc* alns, size_t n_alns,
+                                      double* out_scores, size_t out_capacity, uint64_t* out_offsets, uint32_t* n_codons, uint32_t* skip_bases,
+                                      double* out_bls)
+{
     if (!c) return PCSF_ERR_INVALID_ARG;
     if (n_alns == 0) return PCSF_OK;
     if (!nucleotides || !alns || !out_scores || !out_offsets || !n_codons) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_alignments_6frames: null argument");
+    if (out_bls && !c->bls_ready) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_alignments_6frames_bls: call pcsf_set_bls_branch_lengths first");
     std::vector<pcsf::FrameSegment> seg;
+    std::vector<pcsf::BlsSpan> spans;  // like seg: source of an asynchronous copy, alive until the stream is synchronised
     seg.reserve(n_alns * 6);
     uint64_t total = 0, max_col = 0;
     uint32_t max_codons = 0;
@@ -379,9 +443,14 @@ int pcsf_score_alignments_6frames(pcsf_ctx* c, const char* nucleotides, size_t r
         }
     }
     if (total > out_capacity) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_alignments_6frames: out_capacity too small");
-    if (total == 0) return PCSF_OK;
     hipError_t e;
     if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
+    if (total == 0) {  // alignments shorter than a codon still have branch-length scores
+        if (!out_bls || max_col == 0) return PCSF_OK;
+        for (size_t k = 0; k < n_alns; ++k)
+            if (alns[k].len) spans.push_back(pcsf::BlsSpan{alns[k].col_offset, alns[k].len});
+        return pcsf::bls_columns(c, nucleotides, row_stride, max_col, spans, out_bls);
+    }
     const size_t nl = static_cast<size_t>(c->n_leaves);
     if ((e = c->d_nucl.reserve(nl * max_col)) != hipSuccess) return c->hip_fail(e, "hipMalloc(nucleotides)");
     if ((e = c->d_segments.reserve(seg.size() * sizeof(pcsf::FrameSegment))) != hipSuccess) return c->hip_fail(e, "hipMalloc(segments)");
@@ -391,6 +460,12 @@ int pcsf_score_alignments_6frames(pcsf_ctx* c, const char* nucleotides, size_t r
         return c->hip_fail(e, "hipMemcpy2DAsync(nucleotides)");
     if ((e = hipMemcpyAsync(c->d_segments.ptr, seg.data(), seg.size() * sizeof(pcsf::FrameSegment), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
         return c->hip_fail(e, "hipMemcpyAsync(segments)");
+    if (out_bls) {  // the power track's per-base scores from the same resident rows
+        for (size_t k = 0; k < n_alns; ++k)
+            if (alns[k].len) spans.push_back(pcsf::BlsSpan{alns[k].col_offset, alns[k].len});
+        const int rc = pcsf::bls_enqueue(c, c->d_nucl.as<unsigned char>(), max_col, max_col, spans, out_bls);
+        if (rc != PCSF_OK) return rc;
+    }
     // at most 65535 segments per launch (grid.y)
     for (size_t s0 = 0; s0 < seg.size(); s0 += 65535) {
         const uint32_t ns = static_cast<uint32_t>(std::min<size_t>(65535, seg.size() - s0));
@@ -403,7 +478,69 @@ int pcsf_score_alignments_6frames(pcsf_ctx* c, const char* nucleotides, size_t r
     if ((e = hipMemcpyAsync(out_scores, c->d_out.ptr, total * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
         return c->hip_fail(e, "hipMemcpyAsync(out)");
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return c->hip_fail(e, "hipStreamSynchronize");
+    if (out_bls) return pcsf::bls_check(c, nucleotides, row_stride, max_col);
     return PCSF_OK;
+}
+
+// ---- branch-length score (src/additional_scores.hpp:5-84) --------------------------------------------------
+int pcsf_set_bls_branch_lengths(pcsf_ctx* c, const double* branch_len)
+{
+    if (!c) return PCSF_ERR_INVALID_ARG;
+    if (!branch_len) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_set_bls_branch_lengths: null argument");
+    const int n = c->n_nodes, nl = c->n_leaves;
+    if (nl > 128 || n > pcsf::BLS_MAX_NODES) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_set_bls_branch_lengths: more than 128 species");
+    hipError_t e;
+    if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
+    // one allocation: len[n] | range[n][2] | child1[n] | child2[n]
+    std::vector<uint64_t> range(static_cast<size_t>(n) * 2, 0);
+    for (int i = 0; i < n; ++i) {
+        if (i < nl) {
+            range[2 * i + (i >> 6)] = uint64_t(1) << (i & 63);
+        } else {
+            for (int w = 0; w < 2; ++w) range[2 * i + w] = range[2 * c->child1[i] + w] | range[2 * c->child2[i] + w];
+        }
+    }
+    const size_t off_range = sizeof(double) * n, off_c1 = off_range + sizeof(uint64_t) * 2 * n, off_c2 = off_c1 + ((sizeof(int16_t) * n + 7) & ~size_t(7));
+    const size_t bytes = off_c2 + sizeof(int16_t) * n;
+    std::vector<unsigned char> host(bytes, 0);
+    std::memcpy(host.data(), branch_len, sizeof(double) * n);
+    std::memcpy(host.data() + off_range, range.data(), sizeof(uint64_t) * 2 * n);
+    std::memcpy(host.data() + off_c1, c->child1.data(), sizeof(int16_t) * n);
+    std::memcpy(host.data() + off_c2, c->child2.data(), sizeof(int16_t) * n);
+    if ((e = c->d_bls_tree.reserve(bytes)) != hipSuccess) return c->hip_fail(e, "hipMalloc(bls tree)");
+    if ((e = c->d_bls_flag.reserve(sizeof(unsigned long long))) != hipSuccess) return c->hip_fail(e, "hipMalloc(bls flag)");
+    if ((e = hipMemcpy(c->d_bls_tree.ptr, host.data(), bytes, hipMemcpyHostToDevice)) != hipSuccess) return c->hip_fail(e, "hipMemcpy(bls tree)");
+    unsigned char* base = c->d_bls_tree.as<unsigned char>();
+    c->bls_tree.len = reinterpret_cast<const double*>(base);
+    c->bls_tree.range = reinterpret_cast<const uint64_t*>(base + off_range);
+    c->bls_tree.child1 = reinterpret_cast<const int16_t*>(base + off_c1);
+    c->bls_tree.child2 = reinterpret_cast<const int16_t*>(base + off_c2);
+    c->bls_tree.n_nodes = n;
+    c->bls_tree.n_leaves = nl;
+    // the divisor is the score of the full species set: one column of 'A's through the same kernel (divided by 1)
+    c->bls_tree.total = 1.0;
+    c->bls_ready = true;
+    std::vector<char> all(static_cast<size_t>(nl), 'A');
+    double total = 0.0;
+    const int rc = pcsf::bls_columns(c, all.data(), 1, 1, {pcsf::BlsSpan{0, 1}}, &total);
+    if (rc != PCSF_OK) {
+        c->bls_ready = false;
+        return rc;
+    }
+    if (nl < 2) total = 1.0;  // a single species never scores; avoid 0/0 below
+    c->bls_tree.total = total;
+    return PCSF_OK;
+}
+
+int pcsf_branch_length_scores(pcsf_ctx* c, const char* nucleotides, size_t row_stride, size_t n_columns, double* out_bls)
+{
+    if (!c) return PCSF_ERR_INVALID_ARG;
+    if (n_columns == 0) return PCSF_OK;
+    if (!nucleotides || !out_bls || row_stride < n_columns) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_branch_length_scores: bad argument");
+    if (!c->bls_ready) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_branch_length_scores: call pcsf_set_bls_branch_lengths first");
+    hipError_t e;
+    if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
+    return pcsf::bls_columns(c, nucleotides, row_stride, n_columns, {pcsf::BlsSpan{0, n_columns}}, out_bls);
 }
 
 int pcsf_score_blocks(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64_t* site_offsets, size_t n_blocks,

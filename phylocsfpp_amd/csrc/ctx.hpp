@@ -56,6 +56,11 @@ struct pcsf_ctx {
     pcsf::DeviceBuffer d_program, d_frag, d_leaf_tab, d_prior, d_anc_weight;
     // scratch for the host-pointer entry points
     pcsf::DeviceBuffer d_codons, d_out, d_lnz, d_anc, d_stamps, d_nucl, d_segments;
+    // branch-length score (pcsf_set_bls_branch_lengths)
+    pcsf::DeviceBuffer d_bls_tree, d_bls_out, d_bls_spans, d_bls_flag;
+    pcsf::BlsTree bls_tree{};
+    bool bls_ready = false;
+    unsigned long long bls_first_bad = pcsf::BLS_NO_BAD;  // host copy of the kernel's character check
     uint32_t stamp_block = 0;
     hipStream_t stream = nullptr;        // private stream for host-pointer entry points
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -64,4 +64,77 @@ hipError_t launch_extract_frames(const FrameSegment* d_seg, uint32_t n_segments,
     return hipGetLastError();
 }
 
+// ---- branch-length score ------------------------------------------------------------------------------------
+// compute_bls_score / newick_sum_branch_lengths (src/additional_scores.hpp:5-84) per alignment column: S = the
+// species with one of ACGTacgt in the column; fewer than two -> 0; otherwise the branch lengths of the subtree
+// spanned by S -- every node strictly below S's last common ancestor whose leaves meet S -- over the same sum
+// for the full species set.  The reference recursion adds, per node, (own branch, left subtree, right subtree) in
+// that order; evaluating the nodes bottom-up (children have smaller indices than their parent) performs the same
+// additions on the same operands, so the double results, and the float threshold decisions made from them, are
+// identical.  One thread per column: S is a 128-bit mask built from the column's characters (coalesced across the
+// work-group: consecutive threads read consecutive columns of a species row), overlaps are popcounts against the
+// per-node leaf masks held in LDS, and the per-node partial sums live in the thread's scratch.
+__global__ __launch_bounds__(256) void bls_kernel(BlsTree t, const BlsSpan* __restrict__ spans, const unsigned char* __restrict__ nucl,
+                                                  size_t row_stride, double* __restrict__ out, unsigned long long* __restrict__ first_bad)
+{
+    __shared__ uint64_t s_range[BLS_MAX_NODES][2];
+    __shared__ double s_len[BLS_MAX_NODES];
+    __shared__ int16_t s_c1[BLS_MAX_NODES], s_c2[BLS_MAX_NODES];
+    for (int i = threadIdx.x; i < t.n_nodes; i += 256) {
+        s_range[i][0] = t.range[2 * i];
+        s_range[i][1] = t.range[2 * i + 1];
+        s_len[i] = t.len[i];
+        s_c1[i] = t.child1[i];
+        s_c2[i] = t.child2[i];
+    }
+    __syncthreads();
+    const BlsSpan span = spans[blockIdx.y];
+    const uint64_t x = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+    if (x >= span.len) return;
+    const size_t col = span.col0 + x;
+    uint64_t lo = 0, hi = 0;
+    for (int l = 0; l < t.n_leaves; ++l) {
+        const unsigned char ch = nucl[static_cast<size_t>(l) * row_stride + col];
+        const unsigned char up = ch & 0xDFu;  // letters to upper case
+        const bool acgt = up == 'A' || up == 'C' || up == 'G' || up == 'T';
+        if (acgt) {
+            if (l < 64) lo |= uint64_t(1) << l;
+            else hi |= uint64_t(1) << (l - 64);
+        } else if (!(up == 'N' || ch == '-' || ch == '.')) {
+            atomicMin(first_bad, static_cast<unsigned long long>(static_cast<size_t>(l) * row_stride + col));
+        }
+    }
+    const int in_set = __popcll(lo) + __popcll(hi);
+    if (in_set < 2) {
+        out[col] = 0.0;
+        return;
+    }
+    double val[BLS_MAX_NODES];
+    for (int i = 0; i < t.n_nodes; ++i) {
+        const int ov = __popcll(lo & s_range[i][0]) + __popcll(hi & s_range[i][1]);
+        if (ov == 0) continue;  // never visited
+        if (i < t.n_leaves) {
+            val[i] = s_len[i];
+            continue;
+        }
+        const int l = s_c1[i], r = s_c2[i];
+        const int ol = __popcll(lo & s_range[l][0]) + __popcll(hi & s_range[l][1]);
+        double bl = ov < in_set ? s_len[i] : 0.0;  // strictly below the last common ancestor of S
+        if (ol > 0) bl += val[l];
+        if (ov - ol > 0) bl += val[r];
+        val[i] = bl;
+    }
+    out[col] = val[t.n_nodes - 1] / t.total;
+}
+
+hipError_t launch_bls(const BlsTree& tree, const BlsSpan* d_spans, uint32_t n_spans, uint64_t max_len, const unsigned char* d_nucl,
+                      size_t row_stride, double* d_out, unsigned long long* d_first_bad, hipStream_t stream)
+{
+    if (n_spans == 0 || max_len == 0) return hipSuccess;
+    if (n_spans > 65535u || tree.n_nodes > BLS_MAX_NODES) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bls_kernel, dim3(static_cast<unsigned>((max_len + 255u) / 256u), n_spans), dim3(256), 0, stream, tree, d_spans, d_nucl,
+                       row_stride, d_out, d_first_bad);
+    return hipGetLastError();
+}
+
 }  // namespace pcsf

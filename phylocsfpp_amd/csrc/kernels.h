@@ -128,4 +128,25 @@ struct FrameSegment {
 hipError_t launch_extract_frames(const FrameSegment* d_seg, uint32_t n_segments, uint32_t max_codons, const unsigned char* d_nucl,
                                  size_t row_stride, int n_leaves, unsigned char* d_codons, size_t leaf_stride, hipStream_t stream);
 
+// ---- branch-length score (power track) ---------------------------------------------------------------------
+constexpr int BLS_MAX_NODES = 255;  // species sets are 128-bit masks: at most 128 leaves
+
+struct BlsTree {            // device pointers; nodes in the model's order (children before parents, root last)
+    const int16_t* child1;
+    const int16_t* child2;
+    const double* len;      // [n_nodes] branch lengths in DOUBLE (the likelihood uses the float ones)
+    const uint64_t* range;  // [n_nodes][2] leaves below the node
+    int n_nodes, n_leaves;
+    double total;           // score of the full species set (the divisor)
+};
+struct BlsSpan {            // columns [col0, col0 + len) of the nucleotide matrix belong to one alignment
+    uint64_t col0;
+    uint64_t len;
+};
+constexpr unsigned long long BLS_NO_BAD = ~0ull;
+// d_out[col] for every column of every span; *d_first_bad = smallest row * row_stride + col holding a character
+// outside ACGTNacgtn-. (BLS_NO_BAD if none; the caller initialises it)
+hipError_t launch_bls(const BlsTree& tree, const BlsSpan* d_spans, uint32_t n_spans, uint64_t max_len, const unsigned char* d_nucl,
+                      size_t row_stride, double* d_out, unsigned long long* d_first_bad, hipStream_t stream);
+
 }  // namespace pcsf

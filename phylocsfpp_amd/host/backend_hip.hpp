@@ -25,7 +25,10 @@ public:
         d.pi_noncoding = m.pi_nc.data();
         const int rc = pcsf_create(&ctx_, &d, device);
         if (rc != PCSF_OK) throw std::runtime_error(std::string("pcsf_create failed: ") + pcsf_last_error(nullptr));
+        // branch-length scores on the device: the tree's double branch lengths (up to 128 species)
+        device_bls_ = m.n_leaves <= 128 && pcsf_set_bls_branch_lengths(ctx_, m.branch_len_d.data()) == PCSF_OK;
     }
+    bool device_bls() const override { return device_bls_; }
     ~HipBackend() override { pcsf_destroy(ctx_); }
     void score_sites_fixed(const uint8_t* codons, size_t n_sites, size_t leaf_stride, double* out) override
     {
@@ -39,14 +42,14 @@ public:
 
     size_t score_alignments_6frames(int, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0, const std::vector<uint32_t>& len,
                                     const std::vector<uint64_t>& start_pos, const std::vector<uint64_t>& chrom_len, double* out, size_t out_capacity,
-                                    std::vector<uint64_t>& offsets, std::vector<uint32_t>& n_codons) override
+                                    std::vector<uint64_t>& offsets, std::vector<uint32_t>& n_codons, double* bls_out) override
     {
         const size_t n = col0.size();
         std::vector<pcsf_alignment_desc> d(n);
         for (size_t k = 0; k < n; ++k) d[k] = pcsf_alignment_desc{col0[k], len[k], start_pos[k], chrom_len[k]};
         offsets.assign(n * 6, 0);
         n_codons.assign(n * 6, 0);
-        check(pcsf_score_alignments_6frames(ctx_, nucl, row_stride, d.data(), n, out, out_capacity, offsets.data(), n_codons.data(), nullptr));
+        check(pcsf_score_alignments_6frames_bls(ctx_, nucl, row_stride, d.data(), n, out, out_capacity, offsets.data(), n_codons.data(), nullptr, bls_out));
         size_t total = 0;
         for (size_t i = 0; i < n * 6; ++i) total += n_codons[i];
         return total;
@@ -66,6 +69,7 @@ private:
         if (rc != PCSF_OK) throw std::runtime_error(std::string("phylocsf_amd: ") + pcsf_last_error(ctx_));
     }
     pcsf_ctx* ctx_ = nullptr;
+    bool device_bls_ = false;
 };
 
 }  // namespace pcsf_host

@@ -157,6 +157,7 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
         else if (k == "--threads") bt.threads = atoi(v.c_str());
         else if (k == "--batch-sites") bt.batch_sites = static_cast<size_t>(strtoull(v.c_str(), nullptr, 10));    // codon-frames per backend call
         else if (k == "--window-bytes") bt.window_bytes = static_cast<size_t>(strtoull(v.c_str(), nullptr, 10));  // MAF bytes per pipeline step
+        else if (k == "--host-bls") bt.host_bls = parse_bool(v);  // branch-length scores on the host instead of the scoring backend
         else if (k == "--species-aliases") aliases = v;
         else if (k == "--species") species = v;
         else if (k == "--mapping") mapping = v;

@@ -56,11 +56,15 @@ struct ScoringBackend {
     // the HIP backend overrides it with the device front end.
     // `out` has room for out_capacity values (2 per column is always enough) and, like `nucl`, preferably comes from
     // staging_alloc; returns the number of values written.
+    // true when score_alignments_6frames can also fill bls_out[row_stride] with the per-base branch-length scores of the
+    // batch's columns (and then checks the characters itself); otherwise the driver computes them on the host
+    virtual bool device_bls() const { return false; }
     virtual size_t score_alignments_6frames(int n_leaves, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0,
                                             const std::vector<uint32_t>& len, const std::vector<uint64_t>& start_pos,
                                             const std::vector<uint64_t>& chrom_len, double* out, size_t out_capacity, std::vector<uint64_t>& offsets,
-                                            std::vector<uint32_t>& n_codons)
+                                            std::vector<uint32_t>& n_codons, double* bls_out)
     {
+        if (bls_out) throw std::runtime_error("score_alignments_6frames: this backend does not compute branch-length scores");
         const size_t n = col0.size();
         offsets.assign(n * 6, 0);
         n_codons.assign(n * 6, 0);
@@ -99,6 +103,7 @@ struct BuildTracksParams {
     Hmm hmm;
     size_t batch_sites = 4u << 20;   // codon-frames gathered per backend call
     bool verbose = false;
+    bool host_bls = false;           // branch-length scores on the host even when the backend offers them (--host-bls)
     int threads = 0;                 // host threads for ingest / BLS / text output (0 = all the process may use)
     size_t window_bytes = size_t(32) << 20;   // MAF bytes parsed (in parallel) per pipeline step
 };
@@ -284,13 +289,17 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         uint64_t start_pos = 0, chrom_len = 0, col0 = 0;
         uint32_t len = 0;
         std::vector<std::string> seqs;
-        std::vector<double> bls;
+        std::vector<double> bls_host;      // per-base branch-length scores when computed on the host
+        const double* bls = nullptr;       // [len]: bls_host, or the alignment's columns of its batch's device result
     };
     const size_t nl = static_cast<size_t>(model.n_leaves);
     const int threads = prm.threads > 0 ? prm.threads : effective_threads();
     size_t cap = std::max<size_t>(prm.batch_sites / 2, 1);  // columns per batch: one column yields two codon-frames
     BuildTracksStats st;
     const float threshold3 = prm.power_threshold * 3;
+    // the branch-length scores come from the backend (same uploaded rows as the six frames) when every backend offers that
+    bool dev_bls = need_raw && !prm.host_bls;
+    for (const ScoringBackend* b : backends) dev_bls = dev_bls && b->device_bls();
     StopWatch total, sw;
 
     auto write_power = [&](const std::vector<Item*>& items) {  // frame 3 of the + strand, mean of the three per-base scores
@@ -298,8 +307,8 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         for (const Item* it : items) {
             int64_t skip = static_cast<int64_t>(3 - static_cast<int64_t>(it->start_pos)) % 3;
             if (skip < 0) skip += 3;
-            if (static_cast<uint64_t>(skip) + 2 < it->bls.size()) out.header(it->chrom, static_cast<int64_t>(it->start_pos) + skip);
-            for (size_t pos = static_cast<size_t>(skip); pos + 2 < it->bls.size(); pos += 3)
+            if (static_cast<uint64_t>(skip) + 2 < it->len) out.header(it->chrom, static_cast<int64_t>(it->start_pos) + skip);
+            for (size_t pos = static_cast<size_t>(skip); pos + 2 < it->len; pos += 3)
                 out.value<4>(static_cast<float>((it->bls[pos] + it->bls[pos + 1] + it->bls[pos + 2]) / 3.0));
         }
         out.flush();
@@ -355,7 +364,7 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             std::lock_guard<std::mutex> g(lock);
             free_list.push_back(f);
         }
-    } pool(backend), score_pool(backend);  // batch matrices; score vectors (different sizes: kept apart)
+    } pool(backend), score_pool(backend), bls_pool(backend);  // batch matrices; score vectors; branch-length scores (sizes differ: kept apart)
     struct Batch {  // alignments scored by one backend call, their nucleotides packed leaf-major
         std::vector<Item*> items;
         size_t stride = 0;
@@ -363,6 +372,7 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         std::vector<uint64_t> col0, start_pos, chrom_len;
         std::vector<uint32_t> len;
         std::pair<char*, size_t> score_mem{nullptr, 0};  // page-locked, from the pool
+        std::pair<char*, size_t> bls_mem{nullptr, 0};    // [stride] per-base branch-length scores from the backend
         const double* scores = nullptr;    // filled by the backend
         size_t n_scores = 0;
         std::vector<uint64_t> offsets;
@@ -397,7 +407,8 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
                 it.start_pos = aln.start_pos;
                 it.chrom_len = aln.chrom_len;
                 it.len = static_cast<uint32_t>(aln.length());
-                bls.per_base(aln, &it.bls);  // also validates every character (the reference exits on anything but ACGTNacgtn-.)
+                // also validates every character (the reference exits on anything but ACGTNacgtn-.); the backend does both otherwise
+                if (!dev_bls) bls.per_base(aln, &it.bls_host);
                 it.seqs.swap(aln.seqs);
                 pw->jobs[j].push_back(std::move(it));
                 job_bls[j] += jw.lap();
@@ -415,6 +426,7 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
                 if (!pw->batches.back().items.empty() && pw->batches.back().stride + it.len > cap) pw->batches.emplace_back();
                 Batch& bt = pw->batches.back();
                 it.col0 = bt.stride;
+                it.bls = it.bls_host.data();
                 bt.stride += it.len;
                 bt.items.push_back(&it);
             }
@@ -485,6 +497,8 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             });
             if (batch->score_mem.first) score_pool.put(batch->score_mem);
             batch->score_mem = {nullptr, 0};
+            if (batch->bls_mem.first) bls_pool.put(batch->bls_mem);
+            batch->bls_mem = {nullptr, 0};
             batch->scores = nullptr;
             return ww.lap();
         });
@@ -499,9 +513,16 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
                 const size_t cap_scores = 2 * b->stride;  // six frames of len/3 codons each
                 b->score_mem = score_pool.get(cap_scores * sizeof(double));
                 double* out = reinterpret_cast<double*>(b->score_mem.first);
+                double* bls_out = nullptr;
+                if (dev_bls) {
+                    b->bls_mem = bls_pool.get(b->stride * sizeof(double));
+                    bls_out = reinterpret_cast<double*>(b->bls_mem.first);
+                }
                 b->n_scores = backends[d]->score_alignments_6frames(model.n_leaves, b->nucl.first, b->stride, b->col0, b->len, b->start_pos, b->chrom_len,
-                                                                    out, cap_scores, b->offsets, b->n_codons);
+                                                                    out, cap_scores, b->offsets, b->n_codons, bls_out);
                 b->scores = out;
+                if (dev_bls)
+                    for (Item* p : b->items) p->bls = bls_out + p->col0;
                 pool.put(b->nucl);
                 b->nucl = {nullptr, 0};
             }

@@ -114,6 +114,19 @@ class OracleModel:
             raise RuntimeError("po_run_tracks failed")
         return out
 
+    def bls(self, nucleotides):
+        """compute_bls_score<true> on ASCII rows uint8 [nl, n_cols] -> (block score, per-base float64[n_cols])."""
+        nuc = np.ascontiguousarray(nucleotides, dtype=np.uint8)
+        assert nuc.shape[0] == self.nl
+        out = np.empty(nuc.shape[1], dtype=np.float64)
+        fn = lib().po_bls
+        fn.restype = C.c_double
+        fn.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_double)]
+        score = fn(C.addressof(self.m.tree), nuc.ctypes.data_as(C.c_char_p), nuc.strides[0], nuc.shape[1], _dp(out))
+        if score == -1.0:
+            raise ValueError("unexpected character in alignment")
+        return score, out
+
     def run(self, algo, codons, compute_anc=True, seed=42):
         codons = np.ascontiguousarray(codons, dtype=np.uint8)
         n = codons.shape[1]

@@ -19,12 +19,13 @@ def _cli():
     return CLI
 
 
-def test_build_tracks_golden_wigs_on_gpu(tmp_path):
+@pytest.mark.parametrize("host_bls", ["0", "1"])   # branch-length scores from the device kernel (default) / on the host
+def test_build_tracks_golden_wigs_on_gpu(tmp_path, host_bls):
     maf = tmp_path / "galGal6.maf"
     with gzip.open(os.path.join(GOLD, "build-tracks", "galGal6_chr22_25_28_each_30k_bases.maf.gz"), "rb") as fi, open(maf, "wb") as fo:
         shutil.copyfileobj(fi, fo)
     out = tmp_path / "out"
-    subprocess.check_call([_cli(), "build-tracks", "--output", str(out), os.path.join(GOLD, "models", "53birds"), str(maf)])
+    subprocess.check_call([_cli(), "build-tracks", "--output", str(out), "--host-bls", host_bls, os.path.join(GOLD, "models", "53birds"), str(maf)])
     for n in ["PhyloCSFpower"] + ["PhyloCSFRaw%s%d" % (s, f) for s in "+-" for f in (1, 2, 3)]:
         want = gzip.open(os.path.join(GOLD, "build-tracks", n + ".wig.gz"), "rb").read()
         got = open(out / (n + ".wig"), "rb").read()
@@ -197,3 +198,13 @@ def test_score_msa_mle_and_omega_medium_file_on_gpu(tmp_path):
             assert phylo_checked == 516 and anc_close >= 0.95 * 516
         else:
             assert phylo_checked >= 400
+
+
+def test_build_tracks_rejects_other_characters_on_gpu(tmp_path):
+    """the device validates the characters when it computes the branch-length scores (the reference exits on
+    anything but ACGTNacgtn-., src/translation.hpp:29-88)"""
+    maf = tmp_path / "bad.maf"
+    maf.write_text("a score=0\ns chicken.chr1 10 4 + 1000 ACXT\ns turkey.chr1 10 4 + 1000 ACGT\n")
+    r = subprocess.run([_cli(), "build-tracks", "--output", str(tmp_path / "o"), os.path.join(GOLD, "models", "53birds"), str(maf)],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "unexpected character 'X'" in r.stderr

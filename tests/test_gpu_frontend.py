@@ -60,3 +60,78 @@ def test_six_frames_match_host_translation(model, oracle_models, gpu_contexts):
             if f >= 3:
                 want = want[::-1]                                        # the reference reverses '-' strand scores
             np.testing.assert_allclose(res[k][f], want, rtol=1e-9, atol=1e-9)
+
+
+# ---- branch-length score on the device (reference src/additional_scores.hpp:5-84) --------------------------
+def _random_rows(rng, nl, n_cols):
+    """rows with realistic structure: runs of absent species (N / -), lower case, and fully random columns"""
+    alphabet = np.frombuffer(b"ACGTacgtNn-.", dtype=np.uint8)
+    prob = np.array([.2, .2, .2, .2, .03, .03, .03, .03, .02, .01, .04, .01])
+    nuc = rng.choice(alphabet, size=(nl, n_cols), p=prob / prob.sum())
+    for l in range(nl):                                     # species missing over long stretches, as in real MAFs
+        for _ in range(int(rng.integers(0, 4))):
+            a = int(rng.integers(0, n_cols))
+            b = min(n_cols, a + int(rng.integers(1, n_cols)))
+            nuc[l, a:b] = ord("N") if rng.random() < 0.5 else ord("-")
+    nuc[:, :3] = ord("-")                                   # empty set
+    nuc[0, 1] = ord("A")                                    # one species only -> 0
+    nuc[[0, nl - 1], 2] = ord("c")                          # first and last leaf: the set's ancestor is the root
+    nuc[:, 3] = ord("G")                                    # all species -> exactly 1
+    return nuc
+
+
+@pytest.mark.parametrize("model", ["53birds", "58mammals", "100vertebrates"])
+def test_branch_length_scores_identical_to_the_recursion(model, oracle_models, gpu_contexts):
+    """bit-identical doubles: the float threshold of build-tracks is decided from them"""
+    m = oracle_models(model)
+    ctx = gpu_contexts(model)
+    ctx.set_bls_branch_lengths(m.branch_len_d)
+    rng = np.random.default_rng(5)
+    for n_cols in (1, 7, 255, 256, 257, 5000):
+        nuc = _random_rows(rng, m.nl, max(n_cols, 4))[:, :n_cols] if n_cols < 4 else _random_rows(rng, m.nl, n_cols)
+        got = ctx.branch_length_scores(nuc)
+        _, want = m.bls(nuc)
+        assert got.tobytes() == want.tobytes(), (model, n_cols, np.abs(got - want).max())
+    assert got[3] == 1.0 and got[0] == 0.0 and got[1] == 0.0 and 0.0 < got[2] < 1.0
+
+
+def test_branch_length_scores_with_the_six_frames(oracle_models, gpu_contexts):
+    """one call: frames + per-base scores from the same uploaded rows; padding columns between alignments stay 0
+    and are not checked for characters"""
+    m = oracle_models("53birds")
+    ctx = gpu_contexts("53birds")
+    ctx.set_bls_branch_lengths(m.branch_len_d)
+    rng = np.random.default_rng(9)
+    alns, cols = [], 0
+    for L in (1, 2, 3, 50, 700):
+        alns.append((cols, L, int(rng.integers(1, 10**6)), 3 * 10**6))
+        cols += L + 3
+    nuc = _random_rows(rng, m.nl, cols)
+    for c0, L, _, _ in alns:
+        nuc[:, c0 + L:c0 + L + 3] = ord("#")                # not part of any alignment
+    res, skip, bls = ctx.score_alignments_6frames(nuc, alns, with_bls=True)
+    res2, skip2 = ctx.score_alignments_6frames(nuc, alns)
+    for k in range(len(alns)):
+        for f in range(6):
+            assert np.array_equal(res[k][f], res2[k][f])
+    for c0, L, _, _ in alns:
+        _, want = m.bls(nuc[:, c0:c0 + L])
+        assert bls[c0:c0 + L].tobytes() == want.tobytes()
+        assert (bls[c0 + L:c0 + L + 3] == 0).all()
+    # alignments too short for a codon still get their scores
+    two = _random_rows(rng, m.nl, 50)[:, 10:12].copy()
+    _, _, b2 = ctx.score_alignments_6frames(two, [(0, 2, 5, 1000)], with_bls=True)
+    assert b2.tobytes() == m.bls(two)[1].tobytes()
+
+
+def test_branch_length_scores_reject_other_characters(oracle_models, gpu_contexts):
+    m = oracle_models("53birds")
+    ctx = gpu_contexts("53birds")
+    ctx.set_bls_branch_lengths(m.branch_len_d)
+    nuc = np.full((m.nl, 300), ord("A"), np.uint8)
+    nuc[7, 123] = ord("X")
+    with pytest.raises(RuntimeError, match="unexpected character 'X'"):
+        ctx.branch_length_scores(nuc)
+    with pytest.raises(RuntimeError, match="unexpected character 'X'"):
+        ctx.score_alignments_6frames(nuc, [(0, 300, 1, 1000)], with_bls=True)
+    assert (ctx.branch_length_scores(np.full((m.nl, 10), ord("t"), np.uint8)) == 1.0).all()   # the context stays usable

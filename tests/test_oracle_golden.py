@@ -117,3 +117,19 @@ def test_score_msa_omega_within_reference_tolerance(oracle_cli, tmp_path):
             # the symmetric solver returns a finite score there (parity unpinned)
             assert math.isfinite(float(g[4]))
     assert finite >= 20
+
+
+def test_oracle_bls_matches_golden_bls_column(oracle_models):
+    """po_bls (the recursion of src/additional_scores.hpp:5-84, the checker of the device kernel) reproduces the
+    bls-score column of the reference's score-msa output"""
+    import numpy as np
+    from maf_blocks import block_rows
+    m = oracle_models("100vertebrates")
+    mats = block_rows(os.path.join(GOLD, "score-msa", "chr22.50alignments.maf"), m.labels[:m.nl],
+                      os.path.join(GOLD, "models", "species_aliases.tsv"))
+    _, want = read_scores(os.path.join(GOLD, "score-msa", "chr22.50alignments.fixed.scores"))
+    assert len(mats) == len(want) == 50
+    for mat, row in zip(mats, want):
+        score, per_base = m.bls(mat)
+        assert "%.6f" % np.float32(score) == row[6]
+        assert per_base.shape == (mat.shape[1],) and (per_base >= 0).all() and (per_base <= 1).all()
