@@ -111,8 +111,8 @@ int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t le
 
 namespace pcsf {
 // Branch-length scores of the columns in `spans` of the DEVICE-resident rows d_nucl[n_leaves][d_stride]: enqueues
-// the kernel and the copy of columns [0, n_cols) to host_out on the context's stream (no synchronisation).
-static int bls_enqueue(pcsf_ctx* c, const unsigned char* d_nucl, size_t d_stride, size_t n_cols, const std::vector<BlsSpan>& spans, double* host_out)
+// the kernel on the context's stream (no synchronisation) ...
+static int bls_enqueue(pcsf_ctx* c, const unsigned char* d_nucl, size_t d_stride, size_t n_cols, const std::vector<BlsSpan>& spans)
 {
     hipError_t e;
     if ((e = c->d_bls_out.reserve(n_cols * sizeof(double))) != hipSuccess) return c->hip_fail(e, "hipMalloc(bls out)");
@@ -130,10 +130,20 @@ static int bls_enqueue(pcsf_ctx* c, const unsigned char* d_nucl, size_t d_stride
                             c->d_bls_flag.as<unsigned long long>(), c->stream)) != hipSuccess)
             return c->hip_fail(e, "launch bls");
     }
+    return PCSF_OK;
+}
+
+// ... and the copies of columns [0, n_cols) and of the character check to the host, also without synchronising.
+// Kept apart from the launch so that a caller with more kernels to run can queue all its downloads behind them
+// (a download between two kernels idles the compute queue while the copy engine works).
+static int bls_download(pcsf_ctx* c, size_t n_cols, double* host_out)
+{
+    hipError_t e;
     if ((e = hipMemcpyAsync(host_out, c->d_bls_out.ptr, n_cols * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
         return c->hip_fail(e, "hipMemcpyAsync(bls out)");
-    c->bls_first_bad = BLS_NO_BAD;
-    if ((e = hipMemcpyAsync(&c->bls_first_bad, c->d_bls_flag.ptr, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
+    // into page-locked memory: a copy to pageable memory would block the host here until the kernel has run
+    *c->bls_first_bad = BLS_NO_BAD;
+    if ((e = hipMemcpyAsync(c->bls_first_bad, c->d_bls_flag.ptr, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
         return c->hip_fail(e, "hipMemcpyAsync(bls flag)");
     return PCSF_OK;
 }
@@ -142,7 +152,7 @@ static int bls_enqueue(pcsf_ctx* c, const unsigned char* d_nucl, size_t d_stride
 // one, src/translation.hpp:29-88); host_nucl/host_stride locate the character for the message
 static int bls_check(pcsf_ctx* c, const char* host_nucl, size_t host_stride, size_t d_stride)
 {
-    const unsigned long long bad = c->bls_first_bad;  // copied out behind the kernel by bls_enqueue
+    const unsigned long long bad = *c->bls_first_bad;  // copied out behind the kernel by bls_enqueue
     if (bad == BLS_NO_BAD) return PCSF_OK;
     const size_t row = bad / d_stride, col = bad % d_stride;
     return c->fail(PCSF_ERR_INVALID_ARG, std::string("unexpected character '") + host_nucl[row * host_stride + col] + "' in alignment");
@@ -156,7 +166,8 @@ static int bls_columns(pcsf_ctx* c, const char* nucleotides, size_t row_stride, 
     if ((e = c->d_nucl.reserve(nl * n_cols)) != hipSuccess) return c->hip_fail(e, "hipMalloc(nucleotides)");
     if ((e = hipMemcpy2DAsync(c->d_nucl.ptr, n_cols, nucleotides, row_stride, n_cols, nl, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
         return c->hip_fail(e, "hipMemcpy2DAsync(nucleotides)");
-    const int rc = bls_enqueue(c, c->d_nucl.as<unsigned char>(), n_cols, n_cols, spans, out);
+    int rc = bls_enqueue(c, c->d_nucl.as<unsigned char>(), n_cols, n_cols, spans);
+    if (rc == PCSF_OK) rc = bls_download(c, n_cols, out);
     if (rc != PCSF_OK) return rc;
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return c->hip_fail(e, "hipStreamSynchronize");
     return bls_check(c, nucleotides, row_stride, n_cols);
@@ -170,7 +181,8 @@ const char* pcsf_version(void) { return "phylocsf-amd 0.1.0 (gfx950)"; }
 void* pcsf_host_alloc(size_t bytes)
 {
     void* p = nullptr;
-    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    // portable: page-locked for every device, so one pool can feed the contexts of several GPUs
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;
     return p;
 }
 
@@ -425,6 +437,7 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
         const pcsf_alignment_desc& a = alns[k];
         if (a.col_offset + a.len > row_stride) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_alignments_6frames: alignment exceeds row_stride");
         max_col = std::max<uint64_t>(max_col, a.col_offset + a.len);
+        if (out_bls && a.len) spans.push_back(pcsf::BlsSpan{a.col_offset, a.len});
         for (int f = 0; f < 6; ++f) {
             const pcsf::FrameView v = pcsf::frame_view(a.start_pos, a.chrom_len, a.len, f < 3 ? '+' : '-', static_cast<unsigned>(f % 3 + 1));
             pcsf::FrameSegment s{};
@@ -447,10 +460,12 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
     if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
     if (total == 0) {  // alignments shorter than a codon still have branch-length scores
         if (!out_bls || max_col == 0) return PCSF_OK;
-        for (size_t k = 0; k < n_alns; ++k)
-            if (alns[k].len) spans.push_back(pcsf::BlsSpan{alns[k].col_offset, alns[k].len});
         return pcsf::bls_columns(c, nucleotides, row_stride, max_col, spans, out_bls);
     }
+    // One stream, in order: rows up, branch-length kernel, frame extraction, pruning, then ALL downloads (a download
+    // between two kernels idles the compute queue while the copy engine works).  Splitting the call into chunks on
+    // two streams so that transfers overlap kernels was measured and gains nothing: with page-locked buffers the
+    // transfers are 0.5 ms of a 12 ms call and the extra launches and kernel tails cost as much.
     const size_t nl = static_cast<size_t>(c->n_leaves);
     if ((e = c->d_nucl.reserve(nl * max_col)) != hipSuccess) return c->hip_fail(e, "hipMalloc(nucleotides)");
     if ((e = c->d_segments.reserve(seg.size() * sizeof(pcsf::FrameSegment))) != hipSuccess) return c->hip_fail(e, "hipMalloc(segments)");
@@ -460,12 +475,9 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
         return c->hip_fail(e, "hipMemcpy2DAsync(nucleotides)");
     if ((e = hipMemcpyAsync(c->d_segments.ptr, seg.data(), seg.size() * sizeof(pcsf::FrameSegment), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
         return c->hip_fail(e, "hipMemcpyAsync(segments)");
-    if (out_bls) {  // the power track's per-base scores from the same resident rows
-        for (size_t k = 0; k < n_alns; ++k)
-            if (alns[k].len) spans.push_back(pcsf::BlsSpan{alns[k].col_offset, alns[k].len});
-        const int rc = pcsf::bls_enqueue(c, c->d_nucl.as<unsigned char>(), max_col, max_col, spans, out_bls);
-        if (rc != PCSF_OK) return rc;
-    }
+    int rc;
+    // the power track's per-base scores from the same resident rows
+    if (out_bls && (rc = pcsf::bls_enqueue(c, c->d_nucl.as<unsigned char>(), max_col, max_col, spans)) != PCSF_OK) return rc;
     // at most 65535 segments per launch (grid.y)
     for (size_t s0 = 0; s0 < seg.size(); s0 += 65535) {
         const uint32_t ns = static_cast<uint32_t>(std::min<size_t>(65535, seg.size() - s0));
@@ -473,10 +485,10 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
                                              c->n_leaves, c->d_codons.as<unsigned char>(), total, c->stream)) != hipSuccess)
             return c->hip_fail(e, "launch extract_frames");
     }
-    int rc = pcsf::launch_fixed(c, c->d_codons.as<uint8_t>(), total, total, c->d_out.as<double>(), nullptr, nullptr, c->stream);
-    if (rc != PCSF_OK) return rc;
+    if ((rc = pcsf::launch_fixed(c, c->d_codons.as<uint8_t>(), total, total, c->d_out.as<double>(), nullptr, nullptr, c->stream)) != PCSF_OK) return rc;
     if ((e = hipMemcpyAsync(out_scores, c->d_out.ptr, total * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
         return c->hip_fail(e, "hipMemcpyAsync(out)");
+    if (out_bls && (rc = pcsf::bls_download(c, max_col, out_bls)) != PCSF_OK) return rc;
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return c->hip_fail(e, "hipStreamSynchronize");
     if (out_bls) return pcsf::bls_check(c, nucleotides, row_stride, max_col);
     return PCSF_OK;
@@ -509,6 +521,8 @@ int pcsf_set_bls_branch_lengths(pcsf_ctx* c, const double* branch_len)
     std::memcpy(host.data() + off_c2, c->child2.data(), sizeof(int16_t) * n);
     if ((e = c->d_bls_tree.reserve(bytes)) != hipSuccess) return c->hip_fail(e, "hipMalloc(bls tree)");
     if ((e = c->d_bls_flag.reserve(sizeof(unsigned long long))) != hipSuccess) return c->hip_fail(e, "hipMalloc(bls flag)");
+    if (!c->bls_first_bad && (e = hipHostMalloc(reinterpret_cast<void**>(&c->bls_first_bad), sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
+        return c->hip_fail(e, "hipHostMalloc(bls flag)");
     if ((e = hipMemcpy(c->d_bls_tree.ptr, host.data(), bytes, hipMemcpyHostToDevice)) != hipSuccess) return c->hip_fail(e, "hipMemcpy(bls tree)");
     unsigned char* base = c->d_bls_tree.as<unsigned char>();
     c->bls_tree.len = reinterpret_cast<const double*>(base);

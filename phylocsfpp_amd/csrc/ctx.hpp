@@ -60,7 +60,7 @@ struct pcsf_ctx {
     pcsf::DeviceBuffer d_bls_tree, d_bls_out, d_bls_spans, d_bls_flag;
     pcsf::BlsTree bls_tree{};
     bool bls_ready = false;
-    unsigned long long bls_first_bad = pcsf::BLS_NO_BAD;  // host copy of the kernel's character check
+    unsigned long long* bls_first_bad = nullptr;  // page-locked host copy of the kernel's character check
     uint32_t stamp_block = 0;
     hipStream_t stream = nullptr;        // private stream for host-pointer entry points
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -73,6 +73,7 @@ struct pcsf_ctx {
 
     ~pcsf_ctx()
     {
+        if (bls_first_bad) (void)hipHostFree(bls_first_bad);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);

@@ -364,7 +364,7 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             std::lock_guard<std::mutex> g(lock);
             free_list.push_back(f);
         }
-    } pool(backend), score_pool(backend), bls_pool(backend);  // batch matrices; score vectors; branch-length scores (sizes differ: kept apart)
+    } pool(backend), score_pool(backend);  // batch matrices; score vectors (different sizes: kept apart)
     struct Batch {  // alignments scored by one backend call, their nucleotides packed leaf-major
         std::vector<Item*> items;
         size_t stride = 0;
@@ -372,7 +372,6 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         std::vector<uint64_t> col0, start_pos, chrom_len;
         std::vector<uint32_t> len;
         std::pair<char*, size_t> score_mem{nullptr, 0};  // page-locked, from the pool
-        std::pair<char*, size_t> bls_mem{nullptr, 0};    // [stride] per-base branch-length scores from the backend
         const double* scores = nullptr;    // filled by the backend
         size_t n_scores = 0;
         std::vector<uint64_t> offsets;
@@ -497,8 +496,6 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             });
             if (batch->score_mem.first) score_pool.put(batch->score_mem);
             batch->score_mem = {nullptr, 0};
-            if (batch->bls_mem.first) bls_pool.put(batch->bls_mem);
-            batch->bls_mem = {nullptr, 0};
             batch->scores = nullptr;
             return ww.lap();
         });
@@ -511,13 +508,10 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             StopWatch bw;
             if (need_raw) {
                 const size_t cap_scores = 2 * b->stride;  // six frames of len/3 codons each
-                b->score_mem = score_pool.get(cap_scores * sizeof(double));
+                // one page-locked buffer: the scores, then (device branch-length scores) one value per column
+                b->score_mem = score_pool.get((cap_scores + (dev_bls ? b->stride : 0)) * sizeof(double));
                 double* out = reinterpret_cast<double*>(b->score_mem.first);
-                double* bls_out = nullptr;
-                if (dev_bls) {
-                    b->bls_mem = bls_pool.get(b->stride * sizeof(double));
-                    bls_out = reinterpret_cast<double*>(b->bls_mem.first);
-                }
+                double* bls_out = dev_bls ? out + cap_scores : nullptr;
                 b->n_scores = backends[d]->score_alignments_6frames(model.n_leaves, b->nucl.first, b->stride, b->col0, b->len, b->start_pos, b->chrom_len,
                                                                     out, cap_scores, b->offsets, b->n_codons, bls_out);
                 b->scores = out;

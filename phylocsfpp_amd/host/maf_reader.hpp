@@ -108,7 +108,7 @@ public:
     {
         // a block belongs to this job when the newline before its "a " lies inside the range
         if (pos_ >= size_ || (pos_ > 0 && pos_ - 1 >= end_)) return false;
-        aln.seqs.assign(n_leaves_, std::string());
+        if (!scan_only_) aln.seqs.assign(n_leaves_, std::string());
         bool first_block = true, stop = !concatenate_, reached_bp = false, freeze_restart = false;
         size_t restart_pos = pos_;
         int ref_leaf = -1;
@@ -133,13 +133,8 @@ public:
                     stop = true;  // not contiguous: this block starts the next alignment
                     break;
                 }
-                auto it = names_.find(*s.species_key);
-                if (it == names_.end()) {
-                    if (unknown_.insert(*s.species_key).second && verbose_)
-                        fprintf(stderr, "WARNING: species %s in the alignment file is not part of the model\n", s.species_key->c_str());
-                    continue;
-                }
-                const int leaf = it->second;
+                const int leaf = leaf_of(s);
+                if (leaf < 0) continue;  // not part of the model
                 if (first_block && ref_leaf == -1) {
                     aln.start_pos = s.start + 1;
                     aln.chrom = s.chrom_str();
@@ -164,26 +159,44 @@ public:
                         throw std::runtime_error("alignment block does not start with the reference species: " + s.species_str() + "." + s.chrom_str());
                     check_strand(s);
                 }
+                if (scan_only_) {  // the block's reference row has been seen: nothing else in it decides where the alignment ends
+                    skip_to_next_block();
+                    break;
+                }
                 aln.seqs[leaf].append(s.text, s.text_len);
             }
             if (ref_leaf < 0) throw std::runtime_error("alignment block without any species of the model");
+            first_block = false;
+            if (scan_only_) continue;
             const size_t L = aln.seqs[ref_leaf].size();
             for (auto& row : aln.seqs)
                 if (row.size() != L) row.append(L - row.size(), 'N');
-            first_block = false;
         }
         if (reached_bp && ref_bases >= ref_bases_at_bp + 2) stop = true;
         if (stop && concatenate_) pos_ = restart_pos;
+        if (scan_only_) return true;
 
         // remove the columns where the reference row is a gap
+        // (the kept columns as runs between the gaps: every row is compacted with one memmove per run)
         const std::string& ref = aln.seqs[ref_leaf];
-        keep_.clear();
-        for (size_t i = 0; i < ref.size(); ++i)
-            if (ref[i] != '-') keep_.push_back(static_cast<uint32_t>(i));
-        if (keep_.size() != ref.size()) {
+        runs_.clear();
+        size_t kept = 0;
+        for (size_t i = 0, n = ref.size(); i < n;) {
+            const void* g = memchr(ref.data() + i, '-', n - i);
+            const size_t j = g ? static_cast<size_t>(static_cast<const char*>(g) - ref.data()) : n;
+            if (j > i) runs_.push_back({i, j - i});
+            kept += j - i;
+            i = j;
+            while (i < n && ref[i] == '-') ++i;
+        }
+        if (kept != ref.size()) {
             for (auto& row : aln.seqs) {
-                for (size_t w = 0; w < keep_.size(); ++w) row[w] = row[keep_[w]];
-                row.resize(keep_.size());
+                size_t w = 0;
+                for (const auto& r : runs_) {
+                    if (r.first != w) memmove(&row[w], &row[r.first], r.second);
+                    w += r.second;
+                }
+                row.resize(kept);
             }
         }
         if (reached_bp && ref_bases > ref_bases_at_bp + 2)
@@ -222,19 +235,28 @@ private:
         const size_t keep_end = end_;
         end_ = size_;
         pos_ = prev;
+        // only where that alignment ends matters: walk its blocks looking at the reference rows alone
         Alignment scratch;
         const bool verbose = verbose_;
         verbose_ = false;
+        scan_only_ = true;
         next(scratch);
+        scan_only_ = false;
         verbose_ = verbose;
         end_ = keep_end;
     }
 
     struct SLine {  // views into the mapped file, except `species` (lower-cased copy in a buffer that is reused)
-        const std::string* species_key = nullptr;
+        const char* species = nullptr;  // as written in the file (the model's names are lower case)
+        size_t species_len = 0;
         const char* chrom = nullptr;
         size_t chrom_len = 0;
-        std::string species_str() const { return *species_key; }
+        std::string species_str() const
+        {
+            std::string k(species, species_len);
+            for (char& c : k) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+            return k;
+        }
         std::string chrom_str() const { return std::string(chrom, chrom_len); }
         bool chrom_is(const std::string& c) const { return c.size() == chrom_len && memcmp(c.data(), chrom, chrom_len) == 0; }
         uint64_t start = 0, size = 0, src_size = 0;
@@ -242,6 +264,14 @@ private:
         const char* text = nullptr;
         size_t text_len = 0;
     };
+
+    // to the next line that starts a block ('a'), from the start of a line
+    void skip_to_next_block()
+    {
+        if (pos_ >= size_ || data_[pos_] == 'a') return;
+        const void* hit = memmem(data_ + pos_, size_ - pos_, "\na", 2);
+        pos_ = hit ? static_cast<size_t>(static_cast<const char*>(hit) - data_) + 1 : size_;
+    }
 
     void skip_line()
     {
@@ -263,7 +293,12 @@ private:
             while (p < e && *p == ' ') ++p;
             if (p >= e) break;
             const char* b = p;
-            while (p < e && *p != ' ') ++p;
+            if (k == 6) {  // the sequence: almost the whole line, searched with memchr instead of byte by byte
+                const void* sp = memchr(p, ' ', static_cast<size_t>(e - p));
+                p = sp ? static_cast<const char*>(sp) : e;
+            } else {
+                while (p < e && *p != ' ') ++p;
+            }
             tok[k] = b;
             len[k] = static_cast<size_t>(p - b);
             ++k;
@@ -272,9 +307,8 @@ private:
         SLine s;
         const char* dot = static_cast<const char*>(memchr(tok[1], '.', len[1]));
         if (!dot) throw std::runtime_error("MAF source '" + std::string(tok[1], len[1]) + "' is not of the form species.chrom");
-        key_.assign(tok[1], static_cast<size_t>(dot - tok[1]));  // no allocation once the buffer has grown
-        for (char& c : key_) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
-        s.species_key = &key_;
+        s.species = tok[1];
+        s.species_len = static_cast<size_t>(dot - tok[1]);
         s.chrom = dot + 1;
         s.chrom_len = len[1] - static_cast<size_t>(dot + 1 - tok[1]);
         auto number = [](const char* p, size_t n) {  // atoi semantics for the plain non-negative integers of a MAF
@@ -296,6 +330,28 @@ private:
         return s;
     }
 
+    // leaf of the line's species, -1 if the model does not have it.  A small direct-mapped table keyed by the name as
+    // written in the file answers the repeats (a MAF names the same few species in every block) with one memcmp; the
+    // lower-casing and the hash look-ups happen only for a name not seen recently.
+    int leaf_of(const SLine& s)
+    {
+        uint64_t h = s.species_len;
+        for (size_t i = 0; i < s.species_len; ++i) h = (h ^ static_cast<unsigned char>(s.species[i])) * 0x100000001b3ull;
+        if (recent_.empty()) recent_.resize(RECENT_SLOTS);
+        Recent& r = recent_[(h ^ (h >> 29)) & (RECENT_SLOTS - 1)];
+        if (r.used && r.name.size() == s.species_len && memcmp(r.name.data(), s.species, s.species_len) == 0) return r.leaf;
+        key_.assign(s.species, s.species_len);  // no allocation once the buffer has grown
+        for (char& c : key_) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+        const auto it = names_.find(key_);
+        const int leaf = it == names_.end() ? -1 : it->second;
+        if (leaf < 0 && unknown_.insert(key_).second && verbose_)
+            fprintf(stderr, "WARNING: species %s in the alignment file is not part of the model\n", key_.c_str());
+        r.name.assign(s.species, s.species_len);
+        r.leaf = leaf;
+        r.used = true;
+        return leaf;
+    }
+
     void check_strand(const SLine& s) const
     {
         if (concatenate_ && s.strand != '+')
@@ -305,12 +361,20 @@ private:
     const std::unordered_map<std::string, int>& names_;
     int n_leaves_;
     bool concatenate_, verbose_;
+    bool scan_only_ = false;  // next() walks the blocks of an alignment without collecting its rows (init())
     std::unique_ptr<MafFile> own_;
     const char* data_ = nullptr;
     size_t size_ = 0, pos_ = 0, end_ = 0;
     std::unordered_set<std::string> unknown_;
-    std::string key_;  // lower-cased species name of the line being parsed
-    std::vector<uint32_t> keep_;
+    std::string key_;  // lower-cased species name of the line being looked up
+    struct Recent {
+        std::string name;  // as written in the file
+        int leaf = -1;
+        bool used = false;
+    };
+    static constexpr size_t RECENT_SLOTS = 1024;
+    std::vector<Recent> recent_;
+    std::vector<std::pair<size_t, size_t>> runs_;  // (first column, length) of the runs of non-gap reference columns
 };
 
 }  // namespace pcsf_host
