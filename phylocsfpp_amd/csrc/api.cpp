@@ -164,8 +164,7 @@ static int bls_columns(pcsf_ctx* c, const char* nucleotides, size_t row_stride, 
     hipError_t e;
     const size_t nl = static_cast<size_t>(c->n_leaves);
     if ((e = c->d_nucl.reserve(nl * n_cols)) != hipSuccess) return c->hip_fail(e, "hipMalloc(nucleotides)");
-    if ((e = hipMemcpy2DAsync(c->d_nucl.ptr, n_cols, nucleotides, row_stride, n_cols, nl, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
-        return c->hip_fail(e, "hipMemcpy2DAsync(nucleotides)");
+    if ((e = upload_rows(c->d_nucl.ptr, nucleotides, row_stride, n_cols, nl, c->stream)) != hipSuccess) return c->hip_fail(e, "upload(nucleotides)");
     int rc = bls_enqueue(c, c->d_nucl.as<unsigned char>(), n_cols, n_cols, spans);
     if (rc == PCSF_OK) rc = bls_download(c, n_cols, out);
     if (rc != PCSF_OK) return rc;
@@ -403,8 +402,7 @@ int pcsf_score_sites_fixed(pcsf_ctx* c, const uint8_t* codons, size_t n_sites, s
     if ((e = c->d_codons.reserve(nl * n_sites)) != hipSuccess) return c->hip_fail(e, "hipMalloc(codons)");
     if ((e = c->d_out.reserve(n_sites * sizeof(double))) != hipSuccess) return c->hip_fail(e, "hipMalloc(out)");
     // compact the leaf-major matrix while copying (device stride = n_sites)
-    if ((e = hipMemcpy2DAsync(c->d_codons.ptr, n_sites, codons, leaf_stride, n_sites, nl, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
-        return c->hip_fail(e, "hipMemcpy2DAsync(codons)");
+    if ((e = pcsf::upload_rows(c->d_codons.ptr, codons, leaf_stride, n_sites, nl, c->stream)) != hipSuccess) return c->hip_fail(e, "upload(codons)");
     int rc = pcsf::launch_fixed(c, c->d_codons.as<uint8_t>(), n_sites, n_sites, c->d_out.as<double>(), nullptr, nullptr, c->stream);
     if (rc != PCSF_OK) return rc;
     if ((e = hipMemcpyAsync(out, c->d_out.ptr, n_sites * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
@@ -471,8 +469,7 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
     if ((e = c->d_segments.reserve(seg.size() * sizeof(pcsf::FrameSegment))) != hipSuccess) return c->hip_fail(e, "hipMalloc(segments)");
     if ((e = c->d_codons.reserve(nl * total)) != hipSuccess) return c->hip_fail(e, "hipMalloc(codons)");
     if ((e = c->d_out.reserve(total * sizeof(double))) != hipSuccess) return c->hip_fail(e, "hipMalloc(out)");
-    if ((e = hipMemcpy2DAsync(c->d_nucl.ptr, max_col, nucleotides, row_stride, max_col, nl, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
-        return c->hip_fail(e, "hipMemcpy2DAsync(nucleotides)");
+    if ((e = pcsf::upload_rows(c->d_nucl.ptr, nucleotides, row_stride, max_col, nl, c->stream)) != hipSuccess) return c->hip_fail(e, "upload(nucleotides)");
     if ((e = hipMemcpyAsync(c->d_segments.ptr, seg.data(), seg.size() * sizeof(pcsf::FrameSegment), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
         return c->hip_fail(e, "hipMemcpyAsync(segments)");
     int rc;

@@ -102,7 +102,7 @@ struct BlockEngine {
         HIP_TRY(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
         if (n_sites_total > 0) {
             HIP_TRY(d_codons.reserve(static_cast<size_t>(nl) * n_sites_total));
-            HIP_TRY(hipMemcpy2DAsync(d_codons.ptr, n_sites_total, codons, stride, n_sites_total, nl, hipMemcpyHostToDevice, stream));
+            HIP_TRY(upload_rows(d_codons.ptr, codons, stride, n_sites_total, nl, stream));
         }
         // which rows of each leaf's message table the block's sites read (values above 64 count as 64, like the kernel)
         leaf_codes.assign(nb * static_cast<size_t>(nl) * 2, 0);
@@ -394,7 +394,7 @@ int run_fixed(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
         HIP_TRY(c->d_codons.reserve(nl * n_sites));
         HIP_TRY(c->d_lnz.reserve(2 * n_sites * sizeof(double)));
         HIP_TRY(c->d_anc.reserve(2 * n_sites * sizeof(double)));
-        HIP_TRY(hipMemcpy2DAsync(c->d_codons.ptr, n_sites, codons, leaf_stride, n_sites, nl, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(upload_rows(c->d_codons.ptr, codons, leaf_stride, n_sites, nl, c->stream));
         const int rc = launch_fixed(c, c->d_codons.as<uint8_t>(), n_sites, n_sites, nullptr, c->d_lnz.as<double>(),
                                     compute_anc ? c->d_anc.as<double>() : nullptr, c->stream);
         if (rc != PCSF_OK) return rc;

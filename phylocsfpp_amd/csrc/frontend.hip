@@ -27,14 +27,17 @@ __global__ __launch_bounds__(256) void extract_frames_kernel(const FrameSegment*
                                                              size_t row_stride, int n_leaves, unsigned char* __restrict__ codons,
                                                              size_t leaf_stride)
 {
+    // 64 codons x 4 groups of species per work-group: a wave writes 64 consecutive codons of one species row, and the
+    // four waves walk different species (shorter dependent chains than one thread per codon over all species)
     const FrameSegment s = seg[blockIdx.y];
-    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t c = blockIdx.x * 64u + (threadIdx.x & 63u);
     if (c >= s.n_codons) return;
     const bool minus = s.minus != 0;
     // '+': columns col0+skip+3c .. +2 ; '-': the reverse-complemented row starts at the last column
     const size_t first = minus ? s.col0 + s.len - 1 - s.skip - 3 * static_cast<size_t>(c) : s.col0 + s.skip + 3 * static_cast<size_t>(c);
     const size_t dst = s.dst0 + (minus ? (s.n_codons - 1 - c) : c);
-    for (int l = 0; l < n_leaves; ++l) {
+#pragma unroll 4
+    for (int l = static_cast<int>(threadIdx.x >> 6); l < n_leaves; l += 4) {
         const unsigned char* row = nucl + static_cast<size_t>(l) * row_stride;
         unsigned a, b, d;
         if (minus) {
@@ -59,7 +62,7 @@ hipError_t launch_extract_frames(const FrameSegment* d_seg, uint32_t n_segments,
 {
     if (n_segments == 0 || max_codons == 0) return hipSuccess;
     if (n_segments > 65535u) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(extract_frames_kernel, dim3((max_codons + 255u) / 256u, n_segments), dim3(256), 0, stream, d_seg, d_nucl, row_stride,
+    hipLaunchKernelGGL(extract_frames_kernel, dim3((max_codons + 63u) / 64u, n_segments), dim3(256), 0, stream, d_seg, d_nucl, row_stride,
                        n_leaves, d_codons, leaf_stride);
     return hipGetLastError();
 }
