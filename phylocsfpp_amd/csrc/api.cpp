@@ -9,6 +9,7 @@
 #include <cstring>
 #include <memory>
 #include <new>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -18,6 +19,17 @@
 
 namespace {
 thread_local std::string g_create_error;
+
+// Contexts that share a GPU run their six-frame calls' KERNELS one call after the other, in the order the calls
+// arrive here, while the transfers of one call overlap the kernels of the other: two pruning launches resident at
+// the same time only slow each other down (measured), a transfer under a kernel is free.  Per device: the event
+// recorded behind the kernels of the call that was enqueued last.
+struct KernelTurn {
+    std::mutex lock;
+    hipEvent_t last = nullptr;
+    const pcsf_ctx* owner = nullptr;
+};
+KernelTurn g_kernel_turn[64];
 }  // namespace
 
 using pcsf::DeviceBuffer;
@@ -306,7 +318,7 @@ int pcsf_create(pcsf_ctx** out, const pcsf_model_desc* m, int device_id)
         return PCSF_ERR_HIP;
     }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+        (e = hipEventCreateWithFlags(&c->ev_kernels, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
         g_create_error = std::string("stream/event creation: ") + hipGetErrorString(e);
         return PCSF_ERR_HIP;
     }
@@ -338,6 +350,14 @@ void pcsf_destroy(pcsf_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    {
+        KernelTurn& turn = g_kernel_turn[c->device & 63];
+        std::lock_guard<std::mutex> g(turn.lock);
+        if (turn.owner == c) {
+            turn.last = nullptr;
+            turn.owner = nullptr;
+        }
+    }
     delete c;
 }
 
@@ -473,6 +493,9 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
     if ((e = hipMemcpyAsync(c->d_segments.ptr, seg.data(), seg.size() * sizeof(pcsf::FrameSegment), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
         return c->hip_fail(e, "hipMemcpyAsync(segments)");
     int rc;
+    KernelTurn& turn = g_kernel_turn[c->device & 63];
+    std::unique_lock<std::mutex> my_turn(turn.lock);
+    if (turn.last && turn.owner != c && (e = hipStreamWaitEvent(c->stream, turn.last, 0)) != hipSuccess) return c->hip_fail(e, "hipStreamWaitEvent");
     // the power track's per-base scores from the same resident rows
     if (out_bls && (rc = pcsf::bls_enqueue(c, c->d_nucl.as<unsigned char>(), max_col, max_col, spans)) != PCSF_OK) return rc;
     // at most 65535 segments per launch (grid.y)
@@ -483,6 +506,10 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
             return c->hip_fail(e, "launch extract_frames");
     }
     if ((rc = pcsf::launch_fixed(c, c->d_codons.as<uint8_t>(), total, total, c->d_out.as<double>(), nullptr, nullptr, c->stream)) != PCSF_OK) return rc;
+    if ((e = hipEventRecord(c->ev_kernels, c->stream)) != hipSuccess) return c->hip_fail(e, "hipEventRecord");
+    turn.last = c->ev_kernels;
+    turn.owner = c;
+    my_turn.unlock();
     if ((e = hipMemcpyAsync(out_scores, c->d_out.ptr, total * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
         return c->hip_fail(e, "hipMemcpyAsync(out)");
     if (out_bls && (rc = pcsf::bls_download(c, max_col, out_bls)) != PCSF_OK) return rc;

@@ -72,6 +72,7 @@ struct pcsf_ctx {
     unsigned long long* bls_first_bad = nullptr;  // page-locked host copy of the kernel's character check
     uint32_t stamp_block = 0;
     hipStream_t stream = nullptr;        // private stream for host-pointer entry points
+    hipEvent_t ev_kernels = nullptr;     // behind the kernels of this context's last six-frame call
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false;
     double last_kernel_ms = 0.0;
@@ -83,6 +84,7 @@ struct pcsf_ctx {
     ~pcsf_ctx()
     {
         if (bls_first_bad) (void)hipHostFree(bls_first_bad);
+        if (ev_kernels) (void)hipEventDestroy(ev_kernels);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);

@@ -29,6 +29,7 @@ public:
         device_bls_ = m.n_leaves <= 128 && pcsf_set_bls_branch_lengths(ctx_, m.branch_len_d.data()) == PCSF_OK;
     }
     bool device_bls() const override { return device_bls_; }
+    int contexts_per_device() const override { return 2; }
     ~HipBackend() override { pcsf_destroy(ctx_); }
     void score_sites_fixed(const uint8_t* codons, size_t n_sites, size_t leaf_stride, double* out) override
     {

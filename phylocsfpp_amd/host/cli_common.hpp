@@ -25,6 +25,7 @@ inline int usage(const char* prog)
             "  %s build-tracks [--output DIR] [--power-threshold 0|1] [--output-raw-phylo 0|1] [--output-power 0|1]\n"
             "                  [--output-phylo 0|1] [--output-regions 0|1] [--genome-length N --coding-exons FILE | --hmm-params P]\n"
             "                  [--species A,B,...] [--mapping FILE] [--species-aliases FILE] [--device N | --devices N,M,...]\n"
+            "                  [--threads N] [--window-bytes N] [--batch-sites N] [--contexts-per-device N] [--host-bls 0|1]\n"
             "                  <model prefix> <alignment.maf>...\n"
             "  %s score-msa    [--strategy fixed|mle|omega|fixed_mean] [--comp-phylo 0|1] [--comp-anc 0|1] [--comp-bls 0|1]\n"
             "                  [--output DIR] [--species A,B,...] [--mapping FILE] [--species-aliases FILE] [--device N | --devices N,M,...]\n"
@@ -139,6 +140,7 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
     ScoreMsaParams sm;
     std::string aliases, species, mapping;
     std::vector<int> devices{0};
+    int contexts_per_device = 0;
     int i = 2;
     for (; i < argc && strncmp(argv[i], "--", 2) == 0; i += 2) {
         if (i + 1 >= argc) return usage(argv[0]);
@@ -157,6 +159,7 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
         else if (k == "--threads") bt.threads = atoi(v.c_str());
         else if (k == "--batch-sites") bt.batch_sites = static_cast<size_t>(strtoull(v.c_str(), nullptr, 10));    // codon-frames per backend call
         else if (k == "--window-bytes") bt.window_bytes = static_cast<size_t>(strtoull(v.c_str(), nullptr, 10));  // MAF bytes per pipeline step
+        else if (k == "--contexts-per-device") contexts_per_device = atoi(v.c_str());  // build-tracks; 0 = what the backend suggests
         else if (k == "--host-bls") bt.host_bls = parse_bool(v);  // branch-length scores on the host instead of the scoring backend
         else if (k == "--species-aliases") aliases = v;
         else if (k == "--species") species = v;
@@ -248,6 +251,12 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
         for (int d : devices) {
             owned.push_back(make_backend(model, d));
             backends.push_back(owned.back().get());
+            // build-tracks: a second context on the same GPU puts the transfers of one call under the kernels of the other
+            const int per = cmd == "build-tracks" ? (contexts_per_device > 0 ? contexts_per_device : owned.back()->contexts_per_device()) : 1;
+            for (int k = 1; k < per; ++k) {
+                owned.push_back(make_backend(model, d));
+                backends.push_back(owned.back().get());
+            }
         }
         bool first = true;
         for (; i < argc; ++i) {

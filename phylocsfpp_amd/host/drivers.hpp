@@ -59,6 +59,9 @@ struct ScoringBackend {
     // true when score_alignments_6frames can also fill bls_out[row_stride] with the per-base branch-length scores of the
     // batch's columns (and then checks the characters itself); otherwise the driver computes them on the host
     virtual bool device_bls() const { return false; }
+    // how many contexts per device pay off in build-tracks (the HIP backend: two, their kernels take turns on the GPU
+    // while the transfers of one call run under the kernels of the other)
+    virtual int contexts_per_device() const { return 1; }
     virtual size_t score_alignments_6frames(int n_leaves, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0,
                                             const std::vector<uint32_t>& len, const std::vector<uint64_t>& start_pos,
                                             const std::vector<uint64_t>& chrom_len, double* out, size_t out_capacity, std::vector<uint64_t>& offsets,
