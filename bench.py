@@ -13,14 +13,25 @@ wig writer), done with RCCL inside the timed step.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  Extra objects: "roofline" (dominant kernel vs the fp64-MFMA
-peak; duration measured with HIP events on the launch stream) and "cpu_baseline" (the CPU
-oracle, a reference-structured port, timed on this host's cores; rank 0, N=1 only).
+Prints ONE JSON line on rank 0.  Extra objects:
+  "roofline"      dominant kernel vs the fp64-MFMA peak; duration measured with HIP events on the launch stream
+  "strong"        the same path in STRONG scaling: BASELINE.json configs[3]'s total (100 Mb = 200 M codon-frames) cut into
+                  contiguous 64-aligned ranges by phylocsfpp_amd.dist.shard_bounds, scores gathered to rank 0
+                  (--scaling strong makes this the headline line instead)
+  "end_to_end"    (N = 1) `phylocsf-amd build-tracks 58mammals <synthetic 1 Mb 100-species MAF>` -- text in, seven wig
+                  files out -- run in child processes (reference: src/phylocsf++build_tracks.hpp:55-260, README.rst:116)
+  "cpu_baseline"  (N = 1) the CPU oracle, a reference-structured port, on this host's cores: kernel level on a sample of
+                  the same batch ("value"), the same CLI driver on the same MAF ("end_to_end_value"), one thread
+                  ("single_thread_value")
 """
 import argparse
 import json
 import os
+import re
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -30,11 +41,17 @@ import numpy as np
 import torch
 
 MODEL = "58mammals"
+MODEL_PREFIX = os.path.join(ROOT, "tests", "golden", "models", MODEL)
 SITES_PER_GPU = 2_000_000           # 1 Mb reference x 2 strands x 3 frames / 3 bases per codon
+STRONG_TOTAL_SITES = 200_000_000    # BASELINE.json configs[3]: 100 Mb
 POOL_SITES = 1 << 17                # unique synthetic columns; the batch samples them with replacement
 ALIGNMENT_FRAMES = 600              # ~100 concatenated alignments x 6 frames in a 1 Mb MAF
 PEAK_FP64_MFMA_TFLOPS = 78.6        # MI355X fp64 matrix peak (vendor); 78.0 measured by tools/mfma_f64_bench
 METRIC = "alignment codons/sec (build-tracks, 58mammals) at 1/2/4/8 MI355X"
+E2E_BASES = 1_000_000               # BASELINE.json configs[2]
+E2E_SEED = 20261002
+CLI = os.path.join(ROOT, "phylocsfpp_amd", "host", "phylocsf-amd")
+ORACLE_CLI = os.path.join(ROOT, "oracle", "_build", "oracle_cli")
 
 
 def flop_per_site(nl):
@@ -42,21 +59,24 @@ def flop_per_site(nl):
     return 2 * ((nl - 2) * 2 * 64 * 64 + (nl - 1) * 64 + 2 * 64)
 
 
-def load_model_arrays(name):
-    """Model files -> arrays (host-side mirror of load_model, reference src/models.hpp:1757).
-    Only the file readers of the test binding are used here; nothing is computed by the oracle."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_binding as ob
-    return ob.OracleModel(os.path.join(ROOT, "tests", "golden", "models", name))
-
-
-def make_batch(m, n_sites, seed):
+def make_pool(m, seed):
     from phylocsfpp_amd import synth
-    pool = synth.synthetic_codon_columns(m.child1, m.child2, m.branch_len, m.S_c, m.pi_c, m.S_nc, m.pi_nc,
+    return synth.synthetic_codon_columns(m.child1, m.child2, m.branch_len, m.S_c, m.pi_c, m.S_nc, m.pi_nc,
                                          POOL_SITES, seed=seed)
-    rng = np.random.default_rng(seed + 1)
-    idx = rng.integers(0, POOL_SITES, size=n_sites)
-    return np.ascontiguousarray(pool[:, idx])
+
+
+def sample_columns(pool_dev, lo, hi, seed):
+    """Columns [lo, hi) of the endless synthetic site stream of `seed`: column i is pool column hash(i, seed), so any
+    rank can materialise any range of the SAME stream on its own GPU (one shared generator seed, per-rank slice)."""
+    i = torch.arange(lo, hi, dtype=torch.int64, device=pool_dev.device)
+    mult, add = 0x1E3779B97F4A7C15, (seed * 0x632BE59BD9B4E019) & 0x3FFFFFFFFFFFFFFF
+    idx = ((i * mult + add) >> 23) & (POOL_SITES - 1)   # int64 wrap-around is intended
+    del i
+    out = torch.empty((pool_dev.shape[0], hi - lo), dtype=torch.uint8, device=pool_dev.device)
+    step = 1 << 24
+    for a in range(0, hi - lo, step):   # bounded temporaries for 200 M columns
+        out[:, a:a + step] = pool_dev[:, idx[a:a + step]]
+    return out
 
 
 def effective_cpus():
@@ -72,10 +92,22 @@ def effective_cpus():
     return max(1, n)
 
 
-def cpu_baseline(m, codons, budget_sites):
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(codons, budget_sites):
     """Times the oracle's reference-structured run_tracks loop (model re-instantiated per
     alignment x frame, scalar pruning per codon, OpenMP schedule(dynamic,1) over alignments)."""
-    import oracle_binding as ob  # noqa: F401  (cpu_baseline leg: the oracle is the thing timed here)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob  # cpu_baseline leg: the oracle is the thing timed here
+    m = ob.OracleModel(MODEL_PREFIX)
     n = min(budget_sites, codons.shape[1])
     n_units = max(1, int(round(ALIGNMENT_FRAMES * n / SITES_PER_GPU)))
     off = np.linspace(0, n, n_units + 1).astype(np.uint64)
@@ -84,10 +116,113 @@ def cpu_baseline(m, codons, budget_sites):
     t0 = time.perf_counter()
     m.baseline_run_tracks(sample, off, threads=threads)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "codon-frames/s", "cores": threads, "kind": "port",
+    return {"value": n / dt, "unit": "codon-frames/s", "cores": threads, "kind": "port", "cpu_model": cpu_model_name(),
             "sample": "%d codon-frames in %d alignment-frames of the same batch, %.1f s; reference-structured port "
                       "(model re-instantiated per alignment-frame, scalar pruning), OpenMP schedule(dynamic,1) over "
                       "alignment-frames on %d threads (cgroup CPU quota of this host)" % (n, n_units, dt, threads)}
+
+
+STATS_RE = re.compile(r"(\d+) alignments, (\d+) reference bases, (\d+) codon-frames, (\d+) backend calls")
+SECONDS_RE = re.compile(r"seconds: total ([\d.]+); .*MAF read ([\d.]+), BLS ([\d.]+), batch packing ([\d.]+) \| scoring backend ([\d.]+) \| "
+                        r"wig output ([\d.]+) \| smoothing ([\d.]+)")
+
+
+def run_cli(binary, maf, out_dir, extra_args=(), env=None):
+    """One build-tracks run in a child process; returns the driver's own statistics and the process wall time."""
+    os.makedirs(out_dir, exist_ok=True)
+    cmd = [binary, "build-tracks", "--output", out_dir] + list(extra_args) + [MODEL_PREFIX, maf]
+    t0 = time.perf_counter()
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    wall = time.perf_counter() - t0
+    if p.returncode != 0:
+        raise RuntimeError("%s failed (%d): %s" % (" ".join(cmd), p.returncode, p.stderr[-2000:]))
+    a, s = STATS_RE.search(p.stderr), SECONDS_RE.search(p.stderr)
+    if not a or not s:
+        raise RuntimeError("cannot parse the statistics of %s: %s" % (binary, p.stderr[-2000:]))
+    return {"alignments": int(a.group(1)), "ref_bases": int(a.group(2)), "codon_frames": int(a.group(3)), "backend_calls": int(a.group(4)),
+            "seconds": float(s.group(1)), "process_wall_seconds": wall,
+            "stage_busy": {"maf_read": float(s.group(2)), "bls": float(s.group(3)), "batch_packing": float(s.group(4)),
+                           "scoring_backend": float(s.group(5)), "wig_output": float(s.group(6)), "smoothing": float(s.group(7))}}
+
+
+def maf_prefix(src, dst, fraction):
+    """The first `fraction` of a MAF, cut behind a complete alignment block."""
+    size = os.path.getsize(src)
+    want = max(1 << 16, int(size * fraction))
+    with open(src, "rb") as f:
+        data = f.read(min(size, want))
+    cut = data.rfind(b"\n\n")
+    with open(dst, "wb") as f:
+        f.write(data[:cut + 2] if cut > 0 else data)
+    return os.path.getsize(dst)
+
+
+WIGS = ["PhyloCSFpower.wig"] + ["PhyloCSFRaw%s%d.wig" % (s, f) for s in "+-" for f in (1, 2, 3)]
+
+
+def differing_lines(dir_a, dir_b):
+    """Number of differing text lines over the seven wig files of two runs (None if a file is missing)."""
+    total = 0
+    for w in WIGS:
+        pa_, pb_ = os.path.join(dir_a, w), os.path.join(dir_b, w)
+        if not (os.path.exists(pa_) and os.path.exists(pb_)):
+            return None
+        a, b = open(pa_, "rb").read(), open(pb_, "rb").read()
+        if a != b:
+            la, lb = a.split(b"\n"), b.split(b"\n")
+            total += abs(len(la) - len(lb)) + sum(1 for x, y in zip(la, lb) if x != y)
+    return total
+
+
+def end_to_end(device, runs, cpu_rate_all_cores, work_dir):
+    """north_star's workload: build-tracks 58mammals on a synthetic 100-species MAF, text to wig files, GPU CLI and
+    the oracle-backed CPU driver (same host code, CPU scoring) on the same file."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_synthetic_maf as gen
+    maf = os.path.join(work_dir, "synthetic_%dbp_seed%d.maf" % (E2E_BASES, E2E_SEED))
+    t0 = time.perf_counter()
+    info = gen.generate(maf, bases=E2E_BASES, seed=E2E_SEED)
+    gen_s = time.perf_counter() - t0
+    cpus = effective_cpus()
+    gpu_runs = [run_cli(CLI, maf, os.path.join(work_dir, "gpu"), ["--device", str(device)]) for _ in range(runs)]
+    best = min(gpu_runs, key=lambda r: r["seconds"])
+    e2e = {"command": "phylocsf-amd build-tracks --device %d %s <maf>" % (device, os.path.relpath(MODEL_PREFIX, ROOT)),
+           "maf": "tools/gen_synthetic_maf.py --bases %d --seed %d: %d species rows (58 mapped by the model), %d blocks, %d bytes; generated in %.1f s"
+                  % (E2E_BASES, E2E_SEED, info["rows"], info["blocks"], info["bytes"], gen_s),
+           "maf_bytes": info["bytes"], "codon_frames": best["codon_frames"], "ref_bases": best["ref_bases"], "alignments": best["alignments"],
+           "backend_calls": best["backend_calls"], "runs": runs, "host_threads": cpus,
+           "seconds": best["seconds"], "seconds_all_runs": [r["seconds"] for r in gpu_runs],
+           "process_wall_seconds": best["process_wall_seconds"],
+           "codon_frames_per_s": best["codon_frames"] / best["seconds"],
+           "maf_gigabytes_per_s": info["bytes"] / best["seconds"] / 1e9,
+           "stage_busy": best["stage_busy"],
+           "note": "seconds = build_tracks() inside the child process (file mapped, parsed, scored, seven wig files written); "
+                   "process_wall_seconds adds process start, HIP initialisation and model set-up"}
+    # CPU driver on the same file, or on a prefix sized for ~20 s when the whole file would take longer than ~30 s
+    env = dict(os.environ, PCSF_THREADS=str(cpus), OMP_NUM_THREADS=str(cpus))
+    est = best["codon_frames"] / max(cpu_rate_all_cores, 1.0)
+    frac = 1.0 if est <= 30.0 else 20.0 / est
+    cpu_maf = maf
+    if frac < 1.0:
+        cpu_maf = os.path.join(work_dir, "cpu_prefix.maf")
+        maf_prefix(maf, cpu_maf, frac)
+    cpu_run = run_cli(ORACLE_CLI, cpu_maf, os.path.join(work_dir, "cpu"), env=env)
+    cpu = {"end_to_end_value": cpu_run["codon_frames"] / cpu_run["seconds"], "end_to_end_seconds": cpu_run["seconds"],
+           "end_to_end_sample": ("the whole file" if frac >= 1.0 else "the first %.1f %% of the file" % (100 * frac)) +
+                                ": %d codon-frames, oracle/_build/oracle_cli build-tracks (the product's host driver on the CPU oracle), %d threads"
+                                % (cpu_run["codon_frames"], cpus)}
+    if frac >= 1.0:
+        e2e["wig_lines_differing_from_cpu_driver"] = differing_lines(os.path.join(work_dir, "gpu"), os.path.join(work_dir, "cpu"))
+    # one thread: a prefix sized for ~10 s
+    est1 = best["codon_frames"] / max(cpu_rate_all_cores / cpus, 1.0)
+    one_maf = os.path.join(work_dir, "cpu_one_thread.maf")
+    maf_prefix(maf, one_maf, min(1.0, 10.0 / est1))
+    env1 = dict(os.environ, PCSF_THREADS="1", OMP_NUM_THREADS="1")
+    one = run_cli(ORACLE_CLI, one_maf, os.path.join(work_dir, "cpu1"), ["--threads", "1"], env=env1)
+    cpu["single_thread_value"] = one["codon_frames"] / one["seconds"]
+    cpu["single_thread_sample"] = "%d codon-frames of the same file in %.1f s, same driver, 1 thread" % (one["codon_frames"], one["seconds"])
+    e2e["vs_cpu_driver"] = e2e["codon_frames_per_s"] / cpu["end_to_end_value"]
+    return e2e, cpu
 
 
 def main():
@@ -95,9 +230,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--sites", type=int, default=SITES_PER_GPU, help="codon-frames per GPU per step")
+    ap.add_argument("--sites", type=int, default=SITES_PER_GPU, help="codon-frames per GPU per step (weak scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="strong: --total-sites codon-frames are cut into per-rank ranges (BASELINE.json configs[3])")
+    ap.add_argument("--total-sites", type=int, default=STRONG_TOTAL_SITES, help="codon-frames of the whole job in strong scaling")
+    ap.add_argument("--strong-steps", type=int, default=2, help="steps of the extra strong-scaling leg of a weak run (0 disables)")
     ap.add_argument("--cpu-baseline-sites", type=int, default=-1,
-                    help="codon-frames for the CPU baseline sample (default: sized for ~10-30 s; 0 disables)")
+                    help="codon-frames for the CPU baseline sample (default: sized for ~10 s; 0 disables the CPU legs)")
+    ap.add_argument("--end-to-end-runs", type=int, default=3, help="build-tracks CLI runs on the synthetic 1 Mb MAF (0 disables; N = 1 only)")
+    ap.add_argument("--keep-files", default=None, help="directory for the synthetic MAF and the wig files (default: a temporary one)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,45 +258,69 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import phylocsfpp_amd as pa
-    m = load_model_arrays(MODEL)
-    ctx = pa.ScoringContext(m.child1, m.child2, m.branch_len, m.S_c, m.pi_c, m.S_nc, m.pi_nc, device=local_rank)
-    n_sites = args.sites
-    codons_host = make_batch(m, n_sites, seed=20261002 + rank)
-    codons = torch.from_numpy(codons_host).to(dev)
-    scores = torch.empty(n_sites, dtype=torch.float64, device=dev)
-    # N > 1: two score buffers per rank; the gather of step k (RCCL, its own stream) runs while step k+1 is scored
-    pipe = None
-    if world > 1:
-        from phylocsfpp_amd import dist as pdist
-        pipe = pdist.ScoreGatherPipeline(n_sites, torch.float64, dev, depth=2, dst=0)
+    from phylocsfpp_amd import dist as pdist
+    m = pa.load_model(MODEL_PREFIX)                 # the package's own reader (C-ABI pcsf_model_open)
+    ctx = m.context(device=local_rank)
+    pool_host = make_pool(m, seed=E2E_SEED)
+    pool = torch.from_numpy(pool_host).to(dev)
 
-    def step():
-        if pipe is None:
-            ctx.score_sites_fixed_torch(codons, out=scores)
-        else:
-            ctx.score_sites_fixed_torch(codons, out=pipe.acquire())
-            pipe.submit()
+    def timed(step, fence, steps, warmup):
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
 
-    def fence():
-        if pipe is not None:
-            pipe.drain()       # every rank's scores of every step have arrived on rank 0
-            dist.barrier()
-        torch.cuda.synchronize()
+    def run_leg(n_local, lo, steps, warmup):
+        """Scores columns [lo, lo + n_local) of the synthetic stream `steps` times; N > 1: two score buffers per rank, the
+        gather of step k (RCCL, its own stream) runs while step k+1 is scored.  Ragged strong-scaling shards are padded to
+        the widest shard for the gather (like dist.gather_to_root)."""
+        codons = sample_columns(pool, lo, lo + n_local, E2E_SEED)
+        width = n_local
+        if world > 1:
+            w = torch.tensor([n_local], dtype=torch.int64, device=dev)
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            width = int(w.item())
+        pipe = pdist.ScoreGatherPipeline(width, torch.float64, dev, depth=2, dst=0) if world > 1 else None
+        scores = torch.empty(width, dtype=torch.float64, device=dev) if pipe is None else None
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        def step():
+            if pipe is None:
+                ctx.score_sites_fixed_torch(codons, out=scores[:n_local])
+            else:
+                ctx.score_sites_fixed_torch(codons, out=pipe.acquire()[:n_local])
+                pipe.submit()
+
+        def fence():
+            if pipe is not None:
+                pipe.drain()       # every rank's scores of every step have arrived on rank 0
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        elapsed = timed(step, fence, steps, warmup)
+        return elapsed, codons
+
+    bounds = pdist.shard_bounds(args.total_sites, world, 64)
+    if args.scaling == "weak":
+        n_sites = args.sites
+        elapsed, codons = run_leg(n_sites, rank * n_sites, args.steps, args.warmup)
+        total_per_step = n_sites * world
+    else:
+        lo, hi = bounds[rank]
+        n_sites = hi - lo
+        elapsed, codons = run_leg(n_sites, lo, args.steps, args.warmup)
+        total_per_step = args.total_sites
 
     # dominant-kernel duration: HIP events recorded on the launch stream around each launch
+    scores = torch.empty(n_sites, dtype=torch.float64, device=dev)
     ctx.set_timing(True)
     durs = []
     for _ in range(max(3, min(args.steps, 10))):
@@ -164,41 +329,70 @@ def main():
     ctx.set_timing(False)
     torch.cuda.synchronize()
     kernel_ms = float(np.mean(durs))
+    codons_host = codons[:, :min(n_sites, 1 << 20)].cpu().numpy() if rank == 0 else None
+    del codons, scores
+
+    strong = None
+    if args.scaling == "weak" and args.strong_steps > 0:
+        lo, hi = bounds[rank]
+        s_elapsed, c2 = run_leg(hi - lo, lo, args.strong_steps, 1)
+        del c2
+        strong = {"scaling": "strong", "workload": "BASELINE.json configs[3] total: %d codon-frames (100 Mb x 6 frames) cut into contiguous "
+                  "64-aligned ranges by dist.shard_bounds, one shared site stream, scores gathered to rank 0" % args.total_sites,
+                  "total_codon_frames": args.total_sites, "steps": args.strong_steps, "warmup": 1,
+                  "ms_per_step": s_elapsed / args.strong_steps * 1e3, "value": args.total_sites * args.strong_steps / s_elapsed,
+                  "unit": "codon-frames/s", "n_gpus": world}
+    torch.cuda.empty_cache()
 
     if rank == 0:
-        total_sites = n_sites * world * args.steps
         fl = flop_per_site(m.nl)
         achieved = n_sites * fl / (kernel_ms * 1e-3) / 1e12
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")  # per-launch HBM bytes from the committed PMC passes
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("sites_per_launch") == n_sites:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = "committed rocprofv3 --pmc passes of this command (%s), not measured in this run" % tj.get("source", "profiles/")
             except Exception:
                 traffic = None
         out = {
-            "metric": METRIC, "value": total_sites / elapsed, "unit": "codon-frames/s",
+            "metric": METRIC, "value": total_per_step * args.steps / elapsed, "unit": "codon-frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "build-tracks fixed (run_tracks) on a synthetic 58-row 1 Mb alignment, 6 frames: "
-                                   "%d codon-frames per GPU per step, inputs resident in HBM" % n_sites,
+            "config": {"workload": "build-tracks fixed (run_tracks) on a synthetic 58-row alignment, 6 frames: %d codon-frames on this GPU "
+                                   "per step (%s), inputs resident in HBM"
+                                   % (n_sites, "1 Mb per GPU, BASELINE.json configs[2]" if args.scaling == "weak" else
+                                      "its contiguous share of %d = BASELINE.json configs[3]" % args.total_sites),
                        "model": MODEL, "n_leaves": int(m.nl), "sites_per_gpu": n_sites,
                        "unique_columns": POOL_SITES, "sharding": "columns, gather of scores to rank 0" if world > 1 else "none",
-                       "ref_bases_per_s": total_sites / elapsed / 2.0},
+                       "ref_bases_per_s": total_per_step * args.steps / elapsed / 2.0},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "pcsf::prune_fixed", "kernel_ms": kernel_ms, "flop_per_codon_frame": fl},
         }
-        if world == 1:
+        if strong is not None:
+            out["strong"] = strong
+        if world == 1 and args.cpu_baseline_sites != 0:
             budget = args.cpu_baseline_sites
             if budget < 0:
-                # ~2.5 k codon-frames/s/core incl. the per-alignment model set-up -> aim for ~15 s
-                budget = int(min(n_sites, max(20_000, 2500 * effective_cpus() * 15)))
-            if budget > 0:
-                out["cpu_baseline"] = cpu_baseline(m, codons_host, budget)
+                # ~2.5 k codon-frames/s/core incl. the per-alignment model set-up -> aim for ~10 s
+                budget = int(min(codons_host.shape[1], max(20_000, 2500 * effective_cpus() * 10)))
+            out["cpu_baseline"] = cpu_baseline(codons_host, budget)
+            if args.end_to_end_runs > 0:
+                work = args.keep_files or tempfile.mkdtemp(prefix="pcsf_bench_")
+                os.makedirs(work, exist_ok=True)
+                try:
+                    e2e, cpu_e2e = end_to_end(local_rank, args.end_to_end_runs, out["cpu_baseline"]["value"], work)
+                    out["end_to_end"] = e2e
+                    out["cpu_baseline"].update(cpu_e2e)
+                except Exception as ex:  # the kernel-level line must survive a failure of the CLI leg
+                    out["end_to_end"] = {"error": str(ex)[-1500:]}
+                finally:
+                    if not args.keep_files:
+                        shutil.rmtree(work, ignore_errors=True)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

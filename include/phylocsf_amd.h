@@ -65,6 +65,29 @@ typedef struct {
 
 typedef struct pcsf_ctx pcsf_ctx;
 
+/* ---- load_model (src/models.hpp:1757-1857): the model files behind the arrays above ----------
+ * <prefix>_coding.ECM / <prefix>_noncoding.ECM (get_ecm: 63 lower-triangle rows, blank line, 64 frequencies;
+ * src/ecm.hpp:20-67) and <prefix>.nh (newick_parse + newick_flatten, src/newick.hpp:31-229).
+ * alias_file: "<tree label>\t<other names...>" per line, stands in for the name table compiled into the
+ * reference (src/models.hpp:1240-1706); NULL = species_aliases.tsv next to the model files if present, "" = none.
+ * species_csv: --species (tree reduced like newick_reduce, src/newick.hpp:286-363), NULL/"" = whole tree.
+ * mapping_file: --mapping (update_sequence_name_mapping, src/models.hpp:1709-1740), NULL/"" = none.
+ * Host-only (no GPU needed).  On failure pcsf_last_error(NULL) holds the message. */
+typedef struct pcsf_model pcsf_model;
+int pcsf_model_open(pcsf_model **out, const char *prefix, const char *alias_file, const char *species_csv,
+                    const char *mapping_file);
+void pcsf_model_close(pcsf_model *model);
+/* fills *desc with pointers INTO the model (valid until pcsf_model_close): what pcsf_create takes */
+int pcsf_model_describe(const pcsf_model *model, pcsf_model_desc *desc);
+/* [n_nodes] newick_node::branch_length in double, for pcsf_set_bls_branch_lengths */
+const double *pcsf_model_branch_len_double(const pcsf_model *model);
+/* [n_nodes] parent ids (-1 for the root) */
+const int16_t *pcsf_model_parents(const pcsf_model *model);
+/* lower-cased label of a node ("" for internal nodes); NULL if node is out of range */
+const char *pcsf_model_label(const pcsf_model *model, int32_t node);
+/* leaf index of a species name as it appears in alignments (tree labels and their other names), -1 if unknown */
+int32_t pcsf_model_leaf_of(const pcsf_model *model, const char *species_name);
+
 /* Replaces PhyloCSFModel_make x2 (src/run.hpp:38-39): builds Q, its eigen-system and the
  * 2*(n-1) branch matrices once and keeps them resident in HBM.  device_id: HIP ordinal. */
 int pcsf_create(pcsf_ctx **out, const pcsf_model_desc *model, int device_id);

@@ -35,7 +35,7 @@ public:
         std::vector<uint64_t> off;
         for (size_t s = 0; s < n_sites; s += 4096) off.push_back(s);
         off.push_back(n_sites);
-        if (po_baseline_run_tracks(model_.get(), codons, off.data(), off.size() - 1, leaf_stride, out, 0))
+        if (po_baseline_run_tracks(model_.get(), codons, off.data(), off.size() - 1, leaf_stride, out, pcsf_host::effective_threads()))  // cgroup quota / PCSF_THREADS
             throw std::runtime_error("oracle: run_tracks failed");
     }
     void score_blocks(int algo, const uint8_t* codons, const uint64_t* offsets, size_t n_blocks, size_t leaf_stride, bool compute_anc,

@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-__all__ = ["ScoringContext", "PcsfError", "library_path", "load_library", "FIXED", "MLE", "OMEGA"]
+__all__ = ["ScoringContext", "Model", "load_model", "PcsfError", "library_path", "load_library", "FIXED", "MLE", "OMEGA"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PCSF_LIBRARY: load another build of the same HIP library (kernel experiments); never a CPU implementation
@@ -84,8 +84,80 @@ def load_library():
     lib.pcsf_build_schedule.argtypes = [C.c_int32, C.POINTER(C.c_int16), C.POINTER(C.c_int16), C.POINTER(C.c_uint32),
                                         C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int32)]
+    lib.pcsf_model_open.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]
+    lib.pcsf_model_close.argtypes = [vp]
+    lib.pcsf_model_describe.argtypes = [vp, C.POINTER(_ModelDesc)]
+    lib.pcsf_model_branch_len_double.restype = dp
+    lib.pcsf_model_branch_len_double.argtypes = [vp]
+    lib.pcsf_model_parents.restype = C.POINTER(C.c_int16)
+    lib.pcsf_model_parents.argtypes = [vp]
+    lib.pcsf_model_label.restype = C.c_char_p
+    lib.pcsf_model_label.argtypes = [vp, C.c_int32]
+    lib.pcsf_model_leaf_of.restype = C.c_int32
+    lib.pcsf_model_leaf_of.argtypes = [vp, C.c_char_p]
     _lib = lib
     return lib
+
+
+class Model:
+    """What load_model hands to the scoring core (reference src/models.hpp:1742-1857): the flattened tree in
+    newick_flatten numbering, both ECMs, the species labels.  Arrays are numpy copies; `leaf_of(name)` resolves a
+    species name of an alignment (tree labels and their other names) to a leaf index."""
+
+    def __init__(self, prefix, aliases=None, species=None, mapping=None):
+        lib = load_library()
+        enc = lambda x: None if x is None else os.fsencode(x)
+        h = C.c_void_p()
+        rc = lib.pcsf_model_open(C.byref(h), os.fsencode(prefix), enc(aliases), enc(species), enc(mapping))
+        if rc:
+            raise PcsfError(rc, lib.pcsf_last_error(None).decode())
+        try:
+            d = _ModelDesc()
+            lib.pcsf_model_describe(h, C.byref(d))
+            n = self.n = self.n_nodes = int(d.n_nodes)
+            self.nl = self.n_leaves = (n + 1) // 2
+            arr = lambda p, k, t: np.ctypeslib.as_array(p, shape=(k,)).astype(t, copy=True)
+            self.child1 = arr(d.child1, n, np.int16)
+            self.child2 = arr(d.child2, n, np.int16)
+            self.branch_len = arr(d.branch_len, n, np.float32)
+            self.branch_len_d = arr(lib.pcsf_model_branch_len_double(h), n, np.float64)
+            self.parent = arr(lib.pcsf_model_parents(h), n, np.int16)
+            self.S_c = arr(d.S_coding, 4096, np.float64).reshape(64, 64)
+            self.pi_c = arr(d.pi_coding, 64, np.float64)
+            self.S_nc = arr(d.S_noncoding, 4096, np.float64).reshape(64, 64)
+            self.pi_nc = arr(d.pi_noncoding, 64, np.float64)
+            self.labels = [lib.pcsf_model_label(h, i).decode() for i in range(n)]
+        except Exception:
+            lib.pcsf_model_close(h)
+            raise
+        self._h, self._lib = h, lib
+        self.prefix = prefix
+
+    def leaf_of(self, species_name):
+        return int(self._lib.pcsf_model_leaf_of(self._h, species_name.encode()))
+
+    def context(self, device=0, with_bls=False):
+        """A ScoringContext of this model on GPU `device` (pcsf_create)."""
+        ctx = ScoringContext(self.child1, self.child2, self.branch_len, self.S_c, self.pi_c, self.S_nc, self.pi_nc, device=device)
+        if with_bls:
+            ctx.set_bls_branch_lengths(self.branch_len_d)
+        return ctx
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pcsf_model_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def load_model(prefix, aliases=None, species=None, mapping=None):
+    """<prefix>_coding.ECM, <prefix>_noncoding.ECM, <prefix>.nh -> Model (C-ABI pcsf_model_open; host-only)."""
+    return Model(prefix, aliases=aliases, species=species, mapping=mapping)
 
 
 def build_schedule(child1, child2):

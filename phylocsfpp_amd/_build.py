@@ -13,8 +13,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libphylocsf_amd.so")
-SOURCES = ["kernels.hip", "expm.hip", "eigen.hip", "frontend.hip", "api.cpp", "blocks.cpp"]
-HEADERS = ["kernels.h", "hostmath.hpp", "schedule.hpp", "ctx.hpp", "optimizer.hpp", "frames.hpp", os.path.join("..", "..", "include", "phylocsf_amd.h")]
+SOURCES = ["kernels.hip", "expm.hip", "eigen.hip", "frontend.hip", "api.cpp", "blocks.cpp", "model_abi.cpp"]
+HEADERS = ["kernels.h", "hostmath.hpp", "schedule.hpp", "ctx.hpp", "optimizer.hpp", "frames.hpp", os.path.join("..", "..", "include", "phylocsf_amd.h"),
+           os.path.join("..", "host", "model_io.hpp")]
 
 
 def hipcc():
@@ -35,7 +36,6 @@ def is_stale():
 def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
-    objs = []
     build_dir = os.path.join(HERE, "_build")
     os.makedirs(build_dir, exist_ok=True)
     common = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-result",
@@ -43,15 +43,25 @@ def build(force=False, verbose=False):
     # The op loop of prune_fixed is a switch on a wave-uniform op code.  By default the AMDGPU back end
     # structurises even uniform regions, which turns the switch into a chain of "Flow" blocks whose phi copies
     # cost ~80 v_mov_b64 per op (and 26 spilled VGPRs).  Leaving uniform regions as plain scalar branches
-    # removes both (233 VGPRs, no spills).
-    per_source = {"kernels.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"]}
+    # removes both (no spills).
+    per_source = {"kernels.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"],
+                  "factored.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"]}
+    header_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS if os.path.exists(os.path.join(CSRC, h)))
+    header_time = max(header_time, os.path.getmtime(os.path.abspath(__file__)))
+    objs, jobs = [], []
     for src in SOURCES:
         obj = os.path.join(build_dir, src + ".o")
-        cmd = [hipcc()] + common + per_source.get(src, []) + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        objs.append(obj)
+        path = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(header_time, os.path.getmtime(path)):
+            continue  # object is newer than its source and every header
+        cmd = [hipcc()] + common + per_source.get(src, []) + ["-x", "hip", "-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
-        objs.append(obj)
+        jobs.append((src, subprocess.Popen(cmd)))  # the translation units compile side by side
+    failed = [src for src, pr in jobs if pr.wait() != 0]
+    if failed:
+        raise RuntimeError("hipcc failed for: " + ", ".join(failed))
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -34,6 +34,10 @@ KernelTurn g_kernel_turn[64];
 
 using pcsf::DeviceBuffer;
 
+namespace pcsf {
+void set_global_error(const std::string& msg) { g_create_error = msg; }
+}  // namespace pcsf
+
 namespace {
 
 // uploads fragment images / leaf tables / priors for a set of branch matrices P[2][n-1][4096]

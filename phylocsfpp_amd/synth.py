@@ -54,11 +54,12 @@ def evolve_codons(child1, child2, branch_len, S, pi, n_sites, rng):
 
 def synthetic_codon_columns(child1, child2, branch_len, S_c, pi_c, S_nc, pi_nc, n_sites, seed=20261002,
                             coding_fraction=0.10, segment_codons=120, block_codons=67, dropout=0.3,
-                            gap_rate=0.02, gap_mean_len=2.0, keep_leaves=8):
+                            gap_rate=0.02, gap_mean_len=2.0, keep_leaves=8, return_segments=False):
     """Leaf-major uint8 [n_leaves, n_sites] codon matrix (0..63, 64 = gap/N) that looks like the
     frame-1 translation of a multiz alignment: coding and non-coding segments alternate, every
     ~block_codons columns each species other than the first `keep_leaves` is missing with
-    probability `dropout`, and gap runs hit single species."""
+    probability `dropout`, and gap runs hit single species.  return_segments: also return the boolean
+    vector "segment s (segment_codons columns each) was evolved under the coding model"."""
     rng = np.random.default_rng(seed)
     n = len(child1)
     nl = (n + 1) // 2
@@ -92,4 +93,6 @@ def synthetic_codon_columns(child1, child2, branch_len, S_c, pi_c, S_nc, pi_nc, 
     lens = rng.geometric(1.0 / gap_mean_len, size=len(li))
     for l, s, k in zip(li, si, lens):
         out[l, s:s + k] = 64
+    if return_segments:
+        return out, is_coding
     return out

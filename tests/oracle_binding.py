@@ -34,6 +34,7 @@ class PoQdiag(C.Structure):
 
 
 def build():
+    """make -C oracle: called by tests/conftest.py at session start and by __graft_entry__.build(), never from lib()."""
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
@@ -43,8 +44,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(ORACLE_DIR, "pcsf_oracle.c")):
-            build()
+        if not os.path.exists(LIB):  # no build step inside a (possibly profiled, GPU-initialised) process
+            raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (or make -C oracle)" % LIB)
         _lib = C.CDLL(LIB)
         dp, u8p = C.POINTER(C.c_double), C.POINTER(C.c_uint8)
         _lib.po_model_open.argtypes = [C.c_char_p, C.POINTER(PoModel)]
