@@ -117,7 +117,8 @@ int pcsf_score_sites_fixed_dev(pcsf_ctx *ctx, const uint8_t *d_codons, size_t n_
  * nucleotides: the rows of alignment_t::seqs (reference gaps already removed), ASCII, leaf-major
  * [n_leaves][row_stride]; alignment k occupies columns [col_offset, col_offset+len) of every row, start_pos is
  * its 1-based reference position and chrom_len the reference chromosome length (alignment_t::start_pos /
- * ::chrom_len).  Characters other than ACGTacgt count as N (the reference exits on anything but ACGTNacgtn-.).
+ * ::chrom_len).  N n - . make a codon a gap; any other character outside ACGTacgt fails the call ("unexpected character":
+ * the reference exits on it, src/translation.hpp:29-88) -- in this entry point for the characters a codon touches.
  * Output: for alignment k and frame index f = 0..5 (+1,+2,+3,-1,-2,-3) n_codons[6k+f] scores at
  * out_scores[out_offsets[6k+f] ...] in FORWARD genome order; skip_bases (may be NULL) = alignment_t::skip_bases. */
 typedef struct {
@@ -171,6 +172,17 @@ int pcsf_block_loglik(pcsf_ctx *ctx, int model, const double *q_settings, const 
                       const uint8_t *codons, const uint64_t *site_offsets, size_t n_blocks, size_t leaf_stride,
                       double *out_lpr, int32_t *out_failed);
 
+/* The same evaluation with CALLER-SUPPLIED eigen-systems Q = right diag(lambda) left (the reference's eig.r_s,
+ * eig.r_l, eig.r_s2 of src/instance.hpp:309-434) and root priors: right[n_eig][64][64] eigenvectors in columns,
+ * left[n_eig][64][64] = right^-1 in rows, lambda[n_eig][64], prior[n_eig][64]; n_eig = 1 (shared) or n_blocks.
+ * P(t) with the reference's clamp / diagonal / validation (src/instance.hpp:529-646) and the pruning run on the
+ * device as in every other call; only the eigen-solver is the caller's.  The parity tests feed the oracle's
+ * eigen-systems through this to hold the device's P(t) + pruning to 1e-9 at every parameter the optimisers visit. */
+int pcsf_block_loglik_eig(pcsf_ctx *ctx, const double *right, const double *left, const double *lambda,
+                          const double *prior, size_t n_eig, const double *tree_scale, const uint8_t *codons,
+                          const uint64_t *site_offsets, size_t n_blocks, size_t leaf_stride, double *out_lpr,
+                          int32_t *out_failed);
+
 /* ---- diagnostics ---------------------------------------------------------------------------*/
 /* eigen-systems of n kappa/omega F3x4 rate matrices (q_settings[n][12]) from the device solver that OMEGA uses at
  * every kappa evaluation (replaces gsl_eigen_nonsymmv + complex LU of src/instance.hpp:309-434):
@@ -208,6 +220,8 @@ const char *pcsf_version(void);
  * run at DMA speed and do not occupy host threads (a pageable 58 MB nucleotide matrix costs ~6 ms of CPU-driven
  * staging per call); any other memory works too.  NULL on failure. */
 void *pcsf_host_alloc(size_t bytes);
+/* the same through ctx's GPU (hipSetDevice first): threads that never touched a device do not create a context on GPU 0 */
+void *pcsf_host_alloc_on(pcsf_ctx *ctx, size_t bytes);
 void pcsf_host_free(void *p);
 
 #ifdef __cplusplus

@@ -747,6 +747,25 @@ int po_debug_max_lik(double (*fn)(double, void *), void *user, double init, doub
     return 0;
 }
 
+/* po_run_trace: every objective evaluation of a run, in order (tests replay them on the device) */
+static __thread po_trace_entry *g_trace = NULL;
+static __thread int g_trace_cap = 0, g_trace_n = 0, g_trace_kind = 0;
+
+static void trace_add(int kind, double x, const objective *o, double lpr_raw, int failed)
+{
+    if (!g_trace) return;
+    if (g_trace_n < g_trace_cap) {
+        po_trace_entry *e = &g_trace[g_trace_n];
+        e->kind = kind;
+        e->failed = failed;
+        e->x = x;
+        e->tree_scale = o->tree_settings;
+        memcpy(e->q_settings, o->q_settings, sizeof e->q_settings);
+        e->lpr = lpr_raw;
+    }
+    ++g_trace_n;
+}
+
 /* minimizer_lpr_leaves, src/fixed_lik.hpp:460-467 */
 static double obj_tree_scale(double x, objective *o)
 {
@@ -754,8 +773,10 @@ static double obj_tree_scale(double x, objective *o)
     if (po_lpr_leaves(o->qd, o->tree, x, o->codons, o->n_sites, o->leaf_stride, o->compute_anc, &o->lpr,
                       &o->elpr_anc, NULL)) {
         o->failed = 1;
+        trace_add(g_trace_kind, x, o, NAN, 1);
         return NAN;
     }
+    trace_add(g_trace_kind, x, o, o->lpr, 0);
     return -o->lpr;
 }
 
@@ -803,8 +824,10 @@ static double obj_rho(double x, objective *o)
     o->tree_settings = x;
     if (omega_lik(o, &o->lpr)) {
         o->failed = 1;
+        trace_add(2, x, o, NAN, 1);
         return NAN;
     }
+    trace_add(2, x, o, o->lpr, 0);
     o->lpr += po_lpr_rho(x);
     if (getenv("PO_TRACE")) fprintf(stderr, "TRACE omega rho x %.17g lpr %.17g\n", x, o->lpr);
     return -o->lpr;
@@ -818,8 +841,10 @@ static double obj_kappa(double x, objective *o)
     omega_requantise(o);
     if (omega_lik(o, &o->lpr)) {
         o->failed = 1;
+        trace_add(3, x, o, NAN, 1);
         return NAN;
     }
+    trace_add(3, x, o, o->lpr, 0);
     o->lpr += po_lpr_kappa(x);
     if (getenv("PO_TRACE")) fprintf(stderr, "TRACE omega kappa x %.17g lpr %.17g\n", x, o->lpr);
     return -o->lpr;
@@ -915,9 +940,11 @@ int po_run(const po_model *m, int algo, const uint8_t *codons, size_t n_sites, s
         o.tree = tree; o.codons = codons; o.n_sites = n_sites; o.leaf_stride = leaf_stride;
         o.compute_anc = compute_anc; o.f = obj_tree_scale;
         o.qd = qc;
+        g_trace_kind = 0;
         max_lik(&o, 1.0, 1e-2, 10.0, &gen, &lpr_c, &anc_c);
         if (!o.failed) {
             o.qd = qn;
+            g_trace_kind = 1;
             max_lik(&o, 1.0, 1e-2, 10.0, &gen, &lpr_nc, &anc_nc);
         }
         if (o.failed) rc = -1;
@@ -931,6 +958,21 @@ int po_run(const po_model *m, int algo, const uint8_t *codons, size_t n_sites, s
     }
     free(qc);
     free(qn);
+    return rc;
+}
+
+/* po_run that also records every objective evaluation (kind 0/1: MLE tree scale under the coding / non-coding ECM,
+ * 2: OMEGA rho, 3: OMEGA kappa; x, the model's q_settings and tree scale DURING the evaluation, and the
+ * log-likelihood WITHOUT the prior term).  *n_out = number of evaluations (may exceed cap; only cap are stored). */
+int po_run_trace(const po_model *m, int algo, const uint8_t *codons, size_t n_sites, size_t leaf_stride, int compute_anc,
+                 uint32_t seed, float *phylo, float *anc, po_trace_entry *out, int cap, int *n_out)
+{
+    g_trace = out;
+    g_trace_cap = cap;
+    g_trace_n = 0;
+    const int rc = po_run(m, algo, codons, n_sites, leaf_stride, compute_anc, seed, phylo, anc);
+    *n_out = g_trace_n;
+    g_trace = NULL;
     return rc;
 }
 

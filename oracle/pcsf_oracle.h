@@ -100,6 +100,16 @@ int po_run_tracks(const po_model *m, const uint8_t *codons, size_t n_sites, size
 int po_run(const po_model *m, int algo, const uint8_t *codons, size_t n_sites,
            size_t leaf_stride, int compute_anc, uint32_t seed, float *phylo, float *anc);
 
+/* po_run plus a record of every objective evaluation in order, for replaying the optimiser's path elsewhere:
+ * kind 0/1 = MLE tree scale under the coding / non-coding ECM, 2 = OMEGA rho, 3 = OMEGA kappa; x = the point;
+ * q_settings / tree_scale = the model DURING the evaluation; lpr = the log-likelihood WITHOUT the prior term. */
+typedef struct {
+    int32_t kind, failed;
+    double x, tree_scale, q_settings[12], lpr;
+} po_trace_entry;
+int po_run_trace(const po_model *m, int algo, const uint8_t *codons, size_t n_sites, size_t leaf_stride,
+                 int compute_anc, uint32_t seed, float *phylo, float *anc, po_trace_entry *out, int cap, int *n_out);
+
 /* batch of independent blocks (CSR offsets into the leaf-major codon matrix), OpenMP over
  * blocks; returns the number of blocks that failed (NaN rows). threads<=0: all cores */
 int po_run_blocks(const po_model *m, int algo, const uint8_t *codons, const uint64_t *site_offsets,

@@ -77,6 +77,8 @@ def load_library():
     lib.pcsf_branch_length_scores.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_size_t, dp]
     lib.pcsf_block_loglik.argtypes = [vp, C.c_int, dp, dp, u8p, C.POINTER(C.c_uint64), C.c_size_t, C.c_size_t, dp,
                                       C.POINTER(C.c_int32)]
+    lib.pcsf_block_loglik_eig.argtypes = [vp, dp, dp, dp, dp, C.c_size_t, dp, u8p, C.POINTER(C.c_uint64), C.c_size_t, C.c_size_t, dp,
+                                          C.POINTER(C.c_int32)]
     lib.pcsf_set_timing.argtypes = [vp, C.c_int]
     lib.pcsf_last_kernel_ms.restype = C.c_double
     lib.pcsf_last_kernel_ms.argtypes = [vp]
@@ -337,6 +339,27 @@ class ScoringContext:
             ts.ctypes.data_as(C.POINTER(C.c_double)), codons.ctypes.data_as(C.POINTER(C.c_uint8)),
             off.ctypes.data_as(C.POINTER(C.c_uint64)), nb, codons.strides[0], out.ctypes.data_as(C.POINTER(C.c_double)),
             failed.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out, failed
+
+    def block_loglik_eig(self, codons, site_offsets, tree_scale, right, left, lam, prior):
+        """block_loglik with caller-supplied eigen-systems: right/left [k,64,64], lam/prior [k,64], k = 1 or n_blocks."""
+        codons = np.ascontiguousarray(codons, dtype=np.uint8)
+        off = np.ascontiguousarray(site_offsets, dtype=np.uint64)
+        nb = len(off) - 1
+        ts = np.ascontiguousarray(np.broadcast_to(np.asarray(tree_scale, dtype=np.float64), (nb,)))
+        r = np.ascontiguousarray(np.asarray(right, dtype=np.float64).reshape(-1, 64, 64))
+        l = np.ascontiguousarray(np.asarray(left, dtype=np.float64).reshape(-1, 64, 64))
+        la = np.ascontiguousarray(np.asarray(lam, dtype=np.float64).reshape(-1, 64))
+        pr = np.ascontiguousarray(np.asarray(prior, dtype=np.float64).reshape(-1, 64))
+        k = r.shape[0]
+        assert l.shape[0] == k and la.shape[0] == k and pr.shape[0] == k
+        out = np.empty(nb, dtype=np.float64)
+        failed = np.zeros(nb, dtype=np.int32)
+        dp = C.POINTER(C.c_double)
+        self._check(self._lib.pcsf_block_loglik_eig(
+            self._h, r.ctypes.data_as(dp), l.ctypes.data_as(dp), la.ctypes.data_as(dp), pr.ctypes.data_as(dp), k,
+            ts.ctypes.data_as(dp), codons.ctypes.data_as(C.POINTER(C.c_uint8)), off.ctypes.data_as(C.POINTER(C.c_uint64)), nb,
+            codons.strides[0], out.ctypes.data_as(dp), failed.ctypes.data_as(C.POINTER(C.c_int32))))
         return out, failed
 
     # ---- diagnostics -----------------------------------------------------------------------

@@ -201,6 +201,14 @@ void* pcsf_host_alloc(size_t bytes)
     return p;
 }
 
+void* pcsf_host_alloc_on(pcsf_ctx* c, size_t bytes)
+{
+    // page-locked memory is allocated through the CURRENT device's context: select the context's GPU first, so that a
+    // run on device N does not create a primary context on device 0 (and works when device 0 is masked or exclusive)
+    if (!c || hipSetDevice(c->device) != hipSuccess) return nullptr;
+    return pcsf_host_alloc(bytes);
+}
+
 void pcsf_host_free(void* p)
 {
     if (p) (void)hipHostFree(p);
@@ -500,13 +508,23 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
     KernelTurn& turn = g_kernel_turn[c->device & 63];
     std::unique_lock<std::mutex> my_turn(turn.lock);
     if (turn.last && turn.owner != c && (e = hipStreamWaitEvent(c->stream, turn.last, 0)) != hipSuccess) return c->hip_fail(e, "hipStreamWaitEvent");
-    // the power track's per-base scores from the same resident rows
-    if (out_bls && (rc = pcsf::bls_enqueue(c, c->d_nucl.as<unsigned char>(), max_col, max_col, spans)) != PCSF_OK) return rc;
+    // the power track's per-base scores from the same resident rows (that kernel also checks every character); without
+    // them the frame extraction does the character check itself, so that both entry points reject the same input
+    unsigned long long* d_char_flag = nullptr;
+    if (out_bls) {
+        if ((rc = pcsf::bls_enqueue(c, c->d_nucl.as<unsigned char>(), max_col, max_col, spans)) != PCSF_OK) return rc;
+    } else {
+        if ((e = c->d_bls_flag.reserve(sizeof(unsigned long long))) != hipSuccess) return c->hip_fail(e, "hipMalloc(character flag)");
+        if (!c->bls_first_bad && (e = hipHostMalloc(reinterpret_cast<void**>(&c->bls_first_bad), sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
+            return c->hip_fail(e, "hipHostMalloc(character flag)");
+        if ((e = hipMemsetAsync(c->d_bls_flag.ptr, 0xff, sizeof(unsigned long long), c->stream)) != hipSuccess) return c->hip_fail(e, "hipMemsetAsync(character flag)");
+        d_char_flag = c->d_bls_flag.as<unsigned long long>();
+    }
     // at most 65535 segments per launch (grid.y)
     for (size_t s0 = 0; s0 < seg.size(); s0 += 65535) {
         const uint32_t ns = static_cast<uint32_t>(std::min<size_t>(65535, seg.size() - s0));
         if ((e = pcsf::launch_extract_frames(c->d_segments.as<pcsf::FrameSegment>() + s0, ns, max_codons, c->d_nucl.as<unsigned char>(), max_col,
-                                             c->n_leaves, c->d_codons.as<unsigned char>(), total, c->stream)) != hipSuccess)
+                                             c->n_leaves, c->d_codons.as<unsigned char>(), total, d_char_flag, c->stream)) != hipSuccess)
             return c->hip_fail(e, "launch extract_frames");
     }
     if ((rc = pcsf::launch_fixed(c, c->d_codons.as<uint8_t>(), total, total, c->d_out.as<double>(), nullptr, nullptr, c->stream)) != PCSF_OK) return rc;
@@ -517,9 +535,13 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
     if ((e = hipMemcpyAsync(out_scores, c->d_out.ptr, total * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
         return c->hip_fail(e, "hipMemcpyAsync(out)");
     if (out_bls && (rc = pcsf::bls_download(c, max_col, out_bls)) != PCSF_OK) return rc;
+    if (d_char_flag) {
+        *c->bls_first_bad = pcsf::BLS_NO_BAD;
+        if ((e = hipMemcpyAsync(c->bls_first_bad, d_char_flag, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
+            return c->hip_fail(e, "hipMemcpyAsync(character flag)");
+    }
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return c->hip_fail(e, "hipStreamSynchronize");
-    if (out_bls) return pcsf::bls_check(c, nucleotides, row_stride, max_col);
-    return PCSF_OK;
+    return pcsf::bls_check(c, nucleotides, row_stride, max_col);
 }
 
 // ---- branch-length score (src/additional_scores.hpp:5-84) --------------------------------------------------
@@ -624,6 +646,33 @@ int pcsf_block_loglik(pcsf_ctx* c, int model, const double* q_settings, const do
         return pcsf::block_loglik_impl(c, model, q_settings, tree_scale, codons, site_offsets, n_blocks, leaf_stride, out_lpr, out_failed);
     } catch (const std::exception& ex) {
         return c->fail(PCSF_ERR_HIP, std::string("pcsf_block_loglik: ") + ex.what());
+    }
+}
+
+// parity tests: the same evaluation with caller-supplied eigen-systems (no eigen-solver of this library involved)
+int pcsf_block_loglik_eig(pcsf_ctx* c, const double* right, const double* left, const double* lambda, const double* prior, size_t n_eig,
+                          const double* tree_scale, const uint8_t* codons, const uint64_t* site_offsets, size_t n_blocks, size_t leaf_stride,
+                          double* out_lpr, int32_t* out_failed)
+{
+    if (!c) return PCSF_ERR_INVALID_ARG;
+    if (n_blocks == 0) return PCSF_OK;
+    if (!right || !left || !lambda || !prior || !tree_scale || !site_offsets || !out_lpr || (n_eig != 1 && n_eig != n_blocks))
+        return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_block_loglik_eig: bad argument (n_eig must be 1 or n_blocks)");
+    for (size_t b = 0; b < n_blocks; ++b)
+        if (site_offsets[b + 1] < site_offsets[b] || !(tree_scale[b] >= 0.0)) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_block_loglik_eig: bad block");
+    hipError_t e;
+    if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
+    try {
+        std::vector<pcsf::EigenSystem> es(n_eig);
+        for (size_t k = 0; k < n_eig; ++k) {
+            std::memcpy(es[k].right.data(), right + k * 4096, 4096 * sizeof(double));
+            std::memcpy(es[k].left.data(), left + k * 4096, 4096 * sizeof(double));
+            std::memcpy(es[k].lambda.data(), lambda + k * 64, 64 * sizeof(double));
+            std::memcpy(es[k].prior.data(), prior + k * 64, 64 * sizeof(double));
+        }
+        return pcsf::block_loglik_impl(c, 3, nullptr, tree_scale, codons, site_offsets, n_blocks, leaf_stride, out_lpr, out_failed, es.data(), n_eig);
+    } catch (const std::exception& ex) {
+        return c->fail(PCSF_ERR_HIP, std::string("pcsf_block_loglik_eig: ") + ex.what());
     }
 }
 

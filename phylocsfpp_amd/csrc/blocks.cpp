@@ -72,6 +72,13 @@ struct BlockEngine {
     DeviceBuffer d_eig_r, d_eig_l, d_eig_lam, d_eig_basis, d_prior, d_ancw;  // eigen-systems and their root priors
     DeviceBuffer d_jobs, d_eig_jobs, d_wg0, d_wg1, d_wgt, d_wgp, d_wgo, d_lnz, d_anc;
     DeviceBuffer d_branch_slot, d_branch_len, d_leaf_codes;  // per-branch constants; per (block, leaf) row masks
+    // factored path (factored.hip): evaluations of blocks of at most fact_max_tiles 16-site tiles never form their
+    // branch matrices; one job per tile, one edge-scale record per evaluation
+    DeviceBuffer d_fjobs, d_fevals, d_scale, d_slot_branch;
+    std::vector<FactoredJob> fjobs[2];
+    std::vector<ExpmEval> fevals[2];
+    size_t fact_max_tiles = 4;   // break-even of 3 products per leaf/edge pair against 4 per branch + 1 per edge
+    bool allow_factored = true;  // false: caller-supplied eigen-systems keep the entry-wise post-processing of P
     // Work of one run() is kept in two sets: evaluations whose eigen-system is rebuilt in this run (set 1: eigen ->
     // expm -> prune on the side stream) and all others (set 0: expm -> prune on the main stream), so that the
     // latency-bound eigen kernel overlaps the matrix work of the other evaluations.
@@ -97,9 +104,6 @@ struct BlockEngine {
         nl = c->n_leaves;
         n = c->n_nodes;
         n_sites_total = offsets[nb];
-        HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
         if (n_sites_total > 0) {
             HIP_TRY(d_codons.reserve(static_cast<size_t>(nl) * n_sites_total));
             HIP_TRY(upload_rows(d_codons.ptr, codons, stride, n_sites_total, nl, stream));
@@ -118,8 +122,13 @@ struct BlockEngine {
                 leaf_codes[(b * nl + l) * 2] = lo;
                 leaf_codes[(b * nl + l) * 2 + 1] = hi;
             }
+        if (const char* v = std::getenv("PCSF_FACTORED_MAX_TILES")) fact_max_tiles = static_cast<size_t>(std::max(0, std::atoi(v)));
         std::vector<int32_t> slots(static_cast<size_t>(n - 1));
         for (int b = 0; b < n - 1; ++b) slots[b] = c->branch_slot[b];
+        std::vector<int32_t> slot_branch(c->schedule.slot_node.begin(), c->schedule.slot_node.end());
+        HIP_TRY(d_slot_branch.reserve(std::max<size_t>(slot_branch.size(), 1) * sizeof(int32_t)));
+        if (!slot_branch.empty())
+            HIP_TRY(hipMemcpyAsync(d_slot_branch.ptr, slot_branch.data(), slot_branch.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
         HIP_TRY(d_branch_slot.reserve(slots.size() * sizeof(int32_t)));
         HIP_TRY(d_branch_len.reserve(slots.size() * sizeof(float)));
         HIP_TRY(d_leaf_codes.reserve(std::max<size_t>(leaf_codes.size(), 2) * sizeof(uint64_t)));
@@ -128,38 +137,54 @@ struct BlockEngine {
         if (!leaf_codes.empty())
             HIP_TRY(hipMemcpyAsync(d_leaf_codes.ptr, leaf_codes.data(), leaf_codes.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));  // `slots` is a stack temporary
+        // created last: a throw above leaves nothing behind that only the destructor (not run then) would release
+        try {
+            HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
+        } catch (...) {
+            release_sync_objects();
+            throw;
+        }
     }
-    std::vector<uint64_t> leaf_codes;  // [block][leaf][2]
-    ~BlockEngine()
+    void release_sync_objects()
     {
         if (side) {
             (void)hipStreamSynchronize(side);
             (void)hipStreamDestroy(side);
+            side = nullptr;
         }
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_side) (void)hipEventDestroy(ev_side);
+        ev_start = ev_side = nullptr;
     }
+    std::vector<uint64_t> leaf_codes;  // [block][leaf][2]
+    ~BlockEngine() { release_sync_objects(); }
     BlockEngine(const BlockEngine&) = delete;
     BlockEngine& operator=(const BlockEngine&) = delete;
 
     // capacity: evaluations per run() / eigen-systems alive at a time
+    // table sets only live within one run(): growing between runs loses nothing; growing with evaluations queued would
     void reserve_tables(size_t tables)
     {
         if (tables <= cap_tables) return;
+        if (!evals.empty()) throw std::runtime_error("BlockEngine: reserve_tables with evaluations queued");
         HIP_TRY(d_frag.reserve(std::max<size_t>(1, tables * ne) * 4096 * sizeof(double)));
         HIP_TRY(d_leaf.reserve(tables * nl * LEAF_TABLE_DOUBLES_DEV * sizeof(double)));
         HIP_TRY(d_fail.reserve(tables * sizeof(uint32_t)));
+        HIP_TRY(d_scale.reserve(tables * static_cast<size_t>(n - 1) * 64 * sizeof(double)));
         cap_tables = tables;
     }
+    // eigen-systems already resident (uploaded, or solved by an earlier run()) survive a growth
     void reserve_eig(size_t count)
     {
         if (count <= cap_eig) return;
-        HIP_TRY(d_eig_r.reserve(count * 4096 * sizeof(double)));
-        HIP_TRY(d_eig_l.reserve(count * 4096 * sizeof(double)));
-        HIP_TRY(d_eig_lam.reserve(count * 64 * sizeof(double)));
-        HIP_TRY(d_eig_basis.reserve(count * 4096 * sizeof(double)));
-        HIP_TRY(d_prior.reserve(count * 64 * sizeof(double)));
-        HIP_TRY(d_ancw.reserve(count * 64 * sizeof(double)));
+        HIP_TRY(d_eig_r.reserve_keep(count * 4096 * sizeof(double), cap_eig * 4096 * sizeof(double), stream));
+        HIP_TRY(d_eig_l.reserve_keep(count * 4096 * sizeof(double), cap_eig * 4096 * sizeof(double), stream));
+        HIP_TRY(d_eig_lam.reserve_keep(count * 64 * sizeof(double), cap_eig * 64 * sizeof(double), stream));
+        HIP_TRY(d_eig_basis.reserve_keep(count * 4096 * sizeof(double), cap_eig * 4096 * sizeof(double), stream));
+        HIP_TRY(d_prior.reserve_keep(count * 64 * sizeof(double), cap_eig * 64 * sizeof(double), stream));
+        HIP_TRY(d_ancw.reserve_keep(count * 64 * sizeof(double), cap_eig * 64 * sizeof(double), stream));
         cap_eig = count;
     }
     // a host-side eigen-system (the ECM models of the context) and its root prior into slot idx
@@ -202,13 +227,30 @@ struct BlockEngine {
         ev.table = table;
         ev.block = static_cast<uint32_t>(blk);
         ev.x = x;
-        jobs[set].push_back(ev);
-        for (uint64_t s = off[blk]; s < off[blk + 1]; s += 64) {
-            wg0[set].push_back(s);
-            wg1[set].push_back(std::min<uint64_t>(s + 64, off[blk + 1]));
-            wgt[set].push_back(table);
-            wgp[set].push_back(eig);
-            wgo[set].push_back(out_used + (s - off[blk]));
+        const uint64_t n_block_sites = off[blk + 1] - off[blk];
+        const uint64_t n_tiles = (n_block_sites + 15) / 16;
+        if (allow_factored && n_tiles <= fact_max_tiles) {
+            // short block: factors applied directly, one work-group per 16-site tile (an empty block only has its
+            // model validated)
+            fevals[set].push_back(ev);
+            for (uint64_t s = off[blk]; s < off[blk + 1]; s += 16) {
+                FactoredJob j{};
+                j.site0 = s;
+                j.out0 = out_used + (s - off[blk]);
+                j.n_sites = static_cast<uint32_t>(std::min<uint64_t>(16, off[blk + 1] - s));
+                j.eig = eig;
+                j.eval = table;
+                fjobs[set].push_back(j);
+            }
+        } else {
+            jobs[set].push_back(ev);
+            for (uint64_t s = off[blk]; s < off[blk + 1]; s += 64) {
+                wg0[set].push_back(s);
+                wg1[set].push_back(std::min<uint64_t>(s + 64, off[blk + 1]));
+                wgt[set].push_back(table);
+                wgp[set].push_back(eig);
+                wgo[set].push_back(out_used + (s - off[blk]));
+            }
         }
         evals.push_back({static_cast<uint32_t>(blk), table, out_used});
         out_used += off[blk + 1] - off[blk];
@@ -248,7 +290,20 @@ struct BlockEngine {
                 HIP_TRY(hipMemcpyAsync(d_wgp.as<uint32_t>() + at, wgp[set].data(), cnt * 4, hipMemcpyHostToDevice, stream));
             }
         }
-        const bool use_side = !eig_jobs.empty() || nj1 || nw1;
+        const size_t nf0 = fjobs[0].size(), nf1 = fjobs[1].size(), nfe0 = fevals[0].size(), nfe1 = fevals[1].size();
+        if (nfe0 + nfe1) {
+            HIP_TRY(d_fevals.reserve((nfe0 + nfe1) * sizeof(ExpmEval)));
+            if (nfe0) HIP_TRY(hipMemcpyAsync(d_fevals.as<ExpmEval>(), fevals[0].data(), nfe0 * sizeof(ExpmEval), hipMemcpyHostToDevice, stream));
+            if (nfe1) HIP_TRY(hipMemcpyAsync(d_fevals.as<ExpmEval>() + nfe0, fevals[1].data(), nfe1 * sizeof(ExpmEval), hipMemcpyHostToDevice, stream));
+        }
+        if (nf0 + nf1) {
+            HIP_TRY(d_fjobs.reserve((nf0 + nf1) * sizeof(FactoredJob)));
+            if (nf0) HIP_TRY(hipMemcpyAsync(d_fjobs.as<FactoredJob>(), fjobs[0].data(), nf0 * sizeof(FactoredJob), hipMemcpyHostToDevice, stream));
+            if (nf1) HIP_TRY(hipMemcpyAsync(d_fjobs.as<FactoredJob>() + nf0, fjobs[1].data(), nf1 * sizeof(FactoredJob), hipMemcpyHostToDevice, stream));
+            HIP_TRY(d_lnz.reserve(out_used * 8));
+            HIP_TRY(d_anc.reserve(out_used * 8));
+        }
+        const bool use_side = !eig_jobs.empty() || nj1 || nw1 || nfe1;
         if (use_side) {
             HIP_TRY(hipEventRecord(ev_start, stream));
             HIP_TRY(hipStreamWaitEvent(side, ev_start, 0));
@@ -293,6 +348,31 @@ struct BlockEngine {
                 p.out_anc = want_anc ? d_anc.as<double>() : nullptr;
                 HIP_TRY(launch_prune_fixed(p, 16, st, 0));
             }
+            const size_t nfe = set ? nfe1 : nfe0, fe_at = set ? nfe0 : 0, nf = set ? nf1 : nf0, f_at = set ? nf0 : 0;
+            if (nfe)
+                HIP_TRY(launch_edge_scale(d_fevals.as<ExpmEval>() + fe_at, static_cast<uint32_t>(nfe), static_cast<uint32_t>(n - 1), d_branch_len.as<float>(),
+                                          d_eig_r.as<double>(), d_eig_l.as<double>(), d_eig_lam.as<double>(), d_scale.as<double>(), d_fail.as<uint32_t>(), st));
+            if (nf) {
+                FactoredParams fp{};
+                fp.jobs = d_fjobs.as<FactoredJob>() + f_at;
+                fp.n_jobs = static_cast<uint32_t>(nf);
+                fp.codons = d_codons.as<uint8_t>();
+                fp.leaf_stride = n_sites_total;
+                fp.program = c->d_program.as<uint32_t>();
+                fp.n_ops = static_cast<int>(c->schedule.program.size());
+                fp.slot_branch = d_slot_branch.as<int32_t>();
+                fp.n_edges = ne;
+                fp.n_leaves = nl;
+                fp.n_branches = static_cast<uint32_t>(n - 1);
+                fp.eig_right = d_eig_r.as<double>();
+                fp.eig_left = d_eig_l.as<double>();
+                fp.prior = d_prior.as<double>();
+                fp.anc_weight = d_ancw.as<double>();
+                fp.edge_scale = d_scale.as<double>();
+                fp.out_lnz = d_lnz.as<double>();
+                fp.out_anc = want_anc ? d_anc.as<double>() : nullptr;
+                HIP_TRY(launch_prune_factored(fp, st));
+            }
         };
         if (use_side) {
             if (!eig_jobs.empty()) {
@@ -333,6 +413,8 @@ struct BlockEngine {
             wgo[set].clear();
             wgt[set].clear();
             wgp[set].clear();
+            fjobs[set].clear();
+            fevals[set].clear();
         }
         eig_jobs.clear();
         out_used = 0;
@@ -720,9 +802,12 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
 }  // namespace
 
 
-// one objective evaluation per block at caller-chosen parameters (no prior term)
+// one objective evaluation per block at caller-chosen parameters (no prior term).  model 3: caller-supplied
+// eigen-systems (custom[n_custom], block b uses custom[n_custom == 1 ? 0 : b]) -- the parity tests feed the ORACLE's
+// eigen-system through the device's P(t) and pruning kernels to separate eigen-solver noise from theirs.
 int block_loglik_impl(pcsf_ctx* c, int model, const double* q_settings, const double* tree_scale, const uint8_t* codons,
-                      const uint64_t* site_offsets, size_t n_blocks, size_t leaf_stride, double* out_lpr, int32_t* out_failed)
+                      const uint64_t* site_offsets, size_t n_blocks, size_t leaf_stride, double* out_lpr, int32_t* out_failed,
+                      const EigenSystem* custom, size_t n_custom)
 {
     std::vector<uint64_t> off(n_blocks + 1);
     for (size_t b = 0; b <= n_blocks; ++b) off[b] = site_offsets[b] - site_offsets[0];
@@ -730,12 +815,18 @@ int block_loglik_impl(pcsf_ctx* c, int model, const double* q_settings, const do
     eng.reserve_tables(n_blocks);
     if (model == 2) {
         eng.reserve_eig(n_blocks);  // eigen-systems and root priors come from the device solver (eigen.hip)
+    } else if (model == 3) {
+        eng.allow_factored = false;
+        eng.reserve_eig(n_custom);
+        for (size_t k = 0; k < n_custom; ++k) eng.upload_eig(k, custom[k]);
     } else {
         eng.reserve_eig(1);
         eng.upload_eig(0, c->eig[model]);
     }
-    for (size_t b = 0; b < n_blocks; ++b)
-        eng.queue(b, model == 2 ? static_cast<uint32_t>(b) : 0u, tree_scale[b], model == 2 ? q_settings + 12 * b : nullptr);
+    for (size_t b = 0; b < n_blocks; ++b) {
+        const uint32_t eig = model == 2 ? static_cast<uint32_t>(b) : (model == 3 && n_custom > 1) ? static_cast<uint32_t>(b) : 0u;
+        eng.queue(b, eig, tree_scale[b], model == 2 ? q_settings + 12 * b : nullptr);
+    }
     eng.run(false);
     for (size_t b = 0; b < n_blocks; ++b) {
         const bool f = eng.failed(b);

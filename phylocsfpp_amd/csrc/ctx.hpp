@@ -44,6 +44,22 @@ struct DeviceBuffer {
         if (e == hipSuccess) bytes = n;
         return e;
     }
+    // like reserve(), but the first `keep` bytes of the old contents survive a growth (device-to-device copy on
+    // `stream`, which the caller's later work on that stream is ordered behind)
+    hipError_t reserve_keep(size_t n, size_t keep, hipStream_t stream)
+    {
+        if (n <= bytes) return hipSuccess;
+        if (!ptr || keep == 0) return reserve(n);
+        void* old = ptr;
+        const size_t old_bytes = bytes;
+        ptr = nullptr;
+        bytes = 0;
+        hipError_t e = reserve(n);
+        if (e == hipSuccess) e = hipMemcpyAsync(ptr, old, keep < old_bytes ? keep : old_bytes, hipMemcpyDeviceToDevice, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);  // the old allocation is freed right below
+        (void)hipFree(old);
+        return e;
+    }
     template <class T> T* as() const { return static_cast<T*>(ptr); }
 };
 
@@ -118,7 +134,8 @@ int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t le
 int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64_t* site_offsets, size_t n_blocks,
                       size_t leaf_stride, int compute_anc, uint32_t seed, float* out_phylo, float* out_anc);
 int block_loglik_impl(pcsf_ctx* c, int model, const double* q_settings, const double* tree_scale, const uint8_t* codons,
-                      const uint64_t* site_offsets, size_t n_blocks, size_t leaf_stride, double* out_lpr, int32_t* out_failed);
+                      const uint64_t* site_offsets, size_t n_blocks, size_t leaf_stride, double* out_lpr, int32_t* out_failed,
+                      const EigenSystem* custom = nullptr, size_t n_custom = 0);
 int debug_eigen_omega_impl(pcsf_ctx* c, const double* q_settings, const double* warm_settings, size_t n, double* right, double* left,
                            double* lambda, double* prior, int32_t* failed);
 }  // namespace pcsf

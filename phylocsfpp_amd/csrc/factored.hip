@@ -1,0 +1,295 @@
+// factored.hip -- block-mode pruning WITHOUT explicit branch matrices (MLE / OMEGA evaluations of short blocks).
+//
+// One objective evaluation of the whole-block strategies (reference: lpr_leaves under a freshly instantiated model,
+// src/fixed_lik.hpp:362-449 + src/instance.hpp:449-646) needs all n-1 matrices P(t_b) = R diag(e^{lambda t_b}) L only to
+// apply them to the block's columns -- and the blocks score-msa sees are short (median 6 codons = ONE 16-column tile)
+// and sparse (median 4 of 100 species present).  Forming P explicitly (expm.hip: four tile-products per branch, 32 KiB
+// written and re-read per branch) is then almost all of the work.  This kernel applies the factors instead:
+//     internal edge   m = R (e_b o (L v))          two 64x64 x (64x16) products
+//     leaf edge       m = R (e_b o L[:, codon])    one product; nothing at all when the leaf is a gap in all 16 columns
+//     all-gap subtree m = P 1 = 1                  nothing (the reference gets 1 +- 1 ulp from its row sums)
+// with e_b[k] = exp(lambda_k t_b) from edge_scale_kernel (one exponential per eigenvalue, branch and evaluation).
+//
+// Mapping: ONE WORK-GROUP PER TILE (16 columns of one evaluation), its four waves split every product by OUTPUT ROWS:
+// wave w computes states 16w..16w+15 of the result with 16 x v_mfma_f64_16x16x4_f64 whose A operands -- the wave's
+// 16 rows of R and of L -- stay in registers for the whole tile (no LDS staging of matrices at all).  The B operand is
+// the full 64x16 tile: the MFMA result layout (lane l, register r = state 16w + (l>>4) + 4r, column l&15) is exactly the
+// B layout of k-step q = 4w + r in the SAME lane, so the all-gather between two products is a same-lane exchange
+// through LDS: two ds_write_b128 per wave, one barrier, eight ds_read_b128 (double-buffered, 16 KiB per work-group).
+// Element-wise work (scaling by e_b, message products, clamps) touches 4 registers per lane instead of 16.
+//
+// What is NOT reproduced entry by entry: the reference's clamp of P's negative noise and its diagonal fix
+// (src/instance.hpp:602-640) act on matrix entries that are never formed here.  Messages are clamped at zero instead
+// (identical for leaf messages, which ARE columns of P); the raw row sums are validated per branch by
+// edge_scale_kernel; the entry-wise lower bound cannot fail for eigen-systems from the symmetric Jacobi solvers
+// (P = D^-1/2 U e^{Lt} U^T D^1/2 with U orthonormal to 1e-15).  Caller-supplied eigen-systems and long blocks take the
+// explicit path (expm.hip + prune_fixed), which keeps the entry-wise post-processing.  DESIGN.md section 3.6.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace pcsf {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+namespace {
+
+// position of state k in the "row-split" order [wave][lane group g][register r], k = 16 wave + g + 4 r
+__device__ __forceinline__ int row_split_pos(int k) { return ((k >> 4) * 4 + (k & 3)) * 4 + ((k >> 2) & 3); }
+
+struct Vec4 {
+    double v[4];
+};
+
+}  // namespace
+
+// ---- e_b[k] = exp(lambda_k * t_b) for every branch of every evaluation, and the raw row sums of P(t_b) --------------
+// One work-group per evaluation.  t_b = (double)(float)(len_b * x) like the reference's float tree
+// (src/instance.hpp:299-307,498).  Row sums: sum_j P_ij = sum_k R_ik e_k c_k with c_k = sum_j L_kj; the reference rejects a
+// model when one is off by more than 1e-6 (src/instance.hpp:632-636).
+__global__ __launch_bounds__(256) void edge_scale_kernel(const ExpmEval* __restrict__ evals, uint32_t n_branches, const float* __restrict__ branch_len,
+                                                         const double* __restrict__ eig_right, const double* __restrict__ eig_left,
+                                                         const double* __restrict__ eig_lambda, double* __restrict__ scale_out,
+                                                         uint32_t* __restrict__ fail)
+{
+    __shared__ double cpart[4][64], csum[64], es[4][64];
+    __shared__ int bad;
+    const ExpmEval ev = evals[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double* __restrict__ R = eig_right + static_cast<size_t>(ev.eig) * 4096;
+    const double* __restrict__ L = eig_left + static_cast<size_t>(ev.eig) * 4096;
+    if (tid == 0) bad = 0;
+    {
+        double s = 0.0;
+        for (int j = 16 * wave; j < 16 * wave + 16; ++j) s += L[lane * 64 + j];
+        cpart[wave][lane] = s;
+    }
+    __syncthreads();
+    if (wave == 0) csum[lane] = ((cpart[0][lane] + cpart[1][lane]) + cpart[2][lane]) + cpart[3][lane];
+    __syncthreads();
+    double rc[64];  // row `lane` of R times c
+#pragma unroll
+    for (int k = 0; k < 64; ++k) rc[k] = R[lane * 64 + k] * csum[k];
+    const double lam = eig_lambda[static_cast<size_t>(ev.eig) * 64 + lane];
+    double* __restrict__ dst = scale_out + static_cast<size_t>(ev.table) * n_branches * 64;
+    const int pos = row_split_pos(lane);
+    bool mine_bad = false;
+    for (uint32_t b0 = 0; b0 < n_branches; b0 += 4) {
+        const uint32_t b = b0 + wave;
+        const bool active = b < n_branches;
+        double e = 0.0;
+        if (active) {
+            const double t = static_cast<double>(static_cast<float>(static_cast<double>(branch_len[b]) * ev.x));
+            e = exp(lam * t);
+            dst[static_cast<size_t>(b) * 64 + pos] = e;
+        }
+        es[wave][lane] = e;
+        __syncthreads();
+        if (active) {
+            double sum = 0.0;
+#pragma unroll
+            for (int k = 0; k < 64; ++k) sum += rc[k] * es[wave][k];
+            if (!(fabs(sum - 1.0) <= 1e-6)) mine_bad = true;
+        }
+        __syncthreads();
+    }
+    if (mine_bad) bad = 1;
+    __syncthreads();
+    if (tid == 0 && bad) fail[ev.table] = 1u;
+}
+
+// ---- the pruning kernel ----------------------------------------------------------------------------------------------
+template <bool ANC>
+__global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_fact[];
+    double2_t* xbuf = reinterpret_cast<double2_t*>(lds_fact);                      // [2][4 waves][2 pairs][64 lanes]
+    double* red = reinterpret_cast<double*>(lds_fact + 2 * 4 * 2 * 64 * 16);       // [2][4][16]
+    uint32_t* lprog = reinterpret_cast<uint32_t*>(red + 2 * 4 * 16);               // [n_ops]
+    int32_t* lslot = reinterpret_cast<int32_t*>(lprog + ((p.n_ops + 3) & ~3));     // [n_edges] slot -> branch
+    unsigned char* lcod = reinterpret_cast<unsigned char*>(lslot + ((p.n_edges + 3) & ~3));  // [n_leaves][16]
+
+    const FactoredJob job = p.jobs[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sj = lane & 15, g = lane >> 4;
+
+    for (int idx = tid; idx < p.n_leaves * 16; idx += 256) {
+        const int leaf = idx >> 4, s = idx & 15;
+        unsigned c = 64u;
+        if (static_cast<uint32_t>(s) < job.n_sites) {
+            c = p.codons[static_cast<size_t>(leaf) * p.leaf_stride + job.site0 + s];
+            c = c > 64u ? 64u : c;
+        }
+        lcod[idx] = static_cast<unsigned char>(c);
+    }
+    for (int i = tid; i < p.n_ops; i += 256) lprog[i] = p.program[i];
+    for (int i = tid; i < p.n_edges; i += 256) lslot[i] = p.slot_branch[i];
+
+    // this wave's 16 rows of R and L as MFMA A operands: k-step q needs M[16 wave + (lane & 15)][4q + (lane >> 4)]
+    const double* __restrict__ Rg = p.eig_right + static_cast<size_t>(job.eig) * 4096;
+    const double* __restrict__ Lg = p.eig_left + static_cast<size_t>(job.eig) * 4096;
+    double RA[16], LA[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        RA[q] = Rg[(16 * wave + sj) * 64 + 4 * q + g];
+        LA[q] = Lg[(16 * wave + sj) * 64 + 4 * q + g];
+    }
+    const double* __restrict__ scale = p.edge_scale + static_cast<size_t>(job.eval) * p.n_branches * 64 + (wave * 4 + g) * 4;
+    const double* __restrict__ Lrows = Lg + static_cast<size_t>(16 * wave + g) * 64;  // + 4r * 64 + codon
+    __syncthreads();
+
+    int nprod = 0;
+    // out <- M v for the 64x16 tile whose rows 16 wave + g + 4r this lane holds in v[r]: all-gather through LDS, then
+    // 16 MFMAs in two accumulator chains
+    auto matvec = [&](const double (&MA)[16], const Vec4& v) -> Vec4 {
+        double2_t* xb = xbuf + (nprod & 1) * (4 * 2 * 64);
+        ++nprod;
+        xb[(wave * 2 + 0) * 64 + lane] = double2_t{v.v[0], v.v[1]};
+        xb[(wave * 2 + 1) * 64 + lane] = double2_t{v.v[2], v.v[3]};
+        __syncthreads();
+        double2_t b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] = xb[i * 64 + lane];  // k-steps q = 2i, 2i + 1
+        double4_t a0 = double4_t{0.0, 0.0, 0.0, 0.0}, a1 = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(MA[2 * i], b[i].x, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(MA[2 * i + 1], b[i].y, a1, 0, 0, 0);
+        }
+        Vec4 out;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out.v[r] = a0[r] + a1[r];
+        return out;
+    };
+    auto load_scale = [&](int branch) -> Vec4 {
+        const double2_t* s2 = reinterpret_cast<const double2_t*>(scale + static_cast<size_t>(branch) * 64);
+        const double2_t lo = s2[0], hi = s2[1];
+        return Vec4{{lo.x, lo.y, hi.x, hi.y}};
+    };
+    // message along an internal edge; `ones`: the operand is the all-ones tile (an all-gap subtree) and so is the result
+    auto edge = [&](int branch, const Vec4& v, bool ones) -> Vec4 {
+        if (ones) return Vec4{{1.0, 1.0, 1.0, 1.0}};
+        const Vec4 e = load_scale(branch);
+        Vec4 y = matvec(LA, v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y.v[r] *= e.v[r];
+        Vec4 m = matvec(RA, y);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m.v[r] = fmax(m.v[r], 0.0);
+        return m;
+    };
+    // message of a leaf: column `codon` of P(t_leaf); 1 for a gap.  all_gap (uniform over the work-group) -> no product
+    auto leaf = [&](int a, bool& all_gap) -> Vec4 {
+        const unsigned code = lcod[a * 16 + sj];
+        all_gap = __ballot(code != 64u) == 0ull;
+        if (all_gap) return Vec4{{1.0, 1.0, 1.0, 1.0}};
+        const Vec4 e = load_scale(a);
+        const unsigned col = code == 64u ? 0u : code;
+        Vec4 x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x.v[r] = e.v[r] * Lrows[r * 256 + col];
+        Vec4 m = matvec(RA, x);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m.v[r] = code == 64u ? 1.0 : fmax(m.v[r], 0.0);
+        return m;
+    };
+
+    Vec4 cur{{1.0, 1.0, 1.0, 1.0}}, stk[MAX_STACK_DEPTH_DEV];
+    bool cur_ones = true, stk_ones[MAX_STACK_DEPTH_DEV] = {true, true, true};
+#pragma unroll
+    for (int d = 0; d < MAX_STACK_DEPTH_DEV; ++d) stk[d] = Vec4{{1.0, 1.0, 1.0, 1.0}};
+    int slot = 0;
+    for (int ip = 0; ip < p.n_ops; ++ip) {
+        const uint32_t op = lprog[ip];
+        const uint32_t code = op >> 28;
+        const int a = (op >> 14) & 0x3fff, b = op & 0x3fff;
+        if (code == F_CHERRY_DEV) {
+            bool ga, gb;
+            const Vec4 ma = leaf(a, ga), mb = leaf(b, gb);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cur.v[r] = ma.v[r] * mb.v[r];
+            cur_ones = ga && gb;
+        } else if (code == F_MM_LEAF_DEV) {
+            const Vec4 m = edge(lslot[slot++], cur, cur_ones);
+            bool ga;
+            const Vec4 ma = leaf(a, ga);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cur.v[r] = m.v[r] * ma.v[r];
+            cur_ones = cur_ones && ga;
+        } else if (code >= F_MM_PUSH_CHERRY0_DEV && code < F_MM_POP0_DEV) {
+            const Vec4 m = edge(lslot[slot++], cur, cur_ones);
+            const bool m_ones = cur_ones;
+            bool ga, gb;
+            const Vec4 ma = leaf(a, ga), mb = leaf(b, gb);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cur.v[r] = ma.v[r] * mb.v[r];
+            cur_ones = ga && gb;
+            const int d = static_cast<int>(code - F_MM_PUSH_CHERRY0_DEV);
+            // the stack slot is part of the op code: statically indexed registers
+            if (d == 0) { stk[0] = m; stk_ones[0] = m_ones; }
+            else if (d == 1) { stk[1] = m; stk_ones[1] = m_ones; }
+            else { stk[2] = m; stk_ones[2] = m_ones; }
+        } else if (code >= F_MM_POP0_DEV && code < F_ROOT_DEV) {
+            const Vec4 m = edge(lslot[slot++], cur, cur_ones);
+            const int d = static_cast<int>(code - F_MM_POP0_DEV);
+            const Vec4 s = d == 0 ? stk[0] : (d == 1 ? stk[1] : stk[2]);
+            const bool s_ones = d == 0 ? stk_ones[0] : (d == 1 ? stk_ones[1] : stk_ones[2]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cur.v[r] = s.v[r] * m.v[r];
+            cur_ones = cur_ones && s_ones;
+        } else {  // F_ROOT: z = prior . alpha_root, ln z; the ancestral term sum_x ln(prior_x) prior_x alpha_x / z
+            const double* __restrict__ pr = p.prior + static_cast<size_t>(job.eig) * 64 + g * 16 + 4 * wave;  // lane order [g][q], q = 4 wave + r
+            double z = 0.0, t = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z += pr[r] * cur.v[r];
+            z += __shfl_xor(z, 16);
+            z += __shfl_xor(z, 32);
+            if (ANC) {
+                const double* __restrict__ aw = p.anc_weight + static_cast<size_t>(job.eig) * 64 + g * 16 + 4 * wave;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t += aw[r] * cur.v[r];
+                t += __shfl_xor(t, 16);
+                t += __shfl_xor(t, 32);
+            }
+            if (g == 0) {
+                red[wave * 16 + sj] = z;
+                if (ANC) red[64 + wave * 16 + sj] = t;
+            }
+            __syncthreads();
+            if (wave == 0 && g == 0 && static_cast<uint32_t>(sj) < job.n_sites) {
+                const double zz = ((red[sj] + red[16 + sj]) + red[32 + sj]) + red[48 + sj];
+                p.out_lnz[job.out0 + sj] = log(zz);
+                if (ANC) {
+                    const double tt = ((red[64 + sj] + red[80 + sj]) + red[96 + sj]) + red[112 + sj];
+                    p.out_anc[job.out0 + sj] = zz == 0.0 ? 0.0 : tt / zz;
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_edge_scale(const ExpmEval* d_evals, uint32_t n_evals, uint32_t n_branches, const float* d_branch_len, const double* d_eig_right,
+                             const double* d_eig_left, const double* d_eig_lambda, double* d_scale_out, uint32_t* d_fail, hipStream_t stream)
+{
+    if (n_evals == 0) return hipSuccess;
+    hipLaunchKernelGGL(edge_scale_kernel, dim3(n_evals), dim3(256), 0, stream, d_evals, n_branches, d_branch_len, d_eig_right, d_eig_left,
+                       d_eig_lambda, d_scale_out, d_fail);
+    return hipGetLastError();
+}
+
+hipError_t launch_prune_factored(const FactoredParams& p, hipStream_t stream)
+{
+    if (p.n_jobs == 0) return hipSuccess;
+    const size_t lds = 2 * 4 * 2 * 64 * 16 + 2 * 4 * 16 * 8 + ((static_cast<size_t>(p.n_ops) + 3) & ~size_t(3)) * 4 +
+                       ((static_cast<size_t>(p.n_edges) + 3) & ~size_t(3)) * 4 + static_cast<size_t>(p.n_leaves) * 16;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    if (p.out_anc)
+        hipLaunchKernelGGL(prune_factored<true>, dim3(p.n_jobs), dim3(256), lds, stream, p);
+    else
+        hipLaunchKernelGGL(prune_factored<false>, dim3(p.n_jobs), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace pcsf

@@ -12,6 +12,7 @@
 
 namespace pcsf {
 
+// 0..3 = ACGT (either case), 4 = N n - ., 5 = a character the reference exits on (src/translation.hpp:29-88)
 __device__ __forceinline__ unsigned nucleotide_id(unsigned char c)
 {
     switch (c) {
@@ -19,13 +20,14 @@ __device__ __forceinline__ unsigned nucleotide_id(unsigned char c)
         case 'C': case 'c': return 1u;
         case 'G': case 'g': return 2u;
         case 'T': case 't': return 3u;
-        default: return 4u;  // N n - . (the host rejects every other character before the upload)
+        case 'N': case 'n': case '-': case '.': return 4u;
+        default: return 5u;
     }
 }
 
 __global__ __launch_bounds__(256) void extract_frames_kernel(const FrameSegment* __restrict__ seg, const unsigned char* __restrict__ nucl,
                                                              size_t row_stride, int n_leaves, unsigned char* __restrict__ codons,
-                                                             size_t leaf_stride)
+                                                             size_t leaf_stride, unsigned long long* __restrict__ first_bad)
 {
     // 64 codons x 4 groups of species per work-group: a wave writes 64 consecutive codons of one species row, and the
     // four waves walk different species (shorter dependent chains than one thread per codon over all species)
@@ -40,30 +42,32 @@ __global__ __launch_bounds__(256) void extract_frames_kernel(const FrameSegment*
     for (int l = static_cast<int>(threadIdx.x >> 6); l < n_leaves; l += 4) {
         const unsigned char* row = nucl + static_cast<size_t>(l) * row_stride;
         unsigned a, b, d;
-        if (minus) {
-            a = nucleotide_id(row[first]);
-            b = nucleotide_id(row[first - 1]);
-            d = nucleotide_id(row[first - 2]);
-            a = a < 4u ? 3u - a : a;  // complement: A<->T, C<->G
+        const size_t second = minus ? first - 1 : first + 1, third = minus ? first - 2 : first + 2;
+        a = nucleotide_id(row[first]);
+        b = nucleotide_id(row[second]);
+        d = nucleotide_id(row[third]);
+        if ((a | b | d) > 4u && first_bad) {  // a | b | d > 4 needs a 5: a character outside ACGTNacgtn-. -- the call fails with its position
+            const size_t where = a == 5u ? first : (b == 5u ? second : third);
+            atomicMin(first_bad, static_cast<unsigned long long>(static_cast<size_t>(l) * row_stride + where));
+        }
+        if (minus) {  // complement: A<->T, C<->G
+            a = a < 4u ? 3u - a : a;
             b = b < 4u ? 3u - b : b;
             d = d < 4u ? 3u - d : d;
-        } else {
-            a = nucleotide_id(row[first]);
-            b = nucleotide_id(row[first + 1]);
-            d = nucleotide_id(row[first + 2]);
         }
-        const unsigned cod = (a == 4u || b == 4u || d == 4u) ? 64u : 16u * a + 4u * b + d;
+        const unsigned cod = (a >= 4u || b >= 4u || d >= 4u) ? 64u : 16u * a + 4u * b + d;
         codons[static_cast<size_t>(l) * leaf_stride + dst] = static_cast<unsigned char>(cod);
     }
 }
 
 hipError_t launch_extract_frames(const FrameSegment* d_seg, uint32_t n_segments, uint32_t max_codons, const unsigned char* d_nucl,
-                                 size_t row_stride, int n_leaves, unsigned char* d_codons, size_t leaf_stride, hipStream_t stream)
+                                 size_t row_stride, int n_leaves, unsigned char* d_codons, size_t leaf_stride, unsigned long long* d_first_bad,
+                                 hipStream_t stream)
 {
     if (n_segments == 0 || max_codons == 0) return hipSuccess;
     if (n_segments > 65535u) return hipErrorInvalidValue;
     hipLaunchKernelGGL(extract_frames_kernel, dim3((max_codons + 63u) / 64u, n_segments), dim3(256), 0, stream, d_seg, d_nucl, row_stride,
-                       n_leaves, d_codons, leaf_stride);
+                       n_leaves, d_codons, leaf_stride, d_first_bad);
     return hipGetLastError();
 }
 

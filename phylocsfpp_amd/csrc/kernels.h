@@ -87,6 +87,42 @@ struct ExpmParams {
 
 hipError_t launch_expm(const ExpmParams& p, hipStream_t stream);
 
+// ---- factored block-mode pruning (factored.hip): no explicit branch matrices --------------------------------------
+// One job = one tile: up to 16 consecutive sites of one evaluation.  e_b[k] = exp(lambda_k t_b) comes from
+// launch_edge_scale (row `eval` of edge_scale, states in row-split order), R / L / priors from the eigen-system `eig`.
+struct FactoredJob {
+    uint64_t site0;     // first site of the tile in the codon matrix
+    uint64_t out0;      // index of the tile's first site in out_lnz / out_anc
+    uint32_t n_sites;   // 1..16
+    uint32_t eig;       // eigen-system index
+    uint32_t eval;      // row of edge_scale (= the evaluation's table index)
+    uint32_t pad;
+};
+
+struct FactoredParams {
+    const FactoredJob* jobs;
+    uint32_t n_jobs;
+    const uint8_t* codons;      // [n_leaves][leaf_stride]
+    size_t leaf_stride;
+    const uint32_t* program;    // the fused pruning program of the context (schedule.hpp)
+    int n_ops;
+    const int32_t* slot_branch; // [n_edges] MATMUL slot -> branch (node id of the child)
+    int n_edges, n_leaves;
+    uint32_t n_branches;
+    const double* eig_right;    // [n_eig][64*64]
+    const double* eig_left;     // [n_eig][64*64]
+    const double* prior;        // [n_eig][4][16] lane order
+    const double* anc_weight;   // [n_eig][4][16] lane order (read only if out_anc)
+    const double* edge_scale;   // [n_eval][n_branches][64] row-split order
+    double* out_lnz;
+    double* out_anc;            // or null
+};
+
+// evals[i].table selects the output row of d_scale_out and the failure flag; evals[i].eig the eigen-system
+hipError_t launch_edge_scale(const ExpmEval* d_evals, uint32_t n_evals, uint32_t n_branches, const float* d_branch_len, const double* d_eig_right,
+                             const double* d_eig_left, const double* d_eig_lambda, double* d_scale_out, uint32_t* d_fail, hipStream_t stream);
+hipError_t launch_prune_factored(const FactoredParams& p, hipStream_t stream);
+
 // Batched eigen-systems of the kappa/omega F3x4 rate matrix (eigen.hip): one job = one rate matrix.
 struct EigenJob {
     uint32_t eig;      // destination eigen-system index
@@ -125,8 +161,11 @@ struct FrameSegment {
     uint32_t minus;     // 0 = '+' strand, 1 = '-' strand (reverse complement, codons stored mirrored)
 };
 
+// d_first_bad (may be null): atomicMin of row * row_stride + col over the characters outside ACGTNacgtn-. that a codon touches
+// (the caller initialises it to BLS_NO_BAD)
 hipError_t launch_extract_frames(const FrameSegment* d_seg, uint32_t n_segments, uint32_t max_codons, const unsigned char* d_nucl,
-                                 size_t row_stride, int n_leaves, unsigned char* d_codons, size_t leaf_stride, hipStream_t stream);
+                                 size_t row_stride, int n_leaves, unsigned char* d_codons, size_t leaf_stride, unsigned long long* d_first_bad,
+                                 hipStream_t stream);
 
 // ---- branch-length score (power track) ---------------------------------------------------------------------
 constexpr int BLS_MAX_NODES = 255;  // species sets are 128-bit masks: at most 128 leaves

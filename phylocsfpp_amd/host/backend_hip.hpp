@@ -58,8 +58,9 @@ public:
 
     char* staging_alloc(size_t bytes) override
     {
-        char* p = static_cast<char*>(pcsf_host_alloc(bytes));
-        if (!p) throw std::runtime_error("pcsf_host_alloc failed");
+        // on this context's GPU (no primary context on device 0 for a run on another device); never zero bytes
+        char* p = static_cast<char*>(pcsf_host_alloc_on(ctx_, bytes ? bytes : 1));
+        if (!p) throw std::runtime_error("pcsf_host_alloc_on failed");
         return p;
     }
     void staging_free(char* p) override { pcsf_host_free(p); }

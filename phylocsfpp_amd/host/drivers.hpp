@@ -175,6 +175,44 @@ inline FILE* open_out(const std::string& path, const char* mode)
     return f;
 }
 
+// An output file that is closed on every path out of its scope.  Unless commit() was called, a file this run CREATED
+// (mode "w") is removed again: a failed build-tracks must not leave truncated wig files behind for a later --append or
+// smooth-tracks run to read.
+class OutFile {
+public:
+    OutFile() = default;
+    OutFile(const std::string& path, const char* mode) { open(path, mode); }
+    OutFile(const OutFile&) = delete;
+    OutFile& operator=(const OutFile&) = delete;
+    ~OutFile()
+    {
+        if (!f_) return;
+        fclose(f_);
+        if (!committed_ && created_) unlink(path_.c_str());
+    }
+    void open(const std::string& path, const char* mode)
+    {
+        f_ = open_out(path, mode);
+        path_ = path;
+        created_ = mode[0] == 'w';
+    }
+    void commit()  // success: flush, close, keep
+    {
+        if (!f_) return;
+        committed_ = true;
+        const int rc = fclose(f_);
+        f_ = nullptr;
+        if (rc != 0) throw std::runtime_error("write failed: '" + path_ + "'");
+    }
+    FILE* get() const { return f_; }
+    explicit operator bool() const { return f_ != nullptr; }
+
+private:
+    FILE* f_ = nullptr;
+    std::string path_;
+    bool created_ = false, committed_ = false;
+};
+
 struct BuildTracksStats {
     size_t alignments = 0, ref_bases = 0, codon_frames = 0, backend_calls = 0;
     double backend_seconds = 0.0;                       // inside ScoringBackend::score_sites_fixed (H2D + kernel + D2H)
@@ -237,8 +275,11 @@ inline void smooth_tracks(const std::string& out_dir, const Hmm& hmm, bool write
         const char strand = fi < 3 ? '+' : '-';
         const std::string tag = std::string(1, strand) + std::to_string(fi % 3 + 1);
         const std::string raw = out_dir + "/PhyloCSFRaw" + tag + ".wig";
-        FILE* f_wig = write_smooth ? open_out(out_dir + "/PhyloCSF" + tag + ".wig", "w") : nullptr;
-        FILE* f_bed = write_regions ? open_out(out_dir + "/PhyloCSF" + tag + "Regions.bed", "w") : nullptr;
+        OutFile wig_file, bed_file;  // closed (and, on failure, removed) on every path out of this job
+        if (write_smooth) wig_file.open(out_dir + "/PhyloCSF" + tag + ".wig", "w");
+        if (write_regions) bed_file.open(out_dir + "/PhyloCSF" + tag + "Regions.bed", "w");
+        FILE* f_wig = wig_file.get();
+        FILE* f_bed = bed_file.get();
         std::vector<double> post, work;
         std::vector<BedRegion> regions;
         {
@@ -259,8 +300,8 @@ inline void smooth_tracks(const std::string& out_dir, const Hmm& hmm, bool write
             });
             if (out) out->flush();
         }
-        if (f_wig) fclose(f_wig);
-        if (f_bed) fclose(f_bed);
+        wig_file.commit();
+        bed_file.commit();
         if (!keep_raw) unlink(raw.c_str());
     });
 }
@@ -278,14 +319,18 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     const std::string out_dir = prm.output_dir.empty() ? dirname_of(maf_path) : prm.output_dir;
     mkdir(out_dir.c_str(), 0764);
     const char* mode = append ? "a" : "w";
-    FILE* f_power = prm.write_power ? open_out(out_dir + "/PhyloCSFpower.wig", mode) : nullptr;
+    OutFile power_file, raw_file[6];  // closed on every path; files created by a failed run are removed
+    if (prm.write_power) power_file.open(out_dir + "/PhyloCSFpower.wig", mode);
+    FILE* f_power = power_file.get();
     FILE* f_raw[6] = {nullptr};
     // the smoothing pass reads the raw tracks back (as text, like the reference), so they are written even when
     // they were not asked for, and removed afterwards
     const bool need_raw = prm.write_raw || prm.write_smooth || prm.write_regions;
     if (need_raw)
-        for (int i = 0; i < 6; ++i)
-            f_raw[i] = open_out(out_dir + "/PhyloCSFRaw" + std::string(1, i < 3 ? '+' : '-') + std::to_string(i % 3 + 1) + ".wig", mode);
+        for (int i = 0; i < 6; ++i) {
+            raw_file[i].open(out_dir + "/PhyloCSFRaw" + std::string(1, i < 3 ? '+' : '-') + std::to_string(i % 3 + 1) + ".wig", mode);
+            f_raw[i] = raw_file[i].get();
+        }
 
     struct Item {  // one alignment
         std::string chrom;
@@ -566,9 +611,8 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         throw;
     }
     alive.clear();
-    if (f_power) fclose(f_power);
-    for (FILE* f : f_raw)
-        if (f) fclose(f);
+    power_file.commit();
+    for (OutFile& f : raw_file) f.commit();
     if (prm.write_smooth || prm.write_regions) {
         sw.lap();
         smooth_tracks(out_dir, prm.hmm, prm.write_smooth, prm.write_regions, /*keep_raw=*/prm.write_raw, threads);

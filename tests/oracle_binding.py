@@ -33,6 +33,11 @@ class PoQdiag(C.Structure):
                 ("Sinv", C.c_double * 4096), ("prior", C.c_double * 64)]
 
 
+class PoTraceEntry(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("failed", C.c_int32), ("x", C.c_double), ("tree_scale", C.c_double),
+                ("q_settings", C.c_double * 12), ("lpr", C.c_double)]
+
+
 def build():
     """make -C oracle: called by tests/conftest.py at session start and by __graft_entry__.build(), never from lib()."""
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -134,6 +139,42 @@ class OracleModel:
         ph, an = C.c_float(), C.c_float()
         lib().po_run(C.byref(self.m), algo, _u8p(codons), n, max(n, 1), int(compute_anc), seed, C.byref(ph), C.byref(an))
         return ph.value, an.value
+
+    def run_trace(self, algo, codons, compute_anc=False, seed=42, cap=4096):
+        """po_run plus every objective evaluation in order: (phylo, anc, [PoTraceEntry...])."""
+        codons = np.ascontiguousarray(codons, dtype=np.uint8)
+        n = codons.shape[1]
+        buf = (PoTraceEntry * cap)()
+        ph, an, cnt = C.c_float(), C.c_float(), C.c_int()
+        fn = lib().po_run_trace
+        fn.argtypes = [C.POINTER(PoModel), C.c_int, C.POINTER(C.c_uint8), C.c_size_t, C.c_size_t, C.c_int, C.c_uint32,
+                       C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(PoTraceEntry), C.c_int, C.POINTER(C.c_int)]
+        fn(C.byref(self.m), algo, _u8p(codons), n, max(n, 1), int(compute_anc), seed, C.byref(ph), C.byref(an), buf, cap, C.byref(cnt))
+        assert cnt.value <= cap, "trace buffer too small"
+        return ph.value, an.value, [buf[i] for i in range(cnt.value)]
+
+    def run_blocks(self, algo, codons, site_offsets, compute_anc=True, seed=42, threads=0):
+        """po_run_blocks: score-msa's block loop (every block alone, seeded alike), OpenMP over blocks."""
+        codons = np.ascontiguousarray(codons, dtype=np.uint8)
+        off = np.ascontiguousarray(site_offsets, dtype=np.uint64)
+        nb = len(off) - 1
+        ph = np.full(nb, np.nan, np.float32)
+        an = np.full(nb, np.nan, np.float32)
+        fn = lib().po_run_blocks
+        fn.argtypes = [C.POINTER(PoModel), C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.c_size_t, C.c_size_t, C.c_int,
+                       C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
+        fn(C.byref(self.m), algo, _u8p(codons), off.ctypes.data_as(C.POINTER(C.c_uint64)), nb, codons.shape[1], int(compute_anc), seed,
+           ph.ctypes.data_as(C.POINTER(C.c_float)), an.ctypes.data_as(C.POINTER(C.c_float)), threads)
+        return ph, an
+
+    def eig_of_settings(self, q_settings):
+        """PoQdiag of the kappa/omega F3x4 rate matrix at q_settings[12] (po_q_from_omega + po_eig)."""
+        qs = np.ascontiguousarray(q_settings, dtype=np.float64)
+        Q, pi = np.empty((64, 64)), np.empty(64)
+        lib().po_q_from_omega(_dp(qs), _dp(Q), _dp(pi))
+        qd = PoQdiag()
+        lib().po_eig(_dp(Q), _dp(pi), C.byref(qd))
+        return qd
 
     def baseline_run_tracks(self, codons, site_offsets, threads=0):
         codons = np.ascontiguousarray(codons, dtype=np.uint8)

@@ -133,3 +133,26 @@ def test_oracle_bls_matches_golden_bls_column(oracle_models):
         score, per_base = m.bls(mat)
         assert "%.6f" % np.float32(score) == row[6]
         assert per_base.shape == (mat.shape[1],) and (per_base >= 0).all() and (per_base <= 1).all()
+
+
+def test_kept_oracle_outputs_are_what_the_oracle_computes(oracle_models):
+    """tests/golden/oracle/*.npy (the oracle's MLE / OMEGA end results on the 50 + 516 golden blocks, used by the GPU suite
+    to count the rows that agree to 1e-6) must be what the live oracle computes: a sample of blocks is re-run here."""
+    import numpy as np
+    import maf_blocks
+    import oracle_binding as ob
+    m = oracle_models("100vertebrates")
+    aliases = os.path.join(GOLD, "models", "species_aliases.tsv")
+    for tag, name, picks in (("small", "chr22.50alignments.maf", (0, 7, 23, 49)), ("medium", "chr22.516alignments.maf.gz", (3, 100, 257, 515))):
+        cod, off = maf_blocks.block_codons(os.path.join(GOLD, "score-msa", name), m.labels, aliases)
+        mle = np.load(os.path.join(GOLD, "oracle", tag + "_mle.npy"))
+        omega = np.load(os.path.join(GOLD, "oracle", tag + "_omega.npy"))
+        assert mle.shape == (2, len(off) - 1) and omega.shape == (len(off) - 1,)
+        for b in picks:
+            blk = np.ascontiguousarray(cod[:, int(off[b]):int(off[b + 1])])
+            if blk.shape[1] > 60:
+                continue                                   # keep the CPU suite short; long blocks cost seconds each
+            ph, an = m.run(ob.MLE, blk, compute_anc=True)
+            assert np.array_equal(np.float32([ph, an]), mle[:, b], equal_nan=True), (tag, b)
+            ph, _ = m.run(ob.OMEGA, blk, compute_anc=False)
+            assert np.array_equal(np.float32(ph), omega[b], equal_nan=True), (tag, b)
