@@ -101,7 +101,7 @@ PruneParams base_prune_params(const pcsf_ctx* c)
 }
 
 int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t leaf_stride, double* d_out, double* d_lnz,
-                 double* d_anc, hipStream_t stream)
+                 double* d_anc, hipStream_t stream, const FusedFrontEnd* fused)
 {
     PruneParams p = base_prune_params(c);
     p.codons = d_codons;
@@ -110,9 +110,18 @@ int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t le
     p.out_score = d_out;
     p.out_lnz = d_lnz;
     p.out_anc = d_anc;
+    int variant = c->variant;
+    if (fused) {
+        p.nucl = fused->nucl;
+        p.nucl_stride = fused->nucl_stride;
+        p.segments = fused->segments;
+        p.wg_first_seg = fused->wg_first_seg;
+        p.first_bad = fused->first_bad;
+        variant = 32;
+    }
     hipError_t e;
     if (c->timing && (e = hipEventRecord(c->ev0, stream)) != hipSuccess) return c->hip_fail(e, "hipEventRecord");
-    if ((e = launch_prune_fixed(p, c->variant, stream, c->extra_lds)) != hipSuccess) return c->hip_fail(e, "launch prune_fixed");
+    if ((e = launch_prune_fixed(p, variant, stream, c->extra_lds)) != hipSuccess) return c->hip_fail(e, "launch prune_fixed");
     if (c->timing) {
         if ((e = hipEventRecord(c->ev1, stream)) != hipSuccess) return c->hip_fail(e, "hipEventRecord");
         if ((e = hipEventSynchronize(c->ev1)) != hipSuccess) return c->hip_fail(e, "hipEventSynchronize");
@@ -350,6 +359,7 @@ int pcsf_create(pcsf_ctx** out, const pcsf_model_desc* m, int device_id)
     c->stagger_first_blocks = 2u * static_cast<uint32_t>(prop.multiProcessorCount);
     if (const char* v = std::getenv("PCSF_STAGGER")) c->stagger_sleep = std::atoi(v);
     if (const char* v = std::getenv("PCSF_EXTRA_LDS")) c->extra_lds = static_cast<size_t>(std::atoi(v));
+    if (const char* v = std::getenv("PCSF_FUSED_FRONTEND")) c->fused_frontend = std::atoi(v) != 0;
     if (const char* v = std::getenv("PCSF_PRUNE_VARIANT")) {
         const int vi = std::atoi(v);
         if (vi >= 0 && vi < pcsf::prune_variant_count()) c->variant = vi;
@@ -497,19 +507,35 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
     // two streams so that transfers overlap kernels was measured and gains nothing: with page-locked buffers the
     // transfers are 0.5 ms of a 12 ms call and the extra launches and kernel tails cost as much.
     const size_t nl = static_cast<size_t>(c->n_leaves);
+    // The six-frame translation runs inside the pruning kernel (kernels.hip, FUSED): its work-groups form their codon
+    // columns from the resident nucleotide rows, so no codon matrix is written or re-read.  PCSF_FUSED_FRONTEND=0 keeps
+    // the separate extract_frames_kernel (A/B measurements; results are identical).
+    const bool fused = c->fused_frontend;
+    std::vector<uint32_t> wg_first_seg;
+    if (fused) {  // segment that holds site 64 b, for every work-group b
+        wg_first_seg.resize((total + 63) / 64);
+        size_t k = 0;
+        for (size_t b = 0; b < wg_first_seg.size(); ++b) {
+            while (b * 64 >= seg[k].dst0 + seg[k].n_codons) ++k;
+            wg_first_seg[b] = static_cast<uint32_t>(k);
+        }
+    }
     if ((e = c->d_nucl.reserve(nl * max_col)) != hipSuccess) return c->hip_fail(e, "hipMalloc(nucleotides)");
     if ((e = c->d_segments.reserve(seg.size() * sizeof(pcsf::FrameSegment))) != hipSuccess) return c->hip_fail(e, "hipMalloc(segments)");
-    if ((e = c->d_codons.reserve(nl * total)) != hipSuccess) return c->hip_fail(e, "hipMalloc(codons)");
+    if (!fused && (e = c->d_codons.reserve(nl * total)) != hipSuccess) return c->hip_fail(e, "hipMalloc(codons)");
+    if (fused && (e = c->d_wg_seg.reserve(wg_first_seg.size() * sizeof(uint32_t))) != hipSuccess) return c->hip_fail(e, "hipMalloc(work-group segments)");
     if ((e = c->d_out.reserve(total * sizeof(double))) != hipSuccess) return c->hip_fail(e, "hipMalloc(out)");
     if ((e = pcsf::upload_rows(c->d_nucl.ptr, nucleotides, row_stride, max_col, nl, c->stream)) != hipSuccess) return c->hip_fail(e, "upload(nucleotides)");
     if ((e = hipMemcpyAsync(c->d_segments.ptr, seg.data(), seg.size() * sizeof(pcsf::FrameSegment), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
         return c->hip_fail(e, "hipMemcpyAsync(segments)");
+    if (fused && (e = hipMemcpyAsync(c->d_wg_seg.ptr, wg_first_seg.data(), wg_first_seg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
+        return c->hip_fail(e, "hipMemcpyAsync(work-group segments)");
     int rc;
     KernelTurn& turn = g_kernel_turn[c->device & 63];
     std::unique_lock<std::mutex> my_turn(turn.lock);
     if (turn.last && turn.owner != c && (e = hipStreamWaitEvent(c->stream, turn.last, 0)) != hipSuccess) return c->hip_fail(e, "hipStreamWaitEvent");
     // the power track's per-base scores from the same resident rows (that kernel also checks every character); without
-    // them the frame extraction does the character check itself, so that both entry points reject the same input
+    // them the translation does the character check itself, so that both entry points reject the same input
     unsigned long long* d_char_flag = nullptr;
     if (out_bls) {
         if ((rc = pcsf::bls_enqueue(c, c->d_nucl.as<unsigned char>(), max_col, max_col, spans)) != PCSF_OK) return rc;
@@ -520,14 +546,19 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
         if ((e = hipMemsetAsync(c->d_bls_flag.ptr, 0xff, sizeof(unsigned long long), c->stream)) != hipSuccess) return c->hip_fail(e, "hipMemsetAsync(character flag)");
         d_char_flag = c->d_bls_flag.as<unsigned long long>();
     }
-    // at most 65535 segments per launch (grid.y)
-    for (size_t s0 = 0; s0 < seg.size(); s0 += 65535) {
-        const uint32_t ns = static_cast<uint32_t>(std::min<size_t>(65535, seg.size() - s0));
-        if ((e = pcsf::launch_extract_frames(c->d_segments.as<pcsf::FrameSegment>() + s0, ns, max_codons, c->d_nucl.as<unsigned char>(), max_col,
-                                             c->n_leaves, c->d_codons.as<unsigned char>(), total, d_char_flag, c->stream)) != hipSuccess)
-            return c->hip_fail(e, "launch extract_frames");
+    if (fused) {
+        pcsf::FusedFrontEnd fe{c->d_nucl.as<unsigned char>(), max_col, c->d_segments.as<pcsf::FrameSegment>(), c->d_wg_seg.as<uint32_t>(), d_char_flag};
+        if ((rc = pcsf::launch_fixed(c, nullptr, total, total, c->d_out.as<double>(), nullptr, nullptr, c->stream, &fe)) != PCSF_OK) return rc;
+    } else {
+        // at most 65535 segments per launch (grid.y)
+        for (size_t s0 = 0; s0 < seg.size(); s0 += 65535) {
+            const uint32_t ns = static_cast<uint32_t>(std::min<size_t>(65535, seg.size() - s0));
+            if ((e = pcsf::launch_extract_frames(c->d_segments.as<pcsf::FrameSegment>() + s0, ns, max_codons, c->d_nucl.as<unsigned char>(), max_col,
+                                                 c->n_leaves, c->d_codons.as<unsigned char>(), total, d_char_flag, c->stream)) != hipSuccess)
+                return c->hip_fail(e, "launch extract_frames");
+        }
+        if ((rc = pcsf::launch_fixed(c, c->d_codons.as<uint8_t>(), total, total, c->d_out.as<double>(), nullptr, nullptr, c->stream)) != PCSF_OK) return rc;
     }
-    if ((rc = pcsf::launch_fixed(c, c->d_codons.as<uint8_t>(), total, total, c->d_out.as<double>(), nullptr, nullptr, c->stream)) != PCSF_OK) return rc;
     if ((e = hipEventRecord(c->ev_kernels, c->stream)) != hipSuccess) return c->hip_fail(e, "hipEventRecord");
     turn.last = c->ev_kernels;
     turn.owner = c;

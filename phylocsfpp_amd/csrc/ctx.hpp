@@ -80,7 +80,8 @@ struct pcsf_ctx {
     // device-resident model (table sets 0 = coding, 1 = non-coding at tree scale 1)
     pcsf::DeviceBuffer d_program, d_frag, d_leaf_tab, d_prior, d_anc_weight;
     // scratch for the host-pointer entry points
-    pcsf::DeviceBuffer d_codons, d_out, d_lnz, d_anc, d_stamps, d_nucl, d_segments;
+    pcsf::DeviceBuffer d_codons, d_out, d_lnz, d_anc, d_stamps, d_nucl, d_segments, d_wg_seg;
+    bool fused_frontend = true;          // six-frame translation inside the pruning kernel (PCSF_FUSED_FRONTEND=0: separate kernel)
     // branch-length score (pcsf_set_bls_branch_lengths)
     pcsf::DeviceBuffer d_bls_tree, d_bls_out, d_bls_spans, d_bls_flag;
     pcsf::BlsTree bls_tree{};
@@ -127,9 +128,18 @@ inline hipError_t upload_rows(void* dst, const void* src, size_t src_pitch, size
 }
 // fills the kernel parameters that describe the resident model (tables of sets 0 and 1)
 PruneParams base_prune_params(const pcsf_ctx* c);
-// launches the tracks-mode kernel over `n_sites` device-resident sites (both models)
+// the six-frame front end fused into the pruning kernel: device pointers of one call
+struct FusedFrontEnd {
+    const unsigned char* nucl;
+    size_t nucl_stride;
+    const FrameSegment* segments;
+    const uint32_t* wg_first_seg;
+    unsigned long long* first_bad;
+};
+// launches the tracks-mode kernel over `n_sites` device-resident sites (both models); fused != null: the sites are
+// the codons of fused->segments, formed in the kernel (d_codons is not read)
 int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t leaf_stride, double* d_out, double* d_lnz,
-                 double* d_anc, hipStream_t stream);
+                 double* d_anc, hipStream_t stream, const FusedFrontEnd* fused = nullptr);
 // run() for a batch of blocks (blocks.cpp)
 int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64_t* site_offsets, size_t n_blocks,
                       size_t leaf_stride, int compute_anc, uint32_t seed, float* out_phylo, float* out_anc);

@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "kernels.h"
 
 namespace pcsf {
@@ -312,11 +314,13 @@ hipError_t launch_eigen_omega(const EigenParams& p, hipStream_t stream)
 {
     if (p.n_jobs == 0) return hipSuccess;
     constexpr size_t lds = 2 * 64 * LD * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_set{0};  // per device (kernels.hip launch_impl)
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    if (!(attr_set.load(std::memory_order_acquire) >> (dev & 63) & 1)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eigen_omega_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
     }
     hipLaunchKernelGGL(eigen_omega_kernel, dim3(p.n_jobs), dim3(256), lds, stream, p);
     return hipGetLastError();

@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "kernels.h"
 
 namespace pcsf {
@@ -194,11 +196,13 @@ hipError_t launch_expm(const ExpmParams& p, hipStream_t stream)
     if (n_jobs == 0) return hipSuccess;
     if (n_jobs > 0x7fffffffULL) return hipErrorInvalidValue;
     constexpr size_t lds = (64 * 65 + 64 * 64) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_set{0};  // per device (kernels.hip launch_impl)
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    if (!(attr_set.load(std::memory_order_acquire) >> (dev & 63) & 1)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&expm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
     }
     hipLaunchKernelGGL(expm_kernel, dim3(static_cast<unsigned>((n_jobs + EXPM_CHUNK - 1) / EXPM_CHUNK)), dim3(256), lds, stream, p);
     return hipGetLastError();

@@ -14,8 +14,15 @@ constexpr int MAX_STACK_DEPTH_DEV = 3;
 // fused op codes of the pruning program (schedule.hpp FusedOp is the host-side twin of this list)
 constexpr uint32_t F_CHERRY_DEV = 0, F_MM_LEAF_DEV = 1, F_MM_PUSH_CHERRY0_DEV = 2, F_MM_POP0_DEV = 5, F_ROOT_DEV = 8;
 
+struct FrameSegment;
 struct PruneParams {
-    const uint8_t* codons;   // [n_leaves][leaf_stride], 0..63 or 64 = marginalise
+    const uint8_t* codons;   // [n_leaves][leaf_stride], 0..63 or 64 = marginalise (not read by the fused variant)
+    // fused six-frame front end (variant 32): the sites are the codons of `segments` laid end to end
+    const unsigned char* nucl;        // [n_leaves][nucl_stride] ASCII rows
+    size_t nucl_stride;
+    const FrameSegment* segments;     // in site order, none empty
+    const uint32_t* wg_first_seg;     // [work-groups] segment that holds the work-group's first site
+    unsigned long long* first_bad;    // atomicMin of row * nucl_stride + col over characters outside ACGTNacgtn-. (may be null)
     size_t n_sites;
     size_t leaf_stride;
     const uint32_t* program; // [n_ops]
@@ -46,7 +53,8 @@ struct PruneParams {
 };
 
 // variant: 0 = 4 waves (64 sites) per work-group, 1 = 8 waves (128 sites) per work-group,
-// 2 = variant 0 with in-kernel stamps (diagnostic only), 16 = block mode (per-work-group windows and tables)
+// 2 = variant 0 with in-kernel stamps (diagnostic only), 16 = block mode (per-work-group windows and tables),
+// 32 = variant 0 with the six-frame front end fused in (codons formed from nucleotide rows in the prologue)
 hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t stream, size_t extra_lds = 0);
 int prune_variant_count();
 

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "kernels.h"
@@ -116,7 +117,11 @@ __device__ __forceinline__ unsigned long long stamp_now()
 // BLOCKS: per-work-group site window and table set (whole-block scoring with per-block branch
 // matrices, MLE / OMEGA); otherwise work-group b owns sites [b*SITES, (b+1)*SITES) and passes
 // 0..n_passes-1 use table sets 0..n_passes-1 (coding, non-coding).
-template <int NW, bool STAMP, bool BLOCKS>
+// FUSED (tracks mode): the codon columns are not read from a codon matrix but formed here from the resident
+// nucleotide rows -- the six-frame front end (alignment_t::update_seqs / translate and the reverse complement between
+// the strands, src/parallel_file_reader.hpp:61-113, src/phylocsf++build_tracks.hpp:162-227) runs in the prologue of the
+// work-group that scores the columns, and the leaf-major codon matrix never exists in HBM.
+template <int NW, bool STAMP, bool BLOCKS, bool FUSED>
 __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -140,8 +145,67 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     // ---- stage this work-group's codon columns into LDS (clamped to 0..64; 64 beyond the end)
     // A full, 16-byte aligned window moves as one 16-byte load per thread (58 leaves x 64 sites = 232 pieces):
     // the byte-wise loop below costs ~15 dependent round trips per work-group while the CU's other group runs alone.
-    const bool whole_window = block_site0 + SITES <= site_end && ((block_site0 | p.leaf_stride | reinterpret_cast<size_t>(p.codons)) & 15) == 0;
-    if (whole_window) {
+    const bool whole_window = !FUSED && block_site0 + SITES <= site_end && ((block_site0 | p.leaf_stride | reinterpret_cast<size_t>(p.codons)) & 15) == 0;
+    if constexpr (FUSED) {
+        // phase 1, one thread per site: which (alignment, strand, frame) segment the site belongs to and where its codon
+        // starts.  Segments follow each other in the site stream; the host gives the segment of the window's first site.
+        // Site i of a '-' segment holds codon n-1-i (scores come out in forward genome order); its three columns are read
+        // right to left and complemented.
+        unsigned char* lut = lcod + ((p.n_leaves * SITES + 15) & ~15);                   // [256] character classes
+        long long* lfirst = reinterpret_cast<long long*>(lut + 256);                     // [SITES] first column of the codon, -1: no site
+        unsigned char* lminus = reinterpret_cast<unsigned char*>(lfirst + SITES);        // [SITES]
+        for (int ch = tid; ch < 256; ch += NW * 64) {
+            unsigned v = 5u;                                                             // a character the reference exits on
+            switch (ch) {
+                case 'A': case 'a': v = 0u; break;
+                case 'C': case 'c': v = 1u; break;
+                case 'G': case 'g': v = 2u; break;
+                case 'T': case 't': v = 3u; break;
+                case 'N': case 'n': case '-': case '.': v = 4u; break;
+                default: break;
+            }
+            lut[ch] = static_cast<unsigned char>(v);
+        }
+        if (tid < SITES) {
+            const size_t site = block_site0 + tid;
+            long long first = -1;
+            unsigned minus = 0;
+            if (site < site_end) {
+                uint32_t k = p.wg_first_seg[blockIdx.x];
+                FrameSegment sg = p.segments[k];
+                while (site >= sg.dst0 + sg.n_codons) sg = p.segments[++k];
+                const size_t i = site - sg.dst0;
+                minus = sg.minus;
+                const size_t c = minus ? sg.n_codons - 1 - i : i;
+                first = static_cast<long long>(minus ? sg.col0 + sg.len - 1 - sg.skip - 3 * c : sg.col0 + sg.skip + 3 * c);
+            }
+            lfirst[tid] = first;
+            lminus[tid] = static_cast<unsigned char>(minus);
+        }
+        __syncthreads();
+        // phase 2: (leaf, site) pairs; consecutive threads read consecutive codons of one species row
+        for (int idx = tid; idx < p.n_leaves * SITES; idx += NW * 64) {
+            const int leaf = idx / SITES, s = idx - leaf * SITES;
+            const long long first = lfirst[s];
+            unsigned cod = 64u;
+            if (first >= 0) {
+                const unsigned char* row = p.nucl + static_cast<size_t>(leaf) * p.nucl_stride;
+                const long long step = lminus[s] ? -1 : 1;
+                unsigned a = lut[row[first]], b = lut[row[first + step]], d = lut[row[first + 2 * step]];
+                if ((a | b | d) > 4u && p.first_bad) {  // needs a 5: the call fails with the character's position
+                    const long long where = a == 5u ? first : (b == 5u ? first + step : first + 2 * step);
+                    atomicMin(p.first_bad, static_cast<unsigned long long>(static_cast<size_t>(leaf) * p.nucl_stride + static_cast<size_t>(where)));
+                }
+                if (lminus[s]) {  // complement: A<->T, C<->G
+                    a = a < 4u ? 3u - a : a;
+                    b = b < 4u ? 3u - b : b;
+                    d = d < 4u ? 3u - d : d;
+                }
+                cod = (a >= 4u || b >= 4u || d >= 4u) ? 64u : 16u * a + 4u * b + d;
+            }
+            lcod[idx] = static_cast<unsigned char>(cod);
+        }
+    } else if (whole_window) {
         constexpr int PIECES = SITES / 16;
         for (int idx = tid; idx < p.n_leaves * PIECES; idx += NW * 64) {
             const int leaf = idx / PIECES, piece = idx % PIECES;
@@ -417,23 +481,31 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     }
 }
 
-template <int NW, bool STAMP, bool BLOCKS>
+template <int NW, bool STAMP, bool BLOCKS, bool FUSED = false>
 static hipError_t launch_impl(const PruneParams& p, hipStream_t stream, size_t extra_lds)
 {
     const size_t sites_per_block = static_cast<size_t>(NW) * 16;
     const size_t blocks = BLOCKS ? p.n_wgs : (p.n_sites + sites_per_block - 1) / sites_per_block;
     if (blocks == 0) return hipSuccess;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
-    const size_t lds = 2 * FRAG_DOUBLES_DEV * sizeof(double) + ((static_cast<size_t>(p.n_ops) + 3) & ~size_t(3)) * 4 +
-                       static_cast<size_t>(p.n_leaves) * sites_per_block + extra_lds;
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_set = false;  // one flag per template instantiation
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prune_fixed<NW, STAMP, BLOCKS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
+    size_t lds = 2 * FRAG_DOUBLES_DEV * sizeof(double) + ((static_cast<size_t>(p.n_ops) + 3) & ~size_t(3)) * 4 +
+                 static_cast<size_t>(p.n_leaves) * sites_per_block + extra_lds;
+    if (FUSED) {
+        if (!p.nucl || !p.segments || !p.wg_first_seg) return hipErrorInvalidValue;
+        lds = ((lds + 15) & ~size_t(15)) + 256 + sites_per_block * 9 + 16;  // character classes, codon starts, strands
     }
-    hipLaunchKernelGGL((prune_fixed<NW, STAMP, BLOCKS>), dim3(static_cast<unsigned>(blocks)), dim3(NW * 64), lds, stream, p);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    // the attribute belongs to the (function, device) pair: one flag per template instantiation AND device.  Setting it
+    // twice is harmless, so concurrent first launches from two host threads need no lock, only an atomic bit mask.
+    static std::atomic<uint64_t> attr_set{0};
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    if (!(attr_set.load(std::memory_order_acquire) >> (dev & 63) & 1)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prune_fixed<NW, STAMP, BLOCKS, FUSED>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
+    }
+    hipLaunchKernelGGL((prune_fixed<NW, STAMP, BLOCKS, FUSED>), dim3(static_cast<unsigned>(blocks)), dim3(NW * 64), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -444,6 +516,7 @@ hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t str
         case 1: return launch_impl<8, false, false>(p, stream, extra_lds);
         case 2: return launch_impl<4, true, false>(p, stream, extra_lds);  // diagnostic: in-kernel stamps
         case 16: return launch_impl<4, false, true>(p, stream, extra_lds); // per-work-group windows/tables
+        case 32: return launch_impl<4, false, false, true>(p, stream, extra_lds);  // tracks mode, codons formed from the nucleotide rows
         default: return hipErrorInvalidValue;
     }
 }

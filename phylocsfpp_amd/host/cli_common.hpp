@@ -31,10 +31,12 @@ inline int usage(const char* prog)
             "                  [--output DIR] [--species A,B,...] [--mapping FILE] [--species-aliases FILE] [--device N | --devices N,M,...]\n"
             "                  <model prefix> <alignment.maf>...\n"
             "  %s smooth-tracks [--output-phylo 0|1] [--output-regions 0|1] (--genome-length N --coding-exons FILE | --hmm-params P) DIR\n"
+            "  %s pack-maf     [--threads N] [--species A,B,...] [--mapping FILE] <model prefix> <alignment.maf> <out.pcsfbin>\n"
+            "                  (build-tracks also reads the packed file: same tracks, no text parsing)\n"
             "--hmm-params: coding prior, mean coding length (codons), 3 non-coding weights, 3 non-coding mean lengths (codons)\n"
             "--species reduces the model's tree to the named species (tree labels or their other names)\n"
             "<model prefix> names <prefix>_coding.ECM, <prefix>_noncoding.ECM and <prefix>.nh\n",
-            prog, prog, prog);
+            prog, prog, prog, prog);
     return 2;
 }
 
@@ -127,6 +129,31 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
             for (int v = 0; v < model.n_nodes; ++v)
                 printf("%d\t%d\t%d\t%d\t%.17g\t%.9g\t%s\n", v, model.child1[v], model.child2[v], model.parent[v], model.branch_len_d[v],
                        static_cast<double>(model.branch_len[v]), model.label[v].c_str());
+        } catch (const std::exception& e) {
+            fprintf(stderr, "error: %s\n", e.what());
+            return 1;
+        }
+        return 0;
+    }
+    if (cmd == "pack-maf") {
+        std::string species, mapping;
+        int threads = 0, j = 2;
+        for (; j + 1 < argc && strncmp(argv[j], "--", 2) == 0; j += 2) {
+            if (std::string(argv[j]) == "--species") species = argv[j + 1];
+            else if (std::string(argv[j]) == "--mapping") mapping = argv[j + 1];
+            else if (std::string(argv[j]) == "--threads") threads = atoi(argv[j + 1]);
+            else return usage(argv[0]);
+        }
+        if (argc - j < 3) return usage(argv[0]);
+        try {
+            const std::string prefix = argv[j];
+            std::string al = dirname_of(prefix) + "/species_aliases.tsv";
+            if (FILE* f = fopen(al.c_str(), "r")) fclose(f);
+            else al.clear();
+            const Model model = load_model(prefix, al, species, mapping);
+            const PackStats st = pack_maf(model, argv[j + 1], argv[j + 2], threads);
+            fprintf(stderr, "%s -> %s: %zu alignments, %zu reference bases, %" PRIu64 " -> %" PRIu64 " bytes, %.3f s (%.2f GB/s of text)\n", argv[j + 1], argv[j + 2],
+                    st.alignments, st.ref_bases, st.bytes_in, st.bytes_out, st.seconds, static_cast<double>(st.bytes_in) / st.seconds / 1e9);
         } catch (const std::exception& e) {
             fprintf(stderr, "error: %s\n", e.what());
             return 1;

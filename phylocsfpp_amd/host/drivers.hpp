@@ -30,6 +30,7 @@
 
 #include "hmm.hpp"
 #include "maf_reader.hpp"
+#include "packed_reader.hpp"
 #include "model_io.hpp"
 #include "tracks.hpp"
 
@@ -382,6 +383,9 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     };
 
     MafFile file(maf_path);
+    // a packed alignment file (pack-maf, packed_reader.hpp) holds the reader's alignments ready-made: stage 1 only copies rows
+    const bool packed = is_packed_file(file);
+    const size_t input_bytes = packed ? static_cast<size_t>(PackedReader::data_bytes(file)) : file.size();
     const size_t window = std::max<size_t>(prm.window_bytes, 1 << 16);
     // batch matrices come from the backend (page-locked for the GPU) and are recycled: allocating them is slow
     struct StagingPool {
@@ -437,17 +441,20 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     auto prepare_window = [&](size_t w0) {
         std::unique_ptr<PreparedWindow> pw(new PreparedWindow);
         StopWatch parse_clock;
-        const size_t w1 = std::min(file.size(), w0 + window);
+        const size_t w1 = std::min(input_bytes, w0 + window);
         const size_t n_jobs = std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(threads) * 4, (w1 - w0 + (1 << 16) - 1) >> 16));
         pw->jobs.resize(n_jobs);
         std::vector<double> job_read(n_jobs, 0.0), job_bls(n_jobs, 0.0);
         parallel_for(n_jobs, threads, [&](size_t j) {
             const size_t b = w0 + (w1 - w0) * j / n_jobs, e = w0 + (w1 - w0) * (j + 1) / n_jobs;
-            MafReader reader(file, b, e, model.name_to_leaf, model.n_leaves, /*concatenate=*/true, prm.verbose && j == 0 && w0 == 0);
+            std::unique_ptr<MafReader> text_reader;
+            std::unique_ptr<PackedReader> packed_reader;
+            if (packed) packed_reader.reset(new PackedReader(file, b, e, model.n_leaves));
+            else text_reader.reset(new MafReader(file, b, e, model.name_to_leaf, model.n_leaves, /*concatenate=*/true, prm.verbose && j == 0 && w0 == 0));
             BranchLengthScore bls(model);
             Alignment aln;
             StopWatch jw;
-            while (reader.next(aln)) {
+            while (packed ? packed_reader->next(aln) : text_reader->next(aln)) {
                 job_read[j] += jw.lap();
                 Item it;
                 it.chrom = aln.chrom;
@@ -576,11 +583,11 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         while (inflight.size() > n_dev) retire_front();
     };
     std::future<std::unique_ptr<PreparedWindow>> next;
-    if (file.size() > 0) next = std::async(std::launch::async, prepare_window, size_t(0));
+    if (input_bytes > 0) next = std::async(std::launch::async, prepare_window, size_t(0));
     try {
-    for (size_t w0 = 0; w0 < file.size(); w0 += window) {
+    for (size_t w0 = 0; w0 < input_bytes; w0 += window) {
         std::unique_ptr<PreparedWindow> pw = next.get();
-        if (w0 + window < file.size()) next = std::async(std::launch::async, prepare_window, w0 + window);
+        if (w0 + window < input_bytes) next = std::async(std::launch::async, prepare_window, w0 + window);
         {  // busy seconds of stage 1 (it runs concurrently with the other stages): the parallel parse split by thread time
             const double cpu = pw->read + pw->bls, tot = (cpu > 0 ? cpu : 1.0);
             st.read_seconds += pw->parse_wall * pw->read / tot;
@@ -626,6 +633,48 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
                                      bool append = false)
 {
     return build_tracks(model, maf_path, prm, std::vector<ScoringBackend*>{&backend}, append);
+}
+
+// pack-maf: the build-tracks view of a MAF (what MafReader yields with concatenate = true) as a packed alignment file.
+// Byte-range jobs parse in parallel, window by window; records are written in file order.
+struct PackStats {
+    size_t alignments = 0, ref_bases = 0;
+    uint64_t bytes_in = 0, bytes_out = 0;
+    double seconds = 0.0;
+};
+inline PackStats pack_maf(const Model& model, const std::string& maf_path, const std::string& out_path, int threads, size_t window_bytes = size_t(256) << 20)
+{
+    StopWatch total;
+    MafFile file(maf_path);
+    if (is_packed_file(file)) throw std::runtime_error("'" + maf_path + "' is already a packed alignment file");
+    PackedWriter out(out_path, model.n_leaves);
+    PackStats st;
+    st.bytes_in = file.size();
+    if (threads <= 0) threads = effective_threads();
+    for (size_t w0 = 0; w0 < file.size(); w0 += window_bytes) {
+        const size_t w1 = std::min(file.size(), w0 + window_bytes);
+        const size_t n_jobs = std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(threads) * 4, (w1 - w0 + (1 << 16) - 1) >> 16));
+        std::vector<std::vector<Alignment>> jobs(n_jobs);
+        parallel_for(n_jobs, threads, [&](size_t j) {
+            const size_t b = w0 + (w1 - w0) * j / n_jobs, e = w0 + (w1 - w0) * (j + 1) / n_jobs;
+            MafReader reader(file, b, e, model.name_to_leaf, model.n_leaves, /*concatenate=*/true, false);
+            Alignment aln;
+            while (reader.next(aln)) {
+                jobs[j].emplace_back();
+                std::swap(jobs[j].back(), aln);
+            }
+        });
+        for (const auto& job : jobs)
+            for (const Alignment& a : job) {
+                out.add(a);
+                ++st.alignments;
+                st.ref_bases += a.length();
+            }
+    }
+    out.finish();
+    st.bytes_out = out.bytes();
+    st.seconds = total.lap();
+    return st;
 }
 
 struct ScoreMsaParams {

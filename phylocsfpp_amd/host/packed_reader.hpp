@@ -1,0 +1,172 @@
+// packed_reader.hpp -- binary form of what the MAF reader yields in build-tracks mode (".pcsfbin").
+//
+// build-tracks spends its host time turning ~90 bytes of MAF text per reference base into the leaf-major
+// nucleotide rows the scoring core takes (58 bytes per base for 58mammals).  At 8 GPUs that text parse (~25 GB/s
+// on the 16 host threads of a box) is the ceiling SURVEY.md 8d.4 names.  `phylocsf-amd pack-maf` runs the reader
+// ONCE -- concatenation, 'N' padding, reference-gap removal, the 1 Mb break points, i.e. every column-indexing
+// rule of src/parallel_file_reader.hpp:430-685 -- and stores its alignments; build-tracks on the packed file then
+// only copies rows.  The alignments, and therefore every output byte, are those of the text path
+// (tests/test_host_layer.py).
+//
+// Layout (little-endian):
+//   header   "PCSFBIN1" | u32 n_leaves | u32 0
+//   record   u32 'PCSR' | u32 chrom_bytes | u64 start_pos (1-based) | u64 chrom_len | u32 len | u32 n_leaves
+//            | chrom, padded with zeros to a multiple of 8 | n_leaves rows of len bytes, padded to a multiple of 8
+//   index    u64 record offsets [n_records]
+//   trailer  u64 n_records | u64 index offset | "PCSFIDX1"
+// A byte-range job owns the records that START inside its range (binary search in the index): any split of the
+// file yields every record exactly once, in order.
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "maf_reader.hpp"
+
+namespace pcsf_host {
+
+constexpr char PACKED_MAGIC[9] = "PCSFBIN1";
+constexpr char PACKED_INDEX_MAGIC[9] = "PCSFIDX1";
+constexpr uint32_t PACKED_RECORD_MAGIC = 0x52534350u;  // "PCSR"
+
+inline bool is_packed_file(const MafFile& f) { return f.size() >= 16 + 24 && memcmp(f.data(), PACKED_MAGIC, 8) == 0; }
+
+class PackedWriter {
+public:
+    PackedWriter(const std::string& path, int n_leaves) : n_leaves_(static_cast<uint32_t>(n_leaves))
+    {
+        f_ = fopen(path.c_str(), "wb");
+        if (!f_) throw std::runtime_error("cannot create file '" + path + "'");
+        put(PACKED_MAGIC, 8);
+        const uint32_t hdr[2] = {n_leaves_, 0u};
+        put(hdr, sizeof hdr);
+    }
+    PackedWriter(const PackedWriter&) = delete;
+    PackedWriter& operator=(const PackedWriter&) = delete;
+    ~PackedWriter()
+    {
+        if (f_) fclose(f_);
+    }
+    void add(const Alignment& aln)
+    {
+        if (aln.seqs.size() != n_leaves_) throw std::runtime_error("PackedWriter: alignment with a different number of rows");
+        offsets_.push_back(at_);
+        const uint32_t len = static_cast<uint32_t>(aln.length());
+        const uint32_t head[2] = {PACKED_RECORD_MAGIC, static_cast<uint32_t>(aln.chrom.size())};
+        put(head, sizeof head);
+        const uint64_t pos[2] = {aln.start_pos, aln.chrom_len};
+        put(pos, sizeof pos);
+        const uint32_t dims[2] = {len, n_leaves_};
+        put(dims, sizeof dims);
+        put(aln.chrom.data(), aln.chrom.size());
+        pad();
+        for (const std::string& row : aln.seqs) {
+            if (row.size() != len) throw std::runtime_error("PackedWriter: ragged alignment");
+            put(row.data(), len);
+        }
+        pad();
+    }
+    void finish()
+    {
+        const uint64_t index_at = at_;
+        if (!offsets_.empty()) put(offsets_.data(), offsets_.size() * sizeof(uint64_t));
+        const uint64_t tail[2] = {offsets_.size(), index_at};
+        put(tail, sizeof tail);
+        put(PACKED_INDEX_MAGIC, 8);
+        const int rc = fclose(f_);
+        f_ = nullptr;
+        if (rc != 0) throw std::runtime_error("write failed");
+    }
+    size_t records() const { return offsets_.size(); }
+    uint64_t bytes() const { return at_; }
+
+private:
+    void put(const void* p, size_t n)
+    {
+        if (n && fwrite(p, 1, n, f_) != n) throw std::runtime_error("write failed");
+        at_ += n;
+    }
+    void pad()
+    {
+        static const char zeros[8] = {0};
+        if (at_ % 8) put(zeros, 8 - at_ % 8);
+    }
+    FILE* f_ = nullptr;
+    uint32_t n_leaves_;
+    uint64_t at_ = 0;
+    std::vector<uint64_t> offsets_;
+};
+
+// the records that start in [range_begin, range_end) of a mapped packed file, in order
+class PackedReader {
+public:
+    PackedReader(const MafFile& file, size_t range_begin, size_t range_end, int n_leaves) : data_(file.data()), size_(file.size())
+    {
+        if (!is_packed_file(file)) throw std::runtime_error("not a packed alignment file");
+        uint32_t nl;
+        memcpy(&nl, data_ + 8, 4);
+        if (static_cast<int>(nl) != n_leaves)
+            throw std::runtime_error("packed alignment file was written for a model with " + std::to_string(nl) + " species, this model has " + std::to_string(n_leaves));
+        if (memcmp(data_ + size_ - 8, PACKED_INDEX_MAGIC, 8) != 0) throw std::runtime_error("packed alignment file is truncated (no index)");
+        uint64_t tail[2];
+        memcpy(tail, data_ + size_ - 24, 16);
+        n_records_ = tail[0];
+        if (tail[1] > size_ - 24 || n_records_ > (size_ - 24 - tail[1]) / 8) throw std::runtime_error("packed alignment file: bad index");
+        index_ = reinterpret_cast<const uint64_t*>(data_ + tail[1]);  // offsets are multiples of 8: aligned
+        data_end_ = tail[1];
+        // first record at or after range_begin ... first record at or after range_end
+        next_ = lower_bound(range_begin);
+        stop_ = lower_bound(range_end);
+    }
+    static uint64_t data_bytes(const MafFile& file)  // where the records end: what byte-range jobs are cut from
+    {
+        uint64_t tail[2];
+        memcpy(tail, file.data() + file.size() - 24, 16);
+        return tail[1];
+    }
+    bool next(Alignment& aln)
+    {
+        if (next_ >= stop_) return false;
+        const char* p = data_ + index_[next_++];
+        uint32_t head[2], dims[2];
+        uint64_t pos[2];
+        memcpy(head, p, 8);
+        memcpy(pos, p + 8, 16);
+        memcpy(dims, p + 24, 8);
+        if (head[0] != PACKED_RECORD_MAGIC) throw std::runtime_error("packed alignment file: bad record");
+        p += 32;
+        aln.chrom.assign(p, head[1]);
+        p += (head[1] + 7) & ~7u;
+        aln.start_pos = pos[0];
+        aln.chrom_len = pos[1];
+        aln.strand = '+';
+        const uint32_t len = dims[0], nl = dims[1];
+        if (static_cast<uint64_t>(p - data_) + static_cast<uint64_t>(len) * nl > data_end_) throw std::runtime_error("packed alignment file: record exceeds the file");
+        aln.seqs.resize(nl);
+        for (uint32_t l = 0; l < nl; ++l) aln.seqs[l].assign(p + static_cast<size_t>(l) * len, len);
+        return true;
+    }
+
+private:
+    size_t lower_bound(uint64_t byte) const
+    {
+        size_t lo = 0, hi = n_records_;
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            if (index_[mid] < byte) lo = mid + 1;
+            else hi = mid;
+        }
+        return lo;
+    }
+    const char* data_;
+    size_t size_;
+    const uint64_t* index_ = nullptr;
+    uint64_t n_records_ = 0, data_end_ = 0;
+    size_t next_ = 0, stop_ = 0;
+};
+
+}  // namespace pcsf_host

@@ -208,3 +208,41 @@ def test_build_tracks_rejects_other_characters_on_gpu(tmp_path):
     r = subprocess.run([_cli(), "build-tracks", "--output", str(tmp_path / "o"), os.path.join(GOLD, "models", "53birds"), str(maf)],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "unexpected character 'X'" in r.stderr
+
+
+def test_config5_100vertebrates_all_rows_hmm_estimated_from_exons(tmp_path):
+    """BASELINE.json configs[4] end to end at test size: build-tracks with the 100-leaf model on a generated MAF whose 100
+    rows are ALL mapped, --output-phylo 1 --output-regions 1 with the HMM parameters ESTIMATED from the generator's exon
+    list (--genome-length / --coding-exons: estimate_hmm_params_for_genome, src/estimate_hmm_parameter.hpp:243-340, then
+    src/phylocsf++build_tracks.hpp:262-364,421-424).  GPU driver vs the oracle-backed driver: all 19 files identical;
+    the estimated parameters equal the independent Python restatement's (tests/hmm_oracle.py)."""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hmm_oracle as ho
+    oracle_cli = os.path.join(ROOT, "oracle", "_build", "oracle_cli")
+    maf, exons = tmp_path / "c5.maf", tmp_path / "c5.exons"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_synthetic_maf.py"), str(maf), "--bases", "24000", "--seed", "5",
+                           "--exons", str(exons)], stdout=subprocess.DEVNULL)
+    genome_length = 2048000
+    outs, params = [], []
+    for cli, name in ((_cli(), "gpu"), (oracle_cli, "cpu")):
+        out = tmp_path / name
+        r = subprocess.run([cli, "build-tracks", "--output", str(out), "--output-phylo", "1", "--output-regions", "1", "--genome-length", str(genome_length),
+                            "--coding-exons", str(exons), os.path.join(GOLD, "models", "100vertebrates"), str(maf)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        params.append([float(x) for x in re.search(r"HMM parameters: (\S+)", r.stderr).group(1).split(",")])
+        assert re.search(r"(\d+) reference bases", r.stderr).group(1) == "24000"
+        outs.append(out)
+    want = ho.estimate_params(open(exons).read().splitlines(), genome_length)
+    flat = [want["coding_prior"], want["coding_length"]] + list(want["weights"]) + list(want["lengths"]) if isinstance(want, dict) else list(want)
+    assert params[0] == params[1]
+    assert all(abs(a - b) <= 1e-9 * max(1.0, abs(b)) for a, b in zip(params[0], flat)), (params[0], flat)
+    names = sorted(os.listdir(outs[1]))
+    assert len(names) == 19                                            # power, 6 raw, 6 smoothed, 6 region files
+    n_bytes = 0
+    for n in names:
+        got, want_b = open(outs[0] / n, "rb").read(), open(outs[1] / n, "rb").read()
+        assert got == want_b, n
+        n_bytes += len(got)
+    assert n_bytes > 500000

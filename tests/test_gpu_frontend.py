@@ -135,3 +135,54 @@ def test_branch_length_scores_reject_other_characters(oracle_models, gpu_context
     with pytest.raises(RuntimeError, match="unexpected character 'X'"):
         ctx.score_alignments_6frames(nuc, [(0, 300, 1, 1000)], with_bls=True)
     assert (ctx.branch_length_scores(np.full((m.nl, 10), ord("t"), np.uint8)) == 1.0).all()   # the context stays usable
+
+
+def test_fused_front_end_equals_the_separate_kernel(golden_dir):
+    """The pruning kernel forms its codon columns from the nucleotide rows itself (kernels.hip, FUSED); PCSF_FUSED_FRONTEND=0
+    keeps extract_frames_kernel + the codon matrix.  Same kernel arithmetic on the same codons: the scores must be
+    bit-identical, for ragged alignments whose frame segments straddle work-group windows."""
+    import os
+    import phylocsfpp_amd as pa
+    m = pa.load_model(os.path.join(golden_dir, "models", "58mammals"))
+    rng = np.random.default_rng(123)
+    alphabet = np.frombuffer(b"ACGTacgtNn-.", dtype=np.uint8)
+    prob = np.array([.2, .2, .2, .2, .03, .03, .03, .03, .02, .01, .04, .01])
+    alns, cols = [], 0
+    for L in [1, 2, 3, 5, 64, 191, 193, 3 * 64, 3 * 64 + 1, 1000, 4097, 20000] + [int(x) for x in rng.integers(1, 700, 40)]:
+        alns.append((cols, L, int(rng.integers(1, 10**6)), int(rng.integers(2 * 10**6, 3 * 10**6))))
+        cols += L + int(rng.integers(0, 4))
+    nuc = rng.choice(alphabet, size=(m.nl, cols), p=prob / prob.sum())
+    res = {}
+    old = os.environ.get("PCSF_FUSED_FRONTEND")
+    try:
+        for mode in ("1", "0"):
+            os.environ["PCSF_FUSED_FRONTEND"] = mode
+            ctx = m.context(device=0, with_bls=True)
+            res[mode] = (ctx.score_alignments_6frames(nuc, alns), ctx.score_alignments_6frames(nuc, alns, with_bls=True))
+            ctx.close()
+    finally:
+        if old is None:
+            os.environ.pop("PCSF_FUSED_FRONTEND", None)
+        else:
+            os.environ["PCSF_FUSED_FRONTEND"] = old
+    for variant in (0, 1):
+        a, b = res["1"][variant], res["0"][variant]
+        assert np.array_equal(a[1], b[1])                                  # skip_bases
+        for k in range(len(alns)):
+            for f in range(6):
+                assert a[0][k][f].tobytes() == b[0][k][f].tobytes(), (variant, k, f)
+    assert res["1"][1][2].tobytes() == res["0"][1][2].tobytes()            # per-base branch-length scores
+
+
+def test_six_frame_call_without_branch_length_scores_rejects_other_characters(oracle_models, gpu_contexts):
+    """both six-frame entry points reject what the reference exits on (src/translation.hpp:29-88), not only the one that
+    also computes the branch-length scores"""
+    m = oracle_models("53birds")
+    ctx = gpu_contexts("53birds")
+    nuc = np.full((m.nl, 300), ord("A"), np.uint8)
+    nuc[7, 123] = ord("X")
+    with pytest.raises(RuntimeError, match="unexpected character 'X'"):
+        ctx.score_alignments_6frames(nuc, [(0, 300, 1, 1000)])
+    nuc[7, 123] = ord("n")
+    res, _ = ctx.score_alignments_6frames(nuc, [(0, 300, 1, 1000)])        # the context stays usable
+    assert len(res[0][0]) == 100

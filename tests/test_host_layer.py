@@ -261,3 +261,35 @@ def test_several_backends_small_batches_and_windows_do_not_change_the_output(cli
                               [os.path.join(ROOT, "tests", "golden", "models", "100vertebrates"), str(m)], stderr=subprocess.DEVNULL)
         res.append(open(str(m) + ".scores").read().splitlines()[1:])
     assert res[0] == res[1] and len(res[0]) == 51
+
+
+def test_packed_alignment_file_gives_the_same_tracks(cli, tmp_path):
+    """pack-maf stores what the MAF reader yields in build-tracks mode (packed_reader.hpp); build-tracks on the packed file
+    -- whole, and cut into small windows and byte-range jobs -- must write the same seven files as on the text, and a
+    packed file of another model or a truncated one must be refused."""
+    import gzip
+    maf = tmp_path / "g.maf"
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "build-tracks", "galGal6_chr22_25_28_each_30k_bases.maf.gz"), "rt") as fi:
+        blocks = fi.read().split("\n\n")
+    maf.write_text("\n\n".join(blocks[:1200]) + "\n\n")
+    packed = tmp_path / "g.pcsfbin"
+    r = subprocess.run([cli, "pack-maf", MODEL, str(maf), str(packed)], capture_output=True, text=True)
+    assert r.returncode == 0 and "alignments" in r.stderr
+    assert open(packed, "rb").read(8) == b"PCSFBIN1" and os.path.getsize(packed) < os.path.getsize(maf)
+    outs = []
+    for src, extra in ((maf, []), (packed, []), (packed, ["--window-bytes", "70000", "--batch-sites", "3000", "--threads", "3", "--devices", "0,0"])):
+        out = tmp_path / ("o%d" % len(outs))
+        subprocess.check_call([cli, "build-tracks", "--output", str(out)] + extra + [MODEL, str(src)], stderr=subprocess.DEVNULL)
+        outs.append(out)
+    names = sorted(os.listdir(outs[0]))
+    assert len(names) == 7
+    for n in names:
+        want = open(outs[0] / n, "rb").read()
+        assert len(want) > 1000 and open(outs[1] / n, "rb").read() == want and open(outs[2] / n, "rb").read() == want, n
+    other = subprocess.run([cli, "build-tracks", "--output", str(tmp_path / "x"), os.path.join(ROOT, "tests", "golden", "models", "58mammals"), str(packed)],
+                           capture_output=True, text=True)
+    assert other.returncode != 0 and "species" in other.stderr
+    cut = tmp_path / "cut.pcsfbin"
+    cut.write_bytes(open(packed, "rb").read()[:-100])
+    bad = subprocess.run([cli, "build-tracks", "--output", str(tmp_path / "y"), MODEL, str(cut)], capture_output=True, text=True)
+    assert bad.returncode != 0 and "truncated" in bad.stderr
