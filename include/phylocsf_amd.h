@@ -131,6 +131,11 @@ int pcsf_score_alignments_6frames(pcsf_ctx *ctx, const char *nucleotides, size_t
                                   const pcsf_alignment_desc *alignments, size_t n_alignments, double *out_scores,
                                   size_t out_capacity, uint64_t *out_offsets, uint32_t *n_codons, uint32_t *skip_bases);
 
+/* Optional: gets the context ready for six-frame calls of up to max_columns alignment columns in total (device scratch
+ * reserved, kernels run once on a dummy alignment so that their code is loaded).  A short run -- one 1 Mb file is three
+ * calls -- otherwise pays for both inside its first call.  Never changes a result. */
+int pcsf_prepare_tracks(pcsf_ctx *ctx, size_t max_columns);
+
 /* ---- branch-length score (compute_bls_score, src/additional_scores.hpp:44-84) ---------------------
  * Per alignment column: the branch lengths of the subtree spanned by the species that have one of
  * ACGTacgt there (newick_sum_branch_lengths, src/additional_scores.hpp:5-41: own branch, then left, then

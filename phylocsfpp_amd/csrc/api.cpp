@@ -575,6 +575,36 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
     return pcsf::bls_check(c, nucleotides, row_stride, max_col);
 }
 
+// Gets the context ready for six-frame calls of up to max_columns alignment columns: device scratch reserved, and one
+// call on a dummy alignment so that the kernels' code objects are loaded -- what the first real call of a short run
+// (one 1 Mb file = three calls) would otherwise pay for.  Optional; results never depend on it.
+int pcsf_prepare_tracks(pcsf_ctx* c, size_t max_columns)
+{
+    if (!c) return PCSF_ERR_INVALID_ARG;
+    hipError_t e;
+    if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
+    const size_t nl = static_cast<size_t>(c->n_leaves), cols = std::max<size_t>(max_columns, 192);
+    if ((e = c->d_nucl.reserve(nl * cols)) != hipSuccess) return c->hip_fail(e, "hipMalloc(nucleotides)");
+    if ((e = c->d_segments.reserve(size_t(1) << 20)) != hipSuccess) return c->hip_fail(e, "hipMalloc(segments)");
+    if ((e = c->d_out.reserve(2 * cols * sizeof(double))) != hipSuccess) return c->hip_fail(e, "hipMalloc(out)");
+    if (c->fused_frontend) {
+        if ((e = c->d_wg_seg.reserve((2 * cols / 64 + 1) * sizeof(uint32_t))) != hipSuccess) return c->hip_fail(e, "hipMalloc(work-group segments)");
+    } else if ((e = c->d_codons.reserve(nl * 2 * cols)) != hipSuccess) {
+        return c->hip_fail(e, "hipMalloc(codons)");
+    }
+    if (c->bls_ready) {
+        if ((e = c->d_bls_out.reserve(cols * sizeof(double))) != hipSuccess) return c->hip_fail(e, "hipMalloc(bls out)");
+        if ((e = c->d_bls_spans.reserve(size_t(1) << 18)) != hipSuccess) return c->hip_fail(e, "hipMalloc(bls spans)");
+    }
+    std::vector<char> rows(nl * 192, 'A');
+    std::vector<double> scores(2 * 192), bls(192);
+    const pcsf_alignment_desc aln{0, 192, 1, 1000};
+    uint64_t offsets[6];
+    uint32_t n_codons[6];
+    return pcsf_score_alignments_6frames_bls(c, rows.data(), 192, &aln, 1, scores.data(), scores.size(), offsets, n_codons, nullptr,
+                                             c->bls_ready ? bls.data() : nullptr);
+}
+
 // ---- branch-length score (src/additional_scores.hpp:5-84) --------------------------------------------------
 int pcsf_set_bls_branch_lengths(pcsf_ctx* c, const double* branch_len)
 {

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void extract_frames_kernel(const FrameSegment*
         a = nucleotide_id(row[first]);
         b = nucleotide_id(row[second]);
         d = nucleotide_id(row[third]);
-        if ((a | b | d) > 4u && first_bad) {  // a | b | d > 4 needs a 5: a character outside ACGTNacgtn-. -- the call fails with its position
+        if ((a == 5u || b == 5u || d == 5u) && first_bad) {  // a character outside ACGTNacgtn-.: the call fails with its position
             const size_t where = a == 5u ? first : (b == 5u ? second : third);
             atomicMin(first_bad, static_cast<unsigned long long>(static_cast<size_t>(l) * row_stride + where));
         }

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
                 const unsigned char* row = p.nucl + static_cast<size_t>(leaf) * p.nucl_stride;
                 const long long step = lminus[s] ? -1 : 1;
                 unsigned a = lut[row[first]], b = lut[row[first + step]], d = lut[row[first + 2 * step]];
-                if ((a | b | d) > 4u && p.first_bad) {  // needs a 5: the call fails with the character's position
+                if ((a == 5u || b == 5u || d == 5u) && p.first_bad) {  // outside ACGTNacgtn-.: the call fails with the character's position
                     const long long where = a == 5u ? first : (b == 5u ? first + step : first + 2 * step);
                     atomicMin(p.first_bad, static_cast<unsigned long long>(static_cast<size_t>(leaf) * p.nucl_stride + static_cast<size_t>(where)));
                 }

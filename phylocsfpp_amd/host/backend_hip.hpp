@@ -30,6 +30,7 @@ public:
     }
     bool device_bls() const override { return device_bls_; }
     int contexts_per_device() const override { return 2; }
+    void prepare_tracks(size_t max_columns) override { check(pcsf_prepare_tracks(ctx_, max_columns)); }
     ~HipBackend() override { pcsf_destroy(ctx_); }
     void score_sites_fixed(const uint8_t* codons, size_t n_sites, size_t leaf_stride, double* out) override
     {

@@ -63,6 +63,9 @@ struct ScoringBackend {
     // how many contexts per device pay off in build-tracks (the HIP backend: two, their kernels take turns on the GPU
     // while the transfers of one call run under the kernels of the other)
     virtual int contexts_per_device() const { return 1; }
+    // build-tracks is about to send batches of up to max_columns alignment columns: a backend may set up whatever its
+    // first call would otherwise pay for (the HIP backend: device scratch, kernel code loading)
+    virtual void prepare_tracks(size_t /*max_columns*/) {}
     virtual size_t score_alignments_6frames(int n_leaves, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0,
                                             const std::vector<uint32_t>& len, const std::vector<uint64_t>& start_pos,
                                             const std::vector<uint64_t>& chrom_len, double* out, size_t out_capacity, std::vector<uint64_t>& offsets,
@@ -387,6 +390,13 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     const bool packed = is_packed_file(file);
     const size_t input_bytes = packed ? static_cast<size_t>(PackedReader::data_bytes(file)) : file.size();
     const size_t window = std::max<size_t>(prm.window_bytes, 1 << 16);
+    // the first windows are smaller (1/4, 1/2 of the size) so that the scoring stage starts after a short parse
+    std::vector<size_t> window_begin;
+    for (size_t at = 0, k = 0; at < input_bytes; ++k) {
+        window_begin.push_back(at);
+        at += k == 0 ? std::max<size_t>(window / 4, 1 << 16) : (k == 1 ? std::max<size_t>(window / 2, 1 << 16) : window);
+    }
+    window_begin.push_back(input_bytes);
     // batch matrices come from the backend (page-locked for the GPU) and are recycled: allocating them is slow
     struct StagingPool {
         ScoringBackend& backend;
@@ -438,10 +448,10 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     };
     // Stage 1 (runs one window ahead of the scoring): byte-range jobs parse the MAF and compute the branch-length
     // scores; then the alignments, in file order, are cut into batches and their rows copied into the batch matrix.
-    auto prepare_window = [&](size_t w0) {
+    auto prepare_window = [&](size_t wi) {
         std::unique_ptr<PreparedWindow> pw(new PreparedWindow);
         StopWatch parse_clock;
-        const size_t w1 = std::min(input_bytes, w0 + window);
+        const size_t w0 = window_begin[wi], w1 = window_begin[wi + 1];
         const size_t n_jobs = std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(threads) * 4, (w1 - w0 + (1 << 16) - 1) >> 16));
         pw->jobs.resize(n_jobs);
         std::vector<double> job_read(n_jobs, 0.0), job_bls(n_jobs, 0.0);
@@ -501,6 +511,9 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
                 memcpy(bt.nucl.first + l * bt.stride + p.col0, p.seqs[l].data(), p.len);
             });
             for (Item* p : bt.items) std::vector<std::string>().swap(p->seqs);  // the rows now live in the batch matrix
+            // the batch's page-locked result buffer is taken here, one window ahead of the scoring stage (pinning pages
+            // costs milliseconds): the scores, then (device branch-length scores) one value per column
+            bt.score_mem = score_pool.get((2 * bt.stride + (dev_bls ? bt.stride : 0)) * sizeof(double));
         }
         pw->pack = pack.lap();
         return pw;
@@ -563,8 +576,6 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             StopWatch bw;
             if (need_raw) {
                 const size_t cap_scores = 2 * b->stride;  // six frames of len/3 codons each
-                // one page-locked buffer: the scores, then (device branch-length scores) one value per column
-                b->score_mem = score_pool.get((cap_scores + (dev_bls ? b->stride : 0)) * sizeof(double));
                 double* out = reinterpret_cast<double*>(b->score_mem.first);
                 double* bls_out = dev_bls ? out + cap_scores : nullptr;
                 b->n_scores = backends[d]->score_alignments_6frames(model.n_leaves, b->nucl.first, b->stride, b->col0, b->len, b->start_pos, b->chrom_len,
@@ -584,10 +595,18 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     };
     std::future<std::unique_ptr<PreparedWindow>> next;
     if (input_bytes > 0) next = std::async(std::launch::async, prepare_window, size_t(0));
+    // while the first window is parsed the backends get ready for batches of up to `cap` columns; a backend's first batch
+    // waits for that
+    if (need_raw)
+        for (size_t d = 0; d < n_dev; ++d)
+            dev_last[d] = std::async(std::launch::async, [&, d]() -> double {
+                           backends[d]->prepare_tracks(std::min<size_t>(cap, std::max<size_t>(window / 32, 4096)));
+                           return 0.0;
+                       }).share();
     try {
-    for (size_t w0 = 0; w0 < input_bytes; w0 += window) {
+    for (size_t wi = 0; wi + 1 < window_begin.size(); ++wi) {
         std::unique_ptr<PreparedWindow> pw = next.get();
-        if (w0 + window < input_bytes) next = std::async(std::launch::async, prepare_window, w0 + window);
+        if (wi + 2 < window_begin.size()) next = std::async(std::launch::async, prepare_window, wi + 1);
         {  // busy seconds of stage 1 (it runs concurrently with the other stages): the parallel parse split by thread time
             const double cpu = pw->read + pw->bls, tot = (cpu > 0 ? cpu : 1.0);
             st.read_seconds += pw->parse_wall * pw->read / tot;

@@ -124,8 +124,10 @@ public:
     }
     static uint64_t data_bytes(const MafFile& file)  // where the records end: what byte-range jobs are cut from
     {
+        if (memcmp(file.data() + file.size() - 8, PACKED_INDEX_MAGIC, 8) != 0) throw std::runtime_error("packed alignment file is truncated (no index)");
         uint64_t tail[2];
         memcpy(tail, file.data() + file.size() - 24, 16);
+        if (tail[1] > file.size() - 24 || tail[0] > (file.size() - 24 - tail[1]) / 8) throw std::runtime_error("packed alignment file: bad index");
         return tail[1];
     }
     bool next(Alignment& aln)
