@@ -119,6 +119,7 @@ int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t le
         p.first_bad = fused->first_bad;
         variant = 32;
     }
+    if (c->schedule.stack_depth > pcsf::MAX_STACK_DEPTH) variant = (variant == 32 ? 32 : 0) | 64;  // parked tiles in scratch memory
     hipError_t e;
     if (c->timing && (e = hipEventRecord(c->ev0, stream)) != hipSuccess) return c->hip_fail(e, "hipEventRecord");
     if ((e = launch_prune_fixed(p, variant, stream, c->extra_lds)) != hipSuccess) return c->hip_fail(e, "launch prune_fixed");

@@ -346,7 +346,7 @@ struct BlockEngine {
                 p.n_wgs = nw;
                 p.out_lnz = d_lnz.as<double>();
                 p.out_anc = want_anc ? d_anc.as<double>() : nullptr;
-                HIP_TRY(launch_prune_fixed(p, 16, st, 0));
+                HIP_TRY(launch_prune_fixed(p, 16 | (c->schedule.stack_depth > MAX_STACK_DEPTH ? 64 : 0), st, 0));
             }
             const size_t nfe = set ? nfe1 : nfe0, fe_at = set ? nfe0 : 0, nf = set ? nf1 : nf0, f_at = set ? nf0 : 0;
             if (nfe)

@@ -196,11 +196,12 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
         return m;
     };
 
-    Vec4 cur{{1.0, 1.0, 1.0, 1.0}}, stk[MAX_STACK_DEPTH_DEV];
-    bool cur_ones = true, stk_ones[MAX_STACK_DEPTH_DEV] = {true, true, true};
-#pragma unroll
-    for (int d = 0; d < MAX_STACK_DEPTH_DEV; ++d) stk[d] = Vec4{{1.0, 1.0, 1.0, 1.0}};
-    int slot = 0;
+    // parked messages: pushes and pops nest, so a stack pointer replaces the slot numbers of the op codes (which deep
+    // trees do not carry, schedule.hpp); dynamically indexed -> scratch memory, touched twice per parked tile
+    Vec4 cur{{1.0, 1.0, 1.0, 1.0}}, stk[MAX_STACK_DEPTH_DEEP_DEV];
+    uint32_t stk_ones = 0;  // bit d: parked tile d is all ones
+    bool cur_ones = true;
+    int slot = 0, sp = 0;
     for (int ip = 0; ip < p.n_ops; ++ip) {
         const uint32_t op = lprog[ip];
         const uint32_t code = op >> 28;
@@ -226,16 +227,14 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) cur.v[r] = ma.v[r] * mb.v[r];
             cur_ones = ga && gb;
-            const int d = static_cast<int>(code - F_MM_PUSH_CHERRY0_DEV);
-            // the stack slot is part of the op code: statically indexed registers
-            if (d == 0) { stk[0] = m; stk_ones[0] = m_ones; }
-            else if (d == 1) { stk[1] = m; stk_ones[1] = m_ones; }
-            else { stk[2] = m; stk_ones[2] = m_ones; }
+            stk[sp] = m;
+            stk_ones = (stk_ones & ~(1u << sp)) | (m_ones ? 1u << sp : 0u);
+            ++sp;
         } else if (code >= F_MM_POP0_DEV && code < F_ROOT_DEV) {
             const Vec4 m = edge(lslot[slot++], cur, cur_ones);
-            const int d = static_cast<int>(code - F_MM_POP0_DEV);
-            const Vec4 s = d == 0 ? stk[0] : (d == 1 ? stk[1] : stk[2]);
-            const bool s_ones = d == 0 ? stk_ones[0] : (d == 1 ? stk_ones[1] : stk_ones[2]);
+            --sp;
+            const Vec4 s = stk[sp];
+            const bool s_ones = (stk_ones >> sp) & 1u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) cur.v[r] = s.v[r] * m.v[r];
             cur_ones = cur_ones && s_ones;

@@ -9,7 +9,8 @@ namespace pcsf {
 
 constexpr int FRAG_DOUBLES_DEV = 64 * 64;        // one branch matrix in fragment order
 constexpr int LEAF_TABLE_DOUBLES_DEV = 65 * 64;  // one leaf-message table (65 codes x 64 states)
-constexpr int MAX_STACK_DEPTH_DEV = 3;
+constexpr int MAX_STACK_DEPTH_DEV = 3;        // parked tiles in registers
+constexpr int MAX_STACK_DEPTH_DEEP_DEV = 14;  // DEEP variants: parked tiles in scratch memory (schedule.hpp)
 
 // fused op codes of the pruning program (schedule.hpp FusedOp is the host-side twin of this list)
 constexpr uint32_t F_CHERRY_DEV = 0, F_MM_LEAF_DEV = 1, F_MM_PUSH_CHERRY0_DEV = 2, F_MM_POP0_DEV = 5, F_ROOT_DEV = 8;
@@ -54,7 +55,8 @@ struct PruneParams {
 
 // variant: 0 = 4 waves (64 sites) per work-group, 1 = 8 waves (128 sites) per work-group,
 // 2 = variant 0 with in-kernel stamps (diagnostic only), 16 = block mode (per-work-group windows and tables),
-// 32 = variant 0 with the six-frame front end fused in (codons formed from nucleotide rows in the prologue)
+// 32 = variant 0 with the six-frame front end fused in (codons formed from nucleotide rows in the prologue);
+// + 64 (variants 0, 16, 32): trees that need more than MAX_STACK_DEPTH_DEV parked tiles -- the stack lives in scratch memory
 hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t stream, size_t extra_lds = 0);
 int prune_variant_count();
 

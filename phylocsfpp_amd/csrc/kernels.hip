@@ -121,7 +121,9 @@ __device__ __forceinline__ unsigned long long stamp_now()
 // nucleotide rows -- the six-frame front end (alignment_t::update_seqs / translate and the reverse complement between
 // the strands, src/parallel_file_reader.hpp:61-113, src/phylocsf++build_tracks.hpp:162-227) runs in the prologue of the
 // work-group that scores the columns, and the leaf-major codon matrix never exists in HBM.
-template <int NW, bool STAMP, bool BLOCKS, bool FUSED>
+// DEEP: the tree needs more than MAX_STACK_DEPTH_DEV parked tiles (no tree the reference ships does): pushes and pops
+// nest, so the kernel keeps a stack pointer of its own and parks the tiles in scratch memory.
+template <int NW, bool STAMP, bool BLOCKS, bool FUSED, bool DEEP>
 __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -293,6 +295,9 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
         double cur[16];
         double4_t acc[4];
         double4_t stk[MAX_STACK_DEPTH_DEV][4];  // parked messages, in accumulator layout: a push accumulates in place
+        double4_t deep_stk[DEEP ? MAX_STACK_DEPTH_DEEP_DEV : 1][4];  // DEEP: dynamically indexed -> scratch memory
+        int sp = 0;
+        (void)deep_stk; (void)sp;
 
         // The op word and the codon bytes of op i+1 are fetched from LDS while op i runs, so that no LDS
         // round trip (op word -> leaf index -> codon byte) sits between two products.
@@ -420,10 +425,22 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
                     PCSF_STAMP(3)
                     break;
                 }
-                case F_MM_PUSH_CHERRY0_DEV + 0: PCSF_PUSH_CHERRY(0) break;
+                case F_MM_PUSH_CHERRY0_DEV + 0:
+                    PCSF_PUSH_CHERRY(0)
+                    if constexpr (DEEP) {
+                        _Pragma("unroll") for (int t = 0; t < 4; ++t) deep_stk[sp][t] = stk[0][t];
+                        ++sp;
+                    }
+                    break;
                 case F_MM_PUSH_CHERRY0_DEV + 1: PCSF_PUSH_CHERRY(1) break;
                 case F_MM_PUSH_CHERRY0_DEV + 2: PCSF_PUSH_CHERRY(2) break;
-                case F_MM_POP0_DEV + 0: PCSF_POP(0) break;
+                case F_MM_POP0_DEV + 0:
+                    if constexpr (DEEP) {
+                        --sp;
+                        _Pragma("unroll") for (int t = 0; t < 4; ++t) stk[0][t] = deep_stk[sp][t];
+                    }
+                    PCSF_POP(0)
+                    break;
                 case F_MM_POP0_DEV + 1: PCSF_POP(1) break;
                 case F_MM_POP0_DEV + 2: PCSF_POP(2) break;
                 default: {  // F_ROOT
@@ -481,7 +498,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     }
 }
 
-template <int NW, bool STAMP, bool BLOCKS, bool FUSED = false>
+template <int NW, bool STAMP, bool BLOCKS, bool FUSED = false, bool DEEP = false>
 static hipError_t launch_impl(const PruneParams& p, hipStream_t stream, size_t extra_lds)
 {
     const size_t sites_per_block = static_cast<size_t>(NW) * 16;
@@ -501,11 +518,11 @@ static hipError_t launch_impl(const PruneParams& p, hipStream_t stream, size_t e
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     if (!(attr_set.load(std::memory_order_acquire) >> (dev & 63) & 1)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prune_fixed<NW, STAMP, BLOCKS, FUSED>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prune_fixed<NW, STAMP, BLOCKS, FUSED, DEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
     }
-    hipLaunchKernelGGL((prune_fixed<NW, STAMP, BLOCKS, FUSED>), dim3(static_cast<unsigned>(blocks)), dim3(NW * 64), lds, stream, p);
+    hipLaunchKernelGGL((prune_fixed<NW, STAMP, BLOCKS, FUSED, DEEP>), dim3(static_cast<unsigned>(blocks)), dim3(NW * 64), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -517,6 +534,9 @@ hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t str
         case 2: return launch_impl<4, true, false>(p, stream, extra_lds);  // diagnostic: in-kernel stamps
         case 16: return launch_impl<4, false, true>(p, stream, extra_lds); // per-work-group windows/tables
         case 32: return launch_impl<4, false, false, true>(p, stream, extra_lds);  // tracks mode, codons formed from the nucleotide rows
+        case 64: return launch_impl<4, false, false, false, true>(p, stream, extra_lds);       // + 64: parked tiles in scratch (deep trees)
+        case 64 + 16: return launch_impl<4, false, true, false, true>(p, stream, extra_lds);
+        case 64 + 32: return launch_impl<4, false, false, true, true>(p, stream, extra_lds);
         default: return hipErrorInvalidValue;
     }
 }

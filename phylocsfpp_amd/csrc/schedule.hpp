@@ -42,7 +42,11 @@ inline uint32_t encode_op(OpCode c, int a = 0, int b = 0)
     return (static_cast<uint32_t>(c) << 28) | (static_cast<uint32_t>(a & 0x3fff) << 14) | static_cast<uint32_t>(b & 0x3fff);
 }
 
-constexpr int MAX_STACK_DEPTH = 3;
+constexpr int MAX_STACK_DEPTH = 3;        // parked tiles the kernels keep in registers (enough for every tree the reference ships)
+// Deeper trees run the DEEP kernel variants, which park tiles in scratch memory (correct for any binary tree
+// newick_parse accepts, src/newick.hpp:31-229; slower).  A tree of n leaves never needs more than log2(n) parked
+// tiles and n_nodes < 16384, so 14 levels cover every tree that passes validate_tree.
+constexpr int MAX_STACK_DEPTH_DEEP = 14;
 
 struct Schedule {
     int n_nodes = 0, n_leaves = 0;
@@ -141,9 +145,12 @@ inline Schedule build_schedule(const TreeView& t)
         }
     }
     s.stack_depth = need[t.n_nodes - 1];
-    if (s.stack_depth > MAX_STACK_DEPTH)
+    if (s.stack_depth > MAX_STACK_DEPTH_DEEP)
         throw std::invalid_argument("tree needs " + std::to_string(s.stack_depth) + " parked tiles; this build supports " +
-                                    std::to_string(MAX_STACK_DEPTH));
+                                    std::to_string(MAX_STACK_DEPTH_DEEP));
+    // register-resident stack: the slot is part of the op code.  Deep trees: the kernel keeps its own stack pointer
+    // (pushes and pops nest), the op codes carry slot 0.
+    const bool deep = s.stack_depth > MAX_STACK_DEPTH;
     // iterative post-order emission (explicit stack: caterpillar trees are as deep as they are large)
     struct Frame { int node, depth, stage; };
     std::vector<Frame> st;
@@ -176,12 +183,12 @@ inline Schedule build_schedule(const TreeView& t)
                 st.push_back({first, f.depth, 0});
             } else if (f.stage == 1) {
                 emit_matmul(first);
-                s.program.push_back(encode_op(OP_PUSH, f.depth));
+                s.program.push_back(encode_op(OP_PUSH, deep ? 0 : f.depth));
                 f.stage = 2;
                 st.push_back({second, f.depth + 1, 0});
             } else {
                 emit_matmul(second);
-                s.program.push_back(encode_op(OP_MUL_POP, f.depth));
+                s.program.push_back(encode_op(OP_MUL_POP, deep ? 0 : f.depth));
                 st.pop_back();
             }
         }

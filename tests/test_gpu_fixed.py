@@ -1,6 +1,8 @@
 """GPU parity of the FIXED path (run_tracks, src/run.hpp:35-55) against the CPU oracle,
 through the C-ABI.  Tolerance: north_star asks for <= 1e-6 relative on the LLR scores; the
 kernel and the oracle differ only in fp64 summation order, so we hold it to 1e-9."""
+import os
+
 import numpy as np
 import pytest
 
@@ -91,3 +93,56 @@ def test_linearity_property_large(oracle_models, gpu_contexts):
     assert np.array_equal(a[perm], b)
     assert np.array_equal(a[:4096], a[4096:8192])
     np.testing.assert_allclose(a[:4096], m.run_tracks(base), rtol=RTOL, atol=ATOL)
+
+
+def test_tree_deeper_than_the_register_stack(tmp_path, golden_dir):
+    """A perfectly balanced 64-leaf tree needs 5 parked tiles; the kernels keep 3 in registers (enough for every tree the
+    reference ships) and run the DEEP variants -- stack in scratch memory -- for anything deeper, where
+    newick_parse / newick_flatten (src/newick.hpp:31-229) accept any binary tree.  Tracks mode, the fused six-frame front
+    end, block mode (explicit and factored) against the oracle."""
+    import shutil
+    import oracle_binding as ob
+    import phylocsfpp_amd as pa
+    from phylocsfpp_amd import synth
+    rng = np.random.default_rng(64)
+
+    def newick(lo, hi):
+        if hi - lo == 1:
+            return "s%02d:%.4f" % (lo, rng.uniform(0.01, 0.3))
+        mid = (lo + hi) // 2
+        return "(%s,%s):%.4f" % (newick(lo, mid), newick(mid, hi), rng.uniform(0.01, 0.2))
+    prefix = str(tmp_path / "deep")
+    text = newick(0, 64)
+    open(prefix + ".nh", "w").write(text[:text.rindex(":")] + ";\n")
+    for kind in ("coding", "noncoding"):
+        shutil.copyfile(os.path.join(golden_dir, "models", "58mammals_%s.ECM" % kind), "%s_%s.ECM" % (prefix, kind))
+    pm, om = pa.load_model(prefix, aliases=""), ob.OracleModel(prefix)
+    assert pm.nl == 64 and pa.build_schedule(pm.child1, pm.child2)[2] == 5
+    ctx = pm.context(device=0)
+    cod = synth.synthetic_codon_columns(pm.child1, pm.child2, pm.branch_len, pm.S_c, pm.pi_c, pm.S_nc, pm.pi_nc, 333, seed=8, dropout=0.2, gap_rate=0.05)
+    np.testing.assert_allclose(ctx.score_sites_fixed(cod), om.run_tracks(cod), rtol=1e-9, atol=1e-9)
+    # six frames from nucleotide rows (fused front end, DEEP)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    nuc = lut[rng.integers(0, 4, size=(64, 700))]
+    nuc[rng.random(nuc.shape) < 0.05] = ord("-")
+    res, skip = ctx.score_alignments_6frames(nuc, [(0, 700, 17, 5000)])
+    codes = np.full(256, 4, np.int64)
+    for i, ch in enumerate(b"ACGT"):
+        codes[ch] = i
+    ids = codes[nuc[:, int(skip[0, 0]):]]
+    n = ids.shape[1] // 3
+    tri = ids[:, :3 * n].reshape(64, n, 3)
+    frame1 = np.where((tri == 4).any(axis=2), 64, 16 * tri[:, :, 0] + 4 * tri[:, :, 1] + tri[:, :, 2]).astype(np.uint8)
+    np.testing.assert_allclose(res[0][0], om.run_tracks(np.ascontiguousarray(frame1)), rtol=1e-9, atol=1e-9)
+    # block mode: explicit matrices for the long block, factored pruning for the short ones
+    off = np.array([0, 5, 22, 333], dtype=np.uint64)
+    got, failed = ctx.block_loglik(0, cod, off, 0.8)
+    qd = om.qdiag(True)
+    import ctypes as C
+    for b in range(3):
+        sub = np.ascontiguousarray(cod[:, int(off[b]):int(off[b + 1])])
+        lpr, anc = C.c_double(), C.c_double()
+        assert ob.lib().po_lpr_leaves(C.byref(qd), C.byref(om.m.tree), 0.8, sub.ctypes.data_as(C.POINTER(C.c_uint8)), sub.shape[1], sub.shape[1], 0,
+                                      C.byref(lpr), C.byref(anc), None) == 0
+        assert not failed[b] and abs(got[b] - lpr.value) <= 1e-9 * abs(lpr.value)
+    ctx.close()
