@@ -22,6 +22,7 @@
 #include <chrono>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <random>
 #include <stdexcept>
 #include <thread>
@@ -77,7 +78,13 @@ struct BlockEngine {
     DeviceBuffer d_fjobs, d_fevals, d_scale, d_slot_branch;
     std::vector<FactoredJob> fjobs[2];
     std::vector<ExpmEval> fevals[2];
-    size_t fact_max_tiles = 4;   // break-even of 3 products per leaf/edge pair against 4 per branch + 1 per edge
+    // Which path an evaluation of block b takes is decided once per block from the matrix work either path needs (in
+    // MFMA instructions): explicit = 256 per branch + 64 per internal edge, wave and 64-site window; factored = 64 per
+    // tile and product, one product per species present in the block, two per internal edge above such a species
+    // (all-gap subtrees cost nothing there).  Dense blocks break even at 4 tiles; the sparse blocks of real alignments
+    // (median 4 of 100 species) stay factored at any length.  PCSF_FACTORED_MAX_TILES=n replaces the rule by "at most n tiles".
+    std::vector<char> block_factored;
+    long fixed_max_tiles = -1;
     bool allow_factored = true;  // false: caller-supplied eigen-systems keep the entry-wise post-processing of P
     // Work of one run() is kept in two sets: evaluations whose eigen-system is rebuilt in this run (set 1: eigen ->
     // expm -> prune on the side stream) and all others (set 0: expm -> prune on the main stream), so that the
@@ -97,9 +104,19 @@ struct BlockEngine {
     hipStream_t side = nullptr;
     hipEvent_t ev_start = nullptr, ev_side = nullptr;
 
-    BlockEngine(pcsf_ctx* ctx, const uint8_t* codons, const uint64_t* offsets, size_t nb, size_t stride)
+    // own_streams: the engine works on streams of its own instead of the context's, so that several engines -- groups
+    // of blocks advancing independently, one host thread each -- overlap on the device
+    BlockEngine(pcsf_ctx* ctx, const uint8_t* codons, const uint64_t* offsets, size_t nb, size_t stride, bool own_streams = false)
         : c(ctx), n_blocks(nb), leaf_stride(stride), off(offsets), stream(ctx->stream)
     {
+        if (own_streams) {
+            HIP_TRY(hipStreamCreateWithFlags(&own_main, hipStreamNonBlocking));
+            stream = own_main;
+        }
+        struct Guard {  // a throw below must not leak the stream created above (the destructor does not run then)
+            BlockEngine* e;
+            ~Guard() { if (e) e->release_sync_objects(); }
+        } guard{this};
         ne = static_cast<int>(c->schedule.slot_node.size());
         nl = c->n_leaves;
         n = c->n_nodes;
@@ -122,7 +139,26 @@ struct BlockEngine {
                 leaf_codes[(b * nl + l) * 2] = lo;
                 leaf_codes[(b * nl + l) * 2 + 1] = hi;
             }
-        if (const char* v = std::getenv("PCSF_FACTORED_MAX_TILES")) fact_max_tiles = static_cast<size_t>(std::max(0, std::atoi(v)));
+        if (const char* v = std::getenv("PCSF_FACTORED_MAX_TILES")) fixed_max_tiles = std::max(0, std::atoi(v));
+        block_factored.assign(nb, 0);
+        for (size_t b = 0; b < nb; ++b) {
+            const uint64_t sites = offsets[b + 1] - offsets[b], tiles = (sites + 15) / 16;
+            if (fixed_max_tiles >= 0) {
+                block_factored[b] = tiles <= static_cast<uint64_t>(fixed_max_tiles);
+                continue;
+            }
+            std::vector<char> live(static_cast<size_t>(n), 0);  // a species with a codon in the block below this node
+            size_t present = 0, active_edges = 0;
+            for (int l = 0; l < nl; ++l) {
+                live[l] = leaf_codes[(b * nl + l) * 2] != 0;
+                present += live[l];
+            }
+            for (int v = nl; v < n; ++v) live[v] = live[c->child1[v]] || live[c->child2[v]];
+            for (int v = nl; v < n - 1; ++v) active_edges += live[v];
+            const double factored_cost = static_cast<double>(tiles) * static_cast<double>(present + 2 * active_edges) * 64.0;
+            const double explicit_cost = static_cast<double>(n - 1) * 256.0 + static_cast<double>((sites + 63) / 64) * ne * 64.0 * 4.0;
+            block_factored[b] = factored_cost <= explicit_cost;
+        }
         std::vector<int32_t> slots(static_cast<size_t>(n - 1));
         for (int b = 0; b < n - 1; ++b) slots[b] = c->branch_slot[b];
         std::vector<int32_t> slot_branch(c->schedule.slot_node.begin(), c->schedule.slot_node.end());
@@ -138,17 +174,19 @@ struct BlockEngine {
             HIP_TRY(hipMemcpyAsync(d_leaf_codes.ptr, leaf_codes.data(), leaf_codes.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));  // `slots` is a stack temporary
         // created last: a throw above leaves nothing behind that only the destructor (not run then) would release
-        try {
-            HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
-        } catch (...) {
-            release_sync_objects();
-            throw;
-        }
+        HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
+        guard.e = nullptr;  // constructed: the destructor owns the release from here on
     }
+    hipStream_t own_main = nullptr;
     void release_sync_objects()
     {
+        if (own_main) {
+            (void)hipStreamSynchronize(own_main);
+            (void)hipStreamDestroy(own_main);
+            own_main = nullptr;
+        }
         if (side) {
             (void)hipStreamSynchronize(side);
             (void)hipStreamDestroy(side);
@@ -229,7 +267,8 @@ struct BlockEngine {
         ev.x = x;
         const uint64_t n_block_sites = off[blk + 1] - off[blk];
         const uint64_t n_tiles = (n_block_sites + 15) / 16;
-        if (allow_factored && n_tiles <= fact_max_tiles) {
+        (void)n_tiles;
+        if (allow_factored && block_factored[blk]) {
             // short block: factors applied directly, one work-group per 16-site tile (an empty block only has its
             // model validated)
             fevals[set].push_back(ev);
@@ -499,9 +538,9 @@ int run_fixed(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
 
 // ---- MLE ---------------------------------------------------------------------------------------
 int run_mle(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_blocks, size_t leaf_stride, int compute_anc,
-            uint32_t seed, float* out_phylo, float* out_anc)
+            uint32_t seed, float* out_phylo, float* out_anc, bool own_streams)
 {
-    BlockEngine eng(c, codons, off, n_blocks, leaf_stride);
+    BlockEngine eng(c, codons, off, n_blocks, leaf_stride, own_streams);
     eng.reserve_tables(std::max<size_t>(64, 2 * n_blocks));
     eng.reserve_eig(2);
     eng.upload_eig(0, c->eig[0]);
@@ -596,9 +635,9 @@ struct OmegaBlock {
 };
 
 int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_blocks, size_t leaf_stride, uint32_t seed,
-              float* out_phylo, float* out_anc)
+              float* out_phylo, float* out_anc, bool own_streams)
 {
-    BlockEngine eng(c, codons, off, n_blocks, leaf_stride);
+    BlockEngine eng(c, codons, off, n_blocks, leaf_stride, own_streams);
     const size_t cap = std::max<size_t>(64, 2 * n_blocks);
     eng.reserve_tables(cap);
     eng.reserve_eig(n_blocks + cap);  // slot b: block b's current model; slots n_blocks + k: kappa probes of a round
@@ -889,30 +928,83 @@ int debug_eigen_omega_impl(pcsf_ctx* c, const double* q_settings, const double* 
 int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64_t* site_offsets, size_t n_blocks,
                       size_t leaf_stride, int compute_anc, uint32_t seed, float* out_phylo, float* out_anc)
 {
-    // MLE / OMEGA keep one set of branch-matrix tables per evaluation in HBM (9.6 MB for a 100-leaf tree), up to two
-    // evaluations per block and round: blocks are independent, so a long list is processed in chunks that bound
-    // that footprint to ~32 GB
+    if (algo != PCSF_FIXED && algo != PCSF_MLE && algo != PCSF_OMEGA) return c->fail(PCSF_ERR_INVALID_ARG, "unknown algorithm");
+    // MLE / OMEGA keep one set of branch-matrix tables per evaluation of a LONG block in HBM (9.6 MB for a 100-leaf tree),
+    // up to two evaluations per block and round: blocks are independent, so a long list is processed in chunks that bound
+    // that footprint to ~16 GB.
+    // The rounds of the lock-step optimiser are latency-bound once the short blocks no longer form matrices (a round =
+    // eigen-solver sweeps -> edge scales -> pruning -> download, a few hundred work-groups on 256 CUs): the chunks are
+    // therefore GROUPS that advance concurrently, one host thread and one pair of streams each, and fill the device
+    // between each other's synchronisation points.  Blocks are independent: grouping never changes a result.
     size_t chunk = n_blocks;
+    size_t n_groups = 1;
     if (algo != PCSF_FIXED) {
         const size_t ne = c->schedule.slot_node.size();
         const size_t per_table = (ne * 4096 + static_cast<size_t>(c->n_leaves) * LEAF_TABLE_DOUBLES_DEV) * sizeof(double);
         chunk = std::max<size_t>(64, (size_t(16) << 30) / std::max<size_t>(per_table, 1));
+        n_groups = std::min<size_t>(4, std::max<size_t>(1, n_blocks / 48));
+        if (const char* v = std::getenv("PCSF_BLOCK_GROUPS")) n_groups = static_cast<size_t>(std::max(1, std::atoi(v)));
+        n_groups = std::min(n_groups, std::max<size_t>(n_blocks, 1));
+        chunk = std::min(chunk / n_groups + 1, (n_blocks + n_groups - 1) / n_groups);
+        chunk = std::max<size_t>(chunk, 1);
     }
-    for (size_t b0 = 0; b0 < n_blocks; b0 += chunk) {
-        const size_t nb = std::min(chunk, n_blocks - b0);
-        std::vector<uint64_t> off(nb + 1);  // CSR offsets re-based at the chunk's first site
-        for (size_t b = 0; b <= nb; ++b) off[b] = site_offsets[b0 + b] - site_offsets[b0];
-        const uint8_t* cod = codons ? codons + site_offsets[b0] : nullptr;
-        float* ph = out_phylo + b0;
-        float* an = out_anc ? out_anc + b0 : nullptr;
-        int rc;
+    struct Range {
+        size_t b0, nb;
+    };
+    std::vector<Range> ranges;
+    for (size_t b0 = 0; b0 < n_blocks; b0 += chunk) ranges.push_back({b0, std::min(chunk, n_blocks - b0)});
+    auto run_range = [&](const Range& r, bool own_streams) -> int {
+        std::vector<uint64_t> off(r.nb + 1);  // CSR offsets re-based at the range's first site
+        for (size_t b = 0; b <= r.nb; ++b) off[b] = site_offsets[r.b0 + b] - site_offsets[r.b0];
+        const uint8_t* cod = codons ? codons + site_offsets[r.b0] : nullptr;
+        float* ph = out_phylo + r.b0;
+        float* an = out_anc ? out_anc + r.b0 : nullptr;
         switch (algo) {
-            case PCSF_FIXED: rc = run_fixed(c, cod, off.data(), nb, leaf_stride, compute_anc, ph, an); break;
-            case PCSF_MLE: rc = run_mle(c, cod, off.data(), nb, leaf_stride, compute_anc, seed, ph, an); break;
-            case PCSF_OMEGA: rc = run_omega(c, cod, off.data(), nb, leaf_stride, seed, ph, an); break;
-            default: return c->fail(PCSF_ERR_INVALID_ARG, "unknown algorithm");
+            case PCSF_FIXED: return run_fixed(c, cod, off.data(), r.nb, leaf_stride, compute_anc, ph, an);
+            case PCSF_MLE: return run_mle(c, cod, off.data(), r.nb, leaf_stride, compute_anc, seed, ph, an, own_streams);
+            default: return run_omega(c, cod, off.data(), r.nb, leaf_stride, seed, ph, an, own_streams);
         }
-        if (rc != PCSF_OK) return rc;
+    };
+    if (n_groups <= 1 || ranges.size() <= 1) {
+        for (const Range& r : ranges) {
+            const int rc = run_range(r, false);
+            if (rc != PCSF_OK) return rc;
+        }
+        return PCSF_OK;
+    }
+    // ranges are dealt to n_groups threads; the first failure (an exception message) is reported after all have stopped
+    std::atomic<size_t> next{0};
+    std::mutex err_lock;
+    std::string err;
+    int err_rc = PCSF_OK;
+    std::vector<std::thread> th;
+    for (size_t g = 0; g < std::min(n_groups, ranges.size()); ++g)
+        th.emplace_back([&]() {
+            (void)hipSetDevice(c->device);  // the current device is per host thread
+            for (size_t i = next++; i < ranges.size(); i = next++) {
+                int rc = PCSF_OK;
+                std::string msg;
+                try {
+                    rc = run_range(ranges[i], true);
+                } catch (const std::exception& ex) {
+                    rc = PCSF_ERR_HIP;
+                    msg = ex.what();
+                }
+                if (rc != PCSF_OK) {
+                    std::lock_guard<std::mutex> g2(err_lock);
+                    if (err_rc == PCSF_OK) {
+                        err_rc = rc;
+                        err = msg;
+                    }
+                    next = ranges.size();
+                    return;
+                }
+            }
+        });
+    for (auto& t : th) t.join();
+    if (err_rc != PCSF_OK) {
+        if (!err.empty()) throw std::runtime_error(err);
+        return err_rc;
     }
     return PCSF_OK;
 }

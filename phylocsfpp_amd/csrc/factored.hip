@@ -20,8 +20,8 @@
 //
 // What is NOT reproduced entry by entry: the reference's clamp of P's negative noise and its diagonal fix
 // (src/instance.hpp:602-640) act on matrix entries that are never formed here.  Messages are clamped at zero instead
-// (identical for leaf messages, which ARE columns of P); the raw row sums are validated per branch by
-// edge_scale_kernel; the entry-wise lower bound cannot fail for eigen-systems from the symmetric Jacobi solvers
+// (identical for leaf messages, which ARE columns of P); the raw row sums are validated per evaluation by
+// edge_scale_kernel (they do not depend on the branch); the entry-wise lower bound cannot fail for eigen-systems from the symmetric Jacobi solvers
 // (P = D^-1/2 U e^{Lt} U^T D^1/2 with U orthonormal to 1e-15).  Caller-supplied eigen-systems and long blocks take the
 // explicit path (expm.hip + prune_fixed), which keeps the entry-wise post-processing.  DESIGN.md section 3.6.
 #include <hip/hip_runtime.h>
@@ -45,59 +45,49 @@ struct Vec4 {
 
 }  // namespace
 
-// ---- e_b[k] = exp(lambda_k * t_b) for every branch of every evaluation, and the raw row sums of P(t_b) --------------
-// One work-group per evaluation.  t_b = (double)(float)(len_b * x) like the reference's float tree
-// (src/instance.hpp:299-307,498).  Row sums: sum_j P_ij = sum_k R_ik e_k c_k with c_k = sum_j L_kj; the reference rejects a
-// model when one is off by more than 1e-6 (src/instance.hpp:632-636).
+// ---- e_b[k] = exp(lambda_k * t_b) for every branch of every evaluation ----------------------------------------------
+// t_b = (double)(float)(len_b * x) like the reference's float tree (src/instance.hpp:299-307,498).  One thread per
+// (evaluation, branch, eigenvalue); states are stored in row-split order.
+//
+// Validation (the reference rejects a model whose raw row sums of P(t) are off by more than 1e-6,
+// src/instance.hpp:632-636): sum_j P_ij(t) = sum_k R_ik e^{lambda_k t} c_k with c = L 1.  Q 1 = 0 makes 1 the right
+// eigenvector of eigenvalue 0, so c_k vanishes (to rounding) for every other k and the row sums do not depend on t:
+// they are checked ONCE per evaluation, for the longest branch (smallest e_k: the largest possible deviation), by the
+// first wave of the evaluation's first work-group.
 __global__ __launch_bounds__(256) void edge_scale_kernel(const ExpmEval* __restrict__ evals, uint32_t n_branches, const float* __restrict__ branch_len,
                                                          const double* __restrict__ eig_right, const double* __restrict__ eig_left,
                                                          const double* __restrict__ eig_lambda, double* __restrict__ scale_out,
                                                          uint32_t* __restrict__ fail)
 {
-    __shared__ double cpart[4][64], csum[64], es[4][64];
-    __shared__ int bad;
-    const ExpmEval ev = evals[blockIdx.x];
+    __shared__ double ec[64];
+    const ExpmEval ev = evals[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double* __restrict__ R = eig_right + static_cast<size_t>(ev.eig) * 4096;
-    const double* __restrict__ L = eig_left + static_cast<size_t>(ev.eig) * 4096;
-    if (tid == 0) bad = 0;
-    {
-        double s = 0.0;
-        for (int j = 16 * wave; j < 16 * wave + 16; ++j) s += L[lane * 64 + j];
-        cpart[wave][lane] = s;
-    }
-    __syncthreads();
-    if (wave == 0) csum[lane] = ((cpart[0][lane] + cpart[1][lane]) + cpart[2][lane]) + cpart[3][lane];
-    __syncthreads();
-    double rc[64];  // row `lane` of R times c
-#pragma unroll
-    for (int k = 0; k < 64; ++k) rc[k] = R[lane * 64 + k] * csum[k];
     const double lam = eig_lambda[static_cast<size_t>(ev.eig) * 64 + lane];
-    double* __restrict__ dst = scale_out + static_cast<size_t>(ev.table) * n_branches * 64;
     const int pos = row_split_pos(lane);
-    bool mine_bad = false;
-    for (uint32_t b0 = 0; b0 < n_branches; b0 += 4) {
-        const uint32_t b = b0 + wave;
-        const bool active = b < n_branches;
-        double e = 0.0;
-        if (active) {
-            const double t = static_cast<double>(static_cast<float>(static_cast<double>(branch_len[b]) * ev.x));
-            e = exp(lam * t);
-            dst[static_cast<size_t>(b) * 64 + pos] = e;
-        }
-        es[wave][lane] = e;
-        __syncthreads();
-        if (active) {
-            double sum = 0.0;
-#pragma unroll
-            for (int k = 0; k < 64; ++k) sum += rc[k] * es[wave][k];
-            if (!(fabs(sum - 1.0) <= 1e-6)) mine_bad = true;
-        }
-        __syncthreads();
+    double* __restrict__ dst = scale_out + static_cast<size_t>(ev.table) * n_branches * 64;
+    const uint32_t b = blockIdx.x * 4 + wave;  // four branches per work-group
+    if (b < n_branches) {
+        const double t = static_cast<double>(static_cast<float>(static_cast<double>(branch_len[b]) * ev.x));
+        dst[static_cast<size_t>(b) * 64 + pos] = exp(lam * t);
     }
-    if (mine_bad) bad = 1;
+    if (blockIdx.x != 0) return;
+    // the evaluation's row-sum check (work-group 0, wave 0; no divergent barrier: the whole group reaches it)
+    float longest = 0.0f;
+    for (uint32_t i = 0; i < n_branches; ++i) longest = fmaxf(longest, branch_len[i]);
+    if (wave == 0) {
+        const double* __restrict__ L = eig_left + static_cast<size_t>(ev.eig) * 4096;
+        double c = 0.0;
+        for (int j = 0; j < 64; ++j) c += L[lane * 64 + j];
+        const double t = static_cast<double>(static_cast<float>(static_cast<double>(longest) * ev.x));
+        ec[lane] = exp(lam * t) * c;
+    }
     __syncthreads();
-    if (tid == 0 && bad) fail[ev.table] = 1u;
+    if (wave == 0) {
+        const double* __restrict__ R = eig_right + static_cast<size_t>(ev.eig) * 4096;
+        double sum = 0.0;
+        for (int k = 0; k < 64; ++k) sum += R[lane * 64 + k] * ec[k];
+        if (!(fabs(sum - 1.0) <= 1e-6)) fail[ev.table] = 1u;
+    }
 }
 
 // ---- the pruning kernel ----------------------------------------------------------------------------------------------
@@ -273,8 +263,9 @@ hipError_t launch_edge_scale(const ExpmEval* d_evals, uint32_t n_evals, uint32_t
                              const double* d_eig_left, const double* d_eig_lambda, double* d_scale_out, uint32_t* d_fail, hipStream_t stream)
 {
     if (n_evals == 0) return hipSuccess;
-    hipLaunchKernelGGL(edge_scale_kernel, dim3(n_evals), dim3(256), 0, stream, d_evals, n_branches, d_branch_len, d_eig_right, d_eig_left,
-                       d_eig_lambda, d_scale_out, d_fail);
+    for (uint32_t at = 0; at < n_evals; at += 65535u)  // grid.y
+        hipLaunchKernelGGL(edge_scale_kernel, dim3((n_branches + 3) / 4, n_evals - at < 65535u ? n_evals - at : 65535u), dim3(256), 0, stream, d_evals + at,
+                           n_branches, d_branch_len, d_eig_right, d_eig_left, d_eig_lambda, d_scale_out, d_fail);
     return hipGetLastError();
 }
 

@@ -426,6 +426,12 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             std::lock_guard<std::mutex> g(lock);
             free_list.push_back(f);
         }
+        // page-locking memory costs milliseconds per 10 MB: buffers for the first windows are made ready in the
+        // background while the first window is parsed (a request that finds none large enough allocates its own)
+        void prefill(const std::vector<size_t>& sizes)
+        {
+            for (size_t bytes : sizes) put({backend.staging_alloc(bytes), bytes});
+        }
     } pool(backend), score_pool(backend);  // batch matrices; score vectors (different sizes: kept apart)
     struct Batch {  // alignments scored by one backend call, their nucleotides packed leaf-major
         std::vector<Item*> items;
@@ -595,6 +601,19 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     };
     std::future<std::unique_ptr<PreparedWindow>> next;
     if (input_bytes > 0) next = std::async(std::launch::async, prepare_window, size_t(0));
+    std::future<void> prefill_rows, prefill_scores;
+    if (need_raw && input_bytes > 0) {
+        // estimates from the window sizes: rows ~ 0.75 byte per byte of MAF text (all rows mapped: ~0.9, 58 of 100: 0.65),
+        // scores 24 bytes per column ~ 0.3; the first four windows, which nothing recycled can serve yet
+        std::vector<size_t> rows, scores;
+        for (size_t wi = 0; wi + 1 < window_begin.size() && wi < 4; ++wi) {
+            const size_t w = window_begin[wi + 1] - window_begin[wi];
+            rows.push_back(packed ? w + w / 8 : w - w / 4);
+            scores.push_back(packed ? w / 2 : w / 3);
+        }
+        prefill_rows = std::async(std::launch::async, [&pool, rows]() { pool.prefill(rows); });
+        prefill_scores = std::async(std::launch::async, [&score_pool, scores]() { score_pool.prefill(scores); });
+    }
     // while the first window is parsed the backends get ready for batches of up to `cap` columns; a backend's first batch
     // waits for that
     if (need_raw)
@@ -634,8 +653,12 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             if (f.valid()) f.wait();
         if (writer.valid()) writer.wait();
         if (next.valid()) next.wait();
+        if (prefill_rows.valid()) prefill_rows.wait();
+        if (prefill_scores.valid()) prefill_scores.wait();
         throw;
     }
+    if (prefill_rows.valid()) prefill_rows.get();
+    if (prefill_scores.valid()) prefill_scores.get();
     alive.clear();
     power_file.commit();
     for (OutFile& f : raw_file) f.commit();

@@ -156,3 +156,27 @@ def test_kept_oracle_outputs_are_what_the_oracle_computes(oracle_models):
             assert np.array_equal(np.float32([ph, an]), mle[:, b], equal_nan=True), (tag, b)
             ph, _ = m.run(ob.OMEGA, blk, compute_anc=False)
             assert np.array_equal(np.float32(ph), omega[b], equal_nan=True), (tag, b)
+
+
+def test_omega_nan_policy_is_pinned(oracle_models):
+    """POLICY: the reference's OMEGA column is `nan` (a) for every block without a complete codon and
+    (b) for some 1-6 codon blocks where gsl_eigen_nonsymmv (src/instance.hpp:331) degrades on a near-uniform F3x4
+    matrix and PhyloModel_make throws (src/instance.hpp:612-636).  (b) cannot be reproduced without GSL's solver: this
+    build -- oracle and GPU alike (tests/test_gpu_parity_blocks.py asserts the same NaN pattern on the device) -- emits NaN
+    for (a) and a finite score for (b).  The rows of (b) are counted here so that the policy cannot drift unnoticed:
+    3 of the 50-block file, 28 of the 516-block file, none longer than 6 codons."""
+    import numpy as np
+    import maf_blocks
+    m = oracle_models("100vertebrates")
+    aliases = os.path.join(GOLD, "models", "species_aliases.tsv")
+    for tag, name, n_policy in (("small", "chr22.50alignments", 3), ("medium", "chr22.516alignments", 28)):
+        maf = os.path.join(GOLD, "score-msa", name + (".maf" if tag == "small" else ".maf.gz"))
+        cod, off = maf_blocks.block_codons(maf, m.labels, aliases)
+        n_cod = np.diff(off.astype(np.int64))
+        _, rows = read_scores(os.path.join(GOLD, "score-msa", name + ".omega.scores"))
+        golden_nan = np.array([r[4] in ("nan", "-nan") for r in rows])
+        ours = np.load(os.path.join(GOLD, "oracle", tag + "_omega.npy"))
+        assert np.array_equal(np.isnan(ours), n_cod == 0)               # (a), and nothing else
+        assert golden_nan[n_cod == 0].all()                             # the reference agrees on (a)
+        policy = golden_nan & (n_cod > 0)
+        assert policy.sum() == n_policy and n_cod[policy].max() <= 6    # (b)

@@ -1,4 +1,4 @@
-"""score-msa block strategies on the GPU: python tools/bench_blocks.py [maf] [max_blocks]
+"""score-msa block strategies on the GPU: python tools/bench_blocks.py [maf] [max_blocks] [replicas] [nocpu]
 Times ScoringContext.score_blocks for FIXED / MLE / OMEGA over the blocks of a MAF (default: the reference's
 516-block medium test file), and the oracle on the host CPUs over a sample of the same blocks."""
 import os, sys, time
@@ -9,9 +9,10 @@ import phylocsfpp_amd as pa
 import oracle_binding as ob
 import maf_blocks
 
-maf = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests/golden/score-msa/chr22.516alignments.maf.gz")
+maf = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] != "-" else os.path.join(ROOT, "tests/golden/score-msa/chr22.516alignments.maf.gz")
 max_blocks = int(sys.argv[2]) if len(sys.argv) > 2 else None
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+with_cpu = not (len(sys.argv) > 4 and sys.argv[4] == "nocpu")   # the oracle sample costs ~2 minutes of one host core
 m = ob.OracleModel(os.path.join(ROOT, "tests/golden/models/100vertebrates"))
 cod, offs = maf_blocks.block_codons(maf, m.labels, os.path.join(ROOT, "tests/golden/models/species_aliases.tsv"), max_blocks)
 if reps > 1:   # replicate the block set to see how the lock-step batch scales
@@ -20,13 +21,15 @@ if reps > 1:   # replicate the block set to see how the lock-step batch scales
     offs = np.concatenate([[0]] + [offs[1:] + r * n0 for r in range(reps)]).astype(np.uint64)
 nb = len(offs) - 1
 print("%d blocks, %d codon columns (median %d per block)" % (nb, offs[-1], int(np.median(np.diff(offs)))))
-ctx = pa.ScoringContext(m.child1, m.child2, m.branch_len, m.S_c, m.pi_c, m.S_nc, m.pi_nc)
+ctx = pa.load_model(os.path.join(ROOT, "tests/golden/models/100vertebrates")).context()
 for name, algo in (("FIXED", pa.FIXED), ("MLE", pa.MLE), ("OMEGA", pa.OMEGA)):
     ctx.score_blocks(algo, cod[:, :int(offs[min(4, nb)])], offs[:min(4, nb) + 1], compute_anc=(algo != pa.OMEGA))  # warm-up
     t = time.time()
     ph, an = ctx.score_blocks(algo, cod, offs, compute_anc=(algo != pa.OMEGA))
     dt = time.time() - t
     print("GPU %-6s %8.3f s  %9.1f blocks/s  %10.0f codon columns/s   (finite %d)" % (name, dt, nb / dt, offs[-1] / dt, int(np.isfinite(ph).sum())), flush=True)
+if not with_cpu:
+    sys.exit(0)
 # CPU oracle on a bounded sample
 ns = min(nb, 32)
 sub = cod[:, :int(offs[ns])]

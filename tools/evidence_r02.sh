@@ -3,11 +3,12 @@
 cd ${GRAFT_REPO_ROOT:-.}; export TMPDIR=/tmp; O=gpurun_out/${1:-evidence_r02}; mkdir -p $O
 # block strategies: wall time, where a round's time goes, per-kernel totals
 PCSF_TIME_BLOCKS=1 python3 tools/bench_blocks.py > $O/blocks_bench_516.txt 2>&1
-PCSF_TIME_BLOCKS=1 python3 tools/bench_blocks.py tests/golden/score-msa/chr22.516alignments.maf.gz 0 4 2>&1 | grep -v "CPU oracle" > $O/blocks_bench_2064.txt
-PCSF_FACTORED_MAX_TILES=0 python3 tools/bench_blocks.py 2>&1 | grep -v "CPU oracle" > $O/blocks_bench_516_explicit_only.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_blocks -- python3 tools/bench_blocks.py tests/golden/score-msa/chr22.516alignments.maf.gz 0 4 > /dev/null 2>&1
+PCSF_TIME_BLOCKS=1 python3 tools/bench_blocks.py - 0 4 nocpu > $O/blocks_bench_2064.txt 2>&1
+PCSF_FACTORED_MAX_TILES=0 python3 tools/bench_blocks.py - 0 1 nocpu > $O/blocks_bench_516_explicit_only.txt 2>&1
+PCSF_BLOCK_GROUPS=1 python3 tools/bench_blocks.py - 0 1 nocpu > $O/blocks_bench_516_one_group.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_blocks -- python3 tools/bench_blocks.py - 0 4 nocpu > /dev/null 2>&1
 cp $(find $O/prof_blocks -name "*kernel_stats.csv" | head -1) $O/blocks_kernel_stats.csv
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_blocks -- python3 tools/bench_blocks.py tests/golden/score-msa/chr22.516alignments.maf.gz 0 4 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_blocks -- python3 tools/bench_blocks.py - 0 4 nocpu > /dev/null 2>&1
 python3 - <<PY
 import csv, glob, json
 acc = {}

@@ -12,13 +12,24 @@ import argparse
 import re
 
 
+def tile(src, dst, copies, shift=1_100_000):
+    class A:
+        pass
+    args = A()
+    args.src, args.dst, args.copies, args.shift = src, dst, copies, shift
+    return _tile(args)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("src")
     ap.add_argument("dst")
     ap.add_argument("--copies", type=int, default=100)
     ap.add_argument("--shift", type=int, default=1_100_000)
-    args = ap.parse_args()
+    _tile(ap.parse_args())
+
+
+def _tile(args):
     data = open(args.src, "rb").read()
     head_end = data.index(b"\na ") + 1 if not data.startswith(b"a ") else 0
     header, body = data[:head_end], data[head_end:]
