@@ -195,10 +195,12 @@ def end_to_end(device, runs, cpu_rate_all_cores, work_dir):
            "seconds": best["seconds"], "seconds_all_runs": [r["seconds"] for r in gpu_runs],
            "process_wall_seconds": best["process_wall_seconds"],
            "codon_frames_per_s": best["codon_frames"] / best["seconds"],
+           "codon_frames_per_s_process_wall": best["codon_frames"] / best["process_wall_seconds"],
            "maf_gigabytes_per_s": info["bytes"] / best["seconds"] / 1e9,
            "stage_busy": best["stage_busy"],
            "note": "seconds = build_tracks() inside the child process (file mapped, parsed, scored, seven wig files written); "
-                   "process_wall_seconds adds process start, HIP initialisation and model set-up"}
+                   "process_wall_seconds adds process start, HIP initialisation, model and backend set-up (branch matrices, device "
+                   "scratch, first kernel launches, page-locked buffers of the first windows)"}
     # CPU driver on the same file, or on a prefix sized for ~20 s when the whole file would take longer than ~30 s
     env = dict(os.environ, PCSF_THREADS=str(cpus), OMP_NUM_THREADS=str(cpus))
     est = best["codon_frames"] / max(cpu_rate_all_cores, 1.0)

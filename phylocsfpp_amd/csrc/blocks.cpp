@@ -932,17 +932,17 @@ int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
     // MLE / OMEGA keep one set of branch-matrix tables per evaluation of a LONG block in HBM (9.6 MB for a 100-leaf tree),
     // up to two evaluations per block and round: blocks are independent, so a long list is processed in chunks that bound
     // that footprint to ~16 GB.
-    // The rounds of the lock-step optimiser are latency-bound once the short blocks no longer form matrices (a round =
-    // eigen-solver sweeps -> edge scales -> pruning -> download, a few hundred work-groups on 256 CUs): the chunks are
-    // therefore GROUPS that advance concurrently, one host thread and one pair of streams each, and fill the device
-    // between each other's synchronisation points.  Blocks are independent: grouping never changes a result.
+    // PCSF_BLOCK_GROUPS=g (default 1) advances g groups of blocks concurrently, one host thread and one pair of streams
+    // each.  Measured (profiles/r02): no gain -- a round's time is the latency of its longest dependency chain (eigen-solver
+    // sweeps -> edge scales -> pruning -> download), which does not shrink with the number of blocks, and every group
+    // needs as many rounds as the whole list (the block with the longest optimiser path sets it): 516 blocks OMEGA
+    // 0.47 s as one group, 0.70-0.81 s as four.  Blocks are independent: grouping never changes a result.
     size_t chunk = n_blocks;
     size_t n_groups = 1;
     if (algo != PCSF_FIXED) {
         const size_t ne = c->schedule.slot_node.size();
         const size_t per_table = (ne * 4096 + static_cast<size_t>(c->n_leaves) * LEAF_TABLE_DOUBLES_DEV) * sizeof(double);
         chunk = std::max<size_t>(64, (size_t(16) << 30) / std::max<size_t>(per_table, 1));
-        n_groups = std::min<size_t>(4, std::max<size_t>(1, n_blocks / 48));
         if (const char* v = std::getenv("PCSF_BLOCK_GROUPS")) n_groups = static_cast<size_t>(std::max(1, std::atoi(v)));
         n_groups = std::min(n_groups, std::max<size_t>(n_blocks, 1));
         chunk = std::min(chunk / n_groups + 1, (n_blocks + n_groups - 1) / n_groups);

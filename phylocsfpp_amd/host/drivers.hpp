@@ -63,9 +63,10 @@ struct ScoringBackend {
     // how many contexts per device pay off in build-tracks (the HIP backend: two, their kernels take turns on the GPU
     // while the transfers of one call run under the kernels of the other)
     virtual int contexts_per_device() const { return 1; }
-    // build-tracks is about to send batches of up to max_columns alignment columns: a backend may set up whatever its
-    // first call would otherwise pay for (the HIP backend: device scratch, kernel code loading)
-    virtual void prepare_tracks(size_t /*max_columns*/) {}
+    // Part of a backend's set-up, called once by the CLI between model loading and the first build-tracks run: whatever
+    // the first calls of a short run would otherwise pay for -- the HIP backend reserves device scratch, runs its kernels
+    // once (code loading) and, if `staging`, page-locks the buffers of the first windows (window_bytes of MAF text each)
+    virtual void warm_up(size_t /*window_bytes*/, bool /*staging*/) {}
     virtual size_t score_alignments_6frames(int n_leaves, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0,
                                             const std::vector<uint32_t>& len, const std::vector<uint64_t>& start_pos,
                                             const std::vector<uint64_t>& chrom_len, double* out, size_t out_capacity, std::vector<uint64_t>& offsets,
@@ -426,12 +427,6 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             std::lock_guard<std::mutex> g(lock);
             free_list.push_back(f);
         }
-        // page-locking memory costs milliseconds per 10 MB: buffers for the first windows are made ready in the
-        // background while the first window is parsed (a request that finds none large enough allocates its own)
-        void prefill(const std::vector<size_t>& sizes)
-        {
-            for (size_t bytes : sizes) put({backend.staging_alloc(bytes), bytes});
-        }
     } pool(backend), score_pool(backend);  // batch matrices; score vectors (different sizes: kept apart)
     struct Batch {  // alignments scored by one backend call, their nucleotides packed leaf-major
         std::vector<Item*> items;
@@ -601,27 +596,6 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     };
     std::future<std::unique_ptr<PreparedWindow>> next;
     if (input_bytes > 0) next = std::async(std::launch::async, prepare_window, size_t(0));
-    std::future<void> prefill_rows, prefill_scores;
-    if (need_raw && input_bytes > 0) {
-        // estimates from the window sizes: rows ~ 0.75 byte per byte of MAF text (all rows mapped: ~0.9, 58 of 100: 0.65),
-        // scores 24 bytes per column ~ 0.3; the first four windows, which nothing recycled can serve yet
-        std::vector<size_t> rows, scores;
-        for (size_t wi = 0; wi + 1 < window_begin.size() && wi < 4; ++wi) {
-            const size_t w = window_begin[wi + 1] - window_begin[wi];
-            rows.push_back(packed ? w + w / 8 : w - w / 4);
-            scores.push_back(packed ? w / 2 : w / 3);
-        }
-        prefill_rows = std::async(std::launch::async, [&pool, rows]() { pool.prefill(rows); });
-        prefill_scores = std::async(std::launch::async, [&score_pool, scores]() { score_pool.prefill(scores); });
-    }
-    // while the first window is parsed the backends get ready for batches of up to `cap` columns; a backend's first batch
-    // waits for that
-    if (need_raw)
-        for (size_t d = 0; d < n_dev; ++d)
-            dev_last[d] = std::async(std::launch::async, [&, d]() -> double {
-                           backends[d]->prepare_tracks(std::min<size_t>(cap, std::max<size_t>(window / 32, 4096)));
-                           return 0.0;
-                       }).share();
     try {
     for (size_t wi = 0; wi + 1 < window_begin.size(); ++wi) {
         std::unique_ptr<PreparedWindow> pw = next.get();
@@ -653,12 +627,8 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             if (f.valid()) f.wait();
         if (writer.valid()) writer.wait();
         if (next.valid()) next.wait();
-        if (prefill_rows.valid()) prefill_rows.wait();
-        if (prefill_scores.valid()) prefill_scores.wait();
         throw;
     }
-    if (prefill_rows.valid()) prefill_rows.get();
-    if (prefill_scores.valid()) prefill_scores.get();
     alive.clear();
     power_file.commit();
     for (OutFile& f : raw_file) f.commit();
