@@ -204,6 +204,9 @@ double pcsf_last_kernel_ms(const pcsf_ctx *ctx);
  * out == NULL arms the stamps for work-group `block` and returns the number of values; otherwise copies them out
  * (eight per-segment cycle sums, then eight counts). */
 int pcsf_debug_stamps(pcsf_ctx *ctx, int block, unsigned long long *out, int cap);
+/* the leaf-major codon matrix [n_leaves][*n_sites] of the last six-frame call (the separate extract kernel's; with
+ * PCSF_DUMP_CODONS=1 at pcsf_create, what the fused front end formed inside the pruning kernel) */
+int pcsf_debug_codon_matrix(pcsf_ctx *ctx, uint8_t *out, size_t capacity, size_t *n_sites);
 /* copies the branch matrices the context holds back to the host: [2][n_nodes-1][64][64],
  * row = parent state (for parity tests of the P(t) stage) */
 int pcsf_get_branch_matrices(pcsf_ctx *ctx, double *out);

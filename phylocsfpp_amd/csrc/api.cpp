@@ -117,6 +117,7 @@ int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t le
         p.segments = fused->segments;
         p.wg_first_seg = fused->wg_first_seg;
         p.first_bad = fused->first_bad;
+        p.dump_codons = fused->dump_codons;
         variant = 32;
     }
     if (c->schedule.stack_depth > pcsf::MAX_STACK_DEPTH) variant = (variant == 32 ? 32 : 0) | 64;  // parked tiles in scratch memory
@@ -361,6 +362,7 @@ int pcsf_create(pcsf_ctx** out, const pcsf_model_desc* m, int device_id)
     if (const char* v = std::getenv("PCSF_STAGGER")) c->stagger_sleep = std::atoi(v);
     if (const char* v = std::getenv("PCSF_EXTRA_LDS")) c->extra_lds = static_cast<size_t>(std::atoi(v));
     if (const char* v = std::getenv("PCSF_FUSED_FRONTEND")) c->fused_frontend = std::atoi(v) != 0;
+    if (const char* v = std::getenv("PCSF_DUMP_CODONS")) c->dump_codons = std::atoi(v) != 0;
     if (const char* v = std::getenv("PCSF_PRUNE_VARIANT")) {
         const int vi = std::atoi(v);
         if (vi >= 0 && vi < pcsf::prune_variant_count()) c->variant = vi;
@@ -414,6 +416,20 @@ int pcsf_debug_stamps(pcsf_ctx* c, int block, unsigned long long* out, int cap)
     if ((e = hipDeviceSynchronize()) != hipSuccess) return c->hip_fail(e, "hipDeviceSynchronize");
     if ((e = hipMemcpy(out, c->d_stamps.ptr, n * 8, hipMemcpyDeviceToHost)) != hipSuccess) return c->hip_fail(e, "hipMemcpy(stamps)");
     return static_cast<int>(n);
+}
+
+// diagnostics: the leaf-major codon matrix of the last six-frame call ([n_leaves][n_sites]; the separate extract kernel's, or,
+// with PCSF_DUMP_CODONS=1, what the fused front end formed)
+int pcsf_debug_codon_matrix(pcsf_ctx* c, uint8_t* out, size_t capacity, size_t* n_sites)
+{
+    if (!c || !out || !n_sites) return PCSF_ERR_INVALID_ARG;
+    *n_sites = c->last_total_sites;
+    const size_t bytes = static_cast<size_t>(c->n_leaves) * c->last_total_sites;
+    if (bytes > capacity || !c->d_codons.ptr || c->d_codons.bytes < bytes) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_debug_codon_matrix: no matrix / capacity");
+    hipError_t e;
+    if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
+    if ((e = hipMemcpy(out, c->d_codons.ptr, bytes, hipMemcpyDeviceToHost)) != hipSuccess) return c->hip_fail(e, "hipMemcpy(codons)");
+    return PCSF_OK;
 }
 
 int pcsf_get_branch_matrices(pcsf_ctx* c, double* out)
@@ -523,7 +539,8 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
     }
     if ((e = c->d_nucl.reserve(nl * max_col)) != hipSuccess) return c->hip_fail(e, "hipMalloc(nucleotides)");
     if ((e = c->d_segments.reserve(seg.size() * sizeof(pcsf::FrameSegment))) != hipSuccess) return c->hip_fail(e, "hipMalloc(segments)");
-    if (!fused && (e = c->d_codons.reserve(nl * total)) != hipSuccess) return c->hip_fail(e, "hipMalloc(codons)");
+    if ((!fused || c->dump_codons) && (e = c->d_codons.reserve(nl * total)) != hipSuccess) return c->hip_fail(e, "hipMalloc(codons)");
+    c->last_total_sites = total;
     if (fused && (e = c->d_wg_seg.reserve(wg_first_seg.size() * sizeof(uint32_t))) != hipSuccess) return c->hip_fail(e, "hipMalloc(work-group segments)");
     if ((e = c->d_out.reserve(total * sizeof(double))) != hipSuccess) return c->hip_fail(e, "hipMalloc(out)");
     if ((e = pcsf::upload_rows(c->d_nucl.ptr, nucleotides, row_stride, max_col, nl, c->stream)) != hipSuccess) return c->hip_fail(e, "upload(nucleotides)");
@@ -548,7 +565,8 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
         d_char_flag = c->d_bls_flag.as<unsigned long long>();
     }
     if (fused) {
-        pcsf::FusedFrontEnd fe{c->d_nucl.as<unsigned char>(), max_col, c->d_segments.as<pcsf::FrameSegment>(), c->d_wg_seg.as<uint32_t>(), d_char_flag};
+        pcsf::FusedFrontEnd fe{c->d_nucl.as<unsigned char>(), max_col, c->d_segments.as<pcsf::FrameSegment>(), c->d_wg_seg.as<uint32_t>(), d_char_flag,
+                               c->dump_codons ? c->d_codons.as<unsigned char>() : nullptr};
         if ((rc = pcsf::launch_fixed(c, nullptr, total, total, c->d_out.as<double>(), nullptr, nullptr, c->stream, &fe)) != PCSF_OK) return rc;
     } else {
         // at most 65535 segments per launch (grid.y)

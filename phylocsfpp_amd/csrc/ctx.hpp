@@ -81,6 +81,8 @@ struct pcsf_ctx {
     pcsf::DeviceBuffer d_program, d_frag, d_leaf_tab, d_prior, d_anc_weight;
     // scratch for the host-pointer entry points
     pcsf::DeviceBuffer d_codons, d_out, d_lnz, d_anc, d_stamps, d_nucl, d_segments, d_wg_seg;
+    bool dump_codons = false;            // diagnostics (PCSF_DUMP_CODONS=1): the fused front end also writes its codons to d_codons
+    size_t last_total_sites = 0;
     bool fused_frontend = true;          // six-frame translation inside the pruning kernel (PCSF_FUSED_FRONTEND=0: separate kernel)
     // branch-length score (pcsf_set_bls_branch_lengths)
     pcsf::DeviceBuffer d_bls_tree, d_bls_out, d_bls_spans, d_bls_flag;
@@ -135,6 +137,7 @@ struct FusedFrontEnd {
     const FrameSegment* segments;
     const uint32_t* wg_first_seg;
     unsigned long long* first_bad;
+    unsigned char* dump_codons = nullptr;  // diagnostics
 };
 // launches the tracks-mode kernel over `n_sites` device-resident sites (both models); fused != null: the sites are
 // the codons of fused->segments, formed in the kernel (d_codons is not read)

@@ -24,6 +24,7 @@ struct PruneParams {
     const FrameSegment* segments;     // in site order, none empty
     const uint32_t* wg_first_seg;     // [work-groups] segment that holds the work-group's first site
     unsigned long long* first_bad;    // atomicMin of row * nucl_stride + col over characters outside ACGTNacgtn-. (may be null)
+    unsigned char* dump_codons;       // diagnostics (may be null): the codons the fused front end formed, [n_leaves][leaf_stride]
     size_t n_sites;
     size_t leaf_stride;
     const uint32_t* program; // [n_ops]

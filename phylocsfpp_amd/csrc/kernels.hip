@@ -206,6 +206,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
                 cod = (a >= 4u || b >= 4u || d >= 4u) ? 64u : 16u * a + 4u * b + d;
             }
             lcod[idx] = static_cast<unsigned char>(cod);
+            if (p.dump_codons && first >= 0) p.dump_codons[static_cast<size_t>(leaf) * p.leaf_stride + block_site0 + s] = static_cast<unsigned char>(cod);
         }
     } else if (whole_window) {
         constexpr int PIECES = SITES / 16;
@@ -331,10 +332,10 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
             if (code == F_CHERRY_DEV || code >= F_ROOT_DEV) PCSF_FETCH_NEXT_OP()
             PCSF_STAMP_RAW(5)
 
-            // Every op except the first cherry and the root starts with a product.  Its barrier
-            // (a) completes this wave's LDS-DMA of the current slot (vmcnt(0)), (b) publishes all
-            // waves' parts, (c) retires all reads of the other buffer, which the next slot's DMA
-            // overwrites.  Leaf rows needed after the product are requested before the MFMAs.
+            // Every op except the first cherry and the root starts with a product.  Before it: (a) this wave's
+            // LDS-DMA of the current slot has landed (explicit vmcnt(0), see PCSF_PRODUCT_PROLOGUE), then the barrier
+            // (b) publishes all waves' parts and (c) retires all reads of the other buffer, which the next slot's
+            // DMA overwrites.
 // segment K ends here: add (now - previous stamp) to its scalar sum; nothing is stored inside the loop
 // (a store would put its own latency behind the next vmcnt wait and distort what is measured)
 #define PCSF_STAMP(K)                                                                \
@@ -348,6 +349,12 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     }
 #define PCSF_PRODUCT_PROLOGUE()                                                      \
     PCSF_STAMP(0)                                                                    \
+    /* this wave's LDS-DMA pieces of the current slot must have LANDED before the barrier publishes them.  The barrier does \
+       not do that: __syncthreads() is a work-group fence, which waits for LDS operations (lgkmcnt) but not for vector \
+       memory (vmcnt).  Ops with leaf rows wait for them in their epilogue (in-order return covers the DMA issued earlier); \
+       after a POP nothing did, and a product could read pieces of the matrix two slots back -- seen only under memory \
+       pressure (fused front end: one work-group in ~30,000).  The pieces were requested a product ago: normally free. */ \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
     __syncthreads();                                                                 \
     PCSF_STAMP(1)                                                                    \
     const double2_t* buf = lfrag + (slot & 1) * (FRAG_DOUBLES_DEV / 2);              \
@@ -477,6 +484,11 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
         }
     }
 
+    // The last product of a work-group still stages a slot (into the idle buffer, branch-free): that LDS-DMA must have
+    // landed before the wave ends -- the work-group's LDS is handed to the next work-group on this CU the moment its waves
+    // are gone, and a piece arriving later would overwrite that group's first branch matrix (seen as one work-group in
+    // ~30,000 with 64 slightly wrong scores).  The pieces were requested a whole product ago: the wait is normally free.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (STAMP) {
         if (stamping && lane == 0)
             for (int k = 0; k < 8; ++k) {

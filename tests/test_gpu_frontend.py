@@ -186,3 +186,41 @@ def test_six_frame_call_without_branch_length_scores_rejects_other_characters(or
     nuc[7, 123] = ord("n")
     res, _ = ctx.score_alignments_6frames(nuc, [(0, 300, 1, 1000)])        # the context stays usable
     assert len(res[0][0]) == 100
+
+
+def test_repeated_six_frame_calls_are_bit_identical(golden_dir):
+    """Regression: the pruning kernel double-buffers its branch matrices in LDS with LDS-DMA.  A work-group barrier waits
+    for LDS operations only, not for vector memory, so the DMA pieces of the current slot need an explicit vmcnt(0) before
+    the barrier publishes them; without it a product behind a POP op could read pieces of the matrix two slots back when
+    memory latency exceeded one product (seen with the fused front end: one work-group in ~30,000 with 64 slightly wrong
+    scores, different ones on every call).  Forty calls on the same 600,000 codon-frames must agree bit for bit with each
+    other and with the separate-kernel path."""
+    import os
+    import phylocsfpp_amd as pa
+    m = pa.load_model(os.path.join(golden_dir, "models", "58mammals"))
+    rng = np.random.default_rng(2)
+    L = 300_000
+    nuc = np.frombuffer(b"ACGTacgtN-", dtype=np.uint8)[rng.integers(0, 10, size=(m.nl, L))]
+    alns, c = [], 0
+    while c < L:
+        k = int(min(rng.integers(50, 20000), L - c))
+        alns.append((c, k, int(rng.integers(1, 10**6)), 3 * 10**6))
+        c += k
+    old = os.environ.get("PCSF_FUSED_FRONTEND")
+    ref = None
+    try:
+        for fused, calls in (("0", 3), ("1", 40)):
+            os.environ["PCSF_FUSED_FRONTEND"] = fused
+            ctx = m.context(device=0, with_bls=True)
+            for r in range(calls):
+                res = ctx.score_alignments_6frames(nuc, alns, with_bls=(r % 2 == 0))
+                flat = np.concatenate([res[0][k][f] for k in range(len(alns)) for f in range(6)])
+                if ref is None:
+                    ref = flat
+                assert flat.tobytes() == ref.tobytes(), (fused, r, int((flat != ref).sum()))
+            ctx.close()
+    finally:
+        if old is None:
+            os.environ.pop("PCSF_FUSED_FRONTEND", None)
+        else:
+            os.environ["PCSF_FUSED_FRONTEND"] = old
