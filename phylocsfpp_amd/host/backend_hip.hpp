@@ -32,24 +32,8 @@ public:
     }
     bool device_bls() const override { return device_bls_; }
     int contexts_per_device() const override { return 2; }
-    void warm_up(size_t window_bytes, bool staging) override
-    {
-        check(pcsf_prepare_tracks(ctx_, std::max<size_t>(window_bytes / 64, 4096)));  // ~90 bytes of text per column
-        if (!staging) return;
-        // Page-locked buffers for the first four windows of a run (1/4, 1/2, 1, 1 window; drivers.hpp): rows ~0.75 byte per
-        // byte of MAF text, results ~0.33.  Page-locking costs milliseconds per 10 MB, and doing it while the first
-        // window is parsed slows the parser down (both work on the process's page tables); later windows recycle.
-        for (size_t w : {window_bytes / 4, window_bytes / 2, window_bytes, window_bytes})
-            for (size_t bytes : {w - w / 4, w / 3}) {
-                char* p = static_cast<char*>(pcsf_host_alloc_on(ctx_, std::max<size_t>(bytes, 1)));
-                if (p) cache_.push_back({p, bytes, false});
-            }
-    }
-    ~HipBackend() override
-    {
-        for (const Cached& c : cache_) pcsf_host_free(c.ptr);
-        pcsf_destroy(ctx_);
-    }
+    void prepare_tracks(size_t max_columns) override { check(pcsf_prepare_tracks(ctx_, max_columns)); }
+    ~HipBackend() override { pcsf_destroy(ctx_); }
     void score_sites_fixed(const uint8_t* codons, size_t n_sites, size_t leaf_stride, double* out) override
     {
         check(pcsf_score_sites_fixed(ctx_, codons, n_sites, leaf_stride, out));
@@ -77,46 +61,18 @@ public:
 
     char* staging_alloc(size_t bytes) override
     {
-        {  // smallest fitting buffer of the warm-up cache
-            std::lock_guard<std::mutex> g(cache_lock_);
-            Cached* best = nullptr;
-            for (Cached& c : cache_)
-                if (!c.in_use && c.bytes >= bytes && (!best || c.bytes < best->bytes)) best = &c;
-            if (best) {
-                best->in_use = true;
-                return best->ptr;
-            }
-        }
         // on this context's GPU (no primary context on device 0 for a run on another device); never zero bytes
         char* p = static_cast<char*>(pcsf_host_alloc_on(ctx_, bytes ? bytes : 1));
         if (!p) throw std::runtime_error("pcsf_host_alloc_on failed");
         return p;
     }
-    void staging_free(char* p) override
-    {
-        {
-            std::lock_guard<std::mutex> g(cache_lock_);
-            for (Cached& c : cache_)
-                if (c.ptr == p) {
-                    c.in_use = false;  // stays page-locked for the next run of this process
-                    return;
-                }
-        }
-        pcsf_host_free(p);
-    }
+    void staging_free(char* p) override { pcsf_host_free(p); }
 
 private:
     void check(int rc)
     {
         if (rc != PCSF_OK) throw std::runtime_error(std::string("phylocsf_amd: ") + pcsf_last_error(ctx_));
     }
-    struct Cached {
-        char* ptr;
-        size_t bytes;
-        bool in_use;
-    };
-    std::vector<Cached> cache_;
-    std::mutex cache_lock_;
     pcsf_ctx* ctx_ = nullptr;
     bool device_bls_ = false;
 };

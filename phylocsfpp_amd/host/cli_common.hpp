@@ -285,8 +285,6 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
                 backends.push_back(owned.back().get());
             }
         }
-        if (cmd == "build-tracks")  // backend set-up that a short run would otherwise pay for inside its first calls
-            for (size_t b = 0; b < backends.size(); ++b) backends[b]->warm_up(bt.window_bytes, /*staging=*/b == 0);
         bool first = true;
         for (; i < argc; ++i) {
             if (cmd == "build-tracks") {

@@ -63,10 +63,10 @@ struct ScoringBackend {
     // how many contexts per device pay off in build-tracks (the HIP backend: two, their kernels take turns on the GPU
     // while the transfers of one call run under the kernels of the other)
     virtual int contexts_per_device() const { return 1; }
-    // Part of a backend's set-up, called once by the CLI between model loading and the first build-tracks run: whatever
-    // the first calls of a short run would otherwise pay for -- the HIP backend reserves device scratch, runs its kernels
-    // once (code loading) and, if `staging`, page-locks the buffers of the first windows (window_bytes of MAF text each)
-    virtual void warm_up(size_t /*window_bytes*/, bool /*staging*/) {}
+    // build-tracks is about to send batches of up to max_columns alignment columns: a backend may set up whatever its
+    // first call would otherwise pay for (the HIP backend: device scratch, kernel code loading).  Called on a thread of
+    // its own while the first window is parsed; the backend's first batch waits for it.
+    virtual void prepare_tracks(size_t /*max_columns*/) {}
     virtual size_t score_alignments_6frames(int n_leaves, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0,
                                             const std::vector<uint32_t>& len, const std::vector<uint64_t>& start_pos,
                                             const std::vector<uint64_t>& chrom_len, double* out, size_t out_capacity, std::vector<uint64_t>& offsets,
@@ -512,9 +512,6 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
                 memcpy(bt.nucl.first + l * bt.stride + p.col0, p.seqs[l].data(), p.len);
             });
             for (Item* p : bt.items) std::vector<std::string>().swap(p->seqs);  // the rows now live in the batch matrix
-            // the batch's page-locked result buffer is taken here, one window ahead of the scoring stage (pinning pages
-            // costs milliseconds): the scores, then (device branch-length scores) one value per column
-            bt.score_mem = score_pool.get((2 * bt.stride + (dev_bls ? bt.stride : 0)) * sizeof(double));
         }
         pw->pack = pack.lap();
         return pw;
@@ -577,6 +574,8 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             StopWatch bw;
             if (need_raw) {
                 const size_t cap_scores = 2 * b->stride;  // six frames of len/3 codons each
+                // one page-locked buffer: the scores, then (device branch-length scores) one value per column
+                b->score_mem = score_pool.get((cap_scores + (dev_bls ? b->stride : 0)) * sizeof(double));
                 double* out = reinterpret_cast<double*>(b->score_mem.first);
                 double* bls_out = dev_bls ? out + cap_scores : nullptr;
                 b->n_scores = backends[d]->score_alignments_6frames(model.n_leaves, b->nucl.first, b->stride, b->col0, b->len, b->start_pos, b->chrom_len,
@@ -596,6 +595,12 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     };
     std::future<std::unique_ptr<PreparedWindow>> next;
     if (input_bytes > 0) next = std::async(std::launch::async, prepare_window, size_t(0));
+    if (need_raw)
+        for (size_t d = 0; d < n_dev; ++d)
+            dev_last[d] = std::async(std::launch::async, [&, d]() -> double {
+                           backends[d]->prepare_tracks(std::min<size_t>(cap, std::max<size_t>(window / 64, 4096)));
+                           return 0.0;
+                       }).share();
     try {
     for (size_t wi = 0; wi + 1 < window_begin.size(); ++wi) {
         std::unique_ptr<PreparedWindow> pw = next.get();
