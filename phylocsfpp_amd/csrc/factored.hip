@@ -46,35 +46,38 @@ struct Vec4 {
 }  // namespace
 
 // ---- e_b[k] = exp(lambda_k * t_b) for every branch of every evaluation ----------------------------------------------
-// t_b = (double)(float)(len_b * x) like the reference's float tree (src/instance.hpp:299-307,498).  One thread per
-// (evaluation, branch, eigenvalue); states are stored in row-split order.
+// t_b = (double)(float)(len_b * x) like the reference's float tree (src/instance.hpp:299-307,498).  One work-group per
+// evaluation (a thread computes ~50 exponentials; one launch per round, thousands of evaluations); states are stored in
+// row-split order.
 //
 // Validation (the reference rejects a model whose raw row sums of P(t) are off by more than 1e-6,
 // src/instance.hpp:632-636): sum_j P_ij(t) = sum_k R_ik e^{lambda_k t} c_k with c = L 1.  Q 1 = 0 makes 1 the right
 // eigenvector of eigenvalue 0, so c_k vanishes (to rounding) for every other k and the row sums do not depend on t:
 // they are checked ONCE per evaluation, for the longest branch (smallest e_k: the largest possible deviation), by the
-// first wave of the evaluation's first work-group.
+// first wave of the evaluation's work-group.
 __global__ __launch_bounds__(256) void edge_scale_kernel(const ExpmEval* __restrict__ evals, uint32_t n_branches, const float* __restrict__ branch_len,
                                                          const double* __restrict__ eig_right, const double* __restrict__ eig_left,
                                                          const double* __restrict__ eig_lambda, double* __restrict__ scale_out,
                                                          uint32_t* __restrict__ fail)
 {
+    // one work-group per evaluation; wave w takes branches w, w+4, ...; lane k the eigenvalue k (no barrier in the loop)
     __shared__ double ec[64];
-    const ExpmEval ev = evals[blockIdx.y];
+    const ExpmEval ev = evals[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double lam = eig_lambda[static_cast<size_t>(ev.eig) * 64 + lane];
     const int pos = row_split_pos(lane);
     double* __restrict__ dst = scale_out + static_cast<size_t>(ev.table) * n_branches * 64;
-    const uint32_t b = blockIdx.x * 4 + wave;  // four branches per work-group
-    if (b < n_branches) {
-        const double t = static_cast<double>(static_cast<float>(static_cast<double>(branch_len[b]) * ev.x));
+    float longest = 0.0f;
+    for (uint32_t b = wave; b < n_branches; b += 4) {
+        const float len = branch_len[b];
+        longest = fmaxf(longest, len);
+        const double t = static_cast<double>(static_cast<float>(static_cast<double>(len) * ev.x));
         dst[static_cast<size_t>(b) * 64 + pos] = exp(lam * t);
     }
-    if (blockIdx.x != 0) return;
-    // the evaluation's row-sum check (work-group 0, wave 0; no divergent barrier: the whole group reaches it)
-    float longest = 0.0f;
-    for (uint32_t i = 0; i < n_branches; ++i) longest = fmaxf(longest, branch_len[i]);
+    // the evaluation's row-sum check, by wave 0 (its branches include the longest of every fourth; take the overall
+    // longest from all branches -- a scalar loop over cached values)
     if (wave == 0) {
+        for (uint32_t i = 0; i < n_branches; ++i) longest = fmaxf(longest, branch_len[i]);
         const double* __restrict__ L = eig_left + static_cast<size_t>(ev.eig) * 4096;
         double c = 0.0;
         for (int j = 0; j < 64; ++j) c += L[lane * 64 + j];
@@ -263,9 +266,8 @@ hipError_t launch_edge_scale(const ExpmEval* d_evals, uint32_t n_evals, uint32_t
                              const double* d_eig_left, const double* d_eig_lambda, double* d_scale_out, uint32_t* d_fail, hipStream_t stream)
 {
     if (n_evals == 0) return hipSuccess;
-    for (uint32_t at = 0; at < n_evals; at += 65535u)  // grid.y
-        hipLaunchKernelGGL(edge_scale_kernel, dim3((n_branches + 3) / 4, n_evals - at < 65535u ? n_evals - at : 65535u), dim3(256), 0, stream, d_evals + at,
-                           n_branches, d_branch_len, d_eig_right, d_eig_left, d_eig_lambda, d_scale_out, d_fail);
+    hipLaunchKernelGGL(edge_scale_kernel, dim3(n_evals), dim3(256), 0, stream, d_evals, n_branches, d_branch_len, d_eig_right, d_eig_left,
+                       d_eig_lambda, d_scale_out, d_fail);
     return hipGetLastError();
 }
 

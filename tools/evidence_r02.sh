@@ -30,3 +30,10 @@ cp $(find $O/prof_bt -name "*kernel_stats.csv" | head -1) $O/build_tracks_kernel
 rm -rf $O/prof_bt
 zcat tests/golden/score-msa/chr22.516alignments.maf.gz > /tmp/s516.maf; { for s in fixed mle omega; do a=$(date +%s.%N); phylocsfpp_amd/host/phylocsf-amd score-msa --strategy $s tests/golden/models/100vertebrates /tmp/s516.maf > /dev/null 2>&1; b=$(date +%s.%N); python3 -c "print(\"score-msa --strategy $s, 516 blocks: %.2f s wall (process start to exit)\" % ($b - $a))"; done; } > $O/score_msa_cli.txt 2>&1 || true
 ls -la $O
+# batch size: the same 10 Mb (ten 1 Mb segments) with 32 MB (default) and 64 MB windows of MAF text per pipeline step
+python3 tools/replicate_maf.py /tmp/syn1mb.maf /tmp/syn10mb.maf --copies 10 > /dev/null 2>&1
+{ for w in 33554432 67108864 134217728; do echo "== --window-bytes $w"; for i in 1 2 3; do phylocsfpp_amd/host/phylocsf-amd build-tracks --window-bytes $w --output /tmp/out_bt tests/golden/models/58mammals /tmp/syn10mb.maf 2>&1 | tail -2; done; done; } > $O/build_tracks_window.txt
+python3 tools/diag_determinism.py 40 > $O/determinism.txt 2>&1
+python3 tools/objective_noise.py > $O/objective_noise.txt 2>&1
+python3 tools/omega_divergence.py 14 > $O/omega_divergence.txt 2>&1
+ls -la $O
