@@ -193,9 +193,10 @@ def end_to_end(device, runs, cpu_rate_all_cores, work_dir):
            "maf_bytes": info["bytes"], "codon_frames": best["codon_frames"], "ref_bases": best["ref_bases"], "alignments": best["alignments"],
            "backend_calls": best["backend_calls"], "runs": runs, "host_threads": cpus,
            "seconds": best["seconds"], "seconds_all_runs": [r["seconds"] for r in gpu_runs],
-           "process_wall_seconds": best["process_wall_seconds"],
+           "process_wall_seconds": min(r["process_wall_seconds"] for r in gpu_runs),
+           "process_wall_seconds_all_runs": [r["process_wall_seconds"] for r in gpu_runs],
            "codon_frames_per_s": best["codon_frames"] / best["seconds"],
-           "codon_frames_per_s_process_wall": best["codon_frames"] / best["process_wall_seconds"],
+           "codon_frames_per_s_process_wall": best["codon_frames"] / min(r["process_wall_seconds"] for r in gpu_runs),
            "maf_gigabytes_per_s": info["bytes"] / best["seconds"] / 1e9,
            "stage_busy": best["stage_busy"],
            "note": "seconds = build_tracks() inside the child process (file mapped, parsed, scored, seven wig files written); "

@@ -57,14 +57,18 @@ def main():
     path = os.path.join(P, "blocks_pmc_summary.json")
     if os.path.exists(path):
         d = json.load(open(path))
+        dur = {x["Name"].split("(")[0]: float(x["TotalDurationNs"]) * 1e-9 for x in rows("blocks_kernel_stats.csv")}
         for k, v in d.items():
             if "pcsf" not in k:
                 continue
             val = lambda c: v.get(c, {}).get("sum", 0.0)
-            busy = val("SQ_BUSY_CYCLES")
-            print("   PMC %-40s VALU %.3g (MFMA %.3g) LDS %.3g bank-conflict cycles %.3g waves %.3g; MFMA busy / (4 x SQ busy) = %.3f"
+            # SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of all 1024 SIMDs: utilisation while the kernel runs =
+            # busy / (1024 SIMDs x seconds the kernel ran x clock); durations from the kernel-trace run of the same command
+            secs = dur.get(k, 0.0)
+            util = val("SQ_VALU_MFMA_BUSY_CYCLES") / (1024 * secs * 2.39e9) if secs else 0.0
+            print("   PMC %-40s VALU %.3g (MFMA %.3g) LDS %.3g bank-conflict cycles %.3g waves %.3g; per wave: %.0f VALU + %.0f LDS instructions; MFMA pipe busy while running %.3f"
                   % (k[-40:], val("SQ_INSTS_VALU"), val("SQ_INSTS_MFMA"), val("SQ_INSTS_LDS"), val("SQ_LDS_BANK_CONFLICT"), val("SQ_WAVES"),
-                     val("SQ_VALU_MFMA_BUSY_CYCLES") / (4 * busy) if busy else 0.0))
+                     val("SQ_INSTS_VALU") / max(val("SQ_WAVES"), 1), val("SQ_INSTS_LDS") / max(val("SQ_WAVES"), 1), util))
     for name in ("config4/text_run1.txt", "config4/text_run2.txt", "config4/packed_run1.txt", "config4/packed_run2.txt", "config4/pack.txt", "config4/outputs.txt"):
         path = os.path.join(P, name)
         if os.path.exists(path):

@@ -19,6 +19,13 @@ $W/oracle_cli build-tracks --output $W/out --output-phylo 1 --output-regions 1 -
 $W/oracle_cli build-tracks --output $W/out2 --species Chicken,Turkey,Zebra_finch,Budgerigar $M/53birds $W/g.maf
 for st in fixed mle omega fixed_mean; do $W/oracle_cli score-msa --strategy $st --comp-anc 1 --hmm-params $H $M/100vertebrates $W/s.maf; done
 $W/oracle_cli dump-alignments --jobs 7 $M/53birds $W/g.maf > /dev/null
+$W/oracle_cli pack-maf $M/53birds $W/g.maf $W/g.pcsfbin
+$W/oracle_cli build-tracks --output $W/out3 --window-bytes 300000 --batch-sites 5000 --devices 0,0 $M/53birds $W/g.pcsfbin
+cmp $W/out2/../out3/PhyloCSFRaw+1.wig $W/out/PhyloCSFRaw+1.wig
+head -c 100000 $W/g.pcsfbin > $W/cut.pcsfbin; if $W/oracle_cli build-tracks --output $W/out4 $M/53birds $W/cut.pcsfbin 2>/dev/null; then echo "truncated packed file accepted"; exit 1; fi
+printf 'a score=0\ns chicken.chr1 10 4 + 1000 ACXT\ns turkey.chr1 10 4 + 1000 ACGT\n' > $W/bad.maf
+if $W/oracle_cli build-tracks --output $W/out5 $M/53birds $W/bad.maf 2>/dev/null; then echo "bad character accepted"; exit 1; fi
+test ! -e $W/out5/PhyloCSFRaw+1.wig   # a failed run leaves no truncated outputs behind
 $W/oracle_cli smooth-tracks --output-regions 1 --hmm-params $H $W/out
 $W/oracle_cli selftest-format 200000
 echo "sanitizers: no findings"
