@@ -202,16 +202,24 @@ struct BlockEngine {
     BlockEngine& operator=(const BlockEngine&) = delete;
 
     // capacity: evaluations per run() / eigen-systems alive at a time
-    // table sets only live within one run(): growing between runs loses nothing; growing with evaluations queued would
+    // table sets only live within one run(): growing between runs loses nothing; growing with evaluations queued would.
+    // The branch-matrix tables themselves (9.6 MB per evaluation of a 100-leaf tree) are allocated when the first
+    // evaluation takes the explicit path -- on real alignments none does, and 7 GB of hipMalloc per call is not free.
     void reserve_tables(size_t tables)
     {
         if (tables <= cap_tables) return;
         if (!evals.empty()) throw std::runtime_error("BlockEngine: reserve_tables with evaluations queued");
-        HIP_TRY(d_frag.reserve(std::max<size_t>(1, tables * ne) * 4096 * sizeof(double)));
-        HIP_TRY(d_leaf.reserve(tables * nl * LEAF_TABLE_DOUBLES_DEV * sizeof(double)));
         HIP_TRY(d_fail.reserve(tables * sizeof(uint32_t)));
         HIP_TRY(d_scale.reserve(tables * static_cast<size_t>(n - 1) * 64 * sizeof(double)));
         cap_tables = tables;
+        if (tables_allocated) allocate_tables();
+    }
+    bool tables_allocated = false;
+    void allocate_tables()
+    {
+        HIP_TRY(d_frag.reserve(std::max<size_t>(1, cap_tables * ne) * 4096 * sizeof(double)));
+        HIP_TRY(d_leaf.reserve(cap_tables * nl * LEAF_TABLE_DOUBLES_DEV * sizeof(double)));
+        tables_allocated = true;
     }
     // eigen-systems already resident (uploaded, or solved by an earlier run()) survive a growth
     void reserve_eig(size_t count)
@@ -265,9 +273,6 @@ struct BlockEngine {
         ev.table = table;
         ev.block = static_cast<uint32_t>(blk);
         ev.x = x;
-        const uint64_t n_block_sites = off[blk + 1] - off[blk];
-        const uint64_t n_tiles = (n_block_sites + 15) / 16;
-        (void)n_tiles;
         if (allow_factored && block_factored[blk]) {
             // short block: factors applied directly, one work-group per 16-site tile (an empty block only has its
             // model validated)
@@ -282,6 +287,7 @@ struct BlockEngine {
                 fjobs[set].push_back(j);
             }
         } else {
+            if (!tables_allocated) allocate_tables();
             jobs[set].push_back(ev);
             for (uint64_t s = off[blk]; s < off[blk + 1]; s += 64) {
                 wg0[set].push_back(s);

@@ -246,3 +246,27 @@ def test_config5_100vertebrates_all_rows_hmm_estimated_from_exons(tmp_path):
         assert got == want_b, n
         n_bytes += len(got)
     assert n_bytes > 500000
+
+
+def test_packed_alignment_file_on_gpu(tmp_path):
+    """pack-maf + build-tracks on the packed file through the GPU driver: same seven files as from the MAF text, twice
+    (a second run must reproduce the first bit for bit -- the 4 Mb run that exposed the LDS-DMA race differed from itself)."""
+    import sys
+    maf = tmp_path / "syn.maf"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_synthetic_maf.py"), str(maf), "--bases", "150000", "--seed", "11"],
+                          stdout=subprocess.DEVNULL)
+    packed = tmp_path / "syn.pcsfbin"
+    model = os.path.join(GOLD, "models", "58mammals")
+    subprocess.check_call([_cli(), "pack-maf", model, str(maf), str(packed)], stderr=subprocess.DEVNULL)
+    outs = []
+    for src, extra in ((maf, []), (maf, ["--window-bytes", "3000000"]), (packed, []), (packed, ["--window-bytes", "2000000", "--batch-sites", "50000"])):
+        out = tmp_path / ("o%d" % len(outs))
+        subprocess.check_call([_cli(), "build-tracks", "--output", str(out)] + extra + [model, str(src)], stderr=subprocess.DEVNULL)
+        outs.append(out)
+    names = sorted(os.listdir(outs[0]))
+    assert len(names) == 7
+    for n in names:
+        want = open(outs[0] / n, "rb").read()
+        assert len(want) > 100000
+        for o in outs[1:]:
+            assert open(o / n, "rb").read() == want, (n, str(o))
