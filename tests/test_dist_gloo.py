@@ -111,3 +111,23 @@ def test_overlapped_gather_pipeline(tmp_path, world):
     out = str(tmp_path / "pipe.npy")
     mp.spawn(_pipeline_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert np.load(out)[0] == 1.0
+
+
+def test_bench_site_stream_is_the_same_for_every_sharding():
+    """bench.py materialises its synthetic site stream per rank on the rank's own GPU from a counter-based generator
+    (column i = pool column hash(i, seed)): the strong-scaling shards of any world size must tile the one-GPU stream."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rng = np.random.default_rng(0)
+    pool = torch.from_numpy(rng.integers(0, 65, size=(5, bench.POOL_SITES), dtype=np.uint8))
+    total = 100_003
+    whole = bench.sample_columns(pool, 0, total, seed=7)
+    assert whole.shape == (5, total) and whole.dtype == torch.uint8
+    assert len(torch.unique(whole[0])) > 30 and not torch.equal(whole[:, :1000], bench.sample_columns(pool, 0, 1000, seed=8))
+    for world in (1, 2, 3, 8):
+        bounds = pdist.shard_bounds(total, world, 64)
+        assert bounds[0][0] == 0 and bounds[-1][1] == total and all(b[0] % 64 == 0 for b in bounds)
+        parts = [bench.sample_columns(pool, lo, hi, seed=7) for lo, hi in bounds]
+        assert torch.equal(torch.cat(parts, dim=1), whole)
