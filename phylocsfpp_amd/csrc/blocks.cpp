@@ -85,6 +85,7 @@ struct BlockEngine {
     // (median 4 of 100 species) stay factored at any length.  PCSF_FACTORED_MAX_TILES=n replaces the rule by "at most n tiles".
     std::vector<char> block_factored;
     long fixed_max_tiles = -1;
+    bool host_eigen = false;     // PCSF_EIGEN_HOST=1: parity mode, see run()
     bool allow_factored = true;  // false: caller-supplied eigen-systems keep the entry-wise post-processing of P
     // Work of one run() is kept in two sets: evaluations whose eigen-system is rebuilt in this run (set 1: eigen ->
     // expm -> prune on the side stream) and all others (set 0: expm -> prune on the main stream), so that the
@@ -140,6 +141,7 @@ struct BlockEngine {
                 leaf_codes[(b * nl + l) * 2 + 1] = hi;
             }
         if (const char* v = std::getenv("PCSF_FACTORED_MAX_TILES")) fixed_max_tiles = std::max(0, std::atoi(v));
+        if (const char* v = std::getenv("PCSF_EIGEN_HOST")) host_eigen = std::atoi(v) != 0;
         block_factored.assign(nb, 0);
         for (size_t b = 0; b < nb; ++b) {
             const uint64_t sites = offsets[b + 1] - offsets[b], tiles = (sites + 15) / 16;
@@ -309,7 +311,26 @@ struct BlockEngine {
         if (tables == 0) return;
         HIP_TRY(hipMemsetAsync(d_fail.ptr, 0, tables * sizeof(uint32_t), stream));
         const size_t nj0 = jobs[0].size(), nj1 = jobs[1].size(), nw0 = wg0[0].size(), nw1 = wg0[1].size();
-        if (!eig_jobs.empty()) {
+        if (!eig_jobs.empty() && host_eigen) {
+            // parity mode (PCSF_EIGEN_HOST=1): the kappa/omega eigen-systems come from the HOST solver -- row-cyclic Jacobi from
+            // a cold start, the oracle's algorithm -- instead of eigen_omega_kernel.  Far too slow for production (a few
+            // milliseconds per matrix); it exists to show how much of the OMEGA end-result scatter between this library
+            // and the oracle is eigen-solver rounding (tests/test_gpu_parity_blocks.py).
+            std::vector<EigenSystem> es(eig_jobs.size());
+            std::vector<char> bad(eig_jobs.size(), 0);
+            parallel_for(eig_jobs.size(), [&](size_t i) {
+                Mat Q;
+                Vec pi;
+                rate_matrix_omega(eig_jobs[i].qs, Q, pi);
+                bad[i] = !eigen_reversible(Q, pi.data(), es[i]);
+            });
+            const uint32_t one = 1u;
+            for (size_t i = 0; i < eig_jobs.size(); ++i) {
+                if (bad[i]) HIP_TRY(hipMemcpyAsync(d_fail.as<uint32_t>() + eig_jobs[i].table, &one, sizeof one, hipMemcpyHostToDevice, stream));
+                else upload_eig(eig_jobs[i].eig, es[i]);
+            }
+            HIP_TRY(hipStreamSynchronize(stream));  // `one` is a stack temporary
+        } else if (!eig_jobs.empty()) {
             HIP_TRY(d_eig_jobs.reserve(eig_jobs.size() * sizeof(EigenJob)));
             HIP_TRY(hipMemcpyAsync(d_eig_jobs.ptr, eig_jobs.data(), eig_jobs.size() * sizeof(EigenJob), hipMemcpyHostToDevice, stream));
         }
@@ -420,7 +441,7 @@ struct BlockEngine {
             }
         };
         if (use_side) {
-            if (!eig_jobs.empty()) {
+            if (!eig_jobs.empty() && !host_eigen) {
                 EigenParams gp{};
                 gp.jobs = d_eig_jobs.as<EigenJob>();
                 gp.n_jobs = static_cast<uint32_t>(eig_jobs.size());
