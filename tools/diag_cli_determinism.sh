@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python tools/diag_determinism.py
+python tools/diag_determinism.py 20
 cli=phylocsfpp_amd/host/phylocsf-amd; model=tests/golden/models/58mammals; w=/tmp/dg; rm -rf $w; mkdir -p $w
 python tools/gen_synthetic_maf.py $w/seg.maf --bases 1000000 > /dev/null
 python tools/replicate_maf.py $w/seg.maf $w/c.maf --copies 4 > /dev/null
