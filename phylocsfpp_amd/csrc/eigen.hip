@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
     extern __shared__ __attribute__((aligned(16))) double lds_eig[];  // 2 x 64 x 65 doubles = 66,560 B
     double* A = lds_eig;
     double* V = lds_eig + 64 * LD;
-    __shared__ double pi[64], root[64], iroot[64], cs[32], sn[32], red[8];
-    __shared__ int pp[32], qq[32];
+    __shared__ double pi[64], root[64], iroot[64], cs[64], sn[64], red[8];  // cs / sn / pp / qq: two steps' rotations
+    __shared__ int pp[64], qq[64];
     __shared__ double norm_s;
     __shared__ int flag;
 
@@ -164,6 +164,32 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
         }
         __syncthreads();
     }
+    // rotations of one step into buffer `buf`: tournament pairing of 0..63 (63 stays, the others rotate), lanes 0..31 of wave 0
+    auto rotations = [&](int step, int buf) {
+        if (tid < 32) {
+            int a, b;
+            if (tid == 0) {
+                a = step;
+                b = 63;
+            } else {
+                a = (step + tid) % 63;
+                b = (step - tid + 63) % 63;
+            }
+            const int pi_ = a < b ? a : b, qi = a < b ? b : a;
+            const double g = A[pi_ * LD + qi];
+            double c = 1.0, s = 0.0;
+            if (!(fabs(g) < 1e-290)) {
+                const double zeta = (A[qi * LD + qi] - A[pi_ * LD + pi_]) / (2.0 * g);
+                const double t = (fabs(zeta) > 1e150) ? 0.5 / zeta : copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                c = 1.0 / sqrt(1.0 + t * t);
+                s = t * c;
+            }
+            cs[32 * buf + tid] = c;
+            sn[32 * buf + tid] = s;
+            pp[32 * buf + tid] = pi_;
+            qq[32 * buf + tid] = qi;
+        }
+    };
     for (int sweep = 0; sweep < 60; ++sweep) {
         // convergence: squared off-diagonal mass against squared diagonal mass
         double off = 0.0, total = 0.0;
@@ -187,50 +213,37 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
         __syncthreads();
         if (off <= 1e-58 * total) break;
 
+        // One Jacobi step = (A) B <- J^T B J by all four waves, barrier, (B) V <- V J by waves 1-3 WHILE wave 0 computes the
+        // rotations of the next step from the updated B, barrier.  The rotation parameters are a chain of ~150 dependent
+        // fp64 instructions (two square roots, three divisions) on 32 lanes: as a phase of its own it was a third of a
+        // step during which 224 of 256 threads waited; the arithmetic and its order per element are unchanged.
+        rotations(0, 0);
+        __syncthreads();
         for (int step = 0; step < 63; ++step) {
-            if (tid < 32) {  // tournament pairing of 0..63: 63 stays, the others rotate
-                int a, b;
-                if (tid == 0) {
-                    a = step;
-                    b = 63;
-                } else {
-                    a = (step + tid) % 63;
-                    b = (step - tid + 63) % 63;
-                }
-                const int pi_ = a < b ? a : b, qi = a < b ? b : a;
-                const double g = A[pi_ * LD + qi];
-                double c = 1.0, s = 0.0;
-                if (!(fabs(g) < 1e-290)) {
-                    const double zeta = (A[qi * LD + qi] - A[pi_ * LD + pi_]) / (2.0 * g);
-                    const double t = (fabs(zeta) > 1e150) ? 0.5 / zeta : copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                    c = 1.0 / sqrt(1.0 + t * t);
-                    s = t * c;
-                }
-                cs[tid] = c;
-                sn[tid] = s;
-                pp[tid] = pi_;
-                qq[tid] = qi;
-            }
-            __syncthreads();
-            // B <- J^T B J in ONE pass over 2x2 blocks: block (m, m') = rows {p,q} of pair m x columns {p',q'} of pair
+            const int cur = step & 1;
+            const int* __restrict__ ppc = pp + 32 * cur;
+            const int* __restrict__ qqc = qq + 32 * cur;
+            const double* __restrict__ csc = cs + 32 * cur;
+            const double* __restrict__ snc = sn + 32 * cur;
+            // (A) B <- J^T B J in ONE pass over 2x2 blocks: block (m, m') = rows {p,q} of pair m x columns {p',q'} of pair
             // m' is first rotated from the right by pair m', then from the left by pair m -- the same arithmetic as a
-            // column pass followed by a row pass, with every entry read and written once.  V <- V J on the side.  All
-            // operands are read before any result is written (the items are disjoint, but the compiler cannot know
-            // that for accesses to one LDS array and would otherwise wait for an LDS round trip per item).
+            // column pass followed by a row pass, with every entry read and written once.  All operands are read before
+            // any result is written (the items are disjoint, but the compiler cannot know that for accesses to one LDS
+            // array and would otherwise wait for an LDS round trip per item).
             {
                 double b00[4], b01[4], b10[4], b11[4], cl[4], sl[4], cr[4], sr[4];
                 int pl[4], ql[4], pr[4], qr[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int blk = tid + 256 * i, m = blk >> 5, mr = blk & 31;
-                    pl[i] = pp[m];
-                    ql[i] = qq[m];
-                    cl[i] = cs[m];
-                    sl[i] = sn[m];
-                    pr[i] = pp[mr];
-                    qr[i] = qq[mr];
-                    cr[i] = cs[mr];
-                    sr[i] = sn[mr];
+                    pl[i] = ppc[m];
+                    ql[i] = qqc[m];
+                    cl[i] = csc[m];
+                    sl[i] = snc[m];
+                    pr[i] = ppc[mr];
+                    qr[i] = qqc[mr];
+                    cr[i] = csc[mr];
+                    sr[i] = snc[mr];
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -238,18 +251,6 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
                     b01[i] = A[pl[i] * LD + qr[i]];
                     b10[i] = A[ql[i] * LD + pr[i]];
                     b11[i] = A[ql[i] * LD + qr[i]];
-                }
-                int pm[8], qm[8];
-                double cm[8], sm[8], vx[8], vy[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int m = wave + 4 * i;
-                    pm[i] = pp[m];
-                    qm[i] = qq[m];
-                    cm[i] = cs[m];
-                    sm[i] = sn[m];
-                    vx[i] = V[lane * LD + pm[i]];
-                    vy[i] = V[lane * LD + qm[i]];
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -266,10 +267,31 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
                     A[ql[i] * LD + pr[i]] = n10;
                     A[ql[i] * LD + qr[i]] = n11;
                 }
+            }
+            __syncthreads();
+            // (B) wave 0: rotations of the next step; waves 1..3: V <- V J, row `lane`, pairs wave-1, wave+2, ...
+            if (wave == 0) {
+                if (step + 1 < 63) rotations(step + 1, cur ^ 1);
+            } else {
+                int pm[11], qm[11];
+                double cm[11], sm[11], vx[11], vy[11];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    V[lane * LD + pm[i]] = cm[i] * vx[i] - sm[i] * vy[i];
-                    V[lane * LD + qm[i]] = sm[i] * vx[i] + cm[i] * vy[i];
+                for (int i = 0; i < 11; ++i) {
+                    const int m = (wave - 1) + 3 * i;
+                    const int mm = m < 32 ? m : 31;
+                    pm[i] = ppc[mm];
+                    qm[i] = qqc[mm];
+                    cm[i] = csc[mm];
+                    sm[i] = snc[mm];
+                    vx[i] = V[lane * LD + pm[i]];
+                    vy[i] = V[lane * LD + qm[i]];
+                }
+#pragma unroll
+                for (int i = 0; i < 11; ++i) {
+                    if ((wave - 1) + 3 * i < 32) {
+                        V[lane * LD + pm[i]] = cm[i] * vx[i] - sm[i] * vy[i];
+                        V[lane * LD + qm[i]] = sm[i] * vx[i] + cm[i] * vy[i];
+                    }
                 }
             }
             __syncthreads();
