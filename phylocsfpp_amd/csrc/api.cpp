@@ -96,6 +96,7 @@ PruneParams base_prune_params(const pcsf_ctx* c)
     p.stamps = c->d_stamps.as<unsigned long long>();
     p.stamp_block = c->stamp_block;
     p.stagger_sleep = c->stagger_sleep;
+    p.prio_mode = c->prio_mode;
     p.stagger_first_blocks = c->stagger_first_blocks;
     return p;
 }
@@ -360,6 +361,7 @@ int pcsf_create(pcsf_ctx** out, const pcsf_model_desc* m, int device_id)
     }
     c->stagger_first_blocks = 2u * static_cast<uint32_t>(prop.multiProcessorCount);
     if (const char* v = std::getenv("PCSF_STAGGER")) c->stagger_sleep = std::atoi(v);
+    if (const char* v = std::getenv("PCSF_PRIO_MODE")) c->prio_mode = std::atoi(v);
     if (const char* v = std::getenv("PCSF_EXTRA_LDS")) c->extra_lds = static_cast<size_t>(std::atoi(v));
     if (const char* v = std::getenv("PCSF_FUSED_FRONTEND")) c->fused_frontend = std::atoi(v) != 0;
     if (const char* v = std::getenv("PCSF_DUMP_CODONS")) c->dump_codons = std::atoi(v) != 0;

@@ -97,6 +97,7 @@ struct pcsf_ctx {
     double last_kernel_ms = 0.0;
     int variant = 0;
     size_t extra_lds = 0;                // experiment knob (PCSF_EXTRA_LDS): lowers occupancy
+    int prio_mode = 0;                   // experiment knob (PCSF_PRIO_MODE), see kernels.h
     int stagger_sleep = 0;               // x1024 cycles late start of the odd wave slot (PCSF_STAGGER overrides)
     uint32_t stagger_first_blocks = 0;
 

@@ -46,6 +46,8 @@ struct PruneParams {
                                  // that several evaluations of the same block can run in one launch
     size_t n_wgs;
     int stagger_sleep;           // first-generation stagger of co-resident work-groups, x 1024 cycles (0 = off)
+    int prio_mode;               // experiment (PCSF_PRIO_MODE): 1 = the wave in the odd hardware slot of its SIMD runs at priority 0,
+                                 // the other at 3 (asymmetric: one work-group of a CU owns the matrix pipe, the other fills its gaps)
     uint32_t stagger_first_blocks;
     unsigned long long* stamps;  // diagnostic variant only: [2][n_ops][4] s_memtime values, else null
     uint32_t stamp_block;

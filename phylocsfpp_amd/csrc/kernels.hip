@@ -276,6 +276,20 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
         if (wave_slot & 1)
             for (int i = 0; i < p.stagger_sleep; ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles
     }
+    if (p.prio_mode != 0) {  // experiment: asymmetric instruction priority of the two waves that share a SIMD
+        const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID[3:0] = wave slot
+        const bool odd = (wave_slot & 1) != 0;
+        if (p.prio_mode == 1) {
+            if (odd) __builtin_amdgcn_s_setprio(0);
+            else __builtin_amdgcn_s_setprio(3);
+        } else if (p.prio_mode == 2) {
+            if (odd) __builtin_amdgcn_s_setprio(3);
+            else __builtin_amdgcn_s_setprio(0);
+        } else if (p.prio_mode == 3) {  // by work-group parity instead of the hardware slot
+            if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(0);
+            else __builtin_amdgcn_s_setprio(3);
+        }
+    }
     double lnz0 = 0.0, lnz1 = 0.0, anc0 = 0.0, anc1 = 0.0;
     const bool stamping = STAMP && p.stamps != nullptr && blockIdx.x == p.stamp_block && wave == 0;
     (void)stamping;

@@ -7,6 +7,8 @@ import phylocsfpp_amd as pa
 from phylocsfpp_amd import synth
 import oracle_binding as ob
 
+# A/B of experiment knobs: PCSF_PRIO_MODE, PCSF_STAGGER, PCSF_EXTRA_LDS are read at context creation
+
 model = sys.argv[1] if len(sys.argv) > 1 else "58mammals"
 n_sites = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 20
 variants = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 1]
