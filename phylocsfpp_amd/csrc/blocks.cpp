@@ -927,6 +927,12 @@ int debug_eigen_omega_impl(pcsf_ctx* c, const double* q_settings, const double* 
     gp.eig_basis = d_basis.as<double>();
     gp.prior_plain = d_prior.as<double>();  // state order; the lane-order copies are not wanted here
     gp.fail = d_fail.as<uint32_t>();
+    DeviceBuffer d_stamps;
+    const bool stamps = std::getenv("PCSF_EIGEN_STAMPS") != nullptr;  // diagnostics: where job 0's cycles go (tools/eigen_bench.py)
+    if (stamps) {
+        HIP_TRY(d_stamps.reserve(8 * sizeof(unsigned long long)));
+        gp.stamps = d_stamps.as<unsigned long long>();
+    }
     std::vector<EigenJob> jobs(n);
     for (int pass = warm_settings ? 0 : 1; pass < 2; ++pass) {
         const double* qs = pass == 0 ? warm_settings : q_settings;
@@ -938,8 +944,16 @@ int debug_eigen_omega_impl(pcsf_ctx* c, const double* q_settings, const double* 
             for (int k = 0; k < 12; ++k) jobs[i].qs[k] = qs[12 * i + k];
         }
         HIP_TRY(hipMemcpyAsync(d_jobs.ptr, jobs.data(), n * sizeof(EigenJob), hipMemcpyHostToDevice, c->stream));
+        if (stamps) HIP_TRY(hipMemsetAsync(d_stamps.ptr, 0, 8 * sizeof(unsigned long long), c->stream));
         HIP_TRY(launch_eigen_omega(gp, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));  // `jobs` is rewritten for the second pass
+        if (stamps) {
+            unsigned long long h[8];
+            HIP_TRY(hipMemcpy(h, d_stamps.ptr, sizeof h, hipMemcpyDeviceToHost));
+            const double st = static_cast<double>(std::max<unsigned long long>(h[4], 1));
+            fprintf(stderr, "eigen stamps (job 0, %s start; s_memtime cycles): %llu sweeps, %llu steps, kernel %llu; per step: phase A %.0f, phase B %.0f (wave 0 rotations %.0f, wave 1 V update %.0f)\n",
+                    pass == 0 ? "cold" : (warm_settings ? "warm" : "cold"), h[5], h[4], h[6], h[0] / st, h[3] / st, h[1] / st, h[2] / st);
+        }
     }
     std::vector<uint32_t> f(n);
     HIP_TRY(hipMemcpyAsync(right, d_r.ptr, n * 4096 * 8, hipMemcpyDeviceToHost, c->stream));

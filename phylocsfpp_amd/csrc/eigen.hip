@@ -23,6 +23,8 @@
 
 namespace pcsf {
 
+typedef double double2_loc __attribute__((ext_vector_type(2)));
+
 namespace {
 constexpr int LD = 65;  // padded row length: column walks hit 32 different banks
 
@@ -43,13 +45,27 @@ __device__ __forceinline__ double f3x4_weight(const double* qs, int codon)
 }
 }  // namespace
 
+__device__ __forceinline__ unsigned long long eig_clock()
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
 __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
 {
+    const bool stamping = p.stamps != nullptr && blockIdx.x == 0;
+    const unsigned long long t_kernel = stamping ? eig_clock() : 0ull;
+    unsigned long long acc_a = 0, acc_rot = 0, acc_v = 0, acc_b = 0, n_steps = 0, n_sweeps = 0;
     extern __shared__ __attribute__((aligned(16))) double lds_eig[];  // 2 x 64 x 65 doubles = 66,560 B
     double* A = lds_eig;
     double* V = lds_eig + 64 * LD;
-    __shared__ double pi[64], root[64], iroot[64], cs[64], sn[64], red[8];  // cs / sn / pp / qq: two steps' rotations
-    __shared__ int pp[64], qq[64];
+    // rot[buf][pair] = (cos, sin), pq[buf][pair] = p | q << 8: the rotations of two consecutive steps.  Packed, because the
+    // kernel is bound by the NUMBER of LDS instructions the CU's one LDS pipe can take (PMC: 136 per wave and step, 544 per
+    // step; a (p, q, c, s) look-up per pair as four reads was a third of them), not by bytes or bank conflicts.
+    __shared__ __attribute__((aligned(16))) double rot[2 * 32 * 2];
+    __shared__ double pi[64], root[64], iroot[64], red[8];
+    __shared__ int pq[64], pp[1];
     __shared__ double norm_s;
     __shared__ int flag;
 
@@ -184,10 +200,8 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
                 c = 1.0 / sqrt(1.0 + t * t);
                 s = t * c;
             }
-            cs[32 * buf + tid] = c;
-            sn[32 * buf + tid] = s;
-            pp[32 * buf + tid] = pi_;
-            qq[32 * buf + tid] = qi;
+            reinterpret_cast<double2_loc*>(rot)[32 * buf + tid] = double2_loc{c, s};
+            pq[32 * buf + tid] = pi_ | (qi << 8);
         }
     };
     for (int sweep = 0; sweep < 60; ++sweep) {
@@ -219,12 +233,12 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
         // step during which 224 of 256 threads waited; the arithmetic and its order per element are unchanged.
         rotations(0, 0);
         __syncthreads();
+        n_sweeps += 1;
         for (int step = 0; step < 63; ++step) {
+            const unsigned long long t0 = stamping ? eig_clock() : 0ull;
             const int cur = step & 1;
-            const int* __restrict__ ppc = pp + 32 * cur;
-            const int* __restrict__ qqc = qq + 32 * cur;
-            const double* __restrict__ csc = cs + 32 * cur;
-            const double* __restrict__ snc = sn + 32 * cur;
+            const int* __restrict__ pqc = pq + 32 * cur;
+            const double2_loc* __restrict__ rotc = reinterpret_cast<const double2_loc*>(rot) + 32 * cur;
             // (A) B <- J^T B J in ONE pass over 2x2 blocks: block (m, m') = rows {p,q} of pair m x columns {p',q'} of pair
             // m' is first rotated from the right by pair m', then from the left by pair m -- the same arithmetic as a
             // column pass followed by a row pass, with every entry read and written once.  All operands are read before
@@ -233,17 +247,21 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
             {
                 double b00[4], b01[4], b10[4], b11[4], cl[4], sl[4], cr[4], sr[4];
                 int pl[4], ql[4], pr[4], qr[4];
+                // a thread's four blocks share the column pair mr = tid & 31 and have row pairs (tid >> 5) + 8 i
+                const int mr = tid & 31, pq_r = pqc[mr];
+                const double2_loc rot_r = rotc[mr];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int blk = tid + 256 * i, m = blk >> 5, mr = blk & 31;
-                    pl[i] = ppc[m];
-                    ql[i] = qqc[m];
-                    cl[i] = csc[m];
-                    sl[i] = snc[m];
-                    pr[i] = ppc[mr];
-                    qr[i] = qqc[mr];
-                    cr[i] = csc[mr];
-                    sr[i] = snc[mr];
+                    const int m = (tid >> 5) + 8 * i, pq_l = pqc[m];
+                    const double2_loc rot_l = rotc[m];
+                    pl[i] = pq_l & 0xff;
+                    ql[i] = pq_l >> 8;
+                    cl[i] = rot_l.x;
+                    sl[i] = rot_l.y;
+                    pr[i] = pq_r & 0xff;
+                    qr[i] = pq_r >> 8;
+                    cr[i] = rot_r.x;
+                    sr[i] = rot_r.y;
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -269,9 +287,11 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
                 }
             }
             __syncthreads();
+            const unsigned long long t1 = stamping ? eig_clock() : 0ull;
             // (B) wave 0: rotations of the next step; waves 1..3: V <- V J, row `lane`, pairs wave-1, wave+2, ...
             if (wave == 0) {
                 if (step + 1 < 63) rotations(step + 1, cur ^ 1);
+                if (stamping) acc_rot += eig_clock() - t1;
             } else {
                 int pm[11], qm[11];
                 double cm[11], sm[11], vx[11], vy[11];
@@ -279,10 +299,12 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
                 for (int i = 0; i < 11; ++i) {
                     const int m = (wave - 1) + 3 * i;
                     const int mm = m < 32 ? m : 31;
-                    pm[i] = ppc[mm];
-                    qm[i] = qqc[mm];
-                    cm[i] = csc[mm];
-                    sm[i] = snc[mm];
+                    const int pq_m = pqc[mm];
+                    const double2_loc rot_m = rotc[mm];
+                    pm[i] = pq_m & 0xff;
+                    qm[i] = pq_m >> 8;
+                    cm[i] = rot_m.x;
+                    sm[i] = rot_m.y;
                     vx[i] = V[lane * LD + pm[i]];
                     vy[i] = V[lane * LD + qm[i]];
                 }
@@ -293,9 +315,27 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
                         V[lane * LD + qm[i]] = sm[i] * vx[i] + cm[i] * vy[i];
                     }
                 }
+                if (stamping) acc_v += eig_clock() - t1;
             }
             __syncthreads();
+            if (stamping) {
+                const unsigned long long t2 = eig_clock();
+                acc_a += t1 - t0;
+                acc_b += t2 - t1;
+                n_steps += 1;
+            }
         }
+    }
+    if (stamping) {
+        if (tid == 0) {
+            atomicAdd(p.stamps + 0, acc_a);
+            atomicAdd(p.stamps + 1, acc_rot);
+            atomicAdd(p.stamps + 3, acc_b);
+            atomicAdd(p.stamps + 4, n_steps);
+            atomicAdd(p.stamps + 5, n_sweeps);
+            atomicAdd(p.stamps + 6, eig_clock() - t_kernel);
+        }
+        if (tid == 64) atomicAdd(p.stamps + 2, acc_v);
     }
 
     // eigen-system of Q: right = D^-1/2 V (eigenvectors in columns), left = V^T D^1/2 (in rows)

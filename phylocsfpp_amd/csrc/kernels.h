@@ -156,6 +156,8 @@ struct EigenParams {
     double* anc_weight;   // [n_eig][64] ln(prior)*prior in lane order (may be null)
     double* prior_plain;  // optional [n_eig][64] prior in state order (diagnostics/tests)
     uint32_t* fail;       // [table]: set to 1 when pi has a non-positive entry
+    unsigned long long* stamps;  // diagnostics (may be null): job 0 adds its cycle counts -- [0] phase A (B <- J^T B J), [1] wave 0's
+                                 // rotations, [2] wave 1's V update, [3] phase B incl. its barrier, [4] steps, [5] sweeps, [6] whole kernel
 };
 
 hipError_t launch_eigen_omega(const EigenParams& p, hipStream_t stream);
