@@ -10,8 +10,10 @@
  * Parity status: PINNED against the reference's own golden outputs (tests/golden/, generated
  * by tests/golden/make_fixtures.py from /root/reference/test): the 7 raw/power wigs of the
  * build-tracks test and the FIXED/MLE .scores files of the score-msa test -- see
- * tests/test_oracle_golden.py.  The reference itself cannot be compiled in this image (GSL
- * and libBigWig are absent and un-vendored), so there is no oracle/_ref build.
+ * tests/test_oracle_golden.py.  The reference's likelihood core cannot be compiled in this image
+ * (GSL and libBigWig are absent and un-vendored); oracle/_ref holds only ref_harness, built from
+ * the reference's GSL-free headers (oracle/ref_harness.cpp: MAF reader, frames, branch-length
+ * score, trees, HMM), which pins the code either side of this restatement.
  *
  * GSL (un-pinned version, CMakeLists.txt:43) is replaced as follows:
  *   gsl_eigen_nonsymmv + complex LU inverse  -> cyclic Jacobi on the pi-symmetrised rate matrix

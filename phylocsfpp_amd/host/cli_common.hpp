@@ -129,6 +129,9 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
             for (int v = 0; v < model.n_nodes; ++v)
                 printf("%d\t%d\t%d\t%d\t%.17g\t%.9g\t%s\n", v, model.child1[v], model.child2[v], model.parent[v], model.branch_len_d[v],
                        static_cast<double>(model.branch_len[v]), model.label[v].c_str());
+            std::vector<std::pair<std::string, int>> names(model.name_to_leaf.begin(), model.name_to_leaf.end());
+            std::sort(names.begin(), names.end());
+            for (const auto& kv : names) printf("name\t%s\t%d\n", kv.first.c_str(), kv.second);  // row names a MAF may use -> leaf
         } catch (const std::exception& e) {
             fprintf(stderr, "error: %s\n", e.what());
             return 1;

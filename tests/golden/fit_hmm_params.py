@@ -11,7 +11,10 @@ model, and writes hmm_params_backsolved.json.
 Result (committed): rms 0.0065, max 0.10 log-odds units over the 174,648 values; an UNCONSTRAINED 4-state HMM
 (15 free parameters) fits no better (rms 0.00645) and the residual is a slow random walk along each run that
 does not correlate with the raw score, i.e. the goldens were smoothed from raw scores that differ by a few 1e-3
-from the golden raw tracks -- not from a different model.  HMM parity is therefore pinned only to that tolerance.
+from the golden raw tracks -- not from a different model.  Parity with these golden FILES is therefore pinned only to
+that tolerance; the smoothing pass and the estimation themselves are pinned byte for byte on the reference's own code
+(oracle/ref_harness.cpp, tests/test_reference_vectors.py), which turns the golden raw tracks + these parameters into
+exactly the bytes this repository's pass writes.
 
   python tests/golden/fit_hmm_params.py          # ~2 minutes
 """

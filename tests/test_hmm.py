@@ -1,6 +1,7 @@
 """CPU: the smoothing pass of build-tracks (host code, phylocsfpp_amd/host/hmm.hpp) against the plain-Python
 restatement in tests/hmm_oracle.py, and against the reference's smoothed golden tracks with the back-solved HMM
-parameters (tolerance only -- see tests/golden/fit_hmm_params.py for why they cannot be pinned exactly)."""
+parameters (tolerance only -- see tests/golden/fit_hmm_params.py for why they cannot be pinned exactly).
+The byte-for-byte pins on the reference's own smoothing / estimation code are in tests/test_reference_vectors.py."""
 import gzip
 import json
 import os

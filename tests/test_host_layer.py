@@ -24,6 +24,8 @@ def _dump(cli, path, blocks=False):
     rows = []
     for line in out.splitlines():
         f = line.split("\t")
+        if f[0] == "name":          # the row-name map follows the nodes
+            continue
         rows.append(dict(chrom=f[0], start=int(f[1]), length=int(f[2]), strand=f[3], chrom_len=int(f[4]), seqs=f[5:]))
     return rows
 
@@ -135,6 +137,8 @@ def _dump_model(cli, prefix, species=None, mapping=None):
     rows = []
     for line in out.splitlines():
         f = line.split("\t")
+        if f[0] == "name":          # the row-name map follows the nodes
+            continue
         rows.append((int(f[0]), int(f[1]), int(f[2]), int(f[3]), float(f[4]), f[6] if len(f) > 6 else ""))
     return rows
 
