@@ -52,21 +52,21 @@ def labels_of(prefix):
     return re.findall(r"[(,]([^(),:]+):", re.sub(r"\s+", "", open(prefix + ".nh").read()))
 
 
-def corner_maf(rng, labels, concat):
+def corner_maf(rng, labels, concat, blocks=220, cols_max=30, skip_prob=0.25, absent_prob=0.7, start=999_400, chrom_len=2_500_000, ref_only_prob=0.0):
     """Short blocks around the 1 Mb break point with everything the reader has a branch for: contiguous and skipping
     blocks, a second chromosome, reference-gap columns, missing rows, rows of species the model does not know, i/e/q
     lines and comments, lower case, N and '.', and (block mode only) reference rows on the '-' strand."""
     out = ["##maf version=1 scoring=corner", "# a comment"]
-    chrom, pos, chrom_len = "chrA", 999_400, 2_500_000
+    chrom, pos = "chrA", start
     alphabet = np.frombuffer(b"ACGTacgtNn-.", dtype=np.uint8)
     prob = np.array([.2, .2, .2, .2, .03, .03, .03, .03, .01, .01, .05, .01])
     prob /= prob.sum()
-    for b in range(220):
-        if b == 170:
+    for b in range(blocks):
+        if b == blocks - 50:
             chrom, pos = "chrB", 1_999_700 + int(rng.integers(0, 60))   # ... and the 2 Mb one on another chromosome
-        elif rng.random() < 0.25 and not (999_800 < pos % 1_000_000 or pos % 1_000_000 < 200):   # contiguous across the break points
+        elif rng.random() < skip_prob and not (999_800 < pos % 1_000_000 or pos % 1_000_000 < 200):   # contiguous across the break points
             pos += int(rng.integers(1, 40))                  # not contiguous: a new alignment starts
-        cols = int(rng.integers(1, 30))
+        cols = int(rng.integers(1, cols_max))
         refrow = rng.choice(np.frombuffer(b"ACGTacgtNn", dtype=np.uint8), size=cols, p=[.22, .22, .22, .22, .02, .02, .02, .02, .02, .02])
         if cols > 3 and rng.random() < 0.5:
             refrow[rng.integers(0, cols, size=int(rng.integers(1, 4)))] = ord("-")
@@ -79,7 +79,7 @@ def corner_maf(rng, labels, concat):
         start = pos if strand == "+" else chrom_len - (pos + size)
         out.append("s %s.%s %d %d %s %d %s" % (labels[0], chrom, start, size, strand, chrom_len, refrow.tobytes().decode()))
         for l in range(1, len(labels)):
-            if rng.random() < 0.7:
+            if rng.random() < absent_prob or (ref_only_prob and b % 7 == 3 and rng.random() < ref_only_prob):
                 continue
             row = rng.choice(alphabet, size=cols, p=prob).tobytes().decode()
             name = labels[l] if rng.random() < 0.9 else labels[l].upper()
