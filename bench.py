@@ -128,6 +128,9 @@ SECONDS_RE = re.compile(r"seconds: total ([\d.]+); .*MAF read ([\d.]+), BLS ([\d
                         r"wig output ([\d.]+) \| smoothing ([\d.]+)")
 
 
+STARTUP_RE = re.compile(r"start-up seconds: options \+ model files ([\d.]+), first scoring context ([\d.]+)")
+
+
 def run_cli(binary, maf, out_dir, extra_args=(), env=None):
     """One build-tracks run in a child process; returns the driver's own statistics and the process wall time."""
     os.makedirs(out_dir, exist_ok=True)
@@ -142,6 +145,7 @@ def run_cli(binary, maf, out_dir, extra_args=(), env=None):
         raise RuntimeError("cannot parse the statistics of %s: %s" % (binary, p.stderr[-2000:]))
     return {"alignments": int(a.group(1)), "ref_bases": int(a.group(2)), "codon_frames": int(a.group(3)), "backend_calls": int(a.group(4)),
             "seconds": float(s.group(1)), "process_wall_seconds": wall,
+            "startup_seconds": (lambda u: float(u.group(1)) + float(u.group(2)) if u else None)(STARTUP_RE.search(p.stderr)),
             "stage_busy": {"maf_read": float(s.group(2)), "bls": float(s.group(3)), "batch_packing": float(s.group(4)),
                            "scoring_backend": float(s.group(5)), "wig_output": float(s.group(6)), "smoothing": float(s.group(7))}}
 
@@ -195,13 +199,16 @@ def end_to_end(device, runs, cpu_rate_all_cores, work_dir):
            "seconds": best["seconds"], "seconds_all_runs": [r["seconds"] for r in gpu_runs],
            "process_wall_seconds": min(r["process_wall_seconds"] for r in gpu_runs),
            "process_wall_seconds_all_runs": [r["process_wall_seconds"] for r in gpu_runs],
+           "startup_seconds_all_runs": [r["startup_seconds"] for r in gpu_runs],
            "codon_frames_per_s": best["codon_frames"] / best["seconds"],
            "codon_frames_per_s_process_wall": best["codon_frames"] / min(r["process_wall_seconds"] for r in gpu_runs),
            "maf_gigabytes_per_s": info["bytes"] / best["seconds"] / 1e9,
            "stage_busy": best["stage_busy"],
            "note": "seconds = build_tracks() inside the child process (file mapped, parsed, scored, seven wig files written); "
-                   "process_wall_seconds adds process start, HIP initialisation, model and backend set-up (branch matrices, device "
-                   "scratch, first kernel launches, page-locked buffers of the first windows)"}
+                   "process_wall_seconds adds process start, HIP initialisation, model and backend set-up (startup_seconds: model "
+                   "files + the first scoring context, i.e. HIP runtime, code object, branch matrices) and the tear-down of the HIP "
+                   "runtime at exit; a HIP process that only creates a context and exits takes 0.28 s on this box "
+                   "(profiles/r02/startup_profile.txt)"}
     # CPU driver on the same file, or on a prefix sized for ~20 s when the whole file would take longer than ~30 s
     env = dict(os.environ, PCSF_THREADS=str(cpus), OMP_NUM_THREADS=str(cpus))
     est = best["codon_frames"] / max(cpu_rate_all_cores, 1.0)

@@ -4,8 +4,11 @@
 // for the options that reach the scoring path; options must precede the positionals.
 #pragma once
 
+#include <sys/stat.h>
+
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <functional>
 #include <limits>
 #include <memory>
@@ -44,6 +47,8 @@ using BackendFactory = std::function<std::unique_ptr<ScoringBackend>(const Model
 
 inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
 {
+    const auto t_main = std::chrono::steady_clock::now();
+    auto since_main = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main).count(); };
     if (argc < 2) return usage(argv[0]);
     const std::string cmd = argv[1];
     if (cmd == "selftest-format") {  // tests: format_trimmed<3|4> against snprintf-based print_trimmed on n random floats
@@ -275,19 +280,35 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
             }
         }
         const Model model = load_model(prefix, aliases, species, mapping);
+        const double t_model = since_main();
         if (!species.empty()) fprintf(stderr, "model reduced to %d species\n", model.n_leaves);
         std::vector<std::unique_ptr<ScoringBackend>> owned;
         std::vector<ScoringBackend*> backends;
-        for (int d : devices) {
-            owned.push_back(make_backend(model, d));
+        // build-tracks: a second context on the same GPU puts the transfers of one call under the kernels of the other (2-4 % on long
+        // runs).  Its set-up costs 0.1-0.2 s, so it is only made for inputs of a gigabyte or more, and on a thread of its own: the
+        // first context starts on the first window meanwhile (profiles/r02/startup_profile.txt).
+        uint64_t input_total = 0;
+        for (int j = i; j < argc; ++j) {
+            struct stat sb;
+            if (stat(argv[j], &sb) == 0) input_total += static_cast<uint64_t>(sb.st_size);
+        }
+        for (size_t k = 0; k < devices.size(); ++k) {
+            const int d = devices[k];
+            if (k == 0) owned.push_back(make_backend(model, d));   // owns the staging memory: needed at once
+            else owned.push_back(std::unique_ptr<ScoringBackend>(new DeferredBackend([&model, &make_backend, d] { return make_backend(model, d); },
+                                                                                     owned[0]->device_bls(), owned[0]->contexts_per_device())));
             backends.push_back(owned.back().get());
-            // build-tracks: a second context on the same GPU puts the transfers of one call under the kernels of the other
-            const int per = cmd == "build-tracks" ? (contexts_per_device > 0 ? contexts_per_device : owned.back()->contexts_per_device()) : 1;
-            for (int k = 1; k < per; ++k) {
-                owned.push_back(make_backend(model, d));
+            const int wanted = contexts_per_device > 0 ? contexts_per_device : (input_total >= (uint64_t(1) << 30) ? owned[0]->contexts_per_device() : 1);
+            const int per = cmd == "build-tracks" ? wanted : 1;
+            for (int c = 1; c < per; ++c) {
+                owned.push_back(std::unique_ptr<ScoringBackend>(new DeferredBackend([&model, &make_backend, d] { return make_backend(model, d); },
+                                                                                     owned[0]->device_bls(), owned[0]->contexts_per_device())));
                 backends.push_back(owned.back().get());
             }
         }
+        // start-up, before any input is read: the first context pays for the HIP runtime and the code object
+        fprintf(stderr, "start-up seconds: options + model files %.3f, first scoring context %.3f (%zu more being set up beside the run)\n", t_model,
+                since_main() - t_model, backends.size() - 1);
         bool first = true;
         for (; i < argc; ++i) {
             if (cmd == "build-tracks") {

@@ -20,6 +20,7 @@
 #include <cstring>
 #include <deque>
 #include <exception>
+#include <functional>
 #include <future>
 #include <memory>
 #include <mutex>
@@ -67,6 +68,8 @@ struct ScoringBackend {
     // first call would otherwise pay for (the HIP backend: device scratch, kernel code loading).  Called on a thread of
     // its own while the first window is parsed; the backend's first batch waits for it.
     virtual void prepare_tracks(size_t /*max_columns*/) {}
+    // false while a backend is still being set up (DeferredBackend): build-tracks deals its batches to the others meanwhile
+    virtual bool ready() const { return true; }
     virtual size_t score_alignments_6frames(int n_leaves, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0,
                                             const std::vector<uint32_t>& len, const std::vector<uint64_t>& start_pos,
                                             const std::vector<uint64_t>& chrom_len, double* out, size_t out_capacity, std::vector<uint64_t>& offsets,
@@ -101,6 +104,48 @@ struct ScoringBackend {
             for (int f = 3; f < 6; ++f) std::reverse(out + offsets[k * 6 + f], out + offsets[k * 6 + f] + n_codons[k * 6 + f]);
         return total;
     }
+};
+
+// A backend whose construction runs on a thread of its own (a second scoring context costs 0.1-0.2 s of HIP set-up that a
+// short run should not wait for): calls block until it exists, ready() tells the dealer not to wait.
+class DeferredBackend : public ScoringBackend {
+public:
+    DeferredBackend(std::function<std::unique_ptr<ScoringBackend>()> make, bool device_bls, int contexts_per_device)
+        : made_(std::async(std::launch::async, std::move(make)).share()), device_bls_(device_bls), contexts_(contexts_per_device) {}
+    ~DeferredBackend() override
+    {
+        try {
+            made_.wait();
+        } catch (...) {
+        }
+    }
+    bool ready() const override { return made_.wait_for(std::chrono::seconds(0)) == std::future_status::ready; }
+    bool device_bls() const override { return device_bls_; }  // the same model on the same kind of device as the first backend
+    int contexts_per_device() const override { return contexts_; }
+    char* staging_alloc(size_t bytes) override { return get().staging_alloc(bytes); }
+    void staging_free(char* p) override { get().staging_free(p); }
+    void prepare_tracks(size_t max_columns) override { get().prepare_tracks(max_columns); }
+    void score_sites_fixed(const uint8_t* codons, size_t n_sites, size_t leaf_stride, double* out) override
+    {
+        get().score_sites_fixed(codons, n_sites, leaf_stride, out);
+    }
+    void score_blocks(int algo, const uint8_t* codons, const uint64_t* offsets, size_t n_blocks, size_t leaf_stride, bool compute_anc, uint32_t seed,
+                      float* phylo, float* anc) override
+    {
+        get().score_blocks(algo, codons, offsets, n_blocks, leaf_stride, compute_anc, seed, phylo, anc);
+    }
+    size_t score_alignments_6frames(int n_leaves, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0, const std::vector<uint32_t>& len,
+                                    const std::vector<uint64_t>& start_pos, const std::vector<uint64_t>& chrom_len, double* out, size_t out_capacity,
+                                    std::vector<uint64_t>& offsets, std::vector<uint32_t>& n_codons, double* bls_out) override
+    {
+        return get().score_alignments_6frames(n_leaves, nucl, row_stride, col0, len, start_pos, chrom_len, out, out_capacity, offsets, n_codons, bls_out);
+    }
+
+private:
+    ScoringBackend& get() const { return *made_.get(); }   // rethrows what the construction threw
+    std::shared_future<std::unique_ptr<ScoringBackend>> made_;
+    bool device_bls_;
+    int contexts_;
 };
 
 struct BuildTracksParams {
@@ -535,7 +580,7 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     InFlight writing;
     std::future<double> writer;  // seconds the writers of `writing` took
     const size_t n_dev = backends.size();
-    std::vector<std::shared_future<double>> dev_last(n_dev);
+    std::vector<std::shared_future<double>> dev_last(n_dev), dev_prepared(n_dev);
     size_t next_dev = 0;
     auto finish_writer = [&]() {
         if (!writer.valid()) return;
@@ -569,7 +614,17 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         });
     };
     auto submit = [&](Batch& bt, WindowSlot* ws) {
-        const size_t d = next_dev++ % n_dev;
+        // round robin over the backends that exist (one still being set up -- DeferredBackend -- and its prepare_tracks are skipped)
+        size_t d = next_dev % n_dev;
+        for (size_t k = 0; k < n_dev; ++k) {
+            const size_t cand = (next_dev + k) % n_dev;
+            const bool set_up = backends[cand]->ready() && (!dev_prepared[cand].valid() || dev_prepared[cand].wait_for(std::chrono::seconds(0)) == std::future_status::ready);
+            if (set_up || cand == 0) {
+                d = cand;
+                break;
+            }
+        }
+        next_dev = d + 1;
         const std::shared_future<double> prev = dev_last[d];
         std::shared_future<double> task = std::async(std::launch::async, [&, b = &bt, d, prev]() -> double {
             if (prev.valid()) prev.wait();
@@ -599,10 +654,10 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     if (input_bytes > 0) next = std::async(std::launch::async, prepare_window, size_t(0));
     if (need_raw)
         for (size_t d = 0; d < n_dev; ++d)
-            dev_last[d] = std::async(std::launch::async, [&, d]() -> double {
-                           backends[d]->prepare_tracks(std::min<size_t>(cap, std::max<size_t>(window / 64, 4096)));
-                           return 0.0;
-                       }).share();
+            dev_prepared[d] = dev_last[d] = std::async(std::launch::async, [&, d]() -> double {
+                                  backends[d]->prepare_tracks(std::min<size_t>(cap, std::max<size_t>(window / 64, 4096)));
+                                  return 0.0;
+                              }).share();
     try {
     for (size_t wi = 0; wi + 1 < window_begin.size(); ++wi) {
         std::unique_ptr<PreparedWindow> pw = next.get();
