@@ -196,6 +196,10 @@ int pcsf_block_loglik_eig(pcsf_ctx *ctx, const double *right, const double *left
  * warm_settings (may be NULL): [n][12] settings whose eigenbasis the iteration starts from, as OMEGA does for its probes. */
 int pcsf_debug_eigen_omega(pcsf_ctx *ctx, const double *q_settings, const double *warm_settings, size_t n, double *right,
                            double *left, double *lambda, double *prior, int32_t *failed);
+/* host-only (works without a GPU): the pair schedule of the eigen-solver kernel (csrc/eigen.hip, register-resident variant) --
+ * pairs[63][32][2]: the index pairs every step of one sweep rotates; located[15][16]: where each group of four indices
+ * sits in each round (super-group | half << 3).  For tests/test_schedule.py: every pair exactly once, disjoint per step. */
+void pcsf_debug_eigen_schedule(int32_t *pairs, int32_t *located);
 /* milliseconds spent in the pruning kernel by the last *_fixed / *_fixed_dev call that was
  * timed; pcsf_set_timing(ctx,1) brackets each launch with HIP events ON THE LAUNCH STREAM. */
 int pcsf_set_timing(pcsf_ctx *ctx, int enable);

@@ -422,6 +422,11 @@ int pcsf_debug_stamps(pcsf_ctx* c, int block, unsigned long long* out, int cap)
 
 // diagnostics: the leaf-major codon matrix of the last six-frame call ([n_leaves][n_sites]; the separate extract kernel's, or,
 // with PCSF_DUMP_CODONS=1, what the fused front end formed)
+void pcsf_debug_eigen_schedule(int32_t* pairs, int32_t* located)
+{
+    pcsf::eigen_schedule_for_tests(pairs, located);
+}
+
 int pcsf_debug_codon_matrix(pcsf_ctx* c, uint8_t* out, size_t capacity, size_t* n_sites)
 {
     if (!c || !out || !n_sites) return PCSF_ERR_INVALID_ARG;

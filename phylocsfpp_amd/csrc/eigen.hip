@@ -18,6 +18,8 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -52,6 +54,48 @@ __device__ __forceinline__ unsigned long long eig_clock()
     return t;
 }
 
+// ---- register-resident variant (REG): the pair schedule and its bookkeeping -----------------------------------------------------
+// The 64 indices form 16 groups of four; a ROUND puts two groups into each of eight super-groups (round-robin tournament of the
+// groups, group 15 fixed), and wave 0's thread (R, C) keeps the 8x8 block rows(super-group R) x columns(super-group C) of B in 64
+// registers, wave 1's thread the block rows 8R..8R+7 x columns(super-group C) of V.  Within a round every rotation pair lies inside
+// one super-group, so B <- J^T B J and V <- V J touch registers only: four "cross" steps pair slot i of the first group with slot
+// (i + t) & 3 of the second; round 0 adds three steps for the pairs inside the groups.  15 rounds = 63 steps = all 2,016 pairs once
+// (tests/test_schedule.py checks the cover).  Between rounds the blocks pass through LDS once (lane-major, conflict-free writes).
+namespace rr {
+__host__ __device__ __forceinline__ constexpr int pair_a(int pat, int k)
+{
+    // patterns 0..2: inside the groups {0..3} and {4..7}; 3..6: cross, t = pat - 3
+    return pat == 0 ? 2 * k : pat == 1 ? (k < 2 ? k : k + 2) : pat == 2 ? (k == 0 ? 0 : k == 1 ? 1 : k == 2 ? 4 : 5) : k;
+}
+__host__ __device__ __forceinline__ constexpr int pair_b(int pat, int k)
+{
+    return pat == 0 ? 2 * k + 1 : pat == 1 ? (k < 2 ? k + 2 : k + 4) : pat == 2 ? (k == 0 ? 3 : k == 1 ? 2 : k == 2 ? 7 : 6) : 4 + ((k + (pat - 3)) & 3);
+}
+// the two groups of super-group G in round r
+__host__ __device__ __forceinline__ int group_of(int r, int G, int half)
+{
+    if (G == 0) return half ? 15 : r;
+    const int g = half ? r + 15 - G : r + G;
+    return g >= 15 ? g - 15 : g;
+}
+// where group g sits in round r: super-group | half << 3
+__host__ __device__ __forceinline__ int locate(int r, int g)
+{
+    if (g == 15) return 0 | (1 << 3);
+    int d = g - r;
+    if (d < 0) d += 15;
+    if (d == 0) return 0;
+    return d <= 7 ? d : ((15 - d) | (1 << 3));
+}
+// Regrouping between two rounds is the SAME permutation every time (every group moves one seat round the table): the half
+// `half` of super-group G takes over from super-group | half << 3
+__host__ __device__ __forceinline__ constexpr int shift_source(int G, int half)
+{
+    return half == 0 ? (G <= 6 ? (G + 1) : (7 | (1 << 3))) : (G == 0 ? (0 | (1 << 3)) : G == 1 ? 0 : ((G - 1) | (1 << 3)));
+}
+}  // namespace rr
+
+template <bool REG>
 __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
 {
     const bool stamping = p.stamps != nullptr && blockIdx.x == 0;
@@ -180,6 +224,7 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
         }
         __syncthreads();
     }
+    if constexpr (!REG) {
     // rotations of one step into buffer `buf`: tournament pairing of 0..63 (63 stays, the others rotate), lanes 0..31 of wave 0
     auto rotations = [&](int step, int buf) {
         if (tid < 32) {
@@ -326,6 +371,279 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
             }
         }
     }
+    } else {
+    // ================= register-resident sweeps: wave 0 owns B, wave 1 owns V, waves 2-3 only keep the barriers ==================
+    double2_loc* rt = reinterpret_cast<double2_loc*>(rot);   // [buf][super-group * 4 + pair] = (cos, sin)
+    __shared__ __attribute__((aligned(16))) double dg[32 * 4];  // [super-group * 4 + pair] = B[a][a], B[b][b], B[a][b] of the next step's pairs
+    const int R = lane >> 3, C = lane & 7;
+    // One rotation from (B[a][a], B[b][b], B[a][b]).  The same t = sgn(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (B[b][b] - B[a][a]) / (2 B[a][b]),
+    // as the `rotations` lambda above, written as t = 2g sgn(d) / (|d| + sqrt(d^2 + 4 g^2)) on operands scaled by a power of two (no
+    // overflow / underflow branch) and turned into cos / sin with two reciprocal square roots (hardware seed + three Newton steps)
+    // instead of three IEEE divisions and two square roots: this chain sits between two B updates, nothing can hide it.
+    // c^2 + s^2 = (w^2 + h^2) / (2 r w) = 1 to an ulp.
+    auto rsqrt_nr = [](double x) {
+        double y = __builtin_amdgcn_rsq(x);
+        const double hx = 0.5 * x;
+#pragma unroll
+        for (int it = 0; it < 3; ++it) y = y * __builtin_fma(-hx, y * y, 1.5);
+        return y;
+    };
+    auto rotation_of = [&](double aa, double bb, double g) {
+        double c = 1.0, sn = 0.0;
+        if (!(fabs(g) < 1e-290)) {
+            double d = bb - aa, h = 2.0 * g;
+            const int eh = __builtin_amdgcn_frexp_exp(h), ed = __builtin_amdgcn_frexp_exp(d);
+            const int e = (d == 0.0 || eh > ed) ? eh : ed;   // frexp_exp(0) = 0 must not win; h != 0 here
+            d = __builtin_amdgcn_ldexp(d, -e);
+            h = __builtin_amdgcn_ldexp(h, -e);
+            // r = sqrt(d^2 + h^2), w = r + |d|:  cos = w / sqrt(2 r w), sin = sgn(d) h / sqrt(2 r w)   (tan = sgn(d) h / w as above)
+            const double x = __builtin_fma(d, d, h * h);            // in [1/4, 2)
+            const double w = __builtin_fma(x, rsqrt_nr(x), fabs(d));
+            const double q = rsqrt_nr(2.0 * (w - fabs(d)) * w);
+            c = w * q;
+            sn = copysign(h, d * h) * q;   // sgn(d) h; d = +-0 rotates by 45 degrees like sgn(zeta) = +1
+        }
+        return double2_loc{c, sn};
+    };
+    if (wave == 0) {
+        double b[8][8];
+        double* stage = A;   // 64 elements x 64 lanes once the block is in registers
+        {   // round 0 blocks from the canonical matrix
+            int rb[2], cb[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                rb[h] = 4 * rr::group_of(0, R, h);
+                cb[h] = 4 * rr::group_of(0, C, h);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[i][j] = A[(rb[i >> 2] + (i & 3)) * LD + cb[j >> 2] + (j & 3)];
+        }
+        const bool diag = R == C;
+        int base[2][2];   // where the four 4x4 quarters of the next round's block sit in the staged blocks of this round (16-byte items)
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const int lr = rr::shift_source(R, x), lc = rr::shift_source(C, y);
+                base[x][y] = 1024 * (lr >> 3) + 128 * (lc >> 3) + 8 * (lr & 7) + (lc & 7);
+            }
+        auto regroup = [&]() {   // element pairs (i, 2jp), (i, 2jp+1) as one 16-byte item, lane-major: no bank conflicts
+            double2_loc* st2 = reinterpret_cast<double2_loc*>(stage);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) st2[(i * 4 + jp) * 64 + lane] = double2_loc{b[i][2 * jp], b[i][2 * jp + 1]};
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) {
+                    const double2_loc e = st2[base[i >> 2][jp >> 1] + 256 * (i & 3) + 64 * (jp & 1)];
+                    b[i][2 * jp] = e.x;
+                    b[i][2 * jp + 1] = e.y;
+                }
+        };
+        // parameters of the step with pattern PAT into buffer `buf`: diagonal blocks publish their pairs, lanes 0..31 rotate
+        auto publish = [&](auto pat_tag, int buf) {
+            constexpr int PAT = decltype(pat_tag)::value;
+            if (diag) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int a = rr::pair_a(PAT, k), bq = rr::pair_b(PAT, k);
+                    *reinterpret_cast<double2_loc*>(&dg[(R * 4 + k) * 4]) = double2_loc{b[a][a], b[bq][bq]};
+                    dg[(R * 4 + k) * 4 + 2] = b[a][bq];
+                }
+            }
+            if (lane < 32) {
+                const double2_loc ab = *reinterpret_cast<const double2_loc*>(&dg[lane * 4]);
+                rt[32 * buf + lane] = rotation_of(ab.x, ab.y, dg[lane * 4 + 2]);
+            }
+        };
+        auto b_step = [&](auto pat_tag, int buf) {
+            constexpr int PAT = decltype(pat_tag)::value;
+            double cl[4], sl[4], cr[4], sr[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double2_loc l = rt[32 * buf + R * 4 + k], r2 = rt[32 * buf + C * 4 + k];
+                cl[k] = l.x;
+                sl[k] = l.y;
+                cr[k] = r2.x;
+                sr[k] = r2.y;
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int a = rr::pair_a(PAT, m), bq = rr::pair_b(PAT, m), a2 = rr::pair_a(PAT, n), b2 = rr::pair_b(PAT, n);
+                    const double b00 = b[a][a2], b01 = b[a][b2], b10 = b[bq][a2], b11 = b[bq][b2];
+                    // columns (right rotation of pair n), then rows (left rotation of pair m)
+                    const double t1 = __builtin_fma(cr[n], b00, -(sr[n] * b01)), t2 = __builtin_fma(sr[n], b00, cr[n] * b01);
+                    const double u1 = __builtin_fma(cr[n], b10, -(sr[n] * b11)), u2 = __builtin_fma(sr[n], b10, cr[n] * b11);
+                    b[a][a2] = __builtin_fma(cl[m], t1, -(sl[m] * u1));
+                    b[a][b2] = __builtin_fma(cl[m], t2, -(sl[m] * u2));
+                    b[bq][a2] = __builtin_fma(sl[m], t1, cl[m] * u1);
+                    b[bq][b2] = __builtin_fma(sl[m], t2, cl[m] * u2);
+                }
+            if (diag) {   // the rotated pairs themselves: annihilated (or already below 1e-290)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int a = rr::pair_a(PAT, k), bq = rr::pair_b(PAT, k);
+                    b[a][bq] = 0.0;
+                    b[bq][a] = 0.0;
+                }
+            }
+        };
+        publish(std::integral_constant<int, 0>{}, 0);
+        int buf = 0;
+        // diagnostics (PCSF_EIGEN_STAMPS): cycles in the B update, in publishing the next rotations, in the regrouping, at the barrier
+        auto timed_step = [&](auto pat, auto next_pat, int regroup_from, int regroup_to) {
+            const unsigned long long t0 = stamping ? eig_clock() : 0ull;
+            b_step(pat, buf);
+            const unsigned long long t1 = stamping ? eig_clock() : 0ull;
+            if (regroup_from >= 0) regroup();
+            const unsigned long long t2 = stamping ? eig_clock() : 0ull;
+            publish(next_pat, buf ^ 1);
+            const unsigned long long t3 = stamping ? eig_clock() : 0ull;
+            buf ^= 1;
+            __syncthreads();
+            if (stamping) {
+                acc_a += t1 - t0;
+                acc_v += t2 - t1;
+                acc_rot += t3 - t2;
+                acc_b += eig_clock() - t3;
+            }
+        };
+        for (int sweep = 0; sweep < 60; ++sweep) {
+            double off = 0.0, total = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double x = b[i][j] * b[i][j];
+                    if (i == j) {
+                        total += diag ? x : 0.0;
+                        off += diag ? 0.0 : x;
+                    } else {
+                        off += x;
+                    }
+                }
+            for (int sft = 32; sft > 0; sft >>= 1) {
+                off += __shfl_xor(off, sft);
+                total += __shfl_xor(total, sft);
+            }
+            if (lane == 0) flag = (off <= 1e-58 * total) ? 2 : 0;
+            __syncthreads();
+            if (off <= 1e-58 * total) break;
+            n_sweeps += 1;
+            for (int r = 0; r < 15; ++r) {
+                using std::integral_constant;
+                if (r == 0) {
+                    timed_step(integral_constant<int, 0>{}, integral_constant<int, 1>{}, -1, 0);
+                    timed_step(integral_constant<int, 1>{}, integral_constant<int, 2>{}, -1, 0);
+                    timed_step(integral_constant<int, 2>{}, integral_constant<int, 3>{}, -1, 0);
+                }
+                timed_step(integral_constant<int, 3>{}, integral_constant<int, 4>{}, -1, 0);
+                timed_step(integral_constant<int, 4>{}, integral_constant<int, 5>{}, -1, 0);
+                timed_step(integral_constant<int, 5>{}, integral_constant<int, 6>{}, -1, 0);
+                if (r == 14) timed_step(integral_constant<int, 6>{}, integral_constant<int, 0>{}, 14, 0);
+                else timed_step(integral_constant<int, 6>{}, integral_constant<int, 3>{}, r, r + 1);
+                n_steps += r == 0 ? 7 : 4;
+            }
+        }
+        // eigenvalues into the canonical matrix (round-0 grouping again)
+        if (diag) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = 4 * rr::group_of(0, R, i >> 2) + (i & 3);
+                A[row * LD + row] = b[i][i];
+            }
+        }
+    } else if (wave == 1) {
+        // V <- V J: lane = row of V, all 64 entries of the row in registers in SEAT order (seat 8G + s = slot s of super-group G), so
+        // every rotation is lane-local, the step patterns are static register pairs, and regrouping is a static register shift.
+        double v[64];
+#pragma unroll
+        for (int G = 0; G < 8; ++G)
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) v[8 * G + sl] = V[lane * LD + 4 * rr::group_of(0, G, sl >> 2) + (sl & 3)];
+        auto v_step = [&](auto pat_tag, int buf) {
+            constexpr int PAT = decltype(pat_tag)::value;
+#pragma unroll
+            for (int G = 0; G < 8; ++G)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double2_loc r2 = rt[32 * buf + G * 4 + k];   // the same address in every lane: a broadcast
+                    const int a = 8 * G + rr::pair_a(PAT, k), bq = 8 * G + rr::pair_b(PAT, k);
+                    const double x = v[a], y = v[bq];
+                    v[a] = __builtin_fma(r2.x, x, -(r2.y * y));
+                    v[bq] = __builtin_fma(r2.y, x, r2.x * y);
+                }
+        };
+        // the 15 moving groups form one cycle (0,0) <- (1,0) <- ... <- (7,0) <- (7,1) <- (6,1) <- ... <- (1,1) <- (0,0): walk it in place
+        auto shift = [&]() {
+            double keep[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) keep[q] = v[q];
+            int G = 0, half = 0;
+#pragma unroll
+            for (int n = 0; n < 14; ++n) {
+                const int src = rr::shift_source(G, half), sG = src & 7, sh = src >> 3;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[8 * G + 4 * half + q] = v[8 * sG + 4 * sh + q];
+                G = sG;
+                half = sh;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[8 * 1 + 4 * 1 + q] = keep[q];   // (1,1) takes over from (0,0)
+        };
+        int buf = 0;
+        for (int sweep = 0; sweep < 60; ++sweep) {
+            __syncthreads();
+            if (flag == 2) break;
+            for (int r = 0; r < 15; ++r) {
+                if (r == 0) {
+                    v_step(std::integral_constant<int, 0>{}, buf);
+                    buf ^= 1;
+                    __syncthreads();
+                    v_step(std::integral_constant<int, 1>{}, buf);
+                    buf ^= 1;
+                    __syncthreads();
+                    v_step(std::integral_constant<int, 2>{}, buf);
+                    buf ^= 1;
+                    __syncthreads();
+                }
+                v_step(std::integral_constant<int, 3>{}, buf);
+                buf ^= 1;
+                __syncthreads();
+                v_step(std::integral_constant<int, 4>{}, buf);
+                buf ^= 1;
+                __syncthreads();
+                v_step(std::integral_constant<int, 5>{}, buf);
+                buf ^= 1;
+                __syncthreads();
+                v_step(std::integral_constant<int, 6>{}, buf);
+                shift();
+                buf ^= 1;
+                __syncthreads();
+            }
+        }
+        // eigenvectors back into the canonical matrix (a sweep ends in the seating of round 0)
+#pragma unroll
+        for (int G = 0; G < 8; ++G)
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) V[lane * LD + 4 * rr::group_of(0, G, sl >> 2) + (sl & 3)] = v[8 * G + sl];
+    } else {
+        for (int sweep = 0; sweep < 60; ++sweep) {
+            __syncthreads();
+            if (flag == 2) break;
+            for (int st = 0; st < 63; ++st) __syncthreads();
+        }
+    }
+    __syncthreads();
+    }
     if (stamping) {
         if (tid == 0) {
             atomicAdd(p.stamps + 0, acc_a);
@@ -335,7 +653,7 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
             atomicAdd(p.stamps + 5, n_sweeps);
             atomicAdd(p.stamps + 6, eig_clock() - t_kernel);
         }
-        if (tid == 64) atomicAdd(p.stamps + 2, acc_v);
+        if (tid == (REG ? 0 : 64)) atomicAdd(p.stamps + 2, acc_v);
     }
 
     // eigen-system of Q: right = D^-1/2 V (eigenvectors in columns), left = V^T D^1/2 (in rows)
@@ -380,12 +698,43 @@ hipError_t launch_eigen_omega(const EigenParams& p, hipStream_t stream)
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     if (!(attr_set.load(std::memory_order_acquire) >> (dev & 63) & 1)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eigen_omega_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eigen_omega_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eigen_omega_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
         attr_set.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
     }
-    hipLaunchKernelGGL(eigen_omega_kernel, dim3(p.n_jobs), dim3(256), lds, stream, p);
+    // Two forms of the same iteration.  Blocks in registers (wave 0: B, wave 1: V; 374 registers, one work-group per CU): 0.69 ms per
+    // cold launch against 0.98 ms, the better one while a launch has at most one job per CU -- a round of OMEGA over a few hundred
+    // blocks.  Matrices in LDS (four waves, two work-groups per CU): better throughput once the jobs outnumber the CUs (2,064 blocks:
+    // 0.99 s against 1.04 s).  PCSF_EIGEN_LDS=1 / 0 forces one of them (tests run both).
+    static const int forced = [] { const char* e = getenv("PCSF_EIGEN_LDS"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    static std::atomic<int> cus[64];
+    int n_cu = cus[dev & 63].load(std::memory_order_relaxed);
+    if (n_cu == 0) {
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+        cus[dev & 63].store(n_cu, std::memory_order_relaxed);
+    }
+    const bool in_lds = forced >= 0 ? forced == 1 : p.n_jobs > static_cast<uint32_t>(n_cu);
+    if (in_lds) hipLaunchKernelGGL(eigen_omega_kernel<false>, dim3(p.n_jobs), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL(eigen_omega_kernel<true>, dim3(p.n_jobs), dim3(256), lds, stream, p);
     return hipGetLastError();
+}
+
+// tests: the 63 x 32 index pairs of one sweep of the register-resident schedule, in step order, and locate() of every group
+void eigen_schedule_for_tests(int* pairs /* [63][32][2] */, int* located /* [15][16] */)
+{
+    int step = 0;
+    for (int r = 0; r < 15; ++r)
+        for (int pat = (r == 0 ? 0 : 3); pat < 7; ++pat, ++step)
+            for (int G = 0; G < 8; ++G)
+                for (int k = 0; k < 4; ++k) {
+                    const int a = rr::pair_a(pat, k), b = rr::pair_b(pat, k);
+                    pairs[(step * 32 + G * 4 + k) * 2 + 0] = 4 * rr::group_of(r, G, a >> 2) + (a & 3);
+                    pairs[(step * 32 + G * 4 + k) * 2 + 1] = 4 * rr::group_of(r, G, b >> 2) + (b & 3);
+                }
+    for (int r = 0; r < 15; ++r)
+        for (int g = 0; g < 16; ++g) located[r * 16 + g] = rr::locate(r, g);
 }
 
 }  // namespace pcsf

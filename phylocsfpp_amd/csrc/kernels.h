@@ -161,6 +161,7 @@ struct EigenParams {
 };
 
 hipError_t launch_eigen_omega(const EigenParams& p, hipStream_t stream);
+void eigen_schedule_for_tests(int* pairs, int* located);   // host: the register-resident variant's pair schedule
 
 }  // namespace pcsf
 

@@ -236,3 +236,14 @@ def test_mle_and_omega_on_trees_whose_branch_count_is_not_a_chunk_multiple(oracl
             assert np.all(np.isfinite(ph) == np.isfinite(oph))
             ok = np.isfinite(oph)
             assert np.all((ph[ok] - oph[ok]) ** 2 <= tol), (name, algo, ph, oph)
+
+
+def test_device_eigen_solver_in_its_lds_form():
+    """launch_eigen_omega picks the register-resident form of the Jacobi kernel while a launch has at most one job per CU and
+    the LDS form beyond; PCSF_EIGEN_LDS=1 (read once per process) forces the LDS form: the same accuracy test in a child process."""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_device_eigen_solver_of_the_omega_rate_matrix"],
+                       env=dict(os.environ, PCSF_EIGEN_LDS="1"), capture_output=True, text=True)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:]

@@ -151,3 +151,41 @@ def test_invalid_trees_are_rejected():
     bal(0, 64)
     prog, slots, depth = pa.build_schedule(np.array(c1, dtype=np.int16), np.array(c2, dtype=np.int16))
     assert depth == 5 and len(slots) == 62             # accepted: the DEEP kernel variants park tiles in scratch memory
+
+
+def test_eigen_solver_pair_schedule_covers_every_pair_once():
+    """The register-resident Jacobi kernel (csrc/eigen.hip) rotates 32 disjoint index pairs per step; its 63 steps must
+    be a one-factorisation of K64 (every pair exactly once per sweep), each step's pairs must stay inside one super-group
+    of the round (that is what keeps the rotations in registers), and locate() must invert the round's grouping."""
+    import ctypes as C
+    import phylocsfpp_amd as pa
+    lib = pa.load_library()
+    pairs = (C.c_int32 * (63 * 32 * 2))()
+    located = (C.c_int32 * (15 * 16))()
+    lib.pcsf_debug_eigen_schedule.restype = None
+    lib.pcsf_debug_eigen_schedule(pairs, located)
+    pairs = np.array(pairs).reshape(63, 32, 2)
+    located = np.array(located).reshape(15, 16)
+    seen = set()
+    for step in range(63):
+        idx = pairs[step].ravel()
+        assert sorted(idx) == list(range(64)), step                      # disjoint: every index in exactly one pair
+        for p, q in pairs[step]:
+            key = (min(p, q), max(p, q))
+            assert p != q and key not in seen
+            seen.add(key)
+    assert len(seen) == 64 * 63 // 2
+    # rounds: 7 steps (3 inside the groups + 4 across), then 14 x 4; within a round the super-groups (8 indices) are fixed
+    bounds = [0, 7] + [7 + 4 * k for k in range(1, 15)]
+    for r in range(15):
+        groups_of_sg = None
+        for step in range(bounds[r], bounds[r + 1]):
+            sgs = [frozenset(int(x) // 4 for x in pairs[step, 4 * G:4 * G + 4].ravel()) for G in range(8)]
+            assert all(len(s) <= 2 for s in sgs)
+            if step >= bounds[r] + (3 if r == 0 else 0):                  # cross steps name both groups of every super-group
+                assert all(len(s) == 2 for s in sgs)
+                groups_of_sg = groups_of_sg or sgs
+                assert sgs == groups_of_sg
+        for G, s in enumerate(groups_of_sg):
+            assert sorted(int(located[r, g]) & 7 for g in s) == [G, G]
+            assert sorted(int(located[r, g]) >> 3 for g in s) == [0, 1]
