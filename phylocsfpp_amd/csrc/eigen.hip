@@ -95,9 +95,12 @@ __host__ __device__ __forceinline__ constexpr int shift_source(int G, int half)
 }
 }  // namespace rr
 
+// REG: 128 threads (wave 0: B, wave 1: V; two work-groups fit a CU); otherwise 256 threads with B and V in LDS
 template <bool REG>
-__global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
+__global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const EigenParams p)
 {
+    constexpr int NT = REG ? 128 : 256;     // threads
+    constexpr int CPT = 4096 / NT;          // entries of a row a thread owns in the warm-start products
     const bool stamping = p.stamps != nullptr && blockIdx.x == 0;
     const unsigned long long t_kernel = stamping ? eig_clock() : 0ull;
     unsigned long long acc_a = 0, acc_rot = 0, acc_v = 0, acc_b = 0, n_steps = 0, n_sweeps = 0;
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
         iroot[tid] = 1.0 / root[tid];
     }
     const double kappa = qs[0], omega = qs[1];
-    for (int idx = tid; idx < 4096; idx += 256) {
+    for (int idx = tid; idx < 4096; idx += NT) {
         const int i = idx >> 6, j = idx & 63;
         double rate = 0.0;
         const int x = i ^ j;
@@ -164,12 +167,12 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
         norm_s = norm;
     }
     __syncthreads();
-    for (int idx = tid; idx < 4096; idx += 256) {
+    for (int idx = tid; idx < 4096; idx += NT) {
         const int i = idx >> 6, j = idx & 63;
         A[i * LD + j] = root[i] * (A[i * LD + j] / norm_s) * iroot[j];
     }
     __syncthreads();
-    for (int idx = tid; idx < 4096; idx += 256) {
+    for (int idx = tid; idx < 4096; idx += NT) {
         const int i = idx >> 6, j = idx & 63;
         if (i < j) {
             const double m = 0.5 * (A[i * LD + j] + A[j * LD + i]);
@@ -186,35 +189,35 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
     // eigen-decomposition of B to the same accuracy as a cold start.
     if (job.warm >= 0 && p.eig_basis) {
         const double* __restrict__ V0 = p.eig_basis + static_cast<size_t>(job.warm) * 4096;
-        for (int idx = tid; idx < 4096; idx += 256) V[(idx >> 6) * LD + (idx & 63)] = V0[idx];
+        for (int idx = tid; idx < 4096; idx += NT) V[(idx >> 6) * LD + (idx & 63)] = V0[idx];
         __syncthreads();
-        double t[16];
-        // T = B V0: thread owns row r = tid >> 2 and columns c = 16*(tid & 3) .. +15
-        const int r = tid >> 2, c0 = 16 * (tid & 3);
+        double t[CPT];
+        // T = B V0: thread owns CPT consecutive entries of one row (256 threads: row tid >> 2, columns 16 (tid & 3) .. +15)
+        const int r = tid / (64 / CPT), c0 = CPT * (tid % (64 / CPT));
 #pragma unroll
-        for (int u = 0; u < 16; ++u) t[u] = 0.0;
+        for (int u = 0; u < CPT; ++u) t[u] = 0.0;
         for (int j = 0; j < 64; ++j) {
             const double b = A[r * LD + j];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) t[u] += b * V[j * LD + c0 + u];
+            for (int u = 0; u < CPT; ++u) t[u] += b * V[j * LD + c0 + u];
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 16; ++u) A[r * LD + c0 + u] = t[u];
+        for (int u = 0; u < CPT; ++u) A[r * LD + c0 + u] = t[u];
         __syncthreads();
         // C = V0^T T: entry (r, c) = sum_i V0[i][r] T[i][c]
 #pragma unroll
-        for (int u = 0; u < 16; ++u) t[u] = 0.0;
+        for (int u = 0; u < CPT; ++u) t[u] = 0.0;
         for (int i = 0; i < 64; ++i) {
             const double v = V[i * LD + r];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) t[u] += v * A[i * LD + c0 + u];
+            for (int u = 0; u < CPT; ++u) t[u] += v * A[i * LD + c0 + u];
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 16; ++u) A[r * LD + c0 + u] = t[u];
+        for (int u = 0; u < CPT; ++u) A[r * LD + c0 + u] = t[u];
         __syncthreads();
-        for (int idx = tid; idx < 4096; idx += 256) {  // exact symmetry again
+        for (int idx = tid; idx < 4096; idx += NT) {  // exact symmetry again
             const int i = idx >> 6, j = idx & 63;
             if (i < j) {
                 const double m = 0.5 * (A[i * LD + j] + A[j * LD + i]);
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
     for (int sweep = 0; sweep < 60; ++sweep) {
         // convergence: squared off-diagonal mass against squared diagonal mass
         double off = 0.0, total = 0.0;
-        for (int idx = tid; idx < 4096; idx += 256) {
+        for (int idx = tid; idx < 4096; idx += NT) {
             const int i = idx >> 6, j = idx & 63;
             const double v = A[i * LD + j];
             if (i == j) total += v * v;
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
         }
     }
     } else {
-    // ================= register-resident sweeps: wave 0 owns B, wave 1 owns V, waves 2-3 only keep the barriers ==================
+    // ================= register-resident sweeps: wave 0 owns B, wave 1 owns V ==================
     double2_loc* rt = reinterpret_cast<double2_loc*>(rot);   // [buf][super-group * 4 + pair] = (cos, sin)
     __shared__ __attribute__((aligned(16))) double dg[32 * 4];  // [super-group * 4 + pair] = B[a][a], B[b][b], B[a][b] of the next step's pairs
     const int R = lane >> 3, C = lane & 7;
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
                 A[row * LD + row] = b[i][i];
             }
         }
-    } else if (wave == 1) {
+    } else {
         // V <- V J: lane = row of V, all 64 entries of the row in registers in SEAT order (seat 8G + s = slot s of super-group G), so
         // every rotation is lane-local, the step patterns are static register pairs, and regrouping is a static register shift.
         double v[64];
@@ -635,12 +638,6 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
         for (int G = 0; G < 8; ++G)
 #pragma unroll
             for (int sl = 0; sl < 8; ++sl) V[lane * LD + 4 * rr::group_of(0, G, sl >> 2) + (sl & 3)] = v[8 * G + sl];
-    } else {
-        for (int sweep = 0; sweep < 60; ++sweep) {
-            __syncthreads();
-            if (flag == 2) break;
-            for (int st = 0; st < 63; ++st) __syncthreads();
-        }
     }
     __syncthreads();
     }
@@ -661,7 +658,7 @@ __global__ __launch_bounds__(256) void eigen_omega_kernel(const EigenParams p)
     double* __restrict__ L = p.eig_left + static_cast<size_t>(job.eig) * 4096;
     double* __restrict__ lam = p.eig_lambda + static_cast<size_t>(job.eig) * 64;
     double* __restrict__ basis = p.eig_basis ? p.eig_basis + static_cast<size_t>(job.eig) * 4096 : nullptr;
-    for (int idx = tid; idx < 4096; idx += 256) {
+    for (int idx = tid; idx < 4096; idx += NT) {
         const int r = idx >> 6, c = idx & 63;
         R[idx] = iroot[r] * V[r * LD + c];   // right[i][k], i = r, k = c
         L[idx] = V[c * LD + r] * root[c];    // left[k][i],  k = r, i = c
@@ -704,20 +701,12 @@ hipError_t launch_eigen_omega(const EigenParams& p, hipStream_t stream)
         if (e != hipSuccess) return e;
         attr_set.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
     }
-    // Two forms of the same iteration.  Blocks in registers (wave 0: B, wave 1: V; 374 registers, one work-group per CU): 0.69 ms per
-    // cold launch against 0.98 ms, the better one while a launch has at most one job per CU -- a round of OMEGA over a few hundred
-    // blocks.  Matrices in LDS (four waves, two work-groups per CU): better throughput once the jobs outnumber the CUs (2,064 blocks:
-    // 0.99 s against 1.04 s).  PCSF_EIGEN_LDS=1 / 0 forces one of them (tests run both).
-    static const int forced = [] { const char* e = getenv("PCSF_EIGEN_LDS"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-    static std::atomic<int> cus[64];
-    int n_cu = cus[dev & 63].load(std::memory_order_relaxed);
-    if (n_cu == 0) {
-        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-        cus[dev & 63].store(n_cu, std::memory_order_relaxed);
-    }
-    const bool in_lds = forced >= 0 ? forced == 1 : p.n_jobs > static_cast<uint32_t>(n_cu);
+    // Two forms of the same iteration.  Default: blocks in registers (128 threads: wave 0 holds B, wave 1 V; two work-groups per CU) --
+    // 0.69 ms per cold launch against 0.98 ms, and OMEGA 1.16-1.22x faster at 516 / 2,064 / 8,256 blocks.  PCSF_EIGEN_LDS=1: the
+    // first version (matrices in LDS, 256 threads), kept for A/B runs and tests.
+    static const bool in_lds = [] { const char* e = getenv("PCSF_EIGEN_LDS"); return e && e[0] == '1'; }();
     if (in_lds) hipLaunchKernelGGL(eigen_omega_kernel<false>, dim3(p.n_jobs), dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL(eigen_omega_kernel<true>, dim3(p.n_jobs), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL(eigen_omega_kernel<true>, dim3(p.n_jobs), dim3(128), lds, stream, p);
     return hipGetLastError();
 }
 
