@@ -664,10 +664,12 @@ struct OmegaBlock {
 int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_blocks, size_t leaf_stride, uint32_t seed,
               float* out_phylo, float* out_anc, bool own_streams)
 {
+    const auto t_enter = std::chrono::steady_clock::now();
     BlockEngine eng(c, codons, off, n_blocks, leaf_stride, own_streams);
     const size_t cap = std::max<size_t>(64, 2 * n_blocks);
     eng.reserve_tables(cap);
     eng.reserve_eig(n_blocks + cap);  // slot b: block b's current model; slots n_blocks + k: kappa probes of a round
+    const double t_setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count();
     std::vector<std::unique_ptr<OmegaBlock>> blk(n_blocks);
     const long trace_block = std::getenv("PCSF_TRACE_BLOCK") ? std::atol(std::getenv("PCSF_TRACE_BLOCK")) : -1;  // diagnostics
     const size_t nl = static_cast<size_t>(c->n_leaves);
@@ -744,6 +746,7 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
         if (!blk[b]->failed) start_stage(*blk[b]);
 
     const bool timing = std::getenv("PCSF_TIME_BLOCKS") != nullptr;  // diagnostics: where the rounds spend their time
+    const double t_prelude = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count() - t_setup;
     double t_host = 0.0, t_run = 0.0;
     size_t rounds = 0, evals = 0, eig_evals = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -755,7 +758,6 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
     for (;;) {
         const auto t0 = now();
         // (1) feed every optimiser from its store; finished stages move the block on
-        std::vector<size_t> entering_h1;
         size_t active = 0;
         for (size_t b : live) {
             OmegaBlock& ob = *blk[b];
@@ -771,8 +773,7 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
                     } else if (ob.stage == 6) {  // omega_H1 = 0.2, sigma_H1 = 0.01, keep rho and kappa (src/run.hpp:161-166)
                         ob.q_settings[1] = 0.2;
                         ob.q_settings[2] = 0.01;
-                        ob.needs_validation = true;
-                        entering_h1.push_back(b);
+                        ob.needs_validation = true;   // validated in the round that follows
                     } else {
                         start_stage(ob);
                     }
@@ -790,22 +791,26 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
             }
             if (!ob.failed && !ob.done) ++active;
         }
-        if (!entering_h1.empty()) {
-            validate_all(entering_h1);
-            for (size_t b : entering_h1) {
-                blk[b]->needs_validation = false;
-                if (!blk[b]->failed) start_stage(*blk[b]);
-            }
-            continue;  // their first points join the next round
-        }
         if (!active) break;
+        // Blocks that switch to H1 need their new model validated (one evaluation whose flags are read) before their next
+        // stage starts.  That evaluation rides along with this round's points of the other blocks -- as a round of its own it
+        // cost a full eigen-solver launch and a synchronisation for a handful of blocks, some forty times per run (0.05 of
+        // 0.36 s on the 516-block file).  Blocks whose validation does not fit this round wait for the next.
+        std::vector<std::pair<size_t, size_t>> validating;  // (block, evaluation)
+        for (size_t b = 0; b < n_blocks; ++b) {
+            OmegaBlock& ob = *blk[b];
+            if (ob.failed || ob.done || !ob.needs_validation || eng.free_evaluations() == 0) continue;
+            validating.push_back({b, eng.queue(b, static_cast<uint32_t>(b), ob.tree_scale, ob.q_settings, false, ob.eig_valid ? static_cast<int32_t>(b) : -1)});
+            std::memcpy(ob.eig_settings, ob.q_settings, sizeof ob.q_settings);
+            ob.eig_valid = true;
+        }
         // (2) queue the points the optimisers will or may need next: rank 0 (certain) for every block first
         std::vector<Pending> pending;
         std::vector<Lookahead> ahead(n_blocks);
         std::vector<char> rebuilt(n_blocks, 0);  // block's own eigen-system slot is rebuilt in this run
         for (size_t b : live) {
             OmegaBlock& ob = *blk[b];
-            if (!ob.failed && !ob.done) ahead[b].n = ob.opt.upcoming(ahead[b].x, MAX_POINTS_PER_ROUND, MAX_SPECULATIVE_RESTARTS);
+            if (!ob.failed && !ob.done && !ob.needs_validation) ahead[b].n = ob.opt.upcoming(ahead[b].x, MAX_POINTS_PER_ROUND, MAX_SPECULATIVE_RESTARTS);
         }
         for (int rank = 0; rank < MAX_POINTS_PER_ROUND && eng.free_evaluations() > 0; ++rank) {
             bool any = false;
@@ -851,12 +856,18 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
             lpr += ((ob.stage % 2) == 0) ? log_prior_rho(q.x) : log_prior_kappa(q.x);
             blk[q.block]->store.entries.push_back({q.x, lpr, 0.0, eng.failed(q.eval)});
         }
+        for (const auto& q : validating) {
+            OmegaBlock& ob = *blk[q.first];
+            ob.needs_validation = false;
+            if (eng.failed(q.second)) ob.failed = true;
+            else start_stage(ob);
+        }
         t_host += secs(t0, t1) + secs(t2, now());
         t_run += secs(t1, t2);
     }
     if (timing)
-        fprintf(stderr, "run_omega: %zu blocks, %zu rounds, %zu evaluations (%zu with a new eigen-system): host %.3f s, device rounds %.3f s\n",
-                n_blocks, rounds, evals, eig_evals, t_host, t_run);
+        fprintf(stderr, "run_omega: %zu blocks, %zu rounds, %zu evaluations (%zu with a new eigen-system): host %.3f s, device rounds %.3f s; engine set-up %.3f s, validation passes + F3x4 counts %.3f s, whole call %.3f s\n",
+                n_blocks, rounds, evals, eig_evals, t_host, t_run, t_setup, t_prelude, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count());
     for (size_t b = 0; b < n_blocks; ++b) {
         const OmegaBlock& ob = *blk[b];
         out_phylo[b] = ob.failed ? NAN : decibans(ob.lpr_h1, ob.lpr_h0);
