@@ -573,67 +573,91 @@ int run_mle(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_bl
     eng.upload_eig(0, c->eig[0]);
     eng.upload_eig(1, c->eig[1]);
     std::vector<std::mt19937> gen(n_blocks);
-    std::vector<MaxLik1D> opt(n_blocks);
-    std::vector<EvalStore> store(n_blocks);
+    std::vector<MaxLik1D> opt[2] = {std::vector<MaxLik1D>(n_blocks), std::vector<MaxLik1D>(n_blocks)};
+    std::vector<EvalStore> store[2] = {std::vector<EvalStore>(n_blocks), std::vector<EvalStore>(n_blocks)};
     std::vector<double> res_lpr(2 * n_blocks, 0.0), res_anc(2 * n_blocks, 0.0);
-    std::vector<char> failed(n_blocks, 0);
+    std::vector<char> failed(n_blocks, 0), started1(n_blocks, 0);
     for (size_t b = 0; b < n_blocks; ++b) gen[b].seed(seed);
     struct Pending {
         size_t block, eval;
         double x;
+        int model;
     };
-
-    for (int model = 0; model < 2; ++model) {  // coding first, then non-coding (src/run.hpp:193-194)
+    // The reference optimises the coding model, then the non-coding one (src/run.hpp:193-194), drawing the random restarts of both
+    // from one generator per block.  The two searches are independent otherwise, and a search draws only BEFORE its Brent iteration
+    // (MaxLik1D::draws_finished): the non-coding search of a block starts as soon as the coding one has drawn its last number, sees
+    // the same numbers as it would afterwards, and the two advance in the same rounds -- half the rounds, the same results.
+    for (size_t b = 0; b < n_blocks; ++b) opt[0][b].start(1.0, 1e-2, 10.0, &gen[b]);
+    const bool timing = std::getenv("PCSF_TIME_BLOCKS") != nullptr;  // diagnostics: where the rounds spend their time
+    const auto t_enter = std::chrono::steady_clock::now();
+    double t_run = 0.0;
+    size_t rounds = 0, n_evals = 0;
+    for (;;) {
+        // feed every optimiser from its store; blocks without a codon have lpr = 0 at every scale
+        size_t active = 0;
         for (size_t b = 0; b < n_blocks; ++b) {
-            store[b].clear();
-            if (!failed[b]) opt[b].start(1.0, 1e-2, 10.0, &gen[b]);
-        }
-        for (;;) {
-            // feed every optimiser from its store; blocks without a codon have lpr = 0 at every scale
-            size_t active = 0;
-            for (size_t b = 0; b < n_blocks; ++b) {
-                if (failed[b]) continue;
-                while (!opt[b].done()) {
+            for (int model = 0; model < 2 && !failed[b]; ++model) {
+                if (model == 1) {
+                    if (!started1[b]) {
+                        if (!opt[0][b].draws_finished()) break;
+                        opt[1][b].start(1.0, 1e-2, 10.0, &gen[b]);
+                        started1[b] = 1;
+                    }
+                }
+                MaxLik1D& o = opt[model][b];
+                while (!o.done()) {
                     if (off[b + 1] == off[b]) {
-                        opt[b].supply(0.0, 0.0);
+                        o.supply(0.0, 0.0);
                         continue;
                     }
-                    const EvalStore::Entry* e = store[b].find(opt[b].request());
+                    const EvalStore::Entry* e = store[model][b].find(o.request());
                     if (!e) break;
                     if (e->failed) {  // std::runtime_error in PhyloModel_make -> NaN row
                         failed[b] = 1;
                         break;
                     }
-                    opt[b].supply(e->lpr, e->anc);
+                    o.supply(e->lpr, e->anc);
                 }
-                if (!failed[b] && !opt[b].done()) ++active;
             }
-            if (!active) break;
-            // queue the points the active optimisers will or may need: rank 0 (certain) for everybody first
-            std::vector<Pending> pending;
-            std::vector<Lookahead> ahead(n_blocks);
-            for (size_t b = 0; b < n_blocks; ++b)
-                if (!failed[b] && !opt[b].done()) ahead[b].n = opt[b].upcoming(ahead[b].x, MAX_POINTS_PER_ROUND, MAX_SPECULATIVE_RESTARTS);
-            for (int rank = 0; rank < MAX_POINTS_PER_ROUND && eng.free_evaluations() > 0; ++rank) {
-                bool any = false;
+            if (!failed[b] && (!opt[0][b].done() || !started1[b] || !opt[1][b].done())) ++active;
+        }
+        if (!active) break;
+        // queue the points the active optimisers will or may need: rank 0 (certain) for everybody first
+        std::vector<Pending> pending;
+        std::vector<Lookahead> ahead[2] = {std::vector<Lookahead>(n_blocks), std::vector<Lookahead>(n_blocks)};
+        for (size_t b = 0; b < n_blocks; ++b)
+            for (int model = 0; model < 2; ++model)
+                if (!failed[b] && (model == 0 || started1[b]) && !opt[model][b].done())
+                    ahead[model][b].n = opt[model][b].upcoming(ahead[model][b].x, MAX_POINTS_PER_ROUND, MAX_SPECULATIVE_RESTARTS);
+        for (int rank = 0; rank < MAX_POINTS_PER_ROUND && eng.free_evaluations() > 0; ++rank) {
+            bool any = false;
+            for (int model = 0; model < 2; ++model)
                 for (size_t b = 0; b < n_blocks && eng.free_evaluations() > 0; ++b) {
-                    if (rank >= ahead[b].n) continue;
+                    if (rank >= ahead[model][b].n) continue;
                     any = true;
-                    const double x = ahead[b].x[rank];
-                    if (store[b].find(x) || ahead[b].seen_before(rank)) continue;
-                    pending.push_back({b, eng.queue(b, static_cast<uint32_t>(model), x, nullptr), x});
+                    const double x = ahead[model][b].x[rank];
+                    if (store[model][b].find(x) || ahead[model][b].seen_before(rank)) continue;
+                    pending.push_back({b, eng.queue(b, static_cast<uint32_t>(model), x, nullptr), x, model});
                 }
-                if (!any) break;
-            }
-            eng.run(compute_anc != 0);
-            for (const Pending& q : pending)
-                store[q.block].entries.push_back({q.x, eng.value(q.eval, eng.lnz), compute_anc ? eng.value(q.eval, eng.anc) : 0.0, eng.failed(q.eval)});
+            if (!any) break;
         }
-        for (size_t b = 0; b < n_blocks; ++b) {
-            res_lpr[model * n_blocks + b] = opt[b].last_lpr();
-            res_anc[model * n_blocks + b] = opt[b].last_anc();
-        }
+        const auto t_a = std::chrono::steady_clock::now();
+        eng.run(compute_anc != 0);
+        t_run += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count();
+        ++rounds;
+        n_evals += pending.size();
+        for (const Pending& q : pending)
+            store[q.model][q.block].entries.push_back({q.x, eng.value(q.eval, eng.lnz), compute_anc ? eng.value(q.eval, eng.anc) : 0.0, eng.failed(q.eval)});
     }
+    if (timing) {
+        const double all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count();
+        fprintf(stderr, "run_mle: %zu blocks, %zu rounds, %zu evaluations: host %.3f s, device rounds %.3f s\n", n_blocks, rounds, n_evals, all - t_run, t_run);
+    }
+    for (int model = 0; model < 2; ++model)
+        for (size_t b = 0; b < n_blocks; ++b) {
+            res_lpr[model * n_blocks + b] = opt[model][b].last_lpr();
+            res_anc[model * n_blocks + b] = opt[model][b].last_anc();
+        }
     for (size_t b = 0; b < n_blocks; ++b) {
         if (failed[b]) {
             out_phylo[b] = NAN;

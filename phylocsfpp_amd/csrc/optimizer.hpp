@@ -33,6 +33,9 @@ public:
         evals_ = 0;
     }
     bool done() const { return done_; }
+    // true once the search will never draw from the generator again (the random restarts precede Brent's iteration): a second
+    // search sharing the generator may start then and still sees the numbers it would have seen after this one had finished
+    bool draws_finished() const { return done_ || state_ >= S_FINAL; }
     double request() const { return request_; }  // x at which the objective is wanted next
     double last_x() const { return last_x_; }
     double last_lpr() const { return last_lpr_; }  // result of max_lik_lpr_leaves = LAST evaluation
