@@ -9,7 +9,7 @@
 //   3. diagonalises B with a PARALLEL-ORDER cyclic Jacobi iteration in LDS: 63 steps per sweep, each
 //      applying 32 disjoint plane rotations (round-robin tournament pairing) as B <- J^T B J, V <- V J.
 //      Only rotations, so the near-zero eigenvalue keeps its relative accuracy (the equilibrium prior is read
-//      off its eigenvector), same stopping rule as the host solver (off^2 <= 1e-58 * diag^2),
+//      off its eigenvector), stopping rule off^2 <= 1e-58 * diag^2 like the host solver (register-resident form: 1e-36, see there),
 //   4. writes right = D^-1/2 V, left = V^T D^1/2, lambda, and the root prior (+ ln(prior)*prior) of the
 //      eigen-system in the lane order the pruning kernel reads.
 // The host solver (hostmath.hpp::eigen_reversible, sequential row-cyclic order) stays the reference for tests:
@@ -519,7 +519,10 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
                 acc_b += eig_clock() - t3;
             }
         };
-        for (int sweep = 0; sweep < 60; ++sweep) {
+        // Convergence is checked before every ROUND (4 steps; 7 in round 0), not once per sweep: the iteration converges quadratically,
+        // so a job is usually done a good part of a sweep before the sweep's end, and a launch lasts as long as its slowest job.
+        int r = 0;   // the seating: round within the sweep
+        for (int round = 0; round < 60 * 15; ++round) {
             double off = 0.0, total = 0.0;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -537,30 +540,32 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
                 off += __shfl_xor(off, sft);
                 total += __shfl_xor(total, sft);
             }
-            if (lane == 0) flag = (off <= 1e-58 * total) ? 2 : 0;
+            // The host solver and the LDS form stop at off^2 <= 1e-58 diag^2.  Here: 1e-36, i.e. an off-diagonal mass below 1e-18 of the
+            // diagonal's -- already under the rounding of every product formed from the result.
+            constexpr double STOP = 1e-36;
+            if (lane == 0) flag = (off <= STOP * total) ? 2 : 0;
             __syncthreads();
-            if (off <= 1e-58 * total) break;
-            n_sweeps += 1;
-            for (int r = 0; r < 15; ++r) {
-                using std::integral_constant;
-                if (r == 0) {
-                    timed_step(integral_constant<int, 0>{}, integral_constant<int, 1>{}, -1, 0);
-                    timed_step(integral_constant<int, 1>{}, integral_constant<int, 2>{}, -1, 0);
-                    timed_step(integral_constant<int, 2>{}, integral_constant<int, 3>{}, -1, 0);
-                }
-                timed_step(integral_constant<int, 3>{}, integral_constant<int, 4>{}, -1, 0);
-                timed_step(integral_constant<int, 4>{}, integral_constant<int, 5>{}, -1, 0);
-                timed_step(integral_constant<int, 5>{}, integral_constant<int, 6>{}, -1, 0);
-                if (r == 14) timed_step(integral_constant<int, 6>{}, integral_constant<int, 0>{}, 14, 0);
-                else timed_step(integral_constant<int, 6>{}, integral_constant<int, 3>{}, r, r + 1);
-                n_steps += r == 0 ? 7 : 4;
+            if (off <= STOP * total) break;
+            using std::integral_constant;
+            if (r == 0) {
+                n_sweeps += 1;
+                timed_step(integral_constant<int, 0>{}, integral_constant<int, 1>{}, -1, 0);
+                timed_step(integral_constant<int, 1>{}, integral_constant<int, 2>{}, -1, 0);
+                timed_step(integral_constant<int, 2>{}, integral_constant<int, 3>{}, -1, 0);
             }
+            timed_step(integral_constant<int, 3>{}, integral_constant<int, 4>{}, -1, 0);
+            timed_step(integral_constant<int, 4>{}, integral_constant<int, 5>{}, -1, 0);
+            timed_step(integral_constant<int, 5>{}, integral_constant<int, 6>{}, -1, 0);
+            if (r == 14) timed_step(integral_constant<int, 6>{}, integral_constant<int, 0>{}, 14, 0);
+            else timed_step(integral_constant<int, 6>{}, integral_constant<int, 3>{}, r, r + 1);
+            n_steps += r == 0 ? 7 : 4;
+            r = r == 14 ? 0 : r + 1;
         }
-        // eigenvalues into the canonical matrix (round-0 grouping again)
+        // eigenvalues into the canonical matrix (the seating of the round the iteration stopped in)
         if (diag) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int row = 4 * rr::group_of(0, R, i >> 2) + (i & 3);
+                const int row = 4 * rr::group_of(r, R, i >> 2) + (i & 3);
                 A[row * LD + row] = b[i][i];
             }
         }
@@ -603,41 +608,41 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
             for (int q = 0; q < 4; ++q) v[8 * 1 + 4 * 1 + q] = keep[q];   // (1,1) takes over from (0,0)
         };
         int buf = 0;
-        for (int sweep = 0; sweep < 60; ++sweep) {
+        int r = 0;
+        for (int round = 0; round < 60 * 15; ++round) {
             __syncthreads();
             if (flag == 2) break;
-            for (int r = 0; r < 15; ++r) {
-                if (r == 0) {
-                    v_step(std::integral_constant<int, 0>{}, buf);
-                    buf ^= 1;
-                    __syncthreads();
-                    v_step(std::integral_constant<int, 1>{}, buf);
-                    buf ^= 1;
-                    __syncthreads();
-                    v_step(std::integral_constant<int, 2>{}, buf);
-                    buf ^= 1;
-                    __syncthreads();
-                }
-                v_step(std::integral_constant<int, 3>{}, buf);
+            if (r == 0) {
+                v_step(std::integral_constant<int, 0>{}, buf);
                 buf ^= 1;
                 __syncthreads();
-                v_step(std::integral_constant<int, 4>{}, buf);
+                v_step(std::integral_constant<int, 1>{}, buf);
                 buf ^= 1;
                 __syncthreads();
-                v_step(std::integral_constant<int, 5>{}, buf);
-                buf ^= 1;
-                __syncthreads();
-                v_step(std::integral_constant<int, 6>{}, buf);
-                shift();
+                v_step(std::integral_constant<int, 2>{}, buf);
                 buf ^= 1;
                 __syncthreads();
             }
+            v_step(std::integral_constant<int, 3>{}, buf);
+            buf ^= 1;
+            __syncthreads();
+            v_step(std::integral_constant<int, 4>{}, buf);
+            buf ^= 1;
+            __syncthreads();
+            v_step(std::integral_constant<int, 5>{}, buf);
+            buf ^= 1;
+            __syncthreads();
+            v_step(std::integral_constant<int, 6>{}, buf);
+            shift();
+            buf ^= 1;
+            __syncthreads();
+            r = r == 14 ? 0 : r + 1;
         }
-        // eigenvectors back into the canonical matrix (a sweep ends in the seating of round 0)
+        // eigenvectors back into the canonical matrix (the seating of the round the iteration stopped in)
 #pragma unroll
         for (int G = 0; G < 8; ++G)
 #pragma unroll
-            for (int sl = 0; sl < 8; ++sl) V[lane * LD + 4 * rr::group_of(0, G, sl >> 2) + (sl & 3)] = v[8 * G + sl];
+            for (int sl = 0; sl < 8; ++sl) V[lane * LD + 4 * rr::group_of(r, G, sl >> 2) + (sl & 3)] = v[8 * G + sl];
     }
     __syncthreads();
     }
