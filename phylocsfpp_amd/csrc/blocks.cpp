@@ -62,6 +62,29 @@ void parallel_for(size_t n, F&& f)
 // Device state shared by the lock-step strategies.  One EVALUATION = (block, eigen-system, tree scale): its
 // branch matrices go to a table set of its own, its per-site ln z to an output segment of its own, so any
 // number of evaluations -- also of the same block -- can share a run().
+// The path rule of DESIGN.md section 4: does block b (sites [s0, s1) of the leaf-major codon matrix) go through the factored
+// kernel?  max_tiles >= 0 replaces the cost rule by "at most max_tiles tiles" (PCSF_FACTORED_MAX_TILES).
+static bool block_prefers_factored(const pcsf_ctx* c, const uint8_t* codons, size_t stride, uint64_t s0, uint64_t s1, long max_tiles)
+{
+    const int nl = c->n_leaves, n = c->n_nodes, ne = static_cast<int>(c->schedule.slot_node.size());
+    const uint64_t sites = s1 - s0, tiles = (sites + 15) / 16;
+    if (max_tiles >= 0) return tiles <= static_cast<uint64_t>(max_tiles);
+    std::vector<char> live(static_cast<size_t>(n), 0);  // a species with a codon in the block below this node
+    size_t present = 0, active_edges = 0;
+    for (int l = 0; l < nl; ++l) {
+        const uint8_t* row = codons + static_cast<size_t>(l) * stride;
+        char any = 0;
+        for (uint64_t s = s0; s < s1 && !any; ++s) any = row[s] < 64;
+        live[l] = any;
+        present += any;
+    }
+    for (int v = nl; v < n; ++v) live[v] = live[c->child1[v]] || live[c->child2[v]];
+    for (int v = nl; v < n - 1; ++v) active_edges += live[v];
+    const double factored_cost = static_cast<double>(tiles) * static_cast<double>(present + 2 * active_edges) * 64.0;
+    const double explicit_cost = static_cast<double>(n - 1) * 256.0 + static_cast<double>((sites + 63) / 64) * ne * 64.0 * 4.0;
+    return factored_cost <= explicit_cost;
+}
+
 struct BlockEngine {
     pcsf_ctx* c;
     size_t n_blocks, leaf_stride, n_sites_total;
@@ -143,24 +166,7 @@ struct BlockEngine {
         if (const char* v = std::getenv("PCSF_FACTORED_MAX_TILES")) fixed_max_tiles = std::max(0, std::atoi(v));
         if (const char* v = std::getenv("PCSF_EIGEN_HOST")) host_eigen = std::atoi(v) != 0;
         block_factored.assign(nb, 0);
-        for (size_t b = 0; b < nb; ++b) {
-            const uint64_t sites = offsets[b + 1] - offsets[b], tiles = (sites + 15) / 16;
-            if (fixed_max_tiles >= 0) {
-                block_factored[b] = tiles <= static_cast<uint64_t>(fixed_max_tiles);
-                continue;
-            }
-            std::vector<char> live(static_cast<size_t>(n), 0);  // a species with a codon in the block below this node
-            size_t present = 0, active_edges = 0;
-            for (int l = 0; l < nl; ++l) {
-                live[l] = leaf_codes[(b * nl + l) * 2] != 0;
-                present += live[l];
-            }
-            for (int v = nl; v < n; ++v) live[v] = live[c->child1[v]] || live[c->child2[v]];
-            for (int v = nl; v < n - 1; ++v) active_edges += live[v];
-            const double factored_cost = static_cast<double>(tiles) * static_cast<double>(present + 2 * active_edges) * 64.0;
-            const double explicit_cost = static_cast<double>(n - 1) * 256.0 + static_cast<double>((sites + 63) / 64) * ne * 64.0 * 4.0;
-            block_factored[b] = factored_cost <= explicit_cost;
-        }
+        for (size_t b = 0; b < nb; ++b) block_factored[b] = block_prefers_factored(c, codons, stride, offsets[b], offsets[b + 1], fixed_max_tiles);
         std::vector<int32_t> slots(static_cast<size_t>(n - 1));
         for (int b = 0; b < n - 1; ++b) slots[b] = c->branch_slot[b];
         std::vector<int32_t> slot_branch(c->schedule.slot_node.begin(), c->schedule.slot_node.end());
@@ -1008,18 +1014,35 @@ int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
     // MLE / OMEGA keep one set of branch-matrix tables per evaluation of a LONG block in HBM (9.6 MB for a 100-leaf tree),
     // up to two evaluations per block and round: blocks are independent, so a long list is processed in chunks that bound
     // that footprint to ~16 GB.
-    // PCSF_BLOCK_GROUPS=g (default 1) advances g groups of blocks concurrently, one host thread and one pair of streams
-    // each.  Measured (profiles/r02): no gain -- a round's time is the latency of its longest dependency chain (eigen-solver
-    // sweeps -> edge scales -> pruning -> download), which does not shrink with the number of blocks, and every group
-    // needs as many rounds as the whole list (the block with the longest optimiser path sets it): 516 blocks OMEGA
-    // 0.47 s as one group, 0.70-0.81 s as four.  Blocks are independent: grouping never changes a result.
+    // PCSF_BLOCK_GROUPS=g advances g groups of blocks concurrently, one host thread and one pair of streams each.  A round's
+    // time is the latency of its longest dependency chain (eigen-solver sweeps -> edge scales -> pruning -> download) plus the
+    // host's work on the round, and every group needs as many rounds as the whole list (the block with the longest optimiser
+    // path sets it): short lists lose (516 blocks OMEGA 0.32 s as one group, 0.39 s as two), long lists win because one
+    // group's host work and small kernels run beside the other's (8,256 blocks: MLE 0.58 -> 0.31 s, OMEGA 2.85 -> 2.18 s;
+    // four groups add nothing).  Blocks are independent: grouping never changes a result (tests/test_gpu_blocks.py).
     size_t chunk = n_blocks;
     size_t n_groups = 1;
     if (algo != PCSF_FIXED) {
         const size_t ne = c->schedule.slot_node.size();
         const size_t per_table = (ne * 4096 + static_cast<size_t>(c->n_leaves) * LEAF_TABLE_DOUBLES_DEV) * sizeof(double);
         chunk = std::max<size_t>(64, (size_t(16) << 30) / std::max<size_t>(per_table, 1));
+        // Blocks on the factored path keep no tables: when the whole list is factored (score-msa's short, sparse blocks) the chunks
+        // are bounded by the eigen-system slots instead (3 per block, ~100 KB each) -- every chunk costs a full set of rounds.
+        long max_tiles = -1;
+        if (const char* v = std::getenv("PCSF_FACTORED_MAX_TILES")) max_tiles = std::max(0, std::atoi(v));
+        std::atomic<bool> any_explicit{false};
+        if (codons)
+            parallel_for(n_blocks, [&](size_t b) {
+                if (!any_explicit.load(std::memory_order_relaxed) &&
+                    !block_prefers_factored(c, codons, leaf_stride, site_offsets[b], site_offsets[b + 1], max_tiles))
+                    any_explicit.store(true, std::memory_order_relaxed);
+            });
+        else any_explicit = true;
+        if (!any_explicit) chunk = std::max<size_t>(chunk, 32768);
+        // two groups once the list is long enough for one group's host work (optimisers, job lists: ~3 ms per round at 8,256
+        // blocks) to matter beside the other's kernels -- measured: MLE from 512 blocks, OMEGA from 1,536 (profiles/r02/blocks_groups.txt)
         if (const char* v = std::getenv("PCSF_BLOCK_GROUPS")) n_groups = static_cast<size_t>(std::max(1, std::atoi(v)));
+        else n_groups = n_blocks >= (algo == PCSF_MLE ? 512u : 1536u) ? 2 : 1;
         n_groups = std::min(n_groups, std::max<size_t>(n_blocks, 1));
         chunk = std::min(chunk / n_groups + 1, (n_blocks + n_groups - 1) / n_groups);
         chunk = std::max<size_t>(chunk, 1);

@@ -247,3 +247,37 @@ def test_device_eigen_solver_in_its_lds_form():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_device_eigen_solver_of_the_omega_rate_matrix"],
                        env=dict(os.environ, PCSF_EIGEN_LDS="1"), capture_output=True, text=True)
     assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:]
+
+
+def test_block_groups_do_not_change_any_result(oracle_models, golden_dir):
+    """score_blocks advances long lists as two concurrent groups (MLE from 512 blocks, OMEGA from 1,536; PCSF_BLOCK_GROUPS
+    overrides): every block's result must be bit-identical to the single-group run."""
+    import os
+    import maf_blocks
+    import phylocsfpp_amd as pa
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m = oracle_models("100vertebrates")
+    cod, offs = maf_blocks.block_codons(os.path.join(golden_dir, "score-msa", "chr22.516alignments.maf.gz"), m.labels,
+                                        os.path.join(root, "tests", "golden", "models", "species_aliases.tsv"))
+    reps, n0 = 3, offs[-1]
+    cod = np.ascontiguousarray(np.tile(cod, (1, reps)))
+    offs = np.concatenate([[0]] + [offs[1:] + r * n0 for r in range(reps)]).astype(np.uint64)
+    assert len(offs) - 1 >= 1536
+    ctx = pa.load_model(os.path.join(root, "tests", "golden", "models", "100vertebrates")).context()
+    try:
+        for algo, anc in ((pa.MLE, True), (pa.OMEGA, False)):
+            os.environ["PCSF_BLOCK_GROUPS"] = "1"
+            p1, a1 = ctx.score_blocks(algo, cod, offs, compute_anc=anc)
+            del os.environ["PCSF_BLOCK_GROUPS"]
+            p2, a2 = ctx.score_blocks(algo, cod, offs, compute_anc=anc)      # the default: two groups at this size
+            os.environ["PCSF_BLOCK_GROUPS"] = "3"
+            p3, a3 = ctx.score_blocks(algo, cod, offs, compute_anc=anc)
+            assert p1.tobytes() == p2.tobytes() == p3.tobytes()
+            if anc:
+                assert a1.tobytes() == a2.tobytes() == a3.tobytes()
+            # the three copies of the file are the same blocks: the same results
+            nb = (len(offs) - 1) // reps
+            assert p1[:nb].tobytes() == p1[nb:2 * nb].tobytes() == p1[2 * nb:].tobytes()
+    finally:
+        os.environ.pop("PCSF_BLOCK_GROUPS", None)
+        ctx.close()
