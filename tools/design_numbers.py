@@ -44,7 +44,7 @@ def main():
              g("SQ_VALU_MFMA_BUSY_CYCLES") / 64, (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024 / 1e9, g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")),
              g("GRBM_GUI_ACTIVE") / 8 / (r["kernel_ms"] * 1e-3) / 1e9))
     print("block strategies (516 blocks):")
-    for name in ("blocks_bench_516.txt", "blocks_bench_eigen_forms.txt", "blocks_bench_final.txt", "blocks_bench_516_explicit_only.txt", "blocks_bench_2064.txt"):
+    for name in ("blocks_bench_516.txt", "blocks_bench_eigen_forms.txt", "blocks_bench_516_explicit_only.txt", "blocks_bench_2064.txt"):
         path = os.path.join(P, name)
         if os.path.exists(path):
             for line in open(path):
