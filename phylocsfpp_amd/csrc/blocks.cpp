@@ -443,6 +443,7 @@ struct BlockEngine {
                 fp.edge_scale = d_scale.as<double>();
                 fp.out_lnz = d_lnz.as<double>();
                 fp.out_anc = want_anc ? d_anc.as<double>() : nullptr;
+                fp.deep = c->schedule.stack_depth > MAX_STACK_DEPTH ? 1u : 0u;
                 HIP_TRY(launch_prune_factored(fp, st));
             }
         };

@@ -94,7 +94,9 @@ __global__ __launch_bounds__(256) void edge_scale_kernel(const ExpmEval* __restr
 }
 
 // ---- the pruning kernel ----------------------------------------------------------------------------------------------
-template <bool ANC>
+// DEEP: the tree parks more than MAX_STACK_DEPTH_DEV tiles (none of the reference's eleven trees does): the parked tiles live in
+// scratch memory, dynamically indexed; otherwise in three register sets selected by work-group-uniform branches.
+template <bool ANC, bool DEEP>
 __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_fact[];
@@ -161,87 +163,122 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
         const double2_t lo = s2[0], hi = s2[1];
         return Vec4{{lo.x, lo.y, hi.x, hi.y}};
     };
-    // message along an internal edge; `ones`: the operand is the all-ones tile (an all-gap subtree) and so is the result
-    auto edge = [&](int branch, const Vec4& v, bool ones) -> Vec4 {
-        if (ones) return Vec4{{1.0, 1.0, 1.0, 1.0}};
-        const Vec4 e = load_scale(branch);
-        Vec4 y = matvec(LA, v);
+    // c = L 1 in this lane's rows: the eigen-coordinates of the all-ones message (a gap column of a leaf)
+    Vec4 cgap;
+    {
+        double rowsum = 0.0;   // row 16 wave + sj of L, this lane's 16 entries, then over the four lane groups
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y.v[r] *= e.v[r];
-        Vec4 m = matvec(RA, y);
+        for (int q = 0; q < 16; ++q) rowsum += LA[q];
+        rowsum += __shfl_xor(rowsum, 16);
+        rowsum += __shfl_xor(rowsum, 32);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) m.v[r] = fmax(m.v[r], 0.0);
-        return m;
+        for (int r = 0; r < 4; ++r) cgap.v[r] = __shfl(rowsum, g + 4 * r);   // row 16 wave + g + 4r
+    }
+
+    // A message is kept in one of two forms.  Real: the 64x16 tile itself.  Eigen: y with message = max(R y, 0) still to be formed.
+    // P(t) = R e^{Lambda t} L and L R = I, so an edge applied to a message in eigen form is just y <- e_b o y -- no product -- and
+    // a chain of edges whose other children are all-gap subtrees (the rule in a sparse block: 4 of 100 species present) costs one
+    // L-product at its start and one R-product where the chain meets another message, instead of two products per edge.  Real form
+    // is only needed for the element-wise product of two children and at the root.  `mask`: columns in which the whole subtree is
+    // gaps -- their message is exactly 1 whatever the form (bit s = site s); all 16 bits set = the all-ones tile.  Dense tiles do the
+    // same products in the same order as before.
+    struct Msg {
+        Vec4 v;
+        uint32_t mask;
+        bool eig;
     };
-    // message of a leaf: column `codon` of P(t_leaf); 1 for a gap.  all_gap (uniform over the work-group) -> no product
-    auto leaf = [&](int a, bool& all_gap) -> Vec4 {
+    auto to_real = [&](const Msg& m) -> Msg {
+        if (m.mask == 0xffffu) return Msg{Vec4{{1.0, 1.0, 1.0, 1.0}}, 0xffffu, false};
+        if (!m.eig) return m;
+        Msg out{matvec(RA, m.v), m.mask, false};
+        const bool gap_col = (m.mask >> sj) & 1u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out.v.v[r] = gap_col ? 1.0 : fmax(out.v.v[r], 0.0);
+        return out;
+    };
+    auto apply_edge = [&](int branch, const Msg& m) -> Msg {
+        if (m.mask == 0xffffu) return m;
+        const Vec4 e = load_scale(branch);
+        Msg out{m.eig ? m.v : matvec(LA, m.v), m.mask, true};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out.v.v[r] *= e.v[r];
+        return out;
+    };
+    auto leaf = [&](int a) -> Msg {
         const unsigned code = lcod[a * 16 + sj];
-        all_gap = __ballot(code != 64u) == 0ull;
-        if (all_gap) return Vec4{{1.0, 1.0, 1.0, 1.0}};
+        const uint32_t mask = static_cast<uint32_t>(__ballot(code == 64u)) & 0xffffu;   // lanes 0..15 hold the 16 sites
+        if (mask == 0xffffu) return Msg{Vec4{{1.0, 1.0, 1.0, 1.0}}, mask, false};
         const Vec4 e = load_scale(a);
         const unsigned col = code == 64u ? 0u : code;
-        Vec4 x;
+        Msg out{Vec4{}, mask, true};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x.v[r] = e.v[r] * Lrows[r * 256 + col];
-        Vec4 m = matvec(RA, x);
+        for (int r = 0; r < 4; ++r) out.v.v[r] = e.v[r] * (code == 64u ? cgap.v[r] : Lrows[r * 256 + col]);
+        return out;
+    };
+    auto mul = [&](const Msg& x, const Msg& y) -> Msg {
+        if (x.mask == 0xffffu) return y;
+        if (y.mask == 0xffffu) return x;
+        const Msg a = to_real(x), b = to_real(y);
+        Msg out{Vec4{}, a.mask & b.mask, false};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) m.v[r] = code == 64u ? 1.0 : fmax(m.v[r], 0.0);
-        return m;
+        for (int r = 0; r < 4; ++r) out.v.v[r] = a.v.v[r] * b.v.v[r];
+        return out;
     };
 
     // parked messages: pushes and pops nest, so a stack pointer replaces the slot numbers of the op codes (which deep
-    // trees do not carry, schedule.hpp); dynamically indexed -> scratch memory, touched twice per parked tile
-    Vec4 cur{{1.0, 1.0, 1.0, 1.0}}, stk[MAX_STACK_DEPTH_DEEP_DEV];
-    uint32_t stk_ones = 0;  // bit d: parked tile d is all ones
-    bool cur_ones = true;
+    // trees do not carry, schedule.hpp).  An all-ones tile is never stored or loaded.
+    Vec4 stk[DEEP ? MAX_STACK_DEPTH_DEEP_DEV : 1], s0{{1.0, 1.0, 1.0, 1.0}}, s1 = s0, s2 = s0;
+    uint32_t stk_mask[DEEP ? MAX_STACK_DEPTH_DEEP_DEV : MAX_STACK_DEPTH_DEV];
+    uint32_t stk_eig = 0;  // bit d: parked message d is in eigen form
+    auto park = [&](int d, const Msg& m) {
+        stk_mask[d] = m.mask;
+        stk_eig = (stk_eig & ~(1u << d)) | (m.eig ? 1u << d : 0u);
+        if (m.mask == 0xffffu) return;
+        if (DEEP) {
+            stk[d] = m.v;
+        } else {
+            if (d == 0) s0 = m.v;
+            else if (d == 1) s1 = m.v;
+            else s2 = m.v;
+        }
+    };
+    auto parked = [&](int d) -> Msg {
+        Msg m{Vec4{{1.0, 1.0, 1.0, 1.0}}, stk_mask[d], ((stk_eig >> d) & 1u) != 0};
+        if (m.mask == 0xffffu) return m;
+        if (DEEP) m.v = stk[d];
+        else m.v = d == 0 ? s0 : (d == 1 ? s1 : s2);
+        return m;
+    };
+    Msg cur{Vec4{{1.0, 1.0, 1.0, 1.0}}, 0xffffu, false};
     int slot = 0, sp = 0;
     for (int ip = 0; ip < p.n_ops; ++ip) {
         const uint32_t op = lprog[ip];
         const uint32_t code = op >> 28;
         const int a = (op >> 14) & 0x3fff, b = op & 0x3fff;
         if (code == F_CHERRY_DEV) {
-            bool ga, gb;
-            const Vec4 ma = leaf(a, ga), mb = leaf(b, gb);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cur.v[r] = ma.v[r] * mb.v[r];
-            cur_ones = ga && gb;
+            cur = mul(leaf(a), leaf(b));
         } else if (code == F_MM_LEAF_DEV) {
-            const Vec4 m = edge(lslot[slot++], cur, cur_ones);
-            bool ga;
-            const Vec4 ma = leaf(a, ga);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cur.v[r] = m.v[r] * ma.v[r];
-            cur_ones = cur_ones && ga;
+            cur = mul(apply_edge(lslot[slot++], cur), leaf(a));
         } else if (code >= F_MM_PUSH_CHERRY0_DEV && code < F_MM_POP0_DEV) {
-            const Vec4 m = edge(lslot[slot++], cur, cur_ones);
-            const bool m_ones = cur_ones;
-            bool ga, gb;
-            const Vec4 ma = leaf(a, ga), mb = leaf(b, gb);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cur.v[r] = ma.v[r] * mb.v[r];
-            cur_ones = ga && gb;
-            stk[sp] = m;
-            stk_ones = (stk_ones & ~(1u << sp)) | (m_ones ? 1u << sp : 0u);
+            park(sp, apply_edge(lslot[slot++], cur));
             ++sp;
+            cur = mul(leaf(a), leaf(b));
         } else if (code >= F_MM_POP0_DEV && code < F_ROOT_DEV) {
-            const Vec4 m = edge(lslot[slot++], cur, cur_ones);
+            const Msg m = apply_edge(lslot[slot++], cur);
             --sp;
-            const Vec4 s = stk[sp];
-            const bool s_ones = (stk_ones >> sp) & 1u;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cur.v[r] = s.v[r] * m.v[r];
-            cur_ones = cur_ones && s_ones;
+            cur = mul(parked(sp), m);
         } else {  // F_ROOT: z = prior . alpha_root, ln z; the ancestral term sum_x ln(prior_x) prior_x alpha_x / z
+            const Vec4 cur_v = to_real(cur).v;
             const double* __restrict__ pr = p.prior + static_cast<size_t>(job.eig) * 64 + g * 16 + 4 * wave;  // lane order [g][q], q = 4 wave + r
             double z = 0.0, t = 0.0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) z += pr[r] * cur.v[r];
+            for (int r = 0; r < 4; ++r) z += pr[r] * cur_v.v[r];
             z += __shfl_xor(z, 16);
             z += __shfl_xor(z, 32);
             if (ANC) {
                 const double* __restrict__ aw = p.anc_weight + static_cast<size_t>(job.eig) * 64 + g * 16 + 4 * wave;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t += aw[r] * cur.v[r];
+                for (int r = 0; r < 4; ++r) t += aw[r] * cur_v.v[r];
                 t += __shfl_xor(t, 16);
                 t += __shfl_xor(t, 32);
             }
@@ -277,10 +314,13 @@ hipError_t launch_prune_factored(const FactoredParams& p, hipStream_t stream)
     const size_t lds = 2 * 4 * 2 * 64 * 16 + 2 * 4 * 16 * 8 + ((static_cast<size_t>(p.n_ops) + 3) & ~size_t(3)) * 4 +
                        ((static_cast<size_t>(p.n_edges) + 3) & ~size_t(3)) * 4 + static_cast<size_t>(p.n_leaves) * 16;
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    if (p.out_anc)
-        hipLaunchKernelGGL(prune_factored<true>, dim3(p.n_jobs), dim3(256), lds, stream, p);
-    else
-        hipLaunchKernelGGL(prune_factored<false>, dim3(p.n_jobs), dim3(256), lds, stream, p);
+    if (p.deep) {
+        if (p.out_anc) hipLaunchKernelGGL((prune_factored<true, true>), dim3(p.n_jobs), dim3(256), lds, stream, p);
+        else hipLaunchKernelGGL((prune_factored<false, true>), dim3(p.n_jobs), dim3(256), lds, stream, p);
+    } else {
+        if (p.out_anc) hipLaunchKernelGGL((prune_factored<true, false>), dim3(p.n_jobs), dim3(256), lds, stream, p);
+        else hipLaunchKernelGGL((prune_factored<false, false>), dim3(p.n_jobs), dim3(256), lds, stream, p);
+    }
     return hipGetLastError();
 }
 

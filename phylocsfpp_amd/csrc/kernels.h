@@ -129,6 +129,7 @@ struct FactoredParams {
     const double* edge_scale;   // [n_eval][n_branches][64] row-split order
     double* out_lnz;
     double* out_anc;            // or null
+    uint32_t deep;              // the tree parks more tiles than the register stack holds (schedule.stack_depth > MAX_STACK_DEPTH)
 };
 
 // evals[i].table selects the output row of d_scale_out and the failure flag; evals[i].eig the eigen-system
