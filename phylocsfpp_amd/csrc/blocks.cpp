@@ -100,6 +100,7 @@ struct BlockEngine {
     // branch matrices; one job per tile, one edge-scale record per evaluation
     DeviceBuffer d_fjobs, d_fevals, d_scale, d_slot_branch;
     std::vector<FactoredJob> fjobs[2];
+    DeviceBuffer d_fact_stamps;  // PCSF_FACTORED_STAMPS: cycle sums of prune_factored (printed when the engine goes away)
     std::vector<ExpmEval> fevals[2];
     // Which path an evaluation of block b takes is decided once per block from the matrix work either path needs (in
     // MFMA instructions): explicit = 256 per branch + 64 per internal edge, wave and 64-site window; factored = 64 per
@@ -165,6 +166,10 @@ struct BlockEngine {
             }
         if (const char* v = std::getenv("PCSF_FACTORED_MAX_TILES")) fixed_max_tiles = std::max(0, std::atoi(v));
         if (const char* v = std::getenv("PCSF_EIGEN_HOST")) host_eigen = std::atoi(v) != 0;
+        if (std::getenv("PCSF_FACTORED_STAMPS")) {
+            HIP_TRY(d_fact_stamps.reserve(8 * sizeof(unsigned long long)));
+            HIP_TRY(hipMemsetAsync(d_fact_stamps.ptr, 0, 8 * sizeof(unsigned long long), stream));
+        }
         block_factored.assign(nb, 0);
         for (size_t b = 0; b < nb; ++b) block_factored[b] = block_prefers_factored(c, codons, stride, offsets[b], offsets[b + 1], fixed_max_tiles);
         std::vector<int32_t> slots(static_cast<size_t>(n - 1));
@@ -205,7 +210,16 @@ struct BlockEngine {
         ev_start = ev_side = nullptr;
     }
     std::vector<uint64_t> leaf_codes;  // [block][leaf][2]
-    ~BlockEngine() { release_sync_objects(); }
+    ~BlockEngine()
+    {
+        if (d_fact_stamps.ptr) {
+            unsigned long long h[8] = {0};
+            if (hipMemcpy(h, d_fact_stamps.ptr, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[3])
+                fprintf(stderr, "prune_factored stamps: %llu work-groups, per work-group %.0f cycles (prologue %.0f): %.1f scale loads waiting %.0f, %.1f products taking %.0f\n", h[3],
+                        double(h[0]) / h[3], double(h[6]) / h[3], double(h[4]) / h[3], double(h[1]) / h[3], double(h[5]) / h[3], double(h[2]) / h[3]);
+        }
+        release_sync_objects();
+    }
     BlockEngine(const BlockEngine&) = delete;
     BlockEngine& operator=(const BlockEngine&) = delete;
 
@@ -444,6 +458,7 @@ struct BlockEngine {
                 fp.out_lnz = d_lnz.as<double>();
                 fp.out_anc = want_anc ? d_anc.as<double>() : nullptr;
                 fp.deep = c->schedule.stack_depth > MAX_STACK_DEPTH ? 1u : 0u;
+                fp.stamps = d_fact_stamps.ptr ? d_fact_stamps.as<unsigned long long>() : nullptr;
                 HIP_TRY(launch_prune_factored(fp, st));
             }
         };

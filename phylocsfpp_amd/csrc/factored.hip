@@ -93,6 +93,13 @@ __global__ __launch_bounds__(256) void edge_scale_kernel(const ExpmEval* __restr
     }
 }
 
+__device__ __forceinline__ unsigned long long fact_clock()
+{
+    unsigned long long t;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
 // ---- the pruning kernel ----------------------------------------------------------------------------------------------
 // DEEP: the tree parks more than MAX_STACK_DEPTH_DEV tiles (none of the reference's eleven trees does): the parked tiles live in
 // scratch memory, dynamically indexed; otherwise in three register sets selected by work-group-uniform branches.
@@ -102,24 +109,33 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_fact[];
     double2_t* xbuf = reinterpret_cast<double2_t*>(lds_fact);                      // [2][4 waves][2 pairs][64 lanes]
     double* red = reinterpret_cast<double*>(lds_fact + 2 * 4 * 2 * 64 * 16);       // [2][4][16]
-    uint32_t* lprog = reinterpret_cast<uint32_t*>(red + 2 * 4 * 16);               // [n_ops]
-    int32_t* lslot = reinterpret_cast<int32_t*>(lprog + ((p.n_ops + 3) & ~3));     // [n_edges] slot -> branch
-    unsigned char* lcod = reinterpret_cast<unsigned char*>(lslot + ((p.n_edges + 3) & ~3));  // [n_leaves][16]
+    uint32_t* lprog = reinterpret_cast<uint32_t*>(red + 2 * 4 * 16);               // [n_ops rounded up to 64]
+    int32_t* lslot = reinterpret_cast<int32_t*>(lprog + ((p.n_ops + 63) & ~63u));  // [n_edges] slot -> branch
+    unsigned char* lcod = reinterpret_cast<unsigned char*>(lslot + ((p.n_edges + 3) & ~3u));  // [n_leaves][16]
+    unsigned char* lany = lcod + static_cast<size_t>(p.n_leaves) * 16;             // [n_leaves]: the leaf has a codon in the tile
 
     const FactoredJob job = p.jobs[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sj = lane & 15, g = lane >> 4;
+    const bool stamping = p.stamps != nullptr;
+    const unsigned long long t_begin = stamping ? fact_clock() : 0ull;
+    unsigned long long t_load = 0, t_prod = 0, n_load = 0, n_prod = 0;
 
-    for (int idx = tid; idx < p.n_leaves * 16; idx += 256) {
-        const int leaf = idx >> 4, s = idx & 15;
+    // the tile's codons, and per leaf whether it has a codon in any of the 16 columns (16 consecutive lanes hold one leaf's columns)
+    for (int base = 0; base < p.n_leaves * 16; base += 256) {
+        const int idx = base + tid, leaf = idx >> 4, s = idx & 15;
         unsigned c = 64u;
-        if (static_cast<uint32_t>(s) < job.n_sites) {
+        if (leaf < p.n_leaves && static_cast<uint32_t>(s) < job.n_sites) {
             c = p.codons[static_cast<size_t>(leaf) * p.leaf_stride + job.site0 + s];
             c = c > 64u ? 64u : c;
         }
-        lcod[idx] = static_cast<unsigned char>(c);
+        const unsigned long long has = __ballot(c != 64u);
+        if (leaf < p.n_leaves) {
+            lcod[idx] = static_cast<unsigned char>(c);
+            if (s == 0) lany[leaf] = ((has >> (16 * (lane >> 4))) & 0xffffull) != 0;
+        }
     }
-    for (int i = tid; i < p.n_ops; i += 256) lprog[i] = p.program[i];
+    for (int i = tid; i < static_cast<int>((p.n_ops + 63) & ~63u); i += 256) lprog[i] = p.program[i < static_cast<int>(p.n_ops) ? i : static_cast<int>(p.n_ops) - 1];
     for (int i = tid; i < p.n_edges; i += 256) lslot[i] = p.slot_branch[i];
 
     // this wave's 16 rows of R and L as MFMA A operands: k-step q needs M[16 wave + (lane & 15)][4q + (lane >> 4)]
@@ -134,11 +150,24 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
     const double* __restrict__ scale = p.edge_scale + static_cast<size_t>(job.eval) * p.n_branches * 64 + (wave * 4 + g) * 4;
     const double* __restrict__ Lrows = Lg + static_cast<size_t>(16 * wave + g) * 64;  // + 4r * 64 + codon
     __syncthreads();
+    // leaves 0..127 as two wave-uniform bit masks: most ops of a sparse tile then cost a few scalar instructions (the op loop's LDS
+    // look-ups, not the products, were 70 % of a tile's time: PCSF_FACTORED_STAMPS)
+    const unsigned long long t_prologue = stamping ? fact_clock() - t_begin : 0ull;
+    const unsigned long long has0 = __ballot(lane < p.n_leaves && lany[lane] != 0);
+    const unsigned long long has1 = __ballot(64 + lane < p.n_leaves && lany[64 + lane < p.n_leaves ? 64 + lane : 0] != 0);
+    auto leaf_has = [&](int a) __attribute__((always_inline)) -> bool {
+        if (a < 64) return (has0 >> a) & 1ull;
+        if (a < 128) return (has1 >> (a - 64)) & 1ull;
+        return lany[a] != 0;
+    };
 
     int nprod = 0;
     // out <- M v for the 64x16 tile whose rows 16 wave + g + 4r this lane holds in v[r]: all-gather through LDS, then
     // 16 MFMAs in two accumulator chains
-    auto matvec = [&](const double (&MA)[16], const Vec4& v) -> Vec4 {
+    // (two copies with the operand array named, not passed: a reference parameter made the compiler merge the two call paths and
+    // keep R's and L's rows in scratch memory)
+    auto matvecR = [&](const Vec4& v) __attribute__((always_inline)) -> Vec4 {
+        const unsigned long long t_in = stamping ? fact_clock() : 0ull;
         double2_t* xb = xbuf + (nprod & 1) * (4 * 2 * 64);
         ++nprod;
         xb[(wave * 2 + 0) * 64 + lane] = double2_t{v.v[0], v.v[1]};
@@ -150,17 +179,53 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
         double4_t a0 = double4_t{0.0, 0.0, 0.0, 0.0}, a1 = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(MA[2 * i], b[i].x, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(MA[2 * i + 1], b[i].y, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(RA[2 * i], b[i].x, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(RA[2 * i + 1], b[i].y, a1, 0, 0, 0);
         }
         Vec4 out;
 #pragma unroll
         for (int r = 0; r < 4; ++r) out.v[r] = a0[r] + a1[r];
+        if (stamping) {
+            asm volatile("" ::"v"(out.v[0]), "v"(out.v[3]));
+            t_prod += fact_clock() - t_in;
+            ++n_prod;
+        }
         return out;
     };
-    auto load_scale = [&](int branch) -> Vec4 {
+    auto matvecL = [&](const Vec4& v) __attribute__((always_inline)) -> Vec4 {
+        const unsigned long long t_in = stamping ? fact_clock() : 0ull;
+        double2_t* xb = xbuf + (nprod & 1) * (4 * 2 * 64);
+        ++nprod;
+        xb[(wave * 2 + 0) * 64 + lane] = double2_t{v.v[0], v.v[1]};
+        xb[(wave * 2 + 1) * 64 + lane] = double2_t{v.v[2], v.v[3]};
+        __syncthreads();
+        double2_t b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] = xb[i * 64 + lane];  // k-steps q = 2i, 2i + 1
+        double4_t a0 = double4_t{0.0, 0.0, 0.0, 0.0}, a1 = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(LA[2 * i], b[i].x, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(LA[2 * i + 1], b[i].y, a1, 0, 0, 0);
+        }
+        Vec4 out;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out.v[r] = a0[r] + a1[r];
+        if (stamping) {
+            asm volatile("" ::"v"(out.v[0]), "v"(out.v[3]));
+            t_prod += fact_clock() - t_in;
+            ++n_prod;
+        }
+        return out;
+    };
+    auto load_scale = [&](int branch) __attribute__((always_inline)) -> Vec4 {
+        const unsigned long long t_in = stamping ? fact_clock() : 0ull;
         const double2_t* s2 = reinterpret_cast<const double2_t*>(scale + static_cast<size_t>(branch) * 64);
         const double2_t lo = s2[0], hi = s2[1];
+        if (stamping) {
+            t_load += fact_clock() - t_in;   // fact_clock waits for the loads
+            ++n_load;
+        }
         return Vec4{{lo.x, lo.y, hi.x, hi.y}};
     };
     // c = L 1 in this lane's rows: the eigen-coordinates of the all-ones message (a gap column of a leaf)
@@ -187,24 +252,25 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
         uint32_t mask;
         bool eig;
     };
-    auto to_real = [&](const Msg& m) -> Msg {
+    auto to_real = [&](const Msg& m) __attribute__((always_inline)) -> Msg {
         if (m.mask == 0xffffu) return Msg{Vec4{{1.0, 1.0, 1.0, 1.0}}, 0xffffu, false};
         if (!m.eig) return m;
-        Msg out{matvec(RA, m.v), m.mask, false};
+        Msg out{matvecR(m.v), m.mask, false};
         const bool gap_col = (m.mask >> sj) & 1u;
 #pragma unroll
         for (int r = 0; r < 4; ++r) out.v.v[r] = gap_col ? 1.0 : fmax(out.v.v[r], 0.0);
         return out;
     };
-    auto apply_edge = [&](int branch, const Msg& m) -> Msg {
+    auto apply_edge = [&](int slot_index, const Msg& m) __attribute__((always_inline)) -> Msg {   // the edge of program slot slot_index
         if (m.mask == 0xffffu) return m;
-        const Vec4 e = load_scale(branch);
-        Msg out{m.eig ? m.v : matvec(LA, m.v), m.mask, true};
+        const Vec4 e = load_scale(lslot[slot_index]);
+        Msg out{m.eig ? m.v : matvecL(m.v), m.mask, true};
 #pragma unroll
         for (int r = 0; r < 4; ++r) out.v.v[r] *= e.v[r];
         return out;
     };
-    auto leaf = [&](int a) -> Msg {
+    auto leaf = [&](int a) __attribute__((always_inline)) -> Msg {
+        if (!leaf_has(a)) return Msg{Vec4{{1.0, 1.0, 1.0, 1.0}}, 0xffffu, false};
         const unsigned code = lcod[a * 16 + sj];
         const uint32_t mask = static_cast<uint32_t>(__ballot(code == 64u)) & 0xffffu;   // lanes 0..15 hold the 16 sites
         if (mask == 0xffffu) return Msg{Vec4{{1.0, 1.0, 1.0, 1.0}}, mask, false};
@@ -215,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
         for (int r = 0; r < 4; ++r) out.v.v[r] = e.v[r] * (code == 64u ? cgap.v[r] : Lrows[r * 256 + col]);
         return out;
     };
-    auto mul = [&](const Msg& x, const Msg& y) -> Msg {
+    auto mul = [&](const Msg& x, const Msg& y) __attribute__((always_inline)) -> Msg {
         if (x.mask == 0xffffu) return y;
         if (y.mask == 0xffffu) return x;
         const Msg a = to_real(x), b = to_real(y);
@@ -228,43 +294,59 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
     // parked messages: pushes and pops nest, so a stack pointer replaces the slot numbers of the op codes (which deep
     // trees do not carry, schedule.hpp).  An all-ones tile is never stored or loaded.
     Vec4 stk[DEEP ? MAX_STACK_DEPTH_DEEP_DEV : 1], s0{{1.0, 1.0, 1.0, 1.0}}, s1 = s0, s2 = s0;
-    uint32_t stk_mask[DEEP ? MAX_STACK_DEPTH_DEEP_DEV : MAX_STACK_DEPTH_DEV];
+    uint32_t stk_mask[DEEP ? MAX_STACK_DEPTH_DEEP_DEV : 1];
+    unsigned long long packed_masks = 0;   // shallow trees: 16 bits per parked message, no indexed array (it would live in scratch)
     uint32_t stk_eig = 0;  // bit d: parked message d is in eigen form
-    auto park = [&](int d, const Msg& m) {
-        stk_mask[d] = m.mask;
+    auto park = [&](int d, const Msg& m) __attribute__((always_inline)) {
+        if (DEEP) stk_mask[d] = m.mask;
+        else packed_masks = (packed_masks & ~(0xffffull << (16 * d))) | (static_cast<unsigned long long>(m.mask) << (16 * d));
         stk_eig = (stk_eig & ~(1u << d)) | (m.eig ? 1u << d : 0u);
         if (m.mask == 0xffffu) return;
         if (DEEP) {
             stk[d] = m.v;
-        } else {
-            if (d == 0) s0 = m.v;
-            else if (d == 1) s1 = m.v;
-            else s2 = m.v;
+        } else {   // value selects, component by component: selecting between the three ADDRESSES sends all of them to scratch memory
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s0.v[r] = d == 0 ? m.v.v[r] : s0.v[r];
+                s1.v[r] = d == 1 ? m.v.v[r] : s1.v[r];
+                s2.v[r] = d == 2 ? m.v.v[r] : s2.v[r];
+            }
         }
     };
-    auto parked = [&](int d) -> Msg {
-        Msg m{Vec4{{1.0, 1.0, 1.0, 1.0}}, stk_mask[d], ((stk_eig >> d) & 1u) != 0};
+    auto parked = [&](int d) __attribute__((always_inline)) -> Msg {
+        Msg m{Vec4{{1.0, 1.0, 1.0, 1.0}}, DEEP ? stk_mask[d] : static_cast<uint32_t>((packed_masks >> (16 * d)) & 0xffffull), ((stk_eig >> d) & 1u) != 0};
         if (m.mask == 0xffffu) return m;
-        if (DEEP) m.v = stk[d];
-        else m.v = d == 0 ? s0 : (d == 1 ? s1 : s2);
+        if (DEEP) {
+            m.v = stk[d];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m.v.v[r] = d == 0 ? s0.v[r] : (d == 1 ? s1.v[r] : s2.v[r]);
+        }
         return m;
     };
     Msg cur{Vec4{{1.0, 1.0, 1.0, 1.0}}, 0xffffu, false};
     int slot = 0, sp = 0;
-    for (int ip = 0; ip < p.n_ops; ++ip) {
-        const uint32_t op = lprog[ip];
+    // The op loop must not wait on memory for a trivial op (both subtrees all gaps: most ops of a sparse tile): every dependent
+    // LDS, scalar or scratch access there is a round trip of its own (tools/factored_tile_cost.py: an all-gap tile took 80-110 k
+    // cycles for its 100 ops while the parked tiles' column masks lived in a dynamically indexed -- i.e. scratch -- array).  The
+    // ops come 64 at a time, one per lane; a slot's branch number is looked up only when its edge has something to do.
+    const int n_ops = static_cast<int>(p.n_ops);
+    uint32_t op_lanes = 0;   // 64 ops at a time, one per lane: one LDS read per 64 ops, the op itself through v_readlane
+    for (int ip = 0; ip < n_ops; ++ip) {
+        if ((ip & 63) == 0) op_lanes = lprog[ip + lane];
+        const uint32_t op = __builtin_amdgcn_readlane(op_lanes, ip & 63);
         const uint32_t code = op >> 28;
         const int a = (op >> 14) & 0x3fff, b = op & 0x3fff;
         if (code == F_CHERRY_DEV) {
             cur = mul(leaf(a), leaf(b));
         } else if (code == F_MM_LEAF_DEV) {
-            cur = mul(apply_edge(lslot[slot++], cur), leaf(a));
+            cur = mul(apply_edge(slot++, cur), leaf(a));
         } else if (code >= F_MM_PUSH_CHERRY0_DEV && code < F_MM_POP0_DEV) {
-            park(sp, apply_edge(lslot[slot++], cur));
+            park(sp, apply_edge(slot++, cur));
             ++sp;
             cur = mul(leaf(a), leaf(b));
         } else if (code >= F_MM_POP0_DEV && code < F_ROOT_DEV) {
-            const Msg m = apply_edge(lslot[slot++], cur);
+            const Msg m = apply_edge(slot++, cur);
             --sp;
             cur = mul(parked(sp), m);
         } else {  // F_ROOT: z = prior . alpha_root, ln z; the ancestral term sum_x ln(prior_x) prior_x alpha_x / z
@@ -297,6 +379,15 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
             }
         }
     }
+    if (stamping && tid == 0) {
+        atomicAdd(p.stamps + 0, fact_clock() - t_begin);
+        atomicAdd(p.stamps + 1, t_load);
+        atomicAdd(p.stamps + 2, t_prod);
+        atomicAdd(p.stamps + 3, 1ull);
+        atomicAdd(p.stamps + 4, n_load);
+        atomicAdd(p.stamps + 5, n_prod);
+        atomicAdd(p.stamps + 6, t_prologue);
+    }
 }
 
 hipError_t launch_edge_scale(const ExpmEval* d_evals, uint32_t n_evals, uint32_t n_branches, const float* d_branch_len, const double* d_eig_right,
@@ -311,8 +402,8 @@ hipError_t launch_edge_scale(const ExpmEval* d_evals, uint32_t n_evals, uint32_t
 hipError_t launch_prune_factored(const FactoredParams& p, hipStream_t stream)
 {
     if (p.n_jobs == 0) return hipSuccess;
-    const size_t lds = 2 * 4 * 2 * 64 * 16 + 2 * 4 * 16 * 8 + ((static_cast<size_t>(p.n_ops) + 3) & ~size_t(3)) * 4 +
-                       ((static_cast<size_t>(p.n_edges) + 3) & ~size_t(3)) * 4 + static_cast<size_t>(p.n_leaves) * 16;
+    const size_t lds = 2 * 4 * 2 * 64 * 16 + 2 * 4 * 16 * 8 + ((static_cast<size_t>(p.n_ops) + 63) & ~size_t(63)) * 4 +
+                       ((static_cast<size_t>(p.n_edges) + 3) & ~size_t(3)) * 4 + static_cast<size_t>(p.n_leaves) * 17;
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     if (p.deep) {
         if (p.out_anc) hipLaunchKernelGGL((prune_factored<true, true>), dim3(p.n_jobs), dim3(256), lds, stream, p);
