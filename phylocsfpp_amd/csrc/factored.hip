@@ -8,6 +8,8 @@
 //     internal edge   m = R (e_b o (L v))          two 64x64 x (64x16) products
 //     leaf edge       m = R (e_b o L[:, codon])    one product; nothing at all when the leaf is a gap in all 16 columns
 //     all-gap subtree m = P 1 = 1                  nothing (the reference gets 1 +- 1 ulp from its row sums)
+//     edge above an edge whose sibling is an all-gap subtree:  y <- e_b o y, no product (L R = I; the message stays in eigen
+//                                                  coordinates until two children meet -- see `struct Msg` in the kernel)
 // with e_b[k] = exp(lambda_k t_b) from edge_scale_kernel (one exponential per eigenvalue, branch and evaluation).
 //
 // Mapping: ONE WORK-GROUP PER TILE (16 columns of one evaluation), its four waves split every product by OUTPUT ROWS:
@@ -102,7 +104,7 @@ __device__ __forceinline__ unsigned long long fact_clock()
 
 // ---- the pruning kernel ----------------------------------------------------------------------------------------------
 // DEEP: the tree parks more than MAX_STACK_DEPTH_DEV tiles (none of the reference's eleven trees does): the parked tiles live in
-// scratch memory, dynamically indexed; otherwise in three register sets selected by work-group-uniform branches.
+// scratch memory, dynamically indexed; otherwise in three register sets written and read with value selects (no scratch at all).
 template <bool ANC, bool DEEP>
 __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
 {
