@@ -37,3 +37,13 @@ python3 tools/diag_determinism.py 40 > $O/determinism.txt 2>&1
 python3 tools/objective_noise.py > $O/objective_noise.txt 2>&1
 python3 tools/omega_divergence.py 14 > $O/omega_divergence.txt 2>&1
 ls -la $O
+# ---- added at the end of round 2 (each line is what produced the file of that name under profiles/r02/) --------------------
+bash tools/startup_profile.sh > $O/startup_profile.txt 2>&1
+{ echo "register-resident form (default):"; bash tools/eigen_bench.sh 2>&1 | grep "eigen launch"; echo "LDS form (PCSF_EIGEN_LDS=1):"; PCSF_EIGEN_LDS=1 bash tools/eigen_bench.sh 2>&1 | grep "eigen launch"; PCSF_EIGEN_STAMPS=1 python3 tools/eigen_bench.py 200 2>&1 | grep stamps | head -4; } > $O/eigen_forms.txt
+for r in 1 4 16; do { echo "== bench_blocks.py - 0 $r nocpu, register-resident eigen-solver (default)"; PCSF_TIME_BLOCKS=1 python3 tools/bench_blocks.py - 0 $r nocpu 2>&1 | grep -v amdgpu; echo "== PCSF_EIGEN_LDS=1"; PCSF_EIGEN_LDS=1 PCSF_TIME_BLOCKS=1 python3 tools/bench_blocks.py - 0 $r nocpu 2>&1 | grep "run_omega\|OMEGA"; }; done > $O/blocks_bench_eigen_forms.txt
+for r in 1 2 4 8 16; do for g in 1 2; do echo "copies $r groups $g"; PCSF_BLOCK_GROUPS=$g python3 tools/bench_blocks.py - 0 $r nocpu 2>&1 | grep "GPU MLE\|GPU OMEGA"; done; done > $O/blocks_groups_raw.txt
+for r in 1 4 16; do python3 tools/bench_blocks.py - 0 $r nocpu 2>&1 | grep "GPU "; done > $O/blocks_final.txt
+{ python3 tools/factored_tile_cost.py 200; python3 tools/factored_tile_cost.py 3000; } 2>&1 | grep -v amdgpu > $O/factored_tile_cost.txt
+for r in 1 16; do rm -rf /tmp/pb; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -- python3 tools/bench_blocks.py - 0 $r nocpu > /tmp/pb.log 2>&1; echo "== bench_blocks.py - 0 $r nocpu"; grep "GPU " /tmp/pb.log; head -8 $(find /tmp/pb -name "*kernel_stats.csv" | head -1) | cut -c1-150; done > $O/blocks_kernel_stats_final.txt
+bash tools/config4_one_gpu.sh ${1:-evidence_r02}
+# (profiles/r02/fuzz_against_reference.txt comes from tools/fuzz_against_reference.py in the build container, where /root/reference exists)
