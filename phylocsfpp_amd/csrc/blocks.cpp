@@ -215,8 +215,8 @@ struct BlockEngine {
         if (d_fact_stamps.ptr) {
             unsigned long long h[8] = {0};
             if (hipMemcpy(h, d_fact_stamps.ptr, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[3])
-                fprintf(stderr, "prune_factored stamps: %llu work-groups, per work-group %.0f cycles (prologue %.0f): %.1f scale loads waiting %.0f, %.1f products taking %.0f\n", h[3],
-                        double(h[0]) / h[3], double(h[6]) / h[3], double(h[4]) / h[3], double(h[1]) / h[3], double(h[5]) / h[3], double(h[2]) / h[3]);
+                fprintf(stderr, "prune_factored stamps: %llu work-groups, per work-group %.0f cycles (prologue %.0f, root op reached at %.0f): %.1f scale loads waiting %.0f, %.1f products taking %.0f\n", h[3],
+                        double(h[0]) / h[3], double(h[6]) / h[3], double(h[7]) / h[3], double(h[4]) / h[3], double(h[1]) / h[3], double(h[5]) / h[3], double(h[2]) / h[3]);
         }
         release_sync_objects();
     }

@@ -352,6 +352,7 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
             --sp;
             cur = mul(parked(sp), m);
         } else {  // F_ROOT: z = prior . alpha_root, ln z; the ancestral term sum_x ln(prior_x) prior_x alpha_x / z
+            if (stamping && tid == 0) atomicAdd(p.stamps + 7, fact_clock() - t_begin);   // cycles until the root op
             const Vec4 cur_v = to_real(cur).v;
             const double* __restrict__ pr = p.prior + static_cast<size_t>(job.eig) * 64 + g * 16 + 4 * wave;  // lane order [g][q], q = 4 wave + r
             double z = 0.0, t = 0.0;
