@@ -196,6 +196,12 @@ int pcsf_block_loglik_eig(pcsf_ctx *ctx, const double *right, const double *left
  * warm_settings (may be NULL): [n][12] settings whose eigenbasis the iteration starts from, as OMEGA does for its probes. */
 int pcsf_debug_eigen_omega(pcsf_ctx *ctx, const double *q_settings, const double *warm_settings, size_t n, double *right,
                            double *left, double *lambda, double *prior, int32_t *failed);
+/* host-only (works without a GPU): static facts about the ops of pcsf_build_schedule's program, for trees of at most 128 leaves
+ * (PCSF_ERR_UNSUPPORTED otherwise) -- leaves[2 i], leaves[2 i + 1]: the leaves whose messages op i's result contains (bit l of
+ * word l >> 6); meta[i] = program slot the op starts with | stack depth << 14 | (pops) index of the op that parked the tile << 18.
+ * The factored block-mode kernel skips the ops of all-gap subtrees with them (tests/test_schedule.py). */
+int pcsf_debug_program_facts(int32_t n_nodes, const int16_t *child1, const int16_t *child2, uint64_t *leaves, uint32_t *meta,
+                             int32_t cap_ops);
 /* host-only (works without a GPU): the pair schedule of the eigen-solver kernel (csrc/eigen.hip, register-resident variant) --
  * pairs[63][32][2]: the index pairs every step of one sweep rotates; located[15][16]: where each group of four indices
  * sits in each round (super-group | half << 3).  For tests/test_schedule.py: every pair exactly once, disjoint per step. */

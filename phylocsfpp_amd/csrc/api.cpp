@@ -269,6 +269,23 @@ int pcsf_build_schedule(int32_t n_nodes, const int16_t* child1, const int16_t* c
     return PCSF_OK;
 }
 
+int pcsf_debug_program_facts(int32_t n_nodes, const int16_t* child1, const int16_t* child2, uint64_t* leaves, uint32_t* meta, int32_t cap_ops)
+{
+    if (!child1 || !child2 || !leaves || !meta) return PCSF_ERR_INVALID_ARG;
+    try {
+        const pcsf::Schedule s = pcsf::build_schedule(pcsf::TreeView{n_nodes, child1, child2});
+        const pcsf::ProgramFacts f = pcsf::program_facts(s);
+        if (!f.ok) return PCSF_ERR_UNSUPPORTED;
+        if (static_cast<int32_t>(f.meta.size()) > cap_ops) return PCSF_ERR_INVALID_ARG;
+        std::copy(f.leaves.begin(), f.leaves.end(), leaves);
+        std::copy(f.meta.begin(), f.meta.end(), meta);
+    } catch (const std::exception& ex) {
+        g_create_error = std::string("pcsf_debug_program_facts: ") + ex.what();
+        return PCSF_ERR_INVALID_ARG;
+    }
+    return PCSF_OK;
+}
+
 int pcsf_create(pcsf_ctx** out, const pcsf_model_desc* m, int device_id)
 {
     if (!out || !m || !m->child1 || !m->child2 || !m->branch_len || !m->S_coding || !m->pi_coding || !m->S_noncoding ||
@@ -353,6 +370,18 @@ int pcsf_create(pcsf_ctx** out, const pcsf_model_desc* m, int device_id)
         (e = hipMemcpy(c->d_program.ptr, prog.data(), prog.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) {
         g_create_error = std::string("program upload: ") + hipGetErrorString(e);
         return PCSF_ERR_HIP;
+    }
+    {   // static facts about the ops (factored block-mode kernel: skipping the ops of all-gap subtrees); trees of <= 128 leaves
+        const pcsf::ProgramFacts facts = pcsf::program_facts(c->schedule);
+        if (facts.ok) {
+            if ((e = c->d_op_leaves.reserve(facts.leaves.size() * sizeof(uint64_t))) != hipSuccess ||
+                (e = hipMemcpy(c->d_op_leaves.ptr, facts.leaves.data(), facts.leaves.size() * sizeof(uint64_t), hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = c->d_op_meta.reserve(facts.meta.size() * sizeof(uint32_t))) != hipSuccess ||
+                (e = hipMemcpy(c->d_op_meta.ptr, facts.meta.data(), facts.meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) {
+                g_create_error = std::string("pcsf_create (program facts): ") + hipGetErrorString(e);
+                return PCSF_ERR_HIP;
+            }
+        }
     }
     int rc = upload_model_tables(c.get(), c->host_P.data(), prior);
     if (rc != PCSF_OK) {

@@ -447,6 +447,8 @@ struct BlockEngine {
                 fp.program = c->d_program.as<uint32_t>();
                 fp.n_ops = static_cast<int>(c->schedule.program.size());
                 fp.slot_branch = d_slot_branch.as<int32_t>();
+                fp.op_leaves = c->d_op_meta.ptr ? c->d_op_leaves.as<uint64_t>() : nullptr;
+                fp.op_meta = c->d_op_meta.ptr ? c->d_op_meta.as<uint32_t>() : nullptr;
                 fp.n_edges = ne;
                 fp.n_leaves = nl;
                 fp.n_branches = static_cast<uint32_t>(n - 1);

@@ -79,6 +79,7 @@ struct pcsf_ctx {
     std::vector<double> host_P;          // [2][n-1][64*64] at tree scale 1
     // device-resident model (table sets 0 = coding, 1 = non-coding at tree scale 1)
     pcsf::DeviceBuffer d_program, d_frag, d_leaf_tab, d_prior, d_anc_weight;
+    pcsf::DeviceBuffer d_op_leaves, d_op_meta;  // schedule.hpp ProgramFacts of the program (empty for trees of more than 128 leaves)
     // scratch for the host-pointer entry points
     pcsf::DeviceBuffer d_codons, d_out, d_lnz, d_anc, d_stamps, d_nucl, d_segments, d_wg_seg;
     bool dump_codons = false;            // diagnostics (PCSF_DUMP_CODONS=1): the fused front end also writes its codons to d_codons

@@ -327,30 +327,22 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
         return m;
     };
     Msg cur{Vec4{{1.0, 1.0, 1.0, 1.0}}, 0xffffu, false};
-    int slot = 0, sp = 0;
-    // The op loop must not wait on memory for a trivial op (both subtrees all gaps: most ops of a sparse tile): every dependent
-    // LDS, scalar or scratch access there is a round trip of its own (tools/factored_tile_cost.py: an all-gap tile took 80-110 k
-    // cycles for its 100 ops while the parked tiles' column masks lived in a dynamically indexed -- i.e. scratch -- array).  The
-    // ops come 64 at a time, one per lane; a slot's branch number is looked up only when its edge has something to do.
-    const int n_ops = static_cast<int>(p.n_ops);
-    uint32_t op_lanes = 0;   // 64 ops at a time, one per lane: one LDS read per 64 ops, the op itself through v_readlane
-    for (int ip = 0; ip < n_ops; ++ip) {
-        if ((ip & 63) == 0) op_lanes = lprog[ip + lane];
-        const uint32_t op = __builtin_amdgcn_readlane(op_lanes, ip & 63);
+    // one op: `slot` and `depth` are the program slot and the number of parked tiles the op starts with; parked_ones: the tile a
+    // pop takes back is known to be all ones whatever the registers hold (its parking op was skipped)
+    auto run_op = [&](uint32_t op, int slot, int depth, bool parked_ones) __attribute__((always_inline)) {
         const uint32_t code = op >> 28;
         const int a = (op >> 14) & 0x3fff, b = op & 0x3fff;
         if (code == F_CHERRY_DEV) {
             cur = mul(leaf(a), leaf(b));
         } else if (code == F_MM_LEAF_DEV) {
-            cur = mul(apply_edge(slot++, cur), leaf(a));
+            cur = mul(apply_edge(slot, cur), leaf(a));
         } else if (code >= F_MM_PUSH_CHERRY0_DEV && code < F_MM_POP0_DEV) {
-            park(sp, apply_edge(slot++, cur));
-            ++sp;
+            park(depth, apply_edge(slot, cur));
             cur = mul(leaf(a), leaf(b));
         } else if (code >= F_MM_POP0_DEV && code < F_ROOT_DEV) {
-            const Msg m = apply_edge(slot++, cur);
-            --sp;
-            cur = mul(parked(sp), m);
+            const Msg m = apply_edge(slot, cur);
+            if (parked_ones) cur = m;
+            else cur = mul(parked(depth - 1), m);
         } else {  // F_ROOT: z = prior . alpha_root, ln z; the ancestral term sum_x ln(prior_x) prior_x alpha_x / z
             if (stamping && tid == 0) atomicAdd(p.stamps + 7, fact_clock() - t_begin);   // cycles until the root op
             const Vec4 cur_v = to_real(cur).v;
@@ -380,6 +372,66 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
                     p.out_anc[job.out0 + sj] = zz == 0.0 ? 0.0 : tt / zz;
                 }
             }
+        }
+    };
+
+    const int n_ops = static_cast<int>(p.n_ops);
+    if (p.op_meta != nullptr) {
+        // Skipping the ops of all-gap subtrees.  A trivial op still costs ~430 cycles of branchy scalar code, and 70 of the 100 ops of
+        // a real tile (4 of 100 species present) are trivial.  schedule.hpp `program_facts` knows every op's leaf set, start slot,
+        // stack depth and, for a pop, the parking op; with the tile's leaf bits a lane-parallel pass marks the ops whose result is
+        // the all-ones tile, and the loop visits only the others (trees of at most 128 leaves: n_ops <= 128, two 64-bit sets).
+        uint32_t opw[2], mt[2];
+        unsigned long long ones_after[2], active[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int j = 64 * k + lane;
+            const bool valid = j < n_ops;
+            opw[k] = valid ? p.program[j] : (static_cast<uint32_t>(F_ROOT_DEV) << 28);
+            mt[k] = valid ? p.op_meta[j] : 0u;
+            const unsigned long long l0 = valid ? p.op_leaves[2 * j] : 0ull, l1 = valid ? p.op_leaves[2 * j + 1] : 0ull;
+            ones_after[k] = __ballot(valid && ((l0 & has0) | (l1 & has1)) == 0ull);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int j = 64 * k + lane;
+            const uint32_t code = opw[k] >> 28;
+            const bool is_push = code >= F_MM_PUSH_CHERRY0_DEV && code < F_MM_POP0_DEV, is_root = code >= F_ROOT_DEV;
+            const bool after = (ones_after[k] >> lane) & 1ull;
+            const bool before = lane > 0 ? ((ones_after[k] >> (lane - 1)) & 1ull) : (k == 1 && (ones_after[0] >> 63));   // op j - 1 left all ones
+            const bool trivial = j < n_ops && after && !is_root && (!is_push || before);
+            active[k] = __ballot(j < n_ops && !trivial);
+        }
+        for (int k = 0; k < 2; ++k) {
+            unsigned long long todo = active[k];
+            while (todo) {
+                const int l = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int i = 64 * k + l;
+                const uint32_t op = __builtin_amdgcn_readlane(opw[k], l), meta = __builtin_amdgcn_readlane(mt[k], l);
+                const bool ones_before = i > 0 && ((l > 0 ? ones_after[k] >> (l - 1) : ones_after[0] >> 63) & 1ull);
+                if (ones_before) {   // whatever cur holds is from before a run of skipped ops
+                    cur.mask = 0xffffu;
+                    cur.eig = false;
+                }
+                const int parking = static_cast<int>(meta >> 18);   // >= 1 for a pop
+                const bool parked_ones = parking > 0 && ((ones_after[(parking - 1) >> 6] >> ((parking - 1) & 63)) & 1ull);
+                run_op(op, static_cast<int>(meta & 0x3fffu), static_cast<int>((meta >> 14) & 0xfu), parked_ones);
+            }
+        }
+    } else {
+        // trees of more than 128 leaves: every op, slot and depth counted along the way
+        int slot = 0, sp = 0;
+        uint32_t op_lanes = 0;   // 64 ops at a time, one per lane: one LDS read per 64 ops, the op itself through v_readlane
+        for (int ip = 0; ip < n_ops; ++ip) {
+            if ((ip & 63) == 0) op_lanes = lprog[ip + lane];
+            const uint32_t op = __builtin_amdgcn_readlane(op_lanes, ip & 63);
+            const uint32_t code = op >> 28;
+            const int slot_here = slot, depth_here = sp;
+            if (code != F_CHERRY_DEV && code < F_ROOT_DEV) ++slot;
+            if (code >= F_MM_PUSH_CHERRY0_DEV && code < F_MM_POP0_DEV) ++sp;
+            else if (code >= F_MM_POP0_DEV && code < F_ROOT_DEV) --sp;
+            run_op(op, slot_here, depth_here, false);
         }
     }
     if (stamping && tid == 0) {

@@ -198,6 +198,59 @@ inline Schedule build_schedule(const TreeView& t)
     return s;
 }
 
+// Static facts about every op of the fused program, for kernels that skip the ops of all-gap subtrees (factored.hip): the leaves
+// whose messages the op's result (`cur` after the op) contains, the program slot and stack depth the op starts with, and for a
+// pop the op that parked the tile it takes back.  Trees of at most 128 leaves (two 64-bit leaf sets); `ok` is false otherwise.
+struct ProgramFacts {
+    bool ok = false;
+    std::vector<uint64_t> leaves;   // [n_ops][2]: bit l of word l >> 6
+    std::vector<uint32_t> meta;     // [n_ops]: slot | depth << 14 | parking op << 18
+};
+
+inline ProgramFacts program_facts(const Schedule& s)
+{
+    ProgramFacts f;
+    const size_t n_ops = s.program.size();
+    if (s.n_leaves > 128 || n_ops >= (1u << 14)) return f;
+    f.leaves.assign(2 * n_ops, 0);
+    f.meta.assign(n_ops, 0);
+    struct Set { uint64_t w[2] = {0, 0}; };
+    auto with = [](Set x, int leaf) { x.w[leaf >> 6] |= uint64_t(1) << (leaf & 63); return x; };
+    Set cur;
+    std::vector<std::pair<Set, uint32_t>> parked;   // (leaves of the parked message, index of the parking op)
+    uint32_t slot = 0;
+    for (size_t i = 0; i < n_ops; ++i) {
+        const uint32_t op = s.program[i], code = op >> 28;
+        const int a = static_cast<int>((op >> 14) & 0x3fff), b = static_cast<int>(op & 0x3fff);
+        uint32_t parking = 0;
+        const uint32_t depth = static_cast<uint32_t>(parked.size());
+        const uint32_t slot_here = slot;
+        if (code == F_CHERRY) {
+            cur = with(with(Set{}, a), b);
+        } else if (code == F_MM_LEAF) {
+            ++slot;
+            cur = with(cur, a);
+        } else if (code >= F_MM_PUSH_CHERRY0 && code < F_MM_POP0) {
+            ++slot;
+            parked.push_back({cur, static_cast<uint32_t>(i)});
+            cur = with(with(Set{}, a), b);
+        } else if (code >= F_MM_POP0 && code < F_ROOT) {
+            ++slot;
+            if (parked.empty()) throw std::logic_error("program_facts: pop without a parked tile");
+            parking = parked.back().second;
+            cur.w[0] |= parked.back().first.w[0];
+            cur.w[1] |= parked.back().first.w[1];
+            parked.pop_back();
+        }
+        if (depth > 15 || slot_here >= (1u << 14)) return ProgramFacts{};
+        f.leaves[2 * i] = cur.w[0];
+        f.leaves[2 * i + 1] = cur.w[1];
+        f.meta[i] = slot_here | (depth << 14) | (parking << 18);
+    }
+    f.ok = true;
+    return f;
+}
+
 // ---- device table layouts -------------------------------------------------------------------
 // MFMA v_mfma_f64_16x16x4_f64 computes D[16x16] += A[16x4] * B[4x16]; lane l supplies
 // A[l&15][l>>4] and B[l>>4][l&15] and receives D[(l>>4)+4r][l&15] in result register r.

@@ -189,3 +189,53 @@ def test_eigen_solver_pair_schedule_covers_every_pair_once():
         for G, s in enumerate(groups_of_sg):
             assert sorted(int(located[r, g]) & 7 for g in s) == [G, G]
             assert sorted(int(located[r, g]) >> 3 for g in s) == [0, 1]
+
+
+def test_program_facts_match_an_independent_walk_of_the_program():
+    """pcsf_debug_program_facts (csrc/schedule.hpp program_facts): per op, the leaves below its result, the slot and stack depth it
+    starts with, the op whose parked tile a pop takes back -- against a plain Python walk of the same program, on random trees."""
+    import ctypes as C
+    import phylocsfpp_amd as pa
+    lib = pa.load_library()
+    rng = np.random.default_rng(3)
+    for trial in range(40):
+        nl = int(rng.integers(2, 129))
+        c1, c2 = _random_tree(nl, rng)
+        n = 2 * nl - 1
+        prog = (C.c_uint32 * (4 * n))()
+        slots = (C.c_int32 * n)()
+        n_ops, n_slots, depth = C.c_int32(), C.c_int32(), C.c_int32()
+        a1 = np.ascontiguousarray(c1, np.int16)
+        a2 = np.ascontiguousarray(c2, np.int16)
+        p16 = C.POINTER(C.c_int16)
+        assert lib.pcsf_build_schedule(n, a1.ctypes.data_as(p16), a2.ctypes.data_as(p16), prog, 4 * n, slots, C.byref(n_ops), C.byref(n_slots), C.byref(depth)) == 0
+        leaves = (C.c_uint64 * (2 * n_ops.value))()
+        meta = (C.c_uint32 * n_ops.value)()
+        lib.pcsf_debug_program_facts.argtypes = [C.c_int32, p16, p16, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_int32]
+        rc = lib.pcsf_debug_program_facts(n, a1.ctypes.data_as(p16), a2.ctypes.data_as(p16), leaves, meta, n_ops.value)
+        if depth.value > 15:
+            assert rc != 0
+            continue
+        assert rc == 0
+        cur, parked, slot = set(), [], 0
+        for i in range(n_ops.value):
+            op = prog[i]
+            code, a, b = op >> 28, (op >> 14) & 0x3fff, op & 0x3fff
+            want_slot, want_depth, want_parking = slot, len(parked), 0
+            if code == 0:
+                cur = {a, b}
+            elif code == 1:
+                slot += 1
+                cur = cur | {a}
+            elif 2 <= code < 5:
+                slot += 1
+                parked.append((cur, i))
+                cur = {a, b}
+            elif 5 <= code < 8:
+                slot += 1
+                s, want_parking = parked.pop()
+                cur = cur | s
+            got = {l for l in range(128) if (leaves[2 * i + (l >> 6)] >> (l & 63)) & 1}
+            assert got == cur, (trial, i)
+            assert meta[i] == want_slot | (want_depth << 14) | (want_parking << 18), (trial, i)
+        assert cur == set(range(nl)) and not parked
