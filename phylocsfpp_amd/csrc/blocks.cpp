@@ -92,13 +92,42 @@ struct BlockEngine {
     hipStream_t stream;
     int ne, nl, n;
     DeviceBuffer d_codons;                 // [nl][leaf_stride] compact copy
-    DeviceBuffer d_frag, d_leaf, d_fail;   // table sets, one per evaluation of a run
+    DeviceBuffer d_frag, d_leaf;   // table sets, one per evaluation of a run
     DeviceBuffer d_eig_r, d_eig_l, d_eig_lam, d_eig_basis, d_prior, d_ancw;  // eigen-systems and their root priors
-    DeviceBuffer d_jobs, d_eig_jobs, d_wg0, d_wg1, d_wgt, d_wgp, d_wgo, d_lnz, d_anc;
+    DeviceBuffer d_jobs, d_wg0, d_wg1, d_wgt, d_wgp, d_wgo;
     DeviceBuffer d_branch_slot, d_branch_len, d_leaf_codes;  // per-branch constants; per (block, leaf) row masks
     // factored path (factored.hip): evaluations of blocks of at most fact_max_tiles 16-site tiles never form their
     // branch matrices; one job per tile, one edge-scale record per evaluation
-    DeviceBuffer d_fjobs, d_fevals, d_scale, d_slot_branch;
+    DeviceBuffer d_scale, d_slot_branch;
+    // One upload and one download per round: the eigen jobs, the factored path's evaluations and tile jobs travel in ONE page-locked
+    // blob (d_up), the outputs and failure flags come back in one (d_out) -- a round had ~9 small copies from / to pageable memory,
+    // each a synchronous staging copy of its own (~0.1 of a ~1 ms round).
+    struct PinnedBuffer {
+        void* ptr = nullptr;
+        size_t bytes = 0;
+        PinnedBuffer() = default;
+        PinnedBuffer(const PinnedBuffer&) = delete;
+        PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+        ~PinnedBuffer() { if (ptr) (void)hipHostFree(ptr); }
+        hipError_t reserve(size_t n)
+        {
+            if (n <= bytes) return hipSuccess;
+            if (ptr) (void)hipHostFree(ptr);
+            ptr = nullptr;
+            bytes = 0;
+            const hipError_t e = hipHostMalloc(&ptr, n + n / 2, hipHostMallocDefault);
+            if (e == hipSuccess) bytes = n + n / 2;
+            return e;
+        }
+    };
+    DeviceBuffer d_up, d_out;
+    PinnedBuffer h_up, h_out;
+    EigenJob* p_eig_jobs = nullptr;      // views into d_up / d_out, set by run()
+    ExpmEval* p_fevals = nullptr;
+    FactoredJob* p_fjobs = nullptr;
+    double* p_lnz = nullptr;
+    double* p_anc = nullptr;
+    uint32_t* p_fail = nullptr;
     std::vector<FactoredJob> fjobs[2];
     DeviceBuffer d_fact_stamps;  // PCSF_FACTORED_STAMPS: cycle sums of prune_factored (printed when the engine goes away)
     std::vector<ExpmEval> fevals[2];
@@ -231,7 +260,6 @@ struct BlockEngine {
     {
         if (tables <= cap_tables) return;
         if (!evals.empty()) throw std::runtime_error("BlockEngine: reserve_tables with evaluations queued");
-        HIP_TRY(d_fail.reserve(tables * sizeof(uint32_t)));
         HIP_TRY(d_scale.reserve(tables * static_cast<size_t>(n - 1) * 64 * sizeof(double)));
         cap_tables = tables;
         if (tables_allocated) allocate_tables();
@@ -329,8 +357,37 @@ struct BlockEngine {
     {
         const size_t tables = evals.size();
         if (tables == 0) return;
-        HIP_TRY(hipMemsetAsync(d_fail.ptr, 0, tables * sizeof(uint32_t), stream));
         const size_t nj0 = jobs[0].size(), nj1 = jobs[1].size(), nw0 = wg0[0].size(), nw1 = wg0[1].size();
+        const size_t nf0 = fjobs[0].size(), nf1 = fjobs[1].size(), nfe0 = fevals[0].size(), nfe1 = fevals[1].size();
+        auto aligned = [](size_t b) { return (b + 255) & ~size_t(255); };
+        {   // the download blob: [lnz | anc | fail]
+            const size_t out_bytes = aligned(out_used * 8), anc_bytes = want_anc ? out_bytes : 0;
+            HIP_TRY(d_out.reserve(out_bytes + anc_bytes + aligned(tables * sizeof(uint32_t))));
+            p_lnz = d_out.as<double>();
+            p_anc = reinterpret_cast<double*>(static_cast<char*>(d_out.ptr) + out_bytes);
+            p_fail = reinterpret_cast<uint32_t*>(static_cast<char*>(d_out.ptr) + out_bytes + anc_bytes);
+            HIP_TRY(hipMemsetAsync(p_fail, 0, tables * sizeof(uint32_t), stream));
+        }
+        {   // the upload blob: [eigen jobs | evaluations of the factored path (both sets) | tile jobs (both sets)]
+            const bool dev_eigen = !eig_jobs.empty() && !host_eigen;
+            const size_t b_eig = dev_eigen ? aligned(eig_jobs.size() * sizeof(EigenJob)) : 0, b_fev = aligned((nfe0 + nfe1) * sizeof(ExpmEval)),
+                         b_fj = aligned((nf0 + nf1) * sizeof(FactoredJob)), total = b_eig + b_fev + b_fj;
+            if (total) {
+                HIP_TRY(d_up.reserve(total));
+                HIP_TRY(h_up.reserve(total));
+                char* h = static_cast<char*>(h_up.ptr);
+                char* d = static_cast<char*>(d_up.ptr);
+                p_eig_jobs = reinterpret_cast<EigenJob*>(d);
+                p_fevals = reinterpret_cast<ExpmEval*>(d + b_eig);
+                p_fjobs = reinterpret_cast<FactoredJob*>(d + b_eig + b_fev);
+                if (dev_eigen) std::memcpy(h, eig_jobs.data(), eig_jobs.size() * sizeof(EigenJob));
+                if (nfe0) std::memcpy(h + b_eig, fevals[0].data(), nfe0 * sizeof(ExpmEval));
+                if (nfe1) std::memcpy(h + b_eig + nfe0 * sizeof(ExpmEval), fevals[1].data(), nfe1 * sizeof(ExpmEval));
+                if (nf0) std::memcpy(h + b_eig + b_fev, fjobs[0].data(), nf0 * sizeof(FactoredJob));
+                if (nf1) std::memcpy(h + b_eig + b_fev + nf0 * sizeof(FactoredJob), fjobs[1].data(), nf1 * sizeof(FactoredJob));
+                HIP_TRY(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, stream));
+            }
+        }
         if (!eig_jobs.empty() && host_eigen) {
             // parity mode (PCSF_EIGEN_HOST=1): the kappa/omega eigen-systems come from the HOST solver -- row-cyclic Jacobi from
             // a cold start, the oracle's algorithm -- instead of eigen_omega_kernel.  Far too slow for production (a few
@@ -346,13 +403,10 @@ struct BlockEngine {
             });
             const uint32_t one = 1u;
             for (size_t i = 0; i < eig_jobs.size(); ++i) {
-                if (bad[i]) HIP_TRY(hipMemcpyAsync(d_fail.as<uint32_t>() + eig_jobs[i].table, &one, sizeof one, hipMemcpyHostToDevice, stream));
+                if (bad[i]) HIP_TRY(hipMemcpyAsync(p_fail + eig_jobs[i].table, &one, sizeof one, hipMemcpyHostToDevice, stream));
                 else upload_eig(eig_jobs[i].eig, es[i]);
             }
             HIP_TRY(hipStreamSynchronize(stream));  // `one` is a stack temporary
-        } else if (!eig_jobs.empty()) {
-            HIP_TRY(d_eig_jobs.reserve(eig_jobs.size() * sizeof(EigenJob)));
-            HIP_TRY(hipMemcpyAsync(d_eig_jobs.ptr, eig_jobs.data(), eig_jobs.size() * sizeof(EigenJob), hipMemcpyHostToDevice, stream));
         }
         HIP_TRY(d_jobs.reserve((nj0 + nj1) * sizeof(ExpmEval)));
         if (nj0) HIP_TRY(hipMemcpyAsync(d_jobs.as<ExpmEval>(), jobs[0].data(), nj0 * sizeof(ExpmEval), hipMemcpyHostToDevice, stream));
@@ -364,8 +418,6 @@ struct BlockEngine {
             HIP_TRY(d_wgo.reserve(nw * 8));
             HIP_TRY(d_wgt.reserve(nw * 4));
             HIP_TRY(d_wgp.reserve(nw * 4));
-            HIP_TRY(d_lnz.reserve(out_used * 8));
-            HIP_TRY(d_anc.reserve(out_used * 8));
             for (int set = 0; set < 2; ++set) {
                 const size_t at = set ? nw0 : 0, cnt = wg0[set].size();
                 if (!cnt) continue;
@@ -375,19 +427,6 @@ struct BlockEngine {
                 HIP_TRY(hipMemcpyAsync(d_wgt.as<uint32_t>() + at, wgt[set].data(), cnt * 4, hipMemcpyHostToDevice, stream));
                 HIP_TRY(hipMemcpyAsync(d_wgp.as<uint32_t>() + at, wgp[set].data(), cnt * 4, hipMemcpyHostToDevice, stream));
             }
-        }
-        const size_t nf0 = fjobs[0].size(), nf1 = fjobs[1].size(), nfe0 = fevals[0].size(), nfe1 = fevals[1].size();
-        if (nfe0 + nfe1) {
-            HIP_TRY(d_fevals.reserve((nfe0 + nfe1) * sizeof(ExpmEval)));
-            if (nfe0) HIP_TRY(hipMemcpyAsync(d_fevals.as<ExpmEval>(), fevals[0].data(), nfe0 * sizeof(ExpmEval), hipMemcpyHostToDevice, stream));
-            if (nfe1) HIP_TRY(hipMemcpyAsync(d_fevals.as<ExpmEval>() + nfe0, fevals[1].data(), nfe1 * sizeof(ExpmEval), hipMemcpyHostToDevice, stream));
-        }
-        if (nf0 + nf1) {
-            HIP_TRY(d_fjobs.reserve((nf0 + nf1) * sizeof(FactoredJob)));
-            if (nf0) HIP_TRY(hipMemcpyAsync(d_fjobs.as<FactoredJob>(), fjobs[0].data(), nf0 * sizeof(FactoredJob), hipMemcpyHostToDevice, stream));
-            if (nf1) HIP_TRY(hipMemcpyAsync(d_fjobs.as<FactoredJob>() + nf0, fjobs[1].data(), nf1 * sizeof(FactoredJob), hipMemcpyHostToDevice, stream));
-            HIP_TRY(d_lnz.reserve(out_used * 8));
-            HIP_TRY(d_anc.reserve(out_used * 8));
         }
         const bool use_side = !eig_jobs.empty() || nj1 || nw1 || nfe1;
         if (use_side) {
@@ -411,7 +450,7 @@ struct BlockEngine {
                 ep.eig_lambda = d_eig_lam.as<double>();
                 ep.frag = d_frag.as<double>();
                 ep.leaf_tab = d_leaf.as<double>();
-                ep.fail = d_fail.as<uint32_t>();
+                ep.fail = p_fail;
                 HIP_TRY(launch_expm(ep, st));
             }
             if (nw) {
@@ -430,17 +469,17 @@ struct BlockEngine {
                 p.wg_prior = d_wgp.as<uint32_t>() + w_at;
                 p.wg_out = d_wgo.as<uint64_t>() + w_at;
                 p.n_wgs = nw;
-                p.out_lnz = d_lnz.as<double>();
-                p.out_anc = want_anc ? d_anc.as<double>() : nullptr;
+                p.out_lnz = p_lnz;
+                p.out_anc = want_anc ? p_anc : nullptr;
                 HIP_TRY(launch_prune_fixed(p, 16 | (c->schedule.stack_depth > MAX_STACK_DEPTH ? 64 : 0), st, 0));
             }
             const size_t nfe = set ? nfe1 : nfe0, fe_at = set ? nfe0 : 0, nf = set ? nf1 : nf0, f_at = set ? nf0 : 0;
             if (nfe)
-                HIP_TRY(launch_edge_scale(d_fevals.as<ExpmEval>() + fe_at, static_cast<uint32_t>(nfe), static_cast<uint32_t>(n - 1), d_branch_len.as<float>(),
-                                          d_eig_r.as<double>(), d_eig_l.as<double>(), d_eig_lam.as<double>(), d_scale.as<double>(), d_fail.as<uint32_t>(), st));
+                HIP_TRY(launch_edge_scale(p_fevals + fe_at, static_cast<uint32_t>(nfe), static_cast<uint32_t>(n - 1), d_branch_len.as<float>(),
+                                          d_eig_r.as<double>(), d_eig_l.as<double>(), d_eig_lam.as<double>(), d_scale.as<double>(), p_fail, st));
             if (nf) {
                 FactoredParams fp{};
-                fp.jobs = d_fjobs.as<FactoredJob>() + f_at;
+                fp.jobs = p_fjobs + f_at;
                 fp.n_jobs = static_cast<uint32_t>(nf);
                 fp.codons = d_codons.as<uint8_t>();
                 fp.leaf_stride = n_sites_total;
@@ -457,8 +496,8 @@ struct BlockEngine {
                 fp.prior = d_prior.as<double>();
                 fp.anc_weight = d_ancw.as<double>();
                 fp.edge_scale = d_scale.as<double>();
-                fp.out_lnz = d_lnz.as<double>();
-                fp.out_anc = want_anc ? d_anc.as<double>() : nullptr;
+                fp.out_lnz = p_lnz;
+                fp.out_anc = want_anc ? p_anc : nullptr;
                 fp.deep = c->schedule.stack_depth > MAX_STACK_DEPTH ? 1u : 0u;
                 fp.stamps = d_fact_stamps.ptr ? d_fact_stamps.as<unsigned long long>() : nullptr;
                 HIP_TRY(launch_prune_factored(fp, st));
@@ -467,7 +506,7 @@ struct BlockEngine {
         if (use_side) {
             if (!eig_jobs.empty() && !host_eigen) {
                 EigenParams gp{};
-                gp.jobs = d_eig_jobs.as<EigenJob>();
+                gp.jobs = p_eig_jobs;
                 gp.n_jobs = static_cast<uint32_t>(eig_jobs.size());
                 gp.eig_right = d_eig_r.as<double>();
                 gp.eig_left = d_eig_l.as<double>();
@@ -475,7 +514,7 @@ struct BlockEngine {
                 gp.eig_basis = d_eig_basis.as<double>();
                 gp.prior = d_prior.as<double>();
                 gp.anc_weight = d_ancw.as<double>();
-                gp.fail = d_fail.as<uint32_t>();
+                gp.fail = p_fail;
                 HIP_TRY(launch_eigen_omega(gp, side));
             }
             expm_and_prune(1, side);
@@ -483,17 +522,18 @@ struct BlockEngine {
         }
         expm_and_prune(0, stream);
         if (use_side) HIP_TRY(hipStreamWaitEvent(stream, ev_side, 0));
-        if (out_used) {
-            lnz.resize(out_used);
-            HIP_TRY(hipMemcpyAsync(lnz.data(), d_lnz.ptr, out_used * 8, hipMemcpyDeviceToHost, stream));
-            if (want_anc) {
-                anc.resize(out_used);
-                HIP_TRY(hipMemcpyAsync(anc.data(), d_anc.ptr, out_used * 8, hipMemcpyDeviceToHost, stream));
+        {   // one download: [lnz | anc | fail]
+            const size_t out_bytes = aligned(out_used * 8), anc_bytes = want_anc ? out_bytes : 0, all = out_bytes + anc_bytes + tables * sizeof(uint32_t);
+            HIP_TRY(h_out.reserve(all));
+            HIP_TRY(hipMemcpyAsync(h_out.ptr, d_out.ptr, all, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            const char* h = static_cast<const char*>(h_out.ptr);
+            if (out_used) {
+                lnz.assign(reinterpret_cast<const double*>(h), reinterpret_cast<const double*>(h) + out_used);
+                if (want_anc) anc.assign(reinterpret_cast<const double*>(h + out_bytes), reinterpret_cast<const double*>(h + out_bytes) + out_used);
             }
+            fail.assign(reinterpret_cast<const uint32_t*>(h + out_bytes + anc_bytes), reinterpret_cast<const uint32_t*>(h + out_bytes + anc_bytes) + tables);
         }
-        fail.resize(tables);
-        HIP_TRY(hipMemcpyAsync(fail.data(), d_fail.ptr, tables * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
         done_evals.swap(evals);
         evals.clear();
         for (int set = 0; set < 2; ++set) {
