@@ -42,21 +42,23 @@ struct Hmm {
 // state 0 = coding; states 1..3 = non-coding classes that can only be left towards coding
 inline Hmm make_coding_hmm(const HmmParams& p)
 {
-    double unnorm[3], c_to_nc[3], nc_to_c[3];
-    for (int i = 0; i < 3; ++i) {
-        unnorm[i] = p.non_coding_weights[i] * p.non_coding_lengths_in_codons[i];
-        c_to_nc[i] = p.non_coding_weights[i] / p.coding_length_in_codons;
-        nc_to_c[i] = 1.0 / p.non_coding_lengths_in_codons[i];
-    }
-    Hmm h;
+    Hmm h{};   // every transition not set below is impossible: a non-coding class is only left towards coding
+    const double* weight = p.non_coding_weights;
+    const double* length = p.non_coding_lengths_in_codons;
+    // a class's share of the non-coding positions is proportional to weight x mean length
+    const double mass[3] = {weight[0] * length[0], weight[1] * length[1], weight[2] * length[2]};
+    const double mass_sum = mass[0] + mass[1] + mass[2];
+    // a coding stretch ends with probability 1 / coding length, into class k with its weight
+    const double leave[3] = {weight[0] / p.coding_length_in_codons, weight[1] / p.coding_length_in_codons, weight[2] / p.coding_length_in_codons};
     h.init[0] = p.coding_prior;
-    const double unnorm_sum = unnorm[0] + unnorm[1] + unnorm[2];
-    for (int i = 0; i < 3; ++i) h.init[i + 1] = (1 - p.coding_prior) * unnorm[i] / unnorm_sum;
-    h.trans[0][0] = 1.0 - (c_to_nc[0] + c_to_nc[1] + c_to_nc[2]);
-    for (int j = 0; j < 3; ++j) h.trans[0][j + 1] = c_to_nc[j];
-    for (int i = 1; i < 4; ++i) {
-        h.trans[i][0] = nc_to_c[i - 1];
-        for (int j = 1; j < 4; ++j) h.trans[i][j] = i == j ? 1.0 - nc_to_c[i - 1] : 0.0;
+    h.trans[0][0] = 1.0 - (leave[0] + leave[1] + leave[2]);
+    for (int k = 0; k < 3; ++k) {
+        const int state = k + 1;
+        const double enter_coding = 1.0 / length[k];
+        h.init[state] = (1 - p.coding_prior) * mass[k] / mass_sum;
+        h.trans[0][state] = leave[k];
+        h.trans[state][0] = enter_coding;
+        h.trans[state][state] = 1.0 - enter_coding;
     }
     return h;
 }
