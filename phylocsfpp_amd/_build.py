@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libphylocsf_amd.so")
-SOURCES = ["kernels.hip", "expm.hip", "eigen.hip", "frontend.hip", "factored.hip", "api.cpp", "blocks.cpp", "model_abi.cpp"]
+SOURCES = ["kernels.hip", "expm.hip", "eigen.hip", "frontend.hip", "factored.hip", "tiles.hip", "api.cpp", "blocks.cpp", "model_abi.cpp"]
 HEADERS = ["kernels.h", "hostmath.hpp", "schedule.hpp", "ctx.hpp", "optimizer.hpp", "frames.hpp", os.path.join("..", "..", "include", "phylocsf_amd.h"),
            os.path.join("..", "host", "model_io.hpp")]
 
@@ -45,7 +45,8 @@ def build(force=False, verbose=False):
     # cost ~80 v_mov_b64 per op (and 26 spilled VGPRs).  Leaving uniform regions as plain scalar branches
     # removes both (no spills).
     per_source = {"kernels.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"],
-                  "factored.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"]}
+                  "factored.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"],
+                  "tiles.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"]}
     header_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS if os.path.exists(os.path.join(CSRC, h)))
     header_time = max(header_time, os.path.getmtime(os.path.abspath(__file__)))
     objs, jobs = [], []

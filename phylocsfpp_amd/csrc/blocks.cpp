@@ -129,6 +129,15 @@ struct BlockEngine {
     double* p_anc = nullptr;
     uint32_t* p_fail = nullptr;
     std::vector<FactoredJob> fjobs[2];
+    // tiles.hip (the default): every block of an engine that may apply the factors directly goes through prune_tiles -- one wave per
+    // tile, R and L resident in LDS -- whatever its length; jobs are ordered by eigen-system and cut into work-groups at run().
+    // PCSF_BLOCK_KERNEL=factored brings back round 2's pair (prune_factored for short / sparse blocks, expm + block-mode prune_fixed
+    // for long dense ones).
+    bool use_tiles = true;
+    size_t tile_jobs_per_group = TILE_JOBS_PER_GROUP;
+    std::vector<TileGroup> tgroups[2];
+    TileGroup* p_tgroups = nullptr;
+    std::vector<uint32_t> order_scratch;
     DeviceBuffer d_fact_stamps;  // PCSF_FACTORED_STAMPS: cycle sums of prune_factored (printed when the engine goes away)
     std::vector<ExpmEval> fevals[2];
     // Which path an evaluation of block b takes is decided once per block from the matrix work either path needs (in
@@ -194,13 +203,17 @@ struct BlockEngine {
                 leaf_codes[(b * nl + l) * 2 + 1] = hi;
             }
         if (const char* v = std::getenv("PCSF_FACTORED_MAX_TILES")) fixed_max_tiles = std::max(0, std::atoi(v));
+        if (const char* v = std::getenv("PCSF_BLOCK_KERNEL")) use_tiles = std::string(v) != "factored";
+        if (fixed_max_tiles >= 0) use_tiles = false;   // the tile-count rule is a statement about round 2's two paths
+        if (const char* v = std::getenv("PCSF_TILE_JOBS")) tile_jobs_per_group = static_cast<size_t>(std::max(1, std::atoi(v)));
         if (const char* v = std::getenv("PCSF_EIGEN_HOST")) host_eigen = std::atoi(v) != 0;
         if (std::getenv("PCSF_FACTORED_STAMPS")) {
             HIP_TRY(d_fact_stamps.reserve(8 * sizeof(unsigned long long)));
             HIP_TRY(hipMemsetAsync(d_fact_stamps.ptr, 0, 8 * sizeof(unsigned long long), stream));
         }
         block_factored.assign(nb, 0);
-        for (size_t b = 0; b < nb; ++b) block_factored[b] = block_prefers_factored(c, codons, stride, offsets[b], offsets[b + 1], fixed_max_tiles);
+        for (size_t b = 0; b < nb; ++b)
+            block_factored[b] = use_tiles ? 1 : block_prefers_factored(c, codons, stride, offsets[b], offsets[b + 1], fixed_max_tiles);
         std::vector<int32_t> slots(static_cast<size_t>(n - 1));
         for (int b = 0; b < n - 1; ++b) slots[b] = c->branch_slot[b];
         std::vector<int32_t> slot_branch(c->schedule.slot_node.begin(), c->schedule.slot_node.end());
@@ -327,7 +340,7 @@ struct BlockEngine {
             // short block: factors applied directly, one work-group per 16-site tile (an empty block only has its
             // model validated)
             fevals[set].push_back(ev);
-            for (uint64_t s = off[blk]; s < off[blk + 1]; s += 16) {
+            for (uint64_t s = off[blk]; !use_tiles && s < off[blk + 1]; s += 16) {
                 FactoredJob j{};
                 j.site0 = s;
                 j.out0 = out_used + (s - off[blk]);
@@ -357,8 +370,50 @@ struct BlockEngine {
     {
         const size_t tables = evals.size();
         if (tables == 0) return;
+        if (use_tiles)
+            for (int set = 0; set < 2; ++set) {
+                // tile jobs in the order of their eigen-systems (an evaluation's tiles stay together), cut into work-groups of at most
+                // TILE_JOBS_PER_GROUP jobs of ONE eigen-system
+                const std::vector<ExpmEval>& fe = fevals[set];
+                order_scratch.resize(fe.size());
+                for (uint32_t i = 0; i < fe.size(); ++i) order_scratch[i] = i;
+                std::stable_sort(order_scratch.begin(), order_scratch.end(), [&](uint32_t a, uint32_t b) { return fe[a].eig < fe[b].eig; });
+                fjobs[set].clear();
+                tgroups[set].clear();
+                size_t run0 = 0;
+                auto close_run = [&](size_t end) {   // jobs [run0, end) share an eigen-system: even parts of at most TILE_JOBS_PER_GROUP
+                    const size_t cnt = end - run0;
+                    if (!cnt) return;
+                    const size_t parts = (cnt + tile_jobs_per_group - 1) / tile_jobs_per_group;
+                    for (size_t k = 0; k < parts; ++k) {
+                        const size_t a = run0 + cnt * k / parts, b = run0 + cnt * (k + 1) / parts;
+                        tgroups[set].push_back({static_cast<uint32_t>(a), static_cast<uint32_t>(b - a)});
+                    }
+                    run0 = end;
+                };
+                uint32_t run_eig = 0;
+                for (uint32_t i : order_scratch) {
+                    const ExpmEval& ev = fe[i];
+                    if (ev.eig != run_eig) {
+                        close_run(fjobs[set].size());
+                        run_eig = ev.eig;
+                    }
+                    const uint64_t s0 = off[ev.block], s1 = off[ev.block + 1], out0 = evals[ev.table].out0;
+                    for (uint64_t s = s0; s < s1; s += 16) {
+                        FactoredJob j{};
+                        j.site0 = s;
+                        j.out0 = out0 + (s - s0);
+                        j.n_sites = static_cast<uint32_t>(std::min<uint64_t>(16, s1 - s));
+                        j.eig = ev.eig;
+                        j.eval = ev.table;
+                        fjobs[set].push_back(j);
+                    }
+                }
+                close_run(fjobs[set].size());
+            }
         const size_t nj0 = jobs[0].size(), nj1 = jobs[1].size(), nw0 = wg0[0].size(), nw1 = wg0[1].size();
         const size_t nf0 = fjobs[0].size(), nf1 = fjobs[1].size(), nfe0 = fevals[0].size(), nfe1 = fevals[1].size();
+        const size_t ng0 = tgroups[0].size(), ng1 = tgroups[1].size();
         auto aligned = [](size_t b) { return (b + 255) & ~size_t(255); };
         {   // the download blob: [lnz | anc | fail]
             const size_t out_bytes = aligned(out_used * 8), anc_bytes = want_anc ? out_bytes : 0;
@@ -371,7 +426,7 @@ struct BlockEngine {
         {   // the upload blob: [eigen jobs | evaluations of the factored path (both sets) | tile jobs (both sets)]
             const bool dev_eigen = !eig_jobs.empty() && !host_eigen;
             const size_t b_eig = dev_eigen ? aligned(eig_jobs.size() * sizeof(EigenJob)) : 0, b_fev = aligned((nfe0 + nfe1) * sizeof(ExpmEval)),
-                         b_fj = aligned((nf0 + nf1) * sizeof(FactoredJob)), total = b_eig + b_fev + b_fj;
+                         b_fj = aligned((nf0 + nf1) * sizeof(FactoredJob)), b_tg = aligned((ng0 + ng1) * sizeof(TileGroup)), total = b_eig + b_fev + b_fj + b_tg;
             if (total) {
                 HIP_TRY(d_up.reserve(total));
                 HIP_TRY(h_up.reserve(total));
@@ -380,6 +435,9 @@ struct BlockEngine {
                 p_eig_jobs = reinterpret_cast<EigenJob*>(d);
                 p_fevals = reinterpret_cast<ExpmEval*>(d + b_eig);
                 p_fjobs = reinterpret_cast<FactoredJob*>(d + b_eig + b_fev);
+                p_tgroups = reinterpret_cast<TileGroup*>(d + b_eig + b_fev + b_fj);
+                if (ng0) std::memcpy(h + b_eig + b_fev + b_fj, tgroups[0].data(), ng0 * sizeof(TileGroup));
+                if (ng1) std::memcpy(h + b_eig + b_fev + b_fj + ng0 * sizeof(TileGroup), tgroups[1].data(), ng1 * sizeof(TileGroup));
                 if (dev_eigen) std::memcpy(h, eig_jobs.data(), eig_jobs.size() * sizeof(EigenJob));
                 if (nfe0) std::memcpy(h + b_eig, fevals[0].data(), nfe0 * sizeof(ExpmEval));
                 if (nfe1) std::memcpy(h + b_eig + nfe0 * sizeof(ExpmEval), fevals[1].data(), nfe1 * sizeof(ExpmEval));
@@ -500,7 +558,13 @@ struct BlockEngine {
                 fp.out_anc = want_anc ? p_anc : nullptr;
                 fp.deep = c->schedule.stack_depth > MAX_STACK_DEPTH ? 1u : 0u;
                 fp.stamps = d_fact_stamps.ptr ? d_fact_stamps.as<unsigned long long>() : nullptr;
-                HIP_TRY(launch_prune_factored(fp, st));
+                if (use_tiles) {
+                    fp.groups = p_tgroups + (set ? ng0 : 0);
+                    fp.n_groups = static_cast<uint32_t>(set ? ng1 : ng0);
+                    HIP_TRY(launch_prune_tiles(fp, st));
+                } else {
+                    HIP_TRY(launch_prune_factored(fp, st));
+                }
             }
         };
         if (use_side) {
@@ -544,6 +608,7 @@ struct BlockEngine {
             wgt[set].clear();
             wgp[set].clear();
             fjobs[set].clear();
+            tgroups[set].clear();
             fevals[set].clear();
         }
         eig_jobs.clear();
@@ -568,19 +633,40 @@ struct EvalStore {
     struct Entry {
         double x, lpr, anc;
         bool failed;
+        mutable bool used = false;   // diagnostics: the optimiser consumed this value (speculative evaluations may never be)
     };
     std::vector<Entry> entries;
+    size_t n_used = 0, n_unused = 0;   // over the stages cleared so far
     const Entry* find(double x) const
     {
         for (const Entry& e : entries)
             if (e.x == x) return &e;
         return nullptr;
     }
-    void clear() { entries.clear(); }
+    void tally()
+    {
+        for (const Entry& e : entries) (e.used ? n_used : n_unused) += 1;
+    }
+    void clear()
+    {
+        tally();
+        entries.clear();
+    }
 };
 
 constexpr int MAX_POINTS_PER_ROUND = 12;   // per block: certain points first, then speculative restarts
 constexpr int MAX_SPECULATIVE_RESTARTS = 8;
+// Random restarts are evaluated ahead of knowing that a search needs any only while fewer blocks than this are active: with
+// thousands of blocks a round is bound by its work, not its latency, and a third of OMEGA's evaluations were such restarts
+// that no optimiser ever asked for (PCSF_EAGER_RESTARTS_BELOW overrides)
+inline size_t eager_restarts_below()
+{
+    static const size_t v = [] {
+        const char* e = std::getenv("PCSF_EAGER_RESTARTS_BELOW");
+        return e ? static_cast<size_t>(std::max(0L, std::atol(e))) : size_t(1024);
+    }();
+    return v;
+}
 
 struct Lookahead {  // MaxLik1D::upcoming() of one block for the current round
     int n = 0;
@@ -680,6 +766,7 @@ int run_mle(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_bl
                         failed[b] = 1;
                         break;
                     }
+                    e->used = true;
                     o.supply(e->lpr, e->anc);
                 }
             }
@@ -692,7 +779,7 @@ int run_mle(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_bl
         for (size_t b = 0; b < n_blocks; ++b)
             for (int model = 0; model < 2; ++model)
                 if (!failed[b] && (model == 0 || started1[b]) && !opt[model][b].done())
-                    ahead[model][b].n = opt[model][b].upcoming(ahead[model][b].x, MAX_POINTS_PER_ROUND, MAX_SPECULATIVE_RESTARTS);
+                    ahead[model][b].n = opt[model][b].upcoming(ahead[model][b].x, MAX_POINTS_PER_ROUND, MAX_SPECULATIVE_RESTARTS, active < eager_restarts_below());
         for (int rank = 0; rank < MAX_POINTS_PER_ROUND && eng.free_evaluations() > 0; ++rank) {
             bool any = false;
             for (int model = 0; model < 2; ++model)
@@ -714,8 +801,17 @@ int run_mle(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_bl
             store[q.model][q.block].entries.push_back({q.x, eng.value(q.eval, eng.lnz), compute_anc ? eng.value(q.eval, eng.anc) : 0.0, eng.failed(q.eval)});
     }
     if (timing) {
+        size_t used = 0, unused = 0;
+        for (int model = 0; model < 2; ++model)
+            for (size_t b = 0; b < n_blocks; ++b) {
+                store[model][b].tally();
+                used += store[model][b].n_used;
+                unused += store[model][b].n_unused;
+            }
+        fprintf(stderr, "run_mle: %zu evaluations consumed by the optimisers, %zu speculative ones never asked for\n", used, unused);
         const double all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count();
-        fprintf(stderr, "run_mle: %zu blocks, %zu rounds, %zu evaluations: host %.3f s, device rounds %.3f s\n", n_blocks, rounds, n_evals, all - t_run, t_run);
+        fprintf(stderr, "run_mle: %zu blocks (%zu on the factored path), %zu rounds, %zu evaluations: host %.3f s, device rounds %.3f s\n", n_blocks,
+                static_cast<size_t>(std::count(eng.block_factored.begin(), eng.block_factored.end(), 1)), rounds, n_evals, all - t_run, t_run);
     }
     for (int model = 0; model < 2; ++model)
         for (size_t b = 0; b < n_blocks; ++b) {
@@ -875,6 +971,7 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
                 }
                 if (trace_block >= 0 && static_cast<size_t>(trace_block) == b)
                     fprintf(stderr, "TRACE omega stage %d x %.17g lpr %.17g\n", ob.stage, e->x, e->lpr);
+                e->used = true;
                 ob.opt.supply(e->lpr, 0.0);
             }
             if (!ob.failed && !ob.done) ++active;
@@ -898,7 +995,8 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
         std::vector<char> rebuilt(n_blocks, 0);  // block's own eigen-system slot is rebuilt in this run
         for (size_t b : live) {
             OmegaBlock& ob = *blk[b];
-            if (!ob.failed && !ob.done && !ob.needs_validation) ahead[b].n = ob.opt.upcoming(ahead[b].x, MAX_POINTS_PER_ROUND, MAX_SPECULATIVE_RESTARTS);
+            if (!ob.failed && !ob.done && !ob.needs_validation)
+                ahead[b].n = ob.opt.upcoming(ahead[b].x, MAX_POINTS_PER_ROUND, MAX_SPECULATIVE_RESTARTS, active < eager_restarts_below());
         }
         for (int rank = 0; rank < MAX_POINTS_PER_ROUND && eng.free_evaluations() > 0; ++rank) {
             bool any = false;
@@ -953,9 +1051,18 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
         t_host += secs(t0, t1) + secs(t2, now());
         t_run += secs(t1, t2);
     }
+    if (timing) {
+        size_t used = 0, unused = 0;
+        for (size_t b : live) {
+            blk[b]->store.tally();
+            used += blk[b]->store.n_used;
+            unused += blk[b]->store.n_unused;
+        }
+        fprintf(stderr, "run_omega: %zu evaluations consumed by the optimisers, %zu speculative ones never asked for\n", used, unused);
+    }
     if (timing)
-        fprintf(stderr, "run_omega: %zu blocks, %zu rounds, %zu evaluations (%zu with a new eigen-system): host %.3f s, device rounds %.3f s; engine set-up %.3f s, validation passes + F3x4 counts %.3f s, whole call %.3f s\n",
-                n_blocks, rounds, evals, eig_evals, t_host, t_run, t_setup, t_prelude, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count());
+        fprintf(stderr, "run_omega: %zu blocks (%zu on the factored path), %zu rounds, %zu evaluations (%zu with a new eigen-system): host %.3f s, device rounds %.3f s; engine set-up %.3f s, validation passes + F3x4 counts %.3f s, whole call %.3f s\n",
+                n_blocks, static_cast<size_t>(std::count(eng.block_factored.begin(), eng.block_factored.end(), 1)), rounds, evals, eig_evals, t_host, t_run, t_setup, t_prelude, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count());
     for (size_t b = 0; b < n_blocks; ++b) {
         const OmegaBlock& ob = *blk[b];
         out_phylo[b] = ob.failed ? NAN : decibans(ob.lpr_h1, ob.lpr_h0);
@@ -1088,8 +1195,12 @@ int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
         // are bounded by the eigen-system slots instead (3 per block, ~100 KB each) -- every chunk costs a full set of rounds.
         long max_tiles = -1;
         if (const char* v = std::getenv("PCSF_FACTORED_MAX_TILES")) max_tiles = std::max(0, std::atoi(v));
+        const char* kernel_env = std::getenv("PCSF_BLOCK_KERNEL");
+        const bool tiles = max_tiles < 0 && !(kernel_env && std::string(kernel_env) == "factored");   // BlockEngine::use_tiles
         std::atomic<bool> any_explicit{false};
-        if (codons)
+        if (tiles) {
+            // no block keeps tables
+        } else if (codons)
             parallel_for(n_blocks, [&](size_t b) {
                 if (!any_explicit.load(std::memory_order_relaxed) &&
                     !block_prefers_factored(c, codons, leaf_stride, site_offsets[b], site_offsets[b + 1], max_tiles))

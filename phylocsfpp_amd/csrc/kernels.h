@@ -112,9 +112,17 @@ struct FactoredJob {
     uint32_t pad;
 };
 
+// tiles.hip: work-group w takes jobs [job0, job0 + n_jobs) -- all of the same eigen-system -- one wave per job at a time
+struct TileGroup {
+    uint32_t job0, n_jobs;
+};
+constexpr uint32_t TILE_JOBS_PER_GROUP = 4;   // one per wave: measured on the configs[2] MAF (4 / 8 / 16: OMEGA 1.67 / 1.82 / 1.95 s)
+
 struct FactoredParams {
     const FactoredJob* jobs;
     uint32_t n_jobs;
+    const TileGroup* groups;    // tiles.hip only
+    uint32_t n_groups;
     const uint8_t* codons;      // [n_leaves][leaf_stride]
     size_t leaf_stride;
     const uint32_t* program;    // the fused pruning program of the context (schedule.hpp)
@@ -140,6 +148,9 @@ struct FactoredParams {
 hipError_t launch_edge_scale(const ExpmEval* d_evals, uint32_t n_evals, uint32_t n_branches, const float* d_branch_len, const double* d_eig_right,
                              const double* d_eig_left, const double* d_eig_lambda, double* d_scale_out, uint32_t* d_fail, hipStream_t stream);
 hipError_t launch_prune_factored(const FactoredParams& p, hipStream_t stream);
+// the same jobs, one wave per tile with R and L resident in LDS (tiles.hip); jobs sorted so that p.groups cut them by eigen-system
+hipError_t launch_prune_tiles(const FactoredParams& p, hipStream_t stream);
+size_t prune_tiles_lds_bytes(const FactoredParams& p);
 
 // Batched eigen-systems of the kappa/omega F3x4 rate matrix (eigen.hip): one job = one rate matrix.
 struct EigenJob {

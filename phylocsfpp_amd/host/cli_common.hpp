@@ -318,8 +318,11 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
                 fprintf(stderr, "  seconds: total %.3f; busy per stage (the stages overlap): MAF read %.3f, BLS %.3f, batch packing %.3f | scoring backend %.3f | wig output %.3f | smoothing %.3f\n",
                         st.total_seconds, st.read_seconds, st.bls_seconds, st.extract_seconds, st.backend_seconds, st.write_seconds, st.smooth_seconds);
             } else {
-                const std::string out = score_msa(model, argv[i], sm, backends);
+                ScoreMsaStats st;
+                const std::string out = score_msa(model, argv[i], sm, backends, &st);
                 fprintf(stderr, "%s -> %s\n", argv[i], out.c_str());
+                fprintf(stderr, "  %zu blocks, %zu codon columns; seconds: total %.3f (MAF read + translation + branch-length scores %.3f, scoring backend %.3f, output %.3f)\n",
+                        st.blocks, st.codon_columns, st.total_seconds, st.read_seconds, st.scoring_seconds, st.write_seconds);
             }
             first = false;
         }

@@ -760,9 +760,17 @@ struct ScoreMsaParams {
     std::string version_line = "# PhyloCSF scores computed with phylocsf-amd (MI355X)";
 };
 
-inline std::string score_msa(const Model& model, const std::string& maf_path, const ScoreMsaParams& prm, const std::vector<ScoringBackend*>& backends)
+struct ScoreMsaStats {
+    size_t blocks = 0, codon_columns = 0;
+    double read_seconds = 0.0, scoring_seconds = 0.0, write_seconds = 0.0, total_seconds = 0.0;
+};
+
+inline std::string score_msa(const Model& model, const std::string& maf_path, const ScoreMsaParams& prm, const std::vector<ScoringBackend*>& backends,
+                             ScoreMsaStats* stats = nullptr)
 {
     if (backends.empty()) throw std::runtime_error("score_msa: no scoring backend");
+    const auto t_enter = std::chrono::steady_clock::now();
+    auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     ScoringBackend& backend = *backends[0];
     std::string out_path = prm.output_dir.empty() ? maf_path + ".scores" : prm.output_dir + "/" + maf_path.substr(maf_path.find_last_of('/') == std::string::npos ? 0 : maf_path.find_last_of('/') + 1) + ".scores";
     FILE* out = open_out(out_path, "w");
@@ -799,6 +807,8 @@ inline std::string score_msa(const Model& model, const std::string& maf_path, co
     std::vector<uint8_t> codons(nl * stride);
     for (size_t l = 0; l < nl; ++l) std::copy(per_leaf[l].begin(), per_leaf[l].end(), codons.begin() + l * stride);
     std::vector<float> phylo(rows.size(), NAN), anc(rows.size(), NAN);
+    const double t_read = since(t_enter);
+    const auto t_score = std::chrono::steady_clock::now();
     if (prm.strategy == ALGO_FIXED_MEAN) {
         // src/phylocsf++score_msa.hpp:133-212: per-codon FIXED scores of the block (run_tracks), smoothed by the HMM as
         // ONE run, and the mean log-odds -- accumulated in float like the reference -- reported as the score; no anc score
@@ -833,6 +843,8 @@ inline std::string score_msa(const Model& model, const std::string& maf_path, co
                 backends[d]->score_blocks(prm.strategy, codons.data(), offsets.data() + b0, b1 - b0, stride, prm.comp_anc, 42u, phylo.data() + b0, anc.data() + b0);
         });
     }
+    const double t_scoring = since(t_score);
+    const auto t_write = std::chrono::steady_clock::now();
     for (size_t i = 0; i < rows.size(); ++i) {
         const Row& r = rows[i];
         fprintf(out, "%s\t%" PRIu64 "\t%" PRIu64 "\t%c", r.chrom.c_str(), r.start, r.end, r.strand);
@@ -842,6 +854,14 @@ inline std::string score_msa(const Model& model, const std::string& maf_path, co
         fprintf(out, "\n");
     }
     fclose(out);
+    if (stats) {
+        stats->blocks = rows.size();
+        stats->codon_columns = total;
+        stats->read_seconds = t_read;
+        stats->scoring_seconds = t_scoring;
+        stats->write_seconds = since(t_write);
+        stats->total_seconds = since(t_enter);
+    }
     return out_path;
 }
 
