@@ -93,7 +93,7 @@ struct BlockEngine {
     int ne, nl, n;
     DeviceBuffer d_codons;                 // [nl][leaf_stride] compact copy
     DeviceBuffer d_frag, d_leaf;   // table sets, one per evaluation of a run
-    DeviceBuffer d_eig_r, d_eig_l, d_eig_lam, d_eig_basis, d_prior, d_ancw;  // eigen-systems and their root priors
+    DeviceBuffer d_eig_r, d_eig_l, d_eig_lam, d_eig_basis, d_prior, d_ancw, d_eig_w;  // eigen-systems, their root priors, L = R^T diag(w)
     DeviceBuffer d_jobs, d_wg0, d_wg1, d_wgt, d_wgp, d_wgo;
     DeviceBuffer d_branch_slot, d_branch_len, d_leaf_codes;  // per-branch constants; per (block, leaf) row masks
     // factored path (factored.hip): evaluations of blocks of at most fact_max_tiles 16-site tiles never form their
@@ -294,15 +294,28 @@ struct BlockEngine {
         HIP_TRY(d_eig_basis.reserve_keep(count * 4096 * sizeof(double), cap_eig * 4096 * sizeof(double), stream));
         HIP_TRY(d_prior.reserve_keep(count * 64 * sizeof(double), cap_eig * 64 * sizeof(double), stream));
         HIP_TRY(d_ancw.reserve_keep(count * 64 * sizeof(double), cap_eig * 64 * sizeof(double), stream));
+        HIP_TRY(d_eig_w.reserve_keep(count * 64 * sizeof(double), cap_eig * 64 * sizeof(double), stream));
         cap_eig = count;
     }
-    // a host-side eigen-system (the ECM models of the context) and its root prior into slot idx
-    void upload_eig(size_t idx, const EigenSystem& es)
+    // a host-side eigen-system (the ECM models of the context) and its root prior into slot idx.  pi: the frequencies the rate matrix
+    // was symmetrised with (hostmath.hpp eigen_reversible: left = right^T diag(root / iroot)) -- tiles.hip needs them; null for
+    // caller-supplied eigen-systems, which never take that path.
+    void upload_eig(size_t idx, const EigenSystem& es, const double* pi = nullptr)
     {
         HIP_TRY(hipMemcpyAsync(d_eig_r.as<double>() + idx * 4096, es.right.data(), 4096 * sizeof(double), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(d_eig_l.as<double>() + idx * 4096, es.left.data(), 4096 * sizeof(double), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(d_eig_lam.as<double>() + idx * 64, es.lambda.data(), 64 * sizeof(double), hipMemcpyHostToDevice, stream));
         Vec w, pl, wl;
+        if (pi) {
+            Vec sw, swl;
+            for (int x = 0; x < 64; ++x) {
+                const double root = std::sqrt(pi[x]), iroot = 1.0 / root;
+                sw[x] = root / iroot;
+            }
+            to_lane_order(sw.data(), swl.data());
+            HIP_TRY(hipMemcpyAsync(d_eig_w.as<double>() + idx * 64, swl.data(), 64 * sizeof(double), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipStreamSynchronize(stream));  // swl is a stack temporary
+        }
         for (int x = 0; x < 64; ++x) w[x] = std::log(es.prior[x]) * es.prior[x];
         to_lane_order(es.prior.data(), pl.data());
         to_lane_order(w.data(), wl.data());
@@ -410,6 +423,7 @@ struct BlockEngine {
                     }
                 }
                 close_run(fjobs[set].size());
+                std::stable_sort(tgroups[set].begin(), tgroups[set].end(), [](const TileGroup& a, const TileGroup& b) { return a.n_jobs < b.n_jobs; });
             }
         const size_t nj0 = jobs[0].size(), nj1 = jobs[1].size(), nw0 = wg0[0].size(), nw1 = wg0[1].size();
         const size_t nf0 = fjobs[0].size(), nf1 = fjobs[1].size(), nfe0 = fevals[0].size(), nfe1 = fevals[1].size();
@@ -452,17 +466,17 @@ struct BlockEngine {
             // milliseconds per matrix); it exists to show how much of the OMEGA end-result scatter between this library
             // and the oracle is eigen-solver rounding (tests/test_gpu_parity_blocks.py).
             std::vector<EigenSystem> es(eig_jobs.size());
+            std::vector<Vec> pis(eig_jobs.size());
             std::vector<char> bad(eig_jobs.size(), 0);
             parallel_for(eig_jobs.size(), [&](size_t i) {
                 Mat Q;
-                Vec pi;
-                rate_matrix_omega(eig_jobs[i].qs, Q, pi);
-                bad[i] = !eigen_reversible(Q, pi.data(), es[i]);
+                rate_matrix_omega(eig_jobs[i].qs, Q, pis[i]);
+                bad[i] = !eigen_reversible(Q, pis[i].data(), es[i]);
             });
             const uint32_t one = 1u;
             for (size_t i = 0; i < eig_jobs.size(); ++i) {
                 if (bad[i]) HIP_TRY(hipMemcpyAsync(p_fail + eig_jobs[i].table, &one, sizeof one, hipMemcpyHostToDevice, stream));
-                else upload_eig(eig_jobs[i].eig, es[i]);
+                else upload_eig(eig_jobs[i].eig, es[i], pis[i].data());
             }
             HIP_TRY(hipStreamSynchronize(stream));  // `one` is a stack temporary
         }
@@ -551,6 +565,7 @@ struct BlockEngine {
                 fp.n_branches = static_cast<uint32_t>(n - 1);
                 fp.eig_right = d_eig_r.as<double>();
                 fp.eig_left = d_eig_l.as<double>();
+                fp.eig_w = d_eig_w.as<double>();
                 fp.prior = d_prior.as<double>();
                 fp.anc_weight = d_ancw.as<double>();
                 fp.edge_scale = d_scale.as<double>();
@@ -561,6 +576,9 @@ struct BlockEngine {
                 if (use_tiles) {
                     fp.groups = p_tgroups + (set ? ng0 : 0);
                     fp.n_groups = static_cast<uint32_t>(set ? ng1 : ng0);
+                    for (int k = 0; k < 3; ++k) fp.group_counts[k] = 0;
+                    for (const TileGroup& tg : tgroups[set])
+                        if (tg.n_jobs >= 1 && tg.n_jobs <= 3) ++fp.group_counts[tg.n_jobs - 1];
                     HIP_TRY(launch_prune_tiles(fp, st));
                 } else {
                     HIP_TRY(launch_prune_factored(fp, st));
@@ -578,6 +596,7 @@ struct BlockEngine {
                 gp.eig_basis = d_eig_basis.as<double>();
                 gp.prior = d_prior.as<double>();
                 gp.anc_weight = d_ancw.as<double>();
+                gp.eig_w = d_eig_w.as<double>();
                 gp.fail = p_fail;
                 HIP_TRY(launch_eigen_omega(gp, side));
             }
@@ -720,8 +739,8 @@ int run_mle(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_bl
     BlockEngine eng(c, codons, off, n_blocks, leaf_stride, own_streams);
     eng.reserve_tables(std::max<size_t>(64, 2 * n_blocks));
     eng.reserve_eig(2);
-    eng.upload_eig(0, c->eig[0]);
-    eng.upload_eig(1, c->eig[1]);
+    eng.upload_eig(0, c->eig[0], c->pi[0].data());
+    eng.upload_eig(1, c->eig[1], c->pi[1].data());
     std::vector<std::mt19937> gen(n_blocks);
     std::vector<MaxLik1D> opt[2] = {std::vector<MaxLik1D>(n_blocks), std::vector<MaxLik1D>(n_blocks)};
     std::vector<EvalStore> store[2] = {std::vector<EvalStore>(n_blocks), std::vector<EvalStore>(n_blocks)};
@@ -1093,7 +1112,7 @@ int block_loglik_impl(pcsf_ctx* c, int model, const double* q_settings, const do
         for (size_t k = 0; k < n_custom; ++k) eng.upload_eig(k, custom[k]);
     } else {
         eng.reserve_eig(1);
-        eng.upload_eig(0, c->eig[model]);
+        eng.upload_eig(0, c->eig[model], c->pi[model].data());
     }
     for (size_t b = 0; b < n_blocks; ++b) {
         const uint32_t eig = model == 2 ? static_cast<uint32_t>(b) : (model == 3 && n_custom > 1) ? static_cast<uint32_t>(b) : 0u;

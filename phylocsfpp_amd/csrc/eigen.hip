@@ -689,6 +689,7 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
         if (p.prior) p.prior[static_cast<size_t>(job.eig) * 64 + lane_pos] = pr;
         if (p.anc_weight) p.anc_weight[static_cast<size_t>(job.eig) * 64 + lane_pos] = log(pr) * pr;
         if (p.prior_plain) p.prior_plain[static_cast<size_t>(job.eig) * 64 + tid] = pr;
+        if (p.eig_w) p.eig_w[static_cast<size_t>(job.eig) * 64 + lane_pos] = root[tid] / iroot[tid];
     }
 }
 

@@ -121,8 +121,9 @@ constexpr uint32_t TILE_JOBS_PER_GROUP = 4;   // one per wave: measured on the c
 struct FactoredParams {
     const FactoredJob* jobs;
     uint32_t n_jobs;
-    const TileGroup* groups;    // tiles.hip only
+    const TileGroup* groups;    // tiles.hip only: sorted by n_jobs
     uint32_t n_groups;
+    uint32_t group_counts[3];   // groups of 1, 2 and 3 jobs (the rest have 4 or more): a work-group gets as many waves as it has jobs
     const uint8_t* codons;      // [n_leaves][leaf_stride]
     size_t leaf_stride;
     const uint32_t* program;    // the fused pruning program of the context (schedule.hpp)
@@ -132,6 +133,7 @@ struct FactoredParams {
     uint32_t n_branches;
     const double* eig_right;    // [n_eig][64*64]
     const double* eig_left;     // [n_eig][64*64]
+    const double* eig_w;        // [n_eig][4][16] lane order: w = root / iroot of the symmetrisation, L = R^T diag(w) (tiles.hip only)
     const double* prior;        // [n_eig][4][16] lane order
     const double* anc_weight;   // [n_eig][4][16] lane order (read only if out_anc)
     const double* edge_scale;   // [n_eval][n_branches][64] row-split order
@@ -171,6 +173,7 @@ struct EigenParams {
     double* prior;        // [n_eig][64] equilibrium prior in lane order (may be null)
     double* anc_weight;   // [n_eig][64] ln(prior)*prior in lane order (may be null)
     double* prior_plain;  // optional [n_eig][64] prior in state order (diagnostics/tests)
+    double* eig_w;        // optional [n_eig][64] lane order: root / iroot of the symmetrisation (left = right^T diag(w); tiles.hip)
     uint32_t* fail;       // [table]: set to 1 when pi has a non-positive entry
     unsigned long long* stamps;  // diagnostics (may be null): job 0 adds its cycle counts -- [0] phase A (B <- J^T B J), [1] wave 0's
                                  // rotations, [2] wave 1's V update, [3] phase B incl. its barrier, [4] steps, [5] sweeps, [6] whole kernel
