@@ -85,6 +85,30 @@ static bool block_prefers_factored(const pcsf_ctx* c, const uint8_t* codons, siz
     return factored_cost <= explicit_cost;
 }
 
+// Which pruning kernel a LIST of blocks gets (see BlockEngine::use_tiles): prune_tiles when, on average, at least 16 species have a
+// codon in a block.  PCSF_BLOCK_KERNEL=tiles|factored overrides; PCSF_FACTORED_MAX_TILES (round 2's path rule) implies factored.
+static bool list_prefers_tiles(const pcsf_ctx* c, const uint8_t* codons, size_t stride, const uint64_t* off, size_t n_blocks)
+{
+    if (std::getenv("PCSF_FACTORED_MAX_TILES")) return false;
+    if (const char* v = std::getenv("PCSF_BLOCK_KERNEL")) return std::string(v) != "factored";
+    if (!codons || n_blocks == 0) return true;
+    const size_t nl = static_cast<size_t>(c->n_leaves);
+    std::atomic<uint64_t> present{0}, counted{0};
+    parallel_for(n_blocks, [&](size_t b) {
+        if (off[b + 1] == off[b]) return;
+        uint64_t n = 0;
+        for (size_t l = 0; l < nl; ++l) {
+            const uint8_t* row = codons + l * stride;
+            bool any = false;
+            for (uint64_t s = off[b]; s < off[b + 1] && !any; ++s) any = row[s] < 64;
+            n += any;
+        }
+        present += n;
+        counted += 1;
+    });
+    return counted == 0 || static_cast<double>(present) >= 16.0 * static_cast<double>(counted);
+}
+
 struct BlockEngine {
     pcsf_ctx* c;
     size_t n_blocks, leaf_stride, n_sites_total;
@@ -133,8 +157,19 @@ struct BlockEngine {
     // tile, R and L resident in LDS -- whatever its length; jobs are ordered by eigen-system and cut into work-groups at run().
     // PCSF_BLOCK_KERNEL=factored brings back round 2's pair (prune_factored for short / sparse blocks, expm + block-mode prune_fixed
     // for long dense ones).
-    bool use_tiles = true;
+    bool use_tiles;
+    // ... for lists of DENSE blocks.  An evaluation with an eigen-system of its own (every OMEGA kappa probe) brings only its block's
+    // tiles, and a work-group holds 36 KB of LDS whatever its size: the short, sparse blocks of real alignments (median 6 codons, 4 of
+    // 100 species) leave the CUs at four waves, and prune_factored -- four waves sharing one tile, R / L rows in registers -- is the
+    // better tool there (8,256 real blocks, OMEGA: 1.44 s factored, 1.78 s tiles; configs[2], 43 of 58 species: 1.97 s and 1.76 s).
+    // One kernel per LIST (score_blocks_impl decides from the mean number of species present, before the list is cut into groups, so
+    // grouping never changes a result): both kernels in one round run one after the other, slower than either alone, also on two
+    // streams (measured).  PCSF_BLOCK_KERNEL=tiles|factored overrides.
+    long tiles_min_tiles = 0, tiles_min_present = 0;
+    std::vector<char> block_tiles;
     size_t tile_jobs_per_group = TILE_JOBS_PER_GROUP;
+    std::vector<FactoredJob> tjobs[2];
+    FactoredJob* p_tjobs = nullptr;
     std::vector<TileGroup> tgroups[2];
     TileGroup* p_tgroups = nullptr;
     std::vector<uint32_t> order_scratch;
@@ -167,10 +202,11 @@ struct BlockEngine {
     hipStream_t side = nullptr;
     hipEvent_t ev_start = nullptr, ev_side = nullptr;
 
+
     // own_streams: the engine works on streams of its own instead of the context's, so that several engines -- groups
     // of blocks advancing independently, one host thread each -- overlap on the device
-    BlockEngine(pcsf_ctx* ctx, const uint8_t* codons, const uint64_t* offsets, size_t nb, size_t stride, bool own_streams = false)
-        : c(ctx), n_blocks(nb), leaf_stride(stride), off(offsets), stream(ctx->stream)
+    BlockEngine(pcsf_ctx* ctx, const uint8_t* codons, const uint64_t* offsets, size_t nb, size_t stride, bool tiles, bool own_streams = false)
+        : c(ctx), n_blocks(nb), leaf_stride(stride), off(offsets), stream(ctx->stream), use_tiles(tiles)
     {
         if (own_streams) {
             HIP_TRY(hipStreamCreateWithFlags(&own_main, hipStreamNonBlocking));
@@ -203,17 +239,26 @@ struct BlockEngine {
                 leaf_codes[(b * nl + l) * 2 + 1] = hi;
             }
         if (const char* v = std::getenv("PCSF_FACTORED_MAX_TILES")) fixed_max_tiles = std::max(0, std::atoi(v));
-        if (const char* v = std::getenv("PCSF_BLOCK_KERNEL")) use_tiles = std::string(v) != "factored";
         if (fixed_max_tiles >= 0) use_tiles = false;   // the tile-count rule is a statement about round 2's two paths
         if (const char* v = std::getenv("PCSF_TILE_JOBS")) tile_jobs_per_group = static_cast<size_t>(std::max(1, std::atoi(v)));
+        if (const char* v = std::getenv("PCSF_TILES_MIN_TILES")) tiles_min_tiles = std::atol(v);
+        if (const char* v = std::getenv("PCSF_TILES_MIN_PRESENT")) tiles_min_present = std::atol(v);
         if (const char* v = std::getenv("PCSF_EIGEN_HOST")) host_eigen = std::atoi(v) != 0;
         if (std::getenv("PCSF_FACTORED_STAMPS")) {
             HIP_TRY(d_fact_stamps.reserve(8 * sizeof(unsigned long long)));
             HIP_TRY(hipMemsetAsync(d_fact_stamps.ptr, 0, 8 * sizeof(unsigned long long), stream));
         }
         block_factored.assign(nb, 0);
-        for (size_t b = 0; b < nb; ++b)
+        block_tiles.assign(nb, 0);
+        for (size_t b = 0; b < nb; ++b) {
             block_factored[b] = use_tiles ? 1 : block_prefers_factored(c, codons, stride, offsets[b], offsets[b + 1], fixed_max_tiles);
+            if (use_tiles) {
+                const long tiles = static_cast<long>((offsets[b + 1] - offsets[b] + 15) / 16);
+                long present = 0;
+                for (int l = 0; l < nl; ++l) present += (leaf_codes[(b * nl + l) * 2] != 0);
+                block_tiles[b] = tiles >= tiles_min_tiles || present >= tiles_min_present;   // defaults 0: every block
+            }
+        }
         std::vector<int32_t> slots(static_cast<size_t>(n - 1));
         for (int b = 0; b < n - 1; ++b) slots[b] = c->branch_slot[b];
         std::vector<int32_t> slot_branch(c->schedule.slot_node.begin(), c->schedule.slot_node.end());
@@ -250,6 +295,7 @@ struct BlockEngine {
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_side) (void)hipEventDestroy(ev_side);
         ev_start = ev_side = nullptr;
+
     }
     std::vector<uint64_t> leaf_codes;  // [block][leaf][2]
     ~BlockEngine()
@@ -352,8 +398,9 @@ struct BlockEngine {
         if (allow_factored && block_factored[blk]) {
             // short block: factors applied directly, one work-group per 16-site tile (an empty block only has its
             // model validated)
+            ev.pad = block_tiles[blk] ? 1u : 0u;   // 1: pruned by prune_tiles (jobs made at run()), 0: by prune_factored
             fevals[set].push_back(ev);
-            for (uint64_t s = off[blk]; !use_tiles && s < off[blk + 1]; s += 16) {
+            for (uint64_t s = off[blk]; !block_tiles[blk] && s < off[blk + 1]; s += 16) {
                 FactoredJob j{};
                 j.site0 = s;
                 j.out0 = out_used + (s - off[blk]);
@@ -388,10 +435,11 @@ struct BlockEngine {
                 // tile jobs in the order of their eigen-systems (an evaluation's tiles stay together), cut into work-groups of at most
                 // TILE_JOBS_PER_GROUP jobs of ONE eigen-system
                 const std::vector<ExpmEval>& fe = fevals[set];
-                order_scratch.resize(fe.size());
-                for (uint32_t i = 0; i < fe.size(); ++i) order_scratch[i] = i;
+                order_scratch.clear();
+                for (uint32_t i = 0; i < fe.size(); ++i)
+                    if (fe[i].pad) order_scratch.push_back(i);
                 std::stable_sort(order_scratch.begin(), order_scratch.end(), [&](uint32_t a, uint32_t b) { return fe[a].eig < fe[b].eig; });
-                fjobs[set].clear();
+                tjobs[set].clear();
                 tgroups[set].clear();
                 size_t run0 = 0;
                 auto close_run = [&](size_t end) {   // jobs [run0, end) share an eigen-system: even parts of at most TILE_JOBS_PER_GROUP
@@ -408,7 +456,7 @@ struct BlockEngine {
                 for (uint32_t i : order_scratch) {
                     const ExpmEval& ev = fe[i];
                     if (ev.eig != run_eig) {
-                        close_run(fjobs[set].size());
+                        close_run(tjobs[set].size());
                         run_eig = ev.eig;
                     }
                     const uint64_t s0 = off[ev.block], s1 = off[ev.block + 1], out0 = evals[ev.table].out0;
@@ -419,15 +467,15 @@ struct BlockEngine {
                         j.n_sites = static_cast<uint32_t>(std::min<uint64_t>(16, s1 - s));
                         j.eig = ev.eig;
                         j.eval = ev.table;
-                        fjobs[set].push_back(j);
+                        tjobs[set].push_back(j);
                     }
                 }
-                close_run(fjobs[set].size());
+                close_run(tjobs[set].size());
                 std::stable_sort(tgroups[set].begin(), tgroups[set].end(), [](const TileGroup& a, const TileGroup& b) { return a.n_jobs < b.n_jobs; });
             }
         const size_t nj0 = jobs[0].size(), nj1 = jobs[1].size(), nw0 = wg0[0].size(), nw1 = wg0[1].size();
         const size_t nf0 = fjobs[0].size(), nf1 = fjobs[1].size(), nfe0 = fevals[0].size(), nfe1 = fevals[1].size();
-        const size_t ng0 = tgroups[0].size(), ng1 = tgroups[1].size();
+        const size_t ng0 = tgroups[0].size(), ng1 = tgroups[1].size(), nt0 = tjobs[0].size(), nt1 = tjobs[1].size();
         auto aligned = [](size_t b) { return (b + 255) & ~size_t(255); };
         {   // the download blob: [lnz | anc | fail]
             const size_t out_bytes = aligned(out_used * 8), anc_bytes = want_anc ? out_bytes : 0;
@@ -440,7 +488,8 @@ struct BlockEngine {
         {   // the upload blob: [eigen jobs | evaluations of the factored path (both sets) | tile jobs (both sets)]
             const bool dev_eigen = !eig_jobs.empty() && !host_eigen;
             const size_t b_eig = dev_eigen ? aligned(eig_jobs.size() * sizeof(EigenJob)) : 0, b_fev = aligned((nfe0 + nfe1) * sizeof(ExpmEval)),
-                         b_fj = aligned((nf0 + nf1) * sizeof(FactoredJob)), b_tg = aligned((ng0 + ng1) * sizeof(TileGroup)), total = b_eig + b_fev + b_fj + b_tg;
+                         b_fj = aligned((nf0 + nf1) * sizeof(FactoredJob)), b_tj = aligned((nt0 + nt1) * sizeof(FactoredJob)),
+                         b_tg = aligned((ng0 + ng1) * sizeof(TileGroup)), total = b_eig + b_fev + b_fj + b_tj + b_tg;
             if (total) {
                 HIP_TRY(d_up.reserve(total));
                 HIP_TRY(h_up.reserve(total));
@@ -449,9 +498,12 @@ struct BlockEngine {
                 p_eig_jobs = reinterpret_cast<EigenJob*>(d);
                 p_fevals = reinterpret_cast<ExpmEval*>(d + b_eig);
                 p_fjobs = reinterpret_cast<FactoredJob*>(d + b_eig + b_fev);
-                p_tgroups = reinterpret_cast<TileGroup*>(d + b_eig + b_fev + b_fj);
-                if (ng0) std::memcpy(h + b_eig + b_fev + b_fj, tgroups[0].data(), ng0 * sizeof(TileGroup));
-                if (ng1) std::memcpy(h + b_eig + b_fev + b_fj + ng0 * sizeof(TileGroup), tgroups[1].data(), ng1 * sizeof(TileGroup));
+                p_tjobs = reinterpret_cast<FactoredJob*>(d + b_eig + b_fev + b_fj);
+                if (nt0) std::memcpy(h + b_eig + b_fev + b_fj, tjobs[0].data(), nt0 * sizeof(FactoredJob));
+                if (nt1) std::memcpy(h + b_eig + b_fev + b_fj + nt0 * sizeof(FactoredJob), tjobs[1].data(), nt1 * sizeof(FactoredJob));
+                p_tgroups = reinterpret_cast<TileGroup*>(d + b_eig + b_fev + b_fj + b_tj);
+                if (ng0) std::memcpy(h + b_eig + b_fev + b_fj + b_tj, tgroups[0].data(), ng0 * sizeof(TileGroup));
+                if (ng1) std::memcpy(h + b_eig + b_fev + b_fj + b_tj + ng0 * sizeof(TileGroup), tgroups[1].data(), ng1 * sizeof(TileGroup));
                 if (dev_eigen) std::memcpy(h, eig_jobs.data(), eig_jobs.size() * sizeof(EigenJob));
                 if (nfe0) std::memcpy(h + b_eig, fevals[0].data(), nfe0 * sizeof(ExpmEval));
                 if (nfe1) std::memcpy(h + b_eig + nfe0 * sizeof(ExpmEval), fevals[1].data(), nfe1 * sizeof(ExpmEval));
@@ -549,10 +601,9 @@ struct BlockEngine {
             if (nfe)
                 HIP_TRY(launch_edge_scale(p_fevals + fe_at, static_cast<uint32_t>(nfe), static_cast<uint32_t>(n - 1), d_branch_len.as<float>(),
                                           d_eig_r.as<double>(), d_eig_l.as<double>(), d_eig_lam.as<double>(), d_scale.as<double>(), p_fail, st));
-            if (nf) {
+            const size_t ntj = set ? nt1 : nt0, t_at = set ? nt0 : 0;
+            if (nf || ntj) {
                 FactoredParams fp{};
-                fp.jobs = p_fjobs + f_at;
-                fp.n_jobs = static_cast<uint32_t>(nf);
                 fp.codons = d_codons.as<uint8_t>();
                 fp.leaf_stride = n_sites_total;
                 fp.program = c->d_program.as<uint32_t>();
@@ -573,14 +624,21 @@ struct BlockEngine {
                 fp.out_anc = want_anc ? p_anc : nullptr;
                 fp.deep = c->schedule.stack_depth > MAX_STACK_DEPTH ? 1u : 0u;
                 fp.stamps = d_fact_stamps.ptr ? d_fact_stamps.as<unsigned long long>() : nullptr;
-                if (use_tiles) {
+                if (ntj) {
+                    fp.jobs = p_tjobs + t_at;
+                    fp.n_jobs = static_cast<uint32_t>(ntj);
                     fp.groups = p_tgroups + (set ? ng0 : 0);
                     fp.n_groups = static_cast<uint32_t>(set ? ng1 : ng0);
                     for (int k = 0; k < 3; ++k) fp.group_counts[k] = 0;
                     for (const TileGroup& tg : tgroups[set])
                         if (tg.n_jobs >= 1 && tg.n_jobs <= 3) ++fp.group_counts[tg.n_jobs - 1];
                     HIP_TRY(launch_prune_tiles(fp, st));
-                } else {
+                }
+                if (nf) {
+                    fp.jobs = p_fjobs + f_at;
+                    fp.n_jobs = static_cast<uint32_t>(nf);
+                    fp.groups = nullptr;
+                    fp.n_groups = 0;
                     HIP_TRY(launch_prune_factored(fp, st));
                 }
             }
@@ -627,6 +685,7 @@ struct BlockEngine {
             wgt[set].clear();
             wgp[set].clear();
             fjobs[set].clear();
+            tjobs[set].clear();
             tgroups[set].clear();
             fevals[set].clear();
         }
@@ -734,9 +793,9 @@ int run_fixed(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
 
 // ---- MLE ---------------------------------------------------------------------------------------
 int run_mle(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_blocks, size_t leaf_stride, int compute_anc,
-            uint32_t seed, float* out_phylo, float* out_anc, bool own_streams)
+            uint32_t seed, float* out_phylo, float* out_anc, bool tiles, bool own_streams)
 {
-    BlockEngine eng(c, codons, off, n_blocks, leaf_stride, own_streams);
+    BlockEngine eng(c, codons, off, n_blocks, leaf_stride, tiles, own_streams);
     eng.reserve_tables(std::max<size_t>(64, 2 * n_blocks));
     eng.reserve_eig(2);
     eng.upload_eig(0, c->eig[0], c->pi[0].data());
@@ -865,10 +924,10 @@ struct OmegaBlock {
 };
 
 int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_blocks, size_t leaf_stride, uint32_t seed,
-              float* out_phylo, float* out_anc, bool own_streams)
+              float* out_phylo, float* out_anc, bool tiles, bool own_streams)
 {
     const auto t_enter = std::chrono::steady_clock::now();
-    BlockEngine eng(c, codons, off, n_blocks, leaf_stride, own_streams);
+    BlockEngine eng(c, codons, off, n_blocks, leaf_stride, tiles, own_streams);
     const size_t cap = std::max<size_t>(64, 2 * n_blocks);
     eng.reserve_tables(cap);
     eng.reserve_eig(n_blocks + cap);  // slot b: block b's current model; slots n_blocks + k: kappa probes of a round
@@ -1102,7 +1161,8 @@ int block_loglik_impl(pcsf_ctx* c, int model, const double* q_settings, const do
 {
     std::vector<uint64_t> off(n_blocks + 1);
     for (size_t b = 0; b <= n_blocks; ++b) off[b] = site_offsets[b] - site_offsets[0];
-    BlockEngine eng(c, codons ? codons + site_offsets[0] : nullptr, off.data(), n_blocks, leaf_stride);
+    BlockEngine eng(c, codons ? codons + site_offsets[0] : nullptr, off.data(), n_blocks, leaf_stride,
+                    model != 3 && list_prefers_tiles(c, codons ? codons + site_offsets[0] : nullptr, leaf_stride, off.data(), n_blocks));
     eng.reserve_tables(n_blocks);
     if (model == 2) {
         eng.reserve_eig(n_blocks);  // eigen-systems and root priors come from the device solver (eigen.hip)
@@ -1206,6 +1266,8 @@ int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
     // four groups add nothing).  Blocks are independent: grouping never changes a result (tests/test_gpu_blocks.py).
     size_t chunk = n_blocks;
     size_t n_groups = 1;
+    // one pruning kernel for the whole list, decided before it is cut into chunks and groups
+    const bool tiles = algo != PCSF_FIXED && list_prefers_tiles(c, codons, leaf_stride, site_offsets, n_blocks);
     if (algo != PCSF_FIXED) {
         const size_t ne = c->schedule.slot_node.size();
         const size_t per_table = (ne * 4096 + static_cast<size_t>(c->n_leaves) * LEAF_TABLE_DOUBLES_DEV) * sizeof(double);
@@ -1214,8 +1276,6 @@ int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
         // are bounded by the eigen-system slots instead (3 per block, ~100 KB each) -- every chunk costs a full set of rounds.
         long max_tiles = -1;
         if (const char* v = std::getenv("PCSF_FACTORED_MAX_TILES")) max_tiles = std::max(0, std::atoi(v));
-        const char* kernel_env = std::getenv("PCSF_BLOCK_KERNEL");
-        const bool tiles = max_tiles < 0 && !(kernel_env && std::string(kernel_env) == "factored");   // BlockEngine::use_tiles
         std::atomic<bool> any_explicit{false};
         if (tiles) {
             // no block keeps tables
@@ -1248,8 +1308,8 @@ int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
         float* an = out_anc ? out_anc + r.b0 : nullptr;
         switch (algo) {
             case PCSF_FIXED: return run_fixed(c, cod, off.data(), r.nb, leaf_stride, compute_anc, ph, an);
-            case PCSF_MLE: return run_mle(c, cod, off.data(), r.nb, leaf_stride, compute_anc, seed, ph, an, own_streams);
-            default: return run_omega(c, cod, off.data(), r.nb, leaf_stride, seed, ph, an, own_streams);
+            case PCSF_MLE: return run_mle(c, cod, off.data(), r.nb, leaf_stride, compute_anc, seed, ph, an, tiles, own_streams);
+            default: return run_omega(c, cod, off.data(), r.nb, leaf_stride, seed, ph, an, tiles, own_streams);
         }
     };
     if (n_groups <= 1 || ranges.size() <= 1) {

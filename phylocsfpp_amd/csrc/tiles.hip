@@ -534,6 +534,12 @@ static hipError_t launch_tiles_impl(const FactoredParams& p, size_t lds, hipStre
         if (e != hipSuccess) return e;
         attr_set.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
     }
+    // A launch that does not fill the chip a few times over is bound by the latency of one tile, and four launches in a row would
+    // pay it four times (the reference's 516-block file: 2,218 launches of ~170 us instead of 850): one launch of full work-groups.
+    if (p.n_groups < 2048) {
+        hipLaunchKernelGGL((prune_tiles<ANC>), dim3(p.n_groups), dim3(TILE_WAVES * 64), lds, stream, p);
+        return hipGetLastError();
+    }
     uint32_t at = 0;
     for (int waves = 1; waves <= TILE_WAVES; ++waves) {
         // the last launch takes every group that is left (groups of more than TILE_WAVES jobs loop over their jobs)
