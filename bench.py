@@ -20,6 +20,9 @@ Prints ONE JSON line on rank 0.  Extra objects:
                   (--scaling strong makes this the headline line instead)
   "end_to_end"    (N = 1) `phylocsf-amd build-tracks 58mammals <synthetic 1 Mb 100-species MAF>` -- text in, seven wig
                   files out -- run in child processes (reference: src/phylocsf++build_tracks.hpp:55-260, README.rst:116)
+  "blocks"        (N = 1) the other half of BASELINE.json configs[2]: `phylocsf-amd score-msa --strategy mle|omega` on the same
+                  synthetic MAF in child processes (reference: src/run.hpp:59-182 per block, src/phylocsf++score_msa.hpp:94-127):
+                  blocks/s, codon columns/s, rounds, evaluations, which pruning kernel; "cpu" = oracle_cli on a prefix of the file
   "cpu_baseline"  (N = 1) the CPU oracle, a reference-structured port, on this host's cores: kernel level on a sample of
                   the same batch ("value"), the same CLI driver on the same MAF ("end_to_end_value"), one thread
                   ("single_thread_value")
@@ -251,6 +254,88 @@ def end_to_end(device, runs, cpu_rate_all_cores, work_dir):
     return e2e, cpu
 
 
+MSA_RE = re.compile(r"(\d+) blocks, (\d+) codon columns; seconds: total ([\d.]+) \(MAF read \+ translation \+ branch-length scores ([\d.]+), "
+                    r"scoring backend ([\d.]+), output ([\d.]+)\)")
+ROUNDS_RE = re.compile(r"run_(?:mle|omega): (\d+) blocks \((\d+) on the factored path\), (\d+) rounds, (\d+) evaluations")
+KERNEL_RE = re.compile(r"pruning kernel of this list: (\w+)")
+
+
+def run_score_msa(binary, strategy, maf, out_dir, extra_args=(), env=None):
+    """One score-msa run in a child process: the driver's own statistics, the lock-step engine's (PCSF_TIME_BLOCKS) and the wall time."""
+    os.makedirs(out_dir, exist_ok=True)
+    cmd = [binary, "score-msa", "--strategy", strategy, "--comp-anc", "1" if strategy == "mle" else "0", "--output", out_dir] + list(extra_args) + [MODEL_PREFIX, maf]
+    t0 = time.perf_counter()
+    p = subprocess.run(cmd, capture_output=True, text=True, env=dict(env or os.environ, PCSF_TIME_BLOCKS="1"))
+    wall = time.perf_counter() - t0
+    if p.returncode != 0:
+        raise RuntimeError("%s failed (%d): %s" % (" ".join(cmd), p.returncode, p.stderr[-2000:]))
+    m = MSA_RE.search(p.stderr)
+    if not m:
+        raise RuntimeError("cannot parse the statistics of %s: %s" % (binary, p.stderr[-2000:]))
+    rounds = ROUNDS_RE.findall(p.stderr)
+    k = KERNEL_RE.search(p.stderr)
+    return {"blocks": int(m.group(1)), "codon_columns": int(m.group(2)), "seconds": float(m.group(3)), "read_seconds": float(m.group(4)),
+            "scoring_seconds": float(m.group(5)), "process_wall_seconds": wall,
+            "rounds_max": max([int(r[2]) for r in rounds], default=None), "evaluations": sum(int(r[3]) for r in rounds) or None,
+            "groups": len(rounds) or None, "pruning_kernel": k.group(1) if k else None,
+            "scores": os.path.join(out_dir, os.path.basename(maf) + ".scores")}
+
+
+def read_scores(path):
+    rows = [l.rstrip("\n").split("\t") for l in open(path) if not l.startswith("#")][1:]
+    return np.array([[float(x) for x in r[4:]] for r in rows], dtype=np.float64)
+
+
+def block_strategies(device, maf, work_dir, runs):
+    """configs[2], "fixed + omega MLE": score-msa --strategy mle and omega on the synthetic MAF (GPU CLI), and the oracle driver on a
+    prefix of the same file sized for ~20 s per strategy; rows of the prefix compared between the two."""
+    cpus = effective_cpus()
+    out = {"maf": os.path.basename(maf), "model": MODEL, "host_threads": cpus}
+    env = dict(os.environ, PCSF_THREADS=str(cpus), OMP_NUM_THREADS=str(cpus))
+    # calibrate the CPU sample on a small prefix (MLE), then size both prefixes
+    cal = os.path.join(work_dir, "blocks_cal.maf")
+    maf_prefix(maf, cal, 0.004)
+    t0 = time.perf_counter()
+    c = run_score_msa(ORACLE_CLI, "mle", cal, os.path.join(work_dir, "cpu_cal"), env=env)
+    per_block_mle = max(1e-3, (time.perf_counter() - t0) / max(1, c["blocks"]))
+    total_blocks = None
+    for strategy in ("mle", "omega"):
+        gpu_runs = [run_score_msa(CLI, strategy, maf, os.path.join(work_dir, "gpu_" + strategy), ["--device", str(device)]) for _ in range(runs)]
+        best = min(gpu_runs, key=lambda r: r["scoring_seconds"])
+        total_blocks = best["blocks"]
+        leg = {"command": "phylocsf-amd score-msa --strategy %s --device %d %s <maf>" % (strategy, device, os.path.relpath(MODEL_PREFIX, ROOT)),
+               "blocks": best["blocks"], "codon_columns": best["codon_columns"], "runs": runs,
+               "seconds": best["seconds"], "scoring_seconds": best["scoring_seconds"], "read_seconds": best["read_seconds"],
+               "scoring_seconds_all_runs": [r["scoring_seconds"] for r in gpu_runs],
+               "process_wall_seconds": min(r["process_wall_seconds"] for r in gpu_runs),
+               "blocks_per_s": best["blocks"] / best["scoring_seconds"], "codon_columns_per_s": best["codon_columns"] / best["scoring_seconds"],
+               "blocks_per_s_process_wall": best["blocks"] / min(r["process_wall_seconds"] for r in gpu_runs),
+               "rounds": best["rounds_max"], "evaluations": best["evaluations"], "block_groups": best["groups"], "pruning_kernel": best["pruning_kernel"]}
+        # CPU: a prefix sized for ~20 s (OMEGA costs ~5 MLE evaluations' worth per block more: measured ratio ~2.5)
+        per_block = per_block_mle * (1.0 if strategy == "mle" else 2.5)
+        frac = min(1.0, max(0.002, 20.0 / (per_block * best["blocks"])))
+        cpu_maf = os.path.join(work_dir, "blocks_cpu_%s.maf" % strategy)
+        maf_prefix(maf, cpu_maf, frac)
+        cr = run_score_msa(ORACLE_CLI, strategy, cpu_maf, os.path.join(work_dir, "cpu_" + strategy), env=env)
+        leg["cpu"] = {"kind": "port", "cores": cpus, "blocks": cr["blocks"], "codon_columns": cr["codon_columns"], "scoring_seconds": cr["scoring_seconds"],
+                      "blocks_per_s": cr["blocks"] / cr["scoring_seconds"], "codon_columns_per_s": cr["codon_columns"] / cr["scoring_seconds"],
+                      "sample": "the first %d blocks of the same file, oracle/_build/oracle_cli score-msa --strategy %s, %d threads" % (cr["blocks"], strategy, cpus)}
+        leg["vs_cpu"] = leg["codon_columns_per_s"] / leg["cpu"]["codon_columns_per_s"]
+        # the prefix's rows, GPU against oracle
+        try:
+            g, o = read_scores(best["scores"])[:cr["blocks"], 0], read_scores(cr["scores"])[:, 0]
+            both = np.isfinite(g) & np.isfinite(o)
+            d = np.abs(g[both] - o[both])
+            rel = d / np.maximum(1e-6, np.abs(o[both]))
+            leg["parity_on_cpu_sample"] = {"rows": int(len(o)), "nan_pattern_equal": bool(np.array_equal(np.isnan(g), np.isnan(o))),
+                                           "rows_within_1e-6_relative": int((rel <= 1e-6).sum()), "finite_rows": int(both.sum()),
+                                           "max_abs_diff_decibans": float(d.max()) if len(d) else 0.0, "median_abs_diff_decibans": float(np.median(d)) if len(d) else 0.0}
+        except Exception as ex:
+            leg["parity_on_cpu_sample"] = {"error": str(ex)[-300:]}
+        out[strategy] = leg
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -264,6 +349,7 @@ def main():
     ap.add_argument("--cpu-baseline-sites", type=int, default=-1,
                     help="codon-frames for the CPU baseline sample (default: sized for ~10 s; 0 disables the CPU legs)")
     ap.add_argument("--end-to-end-runs", type=int, default=3, help="build-tracks CLI runs on the synthetic 1 Mb MAF (0 disables; N = 1 only)")
+    ap.add_argument("--block-runs", type=int, default=2, help="score-msa --strategy mle / omega runs on the same MAF (0 disables; N = 1 only)")
     ap.add_argument("--keep-files", default=None, help="directory for the synthetic MAF and the wig files (default: a temporary one)")
     args = ap.parse_args()
 
@@ -407,15 +493,27 @@ def main():
                 # ~2.5 k codon-frames/s/core incl. the per-alignment model set-up -> aim for ~10 s
                 budget = int(min(codons_host.shape[1], max(20_000, 2500 * effective_cpus() * 10)))
             out["cpu_baseline"] = cpu_baseline(codons_host, budget)
-            if args.end_to_end_runs > 0:
+            if args.end_to_end_runs > 0 or args.block_runs > 0:
                 work = args.keep_files or tempfile.mkdtemp(prefix="pcsf_bench_")
                 os.makedirs(work, exist_ok=True)
                 try:
-                    e2e, cpu_e2e = end_to_end(local_rank, args.end_to_end_runs, out["cpu_baseline"]["value"], work)
-                    out["end_to_end"] = e2e
-                    out["cpu_baseline"].update(cpu_e2e)
-                except Exception as ex:  # the kernel-level line must survive a failure of the CLI leg
-                    out["end_to_end"] = {"error": str(ex)[-1500:]}
+                    if args.end_to_end_runs > 0:
+                        try:
+                            e2e, cpu_e2e = end_to_end(local_rank, args.end_to_end_runs, out["cpu_baseline"]["value"], work)
+                            out["end_to_end"] = e2e
+                            out["cpu_baseline"].update(cpu_e2e)
+                        except Exception as ex:  # the kernel-level line must survive a failure of the CLI leg
+                            out["end_to_end"] = {"error": str(ex)[-1500:]}
+                    if args.block_runs > 0:
+                        try:
+                            maf = os.path.join(work, "synthetic_%dbp_seed%d.maf" % (E2E_BASES, E2E_SEED))
+                            if not os.path.exists(maf):
+                                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                                import gen_synthetic_maf as gen
+                                gen.generate(maf, bases=E2E_BASES, seed=E2E_SEED)
+                            out["blocks"] = block_strategies(local_rank, maf, work, args.block_runs)
+                        except Exception as ex:
+                            out["blocks"] = {"error": str(ex)[-1500:]}
                 finally:
                     if not args.keep_files:
                         shutil.rmtree(work, ignore_errors=True)

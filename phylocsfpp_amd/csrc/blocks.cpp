@@ -1268,6 +1268,7 @@ int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
     size_t n_groups = 1;
     // one pruning kernel for the whole list, decided before it is cut into chunks and groups
     const bool tiles = algo != PCSF_FIXED && list_prefers_tiles(c, codons, leaf_stride, site_offsets, n_blocks);
+    if (algo != PCSF_FIXED && std::getenv("PCSF_TIME_BLOCKS")) fprintf(stderr, "pruning kernel of this list: %s\n", tiles ? "prune_tiles" : "prune_factored");
     if (algo != PCSF_FIXED) {
         const size_t ne = c->schedule.slot_node.size();
         const size_t per_table = (ne * 4096 + static_cast<size_t>(c->n_leaves) * LEAF_TABLE_DOUBLES_DEV) * sizeof(double);
