@@ -44,7 +44,7 @@ import numpy as np
 import torch
 
 MODEL = "58mammals"
-MODEL_PREFIX = os.path.join(ROOT, "tests", "golden", "models", MODEL)
+MODEL_PREFIX = MODEL   # a shipped model, by name (phylocsfpp_amd/models; reference: src/models.hpp:1443-1455)
 SITES_PER_GPU = 2_000_000           # 1 Mb reference x 2 strands x 3 frames / 3 bases per codon
 STRONG_TOTAL_SITES = 200_000_000    # BASELINE.json configs[3]: 100 Mb
 POOL_SITES = 1 << 17                # unique synthetic columns; the batch samples them with replacement
@@ -111,7 +111,7 @@ def cpu_baseline(codons, budget_sites):
     alignment x frame, scalar pruning per codon, OpenMP schedule(dynamic,1) over alignments)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob  # cpu_baseline leg: the oracle is the thing timed here
-    m = ob.OracleModel(MODEL_PREFIX)
+    m = ob.OracleModel(os.path.join(ROOT, "phylocsfpp_amd", "models", MODEL))   # the oracle reads the files with its own reader
     n = min(budget_sites, codons.shape[1])
     n_units = max(1, int(round(ALIGNMENT_FRAMES * n / SITES_PER_GPU)))
     off = np.linspace(0, n, n_units + 1).astype(np.uint64)
@@ -194,7 +194,7 @@ def end_to_end(device, runs, cpu_rate_all_cores, work_dir):
     cpus = effective_cpus()
     gpu_runs = [run_cli(CLI, maf, os.path.join(work_dir, "gpu"), ["--device", str(device)]) for _ in range(runs)]
     best = min(gpu_runs, key=lambda r: r["seconds"])
-    e2e = {"command": "phylocsf-amd build-tracks --device %d %s <maf>" % (device, os.path.relpath(MODEL_PREFIX, ROOT)),
+    e2e = {"command": "phylocsf-amd build-tracks --device %d %s <maf>" % (device, MODEL_PREFIX),
            "maf": "tools/gen_synthetic_maf.py --bases %d --seed %d: %d species rows (58 mapped by the model), %d blocks, %d bytes; generated in %.1f s"
                   % (E2E_BASES, E2E_SEED, info["rows"], info["blocks"], info["bytes"], gen_s),
            "maf_bytes": info["bytes"], "codon_frames": best["codon_frames"], "ref_bases": best["ref_bases"], "alignments": best["alignments"],
@@ -303,7 +303,7 @@ def block_strategies(device, maf, work_dir, runs):
         gpu_runs = [run_score_msa(CLI, strategy, maf, os.path.join(work_dir, "gpu_" + strategy), ["--device", str(device)]) for _ in range(runs)]
         best = min(gpu_runs, key=lambda r: r["scoring_seconds"])
         total_blocks = best["blocks"]
-        leg = {"command": "phylocsf-amd score-msa --strategy %s --device %d %s <maf>" % (strategy, device, os.path.relpath(MODEL_PREFIX, ROOT)),
+        leg = {"command": "phylocsf-amd score-msa --strategy %s --device %d %s <maf>" % (strategy, device, MODEL_PREFIX),
                "blocks": best["blocks"], "codon_columns": best["codon_columns"], "runs": runs,
                "seconds": best["seconds"], "scoring_seconds": best["scoring_seconds"], "read_seconds": best["read_seconds"],
                "scoring_seconds_all_runs": [r["scoring_seconds"] for r in gpu_runs],
@@ -311,8 +311,8 @@ def block_strategies(device, maf, work_dir, runs):
                "blocks_per_s": best["blocks"] / best["scoring_seconds"], "codon_columns_per_s": best["codon_columns"] / best["scoring_seconds"],
                "blocks_per_s_process_wall": best["blocks"] / min(r["process_wall_seconds"] for r in gpu_runs),
                "rounds": best["rounds_max"], "evaluations": best["evaluations"], "block_groups": best["groups"], "pruning_kernel": best["pruning_kernel"]}
-        # CPU: a prefix sized for ~20 s (OMEGA costs ~5 MLE evaluations' worth per block more: measured ratio ~2.5)
-        per_block = per_block_mle * (1.0 if strategy == "mle" else 2.5)
+        # CPU: a prefix sized for ~20 s (an OMEGA block costs the oracle ~5.5 MLE blocks)
+        per_block = per_block_mle * (1.0 if strategy == "mle" else 5.5)
         frac = min(1.0, max(0.002, 20.0 / (per_block * best["blocks"])))
         cpu_maf = os.path.join(work_dir, "blocks_cpu_%s.maf" % strategy)
         maf_prefix(maf, cpu_maf, frac)

@@ -507,7 +507,7 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             const size_t b = w0 + (w1 - w0) * j / n_jobs, e = w0 + (w1 - w0) * (j + 1) / n_jobs;
             std::unique_ptr<MafReader> text_reader;
             std::unique_ptr<PackedReader> packed_reader;
-            if (packed) packed_reader.reset(new PackedReader(file, b, e, model.n_leaves));
+            if (packed) packed_reader.reset(new PackedReader(file, b, e, model.n_leaves, row_map_hash(model)));
             else text_reader.reset(new MafReader(file, b, e, model.name_to_leaf, model.n_leaves, /*concatenate=*/true, prm.verbose && j == 0 && w0 == 0));
             BranchLengthScore bls(model);
             Alignment aln;
@@ -721,7 +721,7 @@ inline PackStats pack_maf(const Model& model, const std::string& maf_path, const
     StopWatch total;
     MafFile file(maf_path);
     if (is_packed_file(file)) throw std::runtime_error("'" + maf_path + "' is already a packed alignment file");
-    PackedWriter out(out_path, model.n_leaves);
+    PackedWriter out(out_path, model.n_leaves, row_map_hash(model));
     PackStats st;
     st.bytes_in = file.size();
     if (threads <= 0) threads = effective_threads();

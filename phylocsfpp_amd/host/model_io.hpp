@@ -4,6 +4,10 @@
 // (src/newick.hpp:286-363) and the --mapping name table (src/models.hpp:1709-1740); written from scratch.
 #pragma once
 
+#include <dlfcn.h>
+#include <limits.h>
+#include <sys/stat.h>
+
 #include <algorithm>
 #include <cctype>
 #include <cstdint>
@@ -319,9 +323,55 @@ inline std::unordered_set<std::string> resolve_species(const std::string& csv, c
 }
 
 // <prefix>_coding.ECM, <prefix>_noncoding.ECM, <prefix>.nh  (reference src/models.hpp:1773-1775)
-inline Model load_model(const std::string& prefix, const std::string& alias_file = "", const std::string& species_csv = "",
+// Model names as the reference's command line takes them (src/models.hpp:1443-1455, load_model :1757-1783): a bare name such as
+// "58mammals" selects a model that ships with the program, anything else is the prefix of <prefix>_coding.ECM, <prefix>_noncoding.ECM
+// and <prefix>.nh.  The reference compiles its models in; here they are files in a `models` directory next to the library / the
+// driver (phylocsfpp_amd/models in the source tree; $PCSF_MODEL_DIR first).  A prefix that names existing files always wins.
+inline bool file_exists(const std::string& path)
+{
+    struct stat sb;
+    return stat(path.c_str(), &sb) == 0 && S_ISREG(sb.st_mode);
+}
+
+inline std::vector<std::string> model_directories()
+{
+    std::vector<std::string> dirs;
+    if (const char* e = getenv("PCSF_MODEL_DIR")) dirs.push_back(e);
+    Dl_info info;
+    if (dladdr(reinterpret_cast<const void*>(&file_exists), &info) && info.dli_fname) {   // the object this code was linked into
+        std::string here = info.dli_fname;
+        char resolved[PATH_MAX];
+        if (realpath(here.c_str(), resolved)) here = resolved;
+        const size_t slash = here.find_last_of('/');
+        const std::string dir = slash == std::string::npos ? "." : here.substr(0, slash);
+        for (const char* rel : {"/models", "/../models", "/../../phylocsfpp_amd/models"}) dirs.push_back(dir + rel);
+    }
+    return dirs;
+}
+
+inline std::string resolve_model_prefix(const std::string& name_or_prefix)
+{
+    if (file_exists(name_or_prefix + "_coding.ECM") || name_or_prefix.find('/') != std::string::npos) return name_or_prefix;
+    std::string tried;
+    for (const std::string& d : model_directories()) {
+        const std::string cand = d + "/" + name_or_prefix;
+        if (file_exists(cand + "_coding.ECM")) return cand;
+        tried += (tried.empty() ? "" : ", ") + d;
+    }
+    throw std::runtime_error("model '" + name_or_prefix + "' is neither a shipped model nor the prefix of <prefix>_coding.ECM / _noncoding.ECM / .nh (looked in: " +
+                             (tried.empty() ? std::string("no model directory") : tried) + ")");
+}
+
+inline Model load_model(const std::string& name_or_prefix, const std::string& alias_file_in = "", const std::string& species_csv = "",
                         const std::string& mapping_file = "")
 {
+    const std::string prefix = resolve_model_prefix(name_or_prefix);
+    std::string alias_file = alias_file_in;
+    if (alias_file.empty()) {  // convention: species_aliases.tsv next to the model files
+        const size_t slash = prefix.find_last_of('/');
+        const std::string cand = (slash == std::string::npos ? std::string(".") : prefix.substr(0, slash)) + "/species_aliases.tsv";
+        if (file_exists(cand)) alias_file = cand;
+    }
     Model m;
     read_ecm(prefix + "_coding.ECM", m.S_c, m.pi_c);
     read_ecm(prefix + "_noncoding.ECM", m.S_nc, m.pi_nc);

@@ -297,3 +297,31 @@ def test_packed_alignment_file_gives_the_same_tracks(cli, tmp_path):
     cut.write_bytes(open(packed, "rb").read()[:-100])
     bad = subprocess.run([cli, "build-tracks", "--output", str(tmp_path / "y"), MODEL, str(cut)], capture_output=True, text=True)
     assert bad.returncode != 0 and "truncated" in bad.stderr
+    # the same tree reduced to other species of the same count, or another --mapping: rows would land elsewhere -- refused by the header's
+    # row-map hash instead of silently mis-scored
+    labels = [l.split("\t")[0] for l in open(os.path.join(ROOT, "tests", "golden", "models", "species_aliases.tsv")) if l.strip()]
+    import phylocsfpp_amd as pa
+    leaves = pa.load_model(MODEL).labels[:pa.load_model(MODEL).nl]
+    sel_a, sel_b = ",".join(leaves[:20]), ",".join(leaves[1:21])
+    pa_a = tmp_path / "a.pcsfbin"
+    assert subprocess.run([cli, "pack-maf", "--species", sel_a, MODEL, str(maf), str(pa_a)], capture_output=True).returncode == 0
+    ok = subprocess.run([cli, "build-tracks", "--output", str(tmp_path / "za"), "--species", sel_a, MODEL, str(pa_a)], capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr
+    wrong = subprocess.run([cli, "build-tracks", "--output", str(tmp_path / "zb"), "--species", sel_b, MODEL, str(pa_a)], capture_output=True, text=True)
+    assert wrong.returncode != 0 and "another model" in wrong.stderr
+    # a corrupted index or record is an error, never a read outside the file
+    raw = bytearray(open(packed, "rb").read())
+    import struct
+    n_rec, index_at = struct.unpack_from("<QQ", raw, len(raw) - 24)
+    assert n_rec >= 2
+    for what, patch in (("offset beyond the data", lambda b: struct.pack_into("<Q", b, index_at + 8, index_at + 4096)),
+                        ("unaligned offset", lambda b: struct.pack_into("<Q", b, index_at + 8, struct.unpack_from("<Q", b, index_at + 8)[0] + 3)),
+                        ("chromosome length", lambda b: struct.pack_into("<I", b, struct.unpack_from("<Q", b, index_at)[0] + 4, 0x7fffffff)),
+                        ("row count", lambda b: struct.pack_into("<I", b, struct.unpack_from("<Q", b, index_at)[0] + 28, 7)),
+                        ("record length", lambda b: struct.pack_into("<I", b, struct.unpack_from("<Q", b, index_at)[0] + 24, 0x7fffffff))):
+        b = bytearray(raw)
+        patch(b)
+        f = tmp_path / "corrupt.pcsfbin"
+        f.write_bytes(bytes(b))
+        r = subprocess.run([cli, "build-tracks", "--output", str(tmp_path / "c"), MODEL, str(f)], capture_output=True, text=True)
+        assert r.returncode == 1 and "packed alignment file" in r.stderr, (what, r.returncode, r.stderr[-300:])

@@ -75,3 +75,33 @@ def _is_ancestor(parent, anc, v):
             return True
         v = int(parent[v])
     return False
+
+
+def test_shipped_models_resolve_by_name_like_the_references_command_line(tmp_path, monkeypatch):
+    """`phylocsf++ build-tracks 58mammals x.maf` names a built-in model (reference src/models.hpp:1443-1455, load_model :1757-1783); here
+    the models ship as files next to the library, and a name without a slash that is not a file prefix is looked up there."""
+    import numpy as np
+    import phylocsfpp_amd as pa
+    for name in ("53birds", "58mammals", "100vertebrates"):
+        by_name = pa.load_model(name)
+        by_path = pa.load_model(os.path.join(GOLD, "models", name))
+        assert by_name.nl == by_path.nl and by_name.labels == by_path.labels
+        assert np.array_equal(by_name.S_c, by_path.S_c) and np.array_equal(by_name.pi_nc, by_path.pi_nc)
+        assert np.array_equal(by_name.branch_len, by_path.branch_len)
+    assert pa.load_model("58mammals").leaf_of("hg38") == pa.load_model("58mammals").leaf_of("human")   # the alias table ships with the models
+    with pytest.raises(pa.PcsfError, match="neither a shipped model"):
+        pa.load_model("59mammals")
+    # a prefix that names existing files wins over the shipped model of the same name
+    import shutil
+    for ext in ("_coding.ECM", "_noncoding.ECM", ".nh"):
+        shutil.copyfile(os.path.join(GOLD, "models", "53birds" + ext), str(tmp_path / ("58mammals" + ext)))
+    monkeypatch.chdir(tmp_path)
+    assert pa.load_model("58mammals").nl == 53
+    # PCSF_MODEL_DIR comes first
+    monkeypatch.chdir("/")
+    d = tmp_path / "mine"
+    d.mkdir()
+    for ext in ("_coding.ECM", "_noncoding.ECM", ".nh"):
+        shutil.copyfile(os.path.join(GOLD, "models", "53birds" + ext), str(d / ("mymodel" + ext)))
+    monkeypatch.setenv("PCSF_MODEL_DIR", str(d))
+    assert pa.load_model("mymodel").nl == 53

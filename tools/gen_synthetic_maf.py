@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Synthetic multiz-style MAF for BASELINE.json configs[2].
 
-  python tools/gen_synthetic_maf.py OUT.maf [--bases 1000000] [--seed 20261002] [--tree tests/golden/models/100vertebrates]
+  python tools/gen_synthetic_maf.py OUT.maf [--bases 1000000] [--seed 20261002] [--tree 100vertebrates]
                                     [--exons OUT.exons.txt]
 
 Species = the leaf labels of the 100vertebrates tree written as <label>.chrS (the 58mammals labels are a
@@ -31,7 +31,7 @@ def generate(out, bases=1_000_000, seed=20261002, tree=None, start=1_000_000, ex
     """Writes the MAF (and, optionally, the matching coding-exon list); returns a dict describing it."""
     import phylocsfpp_amd as pa
     from phylocsfpp_amd import synth
-    m = pa.load_model(tree or os.path.join(ROOT, "tests/golden/models/100vertebrates"))
+    m = pa.load_model(tree or "100vertebrates")   # a shipped model, by name
     rng = np.random.default_rng(seed)
     n_cod = (bases + 2) // 3 + 8
     cod, is_coding = synth.synthetic_codon_columns(m.child1, m.child2, m.branch_len, m.S_c, m.pi_c, m.S_nc, m.pi_nc, n_cod,
