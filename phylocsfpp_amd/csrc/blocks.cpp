@@ -1328,15 +1328,19 @@ int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
     std::vector<std::thread> th;
     for (size_t g = 0; g < std::min(n_groups, ranges.size()); ++g)
         th.emplace_back([&]() {
-            (void)hipSetDevice(c->device);  // the current device is per host thread
+            const hipError_t dev_rc = hipSetDevice(c->device);  // the current device is per host thread
             for (size_t i = next++; i < ranges.size(); i = next++) {
                 int rc = PCSF_OK;
                 std::string msg;
                 try {
+                    if (dev_rc != hipSuccess) throw std::runtime_error(std::string("hipSetDevice: ") + hipGetErrorString(dev_rc));
                     rc = run_range(ranges[i], true);
                 } catch (const std::exception& ex) {
                     rc = PCSF_ERR_HIP;
                     msg = ex.what();
+                } catch (...) {   // nothing may leave a worker thread: std::terminate inside a library call
+                    rc = PCSF_ERR_HIP;
+                    msg = "unknown exception in a block-group worker";
                 }
                 if (rc != PCSF_OK) {
                     std::lock_guard<std::mutex> g2(err_lock);

@@ -252,6 +252,7 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
             pq[32 * buf + tid] = pi_ | (qi << 8);
         }
     };
+    bool lds_converged = false;
     for (int sweep = 0; sweep < 60; ++sweep) {
         // convergence: squared off-diagonal mass against squared diagonal mass
         double off = 0.0, total = 0.0;
@@ -273,7 +274,10 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
         off = red[0] + red[1] + red[2] + red[3];
         total = red[4] + red[5] + red[6] + red[7];
         __syncthreads();
-        if (off <= 1e-58 * total) break;
+        if (off <= 1e-58 * total) {
+            lds_converged = true;
+            break;
+        }
 
         // One Jacobi step = (A) B <- J^T B J by all four waves, barrier, (B) V <- V J by waves 1-3 WHILE wave 0 computes the
         // rotations of the next step from the updated B, barrier.  The rotation parameters are a chain of ~150 dependent
@@ -374,6 +378,7 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
             }
         }
     }
+    if (!lds_converged && tid == 0) p.fail[job.table] = 1u;   // sweeps used up (a NaN makes the stop test false for ever): flagged, see below
     } else {
     // ================= register-resident sweeps: wave 0 owns B, wave 1 owns V ==================
     double2_loc* rt = reinterpret_cast<double2_loc*>(rot);   // [buf][super-group * 4 + pair] = (cos, sin)
@@ -522,6 +527,7 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
         // Convergence is checked before every ROUND (4 steps; 7 in round 0), not once per sweep: the iteration converges quadratically,
         // so a job is usually done a good part of a sweep before the sweep's end, and a launch lasts as long as its slowest job.
         int r = 0;   // the seating: round within the sweep
+        bool converged = false;
         for (int round = 0; round < 60 * 15; ++round) {
             double off = 0.0, total = 0.0;
 #pragma unroll
@@ -545,7 +551,10 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
             constexpr double STOP = 1e-36;
             if (lane == 0) flag = (off <= STOP * total) ? 2 : 0;
             __syncthreads();
-            if (off <= STOP * total) break;
+            if (off <= STOP * total) {
+                converged = true;
+                break;
+            }
             using std::integral_constant;
             if (r == 0) {
                 n_sweeps += 1;
@@ -561,6 +570,10 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
             n_steps += r == 0 ? 7 : 4;
             r = r == 14 ? 0 : r + 1;
         }
+        // Rounds used up without meeting the stop rule (a NaN in the rate matrix makes every comparison false; so would a matrix the
+        // iteration cannot finish): the eigen-system written below is whatever the registers hold -- the evaluation is flagged
+        // (NaN row, like a model the reference fails to instantiate) instead of passing silently into the pruning kernels.
+        if (!converged && lane == 0) p.fail[job.table] = 1u;
         // eigenvalues into the canonical matrix (the seating of the round the iteration stopped in)
         if (diag) {
 #pragma unroll
@@ -710,7 +723,8 @@ hipError_t launch_eigen_omega(const EigenParams& p, hipStream_t stream)
     // Two forms of the same iteration.  Default: blocks in registers (128 threads: wave 0 holds B, wave 1 V; two work-groups per CU) --
     // 0.69 ms per cold launch against 0.98 ms, and OMEGA 1.16-1.22x faster at 516 / 2,064 / 8,256 blocks.  PCSF_EIGEN_LDS=1: the
     // first version (matrices in LDS, 256 threads), kept for A/B runs and tests.
-    static const bool in_lds = [] { const char* e = getenv("PCSF_EIGEN_LDS"); return e && e[0] == '1'; }();
+    const char* lds_env = getenv("PCSF_EIGEN_LDS");   // read at every launch: tests switch forms inside one process
+    const bool in_lds = lds_env && lds_env[0] == '1';
     if (in_lds) hipLaunchKernelGGL(eigen_omega_kernel<false>, dim3(p.n_jobs), dim3(256), lds, stream, p);
     else hipLaunchKernelGGL(eigen_omega_kernel<true>, dim3(p.n_jobs), dim3(128), lds, stream, p);
     return hipGetLastError();

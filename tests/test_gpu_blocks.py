@@ -238,15 +238,22 @@ def test_mle_and_omega_on_trees_whose_branch_count_is_not_a_chunk_multiple(oracl
             assert np.all((ph[ok] - oph[ok]) ** 2 <= tol), (name, algo, ph, oph)
 
 
-def test_device_eigen_solver_in_its_lds_form():
-    """launch_eigen_omega picks the register-resident form of the Jacobi kernel while a launch has at most one job per CU and
-    the LDS form beyond; PCSF_EIGEN_LDS=1 (read once per process) forces the LDS form: the same accuracy test in a child process."""
-    import os
-    import subprocess
-    import sys
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_device_eigen_solver_of_the_omega_rate_matrix"],
-                       env=dict(os.environ, PCSF_EIGEN_LDS="1"), capture_output=True, text=True)
-    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:]
+def test_device_eigen_solver_in_its_lds_form(gpu_contexts, monkeypatch):
+    """launch_eigen_omega runs the register-resident form of the Jacobi kernel unless PCSF_EIGEN_LDS=1 (read at every launch) asks for
+    the first version, matrices in LDS: the same accuracy test under that setting."""
+    monkeypatch.setenv("PCSF_EIGEN_LDS", "1")
+    test_device_eigen_solver_of_the_omega_rate_matrix(gpu_contexts)
+
+
+def test_eigen_solver_flags_a_matrix_it_cannot_diagonalise(gpu_contexts, monkeypatch):
+    """A NaN among the settings makes every stop test of the Jacobi iteration false: both device forms must use up their rounds and
+    FLAG the job (fail -> NaN row) instead of handing whatever the registers hold to the pruning kernels."""
+    ctx = gpu_contexts("100vertebrates")
+    qs = np.array([[2.5, 1.0, 1.0] + [1.0] * 9, [float("nan"), 1.0, 1.0] + [1.0] * 9])
+    for form in ("0", "1"):
+        monkeypatch.setenv("PCSF_EIGEN_LDS", form)
+        failed = ctx.debug_eigen_omega(qs)[-1]
+        assert list(failed) == [0, 1], (form, failed)
 
 
 def test_block_groups_do_not_change_any_result(oracle_models, golden_dir):

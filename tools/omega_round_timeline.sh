@@ -14,7 +14,7 @@ for f in glob.glob('/tmp/ort/**/*memory_copy_trace.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), 'copy ' + r.get('Direction', '')))
 ev.sort()
-# the OMEGA part: from the first eigen_omega_kernel launch of the last 60 % of eigen launches (skips the warm-up call)
+# the OMEGA part: from the eigen_omega_kernel launch one eighth into the list of eigen launches on (skips the warm-up call)
 eig = [e for e in ev if 'eigen_omega' in e[2]]
 t0 = eig[len(eig) // 8][0]
 ev = [e for e in ev if e[0] >= t0]
