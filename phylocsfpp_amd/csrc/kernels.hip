@@ -567,6 +567,6 @@ hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t str
     }
 }
 
-int prune_variant_count() { return 8; }   // the instantiations launch_prune_fixed dispatches
+int prune_variant_count() { return 3; }   // variants selectable with PCSF_VARIANT (0, 1, 2); block / fused / deep-tree forms are chosen by the entry points
 
 }  // namespace pcsf
