@@ -254,6 +254,35 @@ def end_to_end(device, runs, cpu_rate_all_cores, work_dir):
     return e2e, cpu
 
 
+def end_to_end_multi(n_gpus, work_dir):
+    """BASELINE.json configs[3] in the form the C++ driver runs it: ONE process, `phylocsf-amd build-tracks --devices 0,..,N-1` on the
+    synthetic segment tiled along the chromosome (10 Mb per GPU, at most 40 Mb), text in, seven wig files out; the same file on one
+    device beside it.  Run by rank 0 while the other ranks wait at a barrier outside every timed region."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_synthetic_maf as gen
+    import replicate_maf
+    maf = os.path.join(work_dir, "synthetic_%dbp_seed%d.maf" % (E2E_BASES, E2E_SEED))
+    if not os.path.exists(maf):
+        gen.generate(maf, bases=E2E_BASES, seed=E2E_SEED)
+    tiles = min(E2E_TILES * n_gpus, 40)
+    big = os.path.join(work_dir, "synthetic_x%d.maf" % tiles)
+    replicate_maf.tile(maf, big, tiles, 1_100_000)
+    out = {"maf": "the 1 Mb synthetic segment tiled %d times (tools/replicate_maf.py), %d bytes" % (tiles, os.path.getsize(big)), "n_gpus": n_gpus}
+    for label, devs in (("all_devices", ",".join(str(d) for d in range(n_gpus))), ("one_device", "0")):
+        runs = [run_cli(CLI, big, os.path.join(work_dir, "gpu_multi_" + label), ["--devices", devs]) for _ in range(2)]
+        b = min(runs, key=lambda r: r["seconds"])
+        out[label] = {"command": "phylocsf-amd build-tracks --devices %s %s <maf>" % (devs, MODEL_PREFIX), "codon_frames": b["codon_frames"], "seconds": b["seconds"],
+                      "seconds_all_runs": [r["seconds"] for r in runs], "process_wall_seconds": min(r["process_wall_seconds"] for r in runs),
+                      "codon_frames_per_s": b["codon_frames"] / b["seconds"], "backend_calls": b["backend_calls"], "stage_busy": b["stage_busy"]}
+    out["speedup_vs_one_device"] = out["all_devices"]["codon_frames_per_s"] / out["one_device"]["codon_frames_per_s"]
+    try:
+        out["wig_lines_differing_between_the_two"] = differing_lines(os.path.join(work_dir, "gpu_multi_all_devices"), os.path.join(work_dir, "gpu_multi_one_device"))
+    except Exception as ex:
+        out["wig_lines_differing_between_the_two"] = str(ex)[-200:]
+    os.remove(big)
+    return out
+
+
 MSA_RE = re.compile(r"(\d+) blocks, (\d+) codon columns; seconds: total ([\d.]+) \(MAF read \+ translation \+ branch-length scores ([\d.]+), "
                     r"scoring backend ([\d.]+), output ([\d.]+)\)")
 ROUNDS_RE = re.compile(r"run_(?:mle|omega): (\d+) blocks \((\d+) on the factored path\), (\d+) rounds, (\d+) evaluations")
@@ -367,6 +396,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rank == 0:
+            try:
+                os.remove("/tmp/pcsf_bench_done_%s" % os.environ.get("MASTER_PORT", "0"))
+            except OSError:
+                pass
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import phylocsfpp_amd as pa
@@ -517,9 +551,34 @@ def main():
                 finally:
                     if not args.keep_files:
                         shutil.rmtree(work, ignore_errors=True)
+        if world > 1 and args.end_to_end_runs > 0:
+            # the C++ driver over all GPUs of the node (one process, PCIe returns), while ranks 1.. wait below
+            work = args.keep_files or tempfile.mkdtemp(prefix="pcsf_bench_")
+            os.makedirs(work, exist_ok=True)
+            try:
+                out["end_to_end_multi"] = end_to_end_multi(world, work)
+            except Exception as ex:
+                out["end_to_end_multi"] = {"error": str(ex)[-1500:]}
+            finally:
+                if not args.keep_files:
+                    shutil.rmtree(work, ignore_errors=True)
         print(json.dumps(out), flush=True)
     if world > 1:
+        # ranks 1.. wait for rank 0's CLI leg on the HOST (a file, not a collective: an RCCL barrier would keep a spinning kernel on
+        # the very GPUs the driver is being timed on)
+        done = "/tmp/pcsf_bench_done_%s" % os.environ.get("MASTER_PORT", "0")
+        if rank == 0:
+            open(done, "w").close()
+        else:
+            t_wait = time.time()
+            while not os.path.exists(done) and time.time() - t_wait < 1800:
+                time.sleep(0.2)
         dist.barrier()
+        if rank == 0:
+            try:
+                os.remove(done)
+            except OSError:
+                pass
         dist.destroy_process_group()
     ctx.close()
 

@@ -95,6 +95,25 @@ def test_linearity_property_large(oracle_models, gpu_contexts):
     np.testing.assert_allclose(a[:4096], m.run_tracks(base), rtol=RTOL, atol=ATOL)
 
 
+def test_bench_sized_batch_of_two_million_sites(oracle_models, gpu_contexts):
+    """BASELINE.json configs[2]'s batch as bench.py scores it (2,000,000 codon-frames in one call, 31,250 work-groups): the oracle on a
+    strided sample of 64,516 sites, and for ALL sites the size-independent property that a site's score depends on its column alone --
+    the batch draws its columns from a pool, so every score must equal, bit for bit, the score of its pool column in a small call."""
+    m = oracle_models("58mammals")
+    ctx = gpu_contexts("58mammals")
+    pool = _columns(m, 1 << 15, seed=21)
+    rng = np.random.default_rng(22)
+    idx = rng.integers(0, pool.shape[1], 2_000_000)
+    cod = np.ascontiguousarray(pool[:, idx])
+    got = ctx.score_sites_fixed(cod)
+    assert got.shape == (2_000_000,) and np.isfinite(got).all()
+    sample = np.arange(0, 2_000_000, 31)
+    np.testing.assert_allclose(got[sample], m.run_tracks(np.ascontiguousarray(cod[:, sample])), rtol=RTOL, atol=ATOL)
+    assert np.array_equal(got, ctx.score_sites_fixed(pool)[idx])
+    perm = rng.permutation(2_000_000)
+    assert np.array_equal(ctx.score_sites_fixed(np.ascontiguousarray(cod[:, perm])), got[perm])
+
+
 def test_tree_deeper_than_the_register_stack(tmp_path, golden_dir):
     """A perfectly balanced 64-leaf tree needs 5 parked tiles; the kernels keep 3 in registers (enough for every tree the
     reference ships) and run the DEEP variants -- stack in scratch memory -- for anything deeper, where
