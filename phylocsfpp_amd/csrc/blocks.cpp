@@ -909,10 +909,21 @@ int run_mle(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_bl
 }
 
 // ---- OMEGA -------------------------------------------------------------------------------------
+// Eigen-systems a block keeps between rounds, by role.  OWN: the model the block is at.  LO / HI: kappa = 1 and kappa = 10, the ends
+// every kappa stage evaluates first -- the three kappa stages of a hypothesis ask for the SAME two rate matrices.  P0 / P1: the last two
+// interior kappa probes (Brent's steps shrink geometrically: the nearest earlier probe is a far better start for the Jacobi iteration
+// than the stage's first point).  A probe whose settings equal a held system is not solved again (a fifth of all solves on the
+// configs[2] list), every other probe starts from the nearest held system of its family (same omega, sigma, frequencies).  Roles map
+// to physical slots through `slot`, so that the system of a stage's last probe BECOMES the block's own by a swap when the stage ends.
+enum EigRole { ROLE_OWN = 0, ROLE_LO = 1, ROLE_HI = 2, ROLE_P0 = 3, ROLE_P1 = 4, N_ROLES = 5 };
 struct OmegaBlock {
     double q_settings[12];      // kappa, omega, sigma, nine ratios: the model the block is AT (src/run.hpp:75-79)
     double eig_settings[12];    // settings the block's own eigen-system slot currently holds
     bool eig_valid = false;
+    uint32_t slot[N_ROLES];     // physical eigen-system slot of every role
+    double held[N_ROLES][12];   // settings the role's slot holds (OWN: eig_settings / eig_valid above)
+    bool held_valid[N_ROLES] = {false, false, false, false, false};
+    int next_p = 0;             // which of P0 / P1 the next interior probe overwrites
     double tree_scale = 1.0;
     std::mt19937 gen;
     MaxLik1D opt;
@@ -930,7 +941,11 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
     BlockEngine eng(c, codons, off, n_blocks, leaf_stride, tiles, own_streams);
     const size_t cap = std::max<size_t>(64, 2 * n_blocks);
     eng.reserve_tables(cap);
-    eng.reserve_eig(n_blocks + cap);  // slot b: block b's current model; slots n_blocks + k: kappa probes of a round
+    // slots [role * n_blocks + b]: the eigen-systems block b holds (EigRole; roles are swapped between them, see OmegaBlock);
+    // slots N_ROLES * n_blocks + k: speculative kappa probes of a round (random restarts nobody may ask for)
+    const bool held_systems = !(std::getenv("PCSF_OMEGA_HELD_SYSTEMS") && std::atoi(std::getenv("PCSF_OMEGA_HELD_SYSTEMS")) == 0);
+    const size_t transient0 = N_ROLES * n_blocks;
+    eng.reserve_eig(transient0 + cap);
     const double t_setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count();
     std::vector<std::unique_ptr<OmegaBlock>> blk(n_blocks);
     const long trace_block = std::getenv("PCSF_TRACE_BLOCK") ? std::atol(std::getenv("PCSF_TRACE_BLOCK")) : -1;  // diagnostics
@@ -943,8 +958,8 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
             std::vector<std::pair<size_t, size_t>> queued;
             for (; at < which.size() && eng.free_evaluations() > 0; ++at) {
                 OmegaBlock& ob = *blk[which[at]];
-                queued.push_back({which[at], eng.queue(which[at], static_cast<uint32_t>(which[at]), ob.tree_scale, ob.q_settings, false,
-                                                       ob.eig_valid ? static_cast<int32_t>(which[at]) : -1)});
+                queued.push_back({which[at], eng.queue(which[at], ob.slot[ROLE_OWN], ob.tree_scale, ob.q_settings, false,
+                                                       ob.eig_valid ? static_cast<int32_t>(ob.slot[ROLE_OWN]) : -1)});
                 std::memcpy(ob.eig_settings, ob.q_settings, sizeof ob.q_settings);
                 ob.eig_valid = true;
             }
@@ -959,6 +974,7 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
         blk[b].reset(new OmegaBlock);
         OmegaBlock& ob = *blk[b];
         ob.gen.seed(seed);
+        for (int r = 0; r < N_ROLES; ++r) ob.slot[r] = static_cast<uint32_t>(r * n_blocks + b);
         // POLICY ("OMEGA NaN rows"): the reference yields NaN for every block without a
         // complete codon (GSL's non-symmetric eigen-solver degrades on the uniform F3x4 matrix)
         if (off[b + 1] == off[b]) {
@@ -1010,7 +1026,7 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
     const bool timing = std::getenv("PCSF_TIME_BLOCKS") != nullptr;  // diagnostics: where the rounds spend their time
     const double t_prelude = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count() - t_setup;
     double t_host = 0.0, t_run = 0.0;
-    size_t rounds = 0, evals = 0, eig_evals = 0;
+    size_t rounds = 0, evals = 0, eig_evals = 0, eig_reused = 0, eig_adopted = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     struct Pending {
@@ -1026,8 +1042,24 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
             while (!ob.failed && !ob.done && !ob.needs_validation) {
                 if (ob.opt.done()) {
                     // max_lik_lpr_leaves returned: the model stays at the LAST evaluated point
-                    if ((ob.stage % 2) == 0) ob.tree_scale = ob.opt.last_x();
-                    else ob.q_settings[0] = ob.opt.last_x();
+                    if ((ob.stage % 2) == 0) {
+                        ob.tree_scale = ob.opt.last_x();
+                    } else {
+                        ob.q_settings[0] = ob.opt.last_x();
+                        // the model stays at the stage's LAST probe -- whose eigen-system, if it was kept, becomes the block's own by a
+                        // swap of roles instead of being solved once more at the next rho evaluation
+                        for (int role = ROLE_LO; role < N_ROLES && held_systems; ++role)
+                            if (ob.held_valid[role] && std::memcmp(ob.held[role], ob.q_settings, sizeof ob.q_settings) == 0) {
+                                std::swap(ob.slot[ROLE_OWN], ob.slot[role]);
+                                double tmp[12];
+                                std::memcpy(tmp, ob.eig_settings, sizeof tmp);
+                                std::memcpy(ob.eig_settings, ob.held[role], sizeof tmp);
+                                std::memcpy(ob.held[role], tmp, sizeof tmp);
+                                std::swap(ob.eig_valid, ob.held_valid[role]);
+                                ++eig_adopted;
+                                break;
+                            }
+                    }
                     (ob.stage < 6 ? ob.lpr_h0 : ob.lpr_h1) = ob.opt.last_lpr();
                     ++ob.stage;
                     if (ob.stage == 12) {
@@ -1063,7 +1095,7 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
         for (size_t b = 0; b < n_blocks; ++b) {
             OmegaBlock& ob = *blk[b];
             if (ob.failed || ob.done || !ob.needs_validation || eng.free_evaluations() == 0) continue;
-            validating.push_back({b, eng.queue(b, static_cast<uint32_t>(b), ob.tree_scale, ob.q_settings, false, ob.eig_valid ? static_cast<int32_t>(b) : -1)});
+            validating.push_back({b, eng.queue(b, ob.slot[ROLE_OWN], ob.tree_scale, ob.q_settings, false, ob.eig_valid ? static_cast<int32_t>(ob.slot[ROLE_OWN]) : -1)});
             std::memcpy(ob.eig_settings, ob.q_settings, sizeof ob.q_settings);
             ob.eig_valid = true;
         }
@@ -1071,10 +1103,12 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
         std::vector<Pending> pending;
         std::vector<Lookahead> ahead(n_blocks);
         std::vector<char> rebuilt(n_blocks, 0);  // block's own eigen-system slot is rebuilt in this run
+        std::vector<unsigned char> written(n_blocks, 0);   // bit role: the role's slot is rewritten in this run
+        std::vector<int> ahead_certain(n_blocks, 0);
         for (size_t b : live) {
             OmegaBlock& ob = *blk[b];
             if (!ob.failed && !ob.done && !ob.needs_validation)
-                ahead[b].n = ob.opt.upcoming(ahead[b].x, MAX_POINTS_PER_ROUND, MAX_SPECULATIVE_RESTARTS, active < eager_restarts_below());
+                ahead[b].n = ob.opt.upcoming(ahead[b].x, MAX_POINTS_PER_ROUND, MAX_SPECULATIVE_RESTARTS, active < eager_restarts_below(), &ahead_certain[b]);
         }
         for (int rank = 0; rank < MAX_POINTS_PER_ROUND && eng.free_evaluations() > 0; ++rank) {
             bool any = false;
@@ -1089,21 +1123,75 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
                 if ((ob.stage % 2) == 0) {  // rho: the block's own eigen-system, brought up to date if need be
                     const bool stale = !ob.eig_valid || std::memcmp(ob.eig_settings, ob.q_settings, sizeof ob.q_settings) != 0;
                     if (stale && !rebuilt[b]) {
-                        k = eng.queue(b, static_cast<uint32_t>(b), x, ob.q_settings, false, ob.eig_valid ? static_cast<int32_t>(b) : -1);
+                        k = eng.queue(b, ob.slot[ROLE_OWN], x, ob.q_settings, false, ob.eig_valid ? static_cast<int32_t>(ob.slot[ROLE_OWN]) : -1);
                         std::memcpy(ob.eig_settings, ob.q_settings, sizeof ob.q_settings);
                         ob.eig_valid = true;
                         rebuilt[b] = 1;
                         ++eig_evals;
                     } else {
-                        k = eng.queue(b, static_cast<uint32_t>(b), x, nullptr, rebuilt[b] != 0);
+                        k = eng.queue(b, ob.slot[ROLE_OWN], x, nullptr, rebuilt[b] != 0);
                     }
-                } else {  // kappa: a probe model in a slot of its own
+                } else {  // kappa: a probe model
                     double qs[12];
                     std::memcpy(qs, ob.q_settings, sizeof qs);
                     qs[0] = x;
-                    k = eng.queue(b, static_cast<uint32_t>(n_blocks + eng.evals.size()), ob.tree_scale, qs, false,
-                                  (ob.eig_valid && !rebuilt[b]) ? static_cast<int32_t>(b) : -1);
-                    ++eig_evals;
+                    // Which probes may change what the block holds: the ends of the range, and the probes of the Brent phase (one per
+                    // round, each asked for only after its predecessor was consumed).  Random restarts never do, and always start from
+                    // the block's own system: whether a restart is evaluated ahead of need, and in which round, depends on how many
+                    // blocks share the engine -- no result may (tests/test_gpu_blocks.py, block groups).
+                    const bool certain = rank < ahead_certain[b];
+                    const bool brent_phase = ob.opt.draws_finished();
+                    auto holds = [&](int role) {   // the role's slot holds exactly this model, and is not being rewritten in this run
+                        const bool valid = role == ROLE_OWN ? (ob.eig_valid && !rebuilt[b]) : (ob.held_valid[role] && !(written[b] & (1u << role)));
+                        return valid && std::memcmp(role == ROLE_OWN ? ob.eig_settings : ob.held[role], qs, sizeof qs) == 0;
+                    };
+                    int hit = -1;
+                    for (int role = 0; role < N_ROLES && held_systems && hit < 0; ++role)
+                        if (holds(role)) hit = role;
+                    if (hit >= 0) {   // solved before (the block's own model, or an end of the kappa range in an earlier stage): no new eigen-system
+                        k = eng.queue(b, ob.slot[hit], ob.tree_scale, nullptr, false);
+                        ++eig_reused;
+                    } else {
+                        // where the new system goes: the ends of the range and the certain interior probes are kept, restarts are not
+                        int target = -1;
+                        if (held_systems && certain) {
+                            if (x == 1.0) target = ROLE_LO;
+                            else if (x == 10.0) target = ROLE_HI;
+                            else if (brent_phase) {
+                                target = ROLE_P0 + ob.next_p;
+                                ob.next_p ^= 1;
+                            }
+                        }
+                        // Jacobi starts in the eigenbasis of the nearest held system of the same family (all settings but kappa equal).
+                        // The ends only look at the block's own system and at what their slot held before: what else is complete when
+                        // they are solved depends on how the round was packed, and no result may depend on that.
+                        int32_t warm = -1;
+                        double best = 0.0;
+                        for (int role = 0; role < N_ROLES; ++role) {
+                            if ((!held_systems || target < 0) && role != ROLE_OWN) break;
+                            if ((target == ROLE_LO || target == ROLE_HI) && role != ROLE_OWN && role != target) continue;
+                            const double* hs = role == ROLE_OWN ? ob.eig_settings : ob.held[role];
+                            const bool valid = role == ROLE_OWN ? (ob.eig_valid && !rebuilt[b]) : (ob.held_valid[role] && !(written[b] & (1u << role)));
+                            if (!valid || std::memcmp(hs + 1, qs + 1, 11 * sizeof(double)) != 0) continue;
+                            const double dist = std::fabs(hs[0] - x);
+                            if (warm < 0 || dist < best) {
+                                warm = static_cast<int32_t>(ob.slot[role]);
+                                best = dist;
+                            }
+                        }
+                        if (warm < 0 && ob.eig_valid && !rebuilt[b]) warm = static_cast<int32_t>(ob.slot[ROLE_OWN]);   // another family: still better than a cold start
+                        uint32_t dst;
+                        if (target >= 0 && !(written[b] & (1u << target))) {
+                            dst = ob.slot[target];
+                            std::memcpy(ob.held[target], qs, sizeof qs);
+                            ob.held_valid[target] = true;
+                            written[b] |= 1u << target;
+                        } else {
+                            dst = static_cast<uint32_t>(transient0 + eng.evals.size());
+                        }
+                        k = eng.queue(b, dst, ob.tree_scale, qs, false, warm);
+                        ++eig_evals;
+                    }
                 }
                 pending.push_back({b, k, x});
             }
@@ -1139,8 +1227,8 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
         fprintf(stderr, "run_omega: %zu evaluations consumed by the optimisers, %zu speculative ones never asked for\n", used, unused);
     }
     if (timing)
-        fprintf(stderr, "run_omega: %zu blocks (%zu on the factored path), %zu rounds, %zu evaluations (%zu with a new eigen-system): host %.3f s, device rounds %.3f s; engine set-up %.3f s, validation passes + F3x4 counts %.3f s, whole call %.3f s\n",
-                n_blocks, static_cast<size_t>(std::count(eng.block_factored.begin(), eng.block_factored.end(), 1)), rounds, evals, eig_evals, t_host, t_run, t_setup, t_prelude, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count());
+        fprintf(stderr, "run_omega: %zu blocks (%zu on the factored path), %zu rounds, %zu evaluations (%zu with a new eigen-system, %zu kappa probes on a held one, %zu stage ends adopted one): host %.3f s, device rounds %.3f s; engine set-up %.3f s, validation passes + F3x4 counts %.3f s, whole call %.3f s\n",
+                n_blocks, static_cast<size_t>(std::count(eng.block_factored.begin(), eng.block_factored.end(), 1)), rounds, evals, eig_evals, eig_reused, eig_adopted, t_host, t_run, t_setup, t_prelude, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count());
     for (size_t b = 0; b < n_blocks; ++b) {
         const OmegaBlock& ob = *blk[b];
         out_phylo[b] = ob.failed ? NAN : decibans(ob.lpr_h1, ob.lpr_h0);

@@ -52,14 +52,17 @@ public:
     // eager_restarts: also list random restarts BEFORE it is known that the search needs any (lo, hi and the start not yet
     // evaluated).  Most searches need none -- the start beats both ends -- so those evaluations are usually thrown away: a third
     // of all OMEGA evaluations on a 5,088-block list (profiles/r03).  Worth it only while a round is latency-bound (few blocks).
-    int upcoming(double* xs, int max_points, int max_restarts, bool eager_restarts = true) const
+    // n_certain (optional): how many of the points, from the front, the search WILL ask for whatever the values (the rest are
+    // restarts that may never be consumed)
+    int upcoming(double* xs, int max_points, int max_restarts, bool eager_restarts = true, int* n_certain = nullptr) const
     {
-        int n = 0;
+        int n = 0, certain = -1;
         auto push = [&](double x) {
             if (n < max_points) xs[n++] = x;
         };
         if (done_ || max_points <= 0) return 0;
         auto restarts = [&](int already) {  // the next random starting points
+            certain = n;
             if (!gen_ || max_restarts <= 0) return;
             std::mt19937 g = *gen_;
             for (int t = already, k = 0; t < 250 && k < max_restarts && n < max_points; ++t, ++k) {
@@ -115,6 +118,7 @@ public:
                 push(request_);
                 break;
         }
+        if (n_certain) *n_certain = certain < 0 ? n : certain;
         return n;
     }
 
