@@ -76,22 +76,40 @@ __global__ __launch_bounds__(256) void edge_scale_kernel(const ExpmEval* __restr
         const double t = static_cast<double>(static_cast<float>(static_cast<double>(len) * ev.x));
         dst[static_cast<size_t>(b) * 64 + pos] = exp(lam * t);
     }
-    // the evaluation's row-sum check, by wave 0 (its branches include the longest of every fourth; take the overall
-    // longest from all branches -- a scalar loop over cached values)
-    if (wave == 0) {
-        for (uint32_t i = 0; i < n_branches; ++i) longest = fmaxf(longest, branch_len[i]);
-        const double* __restrict__ L = eig_left + static_cast<size_t>(ev.eig) * 4096;
+    // The evaluation's row-sum check, by all four waves: thread t owns 16 consecutive entries of row t >> 2 of L and of R (128
+    // contiguous bytes each: the first version had ONE wave walk both matrices with a row per lane -- 128 uncoalesced wave-loads,
+    // ~150 us of a ~185 us launch that sits on every round's critical path).  c = L 1 first, then sum_k R_ik e_k c_k at the longest branch.
+    for (uint32_t i = 0; i < n_branches; ++i) longest = fmaxf(longest, branch_len[i]);
+    const int row = tid >> 2, part = tid & 3;
+    {
+        const double2_t* __restrict__ L2 = reinterpret_cast<const double2_t*>(eig_left + static_cast<size_t>(ev.eig) * 4096 + row * 64 + 16 * part);
         double c = 0.0;
-        for (int j = 0; j < 64; ++j) c += L[lane * 64 + j];
-        const double t = static_cast<double>(static_cast<float>(static_cast<double>(longest) * ev.x));
-        ec[lane] = exp(lam * t) * c;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double2_t v = L2[u];
+            c += v.x;
+            c += v.y;
+        }
+        c += __shfl_xor(c, 1);
+        c += __shfl_xor(c, 2);
+        if (part == 0) {
+            const double t = static_cast<double>(static_cast<float>(static_cast<double>(longest) * ev.x));
+            ec[row] = exp(eig_lambda[static_cast<size_t>(ev.eig) * 64 + row] * t) * c;
+        }
     }
     __syncthreads();
-    if (wave == 0) {
-        const double* __restrict__ R = eig_right + static_cast<size_t>(ev.eig) * 4096;
+    {
+        const double2_t* __restrict__ R2 = reinterpret_cast<const double2_t*>(eig_right + static_cast<size_t>(ev.eig) * 4096 + row * 64 + 16 * part);
         double sum = 0.0;
-        for (int k = 0; k < 64; ++k) sum += R[lane * 64 + k] * ec[k];
-        if (!(fabs(sum - 1.0) <= 1e-6)) fail[ev.table] = 1u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double2_t v = R2[u];
+            sum += v.x * ec[16 * part + 2 * u];
+            sum += v.y * ec[16 * part + 2 * u + 1];
+        }
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        if (part == 0 && !(fabs(sum - 1.0) <= 1e-6)) fail[ev.table] = 1u;
     }
 }
 
