@@ -85,6 +85,9 @@ PruneParams base_prune_params(const pcsf_ctx* c)
 {
     PruneParams p{};
     p.program = c->d_program.as<uint32_t>();
+    p.op_leaves = c->d_op_meta.ptr ? c->d_op_leaves.as<uint64_t>() : nullptr;
+    p.op_meta = c->d_op_meta.ptr ? c->d_op_meta.as<uint32_t>() : nullptr;
+    p.gap_tab = c->d_gap_tab.as<double>();
     p.n_ops = static_cast<int>(c->schedule.program.size());
     p.n_edges = static_cast<int>(c->schedule.slot_node.size());
     p.n_leaves = c->n_leaves;
@@ -122,6 +125,12 @@ int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t le
         variant = 32;
     }
     if (c->schedule.stack_depth > pcsf::MAX_STACK_DEPTH) variant = (variant == 32 ? 32 : 0) | 64;  // parked tiles in scratch memory
+    // All-gap subtrees of a work-group's 64 columns cost nothing (kernels.hip SKIP).  Default: on where the columns come from
+    // alignments (the six-frame entry points: species missing from a block are missing for hundreds of columns; 1.7x on a MAF with
+    // clade-level drop-out, neutral on the bench's), off for the raw codon-matrix entry points, whose columns have no such structure
+    // and would only pay the compaction (1.3 %).  PCSF_SKIP_ALLGAP=1 / 0 forces it on / off everywhere; scores are bit-identical.
+    const bool skip = c->skip_allgap_forced ? c->skip_allgap : (fused != nullptr);
+    if (skip && p.op_meta && p.gap_tab && p.n_ops <= 128 && p.n_leaves <= 128 && (variant & ~(32 | 64)) == 0) variant |= 128;
     hipError_t e;
     if (c->timing && (e = hipEventRecord(c->ev0, stream)) != hipSuccess) return c->hip_fail(e, "hipEventRecord");
     if ((e = launch_prune_fixed(p, variant, stream, c->extra_lds)) != hipSuccess) return c->hip_fail(e, "launch prune_fixed");
@@ -393,7 +402,36 @@ int pcsf_create(pcsf_ctx** out, const pcsf_model_desc* m, int device_id)
     if (const char* v = std::getenv("PCSF_PRIO_MODE")) c->prio_mode = std::atoi(v);
     if (const char* v = std::getenv("PCSF_EXTRA_LDS")) c->extra_lds = static_cast<size_t>(std::atoi(v));
     if (const char* v = std::getenv("PCSF_FUSED_FRONTEND")) c->fused_frontend = std::atoi(v) != 0;
+    if (const char* v = std::getenv("PCSF_SKIP_ALLGAP")) {
+        c->skip_allgap = std::atoi(v) != 0;
+        c->skip_allgap_forced = true;
+    }
     if (const char* v = std::getenv("PCSF_DUMP_CODONS")) c->dump_codons = std::atoi(v) != 0;
+    if (c->skip_allgap && c->d_op_meta.ptr) {
+        // What the full program makes of subtrees that are all gaps -- column-independent vectors close to 1 -- recorded once, by the
+        // full program itself (diagnostic variant, one work-group of all-gap columns): the skipping variants substitute these values,
+        // so their scores are bit-identical to the full program's.
+        const size_t ne = c->schedule.slot_node.size(), doubles = 2 * (ne + 1) * 64;
+        pcsf::DeviceBuffer d_gaps;
+        const size_t nl = static_cast<size_t>(c->n_leaves);
+        if ((e = c->d_gap_tab.reserve(doubles * sizeof(double))) != hipSuccess || (e = d_gaps.reserve(nl * 64)) != hipSuccess ||
+            (e = hipMemset(c->d_gap_tab.ptr, 0, doubles * sizeof(double))) != hipSuccess || (e = hipMemset(d_gaps.ptr, 64, nl * 64)) != hipSuccess) {
+            g_create_error = std::string("pcsf_create (all-gap messages): ") + hipGetErrorString(e);
+            return PCSF_ERR_HIP;
+        }
+        pcsf::PruneParams gp = pcsf::base_prune_params(c.get());
+        gp.gap_tab = nullptr;
+        gp.gap_dump = c->d_gap_tab.as<double>();
+        gp.stamps = nullptr;
+        gp.codons = d_gaps.as<uint8_t>();
+        gp.n_sites = 64;
+        gp.leaf_stride = 64;
+        if ((e = pcsf::launch_prune_fixed(gp, c->schedule.stack_depth > pcsf::MAX_STACK_DEPTH ? 66 : 2, c->stream, 0)) != hipSuccess ||
+            (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
+            g_create_error = std::string("pcsf_create (all-gap messages): ") + hipGetErrorString(e);
+            return PCSF_ERR_HIP;
+        }
+    }
     if (const char* v = std::getenv("PCSF_PRUNE_VARIANT")) {
         const int vi = std::atoi(v);
         if (vi >= 0 && vi < pcsf::prune_variant_count()) c->variant = vi;

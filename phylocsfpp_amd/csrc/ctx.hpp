@@ -80,11 +80,14 @@ struct pcsf_ctx {
     // device-resident model (table sets 0 = coding, 1 = non-coding at tree scale 1)
     pcsf::DeviceBuffer d_program, d_frag, d_leaf_tab, d_prior, d_anc_weight;
     pcsf::DeviceBuffer d_op_leaves, d_op_meta;  // schedule.hpp ProgramFacts of the program (empty for trees of more than 128 leaves)
+    pcsf::DeviceBuffer d_gap_tab;               // [2][n_edges + 1][64] messages of all-gap subtrees, recorded by the full kernel (kernels.hip SKIP)
     // scratch for the host-pointer entry points
     pcsf::DeviceBuffer d_codons, d_out, d_lnz, d_anc, d_stamps, d_nucl, d_segments, d_wg_seg;
     bool dump_codons = false;            // diagnostics (PCSF_DUMP_CODONS=1): the fused front end also writes its codons to d_codons
     size_t last_total_sites = 0;
     bool fused_frontend = true;          // six-frame translation inside the pruning kernel (PCSF_FUSED_FRONTEND=0: separate kernel)
+    bool skip_allgap = true;             // tracks mode skips all-gap subtrees per work-group (kernels.hip SKIP)
+    bool skip_allgap_forced = false;     // PCSF_SKIP_ALLGAP given: `skip_allgap` for every entry point; else on for the six-frame ones only
     // branch-length score (pcsf_set_bls_branch_lengths)
     pcsf::DeviceBuffer d_bls_tree, d_bls_out, d_bls_spans, d_bls_flag;
     pcsf::BlsTree bls_tree{};

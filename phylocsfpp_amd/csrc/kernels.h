@@ -28,6 +28,8 @@ struct PruneParams {
     size_t n_sites;
     size_t leaf_stride;
     const uint32_t* program; // [n_ops]
+    const uint64_t* op_leaves;   // [n_ops][2] and
+    const uint32_t* op_meta;     // [n_ops]: schedule.hpp ProgramFacts of `program` (variants + 128; null for trees of more than 128 leaves)
     int n_ops;
     int n_edges;             // MATMUL ops per model (= internal non-root nodes)
     int n_leaves;
@@ -49,6 +51,8 @@ struct PruneParams {
     int prio_mode;               // experiment (PCSF_PRIO_MODE): 1 = the wave in the odd hardware slot of its SIMD runs at priority 0,
                                  // the other at 3 (asymmetric: one work-group of a CU owns the matrix pipe, the other fills its gaps)
     uint32_t stagger_first_blocks;
+    const double* gap_tab;       // variants + 128: [n_passes][n_edges + 1][64] recorded messages of all-gap subtrees (lane order), see kernels.hip
+    double* gap_dump;            // diagnostic variants (2, 66) only: where work-group 0 records them; else null
     unsigned long long* stamps;  // diagnostic variant only: [2][n_ops][4] s_memtime values, else null
     uint32_t stamp_block;
     double* out_score;       // [n_sites] or null
@@ -60,6 +64,7 @@ struct PruneParams {
 // 2 = variant 0 with in-kernel stamps (diagnostic only), 16 = block mode (per-work-group windows and tables),
 // 32 = variant 0 with the six-frame front end fused in (codons formed from nucleotide rows in the prologue);
 // + 64 (variants 0, 16, 32): trees that need more than MAX_STACK_DEPTH_DEV parked tiles -- the stack lives in scratch memory
+// + 128 (variants 0, 32, also with + 64): all-gap subtrees of a work-group's columns are skipped (needs op_leaves / op_meta)
 hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t stream, size_t extra_lds = 0);
 int prune_variant_count();
 

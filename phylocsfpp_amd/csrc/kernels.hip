@@ -123,7 +123,16 @@ __device__ __forceinline__ unsigned long long stamp_now()
 // work-group that scores the columns, and the leaf-major codon matrix never exists in HBM.
 // DEEP: the tree needs more than MAX_STACK_DEPTH_DEV parked tiles (no tree the reference ships does): pushes and pops
 // nest, so the kernel keeps a stack pointer of its own and parks the tiles in scratch memory.
-template <int NW, bool STAMP, bool BLOCKS, bool FUSED, bool DEEP>
+// SKIP (tracks mode, trees of at most 128 leaves): subtrees that are gaps in all of the work-group's columns cost nothing.  Real
+// multi-species alignments leave most species out of most blocks (they reach the kernel as N-padded rows, codon 64).  The message of
+// an all-gap subtree does not depend on the column -- it is what the full program computes from the tables' row-sum rows, a vector
+// close to 1 (src/instance.hpp:625-639, src/fixed_lik.hpp:111-117) -- so the context records it once per edge and model with the
+// full kernel itself (p.gap_dump, diagnostic variant) and the work-group compacts the program in its prologue: ops whose result is
+// an all-gap message and that do not touch the stack of parked tiles disappear, and any op above an all-gap subtree takes the recorded
+// message instead of its product (`gap_before`).  Every score is BIT-IDENTICAL to the full program's: the recorded vectors are the
+// full program's own values.
+
+template <int NW, bool STAMP, bool BLOCKS, bool FUSED, bool DEEP, bool SKIP>
 __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -236,6 +245,99 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     for (int i = tid; i < p.n_ops; i += NW * 64) lprog[i] = p.program[i];
     const unsigned char* my_cod = lcod + wave * 16 + sl;  // + leaf*SITES
     __syncthreads();
+    // SKIP: the work-group's own program (see above), built by wave 0 from the leaves that have a codon in any of its columns
+    __shared__ unsigned long long lhas[2];
+    __shared__ uint32_t lprog2[SKIP ? 128 : 1];
+    __shared__ uint16_t lslot2[SKIP ? 128 : 1], lnext2[SKIP ? 128 : 1];   // table slot of the op's product; of the NEXT product (bit 15: in the next pass)
+    __shared__ uint32_t linfo2[SKIP ? 128 : 1];                         // lslot2 | lnext2 << 16: what the op loop fetches one op ahead, with the op word
+    __shared__ int lcount2[2];                                           // ops, first product's table slot (-1: no product at all)
+    if constexpr (SKIP) {
+        static_assert(NW == 4, "the presence pass reads 64-byte codon rows");
+        if (wave < 2) {
+            const int leaf = wave * 64 + lane;
+            bool has = false;
+            if (leaf < p.n_leaves) {
+                const uint4* row = reinterpret_cast<const uint4*>(lcod + leaf * SITES);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint4 w = row[u];
+                    has |= (w.x != 0x40404040u) | (w.y != 0x40404040u) | (w.z != 0x40404040u) | (w.w != 0x40404040u);
+                }
+            }
+            const unsigned long long m = __ballot(has);
+            if (lane == 0) lhas[wave] = m;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const unsigned long long has0 = lhas[0], has1 = lhas[1];
+            const int n_ops = p.n_ops;
+            uint32_t opw[2], mt[2];
+            unsigned long long ones_after[2], active[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int j = 64 * k + lane;
+                const bool valid = j < n_ops;
+                opw[k] = valid ? lprog[j] : (F_ROOT_DEV << 28);
+                mt[k] = valid ? p.op_meta[j] : 0u;
+                const unsigned long long l0 = valid ? p.op_leaves[2 * j] : 0ull, l1 = valid ? p.op_leaves[2 * j + 1] : 0ull;
+                ones_after[k] = __ballot(valid && ((l0 & has0) | (l1 & has1)) == 0ull);
+            }
+            uint32_t neww[2];
+            bool prod[2], gapb[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int j = 64 * k + lane;
+                const uint32_t code = opw[k] >> 28, args = opw[k] & 0x0fffffffu;
+                const bool is_push = code >= F_MM_PUSH_CHERRY0_DEV && code < F_MM_POP0_DEV, is_pop = code >= F_MM_POP0_DEV && code < F_ROOT_DEV;
+                const bool is_root = code >= F_ROOT_DEV;
+                const bool after = (ones_after[k] >> lane) & 1ull;
+                const bool before = lane > 0 ? ((ones_after[k] >> (lane - 1)) & 1ull) : (k == 1 && (ones_after[0] >> 63));   // op j - 1 left all ones
+                // Only ops without stack traffic disappear: a push or pop above all-gap subtrees costs no product either way (it
+                // takes the recorded message), and keeping them keeps the stack of parked tiles exactly as the full program has it.
+                const bool trivial = j < n_ops && after && !is_root && !is_push && !is_pop;
+                active[k] = __ballot(j < n_ops && !trivial);
+                neww[k] = opw[k];
+                (void)args;
+                gapb[k] = before && code != F_CHERRY_DEV;
+                prod[k] = !gapb[k] && code != F_CHERRY_DEV && !is_root;
+            }
+            const int n0 = __popcll(active[0]), n2 = n0 + __popcll(active[1]);
+            const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if ((active[k] >> lane) & 1ull) {
+                    const int pos = (k ? n0 : 0) + __popcll(active[k] & below);
+                    lprog2[pos] = neww[k];
+                    lslot2[pos] = static_cast<uint16_t>(mt[k] & 0x3fffu) | (prod[k] ? 0x8000u : 0u) | (gapb[k] ? 0x4000u : 0u);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // the product that follows every op (its matrix is staged while the op's own product runs)
+            unsigned long long pc[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) pc[k] = __ballot(64 * k + lane < n2 && (lslot2[64 * k + lane < n2 ? 64 * k + lane : 0] & 0x8000u));
+            const int first = pc[0] ? __builtin_ctzll(pc[0]) : (pc[1] ? 64 + __builtin_ctzll(pc[1]) : -1);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int j = 64 * k + lane;
+                if (j < n2) {
+                    const unsigned long long above0 = k == 0 ? (lane < 63 ? pc[0] & ~((2ull << lane) - 1ull) : 0ull) : 0ull;
+                    const unsigned long long above1 = k == 0 ? pc[1] : (lane < 63 ? pc[1] & ~((2ull << lane) - 1ull) : 0ull);
+                    const int nx = above0 ? __builtin_ctzll(above0) : (above1 ? 64 + __builtin_ctzll(above1) : -1);
+                    lnext2[j] = nx >= 0 ? static_cast<uint16_t>(lslot2[nx] & 0x3fffu) : static_cast<uint16_t>((first >= 0 ? (lslot2[first] & 0x3fffu) : 0u) | 0x8000u);
+                    linfo2[j] = static_cast<uint32_t>(lslot2[j]) | (static_cast<uint32_t>(lnext2[j]) << 16);
+                }
+            }
+            if (lane == 0) {
+                lcount2[0] = n2;
+                lcount2[1] = first >= 0 ? static_cast<int>(lslot2[first] & 0x3fffu) : -1;
+            }
+        }
+        __syncthreads();
+    }
+    const uint32_t* const prog = SKIP ? lprog2 : lprog;
+    const int n_run = SKIP ? lcount2[0] : p.n_ops;
 
     // ---- fragment staging: 32 KiB per slot, moved by LDS-DMA in 1 KiB wave-instructions
     constexpr int CHUNKS_PER_WAVE = 32 / NW;
@@ -264,8 +366,20 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
             stage_piece(std::integral_constant<int, 7>{}, slot, slot & 1);
         }
     };
-    int slot = 0;
-    if (total_slots > 0) stage_slot(0);
+    int slot = 0;   // products done so far: the LDS buffer a product reads is slot & 1 (SKIP: the table slot comes from lslot2)
+    if constexpr (SKIP) {
+        if (lcount2[1] >= 0 && total_slots > 0) {
+            stage_piece(std::integral_constant<int, 0>{}, lcount2[1], 0);
+            stage_piece(std::integral_constant<int, 1>{}, lcount2[1], 0);
+            stage_piece(std::integral_constant<int, 2>{}, lcount2[1], 0);
+            stage_piece(std::integral_constant<int, 3>{}, lcount2[1], 0);
+            static_assert(!SKIP || CHUNKS_PER_WAVE == 8, "four waves move eight pieces each");
+            stage_piece(std::integral_constant<int, 4>{}, lcount2[1], 0);
+            stage_piece(std::integral_constant<int, 5>{}, lcount2[1], 0);
+            stage_piece(std::integral_constant<int, 6>{}, lcount2[1], 0);
+            stage_piece(std::integral_constant<int, 7>{}, lcount2[1], 0);
+        }
+    } else if (total_slots > 0) stage_slot(0);
     // Two work-groups share a CU (one wave each per SIMD), run the same program and start together,
     // so they would reach their matrix phases and their between-product gaps at the same time and
     // leave the pipe idle in every gap.  The first generation of work-groups is staggered by
@@ -303,6 +417,26 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
         seg_cnt[6] = 1;
         stamp_prev += seg_sum[6];
     }
+    // recorded all-gap messages (SKIP): row `pass * (n_edges + 1) + slot`, slot n_edges = the root's partial likelihoods; [g][q] lane order
+    auto gap_row_ptr = [&](int row) { return reinterpret_cast<const double2_t*>(p.gap_tab + static_cast<size_t>(row) * 64 + g4 * 16); };
+    auto load_gap_row = [&](int row) {
+        const double2_t* r2 = gap_row_ptr(row);
+        LeafRow r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.v[i] = r2[i];
+        return r;
+    };
+    (void)load_gap_row;
+    // ... straight into the accumulator layout of a product's result: acc[t][r] = state 4 (4t + r) + g4
+    auto gap_message = [&](int row, double4_t (&dst)[4]) {
+        const double2_t* r2 = gap_row_ptr(row);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double2_t lo = r2[2 * t], hi = r2[2 * t + 1];
+            dst[t] = double4_t{lo.x, lo.y, hi.x, hi.y};
+        }
+    };
+    (void)gap_message;
     for (int model = 0; model < p.n_passes; ++model) {
         const double* __restrict__ leaf_tab = p.leaf_tab + static_cast<size_t>(table0 + model) * p.n_leaves * LEAF_TABLE_DOUBLES_DEV;
         const double* __restrict__ prior = p.prior + static_cast<size_t>(prior0 + model) * 64 + g4 * 16;
@@ -325,10 +459,12 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
         seg_cnt[K] += 1;                                                             \
         stamp_prev = ts_;                                                            \
     }
-        uint32_t op = __builtin_amdgcn_readfirstlane(lprog[0]);
-        uint32_t word_ahead = lprog[p.n_ops > 1 ? 1 : 0];
+        uint32_t op = __builtin_amdgcn_readfirstlane(prog[0]);
+        uint32_t word_ahead = prog[n_run > 1 ? 1 : 0];
+        uint32_t info = SKIP ? __builtin_amdgcn_readfirstlane(linfo2[0]) : 0u, info_ahead = SKIP ? linfo2[n_run > 1 ? 1 : 0] : 0u;
+        (void)info_ahead;
         uint32_t ca = my_cod[((op >> 14) & 0x3fff) * SITES], cb = my_cod[(op & 0x3fff) * SITES];
-        for (int ip = 0; ip < p.n_ops; ++ip) {
+        for (int ip = 0; ip < n_run; ++ip) {
             PCSF_STAMP_RAW(7)
             const uint32_t code = op >> 28;
             const int a = (op >> 14) & 0x3fff, b = op & 0x3fff;
@@ -339,11 +475,19 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
 #define PCSF_FETCH_NEXT_OP()                                                         \
     {                                                                                \
         op = __builtin_amdgcn_readfirstlane(word_ahead);                             \
-        word_ahead = lprog[ip + 2 < p.n_ops ? ip + 2 : p.n_ops - 1];                 \
+        word_ahead = prog[ip + 2 < n_run ? ip + 2 : n_run - 1];                      \
+        if constexpr (SKIP) {                                                        \
+            info = __builtin_amdgcn_readfirstlane(info_ahead);                       \
+            info_ahead = linfo2[ip + 2 < n_run ? ip + 2 : n_run - 1];                \
+        }                                                                            \
         ca = my_cod[((op >> 14) & 0x3fff) * SITES];                                  \
         cb = my_cod[(op & 0x3fff) * SITES];                                          \
     }
-            if (code == F_CHERRY_DEV || code >= F_ROOT_DEV) PCSF_FETCH_NEXT_OP()
+            // SKIP: table slot of the op's edge | 0x8000: the op runs a product | 0x4000: the walk's message before the op is all gaps
+            const uint32_t op_flags = info & 0xffffu, op_next = info >> 16;   // of THIS op: `info` moves on to the next op with `op`
+            (void)op_next;
+            const bool gap_before = SKIP && (op_flags & 0x4000u);
+            if (SKIP ? !(op_flags & 0x8000u) : (code == F_CHERRY_DEV || code >= F_ROOT_DEV)) PCSF_FETCH_NEXT_OP()   // the arms without a product
             PCSF_STAMP_RAW(5)
 
             // Every op except the first cherry and the root starts with a product.  Before it: (a) this wave's
@@ -374,7 +518,12 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     const double2_t* buf = lfrag + (slot & 1) * (FRAG_DOUBLES_DEV / 2);              \
     const int this_slot = slot;                                                      \
     /* branch-free: the last product re-stages its own slot into the idle buffer (never read) */ \
-    const int stage_next = this_slot + 1 < total_slots ? this_slot + 1 : this_slot;  \
+    int stage_next = this_slot + 1 < total_slots ? this_slot + 1 : this_slot;        \
+    if constexpr (SKIP) {                                                            \
+        const uint32_t nx_ = op_next;                                                \
+        const int pass_ = (nx_ & 0x8000u) ? model + 1 : model;                       \
+        stage_next = pass_ < p.n_passes ? pass_ * p.n_edges + static_cast<int>(nx_ & 0x3fffu) : model * p.n_edges + static_cast<int>(op_flags & 0x3fffu); \
+    }                                                                                \
     ++slot;
 // slot 1 of k-steps 0..CHUNKS_PER_WAVE-1: one LDS-DMA piece of the next slot each
 #define PCSF_STAGE_SLOT(q, j)                                                        \
@@ -384,12 +533,28 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     if constexpr (j == 3 && q == 13) PCSF_FETCH_NEXT_OP()
 // Cherry rows: piece i of row a in k-step i slot 2, of row b in k-step i slot 3 (i = 0..7); multiplied after the
 // product, by which time the last piece has been on its way for eight k-steps.
+/* diagnostic variant only: the message of every edge (and the root vector) of work-group 0's first column into p.gap_dump -- run once \
+   per context on an all-gap column, this records what SKIP substitutes for the products above all-gap subtrees */ \
+#define PCSF_DUMP(A)                                                                 \
+    if constexpr (STAMP) {                                                           \
+        if (p.gap_dump && blockIdx.x == 0 && wave == 0 && sl == 0) {                 \
+            double* d_ = p.gap_dump + (static_cast<size_t>(model) * (p.n_edges + 1) + (this_slot - model * p.n_edges)) * 64 + g4 * 16; \
+            _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) d_[q_] = A[q_ >> 2][q_ & 3]; \
+        }                                                                            \
+    }
 #define PCSF_PUSH_CHERRY(D)                                                          \
     {                                                                                \
-        PCSF_PRODUCT_PROLOGUE()                                                      \
         const double2_t* pa = leaf_row_ptr(leaf_tab, a, cod_a, g4);                  \
         const double2_t* pb = leaf_row_ptr(leaf_tab, b, cod_b, g4);                  \
         LeafRow ra, rb;                                                              \
+        if (gap_before) {   /* SKIP: the recorded message of the all-gap subtree is parked instead of a product */ \
+            gap_message(model * (p.n_edges + 1) + static_cast<int>(op_flags & 0x3fffu), stk[D]); \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) {                          \
+                ra.v[i] = pa[i * ROW_PIECE_STRIDE];                                  \
+                rb.v[i] = pb[i * ROW_PIECE_STRIDE];                                  \
+            }                                                                        \
+        } else {                                                                     \
+        PCSF_PRODUCT_PROLOGUE()                                                      \
         product(buf, lane, cur, stk[D], [&](auto qc, auto jc) {                         \
             constexpr int q = decltype(qc)::value;                                   \
             constexpr int j = decltype(jc)::value;                                   \
@@ -397,6 +562,8 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
             if constexpr (j == 2 && q < 8) ra.v[q] = pa[q * ROW_PIECE_STRIDE];       \
             if constexpr (j == 3 && q < 8) rb.v[q] = pb[q * ROW_PIECE_STRIDE];       \
         });                                                                          \
+        PCSF_DUMP(stk[D])                                                            \
+        }                                                                            \
         PCSF_STAMP(4)                                                                \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) {                              \
             cur[2 * i] = ra.v[i].x * rb.v[i].x;                                      \
@@ -406,12 +573,17 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     }
 #define PCSF_POP(D)                                                                  \
     {                                                                                \
+        if (gap_before) {                                                            \
+            gap_message(model * (p.n_edges + 1) + static_cast<int>(op_flags & 0x3fffu), acc); \
+        } else {                                                                     \
         PCSF_PRODUCT_PROLOGUE()                                                      \
         product(buf, lane, cur, acc, [&](auto qc, auto jc) {                         \
             constexpr int q = decltype(qc)::value;                                   \
             constexpr int j = decltype(jc)::value;                                   \
             PCSF_STAGE_SLOT(q, j)                                                    \
         });                                                                          \
+        PCSF_DUMP(acc)                                                               \
+        }                                                                            \
         PCSF_STAMP(2)                                                                \
         _Pragma("unroll") for (int q = 0; q < 16; ++q) cur[q] = stk[D][q >> 2][q & 3] * acc[q >> 2][q & 3]; \
         PCSF_STAMP(3)                                                                \
@@ -428,15 +600,22 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
                     break;
                 }
                 case F_MM_LEAF_DEV: {
-                    PCSF_PRODUCT_PROLOGUE()
                     const double2_t* pa = leaf_row_ptr(leaf_tab, a, cod_a, g4);
                     LeafRow ra;
+                    if (gap_before) {   // SKIP: the subtree below is all gaps: its recorded message, then the leaf as usual
+                        gap_message(model * (p.n_edges + 1) + static_cast<int>(op_flags & 0x3fffu), acc);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) ra.v[i] = pa[i * ROW_PIECE_STRIDE];
+                    } else {
+                    PCSF_PRODUCT_PROLOGUE()
                     product(buf, lane, cur, acc, [&](auto qc, auto jc) {
                         constexpr int q = decltype(qc)::value;
                         constexpr int j = decltype(jc)::value;
                         PCSF_STAGE_SLOT(q, j)
                         if constexpr (j == 2 && q >= 4 && q < 12) ra.v[q - 4] = pa[(q - 4) * ROW_PIECE_STRIDE];  // one 16-byte piece per k-step
                     });
+                    PCSF_DUMP(acc)
+                    }
                     PCSF_STAMP(2)
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
@@ -465,6 +644,21 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
                 case F_MM_POP0_DEV + 1: PCSF_POP(1) break;
                 case F_MM_POP0_DEV + 2: PCSF_POP(2) break;
                 default: {  // F_ROOT
+                    if (gap_before) {   // SKIP: every species a gap in all of the work-group's columns: the recorded root vector
+                        const LeafRow rr = load_gap_row(model * (p.n_edges + 1) + p.n_edges);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            cur[2 * i] = rr.v[i].x;
+                            cur[2 * i + 1] = rr.v[i].y;
+                        }
+                    }
+                    if constexpr (STAMP) {
+                        if (p.gap_dump && blockIdx.x == 0 && wave == 0 && sl == 0) {
+                            double* d_ = p.gap_dump + (static_cast<size_t>(model) * (p.n_edges + 1) + p.n_edges) * 64 + g4 * 16;
+#pragma unroll
+                            for (int q_ = 0; q_ < 16; ++q_) d_[q_] = cur[q_];
+                        }
+                    }
                     double z = 0.0;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) z += prior[q] * cur[q];
@@ -494,6 +688,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
 #undef PCSF_STAGE_SLOT
 #undef PCSF_FETCH_NEXT_OP
 #undef PCSF_PUSH_CHERRY
+#undef PCSF_DUMP
 #undef PCSF_POP
         }
     }
@@ -524,9 +719,10 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     }
 }
 
-template <int NW, bool STAMP, bool BLOCKS, bool FUSED = false, bool DEEP = false>
+template <int NW, bool STAMP, bool BLOCKS, bool FUSED = false, bool DEEP = false, bool SKIP = false>
 static hipError_t launch_impl(const PruneParams& p, hipStream_t stream, size_t extra_lds)
 {
+    if (SKIP && (!p.op_leaves || !p.op_meta || p.n_ops > 128 || p.n_leaves > 128)) return hipErrorInvalidValue;
     const size_t sites_per_block = static_cast<size_t>(NW) * 16;
     const size_t blocks = BLOCKS ? p.n_wgs : (p.n_sites + sites_per_block - 1) / sites_per_block;
     if (blocks == 0) return hipSuccess;
@@ -537,18 +733,18 @@ static hipError_t launch_impl(const PruneParams& p, hipStream_t stream, size_t e
         if (!p.nucl || !p.segments || !p.wg_first_seg) return hipErrorInvalidValue;
         lds = ((lds + 15) & ~size_t(15)) + 256 + sites_per_block * 9 + 16;  // character classes, codon starts, strands
     }
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 160 * 1024 - (SKIP ? 2048 : 0)) return hipErrorInvalidValue;   // SKIP: 1 KiB of static LDS beside the dynamic array
     // the attribute belongs to the (function, device) pair: one flag per template instantiation AND device.  Setting it
     // twice is harmless, so concurrent first launches from two host threads need no lock, only an atomic bit mask.
     static std::atomic<uint64_t> attr_set{0};
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     if (!(attr_set.load(std::memory_order_acquire) >> (dev & 63) & 1)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prune_fixed<NW, STAMP, BLOCKS, FUSED, DEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prune_fixed<NW, STAMP, BLOCKS, FUSED, DEEP, SKIP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (SKIP ? 2048 : 0));
         if (e != hipSuccess) return e;
         attr_set.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
     }
-    hipLaunchKernelGGL((prune_fixed<NW, STAMP, BLOCKS, FUSED, DEEP>), dim3(static_cast<unsigned>(blocks)), dim3(NW * 64), lds, stream, p);
+    hipLaunchKernelGGL((prune_fixed<NW, STAMP, BLOCKS, FUSED, DEEP, SKIP>), dim3(static_cast<unsigned>(blocks)), dim3(NW * 64), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -561,8 +757,14 @@ hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t str
         case 16: return launch_impl<4, false, true>(p, stream, extra_lds); // per-work-group windows/tables
         case 32: return launch_impl<4, false, false, true>(p, stream, extra_lds);  // tracks mode, codons formed from the nucleotide rows
         case 64: return launch_impl<4, false, false, false, true>(p, stream, extra_lds);       // + 64: parked tiles in scratch (deep trees)
+        case 64 + 2: return launch_impl<4, true, false, false, true>(p, stream, extra_lds);
         case 64 + 16: return launch_impl<4, false, true, false, true>(p, stream, extra_lds);
         case 64 + 32: return launch_impl<4, false, false, true, true>(p, stream, extra_lds);
+        // + 128 (tracks mode, trees of at most 128 leaves): all-gap subtrees of a work-group's columns are skipped
+        case 128: return launch_impl<4, false, false, false, false, true>(p, stream, extra_lds);
+        case 128 + 32: return launch_impl<4, false, false, true, false, true>(p, stream, extra_lds);
+        case 128 + 64: return launch_impl<4, false, false, false, true, true>(p, stream, extra_lds);
+        case 128 + 64 + 32: return launch_impl<4, false, false, true, true, true>(p, stream, extra_lds);
         default: return hipErrorInvalidValue;
     }
 }

@@ -95,6 +95,60 @@ def test_linearity_property_large(oracle_models, gpu_contexts):
     np.testing.assert_allclose(a[:4096], m.run_tracks(base), rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("model", ["58mammals", "100vertebrates"])
+def test_all_gap_subtrees_are_skipped_without_changing_a_score(oracle_models, model, monkeypatch):
+    """Tracks mode drops, per work-group of 64 columns, every product above a subtree that is gaps in all 64 columns (kernels.hip SKIP;
+    the message of such a subtree does not depend on the column, the context records it once with the full program and the kernel
+    substitutes it; reference: src/instance.hpp:625-639, src/fixed_lik.hpp:111-117).  Windows with no species at all, one species, two
+    species of different clades, one clade, a random third, everything -- plus ordinary gaps -- against the oracle, and against the
+    same library with the skipping switched off (PCSF_SKIP_ALLGAP=0): bit for bit the same scores."""
+    import phylocsfpp_amd as pa
+    m = oracle_models(model)
+    rng = np.random.default_rng(77)
+    n_win = 48
+    cod = _columns(m, 64 * n_win, seed=31)
+    nl = m.nl
+    # clades: the leaves below a random internal node
+    c1, c2 = np.asarray(m.child1), np.asarray(m.child2)
+    def leaves_below(v):
+        return [v] if v < nl else leaves_below(int(c1[v])) + leaves_below(int(c2[v]))
+    for w in range(n_win):
+        kind = w % 8
+        if kind == 0:
+            keep = []
+        elif kind == 1:
+            keep = [int(rng.integers(nl))]
+        elif kind == 2:
+            keep = [0, nl - 1]
+        elif kind == 3:
+            keep = leaves_below(int(rng.integers(nl, 2 * nl - 2)))
+        elif kind == 4:
+            keep = list(np.flatnonzero(rng.random(nl) < 0.33))
+        elif kind == 5:
+            keep = leaves_below(int(rng.integers(nl, 2 * nl - 2))) + [int(rng.integers(nl))]
+        elif kind == 6:
+            keep = list(range(nl))
+        else:
+            keep = list(np.flatnonzero(rng.random(nl) < 0.08))
+        drop = np.ones(nl, bool)
+        drop[keep] = False
+        cod[drop, 64 * w:64 * (w + 1)] = 64
+    cod[rng.random(cod.shape) < 0.03] = 64
+    want = m.run_tracks(cod)
+    prefix = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "models", model)
+    got = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PCSF_SKIP_ALLGAP", flag)
+        ctx = pa.load_model(prefix).context(device=0)
+        got[flag] = ctx.score_sites_fixed(cod)
+        # a window boundary that is not a work-group boundary: the same columns shifted by 17
+        shifted = ctx.score_sites_fixed(np.ascontiguousarray(cod[:, 17:]))
+        np.testing.assert_allclose(shifted, want[17:], rtol=RTOL, atol=ATOL)
+        ctx.close()
+        np.testing.assert_allclose(got[flag], want, rtol=RTOL, atol=ATOL)
+    assert np.array_equal(got["1"], got["0"])
+
+
 def test_bench_sized_batch_of_two_million_sites(oracle_models, gpu_contexts):
     """BASELINE.json configs[2]'s batch as bench.py scores it (2,000,000 codon-frames in one call, 31,250 work-groups): the oracle on a
     strided sample of 64,516 sites, and for ALL sites the size-independent property that a site's score depends on its column alone --

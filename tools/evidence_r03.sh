@@ -1,0 +1,31 @@
+#!/bin/bash
+# Runs on the GPU box: the measurements DESIGN.md quotes for round 3.  bash tools/evidence_r03.sh [tag]  -> gpurun_out/<tag>/
+cd ${GRAFT_REPO_ROOT:-.}; export TMPDIR=/tmp; O=gpurun_out/${1:-evidence_r03}; mkdir -p $O
+make -s -C phylocsfpp_amd/host
+# ---- the bench line, its kernel statistics and PMC passes (separate runs)
+python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+bash tools/profile_gpu.sh r03 > $O/profile_gpu.log 2>&1
+cp gpurun_out/prof_r03/pmc_summary.json $O/pmc_summary.json
+cp $(find gpurun_out/prof_r03/trace -name "*kernel_stats.csv" | head -1) $O/kernel_stats_bench.csv
+# ---- BASELINE.json configs[2], block strategies: score-msa mle / omega on the synthetic 1 Mb MAF
+bash tools/config3_blocks.sh $O prof > /dev/null 2>&1
+for s in mle omega; do bash tools/c3_pmc.sh $s $O/config3_${s}_pmc.json > $O/config3_${s}_pmc.txt 2>&1; done
+{ for s in mle omega; do echo "== score-msa --strategy $s"; bash tools/c3_timeline.sh $s; done; } > $O/config3_timeline.txt 2>&1
+{ echo "== PCSF_BLOCK_KERNEL=factored (round 2's pair: prune_factored + expm / block-mode prune_fixed)"; PCSF_BLOCK_KERNEL=factored bash tools/c3_quick.sh mle omega 2>&1 | grep -E "seconds:|pruning kernel|run_";
+  echo "== PCSF_OMEGA_HELD_SYSTEMS=0"; PCSF_OMEGA_HELD_SYSTEMS=0 bash tools/c3_quick.sh omega 2>&1 | grep -E "seconds:|run_omega: [0-9]+ blocks";
+  echo "== PCSF_EAGER_RESTARTS_BELOW=1000000 (restarts evaluated ahead of need, as in round 2)"; PCSF_EAGER_RESTARTS_BELOW=1000000 bash tools/c3_quick.sh omega 2>&1 | grep -E "seconds:|run_omega: [0-9]+ "; } > $O/config3_ablations.txt 2>&1
+# ---- the tile kernel alone: sustained rate, stamps
+{ for a in "16384 64" "65536 64" "16384 64 100vertebrates"; do bash tools/tile_prof.sh $a; done; } > $O/tile_kernel_sustained.txt 2>&1
+# ---- the reference's real blocks (516-block file and copies of it): both pruning kernels
+{ for r in 1 4 16; do echo "== bench_blocks.py - 0 $r nocpu (default: kernel chosen per list)"; PCSF_TIME_BLOCKS=1 python3 tools/bench_blocks.py - 0 $r nocpu 2>&1 | grep -E "GPU |pruning kernel|run_omega: [0-9]+ blocks|run_mle: [0-9]+ blocks";
+    echo "== PCSF_BLOCK_KERNEL=tiles"; PCSF_BLOCK_KERNEL=tiles python3 tools/bench_blocks.py - 0 $r nocpu 2>&1 | grep "GPU "; done; } > $O/blocks_real_files.txt 2>&1
+bash tools/blocks516_timeline.sh > $O/blocks516_timeline.txt 2>&1
+# ---- tracks mode: all-gap subtrees skipped per work-group (tools/skip_e2e.sh)
+python3 tools/gen_synthetic_maf.py /tmp/syn1mb.maf --bases 1000000 > /dev/null 2>&1
+python3 tools/gen_synthetic_maf.py /tmp/clade1mb.maf --bases 1000000 --clade-dropout > $O/clade_maf.txt 2>&1
+python3 tools/replicate_maf.py /tmp/clade1mb.maf /tmp/clade10mb.maf --copies 10 > /dev/null 2>&1
+python3 tools/replicate_maf.py /tmp/syn1mb.maf /tmp/syn10mb.maf --copies 10 > /dev/null 2>&1
+{ for f in syn10mb clade10mb; do for skip in 1 0; do echo "== $f.maf, PCSF_SKIP_ALLGAP=$skip"; for i in 1 2; do PCSF_SKIP_ALLGAP=$skip phylocsfpp_amd/host/phylocsf-amd build-tracks --output /tmp/out_$f$skip 58mammals /tmp/$f.maf 2>&1 | tail -2; done; done;
+    echo "outputs of the two runs: $(diff -rq /tmp/out_${f}1 /tmp/out_${f}0 > /dev/null && echo identical || echo DIFFERENT)"; done; } > $O/skip_allgap.txt 2>&1
+for f in syn10mb clade10mb; do rm -rf /tmp/pk; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -- phylocsfpp_amd/host/phylocsf-amd build-tracks --output /tmp/out_pk 58mammals /tmp/$f.maf > /dev/null 2>&1; echo "== $f.maf"; head -4 $(find /tmp/pk -name "*kernel_stats.csv" | head -1) | cut -c1-170; done > $O/skip_allgap_kernel_stats.txt 2>&1
+ls -la $O

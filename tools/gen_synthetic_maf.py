@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 SEGMENT_CODONS = 120
 
 
-def generate(out, bases=1_000_000, seed=20261002, tree=None, start=1_000_000, exons=None):
+def generate(out, bases=1_000_000, seed=20261002, tree=None, start=1_000_000, exons=None, clade_dropout=False):
     """Writes the MAF (and, optionally, the matching coding-exon list); returns a dict describing it."""
     import phylocsfpp_amd as pa
     from phylocsfpp_amd import synth
@@ -51,6 +51,28 @@ def generate(out, bases=1_000_000, seed=20261002, tree=None, start=1_000_000, ex
     chrom_len = 2 * (start + bases + 100_000)
     ref_of = np.empty(bases, dtype=np.int64)   # 0-based reference position of generated base k (blocks may skip bases)
     n_blocks = 0
+    # --clade-dropout: species absence as real multiz alignments show it -- by clade and in long stretches.  Along the genome, stretches
+    # of ~Geom(mean 25) blocks keep only the species below one ancestor of the reference species (picked at random from the path to
+    # the root, deep ancestors = everything) before the per-block drop-out.  Uses a generator of its own: the default file is unchanged.
+    rng_clade = np.random.default_rng(seed + 1)
+    parent = np.asarray(m.parent)
+    path = []
+    v = 0
+    while parent[v] >= 0:
+        v = int(parent[v])
+        path.append(v)
+    c1, c2 = np.asarray(m.child1), np.asarray(m.child2)
+
+    def leaves_below(node):
+        out_, stack = [], [node]
+        while stack:
+            u = stack.pop()
+            if u < m.nl:
+                out_.append(u)
+            else:
+                stack += [int(c1[u]), int(c2[u])]
+        return out_
+    stretch_left, stretch_keep = 0, np.ones(m.nl, bool)
     with open(out, "w") as f:
         f.write("##maf version=1 scoring=synthetic\n")
         pos, ref = 0, start
@@ -58,6 +80,15 @@ def generate(out, bases=1_000_000, seed=20261002, tree=None, start=1_000_000, ex
             L = int(min(rng.geometric(1.0 / 200.0), bases - pos))
             present = rng.random(m.nl) >= 0.3
             present[:8] = True
+            if clade_dropout:
+                if stretch_left == 0:
+                    stretch_left = int(rng_clade.geometric(1.0 / 25.0))
+                    anc = path[min(len(path) - 1, int(rng_clade.geometric(0.12)) - 1 + 2)]
+                    stretch_keep = np.zeros(m.nl, bool)
+                    stretch_keep[leaves_below(anc)] = True
+                stretch_left -= 1
+                present &= stretch_keep
+                present[0] = True
             # reference-gap columns: '-' in the reference row, random bases in the other rows, BEFORE base k when ins[k]
             ins = rng.random(L) < 0.03
             cols = L + int(ins.sum())
@@ -108,11 +139,12 @@ def main():
     ap.add_argument("out")
     ap.add_argument("--bases", type=int, default=1_000_000)
     ap.add_argument("--seed", type=int, default=20261002)
-    ap.add_argument("--tree", default=os.path.join(ROOT, "tests/golden/models/100vertebrates"))
+    ap.add_argument("--tree", default=None, help="model whose tree names the species (default: the shipped 100vertebrates)")
     ap.add_argument("--start", type=int, default=1_000_000, help="0-based reference start of the first block")
     ap.add_argument("--exons", default=None, help="also write the coding segments as a --coding-exons list")
+    ap.add_argument("--clade-dropout", action="store_true", help="species absent by clade and in long stretches, like real multiz alignments")
     args = ap.parse_args()
-    info = generate(args.out, args.bases, args.seed, args.tree, args.start, args.exons)
+    info = generate(args.out, args.bases, args.seed, args.tree, args.start, args.exons, args.clade_dropout)
     print("wrote %s: %d reference bases, %d rows, %d blocks%s" % (args.out, info["bases"], info["rows"], info["blocks"],
           (", %d exons -> %s" % (info["exons"], args.exons)) if args.exons else ""))
 
