@@ -28,6 +28,7 @@ Prints ONE JSON line on rank 0.  Extra objects:
                   ("single_thread_value")
 """
 import argparse
+import contextlib
 import json
 import os
 import re
@@ -241,7 +242,8 @@ def end_to_end(device, runs, cpu_rate_all_cores, work_dir):
     try:
         import replicate_maf
         big = os.path.join(work_dir, "synthetic_x%d.maf" % E2E_TILES)
-        replicate_maf.tile(maf, big, E2E_TILES, 1_100_000)
+        with contextlib.redirect_stdout(sys.stderr):   # the tool reports what it wrote; stdout carries the one JSON line
+            replicate_maf.tile(maf, big, E2E_TILES, 1_100_000)
         big_runs = [run_cli(CLI, big, os.path.join(work_dir, "gpu_big"), ["--device", str(device)]) for _ in range(2)]
         b = min(big_runs, key=lambda r: r["seconds"])
         e2e["steady_state"] = {"maf": "the same segment tiled %d times along the chromosome (tools/replicate_maf.py), %d bytes" % (E2E_TILES, os.path.getsize(big)),
@@ -266,7 +268,8 @@ def end_to_end_multi(n_gpus, work_dir):
         gen.generate(maf, bases=E2E_BASES, seed=E2E_SEED)
     tiles = min(E2E_TILES * n_gpus, 40)
     big = os.path.join(work_dir, "synthetic_x%d.maf" % tiles)
-    replicate_maf.tile(maf, big, tiles, 1_100_000)
+    with contextlib.redirect_stdout(sys.stderr):
+        replicate_maf.tile(maf, big, tiles, 1_100_000)
     out = {"maf": "the 1 Mb synthetic segment tiled %d times (tools/replicate_maf.py), %d bytes" % (tiles, os.path.getsize(big)), "n_gpus": n_gpus}
     for label, devs in (("all_devices", ",".join(str(d) for d in range(n_gpus))), ("one_device", "0")):
         runs = [run_cli(CLI, big, os.path.join(work_dir, "gpu_multi_" + label), ["--devices", devs]) for _ in range(2)]
