@@ -68,6 +68,9 @@ typedef struct pcsf_ctx pcsf_ctx;
 /* ---- load_model (src/models.hpp:1757-1857): the model files behind the arrays above ----------
  * <prefix>_coding.ECM / <prefix>_noncoding.ECM (get_ecm: 63 lower-triangle rows, blank line, 64 frequencies;
  * src/ecm.hpp:20-67) and <prefix>.nh (newick_parse + newick_flatten, src/newick.hpp:31-229).
+ * prefix: like the reference's model_name_or_path (src/models.hpp:1766-1783) -- a prefix that names existing files, or, failing
+ * that, the bare NAME of a model that ships with the library ("53birds", "58mammals", "100vertebrates": the reference compiles its
+ * models in, src/models.hpp:1443-1455; here they are files in `models/` next to the library, $PCSF_MODEL_DIR first).
  * alias_file: "<tree label>\t<other names...>" per line, stands in for the name table compiled into the
  * reference (src/models.hpp:1240-1706); NULL = species_aliases.tsv next to the model files if present, "" = none.
  * species_csv: --species (tree reduced like newick_reduce, src/newick.hpp:286-363), NULL/"" = whole tree.
