@@ -62,24 +62,32 @@ __global__ __launch_bounds__(256) void edge_scale_kernel(const ExpmEval* __restr
                                                          const double* __restrict__ eig_lambda, double* __restrict__ scale_out,
                                                          uint32_t* __restrict__ fail)
 {
-    // one work-group per evaluation; wave w takes branches w, w+4, ...; lane k the eigenvalue k (no barrier in the loop)
+    // one work-group per evaluation; wave w takes branches w, w+4, ...; lane k the eigenvalue k.  The branch lengths go through LDS
+    // first (one coalesced load; reading them one by one in the loops below was ~250 dependent round trips to L2 per thread -- most
+    // of this kernel's 0.17 ms, which every round of the lock-step optimiser waits for).
     __shared__ double ec[64];
+    __shared__ float lens[512];
     const ExpmEval ev = evals[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double lam = eig_lambda[static_cast<size_t>(ev.eig) * 64 + lane];
     const int pos = row_split_pos(lane);
     double* __restrict__ dst = scale_out + static_cast<size_t>(ev.table) * n_branches * 64;
+    const bool staged = n_branches <= 512;
+    if (staged) {
+        for (uint32_t b = tid; b < n_branches; b += 256) lens[b] = branch_len[b];
+        __syncthreads();
+    }
     float longest = 0.0f;
     for (uint32_t b = wave; b < n_branches; b += 4) {
-        const float len = branch_len[b];
-        longest = fmaxf(longest, len);
+        const float len = staged ? lens[b] : branch_len[b];
         const double t = static_cast<double>(static_cast<float>(static_cast<double>(len) * ev.x));
         dst[static_cast<size_t>(b) * 64 + pos] = exp(lam * t);
     }
     // The evaluation's row-sum check, by all four waves: thread t owns 16 consecutive entries of row t >> 2 of L and of R (128
     // contiguous bytes each: the first version had ONE wave walk both matrices with a row per lane -- 128 uncoalesced wave-loads,
     // ~150 us of a ~185 us launch that sits on every round's critical path).  c = L 1 first, then sum_k R_ik e_k c_k at the longest branch.
-    for (uint32_t i = 0; i < n_branches; ++i) longest = fmaxf(longest, branch_len[i]);
+    for (uint32_t i = lane; i < n_branches; i += 64) longest = fmaxf(longest, staged ? lens[i] : branch_len[i]);
+    for (int sft = 32; sft > 0; sft >>= 1) longest = fmaxf(longest, __shfl_xor(longest, sft));
     const int row = tid >> 2, part = tid & 3;
     {
         const double2_t* __restrict__ L2 = reinterpret_cast<const double2_t*>(eig_left + static_cast<size_t>(ev.eig) * 4096 + row * 64 + 16 * part);
