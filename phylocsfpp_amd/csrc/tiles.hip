@@ -45,10 +45,12 @@ struct V16 {
     double v[16];
 };
 
-// R is kept row-major with its columns XOR-swizzled: element (i, j) at i * 64 + (j ^ swz(i)), swz(i) = ((i & 1) << 4) | (i & 14).
-// For R x the 32 lanes of a ds_read_b64 pass (s = 0..15, two values of g) then hit ((4q + g) ^ swz(s)) mod 32 = 32 different 8-byte
-// slots; for R^T x they hit 16 (t0 ^ (g & 1)) + (s ^ 4 (q & 3)): 32 different slots again.
-__device__ __forceinline__ int swz(int i) { return ((i & 1) << 4) | (i & 14); }
+// R is kept row-major with its columns XOR-swizzled: element (i, j) at i * 64 + (j ^ swz(i)), swz(i) = i & 15.  The compiler reads the
+// four tiles of a k-step as two ds_read2_b64, which the LDS serves in groups of 16 consecutive lanes (s = 0..15 at one g): for R x
+// they hit 8-byte slots ((4q + g) ^ s) mod 16 -- sixteen different ones --, for R^T x (s ^ g ^ 4 (q & 3)) mod 16: sixteen again.
+// (The first swizzle, ((i & 1) << 4) | (i & 14), was derived for 32-lane ds_read_b64 passes and cost a 2-way conflict on every
+// fragment read of R x: SQ_LDS_BANK_CONFLICT 5.8 cycles per LDS instruction.)
+__device__ __forceinline__ int swz(int i) { return i & 15; }
 
 // wave-uniform values the compiler cannot prove uniform (they pass through structs and loop-carried state): forcing them into
 // scalar registers turns the op loop's branches into scalar branches instead of EXEC-masked regions that evaluate both sides
@@ -89,9 +91,9 @@ __device__ __forceinline__ void product_R(const double* __restrict__ Rs, int s, 
     double4_t acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
-    // lane (s, g), tile t, k-step q reads R[16t + s][4q + g]: column (4q + g) ^ swz(s) = 4 (q ^ ms) + (g ^ (s & 2))
-    const int ms = ((s & 1) << 2) | ((s >> 2) & 3);
-    const double* __restrict__ base = Rs + s * 64 + (g ^ (s & 2));
+    // lane (s, g), tile t, k-step q reads R[16t + s][4q + g]: column (4q + g) ^ swz(s) = 4 (q ^ ms) + (g ^ (s & 3))
+    const int ms = (s >> 2) & 3;
+    const double* __restrict__ base = Rs + s * 64 + (g ^ (s & 3));
     double n0 = base[4 * ms], n1 = base[4 * ms + 1024], n2 = base[4 * ms + 2048], n3 = base[4 * ms + 3072];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -121,16 +123,15 @@ __device__ __forceinline__ void product_R(const double* __restrict__ Rs, int s, 
 }
 
 // o <- R^T x b: lane (s, g), tile t, k-step q reads R[4q + g][16t + s], stored at column (16t + s) ^ swz(4q + g)
-// = 32 (t >> 1) + 16 ((t & 1) ^ (g & 1)) + ((s ^ (g & 2)) ^ 4 (q & 3))
+// = 16 t + (s ^ g ^ 4 (q & 3))
 __device__ __forceinline__ void product_Rt(const double* __restrict__ Rs, int s, int g, const V16& b, V16& o)
 {
     double4_t acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
-    const int x = s ^ (g & 2), gb = g & 1;
-    const double* __restrict__ row0 = Rs + g * 64 + 16 * gb;        // tiles 0, 2 (+32); tiles 1, 3 sit at the other half: ^ 16
-    const double* __restrict__ row1 = Rs + g * 64 + 16 * (gb ^ 1);
-    double n0 = row0[x], n1 = row1[x], n2 = row0[32 + x], n3 = row1[32 + x];
+    const int x = s ^ g;
+    const double* __restrict__ row0 = Rs + g * 64;   // tile t at + 16 t
+    double n0 = row0[x], n1 = row0[16 + x], n2 = row0[32 + x], n3 = row0[48 + x];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const double f0 = n0, f1 = n1, f2 = n2, f3 = n3;
@@ -141,9 +142,9 @@ __device__ __forceinline__ void product_Rt(const double* __restrict__ Rs, int s,
         if (q + 1 < 16) {
             const int xq = x ^ (4 * ((q + 1) & 3));
             n0 = row0[(q + 1) * 256 + xq];
-            n1 = row1[(q + 1) * 256 + xq];
+            n1 = row0[(q + 1) * 256 + 16 + xq];
             n2 = row0[(q + 1) * 256 + 32 + xq];
-            n3 = row1[(q + 1) * 256 + 32 + xq];
+            n3 = row0[(q + 1) * 256 + 48 + xq];
         }
 #endif
         __builtin_amdgcn_sched_barrier(0);
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64, 2) void prune_tiles(const Factored
     const uint32_t eig = p.jobs[grp.job0].eig;
 
     // ---- R of the group's eigen-system into LDS: thread t takes row i = t >> 2, columns 16 (t & 3) .. +15 (128 contiguous bytes);
-    // swz(i) is even, so a pair of columns stays a pair: eight 16-byte stores
+    // a pair of columns (2u, 2u + 1) stays a pair under the swizzle -- swapped when swz(i) is odd: eight 16-byte stores
     for (int vt = tid; vt < 256; vt += n_threads) {
         const int i = vt >> 2, cc = vt & 3;
         const double2_t* __restrict__ Rg = reinterpret_cast<const double2_t*>(p.eig_right + static_cast<size_t>(eig) * 4096 + i * 64 + 16 * cc);
@@ -190,7 +191,8 @@ __global__ __launch_bounds__(TILE_WAVES * 64, 2) void prune_tiles(const Factored
         for (int u = 0; u < 8; ++u) r[u] = Rg[u];
         const int sw = swz(i);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) *reinterpret_cast<double2_t*>(Rs + i * 64 + ((16 * cc + 2 * u) ^ sw)) = r[u];
+        for (int u = 0; u < 8; ++u)
+            *reinterpret_cast<double2_t*>(Rs + i * 64 + (((16 * cc + 2 * u) ^ sw) & ~1)) = (sw & 1) ? double2_t{r[u].y, r[u].x} : r[u];
     }
     if (tid < 64) wL[tid] = p.eig_w[static_cast<size_t>(eig) * 64 + tid];
     for (int i = tid; i < static_cast<int>((p.n_ops + 63) & ~63u); i += n_threads) lprog[i] = p.program[i < p.n_ops ? i : p.n_ops - 1];
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64, 2) void prune_tiles(const Factored
         X.mask = Y.mask = 0xffffu;
         X.eig = Y.eig = false;
         // leaf a, eigen form: L[:, codon] o e_a, column `codon` of L being row `codon` of R times w[codon]:
-        // R[c][4q + g] sits at column (4q + g) ^ swz(c) = 4 (q ^ mc) + (g ^ (c & 2)).  A gap column's entries never matter: its message
+        // R[c][4q + g] sits at column (4q + g) ^ swz(c) = 4 (q ^ mc) + (g ^ (c & 3)).  A gap column's entries never matter: its message
         // is forced to exactly 1 when the real form is made.
         auto leaf = [&](int a) __attribute__((always_inline)) -> Msg {
             Msg T;
@@ -282,8 +284,8 @@ __global__ __launch_bounds__(TILE_WAVES * 64, 2) void prune_tiles(const Factored
             PCSF_TILE_SEG0()
             const V16 e = load_scale(a);
             const unsigned col = code == 64u ? 0u : code;
-            const int mc = ((col & 1) << 2) | ((col >> 2) & 3);
-            const double* __restrict__ base = Rs + col * 64 + (g ^ (col & 2));
+            const int mc = (col >> 2) & 3;
+            const double* __restrict__ base = Rs + col * 64 + (g ^ (col & 3));
             const double wc = wL[(col & 3) * 16 + (col >> 2)];
 #pragma unroll
             for (int q = 0; q < 16; ++q) T.v.v[q] = base[4 * (q ^ mc)] * wc * e.v[q];
