@@ -91,10 +91,13 @@ __device__ __forceinline__ void product_R(const double* __restrict__ Rs, int s, 
     double4_t acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
-    // lane (s, g), tile t, k-step q reads R[16t + s][4q + g]: column (4q + g) ^ swz(s) = 4 (q ^ ms) + (g ^ (s & 3))
+    // lane (s, g), tile t, k-step q reads R[16t + s][4q + g]: column (4q + g) ^ swz(s) = 4 (q ^ ms) + (g ^ (s & 3)), ms = s >> 2.  ms only
+    // touches the low two bits of q: four per-lane addresses (q & 3 = 0..3) and compile-time offsets for the rest -- no address
+    // arithmetic between the MFMAs (integer VALU instructions take the matrix pipe's time like any other)
     const int ms = (s >> 2) & 3;
     const double* __restrict__ base = Rs + s * 64 + (g ^ (s & 3));
-    double n0 = base[4 * ms], n1 = base[4 * ms + 1024], n2 = base[4 * ms + 2048], n3 = base[4 * ms + 3072];
+    const double* __restrict__ bj[4] = {base + 4 * (0 ^ ms), base + 4 * (1 ^ ms), base + 4 * (2 ^ ms), base + 4 * (3 ^ ms)};
+    double n0 = bj[0][0], n1 = bj[0][1024], n2 = bj[0][2048], n3 = bj[0][3072];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const double f0 = n0, f1 = n1, f2 = n2, f3 = n3;
@@ -103,7 +106,7 @@ __device__ __forceinline__ void product_R(const double* __restrict__ Rs, int s, 
         __builtin_amdgcn_sched_barrier(0);
 #ifndef PCSF_TILES_NO_FRAGMENT_READS
         if (q + 1 < 16) {
-            const double* __restrict__ nx = base + 4 * ((q + 1) ^ ms);
+            const double* __restrict__ nx = bj[(q + 1) & 3] + 16 * ((q + 1) >> 2);
             n0 = nx[0];
             n1 = nx[1024];
             n2 = nx[2048];
@@ -131,7 +134,8 @@ __device__ __forceinline__ void product_Rt(const double* __restrict__ Rs, int s,
     for (int t = 0; t < 4; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
     const int x = s ^ g;
     const double* __restrict__ row0 = Rs + g * 64;   // tile t at + 16 t
-    double n0 = row0[x], n1 = row0[16 + x], n2 = row0[32 + x], n3 = row0[48 + x];
+    const double* __restrict__ bj[4] = {row0 + (x ^ 0), row0 + (x ^ 4), row0 + (x ^ 8), row0 + (x ^ 12)};   // by q & 3; the rest are constants
+    double n0 = bj[0][0], n1 = bj[0][16], n2 = bj[0][32], n3 = bj[0][48];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const double f0 = n0, f1 = n1, f2 = n2, f3 = n3;
@@ -140,11 +144,11 @@ __device__ __forceinline__ void product_Rt(const double* __restrict__ Rs, int s,
         __builtin_amdgcn_sched_barrier(0);
 #ifndef PCSF_TILES_NO_FRAGMENT_READS
         if (q + 1 < 16) {
-            const int xq = x ^ (4 * ((q + 1) & 3));
-            n0 = row0[(q + 1) * 256 + xq];
-            n1 = row0[(q + 1) * 256 + 16 + xq];
-            n2 = row0[(q + 1) * 256 + 32 + xq];
-            n3 = row0[(q + 1) * 256 + 48 + xq];
+            const double* __restrict__ nx = bj[(q + 1) & 3] + (q + 1) * 256;
+            n0 = nx[0];
+            n1 = nx[16];
+            n2 = nx[32];
+            n3 = nx[48];
         }
 #endif
         __builtin_amdgcn_sched_barrier(0);
@@ -308,7 +312,10 @@ __global__ __launch_bounds__(TILE_WAVES * 64, 2) void prune_tiles(const Factored
             } else {
                 const bool gap_col = (tmask >> sj) & 1u;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) out.v.v[q] = gap_col ? 1.0 : fmax(out.v.v[q], 0.0);
+                for (int q = 0; q < 16; ++q) {
+                    const double c = clamp0(out.v.v[q]);   // unconditionally: inside the select the compiler would branch around the asm
+                    out.v.v[q] = gap_col ? 1.0 : c;
+                }
             }
             out.mask = tmask;
             out.eig = false;
