@@ -219,3 +219,43 @@ def test_tree_deeper_than_the_register_stack(tmp_path, golden_dir):
                                       C.byref(lpr), C.byref(anc), None) == 0
         assert not failed[b] and abs(got[b] - lpr.value) <= 1e-9 * abs(lpr.value)
     ctx.close()
+
+
+def test_tree_of_more_than_128_leaves(tmp_path, golden_dir):
+    """Species sets are two 64-bit words in the kernels that skip all-gap subtrees (schedule.hpp program_facts, kernels.hip SKIP,
+    tiles.hip, factored.hip); a tree of 150 leaves has no such facts and must take the plain paths: tracks mode, six frames, and block
+    mode (prune_tiles walks every op, leaf presence from LDS) against the oracle."""
+    import shutil
+    import ctypes as C
+    import oracle_binding as ob
+    import phylocsfpp_amd as pa
+    rng = np.random.default_rng(150)
+
+    def newick(lo, hi):   # random binary tree over leaves lo..hi-1
+        if hi - lo == 1:
+            return "s%03d:%.4f" % (lo, rng.uniform(0.005, 0.08))
+        mid = int(rng.integers(lo + 1, hi))
+        return "(%s,%s):%.4f" % (newick(lo, mid), newick(mid, hi), rng.uniform(0.005, 0.05))
+    prefix = str(tmp_path / "big")
+    text = newick(0, 150)
+    open(prefix + ".nh", "w").write(text[:text.rindex(":")] + ";\n")
+    for kind in ("coding", "noncoding"):
+        shutil.copyfile(os.path.join(golden_dir, "models", "58mammals_%s.ECM" % kind), "%s_%s.ECM" % (prefix, kind))
+    pm, om = pa.load_model(prefix, aliases=""), ob.OracleModel(prefix)
+    assert pm.nl == 150
+    ctx = pm.context(device=0)
+    cod = synth.synthetic_codon_columns(pm.child1, pm.child2, pm.branch_len, pm.S_c, pm.pi_c, pm.S_nc, pm.pi_nc, 400, seed=8, dropout=0.3, gap_rate=0.05)
+    cod[20:140, 64:192] = 64            # whole windows in which most species are gaps
+    np.testing.assert_allclose(ctx.score_sites_fixed(cod), om.run_tracks(cod), rtol=1e-9, atol=1e-9)
+    off = np.array([0, 7, 40, 400], dtype=np.uint64)
+    got, failed = ctx.block_loglik(0, cod, off, 1.3)
+    qd = om.qdiag(True)
+    for b in range(3):
+        sub = np.ascontiguousarray(cod[:, int(off[b]):int(off[b + 1])])
+        lpr, anc = C.c_double(), C.c_double()
+        assert ob.lib().po_lpr_leaves(C.byref(qd), C.byref(om.m.tree), 1.3, sub.ctypes.data_as(C.POINTER(C.c_uint8)), sub.shape[1], sub.shape[1], 0,
+                                      C.byref(lpr), C.byref(anc), None) == 0
+        assert not failed[b] and abs(got[b] - lpr.value) <= 1e-9 * abs(lpr.value), (b, got[b], lpr.value)
+    ph, an = ctx.score_blocks(pa.MLE, cod, off, compute_anc=True)
+    assert np.isfinite(ph).all() and np.isfinite(an).all()
+    ctx.close()
