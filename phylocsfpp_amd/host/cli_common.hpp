@@ -282,6 +282,11 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
         const Model model = load_model(prefix, aliases, species, mapping);
         const double t_model = since_main();
         if (!species.empty()) fprintf(stderr, "model reduced to %d species\n", model.n_leaves);
+        // OMEGA drives four HIP streams per device at once (two groups of blocks, each with a stream for the evaluations that wait for
+        // new eigen-systems); the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, some taken by the context's
+        // own streams), and streams that share a queue serialise behind each other's kernels.  Eight queues: configs[2] OMEGA 1.63 ->
+        // 1.47 s; MLE, one stream per group, is 8 % FASTER on four, so only OMEGA asks.  Must happen before the first HIP call.
+        if (cmd == "score-msa" && sm.strategy == ALGO_OMEGA) setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
         std::vector<std::unique_ptr<ScoringBackend>> owned;
         std::vector<ScoringBackend*> backends;
         // build-tracks: a second context on the same GPU puts the transfers of one call under the kernels of the other (2-4 % on long
