@@ -165,7 +165,6 @@ struct BlockEngine {
     // One kernel per LIST (score_blocks_impl decides from the mean number of species present, before the list is cut into groups, so
     // grouping never changes a result): both kernels in one round run one after the other, slower than either alone, also on two
     // streams (measured).  PCSF_BLOCK_KERNEL=tiles|factored overrides.
-    long tiles_min_tiles = 0, tiles_min_present = 0;
     std::vector<char> block_tiles;
     size_t tile_jobs_per_group = TILE_JOBS_PER_GROUP;
     std::vector<FactoredJob> tjobs[2];
@@ -205,9 +204,12 @@ struct BlockEngine {
 
     // own_streams: the engine works on streams of its own instead of the context's, so that several engines -- groups
     // of blocks advancing independently, one host thread each -- overlap on the device
-    BlockEngine(pcsf_ctx* ctx, const uint8_t* codons, const uint64_t* offsets, size_t nb, size_t stride, bool tiles, bool own_streams = false)
+    // explicit_path: the caller will queue evaluations with eigen-systems of its own (allow_factored = false): they form branch matrices
+    BlockEngine(pcsf_ctx* ctx, const uint8_t* codons, const uint64_t* offsets, size_t nb, size_t stride, bool tiles, bool own_streams = false,
+                bool explicit_path = false)
         : c(ctx), n_blocks(nb), leaf_stride(stride), off(offsets), stream(ctx->stream), use_tiles(tiles)
     {
+        const bool allow_factored_at_construction = !explicit_path;
         if (own_streams) {
             HIP_TRY(hipStreamCreateWithFlags(&own_main, hipStreamNonBlocking));
             stream = own_main;
@@ -224,40 +226,35 @@ struct BlockEngine {
             HIP_TRY(d_codons.reserve(static_cast<size_t>(nl) * n_sites_total));
             HIP_TRY(upload_rows(d_codons.ptr, codons, stride, n_sites_total, nl, stream));
         }
-        // which rows of each leaf's message table the block's sites read (values above 64 count as 64, like the kernel)
-        leaf_codes.assign(nb * static_cast<size_t>(nl) * 2, 0);
-        for (size_t b = 0; b < nb; ++b)
-            for (int l = 0; l < nl; ++l) {
-                uint64_t lo = 0, hi = 0;
-                const uint8_t* row = codons + static_cast<size_t>(l) * stride;
-                for (uint64_t s = offsets[b]; s < offsets[b + 1]; ++s) {
-                    const unsigned cd = row[s] > 64 ? 64u : row[s];
-                    if (cd < 64) lo |= uint64_t(1) << cd;
-                    else hi |= 1;
-                }
-                leaf_codes[(b * nl + l) * 2] = lo;
-                leaf_codes[(b * nl + l) * 2 + 1] = hi;
-            }
         if (const char* v = std::getenv("PCSF_FACTORED_MAX_TILES")) fixed_max_tiles = std::max(0, std::atoi(v));
         if (fixed_max_tiles >= 0) use_tiles = false;   // the tile-count rule is a statement about round 2's two paths
         if (const char* v = std::getenv("PCSF_TILE_JOBS")) tile_jobs_per_group = static_cast<size_t>(std::max(1, std::atoi(v)));
-        if (const char* v = std::getenv("PCSF_TILES_MIN_TILES")) tiles_min_tiles = std::atol(v);
-        if (const char* v = std::getenv("PCSF_TILES_MIN_PRESENT")) tiles_min_present = std::atol(v);
         if (const char* v = std::getenv("PCSF_EIGEN_HOST")) host_eigen = std::atoi(v) != 0;
         if (std::getenv("PCSF_FACTORED_STAMPS")) {
             HIP_TRY(d_fact_stamps.reserve(8 * sizeof(unsigned long long)));
             HIP_TRY(hipMemsetAsync(d_fact_stamps.ptr, 0, 8 * sizeof(unsigned long long), stream));
         }
-        block_factored.assign(nb, 0);
-        block_tiles.assign(nb, 0);
-        for (size_t b = 0; b < nb; ++b) {
-            block_factored[b] = use_tiles ? 1 : block_prefers_factored(c, codons, stride, offsets[b], offsets[b + 1], fixed_max_tiles);
-            if (use_tiles) {
-                const long tiles = static_cast<long>((offsets[b + 1] - offsets[b] + 15) / 16);
-                long present = 0;
-                for (int l = 0; l < nl; ++l) present += (leaf_codes[(b * nl + l) * 2] != 0);
-                block_tiles[b] = tiles >= tiles_min_tiles || present >= tiles_min_present;   // defaults 0: every block
-            }
+        block_factored.assign(nb, use_tiles ? 1 : 0);
+        block_tiles.assign(nb, use_tiles ? 1 : 0);
+        // which rows of each leaf's message table the block's sites read (values above 64 count as 64, like the kernel): only the
+        // explicit path writes tables, and only a caller-supplied eigen-system or PCSF_BLOCK_KERNEL=factored can take it (20 ms of a
+        // 0.25 s MLE call on the configs[2] list when it was computed regardless, on one thread)
+        if (!use_tiles || !allow_factored_at_construction) {
+            leaf_codes.assign(nb * static_cast<size_t>(nl) * 2, 0);
+            parallel_for(nb, [&](size_t b) {
+                for (int l = 0; l < nl; ++l) {
+                    uint64_t lo = 0, hi = 0;
+                    const uint8_t* row = codons + static_cast<size_t>(l) * stride;
+                    for (uint64_t s = offsets[b]; s < offsets[b + 1]; ++s) {
+                        const unsigned cd = row[s] > 64 ? 64u : row[s];
+                        if (cd < 64) lo |= uint64_t(1) << cd;
+                        else hi |= 1;
+                    }
+                    leaf_codes[(b * nl + l) * 2] = lo;
+                    leaf_codes[(b * nl + l) * 2 + 1] = hi;
+                }
+                if (!use_tiles) block_factored[b] = block_prefers_factored(c, codons, stride, offsets[b], offsets[b + 1], fixed_max_tiles);
+            });
         }
         std::vector<int32_t> slots(static_cast<size_t>(n - 1));
         for (int b = 0; b < n - 1; ++b) slots[b] = c->branch_slot[b];
@@ -267,7 +264,7 @@ struct BlockEngine {
             HIP_TRY(hipMemcpyAsync(d_slot_branch.ptr, slot_branch.data(), slot_branch.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
         HIP_TRY(d_branch_slot.reserve(slots.size() * sizeof(int32_t)));
         HIP_TRY(d_branch_len.reserve(slots.size() * sizeof(float)));
-        HIP_TRY(d_leaf_codes.reserve(std::max<size_t>(leaf_codes.size(), 2) * sizeof(uint64_t)));
+        HIP_TRY(d_leaf_codes.reserve(std::max<size_t>(leaf_codes.size(), 2) * sizeof(uint64_t)));   // (expm_kernel writes every row when a block has none)
         HIP_TRY(hipMemcpyAsync(d_branch_slot.ptr, slots.data(), slots.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(d_branch_len.ptr, c->branch_len.data(), slots.size() * sizeof(float), hipMemcpyHostToDevice, stream));
         if (!leaf_codes.empty())
@@ -568,7 +565,7 @@ struct BlockEngine {
                 ep.n_leaves = nl;
                 ep.branch_slot = d_branch_slot.as<int32_t>();
                 ep.branch_len = d_branch_len.as<float>();
-                ep.leaf_codes = d_leaf_codes.as<uint64_t>();
+                ep.leaf_codes = leaf_codes.empty() ? nullptr : d_leaf_codes.as<uint64_t>();   // null: every row of every leaf table
                 ep.eig_right = d_eig_r.as<double>();
                 ep.eig_left = d_eig_l.as<double>();
                 ep.eig_lambda = d_eig_lam.as<double>();
@@ -1250,7 +1247,8 @@ int block_loglik_impl(pcsf_ctx* c, int model, const double* q_settings, const do
     std::vector<uint64_t> off(n_blocks + 1);
     for (size_t b = 0; b <= n_blocks; ++b) off[b] = site_offsets[b] - site_offsets[0];
     BlockEngine eng(c, codons ? codons + site_offsets[0] : nullptr, off.data(), n_blocks, leaf_stride,
-                    model != 3 && list_prefers_tiles(c, codons ? codons + site_offsets[0] : nullptr, leaf_stride, off.data(), n_blocks));
+                    model != 3 && list_prefers_tiles(c, codons ? codons + site_offsets[0] : nullptr, leaf_stride, off.data(), n_blocks), false,
+                    /*explicit_path=*/model == 3);
     eng.reserve_tables(n_blocks);
     if (model == 2) {
         eng.reserve_eig(n_blocks);  // eigen-systems and root priors come from the device solver (eigen.hip)
