@@ -23,6 +23,22 @@
 
 #include "kernels.h"
 
+#ifndef PCSF_EIG_ABL
+#define PCSF_EIG_ABL 0
+#endif
+// per-phase stamps inside a step of the register-resident form: a build flag (-DPCSF_EIGEN_STEP_STAMPS=1, tools/build_variant.sh), because
+// even a never-taken stamp branch splits the step into basic blocks and stops the compiler from overlapping its phases
+#ifndef PCSF_EIGEN_STEP_STAMPS
+#define PCSF_EIGEN_STEP_STAMPS 0
+#endif
+#if PCSF_EIGEN_STEP_STAMPS
+#define EIG_STEP_STAMPS true
+#define EIG_STEP_CLOCK() (stamping ? eig_clock() : 0ull)
+#else
+#define EIG_STEP_STAMPS false
+#define EIG_STEP_CLOCK() 0ull
+#endif
+
 namespace pcsf {
 
 typedef double double2_loc __attribute__((ext_vector_type(2)));
@@ -70,6 +86,18 @@ __host__ __device__ __forceinline__ constexpr int pair_a(int pat, int k)
 __host__ __device__ __forceinline__ constexpr int pair_b(int pat, int k)
 {
     return pat == 0 ? 2 * k + 1 : pat == 1 ? (k < 2 ? k + 2 : k + 4) : pat == 2 ? (k == 0 ? 3 : k == 1 ? 2 : k == 2 ? 7 : 6) : 4 + ((k + (pat - 3)) & 3);
+}
+// Is the 2x2 block (row pair m) x (column pair n) of step pattern `pat` one the NEXT step's rotations are read from?  Those are B[a][a],
+// B[b][b], B[a][b] of every pair (a, b) of pattern `next`: the four diagonal 2x2 blocks and the four holding the next pairs' (a, b).
+__host__ __device__ __forceinline__ constexpr bool feeds_next(int pat, int next, int m, int n)
+{
+    const int r0 = pair_a(pat, m), r1 = pair_b(pat, m), c0 = pair_a(pat, n), c1 = pair_b(pat, n);
+    for (int k = 0; k < 4; ++k) {
+        const int a = pair_a(next, k), b = pair_b(next, k);
+        const bool row_a = a == r0 || a == r1, row_b = b == r0 || b == r1, col_a = a == c0 || a == c1, col_b = b == c0 || b == c1;
+        if ((row_a && col_a) || (row_b && col_b) || (row_a && col_b)) return true;
+    }
+    return false;
 }
 // the two groups of super-group G in round r
 __host__ __device__ __forceinline__ int group_of(int r, int G, int half)
@@ -382,7 +410,7 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
     } else {
     // ================= register-resident sweeps: wave 0 owns B, wave 1 owns V ==================
     double2_loc* rt = reinterpret_cast<double2_loc*>(rot);   // [buf][super-group * 4 + pair] = (cos, sin)
-    __shared__ __attribute__((aligned(16))) double dg[32 * 4];  // [super-group * 4 + pair] = B[a][a], B[b][b], B[a][b] of the next step's pairs
+    __shared__ __attribute__((aligned(16))) double dg[32 * 2];  // [super-group * 4 + pair] = (B[b][b] - B[a][a], 2 B[a][b]) of the next step's pairs
     const int R = lane >> 3, C = lane & 7;
     // One rotation from (B[a][a], B[b][b], B[a][b]).  The same t = sgn(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (B[b][b] - B[a][a]) / (2 B[a][b]),
     // as the `rotations` lambda above, written as t = 2g sgn(d) / (|d| + sqrt(d^2 + 4 g^2)) on operands scaled by a power of two (no
@@ -396,22 +424,19 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
         for (int it = 0; it < 3; ++it) y = y * __builtin_fma(-hx, y * y, 1.5);
         return y;
     };
-    auto rotation_of = [&](double aa, double bb, double g) {
-        double c = 1.0, sn = 0.0;
-        if (!(fabs(g) < 1e-290)) {
-            double d = bb - aa, h = 2.0 * g;
-            const int eh = __builtin_amdgcn_frexp_exp(h), ed = __builtin_amdgcn_frexp_exp(d);
-            const int e = (d == 0.0 || eh > ed) ? eh : ed;   // frexp_exp(0) = 0 must not win; h != 0 here
-            d = __builtin_amdgcn_ldexp(d, -e);
-            h = __builtin_amdgcn_ldexp(h, -e);
-            // r = sqrt(d^2 + h^2), w = r + |d|:  cos = w / sqrt(2 r w), sin = sgn(d) h / sqrt(2 r w)   (tan = sgn(d) h / w as above)
-            const double x = __builtin_fma(d, d, h * h);            // in [1/4, 2)
-            const double w = __builtin_fma(x, rsqrt_nr(x), fabs(d));
-            const double q = rsqrt_nr(2.0 * (w - fabs(d)) * w);
-            c = w * q;
-            sn = copysign(h, d * h) * q;   // sgn(d) h; d = +-0 rotates by 45 degrees like sgn(zeta) = +1
-        }
-        return double2_loc{c, sn};
+    auto rotation_of = [&](double d, double h) {   // d = B[b][b] - B[a][a], h = 2 B[a][b]
+        const bool tiny = fabs(h) < 2.0 * 1e-290;   // |B[a][b]| < 1e-290: no rotation (identity); computed without a branch, selected below
+        const int eh = __builtin_amdgcn_frexp_exp(h), ed = __builtin_amdgcn_frexp_exp(d);
+        const int e = (d == 0.0 || eh > ed) ? eh : ed;   // frexp_exp(0) = 0 must not win; h != 0 unless tiny
+        d = __builtin_amdgcn_ldexp(d, -e);
+        h = __builtin_amdgcn_ldexp(h, -e);
+        // r = sqrt(d^2 + h^2), w = r + |d|:  cos = w / sqrt(2 r w), sin = sgn(d) h / sqrt(2 r w)   (tan = sgn(d) h / w as above)
+        const double x = __builtin_fma(d, d, h * h);            // in [1/4, 2)
+        const double w = __builtin_fma(x, rsqrt_nr(x), fabs(d));
+        const double q = rsqrt_nr(2.0 * (w - fabs(d)) * w);
+        const double c = w * q;
+        const double sn = copysign(h, d * h) * q;   // sgn(d) h; d = +-0 rotates by 45 degrees like sgn(zeta) = +1
+        return double2_loc{tiny ? 1.0 : c, tiny ? 0.0 : sn};
     };
     if (wave == 0) {
         double b[8][8];
@@ -452,27 +477,37 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
                     b[i][2 * jp + 1] = e.y;
                 }
         };
-        // parameters of the step with pattern PAT into buffer `buf`: diagonal blocks publish their pairs, lanes 0..31 rotate
-        auto publish = [&](auto pat_tag, int buf) {
+        // parameters of the step with pattern PAT into buffer `buf`: diagonal blocks publish (B[b][b] - B[a][a], 2 B[a][b]) of their pairs
+        // (all rotation_of reads of them), every lane rotates one pair (lanes 32..63 repeat 0..31: no branch between the LDS round trip
+        // and the arithmetic, so the compiler is free to run other work of the step inside their latency)
+        double hmax = 0.0;   // largest |2 B[a][b]| among the rotations published since the last stop test
+        auto publish_operands = [&](auto pat_tag) {
             constexpr int PAT = decltype(pat_tag)::value;
             if (diag) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    constexpr int dummy = 0;
-                    (void)dummy;
                     const int a = rr::pair_a(PAT, k), bq = rr::pair_b(PAT, k);
-                    *reinterpret_cast<double2_loc*>(&dg[(R * 4 + k) * 4]) = double2_loc{b[a][a], b[bq][bq]};
-                    dg[(R * 4 + k) * 4 + 2] = b[a][bq];
+                    *reinterpret_cast<double2_loc*>(&dg[(R * 4 + k) * 2]) = double2_loc{b[bq][bq] - b[a][a], 2.0 * b[a][bq]};
                 }
             }
-            if (lane < 32) {
-                const double2_loc ab = *reinterpret_cast<const double2_loc*>(&dg[lane * 4]);
-                rt[32 * buf + lane] = rotation_of(ab.x, ab.y, dg[lane * 4 + 2]);
-            }
         };
-        auto b_step = [&](auto pat_tag, int buf) {
-            constexpr int PAT = decltype(pat_tag)::value;
-            double cl[4], sl[4], cr[4], sr[4];
+        auto publish_rotations = [&](int buf) {
+            const double2_loc dh = *reinterpret_cast<const double2_loc*>(&dg[(lane & 31) * 2]);
+            hmax = fmax(hmax, fabs(dh.y));
+#if PCSF_EIG_ABL & 2
+            const double2_loc rot_new = double2_loc{0.8 + 1e-9 * dh.x, 0.6 + 1e-9 * dh.y};
+#else
+            const double2_loc rot_new = rotation_of(dh.x, dh.y);
+#endif
+            return rot_new;
+        };
+        auto store_rotations = [&](double2_loc rot_new, int buf) {
+            rt[32 * buf + (lane & 31)] = rot_new;   // lanes 32..63 store what lanes 0..31 do (a conditional store would pull the arithmetic into its branch)
+        };
+        // B <- J^T B J of one step.  PART 0: the 2x2 blocks the next step's rotations are read from (rr::feeds_next), PART 1: the others,
+        // PART 2: all of them.
+        double cl[4], sl[4], cr[4], sr[4];
+        auto load_rotations = [&](int buf) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const double2_loc l = rt[32 * buf + R * 4 + k], r2 = rt[32 * buf + C * 4 + k];
@@ -481,10 +516,14 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
                 cr[k] = r2.x;
                 sr[k] = r2.y;
             }
+        };
+        auto b_blocks = [&](auto pat_tag, auto next_tag, auto part_tag) {
+            constexpr int PAT = decltype(pat_tag)::value, NEXT = decltype(next_tag)::value, PART = decltype(part_tag)::value;
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
+                    if (PART != 2 && rr::feeds_next(PAT, NEXT, m, n) != (PART == 0)) continue;
                     const int a = rr::pair_a(PAT, m), bq = rr::pair_b(PAT, m), a2 = rr::pair_a(PAT, n), b2 = rr::pair_b(PAT, n);
                     const double b00 = b[a][a2], b01 = b[a][b2], b10 = b[bq][a2], b11 = b[bq][b2];
                     // columns (right rotation of pair n), then rows (left rotation of pair m)
@@ -495,7 +534,10 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
                     b[bq][a2] = __builtin_fma(sl[m], t1, cl[m] * u1);
                     b[bq][b2] = __builtin_fma(sl[m], t2, cl[m] * u2);
                 }
-            if (diag) {   // the rotated pairs themselves: annihilated (or already below 1e-290)
+        };
+        auto annihilate = [&](auto pat_tag) {   // the rotated pairs themselves: annihilated (or already below 1e-290); they sit in the diagonal 2x2 blocks
+            constexpr int PAT = decltype(pat_tag)::value;
+            if (diag) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int a = rr::pair_a(PAT, k), bq = rr::pair_b(PAT, k);
@@ -504,20 +546,49 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
                 }
             }
         };
-        publish(std::integral_constant<int, 0>{}, 0);
+        publish_operands(std::integral_constant<int, 0>{});
+        store_rotations(publish_rotations(0), 0);
+        load_rotations(0);   // a wave's LDS operations complete in order: it reads back what it has just stored
         int buf = 0;
         // diagnostics (PCSF_EIGEN_STAMPS): cycles in the B update, in publishing the next rotations, in the regrouping, at the barrier
         auto timed_step = [&](auto pat, auto next_pat, int regroup_from, int regroup_to) {
-            const unsigned long long t0 = stamping ? eig_clock() : 0ull;
-            b_step(pat, buf);
-            const unsigned long long t1 = stamping ? eig_clock() : 0ull;
-            if (regroup_from >= 0) regroup();
-            const unsigned long long t2 = stamping ? eig_clock() : 0ull;
-            publish(next_pat, buf ^ 1);
-            const unsigned long long t3 = stamping ? eig_clock() : 0ull;
+            const unsigned long long t0 = EIG_STEP_CLOCK();
+            using std::integral_constant;
+            unsigned long long t1 = 0, t2 = 0;
+            if (regroup_from >= 0) {
+#if !(PCSF_EIG_ABL & 8)
+                b_blocks(pat, next_pat, integral_constant<int, 2>{});
+                annihilate(pat);
+#endif
+                t1 = EIG_STEP_CLOCK();
+#if !(PCSF_EIG_ABL & 1)
+                regroup();
+#endif
+                t2 = EIG_STEP_CLOCK();
+                publish_operands(next_pat);
+                store_rotations(publish_rotations(buf ^ 1), buf ^ 1);
+            } else {
+                // the blocks the next rotations depend on first; the rest of the update runs inside the latency of the operands' trip
+                // through LDS and of the rotation arithmetic (one dependent chain of ~35 fp64 instructions)
+#if !(PCSF_EIG_ABL & 8)
+                b_blocks(pat, next_pat, integral_constant<int, 0>{});
+                annihilate(pat);
+#endif
+                publish_operands(next_pat);
+                t1 = t2 = EIG_STEP_CLOCK();
+                const double2_loc rot_new = publish_rotations(buf ^ 1);
+#if !(PCSF_EIG_ABL & 8)
+                b_blocks(pat, next_pat, integral_constant<int, 1>{});
+#endif
+                store_rotations(rot_new, buf ^ 1);
+            }
+            const unsigned long long t3 = EIG_STEP_CLOCK();
             buf ^= 1;
-            __syncthreads();
-            if (stamping) {
+            // The next step's rotations come straight back (eight reads behind the store, in order), and the barrier only waits for the
+            // STORE: wave 1 reads the rotations after it, this wave's own reads land while it passes the barrier.
+            load_rotations(buf);
+            asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
+            if (EIG_STEP_STAMPS && stamping) {
                 acc_a += t1 - t0;
                 acc_v += t2 - t1;
                 acc_rot += t3 - t2;
@@ -528,27 +599,44 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
         // so a job is usually done a good part of a sweep before the sweep's end, and a launch lasts as long as its slowest job.
         int r = 0;   // the seating: round within the sweep
         bool converged = false;
+        double fro2 = 0.0;   // |B|_F^2 (rotations keep it)
         for (int round = 0; round < 60 * 15; ++round) {
-            double off = 0.0, total = 0.0;
+            // The stop test proper costs 128 fp64 instructions and two wave reductions; it can only pass once the off-diagonal mass is
+            // below 1e-18 of the matrix's, and then every rotation published afterwards has |2 B[a][b]| below 2e-18 |B|_F.  So the test is
+            // run only after a round whose rotations all stayed below 1e-12 |B|_F (one ballot): at worst it passes a round late.
+            const bool test = round == 0 || __builtin_amdgcn_ballot_w64(hmax * hmax > 1e-24 * fro2) == 0ull;
+            hmax = 0.0;
+            double off = 1.0, total = 0.0;
+#if PCSF_EIG_ABL & 4
+            if (false)
+#endif
+            if (test) {
+                off = 0.0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+                for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const double x = b[i][j] * b[i][j];
-                    if (i == j) {
-                        total += diag ? x : 0.0;
-                        off += diag ? 0.0 : x;
-                    } else {
-                        off += x;
+                    for (int j = 0; j < 8; ++j) {
+                        const double x = b[i][j] * b[i][j];
+                        if (i == j) {
+                            total += diag ? x : 0.0;
+                            off += diag ? 0.0 : x;
+                        } else {
+                            off += x;
+                        }
                     }
+                for (int sft = 32; sft > 0; sft >>= 1) {
+                    off += __shfl_xor(off, sft);
+                    total += __shfl_xor(total, sft);
                 }
-            for (int sft = 32; sft > 0; sft >>= 1) {
-                off += __shfl_xor(off, sft);
-                total += __shfl_xor(total, sft);
+                fro2 = off + total;
             }
             // The host solver and the LDS form stop at off^2 <= 1e-58 diag^2.  Here: 1e-36, i.e. an off-diagonal mass below 1e-18 of the
             // diagonal's -- already under the rounding of every product formed from the result.
             constexpr double STOP = 1e-36;
+#ifdef PCSF_EIG_FIXED_ROUNDS
+            off = round >= PCSF_EIG_FIXED_ROUNDS ? 0.0 : 1.0;
+            total = 1.0;
+#endif
             if (lane == 0) flag = (off <= STOP * total) ? 2 : 0;
             __syncthreads();
             if (off <= STOP * total) {
@@ -590,18 +678,35 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
         for (int G = 0; G < 8; ++G)
 #pragma unroll
             for (int sl = 0; sl < 8; ++sl) v[8 * G + sl] = V[lane * LD + 4 * rr::group_of(0, G, sl >> 2) + (sl & 3)];
+        // The 32 rotations of a step are 32 broadcast reads (the same address in every lane).  Left to itself the compiler keeps two or
+        // three of them in flight and the step waits out ~12 LDS round trips -- longer than wave 0's whole step; here they are issued in
+        // batches of eight (two super-groups), each batch one ahead of the arithmetic that uses it.
         auto v_step = [&](auto pat_tag, int buf) {
             constexpr int PAT = decltype(pat_tag)::value;
+            double2_loc rn[2][8];
+            auto fetch = [&](int batch, double2_loc (&dst)[8]) {
 #pragma unroll
-            for (int G = 0; G < 8; ++G)
+                for (int u = 0; u < 8; ++u) dst[u] = rt[32 * buf + batch * 8 + u];
+            };
+            fetch(0, rn[0]);
+#if PCSF_EIG_ABL & 16
+            if (false)
+#endif
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const double2_loc r2 = rt[32 * buf + G * 4 + k];   // the same address in every lane: a broadcast
+            for (int batch = 0; batch < 4; ++batch) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (batch + 1 < 4) fetch(batch + 1, rn[(batch + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int G = batch * 2 + (u >> 2), k = u & 3;
+                    const double2_loc r2 = rn[batch & 1][u];
                     const int a = 8 * G + rr::pair_a(PAT, k), bq = 8 * G + rr::pair_b(PAT, k);
                     const double x = v[a], y = v[bq];
                     v[a] = __builtin_fma(r2.x, x, -(r2.y * y));
                     v[bq] = __builtin_fma(r2.y, x, r2.x * y);
                 }
+            }
         };
         // the 15 moving groups form one cycle (0,0) <- (1,0) <- ... <- (7,0) <- (7,1) <- (6,1) <- ... <- (1,1) <- (0,0): walk it in place
         auto shift = [&]() {
