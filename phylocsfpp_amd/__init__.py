@@ -70,6 +70,7 @@ def load_library():
     lib.pcsf_score_sites_fixed_dev.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, vp, vp]
     lib.pcsf_score_blocks.argtypes = [vp, C.c_int, u8p, C.POINTER(C.c_uint64), C.c_size_t, C.c_size_t, C.c_int,
                                       C.c_uint32, fp, fp]
+    lib.pcsf_prepare_block_scoring.argtypes = [vp, C.c_int]
     lib.pcsf_score_alignments_6frames.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(_AlignmentDesc), C.c_size_t, dp, C.c_size_t,
                                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.pcsf_score_alignments_6frames_bls.argtypes = lib.pcsf_score_alignments_6frames.argtypes + [dp]
@@ -310,6 +311,10 @@ class ScoringContext:
         return res, skip.reshape(n, 6)
 
     # ---- run -----------------------------------------------------------------------------
+    def prepare_block_scoring(self, algo):
+        """Optional: score_blocks(algo, ...) is coming -- its device queues are created in the background meanwhile."""
+        self._check(self._lib.pcsf_prepare_block_scoring(self._h, int(algo)))
+
     def score_blocks(self, algo, codons, site_offsets, compute_anc=True, seed=42):
         codons = np.ascontiguousarray(codons, dtype=np.uint8)
         off = np.ascontiguousarray(site_offsets, dtype=np.uint64)

@@ -781,6 +781,17 @@ int pcsf_score_blocks(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
     }
 }
 
+int pcsf_prepare_block_scoring(pcsf_ctx* c, int algo)
+{
+    if (!c) return PCSF_ERR_INVALID_ARG;
+    if (algo != PCSF_MLE && algo != PCSF_FIXED && algo != PCSF_OMEGA) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_prepare_block_scoring: bad argument");
+    if (algo == PCSF_FIXED) return PCSF_OK;   // no engine, no streams of its own
+    if (const char* v = std::getenv("PCSF_PREPARE_BLOCKS"))   // A/B knob: 0 = create the streams when an engine asks for them
+        if (v[0] == '0') return PCSF_OK;
+    c->block_streams.warm_up(c->device, 4);    // two groups of blocks, a main and a side stream each (score_blocks_impl)
+    return PCSF_OK;
+}
+
 // log-likelihood of every block at caller-chosen parameters: ONE objective evaluation of the MLE / OMEGA
 // strategies without the prior term (minimizer_lpr_leaves, src/fixed_lik.hpp:460-467; lpr_leaves_omega,
 // src/omega.hpp:151-202).  model: 0 coding ECM, 1 non-coding ECM, 2 kappa/omega F3x4 model with

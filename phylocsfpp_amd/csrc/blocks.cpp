@@ -210,10 +210,19 @@ struct BlockEngine {
         : c(ctx), n_blocks(nb), leaf_stride(stride), off(offsets), stream(ctx->stream), use_tiles(tiles)
     {
         const bool allow_factored_at_construction = !explicit_path;
+        const bool marks = std::getenv("PCSF_TIME_SETUP") != nullptr;
+        auto t_mark = std::chrono::steady_clock::now();
+        auto mark = [&](const char* what) {
+            if (!marks) return;
+            const auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "  engine set-up: %-28s %7.0f us\n", what, std::chrono::duration<double>(now - t_mark).count() * 1e6);
+            t_mark = now;
+        };
         if (own_streams) {
-            HIP_TRY(hipStreamCreateWithFlags(&own_main, hipStreamNonBlocking));
+            HIP_TRY(c->block_streams.acquire(&own_main));
             stream = own_main;
         }
+        mark("main stream");
         struct Guard {  // a throw below must not leak the stream created above (the destructor does not run then)
             BlockEngine* e;
             ~Guard() { if (e) e->release_sync_objects(); }
@@ -226,6 +235,7 @@ struct BlockEngine {
             HIP_TRY(d_codons.reserve(static_cast<size_t>(nl) * n_sites_total));
             HIP_TRY(upload_rows(d_codons.ptr, codons, stride, n_sites_total, nl, stream));
         }
+        mark("codon upload");
         if (const char* v = std::getenv("PCSF_FACTORED_MAX_TILES")) fixed_max_tiles = std::max(0, std::atoi(v));
         if (fixed_max_tiles >= 0) use_tiles = false;   // the tile-count rule is a statement about round 2's two paths
         if (const char* v = std::getenv("PCSF_TILE_JOBS")) tile_jobs_per_group = static_cast<size_t>(std::max(1, std::atoi(v)));
@@ -256,6 +266,7 @@ struct BlockEngine {
                 if (!use_tiles) block_factored[b] = block_prefers_factored(c, codons, stride, offsets[b], offsets[b + 1], fixed_max_tiles);
             });
         }
+        mark("row masks / path rule");
         std::vector<int32_t> slots(static_cast<size_t>(n - 1));
         for (int b = 0; b < n - 1; ++b) slots[b] = c->branch_slot[b];
         std::vector<int32_t> slot_branch(c->schedule.slot_node.begin(), c->schedule.slot_node.end());
@@ -270,10 +281,12 @@ struct BlockEngine {
         if (!leaf_codes.empty())
             HIP_TRY(hipMemcpyAsync(d_leaf_codes.ptr, leaf_codes.data(), leaf_codes.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));  // `slots` is a stack temporary
+        mark("constants + sync");
         // created last: a throw above leaves nothing behind that only the destructor (not run then) would release
-        HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        HIP_TRY(c->block_streams.acquire(&side));
         HIP_TRY(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
+        mark("side stream + events");
         guard.e = nullptr;  // constructed: the destructor owns the release from here on
     }
     hipStream_t own_main = nullptr;
@@ -281,12 +294,12 @@ struct BlockEngine {
     {
         if (own_main) {
             (void)hipStreamSynchronize(own_main);
-            (void)hipStreamDestroy(own_main);
+            c->block_streams.release(own_main);
             own_main = nullptr;
         }
         if (side) {
             (void)hipStreamSynchronize(side);
-            (void)hipStreamDestroy(side);
+            c->block_streams.release(side);
             side = nullptr;
         }
         if (ev_start) (void)hipEventDestroy(ev_start);
@@ -792,6 +805,7 @@ int run_fixed(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
 int run_mle(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_blocks, size_t leaf_stride, int compute_anc,
             uint32_t seed, float* out_phylo, float* out_anc, bool tiles, bool own_streams)
 {
+    const auto t_setup = std::chrono::steady_clock::now();
     BlockEngine eng(c, codons, off, n_blocks, leaf_stride, tiles, own_streams);
     eng.reserve_tables(std::max<size_t>(64, 2 * n_blocks));
     eng.reserve_eig(2);
@@ -885,8 +899,9 @@ int run_mle(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_bl
             }
         fprintf(stderr, "run_mle: %zu evaluations consumed by the optimisers, %zu speculative ones never asked for\n", used, unused);
         const double all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count();
-        fprintf(stderr, "run_mle: %zu blocks (%zu on the factored path), %zu rounds, %zu evaluations: host %.3f s, device rounds %.3f s\n", n_blocks,
-                static_cast<size_t>(std::count(eng.block_factored.begin(), eng.block_factored.end(), 1)), rounds, n_evals, all - t_run, t_run);
+        fprintf(stderr, "run_mle: %zu blocks (%zu on the factored path), %zu rounds, %zu evaluations: host %.3f s, device rounds %.3f s; engine set-up %.3f s\n", n_blocks,
+                static_cast<size_t>(std::count(eng.block_factored.begin(), eng.block_factored.end(), 1)), rounds, n_evals, all - t_run, t_run,
+                std::chrono::duration<double>(t_enter - t_setup).count());
     }
     for (int model = 0; model < 2; ++model)
         for (size_t b = 0; b < n_blocks; ++b) {
@@ -1341,6 +1356,11 @@ int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
                       size_t leaf_stride, int compute_anc, uint32_t seed, float* out_phylo, float* out_anc)
 {
     if (algo != PCSF_FIXED && algo != PCSF_MLE && algo != PCSF_OMEGA) return c->fail(PCSF_ERR_INVALID_ARG, "unknown algorithm");
+    struct CallTimer {   // PCSF_TIME_BLOCKS: the whole call, engines' set-up and release included
+        const bool on = std::getenv("PCSF_TIME_BLOCKS") != nullptr;
+        const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~CallTimer() { if (on) fprintf(stderr, "score_blocks: whole call %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
+    } call_timer;
     // MLE / OMEGA keep one set of branch-matrix tables per evaluation of a LONG block in HBM (9.6 MB for a 100-leaf tree),
     // up to two evaluations per block and round: blocks are independent, so a long list is processed in chunks that bound
     // that footprint to ~16 GB.

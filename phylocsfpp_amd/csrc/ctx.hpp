@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/phylocsf_amd.h"
@@ -63,6 +65,70 @@ struct DeviceBuffer {
     template <class T> T* as() const { return static_cast<T*>(ptr); }
 };
 
+// Streams of the block engines (blocks.cpp: a main and a side stream per engine, one engine per group of blocks).  The first use of
+// a new stream makes the runtime create a hardware queue, ~11 ms each on this machine -- 35 ms of a 55 ms MLE call on 516 blocks
+// when two groups created theirs on the spot.  The pool keeps streams across calls, and warm_up() creates them on a thread of its own
+// (pcsf_prepare_block_scoring: the command line starts it before it reads the alignment file).
+struct StreamPool {
+    std::mutex lock;
+    std::vector<hipStream_t> idle;
+    std::thread warming;
+    void warm_up(int device, int count)
+    {
+        std::lock_guard<std::mutex> g(lock);
+        if (warming.joinable() || !idle.empty()) return;
+        warming = std::thread([this, device, count]() {
+            if (hipSetDevice(device) != hipSuccess) return;
+            void* scratch = nullptr;
+            if (hipMalloc(&scratch, 256) != hipSuccess) return;
+            std::vector<hipStream_t> made;
+            for (int i = 0; i < count; ++i) {
+                hipStream_t s = nullptr;
+                if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+                (void)hipMemsetAsync(scratch, 0, 256, s);   // the queue behind a stream is created at its first operation
+                made.push_back(s);
+            }
+            for (hipStream_t s : made) (void)hipStreamSynchronize(s);
+            (void)hipFree(scratch);
+            (void)hipGetLastError();
+            std::lock_guard<std::mutex> g2(lock);
+            idle.insert(idle.end(), made.begin(), made.end());
+        });
+    }
+    void wait_warm()
+    {
+        std::thread t;
+        {
+            std::lock_guard<std::mutex> g(lock);
+            t.swap(warming);
+        }
+        if (t.joinable()) t.join();
+    }
+    hipError_t acquire(hipStream_t* out)
+    {
+        wait_warm();
+        {
+            std::lock_guard<std::mutex> g(lock);
+            if (!idle.empty()) {
+                *out = idle.back();
+                idle.pop_back();
+                return hipSuccess;
+            }
+        }
+        return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    }
+    void release(hipStream_t s)   // the caller has synchronised it
+    {
+        std::lock_guard<std::mutex> g(lock);
+        idle.push_back(s);
+    }
+    ~StreamPool()
+    {
+        wait_warm();
+        for (hipStream_t s : idle) (void)hipStreamDestroy(s);
+    }
+};
+
 }  // namespace pcsf
 
 struct pcsf_ctx {
@@ -95,6 +161,7 @@ struct pcsf_ctx {
     unsigned long long* bls_first_bad = nullptr;  // page-locked host copy of the kernel's character check
     uint32_t stamp_block = 0;
     hipStream_t stream = nullptr;        // private stream for host-pointer entry points
+    pcsf::StreamPool block_streams;      // streams of the MLE / OMEGA engines (blocks.cpp)
     hipEvent_t ev_kernels = nullptr;     // behind the kernels of this context's last six-frame call
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false;

@@ -52,6 +52,8 @@ struct ScoringBackend {
     // run: CSR batch of blocks -> (phylo, anc) floats, NaN on model failure
     virtual void score_blocks(int algo, const uint8_t* codons, const uint64_t* offsets, size_t n_blocks, size_t leaf_stride,
                               bool compute_anc, uint32_t seed, float* phylo, float* anc) = 0;
+    // score_blocks(algo, ...) is coming: what can be set up meanwhile (the HIP backend's device queues, pcsf_prepare_block_scoring)
+    virtual void prepare_blocks(int /*algo*/) {}
     // the six frames of a batch of alignments: nucleotide rows [n_leaves][row_stride], alignment k in columns
     // [col0[k], col0[k]+len[k]); frame f of alignment k gets n_codons[6k+f] scores at out[offsets[6k+f]...] in FORWARD
     // genome order.  Default: translate on the host and call score_sites_fixed (what the CPU oracle backend uses);
@@ -133,6 +135,10 @@ public:
                       float* phylo, float* anc) override
     {
         get().score_blocks(algo, codons, offsets, n_blocks, leaf_stride, compute_anc, seed, phylo, anc);
+    }
+    void prepare_blocks(int algo) override
+    {
+        if (ready()) get().prepare_blocks(algo);   // a backend still being made is not waited for
     }
     size_t score_alignments_6frames(int n_leaves, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0, const std::vector<uint32_t>& len,
                                     const std::vector<uint64_t>& start_pos, const std::vector<uint64_t>& chrom_len, double* out, size_t out_capacity,
@@ -772,6 +778,8 @@ inline std::string score_msa(const Model& model, const std::string& maf_path, co
     const auto t_enter = std::chrono::steady_clock::now();
     auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     ScoringBackend& backend = *backends[0];
+    if (prm.strategy != ALGO_FIXED_MEAN)
+        for (ScoringBackend* b : backends) b->prepare_blocks(prm.strategy);   // while the file is read
     std::string out_path = prm.output_dir.empty() ? maf_path + ".scores" : prm.output_dir + "/" + maf_path.substr(maf_path.find_last_of('/') == std::string::npos ? 0 : maf_path.find_last_of('/') + 1) + ".scores";
     FILE* out = open_out(out_path, "w");
     fprintf(out, "%s\n", prm.version_line.c_str());

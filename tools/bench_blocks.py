@@ -22,6 +22,7 @@ if reps > 1:   # replicate the block set to see how the lock-step batch scales
 nb = len(offs) - 1
 print("%d blocks, %d codon columns (median %d per block)" % (nb, offs[-1], int(np.median(np.diff(offs)))))
 ctx = pa.load_model(os.path.join(ROOT, "tests/golden/models/100vertebrates")).context()
+ctx.prepare_block_scoring(pa.MLE if hasattr(pa, "MLE") else 0)   # the engines' device queues are created while the file is read
 for name, algo in (("FIXED", pa.FIXED), ("MLE", pa.MLE), ("OMEGA", pa.OMEGA)):
     ctx.score_blocks(algo, cod[:, :int(offs[min(4, nb)])], offs[:min(4, nb) + 1], compute_anc=(algo != pa.OMEGA))  # warm-up
     t = time.time()
