@@ -549,17 +549,20 @@ static hipError_t launch_tiles_impl(const FactoredParams& p, size_t lds, hipStre
         hipLaunchKernelGGL((prune_tiles<ANC>), dim3(p.n_groups), dim3(TILE_WAVES * 64), lds, stream, p);
         return hipGetLastError();
     }
-    uint32_t at = 0;
-    for (int waves = 1; waves <= TILE_WAVES; ++waves) {
-        // the last launch takes every group that is left (groups of more than TILE_WAVES jobs loop over their jobs)
-        const uint32_t cnt = waves < TILE_WAVES ? p.group_counts[waves - 1] : p.n_groups - at;
+    // Largest work-groups first: a 4-wave work-group needs four free wave slots on one CU at once, and finds them while the chip is
+    // empty; the small ones fill in behind (configs[2], OMEGA: 1.45 -> 1.38 s against smallest first; the launches on streams of
+    // their own, so that none waits for another's last work-groups: 1.5 s).
+    for (int waves = TILE_WAVES; waves >= 1; --waves) {
+        uint32_t first = 0;
+        for (int w = 1; w < waves; ++w) first += p.group_counts[w - 1];
+        // the 4-wave launch takes every group that is left over (groups of more than TILE_WAVES jobs loop over their jobs)
+        const uint32_t cnt = waves < TILE_WAVES ? p.group_counts[waves - 1] : p.n_groups - first;
         if (cnt == 0) continue;
         FactoredParams q = p;
-        q.groups = p.groups + at;
+        q.groups = p.groups + first;
         q.n_groups = cnt;
         hipLaunchKernelGGL((prune_tiles<ANC>), dim3(cnt), dim3(waves * 64), lds, stream, q);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-        at += cnt;
     }
     return hipSuccess;
 }
