@@ -165,7 +165,9 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx *ctx, const char *nucleotides, si
  * gen.seed() per block (42, src/phylocsf++score_msa.hpp:115).  out_phylo/out_anc: [n_blocks]
  * float like the reference's std::tuple<float,float>; a block whose model fails validation gets
  * NaN in both (score-msa swallows the exception, src/phylocsf++score_msa.hpp:124-127); out_anc
- * may be NULL; it is NaN in OMEGA mode (src/run.hpp:181). */
+ * may be NULL; it is NaN in OMEGA mode (src/run.hpp:181).  When the call fails (return != PCSF_OK)
+ * the contents of out_phylo / out_anc are undefined: long lists are processed in groups, and the
+ * groups that had finished before the failure have written their rows. */
 int pcsf_score_blocks(pcsf_ctx *ctx, int algo, const uint8_t *codons, const uint64_t *site_offsets,
                       size_t n_blocks, size_t leaf_stride, int compute_anc, uint32_t seed,
                       float *out_phylo, float *out_anc);

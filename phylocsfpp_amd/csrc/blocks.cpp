@@ -803,7 +803,7 @@ int run_fixed(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
 
 // ---- MLE ---------------------------------------------------------------------------------------
 int run_mle(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_blocks, size_t leaf_stride, int compute_anc,
-            uint32_t seed, float* out_phylo, float* out_anc, bool tiles, bool own_streams)
+            uint32_t seed, float* out_phylo, float* out_anc, bool tiles, bool own_streams, const std::atomic<bool>* stop)
 {
     const auto t_setup = std::chrono::steady_clock::now();
     BlockEngine eng(c, codons, off, n_blocks, leaf_stride, tiles, own_streams);
@@ -832,6 +832,7 @@ int run_mle(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_bl
     double t_run = 0.0;
     size_t rounds = 0, n_evals = 0;
     for (;;) {
+        if (stop && stop->load(std::memory_order_relaxed)) return PCSF_ERR_HIP;   // another group of this call has failed: its error is the one reported
         // feed every optimiser from its store; blocks without a codon have lpr = 0 at every scale
         size_t active = 0;
         for (size_t b = 0; b < n_blocks; ++b) {
@@ -947,7 +948,7 @@ struct OmegaBlock {
 };
 
 int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_blocks, size_t leaf_stride, uint32_t seed,
-              float* out_phylo, float* out_anc, bool tiles, bool own_streams)
+              float* out_phylo, float* out_anc, bool tiles, bool own_streams, const std::atomic<bool>* stop)
 {
     const auto t_enter = std::chrono::steady_clock::now();
     BlockEngine eng(c, codons, off, n_blocks, leaf_stride, tiles, own_streams);
@@ -1046,6 +1047,7 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
         double x;
     };
     for (;;) {
+        if (stop && stop->load(std::memory_order_relaxed)) return PCSF_ERR_HIP;   // another group of this call has failed: its error is the one reported
         const auto t0 = now();
         // (1) feed every optimiser from its store; finished stages move the block on
         size_t active = 0;
@@ -1407,6 +1409,7 @@ int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
     };
     std::vector<Range> ranges;
     for (size_t b0 = 0; b0 < n_blocks; b0 += chunk) ranges.push_back({b0, std::min(chunk, n_blocks - b0)});
+    std::atomic<bool> stop_groups{false};   // set by the first group that fails: the others leave at their next round
     auto run_range = [&](const Range& r, bool own_streams) -> int {
         std::vector<uint64_t> off(r.nb + 1);  // CSR offsets re-based at the range's first site
         for (size_t b = 0; b <= r.nb; ++b) off[b] = site_offsets[r.b0 + b] - site_offsets[r.b0];
@@ -1415,8 +1418,8 @@ int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
         float* an = out_anc ? out_anc + r.b0 : nullptr;
         switch (algo) {
             case PCSF_FIXED: return run_fixed(c, cod, off.data(), r.nb, leaf_stride, compute_anc, ph, an);
-            case PCSF_MLE: return run_mle(c, cod, off.data(), r.nb, leaf_stride, compute_anc, seed, ph, an, tiles, own_streams);
-            default: return run_omega(c, cod, off.data(), r.nb, leaf_stride, seed, ph, an, tiles, own_streams);
+            case PCSF_MLE: return run_mle(c, cod, off.data(), r.nb, leaf_stride, compute_anc, seed, ph, an, tiles, own_streams, &stop_groups);
+            default: return run_omega(c, cod, off.data(), r.nb, leaf_stride, seed, ph, an, tiles, own_streams, &stop_groups);
         }
     };
     if (n_groups <= 1 || ranges.size() <= 1) {
@@ -1455,6 +1458,7 @@ int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
                         err = msg;
                     }
                     next = ranges.size();
+                    stop_groups.store(true, std::memory_order_relaxed);
                     return;
                 }
             }

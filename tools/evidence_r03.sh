@@ -20,6 +20,14 @@ for s in mle omega; do bash tools/c3_pmc.sh $s $O/config3_${s}_pmc.json > $O/con
 { for r in 1 4 16; do echo "== bench_blocks.py - 0 $r nocpu (default: kernel chosen per list)"; PCSF_TIME_BLOCKS=1 python3 tools/bench_blocks.py - 0 $r nocpu 2>&1 | grep -E "GPU |pruning kernel|run_omega: [0-9]+ blocks|run_mle: [0-9]+ blocks";
     echo "== PCSF_BLOCK_KERNEL=tiles"; PCSF_BLOCK_KERNEL=tiles python3 tools/bench_blocks.py - 0 $r nocpu 2>&1 | grep "GPU "; done; } > $O/blocks_real_files.txt 2>&1
 bash tools/blocks516_timeline.sh > $O/blocks516_timeline.txt 2>&1
+# ---- the eigen-solver kernel alone: 200 jobs per launch (cold / warm starts), and with parts of a step switched off (timing only; the
+#      variants are built here: tools/build_variant.sh eigN eigen.hip -DPCSF_EIG_FIXED_ROUNDS=120 -DPCSF_EIG_ABL=N, eigR0: -DPCSF_EIG_FIXED_ROUNDS=0)
+for v in 0 1 2 4 8 16 31; do bash tools/build_variant.sh eig$v eigen.hip -DPCSF_EIG_FIXED_ROUNDS=120 -DPCSF_EIG_ABL=$v > /dev/null 2>&1 & done
+bash tools/build_variant.sh eigR0 eigen.hip -DPCSF_EIG_FIXED_ROUNDS=0 > /dev/null 2>&1; wait
+{ echo "tools/eigen_bench.sh: launch order warm-up (4 jobs), cold, [cold, warm from kappa +-1 %], [cold, warm +-10 %], [cold, warm from any kappa in [1, 10]]"; bash tools/eigen_bench.sh 2>&1 | grep "eigen launch";
+  echo "tools/eig_abl.sh: 120 rounds (8 sweeps) forced; bit 1 = no regrouping, 2 = no rotation arithmetic, 4 = no stop test, 8 = no B update, 16 = no V update, R0 = no rounds at all (set-up + output; the launches after a warm start add the two 64^3 products)"; bash tools/eig_abl.sh 0 1 2 4 8 16 31 R0; } > $O/eigen_kernel.txt 2>&1
+# ---- pcsf_prepare_block_scoring (stream pool warmed while the file is read) on / off, alternating on one box
+bash tools/ab_prepare.sh > $O/prepare_blocks.txt 2>&1
 # ---- tracks mode: all-gap subtrees skipped per work-group (tools/skip_e2e.sh)
 python3 tools/gen_synthetic_maf.py /tmp/syn1mb.maf --bases 1000000 > /dev/null 2>&1
 python3 tools/gen_synthetic_maf.py /tmp/clade1mb.maf --bases 1000000 --clade-dropout > $O/clade_maf.txt 2>&1
