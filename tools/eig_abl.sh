@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 for v in "$@"; do
   rm -rf /tmp/prof_ea
-  PCSF_LIBRARY=$PWD/tools/_build/lib_eig$v.so rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_ea -- python3 tools/eigen_bench.py 200 > /dev/null 2>&1
+  PCSF_LIBRARY=$PWD/tools/_build/lib_eig$v.so rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_ea -- python3 tools/eigen_bench.py ${EIG_JOBS:-200} > /dev/null 2>&1
   python3 - $v <<'PY'
 import csv, glob, sys
 f = glob.glob('/tmp/prof_ea/**/*kernel_trace.csv', recursive=True)[0]
