@@ -290,8 +290,9 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
         std::vector<std::unique_ptr<ScoringBackend>> owned;
         std::vector<ScoringBackend*> backends;
         // build-tracks: a second context on the same GPU puts the transfers of one call under the kernels of the other (2-4 % on long
-        // runs).  Its set-up costs 0.1-0.2 s, so it is only made for inputs of a gigabyte or more, and on a thread of its own: the
-        // first context starts on the first window meanwhile (profiles/r02/startup_profile.txt).
+        // runs).  Its set-up costs 0.1-0.2 s, so it is only made for inputs of 768 MB or more (0.45 GB of MAF: 0.19 s with one context,
+        // 0.20 s with two; 0.9 GB: 0.36 and 0.34 s), and on a thread of its own: the first context starts on the first window meanwhile
+        // (profiles/r02/startup_profile.txt).
         uint64_t input_total = 0;
         for (int j = i; j < argc; ++j) {
             struct stat sb;
@@ -303,7 +304,7 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
             else owned.push_back(std::unique_ptr<ScoringBackend>(new DeferredBackend([&model, &make_backend, d] { return make_backend(model, d); },
                                                                                      owned[0]->device_bls(), owned[0]->contexts_per_device())));
             backends.push_back(owned.back().get());
-            const int wanted = contexts_per_device > 0 ? contexts_per_device : (input_total >= (uint64_t(1) << 30) ? owned[0]->contexts_per_device() : 1);
+            const int wanted = contexts_per_device > 0 ? contexts_per_device : (input_total >= (uint64_t(3) << 28) ? owned[0]->contexts_per_device() : 1);
             const int per = cmd == "build-tracks" ? wanted : 1;
             for (int c = 1; c < per; ++c) {
                 owned.push_back(std::unique_ptr<ScoringBackend>(new DeferredBackend([&model, &make_backend, d] { return make_backend(model, d); },
