@@ -128,7 +128,6 @@ template <bool REG>
 __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const EigenParams p)
 {
     constexpr int NT = REG ? 128 : 256;     // threads
-    constexpr int CPT = 4096 / NT;          // entries of a row a thread owns in the warm-start products
     const bool stamping = p.stamps != nullptr && blockIdx.x == 0;
     const unsigned long long t_kernel = stamping ? eig_clock() : 0ull;
     unsigned long long acc_a = 0, acc_rot = 0, acc_v = 0, acc_b = 0, n_steps = 0, n_sweeps = 0;
@@ -219,31 +218,63 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
         const double* __restrict__ V0 = p.eig_basis + static_cast<size_t>(job.warm) * 4096;
         for (int idx = tid; idx < 4096; idx += NT) V[(idx >> 6) * LD + (idx & 63)] = V0[idx];
         __syncthreads();
-        double t[CPT];
-        // T = B V0: thread owns CPT consecutive entries of one row (256 threads: row tid >> 2, columns 16 (tid & 3) .. +15)
-        const int r = tid / (64 / CPT), c0 = CPT * (tid % (64 / CPT));
+        // Both 64^3 products on the matrix cores (v_mfma_f64_16x16x4_f64: A operand lane (s, g) = A[s][g], B operand = B[g][s], result
+        // register r = row 4r + g, column s): wave w owns the output tiles of rows 16 TI w .. 16 TI (w + 1) - 1, 16 k-steps per tile, the
+        // operands read from the two LDS matrices (row length 65: two lanes per bank at worst).  As scalar loops -- 32 entries and 4,096
+        // LDS reads per thread and product -- they were 50 us of a 0.31 ms warm solve (profiles/r03/eigen_kernel.txt, variant R0).
+        typedef double double4_loc __attribute__((ext_vector_type(4)));
+        constexpr int TI = 4 / (NT / 64);   // row tiles per wave
+        const int ms = lane & 15, mg = lane >> 4;
+        double4_loc acc[TI][4];
+        // T = B V0
 #pragma unroll
-        for (int u = 0; u < CPT; ++u) t[u] = 0.0;
-        for (int j = 0; j < 64; ++j) {
-            const double b = A[r * LD + j];
+        for (int a = 0; a < TI; ++a)
 #pragma unroll
-            for (int u = 0; u < CPT; ++u) t[u] += b * V[j * LD + c0 + u];
+            for (int b = 0; b < 4; ++b) acc[a][b] = double4_loc{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (int kk = 0; kk < 16; ++kk) {
+            double fa[TI], fb[4];
+#pragma unroll
+            for (int a = 0; a < TI; ++a) fa[a] = A[(16 * (wave * TI + a) + ms) * LD + 4 * kk + mg];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) fb[b] = V[(4 * kk + mg) * LD + 16 * b + ms];
+#pragma unroll
+            for (int a = 0; a < TI; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
+        __syncthreads();   // every wave has read its rows of B
+#pragma unroll
+        for (int a = 0; a < TI; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) A[(16 * (wave * TI + a) + 4 * r + mg) * LD + 16 * b + ms] = acc[a][b][r];
         __syncthreads();
+        // C = V0^T T: A operand V0^T[i][k] = V0[k][i]
 #pragma unroll
-        for (int u = 0; u < CPT; ++u) A[r * LD + c0 + u] = t[u];
-        __syncthreads();
-        // C = V0^T T: entry (r, c) = sum_i V0[i][r] T[i][c]
+        for (int a = 0; a < TI; ++a)
 #pragma unroll
-        for (int u = 0; u < CPT; ++u) t[u] = 0.0;
-        for (int i = 0; i < 64; ++i) {
-            const double v = V[i * LD + r];
+            for (int b = 0; b < 4; ++b) acc[a][b] = double4_loc{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (int kk = 0; kk < 16; ++kk) {
+            double fa[TI], fb[4];
 #pragma unroll
-            for (int u = 0; u < CPT; ++u) t[u] += v * A[i * LD + c0 + u];
+            for (int a = 0; a < TI; ++a) fa[a] = V[(4 * kk + mg) * LD + 16 * (wave * TI + a) + ms];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) fb[b] = A[(4 * kk + mg) * LD + 16 * b + ms];
+#pragma unroll
+            for (int a = 0; a < TI; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
-        __syncthreads();
+        __syncthreads();   // every wave has read T
 #pragma unroll
-        for (int u = 0; u < CPT; ++u) A[r * LD + c0 + u] = t[u];
+        for (int a = 0; a < TI; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) A[(16 * (wave * TI + a) + 4 * r + mg) * LD + 16 * b + ms] = acc[a][b][r];
         __syncthreads();
         for (int idx = tid; idx < 4096; idx += NT) {  // exact symmetry again
             const int i = idx >> 6, j = idx & 63;
