@@ -140,6 +140,7 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
     __shared__ __attribute__((aligned(16))) double rot[2 * 32 * 2];
     __shared__ double pi[64], root[64], iroot[64], red[8];
     __shared__ int pq[64], pp[1];
+    __shared__ char aa_s[64];   // the genetic code, staged once: a look-up in the string literal is a dependent global load per matrix entry
     __shared__ double norm_s;
     __shared__ int flag;
 
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
         const double stop_mass = f3x4_weight(qs, 48) + f3x4_weight(qs, 50) + f3x4_weight(qs, 56);  // TAA, TAG, TGA
         const double denom = 1.0 - ((1.0 - qs[2]) * stop_mass);
         pi[tid] = f3x4_weight(qs, tid) / denom;
+        aa_s[tid] = amino_acid_dev(tid);
     }
     __syncthreads();
     if (tid < 64) {
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
             const int a = (i >> shift) & 3, b = (j >> shift) & 3;
             const bool transition = (a + b == 2) || (a + b == 4);
             rate = transition ? kappa : 1.0;
-            const char ai = amino_acid_dev(i), aj = amino_acid_dev(j);
+            const char ai = aa_s[i], aj = aa_s[j];
             rate *= (ai != '*' && aj != '*' && ai != aj) ? omega : 1.0;
             rate *= pi[j];
         }
