@@ -241,8 +241,8 @@ struct BlockEngine {
         if (const char* v = std::getenv("PCSF_TILE_JOBS")) tile_jobs_per_group = static_cast<size_t>(std::max(1, std::atoi(v)));
         if (const char* v = std::getenv("PCSF_EIGEN_HOST")) host_eigen = std::atoi(v) != 0;
         if (std::getenv("PCSF_FACTORED_STAMPS")) {
-            HIP_TRY(d_fact_stamps.reserve(8 * sizeof(unsigned long long)));
-            HIP_TRY(hipMemsetAsync(d_fact_stamps.ptr, 0, 8 * sizeof(unsigned long long), stream));
+            HIP_TRY(d_fact_stamps.reserve(16 * sizeof(unsigned long long)));
+            HIP_TRY(hipMemsetAsync(d_fact_stamps.ptr, 0, 16 * sizeof(unsigned long long), stream));
         }
         block_factored.assign(nb, use_tiles ? 1 : 0);
         block_tiles.assign(nb, use_tiles ? 1 : 0);
@@ -311,10 +311,14 @@ struct BlockEngine {
     ~BlockEngine()
     {
         if (d_fact_stamps.ptr) {
-            unsigned long long h[8] = {0};
-            if (hipMemcpy(h, d_fact_stamps.ptr, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[3])
+            unsigned long long h[16] = {0};
+            if (hipMemcpy(h, d_fact_stamps.ptr, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[3]) {
                 fprintf(stderr, "prune_factored stamps: %llu work-groups, per work-group %.0f cycles (prologue %.0f, root op reached at %.0f): %.1f scale loads waiting %.0f, %.1f products taking %.0f\n", h[3],
                         double(h[0]) / h[3], double(h[6]) / h[3], double(h[7]) / h[3], double(h[4]) / h[3], double(h[1]) / h[3], double(h[5]) / h[3], double(h[2]) / h[3]);
+                fprintf(stderr, "  per work-group, ops that ran (count, cycles incl. their loads and products): cherry %.1f %.0f | leaf %.1f %.0f | push %.1f %.0f | pop %.1f %.0f; op facts + row list %.0f\n",
+                        double(h[12]) / h[3], double(h[8]) / h[3], double(h[13]) / h[3], double(h[9]) / h[3], double(h[14]) / h[3], double(h[10]) / h[3], double(h[15]) / h[3], double(h[11]) / h[3],
+                        double(h[0] - h[6] - h[8] - h[9] - h[10] - h[11]) / h[3]);
+            }
         }
         release_sync_objects();
     }

@@ -29,6 +29,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace pcsf {
@@ -132,14 +134,16 @@ __device__ __forceinline__ unsigned long long fact_clock()
 // DEEP: the tree parks more than MAX_STACK_DEPTH_DEV tiles (none of the reference's eleven trees does): the parked tiles live in
 // scratch memory, dynamically indexed; otherwise in three register sets written and read with value selects (no scratch at all).
 template <bool ANC, bool DEEP>
-__global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
+__global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_fact[];
     double2_t* xbuf = reinterpret_cast<double2_t*>(lds_fact);                      // [2][4 waves][2 pairs][64 lanes]
     double* red = reinterpret_cast<double*>(lds_fact + 2 * 4 * 2 * 64 * 16);       // [2][4][16]
-    uint32_t* lprog = reinterpret_cast<uint32_t*>(red + 2 * 4 * 16);               // [n_ops rounded up to 64]
+    double* lcgap = red + 2 * 4 * 16;                                              // [64] c = L 1 (eigen coordinates of a gap column's all-ones message)
+    uint32_t* lprog = reinterpret_cast<uint32_t*>(lcgap + 64);                     // [n_ops rounded up to 64]
     int32_t* lslot = reinterpret_cast<int32_t*>(lprog + ((p.n_ops + 63) & ~63u));  // [n_edges] slot -> branch
-    unsigned char* lcod = reinterpret_cast<unsigned char*>(lslot + ((p.n_edges + 3) & ~3u));  // [n_leaves][16]
+    uint32_t* lrow_edge = reinterpret_cast<uint32_t*>(lslot + ((p.n_edges + 3) & ~3u));      // [128] by rank among the ops that run: branch of the op's edge (row of edge_scale)
+    unsigned char* lcod = reinterpret_cast<unsigned char*>(lrow_edge + 128);                  // [n_leaves][16]
     unsigned char* lany = lcod + static_cast<size_t>(p.n_leaves) * 16;             // [n_leaves]: the leaf has a codon in the tile
 
     const FactoredJob job = p.jobs[blockIdx.x];
@@ -147,10 +151,56 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
     const int sj = lane & 15, g = lane >> 4;
     const bool stamping = p.stamps != nullptr;
     const unsigned long long t_begin = stamping ? fact_clock() : 0ull;
-    unsigned long long t_load = 0, t_prod = 0, n_load = 0, n_prod = 0;
+    unsigned long long t_load = 0, t_prod = 0, n_load = 0, n_prod = 0, t_class[4] = {0, 0, 0, 0}, n_class[4] = {0, 0, 0, 0};
 
-    // the tile's codons, and per leaf whether it has a codon in any of the 16 columns (16 consecutive lanes hold one leaf's columns)
-    for (int base = 0; base < p.n_leaves * 16; base += 256) {
+    // Everything the prologue needs from global memory is REQUESTED before anything waits for it (the first version ran seven dependent
+    // round trips for the codon bytes alone -- each iteration's ballot waited for its own load -- then the program, then the operand
+    // rows, then the op facts: 16 k cycles before the first op of a tile whose ten products take 14 k).
+    // (a) this wave's 16 rows of R and L as MFMA A operands: k-step q needs M[16 wave + (lane & 15)][4q + (lane >> 4)]
+    const double* __restrict__ Rg = p.eig_right + static_cast<size_t>(job.eig) * 4096;
+    const double* __restrict__ Lg = p.eig_left + static_cast<size_t>(job.eig) * 4096;
+    double RA[16], LA[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        RA[q] = Rg[(16 * wave + sj) * 64 + 4 * q + g];
+        LA[q] = Lg[(16 * wave + sj) * 64 + 4 * q + g];
+    }
+    // (b) the static facts of ops 64 k + lane (schedule.hpp `program_facts`; trees of at most 128 leaves)
+    const int n_ops = static_cast<int>(p.n_ops);
+    const bool facts = p.op_meta != nullptr;
+    uint32_t opw[2], mt[2];
+    unsigned long long ol0[2], ol1[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int j = 64 * k + lane;
+        const bool valid = facts && j < n_ops;
+        opw[k] = valid ? p.program[j] : (static_cast<uint32_t>(F_ROOT_DEV) << 28);
+        mt[k] = valid ? p.op_meta[j] : 0u;
+        ol0[k] = valid ? p.op_leaves[2 * j] : 0ull;
+        ol1[k] = valid ? p.op_leaves[2 * j + 1] : 0ull;
+    }
+    // (c) the tile's codons (16 consecutive lanes hold one leaf's columns): the first 128 leaves in registers, ...
+    unsigned cc[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = it * 256 + tid, leaf = idx >> 4, s = idx & 15;
+        cc[it] = 64u;
+        if (leaf < p.n_leaves && static_cast<uint32_t>(s) < job.n_sites) cc[it] = p.codons[static_cast<size_t>(leaf) * p.leaf_stride + job.site0 + s];
+    }
+    for (int i = tid; i < static_cast<int>((p.n_ops + 63) & ~63u); i += 256) lprog[i] = p.program[i < static_cast<int>(p.n_ops) ? i : static_cast<int>(p.n_ops) - 1];
+    for (int i = tid; i < p.n_edges; i += 256) lslot[i] = p.slot_branch[i];
+    // ... then into LDS, with per leaf whether it has a codon in any of the 16 columns
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = it * 256 + tid, leaf = idx >> 4;
+        const unsigned c = cc[it] > 64u ? 64u : cc[it];
+        const unsigned long long has = __ballot(c != 64u);
+        if (leaf < p.n_leaves) {
+            lcod[idx] = static_cast<unsigned char>(c);
+            if ((idx & 15) == 0) lany[leaf] = ((has >> (16 * (lane >> 4))) & 0xffffull) != 0;
+        }
+    }
+    for (int base = 2048; base < p.n_leaves * 16; base += 256) {   // trees of more than 128 leaves
         const int idx = base + tid, leaf = idx >> 4, s = idx & 15;
         unsigned c = 64u;
         if (leaf < p.n_leaves && static_cast<uint32_t>(s) < job.n_sites) {
@@ -162,18 +212,6 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
             lcod[idx] = static_cast<unsigned char>(c);
             if (s == 0) lany[leaf] = ((has >> (16 * (lane >> 4))) & 0xffffull) != 0;
         }
-    }
-    for (int i = tid; i < static_cast<int>((p.n_ops + 63) & ~63u); i += 256) lprog[i] = p.program[i < static_cast<int>(p.n_ops) ? i : static_cast<int>(p.n_ops) - 1];
-    for (int i = tid; i < p.n_edges; i += 256) lslot[i] = p.slot_branch[i];
-
-    // this wave's 16 rows of R and L as MFMA A operands: k-step q needs M[16 wave + (lane & 15)][4q + (lane >> 4)]
-    const double* __restrict__ Rg = p.eig_right + static_cast<size_t>(job.eig) * 4096;
-    const double* __restrict__ Lg = p.eig_left + static_cast<size_t>(job.eig) * 4096;
-    double RA[16], LA[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        RA[q] = Rg[(16 * wave + sj) * 64 + 4 * q + g];
-        LA[q] = Lg[(16 * wave + sj) * 64 + 4 * q + g];
     }
     const double* __restrict__ scale = p.edge_scale + static_cast<size_t>(job.eval) * p.n_branches * 64 + (wave * 4 + g) * 4;
     const double* __restrict__ Lrows = Lg + static_cast<size_t>(16 * wave + g) * 64;  // + 4r * 64 + codon
@@ -246,7 +284,36 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
         }
         return out;
     };
-    auto load_scale = [&](int branch) __attribute__((always_inline)) -> Vec4 {
+    // Rows of edge_scale.  Read one by one they were 31 dependent round trips (~620 cycles each) in a tile with four species present --
+    // a fifth of its time -- nearly all of them for the edges of chains (messages in eigen form: the row is all an edge needs).  With
+    // the op facts the edges of the next SIXTEEN ops that run are known ahead: lane (sj, g) fetches its 32 bytes of the row of op
+    // `rank0 + sj`, one batch for all sixteen, and an op takes its row from the lanes of its rank with ds_bpermute (no memory access).
+    // A row fetched and not used costs 32 bytes.  (The rows of an op's leaves are still read where they are used: their wait is the
+    // wait for the leaf's column of L, issued beside them; holding them too took the kernel from three waves per SIMD to two.)
+    double pre[4] = {1.0, 1.0, 1.0, 1.0};
+    int n_active = 0;
+    auto load_batch = [&](int rank0) __attribute__((always_inline)) {
+        const unsigned long long t_in = stamping ? fact_clock() : 0ull;
+        const int idx = rank0 + sj < n_active ? rank0 + sj : n_active - 1;
+        const double2_t* s0 = reinterpret_cast<const double2_t*>(scale + static_cast<size_t>(lrow_edge[idx]) * 64);
+        const double2_t a0 = s0[0], a1 = s0[1];
+        pre[0] = a0.x; pre[1] = a0.y; pre[2] = a1.x; pre[3] = a1.y;
+        if (stamping) {
+            t_load += fact_clock() - t_in;   // fact_clock waits for the loads
+            ++n_load;
+        }
+    };
+    int rank = 0;   // of the op being run among the ops that run (PF: with the op facts; otherwise rows are read from memory)
+    auto load_scale = [&](int branch, int kind, auto pf) __attribute__((always_inline)) -> Vec4 {
+        if constexpr (decltype(pf)::value) {
+            if (kind == 0) {
+                const int src = (lane & 48) | (rank & 15);
+                Vec4 e;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e.v[r] = __shfl(pre[r], src);
+                return e;
+            }
+        }
         const unsigned long long t_in = stamping ? fact_clock() : 0ull;
         const double2_t* s2 = reinterpret_cast<const double2_t*>(scale + static_cast<size_t>(branch) * 64);
         const double2_t lo = s2[0], hi = s2[1];
@@ -256,17 +323,17 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
         }
         return Vec4{{lo.x, lo.y, hi.x, hi.y}};
     };
-    // c = L 1 in this lane's rows: the eigen-coordinates of the all-ones message (a gap column of a leaf)
-    Vec4 cgap;
+    // c = L 1: the eigen-coordinates of the all-ones message (a gap column of a leaf that has codons elsewhere in the tile); kept in LDS --
+    // it is read by the few leaves with such columns, and eight registers less keep the kernel at three waves per SIMD
     {
         double rowsum = 0.0;   // row 16 wave + sj of L, this lane's 16 entries, then over the four lane groups
 #pragma unroll
         for (int q = 0; q < 16; ++q) rowsum += LA[q];
         rowsum += __shfl_xor(rowsum, 16);
         rowsum += __shfl_xor(rowsum, 32);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cgap.v[r] = __shfl(rowsum, g + 4 * r);   // row 16 wave + g + 4r
+        if (g == 0) lcgap[16 * wave + sj] = rowsum;
     }
+    const double* my_cgap = lcgap + 16 * wave + g;   // + 4r: row 16 wave + g + 4r (written by this wave: no barrier needed, only the wave's own order)
 
     // A message is kept in one of two forms.  Real: the 64x16 tile itself.  Eigen: y with message = max(R y, 0) still to be formed.
     // P(t) = R e^{Lambda t} L and L R = I, so an edge applied to a message in eigen form is just y <- e_b o y -- no product -- and
@@ -289,24 +356,24 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
         for (int r = 0; r < 4; ++r) out.v.v[r] = gap_col ? 1.0 : fmax(out.v.v[r], 0.0);
         return out;
     };
-    auto apply_edge = [&](int slot_index, const Msg& m) __attribute__((always_inline)) -> Msg {   // the edge of program slot slot_index
+    auto apply_edge = [&](int slot_index, const Msg& m, auto pf) __attribute__((always_inline)) -> Msg {   // the edge of program slot slot_index
         if (m.mask == 0xffffu) return m;
-        const Vec4 e = load_scale(lslot[slot_index]);
+        const Vec4 e = load_scale(decltype(pf)::value ? 0 : lslot[slot_index], 0, pf);
         Msg out{m.eig ? m.v : matvecL(m.v), m.mask, true};
 #pragma unroll
         for (int r = 0; r < 4; ++r) out.v.v[r] *= e.v[r];
         return out;
     };
-    auto leaf = [&](int a) __attribute__((always_inline)) -> Msg {
+    auto leaf = [&](int a, int kind, auto pf) __attribute__((always_inline)) -> Msg {
         if (!leaf_has(a)) return Msg{Vec4{{1.0, 1.0, 1.0, 1.0}}, 0xffffu, false};
         const unsigned code = lcod[a * 16 + sj];
         const uint32_t mask = static_cast<uint32_t>(__ballot(code == 64u)) & 0xffffu;   // lanes 0..15 hold the 16 sites
         if (mask == 0xffffu) return Msg{Vec4{{1.0, 1.0, 1.0, 1.0}}, mask, false};
-        const Vec4 e = load_scale(a);
+        const Vec4 e = load_scale(a, kind, pf);
         const unsigned col = code == 64u ? 0u : code;
         Msg out{Vec4{}, mask, true};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out.v.v[r] = e.v[r] * (code == 64u ? cgap.v[r] : Lrows[r * 256 + col]);
+        for (int r = 0; r < 4; ++r) out.v.v[r] = e.v[r] * (code == 64u ? my_cgap[4 * r] : Lrows[r * 256 + col]);
         return out;
     };
     auto mul = [&](const Msg& x, const Msg& y) __attribute__((always_inline)) -> Msg {
@@ -355,68 +422,35 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
     Msg cur{Vec4{{1.0, 1.0, 1.0, 1.0}}, 0xffffu, false};
     // one op: `slot` and `depth` are the program slot and the number of parked tiles the op starts with; parked_ones: the tile a
     // pop takes back is known to be all ones whatever the registers hold (its parking op was skipped)
-    auto run_op = [&](uint32_t op, int slot, int depth, bool parked_ones) __attribute__((always_inline)) {
+    auto run_op = [&](uint32_t op, int slot, int depth, bool parked_ones, auto pf) __attribute__((always_inline)) {
         const uint32_t code = op >> 28;
         const int a = (op >> 14) & 0x3fff, b = op & 0x3fff;
         if (code == F_CHERRY_DEV) {
-            cur = mul(leaf(a), leaf(b));
+            cur = mul(leaf(a, 1, pf), leaf(b, 2, pf));
         } else if (code == F_MM_LEAF_DEV) {
-            cur = mul(apply_edge(slot, cur), leaf(a));
+            cur = mul(apply_edge(slot, cur, pf), leaf(a, 1, pf));
         } else if (code >= F_MM_PUSH_CHERRY0_DEV && code < F_MM_POP0_DEV) {
-            park(depth, apply_edge(slot, cur));
-            cur = mul(leaf(a), leaf(b));
+            park(depth, apply_edge(slot, cur, pf));
+            cur = mul(leaf(a, 1, pf), leaf(b, 2, pf));
         } else if (code >= F_MM_POP0_DEV && code < F_ROOT_DEV) {
-            const Msg m = apply_edge(slot, cur);
+            const Msg m = apply_edge(slot, cur, pf);
             if (parked_ones) cur = m;
             else cur = mul(parked(depth - 1), m);
-        } else {  // F_ROOT: z = prior . alpha_root, ln z; the ancestral term sum_x ln(prior_x) prior_x alpha_x / z
-            if (stamping && tid == 0) atomicAdd(p.stamps + 7, fact_clock() - t_begin);   // cycles until the root op
-            const Vec4 cur_v = to_real(cur).v;
-            const double* __restrict__ pr = p.prior + static_cast<size_t>(job.eig) * 64 + g * 16 + 4 * wave;  // lane order [g][q], q = 4 wave + r
-            double z = 0.0, t = 0.0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) z += pr[r] * cur_v.v[r];
-            z += __shfl_xor(z, 16);
-            z += __shfl_xor(z, 32);
-            if (ANC) {
-                const double* __restrict__ aw = p.anc_weight + static_cast<size_t>(job.eig) * 64 + g * 16 + 4 * wave;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) t += aw[r] * cur_v.v[r];
-                t += __shfl_xor(t, 16);
-                t += __shfl_xor(t, 32);
-            }
-            if (g == 0) {
-                red[wave * 16 + sj] = z;
-                if (ANC) red[64 + wave * 16 + sj] = t;
-            }
-            __syncthreads();
-            if (wave == 0 && g == 0 && static_cast<uint32_t>(sj) < job.n_sites) {
-                const double zz = ((red[sj] + red[16 + sj]) + red[32 + sj]) + red[48 + sj];
-                p.out_lnz[job.out0 + sj] = log(zz);
-                if (ANC) {
-                    const double tt = ((red[64 + sj] + red[80 + sj]) + red[96 + sj]) + red[112 + sj];
-                    p.out_anc[job.out0 + sj] = zz == 0.0 ? 0.0 : tt / zz;
-                }
-            }
-        }
+        }   // F_ROOT, always the program's last op, runs after the loop (below): inside it the constants of log() were live across every op
     };
 
-    const int n_ops = static_cast<int>(p.n_ops);
-    if (p.op_meta != nullptr) {
+    using std::false_type;
+    using std::true_type;
+    if (facts) {
         // Skipping the ops of all-gap subtrees.  A trivial op still costs ~430 cycles of branchy scalar code, and 70 of the 100 ops of
         // a real tile (4 of 100 species present) are trivial.  schedule.hpp `program_facts` knows every op's leaf set, start slot,
         // stack depth and, for a pop, the parking op; with the tile's leaf bits a lane-parallel pass marks the ops whose result is
         // the all-ones tile, and the loop visits only the others (trees of at most 128 leaves: n_ops <= 128, two 64-bit sets).
-        uint32_t opw[2], mt[2];
         unsigned long long ones_after[2], active[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int j = 64 * k + lane;
-            const bool valid = j < n_ops;
-            opw[k] = valid ? p.program[j] : (static_cast<uint32_t>(F_ROOT_DEV) << 28);
-            mt[k] = valid ? p.op_meta[j] : 0u;
-            const unsigned long long l0 = valid ? p.op_leaves[2 * j] : 0ull, l1 = valid ? p.op_leaves[2 * j + 1] : 0ull;
-            ones_after[k] = __ballot(valid && ((l0 & has0) | (l1 & has1)) == 0ull);
+            ones_after[k] = __ballot(j < n_ops && ((ol0[k] & has0) | (ol1[k] & has1)) == 0ull);
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -428,21 +462,48 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
             const bool trivial = j < n_ops && after && !is_root && (!is_push || before);
             active[k] = __ballot(j < n_ops && !trivial);
         }
+        // the row of edge_scale the edge of every op that runs reads, by the op's rank among them (all four waves write the same values)
+        const int n_act0 = __popcll(active[0]);
+        n_active = n_act0 + __popcll(active[1]);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if ((active[k] >> lane) & 1ull) {
+                const int at = (k ? n_act0 : 0) + __popcll(active[k] & ((1ull << lane) - 1ull));
+                const uint32_t code = opw[k] >> 28;
+                const bool has_edge = code != F_CHERRY_DEV && code < F_ROOT_DEV;
+                lrow_edge[at] = has_edge ? static_cast<uint32_t>(lslot[mt[k] & 0x3fffu]) : 0u;
+            }
+        __syncthreads();
         for (int k = 0; k < 2; ++k) {
-            unsigned long long todo = active[k];
+            unsigned long long todo = k ? active[1] : active[0];
             while (todo) {
                 const int l = __builtin_ctzll(todo);
                 todo &= todo - 1;
                 const int i = 64 * k + l;
-                const uint32_t op = __builtin_amdgcn_readlane(opw[k], l), meta = __builtin_amdgcn_readlane(mt[k], l);
-                const bool ones_before = i > 0 && ((l > 0 ? ones_after[k] >> (l - 1) : ones_after[0] >> 63) & 1ull);
+                if ((rank & 15) == 0) load_batch(rank);
+                const uint32_t op = __builtin_amdgcn_readlane(k ? opw[1] : opw[0], l), meta = __builtin_amdgcn_readlane(k ? mt[1] : mt[0], l);   // selects: an index would send both arrays to scratch
+                const unsigned long long ones_k = k ? ones_after[1] : ones_after[0];
+                const bool ones_before = i > 0 && ((l > 0 ? ones_k >> (l - 1) : ones_after[0] >> 63) & 1ull);
                 if (ones_before) {   // whatever cur holds is from before a run of skipped ops
                     cur.mask = 0xffffu;
                     cur.eig = false;
                 }
                 const int parking = static_cast<int>(meta >> 18);   // >= 1 for a pop
-                const bool parked_ones = parking > 0 && ((ones_after[(parking - 1) >> 6] >> ((parking - 1) & 63)) & 1ull);
-                run_op(op, static_cast<int>(meta & 0x3fffu), static_cast<int>((meta >> 14) & 0xfu), parked_ones);
+                const bool parked_ones = parking > 0 && (((parking - 1) >> 6 ? ones_after[1] : ones_after[0]) >> ((parking - 1) & 63) & 1ull);
+                const unsigned long long t_op = stamping ? fact_clock() : 0ull;
+                run_op(op, static_cast<int>(meta & 0x3fffu), static_cast<int>((meta >> 14) & 0xfu), parked_ones, true_type{});
+                if (stamping) {
+                    const uint32_t cls = (op >> 28) == F_CHERRY_DEV ? 0u : ((op >> 28) == F_MM_LEAF_DEV ? 1u : ((op >> 28) < F_MM_POP0_DEV ? 2u : 3u));
+                    if ((op >> 28) < F_ROOT_DEV) {   // selects, not an index (an indexed array would live in scratch memory in every build)
+                        const unsigned long long dt = fact_clock() - t_op;
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            t_class[k] += cls == k ? dt : 0ull;
+                            n_class[k] += cls == k ? 1ull : 0ull;
+                        }
+                    }
+                }
+                ++rank;
             }
         }
     } else {
@@ -457,7 +518,37 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
             if (code != F_CHERRY_DEV && code < F_ROOT_DEV) ++slot;
             if (code >= F_MM_PUSH_CHERRY0_DEV && code < F_MM_POP0_DEV) ++sp;
             else if (code >= F_MM_POP0_DEV && code < F_ROOT_DEV) --sp;
-            run_op(op, slot_here, depth_here, false);
+            run_op(op, slot_here, depth_here, false, false_type{});
+        }
+    }
+    {   // F_ROOT: z = prior . alpha_root, ln z; the ancestral term sum_x ln(prior_x) prior_x alpha_x / z
+        if (stamping && tid == 0) atomicAdd(p.stamps + 7, fact_clock() - t_begin);   // cycles until the root op
+        const Vec4 cur_v = to_real(cur).v;
+        const double* __restrict__ pr = p.prior + static_cast<size_t>(job.eig) * 64 + g * 16 + 4 * wave;  // lane order [g][q], q = 4 wave + r
+        double z = 0.0, t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z += pr[r] * cur_v.v[r];
+        z += __shfl_xor(z, 16);
+        z += __shfl_xor(z, 32);
+        if (ANC) {
+            const double* __restrict__ aw = p.anc_weight + static_cast<size_t>(job.eig) * 64 + g * 16 + 4 * wave;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t += aw[r] * cur_v.v[r];
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+        }
+        if (g == 0) {
+            red[wave * 16 + sj] = z;
+            if (ANC) red[64 + wave * 16 + sj] = t;
+        }
+        __syncthreads();
+        if (wave == 0 && g == 0 && static_cast<uint32_t>(sj) < job.n_sites) {
+            const double zz = ((red[sj] + red[16 + sj]) + red[32 + sj]) + red[48 + sj];
+            p.out_lnz[job.out0 + sj] = log(zz);
+            if (ANC) {
+                const double tt = ((red[64 + sj] + red[80 + sj]) + red[96 + sj]) + red[112 + sj];
+                p.out_anc[job.out0 + sj] = zz == 0.0 ? 0.0 : tt / zz;
+            }
         }
     }
     if (stamping && tid == 0) {
@@ -468,6 +559,10 @@ __global__ __launch_bounds__(256, 2) void prune_factored(const FactoredParams p)
         atomicAdd(p.stamps + 4, n_load);
         atomicAdd(p.stamps + 5, n_prod);
         atomicAdd(p.stamps + 6, t_prologue);
+        for (int k = 0; k < 4; ++k) {
+            atomicAdd(p.stamps + 8 + k, t_class[k]);
+            atomicAdd(p.stamps + 12 + k, n_class[k]);
+        }
     }
 }
 
@@ -483,8 +578,8 @@ hipError_t launch_edge_scale(const ExpmEval* d_evals, uint32_t n_evals, uint32_t
 hipError_t launch_prune_factored(const FactoredParams& p, hipStream_t stream)
 {
     if (p.n_jobs == 0) return hipSuccess;
-    const size_t lds = 2 * 4 * 2 * 64 * 16 + 2 * 4 * 16 * 8 + ((static_cast<size_t>(p.n_ops) + 63) & ~size_t(63)) * 4 +
-                       ((static_cast<size_t>(p.n_edges) + 3) & ~size_t(3)) * 4 + static_cast<size_t>(p.n_leaves) * 17;
+    const size_t lds = 2 * 4 * 2 * 64 * 16 + 2 * 4 * 16 * 8 + 64 * 8 + ((static_cast<size_t>(p.n_ops) + 63) & ~size_t(63)) * 4 +
+                       ((static_cast<size_t>(p.n_edges) + 3) & ~size_t(3)) * 4 + 128 * 4 + static_cast<size_t>(p.n_leaves) * 17;
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     if (p.deep) {
         if (p.out_anc) hipLaunchKernelGGL((prune_factored<true, true>), dim3(p.n_jobs), dim3(256), lds, stream, p);
