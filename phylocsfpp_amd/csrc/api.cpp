@@ -707,7 +707,7 @@ int pcsf_set_bls_branch_lengths(pcsf_ctx* c, const double* branch_len)
     if (nl > 128 || n > pcsf::BLS_MAX_NODES) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_set_bls_branch_lengths: more than 128 species");
     hipError_t e;
     if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
-    // one allocation: len[n] | range[n][2] | child1[n] | child2[n]
+    // one allocation: len[n] | range[n][2] | child1[n] | child2[n] | prog[n - nl]
     std::vector<uint64_t> range(static_cast<size_t>(n) * 2, 0);
     for (int i = 0; i < n; ++i) {
         if (i < nl) {
@@ -716,9 +716,47 @@ int pcsf_set_bls_branch_lengths(pcsf_ctx* c, const double* branch_len)
             for (int w = 0; w < 2; ++w) range[2 * i + w] = range[2 * c->child1[i] + w] | range[2 * c->child2[i] + w];
         }
     }
+    // The internal nodes as a stack program for bls_kernel: a node runs when both children's values exist; of two internal children
+    // the one whose subtree needs the deeper stack goes first (Sethi-Ullman), so at most log2(internal nodes) + 1 values wait.
+    std::vector<uint32_t> prog;
+    {
+        std::vector<int> need(static_cast<size_t>(n), 0);   // stack entries the subtree of an internal node needs, its own result included
+        for (int i = nl; i < n; ++i) {
+            const int l = c->child1[i], r = c->child2[i];
+            const int a = l >= nl ? need[l] : 0, b = r >= nl ? need[r] : 0;
+            need[i] = std::max(1, a == 0 || b == 0 ? std::max(a, b) : std::max(std::max(a, b), std::min(a, b) + 1));
+        }
+        if (n > nl && need[n - 1] > pcsf::BLS_STACK_DEPTH) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_set_bls_branch_lengths: tree too deep for the branch-length kernel");
+        std::vector<std::pair<int, int>> todo;   // (node, stage) -- an explicit stack: the tree may be a chain of 127 internal nodes
+        if (n > nl) todo.push_back({n - 1, 0});
+        while (!todo.empty()) {
+            auto [i, stage] = todo.back();
+            todo.pop_back();
+            const int l = c->child1[i], r = c->child2[i];
+            const bool li = l >= nl, ri = r >= nl;
+            const bool left_first = !(li && ri) || need[l] >= need[r];
+            if (stage == 0) {
+                todo.push_back({i, 1});
+                // pushed in reverse: the child to run first is popped first
+                if (left_first) {
+                    if (ri) todo.push_back({r, 0});
+                    if (li) todo.push_back({l, 0});
+                } else {
+                    todo.push_back({l, 0});
+                    todo.push_back({r, 0});
+                }
+            } else {
+                uint32_t flags = (li ? 0u : pcsf::BLS_LEFT_LEAF) | (ri ? 0u : pcsf::BLS_RIGHT_LEAF);
+                if (li && ri && left_first) flags |= pcsf::BLS_RIGHT_ON_TOP;
+                prog.push_back(static_cast<uint32_t>(i) | static_cast<uint32_t>(l) << 8 | static_cast<uint32_t>(r) << 16 | flags << 24);
+            }
+        }
+    }
     const size_t off_range = sizeof(double) * n, off_c1 = off_range + sizeof(uint64_t) * 2 * n, off_c2 = off_c1 + ((sizeof(int16_t) * n + 7) & ~size_t(7));
-    const size_t bytes = off_c2 + sizeof(int16_t) * n;
+    const size_t off_prog = off_c2 + ((sizeof(int16_t) * n + 7) & ~size_t(7));
+    const size_t bytes = off_prog + sizeof(uint32_t) * std::max<size_t>(prog.size(), 1);
     std::vector<unsigned char> host(bytes, 0);
+    std::memcpy(host.data() + off_prog, prog.data(), sizeof(uint32_t) * prog.size());
     std::memcpy(host.data(), branch_len, sizeof(double) * n);
     std::memcpy(host.data() + off_range, range.data(), sizeof(uint64_t) * 2 * n);
     std::memcpy(host.data() + off_c1, c->child1.data(), sizeof(int16_t) * n);
@@ -735,6 +773,8 @@ int pcsf_set_bls_branch_lengths(pcsf_ctx* c, const double* branch_len)
     c->bls_tree.child2 = reinterpret_cast<const int16_t*>(base + off_c2);
     c->bls_tree.n_nodes = n;
     c->bls_tree.n_leaves = nl;
+    c->bls_tree.prog = reinterpret_cast<const uint32_t*>(base + off_prog);
+    c->bls_tree.n_prog = static_cast<int>(prog.size());
     // the divisor is the score of the full species set: one column of 'A's through the same kernel (divided by 1)
     c->bls_tree.total = 1.0;
     c->bls_ready = true;

@@ -76,24 +76,27 @@ hipError_t launch_extract_frames(const FrameSegment* d_seg, uint32_t n_segments,
 // species with one of ACGTacgt in the column; fewer than two -> 0; otherwise the branch lengths of the subtree
 // spanned by S -- every node strictly below S's last common ancestor whose leaves meet S -- over the same sum
 // for the full species set.  The reference recursion adds, per node, (own branch, left subtree, right subtree) in
-// that order; evaluating the nodes bottom-up (children have smaller indices than their parent) performs the same
-// additions on the same operands, so the double results, and the float threshold decisions made from them, are
-// identical.  One thread per column: S is a 128-bit mask built from the column's characters (coalesced across the
-// work-group: consecutive threads read consecutive columns of a species row), overlaps are popcounts against the
-// per-node leaf masks held in LDS, and the per-node partial sums live in the thread's scratch.
+// that order; any evaluation order that has both children's values ready performs the same additions on the same
+// operands, so the double results, and the float threshold decisions made from them, are identical.
+// One thread per column: S is a 128-bit mask built from the column's characters (coalesced across the work-group:
+// consecutive threads read consecutive columns of a species row); overlaps are popcounts against the per-node leaf
+// masks held in LDS.  The internal nodes run as a stack program (api.cpp `bls_program`: the deeper subtree first, a leaf
+// child's value is its branch length and never touches the stack), the waiting values in a column of LDS per thread
+// (conflict-free: thread t uses bank pair t) -- the first version kept one value per NODE in a per-thread array,
+// i.e. 2 KB of scratch memory per thread and a dependent scratch round trip per node: 0.12 TB/s on a byte kernel.
 __global__ __launch_bounds__(256) void bls_kernel(BlsTree t, const BlsSpan* __restrict__ spans, const unsigned char* __restrict__ nucl,
                                                   size_t row_stride, double* __restrict__ out, unsigned long long* __restrict__ first_bad)
 {
     __shared__ uint64_t s_range[BLS_MAX_NODES][2];
     __shared__ double s_len[BLS_MAX_NODES];
-    __shared__ int16_t s_c1[BLS_MAX_NODES], s_c2[BLS_MAX_NODES];
+    __shared__ uint32_t s_prog[128];
+    __shared__ double s_stack[BLS_STACK_DEPTH][256];
     for (int i = threadIdx.x; i < t.n_nodes; i += 256) {
         s_range[i][0] = t.range[2 * i];
         s_range[i][1] = t.range[2 * i + 1];
         s_len[i] = t.len[i];
-        s_c1[i] = t.child1[i];
-        s_c2[i] = t.child2[i];
     }
+    for (int i = threadIdx.x; i < t.n_prog; i += 256) s_prog[i] = t.prog[i];
     __syncthreads();
     const BlsSpan span = spans[blockIdx.y];
     const uint64_t x = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
@@ -116,29 +119,39 @@ __global__ __launch_bounds__(256) void bls_kernel(BlsTree t, const BlsSpan* __re
         out[col] = 0.0;
         return;
     }
-    double val[BLS_MAX_NODES];
-    for (int i = 0; i < t.n_nodes; ++i) {
-        const int ov = __popcll(lo & s_range[i][0]) + __popcll(hi & s_range[i][1]);
-        if (ov == 0) continue;  // never visited
-        if (i < t.n_leaves) {
-            val[i] = s_len[i];
-            continue;
-        }
-        const int l = s_c1[i], r = s_c2[i];
+    double* stk = &s_stack[0][threadIdx.x];   // + 256 per level
+    int sp = 0;
+    double bl = 0.0;   // a tree of one leaf has no internal node (and never gets here: in_set < 2)
+    for (int k = 0; k < t.n_prog; ++k) {
+        const uint32_t w = s_prog[k];
+        const int i = w & 0xffu, l = (w >> 8) & 0xffu, r = (w >> 16) & 0xffu;
+        const uint32_t flags = w >> 24;
         const int ol = __popcll(lo & s_range[l][0]) + __popcll(hi & s_range[l][1]);
-        double bl = ov < in_set ? s_len[i] : 0.0;  // strictly below the last common ancestor of S
-        if (ol > 0) bl += val[l];
-        if (ov - ol > 0) bl += val[r];
-        val[i] = bl;
+        const int orr = __popcll(lo & s_range[r][0]) + __popcll(hi & s_range[r][1]);
+        double vl = s_len[l], vr = s_len[r];
+        if (!(flags & (BLS_LEFT_LEAF | BLS_RIGHT_LEAF))) {   // two values waiting (wave-uniform branches: the program is the same for every column)
+            const double top = stk[(sp - 1) * 256], below = stk[(sp - 2) * 256];
+            sp -= 2;
+            vl = (flags & BLS_RIGHT_ON_TOP) ? below : top;
+            vr = (flags & BLS_RIGHT_ON_TOP) ? top : below;
+        } else if (!(flags & BLS_LEFT_LEAF)) {
+            vl = stk[--sp * 256];
+        } else if (!(flags & BLS_RIGHT_LEAF)) {
+            vr = stk[--sp * 256];
+        }
+        bl = ol + orr < in_set ? s_len[i] : 0.0;  // strictly below the last common ancestor of S (a node outside S's subtree gets a value nobody adds)
+        if (ol > 0) bl += vl;
+        if (orr > 0) bl += vr;
+        stk[sp++ * 256] = bl;
     }
-    out[col] = val[t.n_nodes - 1] / t.total;
+    out[col] = bl / t.total;
 }
 
 hipError_t launch_bls(const BlsTree& tree, const BlsSpan* d_spans, uint32_t n_spans, uint64_t max_len, const unsigned char* d_nucl,
                       size_t row_stride, double* d_out, unsigned long long* d_first_bad, hipStream_t stream)
 {
     if (n_spans == 0 || max_len == 0) return hipSuccess;
-    if (n_spans > 65535u || tree.n_nodes > BLS_MAX_NODES) return hipErrorInvalidValue;
+    if (n_spans > 65535u || tree.n_nodes > BLS_MAX_NODES || tree.n_prog > 128 || !tree.prog) return hipErrorInvalidValue;
     hipLaunchKernelGGL(bls_kernel, dim3(static_cast<unsigned>((max_len + 255u) / 256u), n_spans), dim3(256), 0, stream, tree, d_spans, d_nucl,
                        row_stride, d_out, d_first_bad);
     return hipGetLastError();

@@ -217,7 +217,13 @@ struct BlsTree {            // device pointers; nodes in the model's order (chil
     const uint64_t* range;  // [n_nodes][2] leaves below the node
     int n_nodes, n_leaves;
     double total;           // score of the full species set (the divisor)
+    // the internal nodes in the order a stack machine evaluates them (bls_program): node | left << 8 | right << 16 | flags << 24
+    const uint32_t* prog;
+    int n_prog;
 };
+constexpr int BLS_STACK_DEPTH = 10;   // values of internal nodes waiting for their parent (deeper subtree first: <= log2(n internal) + 1)
+constexpr uint32_t BLS_LEFT_LEAF = 1u, BLS_RIGHT_LEAF = 2u, BLS_RIGHT_ON_TOP = 4u;   // flags: a child is a leaf (its value is its branch length, nothing
+                                                                                    // is popped); both internal: the right child's value was pushed last
 struct BlsSpan {            // columns [col0, col0 + len) of the nucleotide matrix belong to one alignment
     uint64_t col0;
     uint64_t len;
