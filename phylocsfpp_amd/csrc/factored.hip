@@ -292,10 +292,13 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
     // wait for the leaf's column of L, issued beside them; holding them too took the kernel from three waves per SIMD to two.)
     double pre[4] = {1.0, 1.0, 1.0, 1.0};
     int n_active = 0;
+    uint32_t chain16 = 0;   // bit j: the op of rank rank0 + j only scales a message in eigen form (see the op loop)
     auto load_batch = [&](int rank0) __attribute__((always_inline)) {
         const unsigned long long t_in = stamping ? fact_clock() : 0ull;
         const int idx = rank0 + sj < n_active ? rank0 + sj : n_active - 1;
-        const double2_t* s0 = reinterpret_cast<const double2_t*>(scale + static_cast<size_t>(lrow_edge[idx]) * 64);
+        const uint32_t row = lrow_edge[idx];
+        chain16 = static_cast<uint32_t>(__ballot((row >> 31) != 0u && rank0 + sj < n_active)) & 0xffffu;   // lanes 0..15: sj = 0..15 of lane group 0
+        const double2_t* s0 = reinterpret_cast<const double2_t*>(scale + static_cast<size_t>(row & 0x7fffffffu) * 64);
         const double2_t a0 = s0[0], a1 = s0[1];
         pre[0] = a0.x; pre[1] = a0.y; pre[2] = a1.x; pre[3] = a1.y;
         if (stamping) {
@@ -471,16 +474,43 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
                 const int at = (k ? n_act0 : 0) + __popcll(active[k] & ((1ull << lane) - 1ull));
                 const uint32_t code = opw[k] >> 28;
                 const bool has_edge = code != F_CHERRY_DEV && code < F_ROOT_DEV;
-                lrow_edge[at] = has_edge ? static_cast<uint32_t>(lslot[mt[k] & 0x3fffu]) : 0u;
+                // an op that, on a message in eigen form, is nothing but y <- e_b o y: the other operand of its product of messages is all
+                // ones -- a leaf edge whose leaf has no codon in the tile, a pop whose parked tile is all ones
+                const int a = static_cast<int>((opw[k] >> 14) & 0x3fffu);
+                const bool a_has = ((a < 64 ? has0 >> a : has1 >> (a - 64)) & 1ull) != 0;
+                const int parking = static_cast<int>(mt[k] >> 18);
+                const bool parked_ones = parking > 0 && ((((parking - 1) >> 6) ? ones_after[1] : ones_after[0]) >> ((parking - 1) & 63) & 1ull);
+                const bool before = lane > 0 ? ((ones_after[k] >> (lane - 1)) & 1ull) : (k == 1 && (ones_after[0] >> 63));
+                const bool scales_only = !before && ((code == F_MM_LEAF_DEV && !a_has) || (code >= F_MM_POP0_DEV && code < F_ROOT_DEV && parked_ones));
+                lrow_edge[at] = (has_edge ? static_cast<uint32_t>(lslot[mt[k] & 0x3fffu]) : 0u) | (scales_only ? 0x80000000u : 0u);
             }
         __syncthreads();
         for (int k = 0; k < 2; ++k) {
             unsigned long long todo = k ? active[1] : active[0];
             while (todo) {
+                if ((rank & 15) == 0) load_batch(rank);
+                // A chain of edges above a lone species is a run of ops that only scale: y <- e_b o y, one after the other in the order the
+                // ops would do it (same roundings), without an op's dispatch each -- 21 of the 38 ops of a tile with four species present.
+                if (cur.eig && cur.mask != 0xffffu) {
+                    const uint32_t run_bits = ~(chain16 >> (rank & 15));
+                    int n_run = run_bits ? __builtin_ctz(run_bits) : 16;
+                    n_run = n_run < 16 - (rank & 15) ? n_run : 16 - (rank & 15);
+                    const int left = __popcll(todo);
+                    n_run = n_run < left ? n_run : left;
+                    if (n_run > 0) {
+                        for (int j = 0; j < n_run; ++j) {
+                            const int src = (lane & 48) | ((rank + j) & 15);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) cur.v.v[r] *= __shfl(pre[r], src);
+                            todo &= todo - 1;
+                        }
+                        rank += n_run;
+                        continue;
+                    }
+                }
                 const int l = __builtin_ctzll(todo);
                 todo &= todo - 1;
                 const int i = 64 * k + l;
-                if ((rank & 15) == 0) load_batch(rank);
                 const uint32_t op = __builtin_amdgcn_readlane(k ? opw[1] : opw[0], l), meta = __builtin_amdgcn_readlane(k ? mt[1] : mt[0], l);   // selects: an index would send both arrays to scratch
                 const unsigned long long ones_k = k ? ones_after[1] : ones_after[0];
                 const bool ones_before = i > 0 && ((l > 0 ? ones_k >> (l - 1) : ones_after[0] >> 63) & 1ull);

@@ -321,20 +321,24 @@ struct WigSink {
 };
 
 
-// a piece of wig text formatted in memory (build_tracks stage 3)
+// a piece of wig text formatted in memory (build_tracks stage 3); the buffer is kept between batches (fresh memory costs page faults)
 struct TextPiece {
     std::vector<char> buf;
+    size_t len = 0;
+    void start(size_t expected)
+    {
+        len = 0;
+        if (buf.size() < expected) buf.resize(expected);
+    }
     char* room(size_t n)
     {
-        const size_t at = buf.size();
-        buf.resize(at + n);
-        return buf.data() + at;
+        if (len + n > buf.size()) buf.resize(std::max(buf.size() * 2, len + n));
+        return buf.data() + len;
     }
     void header(const std::string& chrom, int64_t pos)
     {
         char* p = room(chrom.size() + 64);
-        const int n = snprintf(p, chrom.size() + 64, "fixedStep chrom=%s start=%" PRId64 " step=3 span=3\n", chrom.c_str(), pos);
-        buf.resize(buf.size() - (chrom.size() + 64 - static_cast<size_t>(n)));
+        len += static_cast<size_t>(snprintf(p, chrom.size() + 64, "fixedStep chrom=%s start=%" PRId64 " step=3 span=3\n", chrom.c_str(), pos));
     }
     template <int D>
     void value(float v)
@@ -342,7 +346,7 @@ struct TextPiece {
         char* p = room(72);
         const size_t n = format_trimmed<D>(p, v);
         p[n] = '\n';
-        buf.resize(buf.size() - (72 - (n + 1)));
+        len += n + 1;
     }
 };
 
@@ -442,10 +446,10 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         size_t a = 0, b = 0;   // power: positions [a, b) of the alignment (a = skip mod 3); frames: codons [a, b)
     };
     constexpr size_t PIECE_CODONS = 16384;
+    std::vector<TextPiece> text;   // stage 3's buffers, reused from batch to batch
     auto format_piece = [&](const PieceJob& j, TextPiece& out) {
         const Item& p = *j.it;
-        out.buf.clear();
-        out.buf.reserve((j.b - j.a) * (j.file == 0 ? 3 : 9) + 128);
+        out.start((j.b - j.a) * (j.file == 0 ? 4 : 10) + 256);
         if (j.file == 0) {  // frame 3 of the + strand, mean of the three per-base scores
             int64_t skip = static_cast<int64_t>(3 - static_cast<int64_t>(p.start_pos)) % 3;
             if (skip < 0) skip += 3;
@@ -666,13 +670,13 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         writer = std::async(std::launch::async, [&, batch = f.bt]() {
             StopWatch ww;
             const std::vector<PieceJob> jobs = batch_pieces(batch->items, batch->scores, batch->offsets);
-            std::vector<TextPiece> text(jobs.size());
+            if (text.size() < jobs.size()) text.resize(jobs.size());   // one writer runs at a time; the buffers keep their memory
             parallel_for(jobs.size(), threads, [&](size_t i) { format_piece(jobs[i], text[i]); });
             parallel_for(7, threads, [&](size_t t) {   // every file's pieces in order; the files side by side
                 FILE* f = t == 0 ? f_power : f_raw[t - 1];
                 if (!f) return;
                 for (size_t i = 0; i < jobs.size(); ++i)
-                    if (jobs[i].file == static_cast<int>(t) && !text[i].buf.empty() && fwrite(text[i].buf.data(), 1, text[i].buf.size(), f) != text[i].buf.size())
+                    if (jobs[i].file == static_cast<int>(t) && text[i].len && fwrite(text[i].buf.data(), 1, text[i].len, f) != text[i].len)
                         throw std::runtime_error("write failed");
             });
             if (batch->score_mem.first) score_pool.put(batch->score_mem);
