@@ -159,6 +159,26 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx *ctx, const char *nucleotides, si
                                       size_t out_capacity, uint64_t *out_offsets, uint32_t *n_codons,
                                       uint32_t *skip_bases, double *out_bls);
 
+/* ---- the smoothing pass of build-tracks (--output-phylo / --output-regions) --------------------------------
+ * hmm::state_posterior_probabilities and the forward half of get_best_path_by_viterbi (src/create_tracks.hpp:25-159,
+ * called per run of a raw track by process_scores, src/create_tracks.hpp:226-314) for a batch of runs at once.
+ * init[4] / trans[4][4] (row-major, trans[from][to]): get_coding_hmm (src/create_tracks.hpp:163-200), state 0 = coding.
+ * emissions[n]: the coding state's emission at every position, pow(10, score / 10) as the caller's libm gives it (the
+ * other states emit 1); run r owns positions [run_offsets[r], run_offsets[r + 1]), n = run_offsets[n_runs].
+ * out_posterior[n]: posterior probability of the coding state (the reference's scaled forward-backward, same operation
+ * order: the values equal a sequential evaluation bit for bit -- csrc/hmm.hip says how).  Optionally the Viterbi
+ * recursion: out_back[n] holds, for every position but a run's first, the best predecessor of each of the four states
+ * (2 bits per state, state s in bits 2s..2s+1) and out_last[n_runs][4] the rescaled probabilities at each run's last
+ * position -- the caller picks the final state (first maximum) and walks back.  out_back and out_last are both NULL or
+ * both given.  stats (may be NULL): how many chunks the runs were cut into and how many had to be evaluated again. */
+typedef struct pcsf_hmm_stats {
+    uint32_t chunks;
+    uint32_t forward_reruns, forward_passes, backward_reruns, backward_passes, viterbi_reruns, viterbi_passes;
+} pcsf_hmm_stats;
+int pcsf_hmm_smooth_runs(pcsf_ctx *ctx, const double *init, const double *trans, const double *emissions,
+                         const uint64_t *run_offsets, size_t n_runs, double *out_posterior, uint8_t *out_back,
+                         double *out_last, pcsf_hmm_stats *stats);
+
 /* ---- run (src/run.hpp:57-211): whole-block scores -----------------------------------------
  * A batch of blocks in CSR form: block b owns sites [site_offsets[b], site_offsets[b+1]) of the
  * leaf-major codon matrix.  algo FIXED / MLE / OMEGA; seed is what score-msa passes to

@@ -76,6 +76,7 @@ def load_library():
     lib.pcsf_score_alignments_6frames_bls.argtypes = lib.pcsf_score_alignments_6frames.argtypes + [dp]
     lib.pcsf_set_bls_branch_lengths.argtypes = [vp, dp]
     lib.pcsf_branch_length_scores.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_size_t, dp]
+    lib.pcsf_hmm_smooth_runs.argtypes = [vp, dp, dp, dp, C.POINTER(C.c_uint64), C.c_size_t, dp, u8p, dp, C.POINTER(C.c_uint32)]
     lib.pcsf_block_loglik.argtypes = [vp, C.c_int, dp, dp, u8p, C.POINTER(C.c_uint64), C.c_size_t, C.c_size_t, dp,
                                       C.POINTER(C.c_int32)]
     lib.pcsf_block_loglik_eig.argtypes = [vp, dp, dp, dp, dp, C.c_size_t, dp, u8p, C.POINTER(C.c_uint64), C.c_size_t, C.c_size_t, dp,
@@ -284,6 +285,27 @@ class ScoringContext:
         self._check(self._lib.pcsf_branch_length_scores(self._h, nuc.ctypes.data_as(C.c_char_p), nuc.strides[0], nuc.shape[1],
                                                         out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
+
+    def hmm_smooth_runs(self, init, trans, emissions, run_offsets, viterbi=True):
+        """The smoothing pass's recurrences for a batch of runs (pcsf_hmm_smooth_runs): coding posterior float64[n] and, with
+        viterbi, the packed back pointers uint8[n] and the last rescaled Viterbi vector of every run float64[n_runs, 4];
+        the fourth value is the call's statistics (chunks, forward reruns / passes, backward ..., viterbi ...)."""
+        dp = C.POINTER(C.c_double)
+        init = np.ascontiguousarray(init, dtype=np.float64)
+        trans = np.ascontiguousarray(trans, dtype=np.float64)
+        em = np.ascontiguousarray(emissions, dtype=np.float64)
+        offs = np.ascontiguousarray(run_offsets, dtype=np.uint64)
+        assert init.shape == (4,) and trans.shape == (4, 4) and offs.ndim == 1 and len(offs) >= 1 and int(offs[-1]) == len(em)
+        n_runs = len(offs) - 1
+        post = np.empty(len(em), dtype=np.float64)
+        back = np.zeros(len(em), dtype=np.uint8) if viterbi else None
+        last = np.zeros((n_runs, 4), dtype=np.float64) if viterbi else None
+        stats = np.zeros(7, dtype=np.uint32)
+        self._check(self._lib.pcsf_hmm_smooth_runs(self._h, init.ctypes.data_as(dp), trans.ctypes.data_as(dp), em.ctypes.data_as(dp),
+                                                   offs.ctypes.data_as(C.POINTER(C.c_uint64)), n_runs, post.ctypes.data_as(dp),
+                                                   back.ctypes.data_as(C.POINTER(C.c_uint8)) if viterbi else None,
+                                                   last.ctypes.data_as(dp) if viterbi else None, stats.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return post, back, last, stats
 
     def score_alignments_6frames(self, nucleotides, alignments, with_bls=False):
         """Six-frame front end (device translation + run_tracks).  nucleotides: uint8/bytes ndarray

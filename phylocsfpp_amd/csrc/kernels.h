@@ -159,6 +159,23 @@ hipError_t launch_prune_factored(const FactoredParams& p, hipStream_t stream);
 hipError_t launch_prune_tiles(const FactoredParams& p, hipStream_t stream);
 size_t prune_tiles_lds_bytes(const FactoredParams& p);
 
+// ---- the smoothing pass (hmm.hip): chunks of runs of raw scores, one thread per chunk ---------------------------------------------
+struct HmmModel {   // host/hmm.hpp `Hmm`: state 0 = coding, 1..3 = non-coding classes
+    double init[4];
+    double trans[4][4];
+};
+struct HmmChunk {   // positions [begin, end) of the run [run_begin, run_end); chunks of a run are consecutive, in position order
+    uint64_t run_begin, run_end, begin, end;
+};
+// mode 0: forward (d_fwd[n][4]), 1: Viterbi (d_back[n]: four 2-bit predecessors per position), 2: backward + posterior (reads d_fwd,
+// writes d_post[n]).  d_todo: the chunks to run (null: chunks 0..n_todo-1); rerun: start from the neighbouring chunk's exit state
+// instead of burning in.  d_entry / d_exit [n_chunks][4]: the state a chunk started from / ended with.
+hipError_t launch_hmm_chunks(int mode, const HmmModel& h, const HmmChunk* d_chunks, const uint32_t* d_todo, uint32_t n_todo, bool rerun, uint32_t burn_in,
+                             const double* d_emit, double* d_fwd, uint8_t* d_back, double* d_post, double* d_entry, double* d_exit, hipStream_t stream);
+// d_same[c] = chunk c's entry state equals, bit for bit, the exit state of the chunk it depends on (c - 1; backward: c + 1)
+hipError_t launch_hmm_compare(const HmmChunk* d_chunks, uint32_t n_chunks, bool backward, const double* d_entry, const double* d_exit, uint8_t* d_same,
+                              hipStream_t stream);
+
 // Batched eigen-systems of the kappa/omega F3x4 rate matrix (eigen.hip): one job = one rate matrix.
 struct EigenJob {
     uint32_t eig;      // destination eigen-system index

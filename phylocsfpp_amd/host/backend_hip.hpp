@@ -2,6 +2,9 @@
 #pragma once
 
 #include <algorithm>
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -44,6 +47,15 @@ public:
         check(pcsf_score_blocks(ctx_, algo, codons, offsets, n_blocks, leaf_stride, compute_anc ? 1 : 0, seed, phylo, anc));
     }
     void prepare_blocks(int algo) override { check(pcsf_prepare_block_scoring(ctx_, algo)); }
+    bool device_hmm() const override { return std::getenv("PCSF_HOST_HMM") == nullptr; }   // PCSF_HOST_HMM=1: the host code (A/B, tests)
+    void hmm_smooth_runs(const Hmm& h, const double* emissions, const uint64_t* run_offsets, size_t n_runs, double* posterior, uint8_t* back, double* last) override
+    {
+        pcsf_hmm_stats st{};
+        check(pcsf_hmm_smooth_runs(ctx_, h.init, &h.trans[0][0], emissions, run_offsets, n_runs, posterior, back, last, &st));
+        if (std::getenv("PCSF_HMM_STATS"))
+            fprintf(stderr, "hmm_smooth_runs: %zu runs, %" PRIu64 " values in %u chunks; evaluated again: forward %u (%u passes), backward %u (%u), viterbi %u (%u)\n", n_runs,
+                    run_offsets[n_runs], st.chunks, st.forward_reruns, st.forward_passes, st.backward_reruns, st.backward_passes, st.viterbi_reruns, st.viterbi_passes);
+    }
 
     size_t score_alignments_6frames(int, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0, const std::vector<uint32_t>& len,
                                     const std::vector<uint64_t>& start_pos, const std::vector<uint64_t>& chrom_len, double* out, size_t out_capacity,

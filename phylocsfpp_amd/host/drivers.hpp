@@ -72,6 +72,16 @@ struct ScoringBackend {
     virtual void prepare_tracks(size_t /*max_columns*/) {}
     // false while a backend is still being set up (DeferredBackend): build-tracks deals its batches to the others meanwhile
     virtual bool ready() const { return true; }
+    // The smoothing pass's recurrences for a batch of runs of raw scores (hmm.hpp: scaled forward-backward, Viterbi): coding-state
+    // emissions[n], run r = positions [run_offsets[r], run_offsets[r + 1]) -> posterior[n]; with back / last also the Viterbi back
+    // pointers (2 bits per state and position) and every run's last rescaled vector.  The HIP backend runs them on the device
+    // (pcsf_hmm_smooth_runs); a backend without it leaves the pass to the host code.
+    virtual bool device_hmm() const { return false; }
+    virtual void hmm_smooth_runs(const Hmm& /*h*/, const double* /*emissions*/, const uint64_t* /*run_offsets*/, size_t /*n_runs*/, double* /*posterior*/,
+                                 uint8_t* /*back*/, double* /*last*/)
+    {
+        throw std::runtime_error("hmm_smooth_runs: this backend does not smooth tracks");
+    }
     virtual size_t score_alignments_6frames(int n_leaves, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0,
                                             const std::vector<uint32_t>& len, const std::vector<uint64_t>& start_pos,
                                             const std::vector<uint64_t>& chrom_len, double* out, size_t out_capacity, std::vector<uint64_t>& offsets,
@@ -139,6 +149,11 @@ public:
     void prepare_blocks(int algo) override
     {
         if (ready()) get().prepare_blocks(algo);   // a backend still being made is not waited for
+    }
+    bool device_hmm() const override { return get().device_hmm(); }
+    void hmm_smooth_runs(const Hmm& h, const double* emissions, const uint64_t* run_offsets, size_t n_runs, double* posterior, uint8_t* back, double* last) override
+    {
+        get().hmm_smooth_runs(h, emissions, run_offsets, n_runs, posterior, back, last);
     }
     size_t score_alignments_6frames(int n_leaves, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0, const std::vector<uint32_t>& len,
                                     const std::vector<uint64_t>& start_pos, const std::vector<uint64_t>& chrom_len, double* out, size_t out_capacity,
@@ -389,6 +404,242 @@ inline void smooth_tracks(const std::string& out_dir, const Hmm& hmm, bool write
         bed_file.commit();
         if (!keep_raw) unlink(raw.c_str());
     });
+}
+
+// The same pass with the recurrences on the device (backend.hmm_smooth_runs).  Tracks are taken in groups of up to ~64 M values (all six
+// of a 10 Mb chromosome, one at a time for a large one): (1) the text of the group's raw tracks is parsed on all host threads into runs
+// merged like the reference's wig reader (for_each_wig_run); (2) the coding emissions pow(10, score / 10) come from the host's libm --
+// scores are multiples of 0.001, so a table over [-200, 200] is computed once and every value is a look-up; anything that is not such
+// a multiple goes through pow() itself; (3) ONE backend call returns the coding posterior and the Viterbi back pointers of all runs
+// of the group; (4) log-odds, text and regions are made on all host threads, the files appended side by side.  Output files are
+// byte-identical to smooth_tracks' (tests/test_gpu_hmm.py).
+inline void smooth_tracks_device(const std::string& out_dir, const Hmm& hmm, bool write_smooth, bool write_regions, bool keep_raw, int threads,
+                                 ScoringBackend& backend)
+{
+    constexpr int TABLE_HALF = 200000;   // scores in [-200, 200] decibans by look-up
+    constexpr size_t GROUP_VALUES = size_t(64) << 20;
+    const bool verbose = std::getenv("PCSF_HMM_STATS") != nullptr;
+    std::vector<double> table(2 * TABLE_HALF + 1);
+    parallel_for(64, threads, [&](size_t part) {
+        for (int k = static_cast<int>(part) - TABLE_HALF; k <= TABLE_HALF; k += 64) table[k + TABLE_HALF] = hmm_emit(0, static_cast<double>(k) / 1000.0);
+    });
+    struct Piece {   // a stretch of a file, cut at line starts: its headers and values in order
+        std::vector<std::pair<size_t, std::pair<std::string, uint64_t>>> headers;   // (values before the header within the piece, (chrom, start))
+        std::vector<double> values;
+        size_t at = 0;   // position of the piece's first value in the group's arrays
+    };
+    struct Run {
+        std::string chrom;
+        uint64_t start;
+    };
+    struct Frame {
+        int fi = 0;
+        std::string raw;
+        std::unique_ptr<MafFile> text;
+        std::vector<Piece> pieces;
+        std::vector<Run> runs;
+        size_t run0 = 0;   // index of the frame's first run in the group's run list
+        OutFile wig_file, bed_file;   // closed (and, on failure, removed) on every path out
+    };
+    auto tag_of = [](int fi) { return std::string(1, fi < 3 ? '+' : '-') + std::to_string(fi % 3 + 1); };
+    for (int f0 = 0; f0 < 6;) {
+        StopWatch phase;
+        std::vector<std::unique_ptr<Frame>> group;
+        size_t estimate = 0;
+        for (; f0 < 6; ++f0) {
+            std::unique_ptr<Frame> fr(new Frame);
+            fr->fi = f0;
+            fr->raw = out_dir + "/PhyloCSFRaw" + tag_of(f0) + ".wig";
+            fr->text.reset(new MafFile(fr->raw));
+            const size_t est = fr->text->size() / 6;
+            if (!group.empty() && estimate + est > GROUP_VALUES) break;
+            estimate += est;
+            group.push_back(std::move(fr));
+        }
+        // (1) parse: pieces of every file of the group
+        std::vector<std::pair<size_t, size_t>> piece_jobs;   // (frame, piece)
+        for (size_t g = 0; g < group.size(); ++g) {
+            const size_t n_pieces = std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(threads) * 2, group[g]->text->size() >> 16));
+            group[g]->pieces.resize(n_pieces);
+            for (size_t pi = 0; pi < n_pieces; ++pi) piece_jobs.push_back({g, pi});
+        }
+        parallel_for(piece_jobs.size(), threads, [&](size_t j) {
+            Frame& fr = *group[piece_jobs[j].first];
+            const size_t pi = piece_jobs[j].second, n_pieces = fr.pieces.size();
+            const char* base = fr.text->data();
+            const size_t size = fr.text->size();
+            auto line_start = [&](size_t at) {   // first line start at or after `at`
+                if (at == 0) return size_t(0);
+                const void* nl = memchr(base + at - 1, '\n', size - (at - 1));
+                return nl ? static_cast<size_t>(static_cast<const char*>(nl) - base) + 1 : size;
+            };
+            size_t at = line_start(size * pi / n_pieces);
+            const size_t end = line_start(size * (pi + 1) / n_pieces);
+            Piece& pc = fr.pieces[pi];
+            pc.values.reserve((end - at) / 5 + 16);
+            while (at < end) {
+                const char* line = base + at;
+                const void* nl = memchr(line, '\n', size - at);
+                const size_t len = nl ? static_cast<size_t>(static_cast<const char*>(nl) - line) : size - at;
+                at += len + 1;
+                if (len == 0) continue;
+                if (line[0] == 'f') {
+                    char chrom[256] = {0};
+                    uint64_t start = 0;
+                    const std::string l(line, len);
+                    if (sscanf(l.c_str(), "fixedStep chrom=%255s start=%" SCNu64, chrom, &start) != 2) throw std::runtime_error("malformed fixedStep line in " + fr.raw);
+                    pc.headers.push_back({pc.values.size(), {chrom, start}});
+                    continue;
+                }
+                // a plain decimal with at most three decimals is k / 1000 exactly rounded -- what strtod returns; anything else: strtod
+                size_t i = 0;
+                const bool neg = line[0] == '-';
+                if (neg) ++i;
+                uint64_t ip = 0, frac = 0;
+                size_t nd = 0, nf = 0;
+                while (i < len && line[i] >= '0' && line[i] <= '9' && nd < 9) { ip = ip * 10 + static_cast<uint64_t>(line[i] - '0'); ++i; ++nd; }
+                bool plain = nd > 0;
+                if (plain && i < len && line[i] == '.') {
+                    ++i;
+                    while (i < len && line[i] >= '0' && line[i] <= '9' && nf < 3) { frac = frac * 10 + static_cast<uint64_t>(line[i] - '0'); ++i; ++nf; }
+                    for (size_t pad = nf; pad < 3; ++pad) frac *= 10;
+                }
+                plain = plain && i == len;
+                if (plain) {
+                    const double v = static_cast<double>(ip * 1000 + frac) / 1000.0;
+                    pc.values.push_back(neg ? -v : v);
+                } else {
+                    pc.values.push_back(strtod(std::string(line, len).c_str(), nullptr));
+                }
+            }
+        });
+        // runs: a header that continues the stretch before it (same chromosome, start == start of the run + 3 x values so far) starts nothing
+        std::vector<uint64_t> run_offsets;
+        std::vector<std::pair<size_t, size_t>> run_owner;   // (frame, run within the frame)
+        size_t n = 0;
+        for (size_t g = 0; g < group.size(); ++g) {
+            Frame& fr = *group[g];
+            fr.run0 = run_offsets.size();
+            const size_t frame_at = n;
+            auto run_begin = [&]() { return run_offsets.back(); };
+            for (Piece& pc : fr.pieces) {
+                pc.at = n;
+                for (const auto& hd : pc.headers) {
+                    const uint64_t at = pc.at + hd.first;
+                    const bool open = !fr.runs.empty();
+                    if (open && at > run_begin() && fr.runs.back().chrom == hd.second.first && fr.runs.back().start + 3 * (at - run_begin()) == hd.second.second) continue;
+                    if (open && at == run_begin()) {   // a header right behind a header: the earlier one had no values
+                        fr.runs.back() = Run{hd.second.first, hd.second.second};
+                        continue;
+                    }
+                    if (!open && at > frame_at) throw std::runtime_error("values before the first fixedStep line in " + fr.raw);
+                    fr.runs.push_back(Run{hd.second.first, hd.second.second});
+                    run_offsets.push_back(at);
+                    run_owner.push_back({g, fr.runs.size() - 1});
+                }
+                n += pc.values.size();
+            }
+            if (fr.runs.empty() && n > frame_at) throw std::runtime_error("values before the first fixedStep line in " + fr.raw);
+            if (!fr.runs.empty() && run_begin() == n) {   // a last header without values
+                fr.runs.pop_back();
+                run_offsets.pop_back();
+                run_owner.pop_back();
+            }
+            if (write_smooth) fr.wig_file.open(out_dir + "/PhyloCSF" + tag_of(fr.fi) + ".wig", "w");
+            if (write_regions) fr.bed_file.open(out_dir + "/PhyloCSF" + tag_of(fr.fi) + "Regions.bed", "w");
+        }
+        run_offsets.push_back(n);
+        const size_t n_runs = run_owner.size();
+        const double t_parse = phase.lap();
+        double t_emit = 0, t_dev = 0, t_text = 0, t_regions = 0;
+        if (n_runs > 0) {
+            // (2) emissions (the arrays are not value-initialised: 17 bytes per value that are written before they are read)
+            std::unique_ptr<double[]> emit(new double[n]), post(new double[n]), last(write_regions ? new double[n_runs * 4] : nullptr);
+            std::unique_ptr<uint8_t[]> back(write_regions ? new uint8_t[n] : nullptr);
+            parallel_for(piece_jobs.size(), threads, [&](size_t j) {
+                Piece& pc = group[piece_jobs[j].first]->pieces[piece_jobs[j].second];
+                const std::vector<double>& v = pc.values;
+                double* dst = emit.get() + pc.at;
+                for (size_t i = 0; i < v.size(); ++i) {
+                    const double scaled = v[i] * 1000.0;
+                    const bool in_table = std::fabs(scaled) <= TABLE_HALF;
+                    const long k = in_table ? std::lrint(scaled) : 0;
+                    dst[i] = (in_table && static_cast<double>(k) / 1000.0 == v[i]) ? table[k + TABLE_HALF] : hmm_emit(0, v[i]);
+                }
+                std::vector<double>().swap(pc.values);
+            });
+            t_emit = phase.lap();
+            // (3) the recurrences
+            backend.hmm_smooth_runs(hmm, emit.get(), run_offsets.data(), n_runs, post.get(), back.get(), last.get());
+            emit.reset();
+            t_dev = phase.lap();
+            // (4) text: pieces of runs on all threads, every file's pieces appended in order
+            if (write_smooth) {
+                struct Job { size_t run, a, b; };
+                std::vector<Job> jobs;
+                constexpr size_t PIECE = 32768;
+                for (size_t r = 0; r < n_runs; ++r)
+                    for (size_t a = run_offsets[r]; a < run_offsets[r + 1]; a += PIECE) jobs.push_back(Job{r, a, std::min<size_t>(a + PIECE, run_offsets[r + 1])});
+                constexpr size_t WAVE = 8192;   // jobs formatted before their text is written (bounds the memory held as text)
+                std::vector<TextPiece> out(std::min(jobs.size(), WAVE));
+                for (size_t j0 = 0; j0 < jobs.size(); j0 += WAVE) {
+                    const size_t j1 = std::min(jobs.size(), j0 + WAVE);
+                    parallel_for(j1 - j0, threads, [&](size_t j) {
+                        const Job& jb = jobs[j0 + j];
+                        const Run& run = group[run_owner[jb.run].first]->runs[run_owner[jb.run].second];
+                        TextPiece& o = out[j];
+                        o.start((jb.b - jb.a) * 9 + 256);
+                        if (jb.a == run_offsets[jb.run]) o.header(run.chrom, static_cast<int64_t>(run.start));
+                        for (size_t i = jb.a; i < jb.b; ++i) o.value<3>(static_cast<float>(hmm_log_odds(post[i])));
+                    });
+                    parallel_for(group.size(), threads, [&](size_t g) {
+                        FILE* f_wig = group[g]->wig_file.get();
+                        for (size_t j = 0; j < j1 - j0; ++j)
+                            if (run_owner[jobs[j0 + j].run].first == g && out[j].len && fwrite(out[j].buf.data(), 1, out[j].len, f_wig) != out[j].len)
+                                throw std::runtime_error("write failed");
+                    });
+                }
+            }
+            t_text = phase.lap();
+            if (write_regions) {
+                std::vector<std::vector<BedRegion>> regions(n_runs);
+                parallel_for(n_runs, threads, [&](size_t r) {
+                    const size_t b = run_offsets[r], len = run_offsets[r + 1] - b;
+                    std::vector<uint32_t> path(len, 0);
+                    const double* prev = last.get() + 4 * r;
+                    uint32_t best = 0;  // hmm_viterbi's rule: the first maximum; all zero: state 0
+                    for (uint32_t i = 1; i < 4; ++i)
+                        if (prev[i] > prev[best]) best = i;
+                    if (!(prev[best] > 0.0)) best = 0;
+                    path[len - 1] = best;
+                    for (size_t pos = len - 1; pos-- > 0;) path[pos] = (back[b + pos + 1] >> (2 * path[pos + 1])) & 3u;
+                    const std::vector<double> run_post(post.get() + b, post.get() + b + len);
+                    hmm_regions(path, run_post, static_cast<uint32_t>(group[run_owner[r].first]->runs[run_owner[r].second].start), regions[r]);
+                });
+                parallel_for(group.size(), threads, [&](size_t g) {
+                    FILE* f_bed = group[g]->bed_file.get();
+                    const char strand = group[g]->fi < 3 ? '+' : '-';
+                    for (size_t r = 0; r < n_runs; ++r) {
+                        if (run_owner[r].first != g) continue;
+                        const Run& run = group[g]->runs[run_owner[r].second];
+                        for (const BedRegion& rg : regions[r])
+                            fprintf(f_bed, "%s\t%" PRIu32 "\t%" PRIu32 "\t%s:%" PRIu32 "-%" PRIu32 "\t0\t%c\t%" PRIu32 "\t%" PRIu32 "\t%" PRIu32 ",%" PRIu32 ",%" PRIu32 "\n",
+                                    run.chrom.c_str(), rg.start, rg.end, run.chrom.c_str(), rg.start + 1, rg.end, strand, rg.start, rg.end, rg.color, rg.color, rg.color);
+                    }
+                });
+            }
+            t_regions = phase.lap();
+        }
+        for (auto& fr : group) {
+            fr->wig_file.commit();
+            fr->bed_file.commit();
+            fr->text.reset();
+            if (!keep_raw) unlink(fr->raw.c_str());
+        }
+        if (verbose)
+            fprintf(stderr, "smooth_tracks_device, tracks %s..%s: %zu values in %zu runs; parse %.3f s, emissions %.3f, recurrences (backend) %.3f, log-odds + text %.3f, paths + regions %.3f\n",
+                    tag_of(group.front()->fi).c_str(), tag_of(group.back()->fi).c_str(), n, n_runs, t_parse, t_emit, t_dev, t_text, t_regions);
+    }
 }
 
 // build-tracks for one MAF file.  append: later files of a multi-file run append to the wigs.
@@ -768,7 +1019,8 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     for (OutFile& f : raw_file) f.commit();
     if (prm.write_smooth || prm.write_regions) {
         sw.lap();
-        smooth_tracks(out_dir, prm.hmm, prm.write_smooth, prm.write_regions, /*keep_raw=*/prm.write_raw, threads);
+        if (backend.device_hmm()) smooth_tracks_device(out_dir, prm.hmm, prm.write_smooth, prm.write_regions, /*keep_raw=*/prm.write_raw, threads, backend);
+        else smooth_tracks(out_dir, prm.hmm, prm.write_smooth, prm.write_regions, /*keep_raw=*/prm.write_raw, threads);
         st.smooth_seconds += sw.lap();
     }
     st.total_seconds = total.lap();
