@@ -21,11 +21,24 @@ struct Buffers {
 
 }  // namespace
 
-extern "C" int pcsf_hmm_smooth_runs(pcsf_ctx* c, const double* init, const double* trans, const double* emissions, const uint64_t* run_offsets, size_t n_runs,
-                                    double* out_posterior, uint8_t* out_back, double* out_last, pcsf_hmm_stats* stats)
+struct BinRequest {   // pcsf_hmm_smooth_runs_binned: bins of the posterior instead of the posterior
+    const double* thresholds = nullptr;
+    size_t n_thresholds = 0;
+    uint16_t* out_bins = nullptr;
+    uint64_t* exc_index = nullptr;
+    double* exc_value = nullptr;
+    size_t exc_capacity = 0;
+    size_t* n_exc = nullptr;
+};
+
+static int smooth_runs(pcsf_ctx* c, const double* init, const double* trans, const double* emissions, const uint64_t* run_offsets, size_t n_runs,
+                       double* out_posterior, const BinRequest* bins, uint8_t* out_back, double* out_last, pcsf_hmm_stats* stats)
 {
     if (!c) return PCSF_ERR_INVALID_ARG;
-    if (!init || !trans || !run_offsets || !out_posterior) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_hmm_smooth_runs: null argument");
+    if (!init || !trans || !run_offsets || (!out_posterior && !bins)) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_hmm_smooth_runs: null argument");
+    if (bins && (!bins->thresholds || !bins->out_bins || !bins->n_exc || bins->n_thresholds >= 0xffffu || (bins->exc_capacity && (!bins->exc_index || !bins->exc_value))))
+        return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_hmm_smooth_runs_binned: null argument or 65,535 thresholds or more");
+    if (bins) *bins->n_exc = 0;
     if ((out_back == nullptr) != (out_last == nullptr)) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_hmm_smooth_runs: out_back and out_last go together");
     if (stats) *stats = pcsf_hmm_stats{};
     const uint64_t n = n_runs ? run_offsets[n_runs] : 0;
@@ -124,9 +137,54 @@ extern "C" int pcsf_hmm_smooth_runs(pcsf_ctx* c, const double* init, const doubl
     }
     if ((rc = recurrence(0, &local.forward_reruns, &local.forward_passes)) != PCSF_OK) return rc;
     if ((rc = recurrence(2, &local.backward_reruns, &local.backward_passes)) != PCSF_OK) return rc;
-    HMM_TRY(hipMemcpyAsync(out_posterior, B.post.ptr, n * sizeof(double), hipMemcpyDeviceToHost, st), "hipMemcpyAsync(hmm posterior)");
+    if (out_posterior) HMM_TRY(hipMemcpyAsync(out_posterior, B.post.ptr, n * sizeof(double), hipMemcpyDeviceToHost, st), "hipMemcpyAsync(hmm posterior)");
+    unsigned int n_exc = 0;
+    if (bins) {
+        pcsf::DeviceBuffer d_thr, d_bins, d_exc_i, d_exc_v, d_count;
+        HMM_TRY(d_thr.reserve(std::max<size_t>(bins->n_thresholds, 1) * sizeof(double)), "hipMalloc(hmm thresholds)");
+        HMM_TRY(d_bins.reserve(n * sizeof(uint16_t)), "hipMalloc(hmm bins)");
+        HMM_TRY(d_exc_i.reserve(std::max<size_t>(bins->exc_capacity, 1) * sizeof(uint64_t)), "hipMalloc(hmm exceptions)");
+        HMM_TRY(d_exc_v.reserve(std::max<size_t>(bins->exc_capacity, 1) * sizeof(double)), "hipMalloc(hmm exceptions)");
+        HMM_TRY(d_count.reserve(sizeof(unsigned int)), "hipMalloc(hmm exceptions)");
+        HMM_TRY(hipMemcpyAsync(d_thr.ptr, bins->thresholds, bins->n_thresholds * sizeof(double), hipMemcpyHostToDevice, st), "hipMemcpyAsync(hmm thresholds)");
+        HMM_TRY(hipMemsetAsync(d_count.ptr, 0, sizeof(unsigned int), st), "hipMemsetAsync(hmm exceptions)");
+        HMM_TRY(pcsf::launch_hmm_bins(B.post.as<double>(), n, d_thr.as<double>(), static_cast<uint32_t>(bins->n_thresholds), d_bins.as<uint16_t>(), d_exc_i.as<uint64_t>(),
+                                      d_exc_v.as<double>(), static_cast<uint32_t>(std::min<size_t>(bins->exc_capacity, 0xffffffffu)), d_count.as<unsigned int>(), st),
+                "hmm_bin_kernel");
+        HMM_TRY(hipMemcpyAsync(bins->out_bins, d_bins.ptr, n * sizeof(uint16_t), hipMemcpyDeviceToHost, st), "hipMemcpyAsync(hmm bins)");
+        HMM_TRY(hipMemcpyAsync(&n_exc, d_count.ptr, sizeof n_exc, hipMemcpyDeviceToHost, st), "hipMemcpyAsync(hmm exceptions)");
+        HMM_TRY(hipStreamSynchronize(st), "hipStreamSynchronize(hmm)");
+        const size_t got = std::min<size_t>(n_exc, bins->exc_capacity);
+        if (got) {
+            HMM_TRY(hipMemcpy(bins->exc_index, d_exc_i.ptr, got * sizeof(uint64_t), hipMemcpyDeviceToHost), "hipMemcpy(hmm exceptions)");
+            HMM_TRY(hipMemcpy(bins->exc_value, d_exc_v.ptr, got * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy(hmm exceptions)");
+        }
+        *bins->n_exc = n_exc;
+    }
     HMM_TRY(hipStreamSynchronize(st), "hipStreamSynchronize(hmm)");
 #undef HMM_TRY
     if (stats) *stats = local;
     return PCSF_OK;
+}
+
+extern "C" int pcsf_hmm_smooth_runs(pcsf_ctx* c, const double* init, const double* trans, const double* emissions, const uint64_t* run_offsets, size_t n_runs,
+                                    double* out_posterior, uint8_t* out_back, double* out_last, pcsf_hmm_stats* stats)
+{
+    if (c && !out_posterior) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_hmm_smooth_runs: null argument");
+    return smooth_runs(c, init, trans, emissions, run_offsets, n_runs, out_posterior, nullptr, out_back, out_last, stats);
+}
+
+extern "C" int pcsf_hmm_smooth_runs_binned(pcsf_ctx* c, const double* init, const double* trans, const double* emissions, const uint64_t* run_offsets, size_t n_runs,
+                                           const double* thresholds, size_t n_thresholds, uint16_t* out_bins, uint64_t* exc_index, double* exc_value,
+                                           size_t exc_capacity, size_t* n_exceptions, uint8_t* out_back, double* out_last, pcsf_hmm_stats* stats)
+{
+    BinRequest b;
+    b.thresholds = thresholds;
+    b.n_thresholds = n_thresholds;
+    b.out_bins = out_bins;
+    b.exc_index = exc_index;
+    b.exc_value = exc_value;
+    b.exc_capacity = exc_capacity;
+    b.n_exc = n_exceptions;
+    return smooth_runs(c, init, trans, emissions, run_offsets, n_runs, nullptr, &b, out_back, out_last, stats);
 }

@@ -172,6 +172,9 @@ struct HmmChunk {   // positions [begin, end) of the run [run_begin, run_end); c
 // instead of burning in.  d_entry / d_exit [n_chunks][4]: the state a chunk started from / ended with.
 hipError_t launch_hmm_chunks(int mode, const HmmModel& h, const HmmChunk* d_chunks, const uint32_t* d_todo, uint32_t n_todo, bool rerun, uint32_t burn_in,
                              const double* d_emit, double* d_fwd, uint8_t* d_back, double* d_post, double* d_entry, double* d_exit, hipStream_t stream);
+// d_bins[i] = number of thresholds <= d_post[i] (ascending, fewer than 65,535); NaN: 0xffff and an entry in the exception list
+hipError_t launch_hmm_bins(const double* d_post, uint64_t n, const double* d_thresholds, uint32_t n_thresholds, uint16_t* d_bins, uint64_t* d_exc_index,
+                           double* d_exc_value, uint32_t exc_capacity, unsigned int* d_n_exc, hipStream_t stream);
 // d_same[c] = chunk c's entry state equals, bit for bit, the exit state of the chunk it depends on (c - 1; backward: c + 1)
 hipError_t launch_hmm_compare(const HmmChunk* d_chunks, uint32_t n_chunks, bool backward, const double* d_entry, const double* d_exit, uint8_t* d_same,
                               hipStream_t stream);

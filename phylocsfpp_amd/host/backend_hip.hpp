@@ -56,6 +56,18 @@ public:
             fprintf(stderr, "hmm_smooth_runs: %zu runs, %" PRIu64 " values in %u chunks; evaluated again: forward %u (%u passes), backward %u (%u), viterbi %u (%u)\n", n_runs,
                     run_offsets[n_runs], st.chunks, st.forward_reruns, st.forward_passes, st.backward_reruns, st.backward_passes, st.viterbi_reruns, st.viterbi_passes);
     }
+    size_t hmm_smooth_runs_binned(const Hmm& h, const double* emissions, const uint64_t* run_offsets, size_t n_runs, const double* thresholds, size_t n_thresholds,
+                                  uint16_t* bins, uint64_t* exc_index, double* exc_value, size_t exc_capacity, uint8_t* back, double* last) override
+    {
+        pcsf_hmm_stats st{};
+        size_t n_exc = 0;
+        check(pcsf_hmm_smooth_runs_binned(ctx_, h.init, &h.trans[0][0], emissions, run_offsets, n_runs, thresholds, n_thresholds, bins, exc_index, exc_value, exc_capacity,
+                                          &n_exc, back, last, &st));
+        if (std::getenv("PCSF_HMM_STATS"))
+            fprintf(stderr, "hmm_smooth_runs: %zu runs, %" PRIu64 " values in %u chunks; evaluated again: forward %u (%u passes), backward %u (%u), viterbi %u (%u); %zu without a posterior\n",
+                    n_runs, run_offsets[n_runs], st.chunks, st.forward_reruns, st.forward_passes, st.backward_reruns, st.backward_passes, st.viterbi_reruns, st.viterbi_passes, n_exc);
+        return n_exc;
+    }
 
     size_t score_alignments_6frames(int, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0, const std::vector<uint32_t>& len,
                                     const std::vector<uint64_t>& start_pos, const std::vector<uint64_t>& chrom_len, double* out, size_t out_capacity,

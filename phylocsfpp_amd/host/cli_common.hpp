@@ -83,6 +83,42 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
         printf("20000 character rows classified, %zu mismatches between the vector and the scalar path\n", bad_rows);
         return (bad || bad_rows) ? 1 : 0;
     }
+    if (cmd == "selftest-printed-codes") {  // tests: the smoothing pass's printed-value bins -- thresholds by bisection vs the printing code itself
+        const size_t n = argc > 2 ? static_cast<size_t>(atoll(argv[2])) : 1000000;
+        const std::vector<double> thr = printed_code_thresholds(effective_threads());
+        size_t bad = 0, checked = 0;
+        bool ascending = true;
+        for (size_t j = 1; j < thr.size(); ++j) ascending = ascending && thr[j - 1] <= thr[j];
+        auto check = [&](double p) {
+            if (p != p) return;
+            const int bin = static_cast<int>(std::upper_bound(thr.begin(), thr.end(), p) - thr.begin());   // thresholds <= p
+            char want[80], got[80];
+            format_trimmed<3>(want, static_cast<float>(hmm_log_odds(p)));
+            const int code = PRINTED_CODE_MIN + bin;
+            format_scaled<3>(got, code < 0, static_cast<uint64_t>(code < 0 ? -1 - code : code));
+            ++checked;
+            if ((bin != printed_code(p) - PRINTED_CODE_MIN || strcmp(want, got) != 0) && bad++ < 10)
+                fprintf(stderr, "mismatch p = %.17g: bin %d, code %d, text %s vs %s\n", p, bin, printed_code(p), want, got);
+        };
+        for (double t : thr) {   // both sides of every step
+            if (!(t <= 1.0)) continue;
+            check(t);
+            check(std::nextafter(t, -1.0));
+            check(std::nextafter(t, 2.0));
+        }
+        const double edge[] = {0.0, -0.0, 1.0, 0.5, std::nextafter(0.5, 0.0), std::nextafter(0.5, 1.0), 1e-15, 9.99e-16, 1.0 - 1e-15, 1e-300, 5e-324, -1e-3, 1.0000001, 2.0};
+        for (double p : edge) check(p);
+        uint64_t state = 0x9e3779b97f4a7c15ull;
+        for (size_t i = 0; i < n; ++i) {
+            state ^= state << 13; state ^= state >> 7; state ^= state << 17;
+            const double u = static_cast<double>(state >> 11) / 9007199254740992.0;
+            if (i % 3 == 0) check(u);                                       // anywhere
+            else if (i % 3 == 1) check(std::pow(10.0, -17.0 * u));          // towards 0
+            else check(1.0 - std::pow(10.0, -17.0 * u));                    // towards 1
+        }
+        printf("%zu thresholds (ascending: %s), %zu posteriors checked, %zu mismatches\n", thr.size(), ascending ? "yes" : "NO", checked, bad);
+        return (bad || !ascending) ? 1 : 0;
+    }
     if (cmd == "dump-alignments") {  // diagnostics/tests: what the MAF reader yields (build-tracks semantics unless --blocks 1)
         bool blocks = false;
         size_t jobs = 1;

@@ -22,6 +22,7 @@
 #include <exception>
 #include <functional>
 #include <future>
+#include <limits>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -81,6 +82,14 @@ struct ScoringBackend {
                                  uint8_t* /*back*/, double* /*last*/)
     {
         throw std::runtime_error("hmm_smooth_runs: this backend does not smooth tracks");
+    }
+    // ... with, instead of the posterior, bins[n] = how many of the ascending thresholds are <= it (NaN: listed in exc_index / exc_value,
+    // returns how many there were)
+    virtual size_t hmm_smooth_runs_binned(const Hmm& /*h*/, const double* /*emissions*/, const uint64_t* /*run_offsets*/, size_t /*n_runs*/, const double* /*thresholds*/,
+                                          size_t /*n_thresholds*/, uint16_t* /*bins*/, uint64_t* /*exc_index*/, double* /*exc_value*/, size_t /*exc_capacity*/,
+                                          uint8_t* /*back*/, double* /*last*/)
+    {
+        throw std::runtime_error("hmm_smooth_runs_binned: this backend does not smooth tracks");
     }
     virtual size_t score_alignments_6frames(int n_leaves, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0,
                                             const std::vector<uint32_t>& len, const std::vector<uint64_t>& start_pos,
@@ -154,6 +163,11 @@ public:
     void hmm_smooth_runs(const Hmm& h, const double* emissions, const uint64_t* run_offsets, size_t n_runs, double* posterior, uint8_t* back, double* last) override
     {
         get().hmm_smooth_runs(h, emissions, run_offsets, n_runs, posterior, back, last);
+    }
+    size_t hmm_smooth_runs_binned(const Hmm& h, const double* emissions, const uint64_t* run_offsets, size_t n_runs, const double* thresholds, size_t n_thresholds,
+                                  uint16_t* bins, uint64_t* exc_index, double* exc_value, size_t exc_capacity, uint8_t* back, double* last) override
+    {
+        return get().hmm_smooth_runs_binned(h, emissions, run_offsets, n_runs, thresholds, n_thresholds, bins, exc_index, exc_value, exc_capacity, back, last);
     }
     size_t score_alignments_6frames(int n_leaves, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0, const std::vector<uint32_t>& len,
                                     const std::vector<uint64_t>& start_pos, const std::vector<uint64_t>& chrom_len, double* out, size_t out_capacity,
@@ -406,6 +420,45 @@ inline void smooth_tracks(const std::string& out_dir, const Hmm& hmm, bool write
     });
 }
 
+// What the smoothed track prints for a coding posterior p is a monotone step function of p: log-odds (hmm_log_odds), narrowed to
+// float, rounded to three decimals (format_trimmed<3>), with "-0.0" and "0.0" apart.  printed_code numbers the steps: value x 1000
+// for values >= +0, -1 - |value| x 1000 for negative ones ("-0.0" = -1, "-15.0" = -15001) -- increasing with p.
+inline int printed_code(double p)
+{
+    const double x = static_cast<double>(static_cast<float>(hmm_log_odds(p)));
+#if defined(__x86_64__)
+    const long long scaled = _mm_cvtsd_si64(_mm_set_sd(std::fabs(x) * 1000.0));   // as format_trimmed rounds
+#else
+    const long long scaled = static_cast<long long>(std::nearbyint(std::fabs(x) * 1000.0));
+#endif
+    return std::signbit(x) ? -1 - static_cast<int>(scaled) : static_cast<int>(scaled);
+}
+constexpr int PRINTED_CODE_MIN = -15001, PRINTED_CODE_MAX = 15000;
+// thresholds[j], j = 0 .. MAX - MIN - 1: the smallest double p in [0, 1] with printed_code(p) >= MIN + 1 + j, by bisection over the
+// doubles with this host's own libm (so the steps are where THIS host's log10 puts them); +infinity where no p reaches the code.
+// The number of thresholds <= p is then printed_code(p) - MIN for every p that is not NaN.
+inline std::vector<double> printed_code_thresholds(int threads)
+{
+    const size_t n = static_cast<size_t>(PRINTED_CODE_MAX - PRINTED_CODE_MIN);
+    std::vector<double> thr(n);
+    parallel_for(n, threads, [&](size_t j) {
+        const int want = PRINTED_CODE_MIN + 1 + static_cast<int>(j);
+        auto as_double = [](uint64_t b) { double d; memcpy(&d, &b, 8); return d; };
+        uint64_t lo = 0, hi;   // bit patterns of non-negative doubles order like the doubles
+        const double one = 1.0;
+        memcpy(&hi, &one, 8);
+        if (printed_code(0.0) >= want) { thr[j] = 0.0; return; }
+        if (printed_code(1.0) < want) { thr[j] = std::numeric_limits<double>::infinity(); return; }
+        while (hi - lo > 1) {   // code(lo) < want <= code(hi)
+            const uint64_t mid = lo + (hi - lo) / 2;
+            if (printed_code(as_double(mid)) >= want) hi = mid;
+            else lo = mid;
+        }
+        thr[j] = as_double(hi);
+    });
+    return thr;
+}
+
 // The same pass with the recurrences on the device (backend.hmm_smooth_runs).  Tracks are taken in groups of up to ~64 M values (all six
 // of a 10 Mb chromosome, one at a time for a large one): (1) the text of the group's raw tracks is parsed on all host threads into runs
 // merged like the reference's wig reader (for_each_wig_run); (2) the coding emissions pow(10, score / 10) come from the host's libm --
@@ -419,6 +472,7 @@ inline void smooth_tracks_device(const std::string& out_dir, const Hmm& hmm, boo
     constexpr int TABLE_HALF = 200000;   // scores in [-200, 200] decibans by look-up
     constexpr size_t GROUP_VALUES = size_t(64) << 20;
     const bool verbose = std::getenv("PCSF_HMM_STATS") != nullptr;
+    const std::vector<double> thresholds = printed_code_thresholds(threads);
     std::vector<double> table(2 * TABLE_HALF + 1);
     parallel_for(64, threads, [&](size_t part) {
         for (int k = static_cast<int>(part) - TABLE_HALF; k <= TABLE_HALF; k += 64) table[k + TABLE_HALF] = hmm_emit(0, static_cast<double>(k) / 1000.0);
@@ -554,7 +608,8 @@ inline void smooth_tracks_device(const std::string& out_dir, const Hmm& hmm, boo
         double t_emit = 0, t_dev = 0, t_text = 0, t_regions = 0;
         if (n_runs > 0) {
             // (2) emissions (the arrays are not value-initialised: 17 bytes per value that are written before they are read)
-            std::unique_ptr<double[]> emit(new double[n]), post(new double[n]), last(write_regions ? new double[n_runs * 4] : nullptr);
+            std::unique_ptr<double[]> emit(new double[n]), last(write_regions ? new double[n_runs * 4] : nullptr);
+            std::unique_ptr<uint16_t[]> bins(new uint16_t[n]);
             std::unique_ptr<uint8_t[]> back(write_regions ? new uint8_t[n] : nullptr);
             parallel_for(piece_jobs.size(), threads, [&](size_t j) {
                 Piece& pc = group[piece_jobs[j].first]->pieces[piece_jobs[j].second];
@@ -570,7 +625,11 @@ inline void smooth_tracks_device(const std::string& out_dir, const Hmm& hmm, boo
             });
             t_emit = phase.lap();
             // (3) the recurrences
-            backend.hmm_smooth_runs(hmm, emit.get(), run_offsets.data(), n_runs, post.get(), back.get(), last.get());
+            std::vector<uint64_t> exc_index(4096);
+            std::vector<double> exc_value(4096);
+            const size_t n_exc = backend.hmm_smooth_runs_binned(hmm, emit.get(), run_offsets.data(), n_runs, thresholds.data(), thresholds.size(), bins.get(),
+                                                                exc_index.data(), exc_value.data(), exc_index.size(), back.get(), last.get());
+            if (n_exc > exc_index.size()) throw std::runtime_error("smoothing: " + std::to_string(n_exc) + " positions without a posterior (the HMM parameters give no state a probability)");
             emit.reset();
             t_dev = phase.lap();
             // (4) text: pieces of runs on all threads, every file's pieces appended in order
@@ -590,7 +649,19 @@ inline void smooth_tracks_device(const std::string& out_dir, const Hmm& hmm, boo
                         TextPiece& o = out[j];
                         o.start((jb.b - jb.a) * 9 + 256);
                         if (jb.a == run_offsets[jb.run]) o.header(run.chrom, static_cast<int64_t>(run.start));
-                        for (size_t i = jb.a; i < jb.b; ++i) o.value<3>(static_cast<float>(hmm_log_odds(post[i])));
+                        for (size_t i = jb.a; i < jb.b; ++i) {
+                            const uint16_t bin = bins[i];
+                            if (bin == 0xffffu) {   // no posterior (0 / 0): whatever the host pass makes of this host's NaN
+                                volatile double zero = 0.0;
+                                o.value<3>(static_cast<float>(hmm_log_odds(zero / zero)));
+                                continue;
+                            }
+                            const int code = PRINTED_CODE_MIN + static_cast<int>(bin);
+                            char* p = o.room(72);
+                            const size_t len = format_scaled<3>(p, code < 0, static_cast<uint64_t>(code < 0 ? -1 - code : code));
+                            p[len] = '\n';
+                            o.len += len + 1;
+                        }
                     });
                     parallel_for(group.size(), threads, [&](size_t g) {
                         FILE* f_wig = group[g]->wig_file.get();
@@ -613,7 +684,7 @@ inline void smooth_tracks_device(const std::string& out_dir, const Hmm& hmm, boo
                     if (!(prev[best] > 0.0)) best = 0;
                     path[len - 1] = best;
                     for (size_t pos = len - 1; pos-- > 0;) path[pos] = (back[b + pos + 1] >> (2 * path[pos + 1])) & 3u;
-                    const std::vector<double> run_post(post.get() + b, post.get() + b + len);
+                    const std::vector<double> run_post(len, 0.0);   // a region's `prob` is computed by the reference and never printed
                     hmm_regions(path, run_post, static_cast<uint32_t>(group[run_owner[r].first]->runs[run_owner[r].second].start), regions[r]);
                 });
                 parallel_for(group.size(), threads, [&](size_t g) {

@@ -357,6 +357,39 @@ struct Digits3Table {
 inline const Digits3Table DIGITS3;
 static_assert(__BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__, "format_trimmed shifts digit bytes inside a word");
 
+// the text of sign and |value| * 10^D = scaled (< 1000 * 10^D) with trailing zeros removed but one decimal kept: format_trimmed's
+// branch-free path, also used where the scaled integer is what a caller holds (the smoothing pass's printed-value bins)
+template <int D>
+inline size_t format_scaled(char* dst, bool negative, uint64_t scaled)
+{
+    constexpr uint64_t POW = D == 3 ? 1000 : 10000;
+    {
+        const unsigned ip = static_cast<unsigned>(scaled / POW), frac = static_cast<unsigned>(scaled % POW);
+        char* p = dst;
+        *p = '-';
+        p += negative ? 1 : 0;
+        const unsigned nd = 1u + (ip >= 10u) + (ip >= 100u);
+        uint32_t w;
+        memcpy(&w, &DIGITS3.e[ip], 4);                                    // digits in bytes 0..2 (x86 is little-endian: byte 0 is written first)
+        w = ((w & 0x00ffffffu) | (uint32_t('.') << 24)) >> (8 * (3 - nd));   // the last nd digits, then the point
+        memcpy(p, &w, 4);                                                 // (up to three bytes beyond them are rewritten below)
+        p += nd + 1;
+        if (D == 3) {
+            const Digits3& F = DIGITS3.e[frac];
+            memcpy(p, &F, 4);
+            p += F.trimmed;
+        } else {
+            const Digits3& F = DIGITS3.e[frac / 10];
+            const unsigned last = frac % 10;
+            memcpy(p, &F, 4);
+            p[3] = static_cast<char>('0' + last);
+            p += last ? 4u : F.trimmed;
+        }
+        *p = 0;
+        return static_cast<size_t>(p - dst);
+    }
+}
+
 template <int D>
 inline size_t format_trimmed(char* dst, float v)
 {
@@ -386,31 +419,7 @@ inline size_t format_trimmed(char* dst, float v)
 #else
     const uint64_t scaled = static_cast<uint64_t>(std::nearbyint(std::fabs(x) * static_cast<double>(POW)));
 #endif
-    if (scaled < 1000 * POW) {
-        const unsigned ip = static_cast<unsigned>(scaled / POW), frac = static_cast<unsigned>(scaled % POW);
-        char* p = dst;
-        *p = '-';
-        p += std::signbit(x) ? 1 : 0;
-        const unsigned nd = 1u + (ip >= 10u) + (ip >= 100u);
-        uint32_t w;
-        memcpy(&w, &DIGITS3.e[ip], 4);                                    // digits in bytes 0..2 (x86 is little-endian: byte 0 is written first)
-        w = ((w & 0x00ffffffu) | (uint32_t('.') << 24)) >> (8 * (3 - nd));   // the last nd digits, then the point
-        memcpy(p, &w, 4);                                                 // (up to three bytes beyond them are rewritten below)
-        p += nd + 1;
-        if (D == 3) {
-            const Digits3& F = DIGITS3.e[frac];
-            memcpy(p, &F, 4);
-            p += F.trimmed;
-        } else {
-            const Digits3& F = DIGITS3.e[frac / 10];
-            const unsigned last = frac % 10;
-            memcpy(p, &F, 4);
-            p[3] = static_cast<char>('0' + last);
-            p += last ? 4u : F.trimmed;
-        }
-        *p = 0;
-        return static_cast<size_t>(p - dst);
-    }
+    if (scaled < 1000 * POW) return format_scaled<D>(dst, std::signbit(x), scaled);
     uint64_t ip = scaled / POW;
     unsigned frac = static_cast<unsigned>(scaled % POW);
     char* p = dst;

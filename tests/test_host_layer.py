@@ -237,6 +237,14 @@ def test_fast_number_formatting_matches_printf(cli):
     assert lines[0].endswith("0 mismatches") and " 0 mismatches" in lines[1], out   # numbers; AVX2 vs scalar character classes
 
 
+def test_printed_value_bins_of_the_smoothing_pass_equal_the_printing_code(cli):
+    """The device smoothing pass returns, per position, the step of the printed log-odds its posterior falls on (thresholds found by
+    bisection with this host's libm): the text from the step must be the text from the posterior, on both sides of all 30,001 steps
+    and on random posteriors."""
+    out = subprocess.check_output([cli, "selftest-printed-codes", "1500000"], text=True)
+    assert "ascending: yes" in out and out.strip().endswith(" 0 mismatches"), out
+
+
 def test_several_backends_small_batches_and_windows_do_not_change_the_output(cli, tmp_path):
     """build-tracks with three scoring backends (--devices; one per GPU in production), batches of ~2,000 columns and
     100 kB windows -- dozens of batches retired in order behind concurrent backends -- against the one-batch run; and
