@@ -46,11 +46,14 @@ static int smooth_runs(pcsf_ctx* c, const double* init, const double* trans, con
     if (!emissions) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_hmm_smooth_runs: null argument");
     for (size_t r = 0; r < n_runs; ++r)
         if (run_offsets[r + 1] <= run_offsets[r]) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_hmm_smooth_runs: empty run or offsets not increasing");
-    // Chunk length and burn-in.  How fast the filter forgets is set by the model, not by the scores: the three non-coding classes emit
-    // the same, so what tells them apart decays with the ratio of their self-transitions -- e-folding in ~600 positions for the
-    // reference's parameters (class lengths 570 and 21,970 codons), ~22,000 positions until two trajectories agree to the last bit
-    // (a burn-in of 1,024 left every chunk but a run's first two to be evaluated again).  Runs shorter than a chunk -- the rule in real
-    // tracks -- are one thread each and exact by construction.  PCSF_HMM_CHUNK / PCSF_HMM_BURN_IN for experiments and tests.
+    // Chunk length and burn-in.  How fast the filter forgets is set by the model more than by the scores: the three non-coding classes
+    // emit the same, a class is only left towards coding, and the reference's parameters give them mean lengths of 105, 570 and
+    // 21,970 codons -- what tells two trajectories apart survives until a stretch of high scores pushes both through the coding state.
+    // Measured (tools/hmm_long_run.py, one run of 5 M random scores): with 32,768 / 32,768 half of the 152 later chunks arrive at
+    // their neighbour's state and half are evaluated again (1.7 s against 5.3 s for the run as one chunk); with 4,096 / 4,096 nearly
+    // all are.  Runs shorter than a chunk -- the rule: the reader's break points end a run every 333 k codons at the latest, gaps in
+    // the alignment much sooner -- are one thread each and exact by construction; the command line keeps runs of a million values and
+    // more on host threads (drivers.hpp).  PCSF_HMM_CHUNK / PCSF_HMM_BURN_IN for experiments and tests.
     uint64_t chunk_len = 32768, burn_in = 32768;
     if (const char* v = std::getenv("PCSF_HMM_CHUNK")) chunk_len = std::max<uint64_t>(1, std::strtoull(v, nullptr, 10));
     if (const char* v = std::getenv("PCSF_HMM_BURN_IN")) burn_in = std::max<uint64_t>(1, std::strtoull(v, nullptr, 10));

@@ -625,10 +625,59 @@ inline void smooth_tracks_device(const std::string& out_dir, const Hmm& hmm, boo
             });
             t_emit = phase.lap();
             // (3) the recurrences
+            // Runs of a million values and more (a contiguous chromosome without the reader's break points) stay on the host, one thread
+            // each, beside the device call: a recurrence is sequential along a run, a device thread takes ~10x a host core's time per step,
+            // and for this model the device's chunks of such a run seldom meet their neighbours' states (the classes' memory is tens of
+            // thousands of positions long) -- hmm_abi.cpp would evaluate them again one after the other.
+            size_t host_run_min = size_t(1) << 20;
+            if (const char* v = std::getenv("PCSF_HMM_HOST_RUN")) host_run_min = std::max<size_t>(1, strtoull(v, nullptr, 10));
+            std::vector<size_t> host_runs, dev_runs;
+            for (size_t r = 0; r < n_runs; ++r) (run_offsets[r + 1] - run_offsets[r] >= host_run_min ? host_runs : dev_runs).push_back(r);
+            std::vector<std::vector<uint32_t>> host_path(n_runs);   // Viterbi paths of the runs done on the host
             std::vector<uint64_t> exc_index(4096);
             std::vector<double> exc_value(4096);
-            const size_t n_exc = backend.hmm_smooth_runs_binned(hmm, emit.get(), run_offsets.data(), n_runs, thresholds.data(), thresholds.size(), bins.get(),
-                                                                exc_index.data(), exc_value.data(), exc_index.size(), back.get(), last.get());
+            size_t n_exc = 0;
+            if (host_runs.empty()) {
+                n_exc = backend.hmm_smooth_runs_binned(hmm, emit.get(), run_offsets.data(), n_runs, thresholds.data(), thresholds.size(), bins.get(), exc_index.data(),
+                                                       exc_value.data(), exc_index.size(), back.get(), last.get());
+            } else {
+                std::vector<uint64_t> d_off{0};
+                for (size_t r : dev_runs) d_off.push_back(d_off.back() + (run_offsets[r + 1] - run_offsets[r]));
+                const size_t nd = d_off.back();
+                std::unique_ptr<double[]> d_emit(new double[std::max<size_t>(nd, 1)]), d_last(write_regions ? new double[std::max<size_t>(dev_runs.size(), 1) * 4] : nullptr);
+                std::unique_ptr<uint16_t[]> d_bins(new uint16_t[std::max<size_t>(nd, 1)]);
+                std::unique_ptr<uint8_t[]> d_back(write_regions ? new uint8_t[std::max<size_t>(nd, 1)] : nullptr);
+                parallel_for(dev_runs.size(), threads, [&](size_t k) {
+                    const size_t r = dev_runs[k];
+                    memcpy(d_emit.get() + d_off[k], emit.get() + run_offsets[r], (run_offsets[r + 1] - run_offsets[r]) * sizeof(double));
+                });
+                auto device_part = std::async(std::launch::async, [&]() -> size_t {
+                    if (dev_runs.empty()) return 0;
+                    return backend.hmm_smooth_runs_binned(hmm, d_emit.get(), d_off.data(), dev_runs.size(), thresholds.data(), thresholds.size(), d_bins.get(), exc_index.data(),
+                                                          exc_value.data(), exc_index.size(), d_back.get(), d_last.get());
+                });
+                try {
+                    parallel_for(host_runs.size(), threads, [&](size_t k) {
+                        const size_t r = host_runs[k], b = run_offsets[r], len = run_offsets[r + 1] - b;
+                        std::vector<double> run_post(len), work;
+                        hmm_coding_posterior_emissions(hmm, emit.get() + b, len, run_post.data(), work);
+                        for (size_t i = 0; i < len; ++i) bins[b + i] = run_post[i] != run_post[i] ? uint16_t(0xffffu) : static_cast<uint16_t>(printed_code(run_post[i]) - PRINTED_CODE_MIN);
+                        if (write_regions) host_path[r] = hmm_viterbi_emissions(hmm, emit.get() + b, len);
+                    });
+                } catch (...) {
+                    device_part.wait();   // it works on this frame's arrays
+                    throw;
+                }
+                n_exc = device_part.get();
+                parallel_for(dev_runs.size(), threads, [&](size_t k) {
+                    const size_t r = dev_runs[k], b = run_offsets[r], len = run_offsets[r + 1] - b;
+                    memcpy(bins.get() + b, d_bins.get() + d_off[k], len * sizeof(uint16_t));
+                    if (write_regions) {
+                        memcpy(back.get() + b, d_back.get() + d_off[k], len);
+                        memcpy(last.get() + 4 * r, d_last.get() + 4 * k, 4 * sizeof(double));
+                    }
+                });
+            }
             if (n_exc > exc_index.size()) throw std::runtime_error("smoothing: " + std::to_string(n_exc) + " positions without a posterior (the HMM parameters give no state a probability)");
             emit.reset();
             t_dev = phase.lap();
@@ -676,14 +725,19 @@ inline void smooth_tracks_device(const std::string& out_dir, const Hmm& hmm, boo
                 std::vector<std::vector<BedRegion>> regions(n_runs);
                 parallel_for(n_runs, threads, [&](size_t r) {
                     const size_t b = run_offsets[r], len = run_offsets[r + 1] - b;
-                    std::vector<uint32_t> path(len, 0);
-                    const double* prev = last.get() + 4 * r;
-                    uint32_t best = 0;  // hmm_viterbi's rule: the first maximum; all zero: state 0
-                    for (uint32_t i = 1; i < 4; ++i)
-                        if (prev[i] > prev[best]) best = i;
-                    if (!(prev[best] > 0.0)) best = 0;
-                    path[len - 1] = best;
-                    for (size_t pos = len - 1; pos-- > 0;) path[pos] = (back[b + pos + 1] >> (2 * path[pos + 1])) & 3u;
+                    std::vector<uint32_t> path;
+                    if (!host_path[r].empty()) {
+                        path.swap(host_path[r]);
+                    } else {
+                        path.assign(len, 0);
+                        const double* prev = last.get() + 4 * r;
+                        uint32_t best = 0;  // hmm_viterbi's rule: the first maximum; all zero: state 0
+                        for (uint32_t i = 1; i < 4; ++i)
+                            if (prev[i] > prev[best]) best = i;
+                        if (!(prev[best] > 0.0)) best = 0;
+                        path[len - 1] = best;
+                        for (size_t pos = len - 1; pos-- > 0;) path[pos] = (back[b + pos + 1] >> (2 * path[pos + 1])) & 3u;
+                    }
                     const std::vector<double> run_post(len, 0.0);   // a region's `prob` is computed by the reference and never printed
                     hmm_regions(path, run_post, static_cast<uint32_t>(group[run_owner[r].first]->runs[run_owner[r].second].start), regions[r]);
                 });

@@ -65,18 +65,17 @@ inline Hmm make_coding_hmm(const HmmParams& p)
 
 inline double hmm_emit(int state, double score) { return state == 0 ? std::pow(10.0, score / 10.0) : 1.0; }
 
-// posterior probability of the coding state at every position (scaled forward-backward)
-inline void hmm_coding_posterior(const Hmm& h, const std::vector<double>& obs, std::vector<double>& post, std::vector<double>& work)
+// posterior probability of the coding state at every position (scaled forward-backward); e0[pos] = the coding state's emission
+// hmm_emit(0, obs[pos]) (the other states emit 1)
+inline void hmm_coding_posterior_emissions(const Hmm& h, const double* e0s, size_t n, double* post, std::vector<double>& work)
 {
-    const size_t n = obs.size();
-    post.resize(n);
     if (n == 0) return;
     work.resize(n * 8);
     double* fwd = work.data();
     double* bwd = work.data() + n * 4;
-    for (int s = 0; s < 4; ++s) fwd[s] = h.init[s] * hmm_emit(s, obs[0]);
+    for (int s = 0; s < 4; ++s) fwd[s] = h.init[s] * (s == 0 ? e0s[0] : 1.0);
     for (size_t pos = 1; pos < n; ++pos) {
-        const double e0 = hmm_emit(0, obs[pos]);
+        const double e0 = e0s[pos];
         double maxf = 0.0;
         for (int s = 0; s < 4; ++s) {
             double sum = 0.0;
@@ -89,7 +88,7 @@ inline void hmm_coding_posterior(const Hmm& h, const std::vector<double>& obs, s
     }
     for (int s = 0; s < 4; ++s) bwd[(n - 1) * 4 + s] = 1.0;
     for (size_t pos = n - 1; pos-- > 0;) {
-        const double e0 = hmm_emit(0, obs[pos + 1]);
+        const double e0 = e0s[pos + 1];
         double maxb = 0.0;
         for (int s = 0; s < 4; ++s) {
             double sum = 0.0;
@@ -106,6 +105,15 @@ inline void hmm_coding_posterior(const Hmm& h, const std::vector<double>& obs, s
     }
 }
 
+inline void hmm_coding_posterior(const Hmm& h, const std::vector<double>& obs, std::vector<double>& post, std::vector<double>& work)
+{
+    const size_t n = obs.size();
+    post.resize(n);
+    std::vector<double> e0s(n);
+    for (size_t pos = 0; pos < n; ++pos) e0s[pos] = hmm_emit(0, obs[pos]);
+    hmm_coding_posterior_emissions(h, e0s.data(), n, post.data(), work);
+}
+
 inline double hmm_log_odds(double prob)
 {
     const double MAX_LOG_ODDS = 15.0;
@@ -114,15 +122,14 @@ inline double hmm_log_odds(double prob)
     return std::log10(prob / (1 - prob));
 }
 
-// most probable state path (Viterbi with per-position rescaling; ties keep the lowest previous state)
-inline std::vector<uint32_t> hmm_viterbi(const Hmm& h, const std::vector<double>& obs)
+// most probable state path (Viterbi with per-position rescaling; ties keep the lowest previous state); e0s as above
+inline std::vector<uint32_t> hmm_viterbi_emissions(const Hmm& h, const double* e0s, size_t n)
 {
-    const size_t n = obs.size();
     std::vector<uint32_t> path(n, 0);
     if (n == 0) return path;
     std::vector<uint8_t> back((n - 1) * 4);
     double prev[4];
-    for (int s = 0; s < 4; ++s) prev[s] = h.init[s] * hmm_emit(s, obs[0]);
+    for (int s = 0; s < 4; ++s) prev[s] = h.init[s] * (s == 0 ? e0s[0] : 1.0);
     for (size_t pos = 1; pos < n; ++pos) {
         double cur[4], max_prob = 0.0;
         for (int s = 0; s < 4; ++s) {
@@ -135,7 +142,7 @@ inline std::vector<uint32_t> hmm_viterbi(const Hmm& h, const std::vector<double>
                     best = v;
                 }
             }
-            best *= hmm_emit(s, obs[pos]);
+            best *= (s == 0 ? e0s[pos] : 1.0);
             back[(pos - 1) * 4 + s] = arg;
             cur[s] = best;
             max_prob = std::max(max_prob, best);
@@ -151,6 +158,13 @@ inline std::vector<uint32_t> hmm_viterbi(const Hmm& h, const std::vector<double>
     path[n - 1] = best;
     for (size_t pos = n - 1; pos-- > 0;) path[pos] = back[pos * 4 + path[pos + 1]];
     return path;
+}
+
+inline std::vector<uint32_t> hmm_viterbi(const Hmm& h, const std::vector<double>& obs)
+{
+    std::vector<double> e0s(obs.size());
+    for (size_t pos = 0; pos < obs.size(); ++pos) e0s[pos] = hmm_emit(0, obs[pos]);
+    return hmm_viterbi_emissions(h, e0s.data(), obs.size());
 }
 
 struct BedRegion {
