@@ -250,6 +250,22 @@ def end_to_end(device, runs, cpu_rate_all_cores, work_dir):
                                "codon_frames": b["codon_frames"], "seconds": b["seconds"], "seconds_all_runs": [r["seconds"] for r in big_runs],
                                "codon_frames_per_s": b["codon_frames"] / b["seconds"], "backend_calls": b["backend_calls"],
                                "maf_gigabytes_per_s": os.path.getsize(big) / b["seconds"] / 1e9, "stage_busy": b["stage_busy"]}
+        # the smoothing pass on the same file (--output-phylo 1 --output-regions 1, BASELINE.json configs[4]'s addition): the recurrences
+        # on the device (default) and on the host (PCSF_HOST_HMM=1: host/hmm.hpp, six threads), the twelve smoothed files compared
+        try:
+            prm = json.load(open(os.path.join(ROOT, "tests", "golden", "build-tracks", "hmm_params_backsolved.json")))["hmm_params"]
+            sm_args = ["--device", str(device), "--output-phylo", "1", "--output-regions", "1", "--hmm-params", ",".join("%.17g" % x for x in prm)]
+            dev = min([run_cli(CLI, big, os.path.join(work_dir, "gpu_sm_dev"), sm_args) for _ in range(2)], key=lambda r: r["seconds"])
+            host = run_cli(CLI, big, os.path.join(work_dir, "gpu_sm_host"), sm_args, env=dict(os.environ, PCSF_HOST_HMM="1"))
+            names = sorted(n for n in os.listdir(os.path.join(work_dir, "gpu_sm_host")) if not n.startswith("PhyloCSFRaw") and n != "PhyloCSFpower.wig")
+            same = all(open(os.path.join(work_dir, "gpu_sm_dev", n), "rb").read() == open(os.path.join(work_dir, "gpu_sm_host", n), "rb").read() for n in names)
+            e2e["steady_state"]["with_smoothing"] = {
+                "command": "phylocsf-amd build-tracks --output-phylo 1 --output-regions 1 --hmm-params <the reference's test parameters> 58mammals <maf>",
+                "seconds": dev["seconds"], "smoothing_seconds": dev["stage_busy"]["smoothing"],
+                "host_pass_seconds": host["seconds"], "host_pass_smoothing_seconds": host["stage_busy"]["smoothing"],
+                "smoothed_files": len(names), "smoothed_files_identical_to_host_pass": bool(same)}
+        except Exception as ex:
+            e2e["steady_state"]["with_smoothing"] = {"error": str(ex)[-500:]}
         os.remove(big)
     except Exception as ex:
         e2e["steady_state"] = {"error": str(ex)[-500:]}

@@ -36,4 +36,16 @@ python3 tools/replicate_maf.py /tmp/syn1mb.maf /tmp/syn10mb.maf --copies 10 > /d
 { for f in syn10mb clade10mb; do for skip in 1 0; do echo "== $f.maf, PCSF_SKIP_ALLGAP=$skip"; for i in 1 2; do PCSF_SKIP_ALLGAP=$skip phylocsfpp_amd/host/phylocsf-amd build-tracks --output /tmp/out_$f$skip 58mammals /tmp/$f.maf 2>&1 | tail -2; done; done;
     echo "outputs of the two runs: $(diff -rq /tmp/out_${f}1 /tmp/out_${f}0 > /dev/null && echo identical || echo DIFFERENT)"; done; } > $O/skip_allgap.txt 2>&1
 for f in syn10mb clade10mb; do rm -rf /tmp/pk; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -- phylocsfpp_amd/host/phylocsf-amd build-tracks --output /tmp/out_pk 58mammals /tmp/$f.maf > /dev/null 2>&1; echo "== $f.maf"; head -4 $(find /tmp/pk -name "*kernel_stats.csv" | head -1) | cut -c1-170; done > $O/skip_allgap_kernel_stats.txt 2>&1
+# ---- prune_factored: cycles of a tile by content (in-kernel stamps; lone work-groups and a loaded device)
+{ python3 tools/factored_tile_cost.py 200 2>&1 | grep -A1 "stamps"; python3 tools/factored_tile_cost.py 3000 2>&1 | grep -A1 stamps; } > $O/factored_tile_cost.txt 2>&1
+# ---- bls_kernel inside a build-tracks run (kernel statistics of the segment tiled ten times)
+bash tools/bls_ab.sh $O/bls > /dev/null 2>&1; cp $O/bls/kernel_stats.txt $O/build_tracks_kernel_stats.txt; rm -rf $O/bls
+# ---- the smoothing pass: device recurrences against the host pass, and one long run cut into chunks
+PCSF_HMM_STATS=1 bash tools/smooth_time.sh $O/smooth > /dev/null 2>&1; cp $O/smooth/smooth_time.txt $O/smoothing_pass.txt; rm -rf $O/smooth
+{ echo "== PCSF_HOST_HMM=1 (host/hmm.hpp, six threads)"; P=$(python3 -c "import json;print(','.join('%.17g'%x for x in json.load(open('tests/golden/build-tracks/hmm_params_backsolved.json'))['hmm_params']))");
+  for i in 1 2; do PCSF_HOST_HMM=1 phylocsfpp_amd/host/phylocsf-amd build-tracks --output /tmp/out_smh --output-phylo 1 --output-regions 1 --hmm-params $P 58mammals /tmp/syn10mb.maf 2>&1 | grep "seconds:"; done;
+  echo "smoothed files of the two passes: $(for f in /tmp/out_sm/PhyloCSF[+-]*; do cmp -s $f /tmp/out_smh/$(basename $f) || echo DIFFERENT $f; done | head -3; echo compared)"; } >> $O/smoothing_pass.txt 2>&1
+{ python3 tools/hmm_long_run.py 5000000; python3 tools/hmm_long_run.py 2000000 constant; } 2>&1 | grep -v amdgpu.ids > $O/hmm_long_run.txt
+# ---- BASELINE.json configs[3] on one GPU (100 Mb, text and packed)
+bash tools/config4_one_gpu.sh tmp_c4 100 > /dev/null 2>&1; mkdir -p $O/config4; cp gpurun_out/tmp_c4/config4/* $O/config4/; rm -rf gpurun_out/tmp_c4
 ls -la $O
