@@ -685,7 +685,8 @@ inline void smooth_tracks_device(const std::string& out_dir, const Hmm& hmm, boo
             if (write_smooth) {
                 struct Job { size_t run, a, b; };
                 std::vector<Job> jobs;
-                constexpr size_t PIECE = 32768;
+                size_t PIECE = 32768;
+                if (const char* v = std::getenv("PCSF_WIG_PIECE")) PIECE = std::max<size_t>(1, strtoull(v, nullptr, 10));   // tests: seams inside a run
                 for (size_t r = 0; r < n_runs; ++r)
                     for (size_t a = run_offsets[r]; a < run_offsets[r + 1]; a += PIECE) jobs.push_back(Job{r, a, std::min<size_t>(a + PIECE, run_offsets[r + 1])});
                 constexpr size_t WAVE = 8192;   // jobs formatted before their text is written (bounds the memory held as text)
@@ -821,7 +822,8 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         const double* sc = nullptr;   // the frame's scores of this alignment
         size_t a = 0, b = 0;   // power: positions [a, b) of the alignment (a = skip mod 3); frames: codons [a, b)
     };
-    constexpr size_t PIECE_CODONS = 16384;
+    size_t PIECE_CODONS = 16384;
+    if (const char* v = std::getenv("PCSF_WIG_PIECE")) PIECE_CODONS = std::max<size_t>(1, strtoull(v, nullptr, 10));   // tests: seams inside an alignment
     std::vector<TextPiece> text;   // stage 3's buffers, reused from batch to batch
     auto format_piece = [&](const PieceJob& j, TextPiece& out) {
         const Item& p = *j.it;

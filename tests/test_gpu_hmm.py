@@ -76,7 +76,7 @@ def _cli():
     return CLI
 
 
-@pytest.mark.parametrize("env", [{}, {"PCSF_HMM_CHUNK": "50", "PCSF_HMM_BURN_IN": "5"}, {"PCSF_HMM_HOST_RUN": "400"}])   # default; many chunks per run; long runs on host threads beside the device call
+@pytest.mark.parametrize("env", [{}, {"PCSF_HMM_CHUNK": "50", "PCSF_HMM_BURN_IN": "5", "PCSF_WIG_PIECE": "100"}, {"PCSF_HMM_HOST_RUN": "400"}])   # default; many chunks per run and text pieces inside runs; long runs on host threads beside the device call
 def test_build_tracks_smooths_on_the_device_and_writes_the_host_pass_files(tmp_path, env):
     """--output-phylo 1 --output-regions 1: the twelve smoothed files from the device recurrences (default) equal those of the host
     pass (PCSF_HOST_HMM=1) byte for byte."""

@@ -37,12 +37,14 @@ def read_scores(path):
     return rows[0], rows[1:]
 
 
-def test_build_tracks_wigs_byte_identical(oracle_cli, tmp_path):
+@pytest.mark.parametrize("piece", [None, "37", "1"])   # stage 3 formats a track in pieces of 16,384 codons: no alignment of the test file is
+def test_build_tracks_wigs_byte_identical(oracle_cli, tmp_path, piece):   # that long, so smaller pieces exercise the seams inside an alignment
     maf = tmp_path / "galGal6.maf"
     gunzip_to(os.path.join(GOLD, "build-tracks", "galGal6_chr22_25_28_each_30k_bases.maf.gz"), maf)
     out = tmp_path / "out"
+    env = dict(os.environ, **({"PCSF_WIG_PIECE": piece} if piece else {}))
     subprocess.check_call([oracle_cli, "build-tracks", "--output", str(out), os.path.join(GOLD, "models", "53birds"), str(maf)],
-                          stderr=subprocess.DEVNULL)
+                          stderr=subprocess.DEVNULL, env=env)
     names = ["PhyloCSFpower"] + ["PhyloCSFRaw%s%d" % (s, f) for s in "+-" for f in (1, 2, 3)]
     for n in names:
         want = gzip.open(os.path.join(GOLD, "build-tracks", n + ".wig.gz"), "rb").read()
