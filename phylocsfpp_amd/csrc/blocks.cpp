@@ -173,6 +173,7 @@ struct BlockEngine {
     TileGroup* p_tgroups = nullptr;
     std::vector<uint32_t> order_scratch;
     DeviceBuffer d_fact_stamps;  // PCSF_FACTORED_STAMPS: cycle sums of prune_factored (printed when the engine goes away)
+    bool fact_stamp_classes = false;   // PCSF_FACTORED_STAMPS=2: also per class of op (every op that runs is stamped: ~400 cycles each)
     std::vector<ExpmEval> fevals[2];
     // Which path an evaluation of block b takes is decided once per block from the matrix work either path needs (in
     // MFMA instructions): explicit = 256 per branch + 64 per internal edge, wave and 64-site window; factored = 64 per
@@ -240,7 +241,8 @@ struct BlockEngine {
         if (fixed_max_tiles >= 0) use_tiles = false;   // the tile-count rule is a statement about round 2's two paths
         if (const char* v = std::getenv("PCSF_TILE_JOBS")) tile_jobs_per_group = static_cast<size_t>(std::max(1, std::atoi(v)));
         if (const char* v = std::getenv("PCSF_EIGEN_HOST")) host_eigen = std::atoi(v) != 0;
-        if (std::getenv("PCSF_FACTORED_STAMPS")) {
+        if (const char* fs = std::getenv("PCSF_FACTORED_STAMPS")) {
+            fact_stamp_classes = std::atoi(fs) >= 2;
             HIP_TRY(d_fact_stamps.reserve(16 * sizeof(unsigned long long)));
             HIP_TRY(hipMemsetAsync(d_fact_stamps.ptr, 0, 16 * sizeof(unsigned long long), stream));
         }
@@ -315,7 +317,7 @@ struct BlockEngine {
             if (hipMemcpy(h, d_fact_stamps.ptr, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[3]) {
                 fprintf(stderr, "prune_factored stamps: %llu work-groups, per work-group %.0f cycles (prologue %.0f, root op reached at %.0f): %.1f scale loads waiting %.0f, %.1f products taking %.0f\n", h[3],
                         double(h[0]) / h[3], double(h[6]) / h[3], double(h[7]) / h[3], double(h[4]) / h[3], double(h[1]) / h[3], double(h[5]) / h[3], double(h[2]) / h[3]);
-                fprintf(stderr, "  per work-group, ops that ran (count, cycles incl. their loads and products): cherry %.1f %.0f | leaf %.1f %.0f | push %.1f %.0f | pop %.1f %.0f; op facts + row list %.0f\n",
+                if (fact_stamp_classes) fprintf(stderr, "  per work-group, ops that ran (count, cycles incl. their loads and products): cherry %.1f %.0f | leaf %.1f %.0f | push %.1f %.0f | pop %.1f %.0f; op facts + row list %.0f\n",
                         double(h[12]) / h[3], double(h[8]) / h[3], double(h[13]) / h[3], double(h[9]) / h[3], double(h[14]) / h[3], double(h[10]) / h[3], double(h[15]) / h[3], double(h[11]) / h[3],
                         double(h[0] - h[6] - h[8] - h[9] - h[10] - h[11]) / h[3]);
             }
@@ -638,6 +640,7 @@ struct BlockEngine {
                 fp.out_anc = want_anc ? p_anc : nullptr;
                 fp.deep = c->schedule.stack_depth > MAX_STACK_DEPTH ? 1u : 0u;
                 fp.stamps = d_fact_stamps.ptr ? d_fact_stamps.as<unsigned long long>() : nullptr;
+                fp.stamp_classes = fact_stamp_classes ? 1u : 0u;
                 if (ntj) {
                     fp.jobs = p_tjobs + t_at;
                     fp.n_jobs = static_cast<uint32_t>(ntj);

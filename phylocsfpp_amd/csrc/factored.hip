@@ -145,6 +145,7 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
     uint32_t* lrow_edge = reinterpret_cast<uint32_t*>(lslot + ((p.n_edges + 3) & ~3u));      // [128] by rank among the ops that run: branch of the op's edge (row of edge_scale)
     unsigned char* lcod = reinterpret_cast<unsigned char*>(lrow_edge + 128);                  // [n_leaves][16]
     unsigned char* lany = lcod + static_cast<size_t>(p.n_leaves) * 16;             // [n_leaves]: the leaf has a codon in the tile
+    unsigned char* lpush = lany + p.n_leaves;                                      // [128]: the push op only carries its message across an all-gap subtree
 
     const FactoredJob job = p.jobs[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
     }
     for (int i = tid; i < static_cast<int>((p.n_ops + 63) & ~63u); i += 256) lprog[i] = p.program[i < static_cast<int>(p.n_ops) ? i : static_cast<int>(p.n_ops) - 1];
     for (int i = tid; i < p.n_edges; i += 256) lslot[i] = p.slot_branch[i];
+    if (tid < 128) lpush[tid] = 0;
     // ... then into LDS, with per leaf whether it has a codon in any of the 16 columns
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
@@ -455,6 +457,25 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
             const int j = 64 * k + lane;
             ones_after[k] = __ballot(j < n_ops && ((ol0[k] & has0) | (ol1[k] & has1)) == 0ull);
         }
+        // A push whose second subtree is all gaps, and the pop that takes its tile back, only carry a message across that subtree: the
+        // push applies its edge and parks, everything up to the pop is skipped, the pop multiplies by ones.  Such a pair becomes ONE
+        // scaling -- the push applies its edge and leaves the message where it is, the pop is skipped like the ops between them (most
+        // of the pushes and pops of a sparse tile: ~1,000 cycles each for two selects' worth of work).
+        unsigned long long carried[2], push_carries[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int j = 64 * k + lane;
+            const uint32_t code = opw[k] >> 28;
+            const bool before = lane > 0 ? ((ones_after[k] >> (lane - 1)) & 1ull) : (k == 1 && (ones_after[0] >> 63));   // op j - 1 left all ones
+            const int parking = static_cast<int>(mt[k] >> 18);   // the parking op of a pop (>= 1)
+            const bool parked_ones = parking > 0 && ((((parking - 1) >> 6) ? ones_after[1] : ones_after[0]) >> ((parking - 1) & 63) & 1ull);
+            const bool c = j < n_ops && code >= F_MM_POP0_DEV && code < F_ROOT_DEV && before && !parked_ones && parking < 128;
+            carried[k] = __ballot(c);
+            if (c) lpush[parking] = 1;   // all four waves write the same bytes
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) push_carries[k] = __ballot(64 * k + lane < n_ops && lpush[64 * k + lane] != 0);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int j = 64 * k + lane;
@@ -462,7 +483,7 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
             const bool is_push = code >= F_MM_PUSH_CHERRY0_DEV && code < F_MM_POP0_DEV, is_root = code >= F_ROOT_DEV;
             const bool after = (ones_after[k] >> lane) & 1ull;
             const bool before = lane > 0 ? ((ones_after[k] >> (lane - 1)) & 1ull) : (k == 1 && (ones_after[0] >> 63));   // op j - 1 left all ones
-            const bool trivial = j < n_ops && after && !is_root && (!is_push || before);
+            const bool trivial = j < n_ops && ((after && !is_root && (!is_push || before)) || ((carried[k] >> lane) & 1ull));
             active[k] = __ballot(j < n_ops && !trivial);
         }
         // the row of edge_scale the edge of every op that runs reads, by the op's rank among them (all four waves write the same values)
@@ -481,7 +502,7 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
                 const int parking = static_cast<int>(mt[k] >> 18);
                 const bool parked_ones = parking > 0 && ((((parking - 1) >> 6) ? ones_after[1] : ones_after[0]) >> ((parking - 1) & 63) & 1ull);
                 const bool before = lane > 0 ? ((ones_after[k] >> (lane - 1)) & 1ull) : (k == 1 && (ones_after[0] >> 63));
-                const bool scales_only = !before && ((code == F_MM_LEAF_DEV && !a_has) || (code >= F_MM_POP0_DEV && code < F_ROOT_DEV && parked_ones));
+                const bool scales_only = !before && ((code == F_MM_LEAF_DEV && !a_has) || (code >= F_MM_POP0_DEV && code < F_ROOT_DEV && parked_ones) || ((push_carries[k] >> lane) & 1ull));
                 lrow_edge[at] = (has_edge ? static_cast<uint32_t>(lslot[mt[k] & 0x3fffu]) : 0u) | (scales_only ? 0x80000000u : 0u);
             }
         __syncthreads();
@@ -491,22 +512,33 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
                 if ((rank & 15) == 0) load_batch(rank);
                 // A chain of edges above a lone species is a run of ops that only scale: y <- e_b o y, one after the other in the order the
                 // ops would do it (same roundings), without an op's dispatch each -- 21 of the 38 ops of a tile with four species present.
-                if (cur.eig && cur.mask != 0xffffu) {
+                if ((chain16 >> (rank & 15)) & 1u) {   // an op that only applies its edge: never through run_op (a carrying push must not park)
+                    if (cur.mask == 0xffffu) {   // nothing to scale (the op facts say the message has content: cannot happen)
+                        todo &= todo - 1;
+                        ++rank;
+                        continue;
+                    }
+                    if (!cur.eig) {   // real form: the L-product, then the scale
+                        const int l1 = __builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        const uint32_t meta1 = __builtin_amdgcn_readlane(k ? mt[1] : mt[0], l1);
+                        cur = apply_edge(static_cast<int>(meta1 & 0x3fffu), cur, true_type{});
+                        ++rank;
+                        continue;
+                    }
                     const uint32_t run_bits = ~(chain16 >> (rank & 15));
                     int n_run = run_bits ? __builtin_ctz(run_bits) : 16;
                     n_run = n_run < 16 - (rank & 15) ? n_run : 16 - (rank & 15);
                     const int left = __popcll(todo);
                     n_run = n_run < left ? n_run : left;
-                    if (n_run > 0) {
-                        for (int j = 0; j < n_run; ++j) {
-                            const int src = (lane & 48) | ((rank + j) & 15);
+                    for (int j = 0; j < n_run; ++j) {
+                        const int src = (lane & 48) | ((rank + j) & 15);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) cur.v.v[r] *= __shfl(pre[r], src);
-                            todo &= todo - 1;
-                        }
-                        rank += n_run;
-                        continue;
+                        for (int r = 0; r < 4; ++r) cur.v.v[r] *= __shfl(pre[r], src);
+                        todo &= todo - 1;
                     }
+                    rank += n_run;
+                    continue;
                 }
                 const int l = __builtin_ctzll(todo);
                 todo &= todo - 1;
@@ -520,9 +552,10 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
                 }
                 const int parking = static_cast<int>(meta >> 18);   // >= 1 for a pop
                 const bool parked_ones = parking > 0 && (((parking - 1) >> 6 ? ones_after[1] : ones_after[0]) >> ((parking - 1) & 63) & 1ull);
-                const unsigned long long t_op = stamping ? fact_clock() : 0ull;
+                const bool stamp_op = stamping && p.stamp_classes != 0;
+                const unsigned long long t_op = stamp_op ? fact_clock() : 0ull;
                 run_op(op, static_cast<int>(meta & 0x3fffu), static_cast<int>((meta >> 14) & 0xfu), parked_ones, true_type{});
-                if (stamping) {
+                if (stamp_op) {
                     const uint32_t cls = (op >> 28) == F_CHERRY_DEV ? 0u : ((op >> 28) == F_MM_LEAF_DEV ? 1u : ((op >> 28) < F_MM_POP0_DEV ? 2u : 3u));
                     if ((op >> 28) < F_ROOT_DEV) {   // selects, not an index (an indexed array would live in scratch memory in every build)
                         const unsigned long long dt = fact_clock() - t_op;
@@ -609,7 +642,7 @@ hipError_t launch_prune_factored(const FactoredParams& p, hipStream_t stream)
 {
     if (p.n_jobs == 0) return hipSuccess;
     const size_t lds = 2 * 4 * 2 * 64 * 16 + 2 * 4 * 16 * 8 + 64 * 8 + ((static_cast<size_t>(p.n_ops) + 63) & ~size_t(63)) * 4 +
-                       ((static_cast<size_t>(p.n_edges) + 3) & ~size_t(3)) * 4 + 128 * 4 + static_cast<size_t>(p.n_leaves) * 17;
+                       ((static_cast<size_t>(p.n_edges) + 3) & ~size_t(3)) * 4 + 128 * 4 + static_cast<size_t>(p.n_leaves) * 17 + 128;
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     if (p.deep) {
         if (p.out_anc) hipLaunchKernelGGL((prune_factored<true, true>), dim3(p.n_jobs), dim3(256), lds, stream, p);

@@ -147,6 +147,7 @@ struct FactoredParams {
     uint32_t deep;              // the tree parks more tiles than the register stack holds (schedule.stack_depth > MAX_STACK_DEPTH)
     const uint64_t* op_leaves;  // [n_ops][2] and
     const uint32_t* op_meta;    // [n_ops]: schedule.hpp ProgramFacts of `program` (null: tree of more than 128 leaves -- no op is skipped)
+    uint32_t stamp_classes;     // diagnostics: also stamp every op that runs, by class (stamps[8..15]; a stamp costs ~200 cycles: PCSF_FACTORED_STAMPS=2)
     unsigned long long* stamps; // diagnostics (may be null; PCSF_FACTORED_STAMPS): work-groups add cycles -- [0] whole kernel, [1] waiting for
                                 // edge-scale / leaf-column loads, [2] in products, [3] work-groups, [4] loads, [5] products
 };

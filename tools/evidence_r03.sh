@@ -37,7 +37,7 @@ python3 tools/replicate_maf.py /tmp/syn1mb.maf /tmp/syn10mb.maf --copies 10 > /d
     echo "outputs of the two runs: $(diff -rq /tmp/out_${f}1 /tmp/out_${f}0 > /dev/null && echo identical || echo DIFFERENT)"; done; } > $O/skip_allgap.txt 2>&1
 for f in syn10mb clade10mb; do rm -rf /tmp/pk; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -- phylocsfpp_amd/host/phylocsf-amd build-tracks --output /tmp/out_pk 58mammals /tmp/$f.maf > /dev/null 2>&1; echo "== $f.maf"; head -4 $(find /tmp/pk -name "*kernel_stats.csv" | head -1) | cut -c1-170; done > $O/skip_allgap_kernel_stats.txt 2>&1
 # ---- prune_factored: cycles of a tile by content (in-kernel stamps; lone work-groups and a loaded device)
-{ python3 tools/factored_tile_cost.py 200 2>&1 | grep -A1 "stamps"; python3 tools/factored_tile_cost.py 3000 2>&1 | grep -A1 stamps; } > $O/factored_tile_cost.txt 2>&1
+{ echo "== PCSF_FACTORED_STAMPS=1 (summary stamps only)"; python3 tools/factored_tile_cost.py 200 2>&1 | grep "stamps"; python3 tools/factored_tile_cost.py 3000 2>&1 | grep stamps; echo "== PCSF_FACTORED_STAMPS=2 (every op that runs is stamped too: ~400 cycles each)"; PCSF_FACTORED_STAMPS=2 python3 tools/factored_tile_cost.py 200 2>&1 | grep -A1 "stamps"; } > $O/factored_tile_cost.txt 2>&1
 # ---- bls_kernel inside a build-tracks run (kernel statistics of the segment tiled ten times)
 bash tools/bls_ab.sh $O/bls > /dev/null 2>&1; cp $O/bls/kernel_stats.txt $O/build_tracks_kernel_stats.txt; rm -rf $O/bls
 # ---- the smoothing pass: device recurrences against the host pass, and one long run cut into chunks

@@ -3,7 +3,7 @@ tiles with 1 / 4 / 20 / 100 species present.  python tools/factored_tile_cost.py
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["PCSF_FACTORED_STAMPS"] = "1"
+os.environ.setdefault("PCSF_FACTORED_STAMPS", "1")   # 2: also cycles per class of op (every op that runs is stamped, ~400 cycles each)
 import numpy as np
 import phylocsfpp_amd as pa
 m = pa.load_model(os.path.join(ROOT, "tests/golden/models/100vertebrates"))
