@@ -48,4 +48,6 @@ PCSF_HMM_STATS=1 bash tools/smooth_time.sh $O/smooth > /dev/null 2>&1; cp $O/smo
 { python3 tools/hmm_long_run.py 5000000; python3 tools/hmm_long_run.py 2000000 constant; } 2>&1 | grep -v amdgpu.ids > $O/hmm_long_run.txt
 # ---- BASELINE.json configs[3] on one GPU (100 Mb, text and packed)
 bash tools/config4_one_gpu.sh tmp_c4 100 > /dev/null 2>&1; mkdir -p $O/config4; cp gpurun_out/tmp_c4/config4/* $O/config4/; rm -rf gpurun_out/tmp_c4
+# ---- BASELINE.json configs[4] on one GPU at 20 Mb: 100vertebrates, HMM parameters estimated from the exon list, device against host smoothing
+bash tools/config5_one_gpu.sh $O/c5 20 > /dev/null 2>&1; cp $O/c5/config5.txt $O/config5_one_gpu.txt; rm -rf $O/c5
 ls -la $O
