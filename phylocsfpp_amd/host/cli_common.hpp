@@ -33,7 +33,7 @@ inline int usage(const char* prog)
             "  %s score-msa    [--strategy fixed|mle|omega|fixed_mean] [--comp-phylo 0|1] [--comp-anc 0|1] [--comp-bls 0|1]\n"
             "                  [--output DIR] [--species A,B,...] [--mapping FILE] [--species-aliases FILE] [--device N | --devices N,M,...]\n"
             "                  <model prefix> <alignment.maf>...\n"
-            "  %s smooth-tracks [--output-phylo 0|1] [--output-regions 0|1] (--genome-length N --coding-exons FILE | --hmm-params P) DIR\n"
+            "  %s smooth-tracks [--output-phylo 0|1] [--output-regions 0|1] [--context-model MODEL [--device N]] (--genome-length N --coding-exons FILE | --hmm-params P) DIR\n"
             "  %s pack-maf     [--threads N] [--species A,B,...] [--mapping FILE] <model prefix> <alignment.maf> <out.pcsfbin>\n"
             "                  (build-tracks also reads the packed file: same tracks, no text parsing)\n"
             "--hmm-params: coding prior, mean coding length (codons), 3 non-coding weights, 3 non-coding mean lengths (codons)\n"
@@ -209,7 +209,7 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
     std::string coding_exons, hmm_params, hmm_matrix;
     uint64_t genome_length = 0;
     ScoreMsaParams sm;
-    std::string aliases, species, mapping;
+    std::string aliases, species, mapping, context_model;
     std::vector<int> devices{0};
     int contexts_per_device = 0;
     int i = 2;
@@ -235,6 +235,7 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
         else if (k == "--species-aliases") aliases = v;
         else if (k == "--species") species = v;
         else if (k == "--mapping") mapping = v;
+        else if (k == "--context-model") context_model = v;   // smooth-tracks: a model to make a scoring context with, for the device recurrences
         else if (k == "--device") devices = {atoi(v.c_str())};
         else if (k == "--devices") {  // one scoring context per listed GPU; batches / block ranges are dealt to them
             devices.clear();
@@ -303,7 +304,13 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend)
                 sm.hmm = bt.hmm;
             }
             if (cmd == "smooth-tracks") {
-                smooth_tracks(argv[i], bt.hmm, bt.write_smooth, bt.write_regions, /*keep_raw=*/true, bt.threads > 0 ? bt.threads : effective_threads());
+                const int threads = bt.threads > 0 ? bt.threads : effective_threads();
+                // The pass needs no model; the device recurrences need a scoring context, and a context is made for a model: with
+                // --context-model <name or prefix> (any model will do) the pass runs as build-tracks runs it, otherwise as host code.
+                std::unique_ptr<ScoringBackend> ctx_backend;
+                if (!context_model.empty()) ctx_backend = make_backend(load_model(context_model, aliases, "", ""), devices[0]);
+                if (ctx_backend && ctx_backend->device_hmm()) smooth_tracks_device(argv[i], bt.hmm, bt.write_smooth, bt.write_regions, /*keep_raw=*/true, threads, *ctx_backend);
+                else smooth_tracks(argv[i], bt.hmm, bt.write_smooth, bt.write_regions, /*keep_raw=*/true, threads);
                 return 0;
             }
         }

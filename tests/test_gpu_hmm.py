@@ -97,3 +97,63 @@ def test_build_tracks_smooths_on_the_device_and_writes_the_host_pass_files(tmp_p
     assert names == sorted(os.listdir(outs["device"])) and len([n for n in names if n.endswith("Regions.bed")]) == 6
     for n in names:
         assert open(outs["device"] / n, "rb").read() == open(outs["host"] / n, "rb").read(), n
+
+
+def _write_raw_tracks(d, rng):
+    """six raw tracks with runs the wig reader merges or not: short runs, a header that continues the stretch before it, a header
+    right behind a header, a second chromosome, a constant stretch, and one run of 300,000 values (ten chunks at the default length)"""
+    def fmt(v):
+        s = "%.3f" % v
+        s = s.rstrip("0")
+        return s + "0" if s.endswith(".") else s
+    for strand in "+-":
+        for f in (1, 2, 3):
+            lines, pos = [], 1000 + f
+            def run(chrom, n, start, values=None):
+                lines.append("fixedStep chrom=%s start=%d step=3 span=3" % (chrom, start))
+                vals = values if values is not None else np.round(rng.normal(-5.0, 8.0, size=n), 3)
+                lines.extend(fmt(float(v)) for v in vals)
+                return start + 3 * n
+            pos = run("chrA", 1, pos)
+            pos = run("chrA", 2, pos + 30)
+            pos = run("chrA", 50, pos + 3)            # a gap of one codon: a new run
+            pos = run("chrA", 5000, pos)              # continues the stretch before it: the same run
+            lines.append("fixedStep chrom=chrA start=%d step=3 span=3" % (pos + 300))   # a header without values ...
+            pos = run("chrA", 300000, pos + 600)      # ... right before the long run
+            pos = run("chrA", 70000, pos + 9, values=np.zeros(70000))
+            pos = run("chrB", 1200, 7)
+            lines.extend(["-0.0", "3.0", "12.5", "-7.25"])   # fewer decimals than three
+            open(os.path.join(d, "PhyloCSFRaw%s%d.wig" % (strand, f)), "w").write("\n".join(lines) + "\n")
+
+
+def test_smooth_tracks_on_long_runs_device_against_host(tmp_path):
+    """smooth-tracks over generated raw tracks, as host code and with the device recurrences (--context-model): runs of 300,000 values
+    are cut into ten chunks at the default chunk length and burn-in -- some meet their neighbours' states, the others are evaluated
+    again -- and the twelve files must not differ in a byte."""
+    d = tmp_path / "tracks"
+    os.makedirs(d)
+    _write_raw_tracks(str(d), np.random.default_rng(3))
+    prm = ",".join("%.17g" % x for x in _params())
+    results = {}
+    for name, extra in (("host", []), ("device", ["--context-model", "53birds"])):
+        r = subprocess.run([_cli(), "smooth-tracks", "--output-phylo", "1", "--output-regions", "1", "--hmm-params", prm] + extra + [str(d)],
+                           env=dict(os.environ, PCSF_HMM_STATS="1"), stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr
+        assert ("hmm_smooth_runs:" in r.stderr) == (name == "device"), r.stderr
+        out = tmp_path / name
+        os.makedirs(out)
+        for n in os.listdir(d):
+            if not n.startswith("PhyloCSFRaw"):
+                shutil.move(str(d / n), str(out / n))
+        results[name] = (out, r.stderr)
+    names = sorted(os.listdir(results["host"][0]))
+    assert len(names) == 12 and names == sorted(os.listdir(results["device"][0]))
+    total = 0
+    for n in names:
+        a, b = open(results["host"][0] / n, "rb").read(), open(results["device"][0] / n, "rb").read()
+        assert a == b, n
+        total += len(a)
+    assert total > 10_000_000
+    import re
+    m = re.search(r"(\d+) runs, (\d+) values in (\d+) chunks", results["device"][1])
+    assert m and int(m.group(3)) > int(m.group(1)) + 40, results["device"][1]   # the long runs were cut into chunks
