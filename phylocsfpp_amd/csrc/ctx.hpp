@@ -156,6 +156,11 @@ struct pcsf_ctx {
     bool skip_allgap_forced = false;     // PCSF_SKIP_ALLGAP given: `skip_allgap` for every entry point; else on for the six-frame ones only
     // branch-length score (pcsf_set_bls_branch_lengths)
     pcsf::DeviceBuffer d_bls_tree, d_bls_out, d_bls_spans, d_bls_flag;
+    // pcsf_hmm_smooth_runs (hmm_abi.cpp): kept between calls -- a call on a 10 Mb chromosome holds ~1 GB, and allocating and freeing that
+    // around every call cost as much as its kernels
+    struct HmmBuffers {
+        pcsf::DeviceBuffer emit, fwd, back, post, chunks, entry, exit_state, same, todo, thresholds, bins, exc_index, exc_value, exc_count;
+    } hmm;
     pcsf::BlsTree bls_tree{};
     bool bls_ready = false;
     unsigned long long* bls_first_bad = nullptr;  // page-locked host copy of the kernel's character check

@@ -13,14 +13,6 @@
 
 #include "ctx.hpp"
 
-namespace {
-
-struct Buffers {
-    pcsf::DeviceBuffer emit, fwd, back, post, chunks, entry, exit_state, same, todo;
-};
-
-}  // namespace
-
 struct BinRequest {   // pcsf_hmm_smooth_runs_binned: bins of the posterior instead of the posterior
     const double* thresholds = nullptr;
     size_t n_thresholds = 0;
@@ -71,7 +63,7 @@ static int smooth_runs(pcsf_ctx* c, const double* init, const double* trans, con
     hipError_t e;
     if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
     hipStream_t st = c->stream;
-    Buffers B;
+    pcsf_ctx::HmmBuffers& B = c->hmm;
 #define HMM_TRY(x, what) \
     if ((e = (x)) != hipSuccess) return c->hip_fail(e, what)
     HMM_TRY(B.emit.reserve(n * sizeof(double)), "hipMalloc(hmm emissions)");
@@ -143,7 +135,7 @@ static int smooth_runs(pcsf_ctx* c, const double* init, const double* trans, con
     if (out_posterior) HMM_TRY(hipMemcpyAsync(out_posterior, B.post.ptr, n * sizeof(double), hipMemcpyDeviceToHost, st), "hipMemcpyAsync(hmm posterior)");
     unsigned int n_exc = 0;
     if (bins) {
-        pcsf::DeviceBuffer d_thr, d_bins, d_exc_i, d_exc_v, d_count;
+        pcsf::DeviceBuffer &d_thr = B.thresholds, &d_bins = B.bins, &d_exc_i = B.exc_index, &d_exc_v = B.exc_value, &d_count = B.exc_count;
         HMM_TRY(d_thr.reserve(std::max<size_t>(bins->n_thresholds, 1) * sizeof(double)), "hipMalloc(hmm thresholds)");
         HMM_TRY(d_bins.reserve(n * sizeof(uint16_t)), "hipMalloc(hmm bins)");
         HMM_TRY(d_exc_i.reserve(std::max<size_t>(bins->exc_capacity, 1) * sizeof(uint64_t)), "hipMalloc(hmm exceptions)");
