@@ -115,6 +115,58 @@ __device__ __forceinline__ void store_vec(double* p, const Vec& v)
     q[1] = double2{v.s[2], v.s[3]};
 }
 
+// A thread's emissions, eight positions at a time and one block ahead: every lane walks its own stretch of memory, so a load per step
+// is a cache line per lane and a full memory round trip in the recurrence's dependency chain (measured: 6-8 k cycles per step where
+// the arithmetic needs ~1 k).  Eight independent loads per block, issued while the block before is computed.  UP: positions ascend.
+template <bool UP>
+struct EmissionStream {
+    const double* __restrict__ base;
+    uint64_t next;        // first position of the block after the current one (UP) / one past the last position of it (!UP)
+    uint64_t limit;       // positions are in [limit_lo .. ) for !UP resp. [ .. limit) for UP: loads beyond are clamped and never used
+    double cur[8], ahead[8];
+    __device__ __forceinline__ void fetch(double (&dst)[8], uint64_t at)
+    {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (UP) {
+                const uint64_t p = at + k;
+                dst[k] = base[p < limit ? p : limit - 1];
+            } else {
+                const uint64_t p = at >= static_cast<uint64_t>(k) + 1 + limit ? at - 1 - k : limit;   // at - 1 - k, not below limit
+                dst[k] = base[p];
+            }
+        }
+    }
+    // positions first, first + 1, ... (UP) or first, first - 1, ... (!UP), none outside [lo, hi)
+    __device__ __forceinline__ void start(const double* b, uint64_t first, uint64_t lo, uint64_t hi)
+    {
+        base = b;
+        if (UP) {
+            limit = hi;
+            fetch(cur, first);
+            next = first + 8;
+            fetch(ahead, next);
+        } else {
+            limit = lo;
+            fetch(cur, first + 1);
+            next = first + 1 >= 8 + lo ? first + 1 - 8 : lo;
+            fetch(ahead, next);
+        }
+    }
+    __device__ __forceinline__ void advance()
+    {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cur[k] = ahead[k];
+        if (UP) {
+            next += 8;
+            fetch(ahead, next);
+        } else {
+            next = next >= 8 + limit ? next - 8 : limit;
+            fetch(ahead, next);
+        }
+    }
+};
+
 }  // namespace
 
 // MODE 0: forward (fwd[n][4] out), 1: Viterbi (back[n] out: four 2-bit predecessors per position; nothing at a run's first position),
@@ -144,16 +196,37 @@ __global__ __launch_bounds__(64) void hmm_chunks_kernel(const HmmModel h, const 
             } else {
                 uint64_t p = ch.begin - ch.run_begin > burn_in ? ch.begin - burn_in : ch.run_begin;
                 v = start_vector(h, emit[p]);   // a made-up state unless p is the run's first position
-                for (++p; p < ch.begin; ++p) v = MODE == 0 ? forward_step(h, v, emit[p]) : viterbi_step(h, v, emit[p], nullptr);
+                ++p;
+                if (p < ch.begin) {
+                    EmissionStream<true> es;
+                    es.start(emit, p, ch.run_begin, ch.begin);
+                    while (p < ch.begin) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            if (p + k < ch.begin) v = MODE == 0 ? forward_step(h, v, es.cur[k]) : viterbi_step(h, v, es.cur[k], nullptr);
+                        p += 8;
+                        es.advance();
+                    }
+                }
             }
             store_vec(entry + static_cast<size_t>(c) * 4, v);   // the state at begin - 1
         }
-        for (; pos < ch.end; ++pos) {
-            if (MODE == 0) {
-                v = forward_step(h, v, emit[pos]);
-                store_vec(fwd + pos * 4, v);
-            } else {
-                v = viterbi_step(h, v, emit[pos], back + pos);
+        if (pos < ch.end) {
+            EmissionStream<true> es;
+            es.start(emit, pos, ch.run_begin, ch.end);
+            while (pos < ch.end) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (pos + k < ch.end) {
+                        if (MODE == 0) {
+                            v = forward_step(h, v, es.cur[k]);
+                            store_vec(fwd + (pos + k) * 4, v);
+                        } else {
+                            v = viterbi_step(h, v, es.cur[k], back + pos + k);
+                        }
+                    }
+                pos += 8;
+                es.advance();
             }
         }
         store_vec(exit_state + static_cast<size_t>(c) * 4, v);   // the state at end - 1
@@ -177,17 +250,40 @@ __global__ __launch_bounds__(64) void hmm_chunks_kernel(const HmmModel h, const 
             } else {
                 uint64_t p = ch.run_end - ch.end > burn_in ? ch.end + burn_in : ch.run_end;   // one past the made-up start
                 v = Vec{{1.0, 1.0, 1.0, 1.0}};
-                for (--p; p > ch.end; --p) v = backward_step(h, v, emit[p]);   // state at p - 1 from the state at p
+                --p;
+                if (p > ch.end) {   // state at p - 1 from the state at p, for p down to end + 1
+                    EmissionStream<false> es;
+                    es.start(emit, p, ch.end + 1, ch.run_end);
+                    while (p > ch.end) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            if (p >= ch.end + 1 + static_cast<uint64_t>(k)) v = backward_step(h, v, es.cur[k]);
+                        p = p >= ch.end + 8 ? p - 8 : ch.end;
+                        es.advance();
+                    }
+                }
             }
             store_vec(entry + static_cast<size_t>(c) * 4, v);   // the state at `end`
         }
-        for (; pos > ch.begin; --pos) {   // state at pos - 1 from the state at pos
-            v = backward_step(h, v, emit[pos]);
-            const Vec f = load_vec(fwd + (pos - 1) * 4);
-            double total = 0.0;
+        if (pos > ch.begin) {   // state at pos - 1 from the state at pos (emission of pos), for pos down to begin + 1
+            EmissionStream<false> es;
+            es.start(emit, pos, ch.begin + 1, ch.run_end);
+            while (pos > ch.begin) {
+                Vec f[8];   // the forward vectors of the block's positions, requested together
 #pragma unroll
-            for (int s = 0; s < 4; ++s) total += (f.s[s] * v.s[s]);
-            post[pos - 1] = (f.s[0] * v.s[0]) / total;
+                for (int k = 0; k < 8; ++k) f[k] = load_vec(fwd + (pos >= ch.begin + 1 + static_cast<uint64_t>(k) ? pos - 1 - k : ch.begin) * 4);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (pos >= ch.begin + 1 + static_cast<uint64_t>(k)) {
+                        v = backward_step(h, v, es.cur[k]);
+                        double total = 0.0;
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) total += (f[k].s[s] * v.s[s]);
+                        post[pos - 1 - k] = (f[k].s[0] * v.s[0]) / total;
+                    }
+                pos = pos >= ch.begin + 8 ? pos - 8 : ch.begin;
+                es.advance();
+            }
         }
         store_vec(exit_state + static_cast<size_t>(c) * 4, v);   // the state at begin
     }
