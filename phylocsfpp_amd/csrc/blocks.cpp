@@ -1007,7 +1007,9 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
         ob.q_settings[2] = 1.0;
         for (int i = 3; i < 12; ++i) ob.q_settings[i] = 1.0;
     }
+    const auto tp0 = std::chrono::steady_clock::now();
     validate_all(live);
+    const auto tp1 = std::chrono::steady_clock::now();
     // F3x4 nucleotide counts over every non-gap codon of every row (src/run.hpp:105-134)
     parallel_for(live.size(), [&](size_t i) {
         OmegaBlock& ob = *blk[live[i]];
@@ -1028,12 +1030,16 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
         for (int p = 0; p < 3; ++p)
             for (int j = 0; j < 3; ++j) ob.q_settings[3 + 3 * p + j] = cnt[p][j] / cnt[p][3];
     });
+    const auto tp2 = std::chrono::steady_clock::now();
     {
         std::vector<size_t> ok;
         for (size_t b : live)
             if (!blk[b]->failed) ok.push_back(b);
         validate_all(ok);
     }
+    if (std::getenv("PCSF_TIME_BLOCKS"))
+        fprintf(stderr, "run_omega prelude: first validation %.3f s, F3x4 counts %.3f s, second validation %.3f s\n", std::chrono::duration<double>(tp1 - tp0).count(),
+                std::chrono::duration<double>(tp2 - tp1).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - tp2).count());
 
     auto start_stage = [&](OmegaBlock& ob) {
         ob.store.clear();
