@@ -180,9 +180,9 @@ int pcsf_hmm_smooth_runs(pcsf_ctx *ctx, const double *init, const double *trans,
                          double *out_last, pcsf_hmm_stats *stats);
 /* The same for a caller that only PRINTS a monotone function of the posterior, as process_scores does (log-odds as
  * "%.3f", src/create_tracks.hpp:226-260, src/common.hpp:48-68): instead of the posterior, out_bins[n] = how many of
- * the ascending thresholds[n_thresholds] (fewer than 65,535) are <= the posterior -- with the thresholds at the values
+ * the ascending thresholds[n_thresholds] (fewer than 65,534) are <= the posterior -- with the thresholds at the values
  * where the printed text changes that IS the text, in 2 bytes per position and without a log10 per value on the host.
- * A NaN posterior has no bin (out_bins 0xffff): position and value are appended to exc_index / exc_value (up to
+ * A NaN posterior has no bin (out_bins 0xffff, or 0xfffe when its sign bit is set): position and value are appended to exc_index / exc_value (up to
  * exc_capacity entries; *n_exceptions counts all of them). */
 int pcsf_hmm_smooth_runs_binned(pcsf_ctx *ctx, const double *init, const double *trans, const double *emissions,
                                 const uint64_t *run_offsets, size_t n_runs, const double *thresholds,

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void hmm_compare_kernel(const HmmChunk* __rest
 
 // bins[i] = the number of thresholds <= posterior[i] (thresholds ascending): for a caller that only PRINTS a monotone function of the
 // posterior, with the thresholds at the values where the printed text changes, this is all it needs -- 2 bytes per position instead of
-// 8, and no log10 per value on the host.  NaN has no bin: its position and value go to the exception list.
+// 8, and no log10 per value on the host.  NaN has no bin (0xffff, with the sign bit set 0xfffe): its position and value go to the exception list.
 __global__ __launch_bounds__(256) void hmm_bin_kernel(const double* __restrict__ post, uint64_t n, const double* __restrict__ thresholds, uint32_t n_thresholds,
                                                       uint16_t* __restrict__ bins, uint64_t* __restrict__ exc_index, double* __restrict__ exc_value,
                                                       uint32_t exc_capacity, unsigned int* __restrict__ n_exc)
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void hmm_bin_kernel(const double* __restrict__
             exc_index[slot] = i;
             exc_value[slot] = p;
         }
-        bins[i] = 0xffffu;
+        bins[i] = static_cast<uint16_t>(0xffffu - (__double_as_longlong(p) < 0 ? 1u : 0u));   // 0xffff: NaN, 0xfffe: NaN with the sign bit set
         return;
     }
     uint32_t lo = 0, hi = n_thresholds;
@@ -340,7 +340,7 @@ hipError_t launch_hmm_bins(const double* d_post, uint64_t n, const double* d_thr
                            double* d_exc_value, uint32_t exc_capacity, unsigned int* d_n_exc, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    if (n_thresholds >= 0xffffu || (n + 255u) / 256u > 0x7fffffffull) return hipErrorInvalidValue;
+    if (n_thresholds >= 0xfffeu || (n + 255u) / 256u > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(hmm_bin_kernel, dim3(static_cast<unsigned>((n + 255u) / 256u)), dim3(256), 0, stream, d_post, n, d_thresholds, n_thresholds, d_bins, d_exc_index,
                        d_exc_value, exc_capacity, d_n_exc);
     return hipGetLastError();

@@ -28,8 +28,8 @@ static int smooth_runs(pcsf_ctx* c, const double* init, const double* trans, con
 {
     if (!c) return PCSF_ERR_INVALID_ARG;
     if (!init || !trans || !run_offsets || (!out_posterior && !bins)) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_hmm_smooth_runs: null argument");
-    if (bins && (!bins->thresholds || !bins->out_bins || !bins->n_exc || bins->n_thresholds >= 0xffffu || (bins->exc_capacity && (!bins->exc_index || !bins->exc_value))))
-        return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_hmm_smooth_runs_binned: null argument or 65,535 thresholds or more");
+    if (bins && (!bins->thresholds || !bins->out_bins || !bins->n_exc || bins->n_thresholds >= 0xfffeu || (bins->exc_capacity && (!bins->exc_index || !bins->exc_value))))
+        return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_hmm_smooth_runs_binned: null argument or 65,534 thresholds or more");
     if (bins) *bins->n_exc = 0;
     if ((out_back == nullptr) != (out_last == nullptr)) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_hmm_smooth_runs: out_back and out_last go together");
     if (stats) *stats = pcsf_hmm_stats{};

@@ -661,7 +661,7 @@ inline void smooth_tracks_device(const std::string& out_dir, const Hmm& hmm, boo
                         const size_t r = host_runs[k], b = run_offsets[r], len = run_offsets[r + 1] - b;
                         std::vector<double> run_post(len), work;
                         hmm_coding_posterior_emissions(hmm, emit.get() + b, len, run_post.data(), work);
-                        for (size_t i = 0; i < len; ++i) bins[b + i] = run_post[i] != run_post[i] ? uint16_t(0xffffu) : static_cast<uint16_t>(printed_code(run_post[i]) - PRINTED_CODE_MIN);
+                        for (size_t i = 0; i < len; ++i) bins[b + i] = run_post[i] != run_post[i] ? static_cast<uint16_t>(std::signbit(run_post[i]) ? 0xfffeu : 0xffffu) : static_cast<uint16_t>(printed_code(run_post[i]) - PRINTED_CODE_MIN);
                         if (write_regions) host_path[r] = hmm_viterbi_emissions(hmm, emit.get() + b, len);
                     });
                 } catch (...) {
@@ -678,7 +678,7 @@ inline void smooth_tracks_device(const std::string& out_dir, const Hmm& hmm, boo
                     }
                 });
             }
-            (void)n_exc;   // positions without a posterior (0 / 0) carry bin 0xffff and are printed as the host pass prints its NaN: the list is not needed
+            (void)n_exc;   // positions whose posterior is NaN carry bin 0xffff / 0xfffe (sign) and are printed as the host pass prints such a NaN: the list is not needed
             emit.reset();
             t_dev = phase.lap();
             // (4) text: pieces of runs on all threads, every file's pieces appended in order
@@ -701,9 +701,8 @@ inline void smooth_tracks_device(const std::string& out_dir, const Hmm& hmm, boo
                         if (jb.a == run_offsets[jb.run]) o.header(run.chrom, static_cast<int64_t>(run.start));
                         for (size_t i = jb.a; i < jb.b; ++i) {
                             const uint16_t bin = bins[i];
-                            if (bin == 0xffffu) {   // no posterior (0 / 0): whatever the host pass makes of this host's NaN
-                                volatile double zero = 0.0;
-                                o.value<3>(static_cast<float>(hmm_log_odds(zero / zero)));
+                            if (bin >= 0xfffeu) {   // a NaN posterior (a raw score that is "nan"): printed as the host pass prints a NaN of that sign
+                                o.value<3>(static_cast<float>(hmm_log_odds(std::copysign(std::numeric_limits<double>::quiet_NaN(), bin == 0xfffeu ? -1.0 : 1.0))));
                                 continue;
                             }
                             const int code = PRINTED_CODE_MIN + static_cast<int>(bin);
