@@ -123,6 +123,7 @@ def _write_raw_tracks(d, rng):
             pos = run("chrA", 70000, pos + 9, values=np.zeros(70000))
             pos = run("chrB", 1200, 7)
             lines.extend(["-0.0", "3.0", "12.5", "-7.25"])   # fewer decimals than three
+            lines.extend(["250.5", "-350.125", "1234.5", "1.23456", "1e-3", "-2.5E1", "0.0005"])   # beyond the emission table, more than three decimals, exponents
             pos = run("chrC", 40, 100)
             lines.append("nan")                              # what a NaN score looks like in a raw track: the whole run has no posterior
             lines.extend(fmt(float(v)) for v in np.round(rng.normal(-5.0, 8.0, size=30), 3))
