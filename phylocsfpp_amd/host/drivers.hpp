@@ -441,20 +441,28 @@ inline std::vector<double> printed_code_thresholds(int threads)
 {
     const size_t n = static_cast<size_t>(PRINTED_CODE_MAX - PRINTED_CODE_MIN);
     std::vector<double> thr(n);
-    parallel_for(n, threads, [&](size_t j) {
-        const int want = PRINTED_CODE_MIN + 1 + static_cast<int>(j);
+    constexpr size_t PARTS = 256;   // a task per threshold would spend its time handing out tasks
+    parallel_for(PARTS, threads, [&](size_t part) {
         auto as_double = [](uint64_t b) { double d; memcpy(&d, &b, 8); return d; };
-        uint64_t lo = 0, hi;   // bit patterns of non-negative doubles order like the doubles
         const double one = 1.0;
-        memcpy(&hi, &one, 8);
-        if (printed_code(0.0) >= want) { thr[j] = 0.0; return; }
-        if (printed_code(1.0) < want) { thr[j] = std::numeric_limits<double>::infinity(); return; }
-        while (hi - lo > 1) {   // code(lo) < want <= code(hi)
-            const uint64_t mid = lo + (hi - lo) / 2;
-            if (printed_code(as_double(mid)) >= want) hi = mid;
-            else lo = mid;
+        uint64_t one_bits;
+        memcpy(&one_bits, &one, 8);
+        const int code0 = printed_code(0.0), code1 = printed_code(1.0);
+        uint64_t floor_bits = 0;   // thresholds ascend: the one before bounds the search from below
+        for (size_t j = n * part / PARTS; j < n * (part + 1) / PARTS; ++j) {
+            const int want = PRINTED_CODE_MIN + 1 + static_cast<int>(j);
+            if (code0 >= want) { thr[j] = 0.0; continue; }
+            if (code1 < want) { thr[j] = std::numeric_limits<double>::infinity(); continue; }
+            uint64_t lo = floor_bits, hi = one_bits;   // bit patterns of non-negative doubles order like the doubles; code(lo) < want <= code(hi)
+            if (printed_code(as_double(lo)) >= want) lo = 0;   // (cannot happen for ascending codes; keeps the invariant whatever libm does)
+            while (hi - lo > 1) {
+                const uint64_t mid = lo + (hi - lo) / 2;
+                if (printed_code(as_double(mid)) >= want) hi = mid;
+                else lo = mid;
+            }
+            thr[j] = as_double(hi);
+            floor_bits = lo;   // code(lo) < want <= the next code wanted
         }
-        thr[j] = as_double(hi);
     });
     return thr;
 }
