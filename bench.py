@@ -22,7 +22,10 @@ Prints ONE JSON line on rank 0.  Extra objects:
                   files out -- run in child processes (reference: src/phylocsf++build_tracks.hpp:55-260, README.rst:116)
   "blocks"        (N = 1) the other half of BASELINE.json configs[2]: `phylocsf-amd score-msa --strategy mle|omega` on the same
                   synthetic MAF in child processes (reference: src/run.hpp:59-182 per block, src/phylocsf++score_msa.hpp:94-127):
-                  blocks/s, codon columns/s, rounds, evaluations, which pruning kernel; "cpu" = oracle_cli on a prefix of the file
+                  blocks/s, codon columns/s, rounds, evaluations, which pruning kernel and engine; "roofline" = the products the pruning
+                  kernels executed (counted on the device) x 131,072 FLOP over the scoring seconds, against the fp64-MFMA peak;
+                  "cpu" = oracle_cli on a prefix of the file
+  "other_models"  (N = 1) prune_fixed on 53birds (BASELINE.json configs[1]) and 100vertebrates (configs[4]): three steps each, roofline
   "cpu_baseline"  (N = 1) the CPU oracle, a reference-structured port, on this host's cores: kernel level on a sample of
                   the same batch ("value"), the same CLI driver on the same MAF ("end_to_end_value"), one thread
                   ("single_thread_value")
@@ -304,7 +307,8 @@ def end_to_end_multi(n_gpus, work_dir):
 
 MSA_RE = re.compile(r"(\d+) blocks, (\d+) codon columns; seconds: total ([\d.]+) \(MAF read \+ translation \+ branch-length scores ([\d.]+), "
                     r"scoring backend ([\d.]+), output ([\d.]+)\)")
-ROUNDS_RE = re.compile(r"run_(?:mle|omega): (\d+) blocks \((\d+) on the factored path\), (\d+) rounds, (\d+) evaluations")
+ROUNDS_RE = re.compile(r"run_(?:mle|omega): (\d+) blocks, (\w+) engine, (\w+): (\d+) rounds, (\d+) evaluations \((\d+) with a new eigen-system\): set-up ([\d.]+) s, rounds ([\d.]+) s")
+PRODUCTS_RE = re.compile(r"run_(?:mle|omega): pruning products (\d+) =")
 KERNEL_RE = re.compile(r"pruning kernel of this list: (\w+)")
 
 
@@ -324,7 +328,9 @@ def run_score_msa(binary, strategy, maf, out_dir, extra_args=(), env=None):
     k = KERNEL_RE.search(p.stderr)
     return {"blocks": int(m.group(1)), "codon_columns": int(m.group(2)), "seconds": float(m.group(3)), "read_seconds": float(m.group(4)),
             "scoring_seconds": float(m.group(5)), "process_wall_seconds": wall,
-            "rounds_max": max([int(r[2]) for r in rounds], default=None), "evaluations": sum(int(r[3]) for r in rounds) or None,
+            "rounds_max": max([int(r[3]) for r in rounds], default=None), "evaluations": sum(int(r[4]) for r in rounds) or None,
+            "eigen_solves": sum(int(r[5]) for r in rounds), "engine": rounds[0][1] if rounds else None,
+            "products": sum(int(x) for x in PRODUCTS_RE.findall(p.stderr)),
             "groups": len(rounds) or None, "pruning_kernel": k.group(1) if k else None,
             "scores": os.path.join(out_dir, os.path.basename(maf) + ".scores")}
 
@@ -358,7 +364,18 @@ def block_strategies(device, maf, work_dir, runs):
                "process_wall_seconds": min(r["process_wall_seconds"] for r in gpu_runs),
                "blocks_per_s": best["blocks"] / best["scoring_seconds"], "codon_columns_per_s": best["codon_columns"] / best["scoring_seconds"],
                "blocks_per_s_process_wall": best["blocks"] / min(r["process_wall_seconds"] for r in gpu_runs),
-               "rounds": best["rounds_max"], "evaluations": best["evaluations"], "block_groups": best["groups"], "pruning_kernel": best["pruning_kernel"]}
+               "rounds": best["rounds_max"], "evaluations": best["evaluations"], "eigen_solves": best["eigen_solves"], "block_groups": best["groups"],
+               "pruning_kernel": best["pruning_kernel"], "engine": best["engine"]}
+        # Roofline of the leg: the matrix work the pruning kernels EXECUTED -- every tile job counts its 64x64 x 64x16 products on the device
+        # (FactoredParams::product_count), 64 x v_mfma_f64_16x16x4_f64 = 131,072 FLOP each -- over the scoring seconds of the whole call
+        # (engine set-up, every round's eigen-solver / edge-scale / pruning launches, the host's share).  Not counted: the eigen-solver's
+        # Jacobi sweeps (vector fp64, ~0.3 MFLOP per solve) and the element-wise work.
+        flop = best["products"] * 131072.0
+        leg["roofline"] = {"bound": "mfma", "achieved": flop / best["scoring_seconds"] / 1e12, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": flop / best["scoring_seconds"] / 1e12 / PEAK_FP64_MFMA_TFLOPS, "executed_products": best["products"],
+                           "executed_tflop": flop / 1e12, "seconds": best["scoring_seconds"],
+                           "kernels": "pcsf::%s (products), pcsf::eigen_omega_kernel, pcsf::edge_scale_kernel, pcsf::advance_blocks" % best["pruning_kernel"],
+                           "note": "whole-call fraction; the kernel split is in profiles/r04/config3_%s_kernel_stats.csv" % strategy}
         # CPU: a prefix sized for ~20 s (an OMEGA block costs the oracle ~5.5 MLE blocks)
         per_block = per_block_mle * (1.0 if strategy == "mle" else 5.5)
         frac = min(1.0, max(0.002, 20.0 / (per_block * best["blocks"])))
@@ -398,6 +415,7 @@ def main():
                     help="codon-frames for the CPU baseline sample (default: sized for ~10 s; 0 disables the CPU legs)")
     ap.add_argument("--end-to-end-runs", type=int, default=3, help="build-tracks CLI runs on the synthetic 1 Mb MAF (0 disables; N = 1 only)")
     ap.add_argument("--block-runs", type=int, default=2, help="score-msa --strategy mle / omega runs on the same MAF (0 disables; N = 1 only)")
+    ap.add_argument("--other-models", type=int, default=1, help="1: also time prune_fixed on 53birds and 100vertebrates (three steps each; N = 1 only)")
     ap.add_argument("--keep-files", default=None, help="directory for the synthetic MAF and the wig files (default: a temporary one)")
     args = ap.parse_args()
 
@@ -497,6 +515,39 @@ def main():
     codons_host = codons[:, :min(n_sites, 1 << 20)].cpu().numpy() if rank == 0 else None
     del codons, scores
 
+    # the same kernel on the other two models the reference ships and BASELINE.json's configs name (53birds: configs[1]; 100vertebrates:
+    # configs[4]): three steps each on synthetic columns of that model's tree, HIP events on the launch stream
+    other_models = None
+    if rank == 0 and world == 1 and args.other_models:
+        other_models = {}
+        for name in ("53birds", "100vertebrates"):
+            try:
+                m2 = pa.load_model(name)
+                c2 = m2.context(device=local_rank)
+                pool2 = torch.from_numpy(make_pool(m2, seed=E2E_SEED)).to(dev)
+                cod2 = sample_columns(pool2, 0, args.sites, E2E_SEED)
+                sc2 = torch.empty(args.sites, dtype=torch.float64, device=dev)
+                c2.score_sites_fixed_torch(cod2, out=sc2)      # warm-up
+                c2.set_timing(True)
+                d2 = []
+                for _ in range(3):
+                    c2.score_sites_fixed_torch(cod2, out=sc2)
+                    d2.append(c2.last_kernel_ms())
+                c2.set_timing(False)
+                torch.cuda.synchronize()
+                ms = float(np.mean(d2))
+                fl2 = flop_per_site(m2.nl)
+                tf = args.sites * fl2 / (ms * 1e-3) / 1e12
+                other_models[name] = {"n_leaves": int(m2.nl), "codon_frames": args.sites, "steps": 3, "kernel_ms": ms, "codon_frames_per_s": args.sites / (ms * 1e-3),
+                                      "flop_per_codon_frame": fl2,
+                                      "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_MFMA_TFLOPS,
+                                                   "kernel": "pcsf::prune_fixed"}}
+                c2.close()
+                del pool2, cod2, sc2
+            except Exception as ex:
+                other_models[name] = {"error": str(ex)[-500:]}
+        torch.cuda.empty_cache()
+
     strong = None
     if args.scaling == "weak" and args.strong_steps > 0:
         lo, hi = bounds[rank]
@@ -540,6 +591,8 @@ def main():
         }
         if strong is not None:
             out["strong"] = strong
+        if other_models:
+            out["other_models"] = other_models
         if world == 1 and args.cpu_baseline_sites != 0:
             budget = args.cpu_baseline_sites
             if budget < 0:

@@ -189,6 +189,9 @@ int pcsf_hmm_smooth_runs_binned(pcsf_ctx *ctx, const double *init, const double 
                                 size_t n_thresholds, uint16_t *out_bins, uint64_t *exc_index, double *exc_value,
                                 size_t exc_capacity, size_t *n_exceptions, uint8_t *out_back, double *out_last,
                                 pcsf_hmm_stats *stats);
+/* The two calls above keep their device buffers (~60 bytes per value of the largest call so far) on the context for the next call;
+ * this frees them (a caller that has finished its smoothing pass).  They are also freed by pcsf_destroy. */
+int pcsf_hmm_release(pcsf_ctx *ctx);
 
 /* ---- run (src/run.hpp:57-211): whole-block scores -----------------------------------------
  * A batch of blocks in CSR form: block b owns sites [site_offsets[b], site_offsets[b+1]) of the
@@ -202,6 +205,19 @@ int pcsf_hmm_smooth_runs_binned(pcsf_ctx *ctx, const double *init, const double 
 int pcsf_score_blocks(pcsf_ctx *ctx, int algo, const uint8_t *codons, const uint64_t *site_offsets,
                       size_t n_blocks, size_t leaf_stride, int compute_anc, uint32_t seed,
                       float *out_phylo, float *out_anc);
+/* Which kernel prunes the blocks of MLE / OMEGA calls on this context.  The engine has two -- prune_tiles for dense blocks, prune_factored
+ * for the short sparse blocks of real alignments -- whose sums round differently (objective values differ by ~1e-13, OMEGA end results by
+ * more: DESIGN.md section 5).  PCSF_BLOCK_KERNEL_AUTO (the default) lets every pcsf_score_blocks call pick one from ITS list (the mean
+ * number of species with a codon per block), so a list scored whole and the same list cut into several calls -- or across several
+ * devices -- may use different kernels.  A caller that cuts a list and wants the reference's guarantee that parallelisation does not
+ * change a result (src/phylocsf++score_msa.hpp:115) decides ONCE, with pcsf_choose_block_kernel on the whole list, and pins the answer
+ * on every context it uses (the command line's score-msa does).  The environment variable PCSF_BLOCK_KERNEL=tiles|factored overrides both. */
+typedef enum { PCSF_BLOCK_KERNEL_AUTO = 0, PCSF_BLOCK_KERNEL_TILES = 1, PCSF_BLOCK_KERNEL_FACTORED = 2 } pcsf_block_kernel;
+int pcsf_set_block_kernel(pcsf_ctx *ctx, int kernel);
+/* Host-only (no GPU needed): the AUTO rule evaluated on a list -- PCSF_BLOCK_KERNEL_TILES or PCSF_BLOCK_KERNEL_FACTORED; a negative
+ * pcsf_status on bad arguments.  n_leaves: rows of the codon matrix. */
+int pcsf_choose_block_kernel(int32_t n_leaves, const uint8_t *codons, const uint64_t *site_offsets, size_t n_blocks,
+                             size_t leaf_stride);
 /* Optional, no reference counterpart: a caller that WILL call pcsf_score_blocks with MLE or OMEGA says so early (the
  * command line: before it reads the alignment file).  Returns at once; the device queues the lock-step engine works on
  * are created on a thread of the library's meanwhile (~11 ms each the first time, 35 ms of a 55 ms MLE call on 516
@@ -273,6 +289,11 @@ int pcsf_build_schedule(int32_t n_nodes, const int16_t *child1, const int16_t *c
  * `skip_draws` 32-bit draws; returns the evaluation points in order and the value of the LAST one. */
 int pcsf_debug_maxlik(double (*objective)(double x, void *user), void *user, double init, double lo, double hi,
                       uint32_t seed, int skip_draws, double *xs_out, int cap, int *n_evals, double *last_lpr);
+/* The same search ON THE DEVICE (the state machine the MLE / OMEGA engine runs per block, csrc/chain.hip), fed with a RECORDED sequence of
+ * objective values: the points it asks for go to xs_out (at most cap), *n_requests = how many it asked for, or -1 when it wanted more
+ * values than n_values.  A search that takes the decisions of the one that produced `values` asks for exactly its points. */
+int pcsf_debug_maxlik_device(pcsf_ctx *ctx, double init, double lo, double hi, uint32_t seed, int skip_draws, const double *values,
+                             int n_values, double *xs_out, int cap, int *n_requests, double *last_lpr);
 const char *pcsf_version(void);
 
 /* Optional: page-locked host memory for the buffers handed to the scoring calls.  Transfers from/to such buffers

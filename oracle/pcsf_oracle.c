@@ -425,17 +425,41 @@ int po_make_all_P(const po_qdiag *qd, const po_tree *tree, double x, double *P)
  * pruning
  * ---------------------------------------------------------------------------------------- */
 
+/* CONTROL EXPERIMENT ONLY (tests/golden/make_omega_control.py, profiles/r04/omega_control.txt): the same algorithm with the terms of
+ * some sums added in another order -- every objective value moves by a few ulp, nothing else changes.  Shows how far the END results of
+ * the MLE / OMEGA procedures move under a perturbation of that size, i.e. how much of the difference between two implementations
+ * (this oracle and the HIP path; two builds of the reference) the procedure itself accounts for.  Bits: 1 = the 64-term sums of
+ * internal-node and gap messages run from state 63 down to 0; 2 = the root sum runs backwards; 4 = a block's site log-likelihoods are
+ * added from the last site to the first.  0 (the default, and what every parity test uses) = the reference's order.
+ * PO_PERTURB=<bits> in the environment sets it for the command-line driver. */
+static int g_perturb = -1;
+void po_set_perturbation(int bits) { g_perturb = bits; }
+static inline int perturbation(void)
+{
+    if (g_perturb < 0) {
+        const char *e = getenv("PO_PERTURB");
+        g_perturb = e ? atoi(e) : 0;
+    }
+    return g_perturb;
+}
+
 /* src/fixed_lik.hpp:105-123 */
-static inline double child_msg(const double *Prow, int is_leaf, uint8_t code, const double *alpha)
+static inline double child_msg(const double *Prow, int is_leaf, uint8_t code, const double *alpha, int reversed)
 {
     if (!is_leaf) {
         double d = 0.0;
-        for (int b = 0; b < K; ++b) d += Prow[b] * alpha[b];
+        if (reversed)
+            for (int b = K - 1; b >= 0; --b) d += Prow[b] * alpha[b];
+        else
+            for (int b = 0; b < K; ++b) d += Prow[b] * alpha[b];
         return d;
     }
     if (code == PO_GAP) {
         double d = 0.0;
-        for (int b = 0; b < K; ++b) d += Prow[b];
+        if (reversed)
+            for (int b = K - 1; b >= 0; --b) d += Prow[b];
+        else
+            for (int b = 0; b < K; ++b) d += Prow[b];
         return d;
     }
     return Prow[code];
@@ -446,6 +470,7 @@ double po_prune_site(const po_tree *tree, const double *P, const double *prior, 
                      size_t leaf_stride, size_t site, double *alpha_root)
 {
     const int n = tree->n, nl = tree->nl;
+    const int pert = perturbation(), rev = pert & 1;
     double alpha[(PO_MAX_NODES / 2 + 1) * K];
     for (int i = nl; i < n; ++i) {
         const int lc = tree->child1[i], rc = tree->child2[i];
@@ -457,14 +482,17 @@ double po_prune_site(const po_tree *tree, const double *P, const double *prior, 
         const double *ra = r_leaf ? NULL : alpha + (size_t)(rc - nl) * K;
         double *out = alpha + (size_t)(i - nl) * K;
         for (int a = 0; a < K; ++a) {
-            const double r1 = child_msg(ls + a * K, l_leaf, lcode, la);
-            const double r2 = child_msg(rs + a * K, r_leaf, rcode, ra);
+            const double r1 = child_msg(ls + a * K, l_leaf, lcode, la, rev);
+            const double r2 = child_msg(rs + a * K, r_leaf, rcode, ra, rev);
             out[a] = r1 * r2;
         }
     }
     const double *ar = alpha + (size_t)(n - 1 - nl) * K;
     double z = 0.0;
-    for (int a = 0; a < K; ++a) z += prior[a] * ar[a];
+    if (pert & 2)
+        for (int a = K - 1; a >= 0; --a) z += prior[a] * ar[a];
+    else
+        for (int a = 0; a < K; ++a) z += prior[a] * ar[a];
     if (alpha_root) memcpy(alpha_root, ar, sizeof(double) * K);
     return z;
 }
@@ -489,7 +517,9 @@ int po_lpr_leaves(const po_qdiag *qd, const po_tree *tree, double x, const uint8
     if (compute_anc)
         for (int i = 0; i < K; ++i) lprior[i] = log(qd->prior[i]);
     double l = 0.0, anc = 0.0;
-    for (size_t s = 0; s < n_sites; ++s) {
+    const int backwards = (perturbation() & 4) != 0;   /* control experiment only, see po_set_perturbation */
+    for (size_t k = 0; k < n_sites; ++k) {
+        const size_t s = backwards ? n_sites - 1 - k : k;
         const double z = po_prune_site(tree, P, qd->prior, codons, leaf_stride, s, compute_anc ? ar : NULL);
         const double lz = log(z);
         l += lz;

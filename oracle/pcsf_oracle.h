@@ -118,6 +118,10 @@ int po_run_blocks(const po_model *m, int algo, const uint8_t *codons, const uint
                   size_t n_blocks, size_t leaf_stride, int compute_anc, uint32_t seed, float *phylo,
                   float *anc, int threads);
 
+/* control experiment only (pcsf_oracle.c, "CONTROL EXPERIMENT"): other summation orders; 0 = the reference's.  Not thread-safe: set
+ * it before any run. */
+void po_set_perturbation(int bits);
+
 /* number of objective evaluations done by the last po_run on this thread (diagnostics) */
 long po_last_eval_count(void);
 

@@ -71,6 +71,10 @@ def load_library():
     lib.pcsf_score_blocks.argtypes = [vp, C.c_int, u8p, C.POINTER(C.c_uint64), C.c_size_t, C.c_size_t, C.c_int,
                                       C.c_uint32, fp, fp]
     lib.pcsf_prepare_block_scoring.argtypes = [vp, C.c_int]
+    lib.pcsf_set_block_kernel.argtypes = [vp, C.c_int]
+    lib.pcsf_debug_maxlik_device.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_int, dp, C.c_int, dp, C.c_int,
+                                             C.POINTER(C.c_int), dp]
+    lib.pcsf_choose_block_kernel.argtypes = [C.c_int32, u8p, C.POINTER(C.c_uint64), C.c_size_t, C.c_size_t]
     lib.pcsf_score_alignments_6frames.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(_AlignmentDesc), C.c_size_t, dp, C.c_size_t,
                                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.pcsf_score_alignments_6frames_bls.argtypes = lib.pcsf_score_alignments_6frames.argtypes + [dp]
@@ -336,6 +340,33 @@ class ScoringContext:
     def prepare_block_scoring(self, algo):
         """Optional: score_blocks(algo, ...) is coming -- its device queues are created in the background meanwhile."""
         self._check(self._lib.pcsf_prepare_block_scoring(self._h, int(algo)))
+
+    BLOCK_KERNEL_AUTO, BLOCK_KERNEL_TILES, BLOCK_KERNEL_FACTORED = 0, 1, 2
+
+    def set_block_kernel(self, kernel):
+        """Pins the pruning kernel of MLE / OMEGA calls (pcsf_set_block_kernel).  AUTO lets every score_blocks call pick from its own
+        list: a caller that cuts one list into several calls and wants identical scores pins choose_block_kernel(whole list)."""
+        self._check(self._lib.pcsf_set_block_kernel(self._h, int(kernel)))
+
+    def choose_block_kernel(self, codons, site_offsets):
+        """The AUTO rule evaluated on a list (host only): BLOCK_KERNEL_TILES or BLOCK_KERNEL_FACTORED."""
+        codons = np.ascontiguousarray(codons, dtype=np.uint8)
+        off = np.ascontiguousarray(site_offsets, dtype=np.uint64)
+        k = self._lib.pcsf_choose_block_kernel(self.n_leaves, codons.ctypes.data_as(C.POINTER(C.c_uint8)), off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                               len(off) - 1, codons.strides[0])
+        if k < 0:
+            raise ValueError("pcsf_choose_block_kernel: bad argument")
+        return k
+
+    def debug_maxlik_device(self, init, lo, hi, values, seed=42, skip_draws=0):
+        """Tests: the 1-D maximiser of the MLE / OMEGA engine on the device, fed with recorded objective values.  Returns
+        (points asked for, number of requests or -1, last value)."""
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        xs = np.zeros(len(values) + 8)
+        n, last = C.c_int(), C.c_double()
+        self._check(self._lib.pcsf_debug_maxlik_device(self._h, init, lo, hi, seed, skip_draws, values.ctypes.data_as(C.POINTER(C.c_double)), len(values),
+                                                       xs.ctypes.data_as(C.POINTER(C.c_double)), len(xs), C.byref(n), C.byref(last)))
+        return xs, n.value, last.value
 
     def score_blocks(self, algo, codons, site_offsets, compute_anc=True, seed=42):
         codons = np.ascontiguousarray(codons, dtype=np.uint8)

@@ -10,6 +10,7 @@
 #include <memory>
 #include <new>
 #include <mutex>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -238,23 +239,70 @@ void pcsf_host_free(void* p)
 // host-only helper: drives the lock-step optimiser's state machine (optimizer.hpp) with a caller-supplied
 // objective; records the evaluation points.  Lets the tests check that it takes exactly the decisions
 // of the reference's fit_find_init + GSL Brent without a GPU in the loop.
+// the restart points a search over [lo, hi] draws from a std::mt19937 in state `gen` (optimizer.hpp DrawTable)
+static std::vector<double> debug_draw_table(std::mt19937 gen, double lo, double hi, size_t n)
+{
+    std::vector<double> t(n);
+    const double width = std::log(hi) - std::log(lo);
+    for (double& x : t) {
+        std::uniform_real_distribution<> dis(0.0, width);
+        const double r = dis(gen);
+        x = std::exp(std::log(lo) + r);
+    }
+    return t;
+}
+
 int pcsf_debug_maxlik(double (*objective)(double x, void* user), void* user, double init, double lo, double hi, uint32_t seed,
                       int skip_draws, double* xs_out, int cap, int* n_evals, double* last_lpr)
 {
     if (!objective || !n_evals || !last_lpr) return PCSF_ERR_INVALID_ARG;
     std::mt19937 gen(seed);
     for (int i = 0; i < skip_draws; ++i) (void)gen();
+    const std::vector<double> table = debug_draw_table(gen, lo, hi, 260);
+    const pcsf::DrawTable dt{table.data(), static_cast<uint32_t>(table.size())};
+    uint32_t next = 0;
     pcsf::MaxLik1D opt;
-    opt.start(init, lo, hi, &gen);
+    opt.start(init, lo, hi);
     int n = 0;
     while (!opt.done()) {
         const double x = opt.request();
         if (xs_out && n < cap) xs_out[n] = x;
         ++n;
-        opt.supply(objective(x, user), 0.0);
+        opt.supply(objective(x, user), 0.0, dt, next);
     }
     *n_evals = n;
     *last_lpr = opt.last_lpr();
+    return PCSF_OK;
+}
+
+// The same state machine ON THE DEVICE (chain.hip maxlik_replay_kernel: the code advance_blocks runs per block), fed with a recorded
+// sequence of objective values: equal histories give equal requests, so a search that decides like the one that produced `values`
+// asks for exactly its points.  *n_requests = -1 when it wanted more values than were recorded.
+int pcsf_debug_maxlik_device(pcsf_ctx* c, double init, double lo, double hi, uint32_t seed, int skip_draws, const double* values, int n_values,
+                             double* xs_out, int cap, int* n_requests, double* last_lpr)
+{
+    if (!c) return PCSF_ERR_INVALID_ARG;
+    if (!values || n_values <= 0 || !xs_out || cap <= 0 || !n_requests || !last_lpr) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_debug_maxlik_device: bad argument");
+    hipError_t e;
+    if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
+    std::mt19937 gen(seed);
+    for (int i = 0; i < skip_draws; ++i) (void)gen();
+    const std::vector<double> table = debug_draw_table(gen, lo, hi, 260);
+    pcsf::DeviceBuffer d_table, d_values, d_xs, d_n, d_last;
+    if ((e = d_table.reserve(table.size() * 8)) != hipSuccess || (e = d_values.reserve(size_t(n_values) * 8)) != hipSuccess ||
+        (e = d_xs.reserve(size_t(cap) * 8)) != hipSuccess || (e = d_n.reserve(sizeof(int))) != hipSuccess || (e = d_last.reserve(16)) != hipSuccess)
+        return c->hip_fail(e, "hipMalloc");
+    double last[2] = {0, 0};
+    if ((e = hipMemcpyAsync(d_table.ptr, table.data(), table.size() * 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(d_values.ptr, values, size_t(n_values) * 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess ||
+        (e = hipMemsetAsync(d_xs.ptr, 0, size_t(cap) * 8, c->stream)) != hipSuccess ||
+        (e = pcsf::launch_maxlik_replay(init, lo, hi, d_table.as<double>(), static_cast<uint32_t>(table.size()), d_values.as<double>(), n_values, d_xs.as<double>(), cap,
+                                        d_n.as<int>(), d_last.as<double>(), c->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(xs_out, d_xs.ptr, size_t(cap) * 8, hipMemcpyDeviceToHost, c->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(n_requests, d_n.ptr, sizeof(int), hipMemcpyDeviceToHost, c->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(last, d_last.ptr, 16, hipMemcpyDeviceToHost, c->stream)) != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess)
+        return c->hip_fail(e, "pcsf_debug_maxlik_device");
+    *last_lpr = last[0];
     return PCSF_OK;
 }
 
@@ -818,6 +866,29 @@ int pcsf_score_blocks(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
         return pcsf::score_blocks_impl(c, algo, codons, site_offsets, n_blocks, leaf_stride, compute_anc, seed, out_phylo, out_anc);
     } catch (const std::exception& ex) {
         return c->fail(PCSF_ERR_HIP, std::string("pcsf_score_blocks: ") + ex.what());
+    }
+}
+
+int pcsf_set_block_kernel(pcsf_ctx* c, int kernel)
+{
+    if (!c) return PCSF_ERR_INVALID_ARG;
+    if (kernel != PCSF_BLOCK_KERNEL_AUTO && kernel != PCSF_BLOCK_KERNEL_TILES && kernel != PCSF_BLOCK_KERNEL_FACTORED)
+        return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_set_block_kernel: bad argument");
+    c->block_kernel = kernel;
+    return PCSF_OK;
+}
+
+int pcsf_choose_block_kernel(int32_t n_leaves, const uint8_t* codons, const uint64_t* site_offsets, size_t n_blocks, size_t leaf_stride)
+{
+    if (n_leaves <= 0 || (n_blocks > 0 && !site_offsets)) return PCSF_ERR_INVALID_ARG;
+    for (size_t b = 0; b < n_blocks; ++b)
+        if (site_offsets[b + 1] < site_offsets[b]) return PCSF_ERR_INVALID_ARG;
+    if (n_blocks > 0 && site_offsets[n_blocks] > site_offsets[0] && (!codons || leaf_stride < site_offsets[n_blocks])) return PCSF_ERR_INVALID_ARG;
+    try {
+        return pcsf::list_prefers_tiles(static_cast<size_t>(n_leaves), codons, leaf_stride, site_offsets, n_blocks) ? PCSF_BLOCK_KERNEL_TILES
+                                                                                                                        : PCSF_BLOCK_KERNEL_FACTORED;
+    } catch (...) {
+        return PCSF_ERR_HIP;
     }
 }
 

@@ -26,9 +26,11 @@
 #include <random>
 #include <stdexcept>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "ctx.hpp"
+#include "machine.hpp"
 #include "optimizer.hpp"
 
 namespace pcsf {
@@ -85,28 +87,16 @@ static bool block_prefers_factored(const pcsf_ctx* c, const uint8_t* codons, siz
     return factored_cost <= explicit_cost;
 }
 
-// Which pruning kernel a LIST of blocks gets (see BlockEngine::use_tiles): prune_tiles when, on average, at least 16 species have a
-// codon in a block.  PCSF_BLOCK_KERNEL=tiles|factored overrides; PCSF_FACTORED_MAX_TILES (round 2's path rule) implies factored.
-static bool list_prefers_tiles(const pcsf_ctx* c, const uint8_t* codons, size_t stride, const uint64_t* off, size_t n_blocks)
+// Which pruning kernel the blocks of a call get (see BlockEngine::use_tiles).  PCSF_BLOCK_KERNEL=tiles|factored overrides everything;
+// PCSF_FACTORED_MAX_TILES (round 2's path rule) implies factored; then what the caller pinned (pcsf_set_block_kernel: the command line
+// decides once per FILE, before it cuts the file into per-device lists); else the AUTO rule on this call's list.
+static bool call_uses_tiles(const pcsf_ctx* c, const uint8_t* codons, size_t stride, const uint64_t* off, size_t n_blocks)
 {
     if (std::getenv("PCSF_FACTORED_MAX_TILES")) return false;
     if (const char* v = std::getenv("PCSF_BLOCK_KERNEL")) return std::string(v) != "factored";
-    if (!codons || n_blocks == 0) return true;
-    const size_t nl = static_cast<size_t>(c->n_leaves);
-    std::atomic<uint64_t> present{0}, counted{0};
-    parallel_for(n_blocks, [&](size_t b) {
-        if (off[b + 1] == off[b]) return;
-        uint64_t n = 0;
-        for (size_t l = 0; l < nl; ++l) {
-            const uint8_t* row = codons + l * stride;
-            bool any = false;
-            for (uint64_t s = off[b]; s < off[b + 1] && !any; ++s) any = row[s] < 64;
-            n += any;
-        }
-        present += n;
-        counted += 1;
-    });
-    return counted == 0 || static_cast<double>(present) >= 16.0 * static_cast<double>(counted);
+    if (c->block_kernel == PCSF_BLOCK_KERNEL_TILES) return true;
+    if (c->block_kernel == PCSF_BLOCK_KERNEL_FACTORED) return false;
+    return list_prefers_tiles(static_cast<size_t>(c->n_leaves), codons, stride, off, n_blocks);
 }
 
 struct BlockEngine {
@@ -172,6 +162,13 @@ struct BlockEngine {
     std::vector<TileGroup> tgroups[2];
     TileGroup* p_tgroups = nullptr;
     std::vector<uint32_t> order_scratch;
+    DeviceBuffer d_products;     // products (64 MFMAs each) the pruning kernels of this engine ran: the executed work, read under PCSF_TIME_BLOCKS
+    unsigned long long products_run()
+    {
+        unsigned long long v = 0;
+        if (d_products.ptr) (void)hipMemcpy(&v, d_products.ptr, sizeof v, hipMemcpyDeviceToHost);
+        return v;
+    }
     DeviceBuffer d_fact_stamps;  // PCSF_FACTORED_STAMPS: cycle sums of prune_factored (printed when the engine goes away)
     bool fact_stamp_classes = false;   // PCSF_FACTORED_STAMPS=2: also per class of op (every op that runs is stamped: ~400 cycles each)
     std::vector<ExpmEval> fevals[2];
@@ -241,12 +238,14 @@ struct BlockEngine {
         if (fixed_max_tiles >= 0) use_tiles = false;   // the tile-count rule is a statement about round 2's two paths
         if (const char* v = std::getenv("PCSF_TILE_JOBS")) tile_jobs_per_group = static_cast<size_t>(std::max(1, std::atoi(v)));
         if (const char* v = std::getenv("PCSF_EIGEN_HOST")) host_eigen = std::atoi(v) != 0;
+        HIP_TRY(d_products.reserve(sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(d_products.ptr, 0, sizeof(unsigned long long), stream));
         if (const char* fs = std::getenv("PCSF_FACTORED_STAMPS")) {
             fact_stamp_classes = std::atoi(fs) >= 2;
             HIP_TRY(d_fact_stamps.reserve(16 * sizeof(unsigned long long)));
             HIP_TRY(hipMemsetAsync(d_fact_stamps.ptr, 0, 16 * sizeof(unsigned long long), stream));
         }
-        block_factored.assign(nb, use_tiles ? 1 : 0);
+        block_factored.assign(nb, (use_tiles || fixed_max_tiles < 0) ? 1 : 0);   // the explicit path (expm + block-mode prune_fixed) only under PCSF_FACTORED_MAX_TILES
         block_tiles.assign(nb, use_tiles ? 1 : 0);
         // which rows of each leaf's message table the block's sites read (values above 64 count as 64, like the kernel): only the
         // explicit path writes tables, and only a caller-supplied eigen-system or PCSF_BLOCK_KERNEL=factored can take it (20 ms of a
@@ -265,7 +264,7 @@ struct BlockEngine {
                     leaf_codes[(b * nl + l) * 2] = lo;
                     leaf_codes[(b * nl + l) * 2 + 1] = hi;
                 }
-                if (!use_tiles) block_factored[b] = block_prefers_factored(c, codons, stride, offsets[b], offsets[b + 1], fixed_max_tiles);
+                if (!use_tiles && fixed_max_tiles >= 0) block_factored[b] = block_prefers_factored(c, codons, stride, offsets[b], offsets[b + 1], fixed_max_tiles);
             });
         }
         mark("row masks / path rule");
@@ -641,6 +640,7 @@ struct BlockEngine {
                 fp.deep = c->schedule.stack_depth > MAX_STACK_DEPTH ? 1u : 0u;
                 fp.stamps = d_fact_stamps.ptr ? d_fact_stamps.as<unsigned long long>() : nullptr;
                 fp.stamp_classes = fact_stamp_classes ? 1u : 0u;
+                fp.product_count = d_products.as<unsigned long long>();
                 if (ntj) {
                     fp.jobs = p_tjobs + t_at;
                     fp.n_jobs = static_cast<uint32_t>(ntj);
@@ -722,58 +722,6 @@ struct BlockEngine {
     }
 };
 
-// values an optimiser stage has seen: the objective is a pure function of the point, so a point asked for
-// again (the reference re-evaluates lo, hi and the chosen start when it sets up Brent) is served from here
-struct EvalStore {
-    struct Entry {
-        double x, lpr, anc;
-        bool failed;
-        mutable bool used = false;   // diagnostics: the optimiser consumed this value (speculative evaluations may never be)
-    };
-    std::vector<Entry> entries;
-    size_t n_used = 0, n_unused = 0;   // over the stages cleared so far
-    const Entry* find(double x) const
-    {
-        for (const Entry& e : entries)
-            if (e.x == x) return &e;
-        return nullptr;
-    }
-    void tally()
-    {
-        for (const Entry& e : entries) (e.used ? n_used : n_unused) += 1;
-    }
-    void clear()
-    {
-        tally();
-        entries.clear();
-    }
-};
-
-constexpr int MAX_POINTS_PER_ROUND = 12;   // per block: certain points first, then speculative restarts
-constexpr int MAX_SPECULATIVE_RESTARTS = 8;
-// Random restarts are evaluated ahead of knowing that a search needs any only while fewer blocks than this are active: with
-// thousands of blocks a round is bound by its work, not its latency, and a third of OMEGA's evaluations were such restarts
-// that no optimiser ever asked for (PCSF_EAGER_RESTARTS_BELOW overrides)
-inline size_t eager_restarts_below()
-{
-    static const size_t v = [] {
-        const char* e = std::getenv("PCSF_EAGER_RESTARTS_BELOW");
-        return e ? static_cast<size_t>(std::max(0L, std::atol(e))) : size_t(1024);
-    }();
-    return v;
-}
-
-struct Lookahead {  // MaxLik1D::upcoming() of one block for the current round
-    int n = 0;
-    double x[MAX_POINTS_PER_ROUND];
-    bool seen_before(int rank) const  // the same point earlier in the list (lo, hi, chosen recur when Brent is set up)
-    {
-        for (int i = 0; i < rank; ++i)
-            if (x[i] == x[rank]) return true;
-        return false;
-    }
-};
-
 inline float decibans(double a, double b) { return static_cast<float>(10.0 * (a - b) / std::log(10.0)); }
 
 // ---- FIXED -------------------------------------------------------------------------------------
@@ -808,216 +756,343 @@ int run_fixed(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
     return PCSF_OK;
 }
 
+// ---- MLE / OMEGA: blocks as chains of rounds ------------------------------------------------------------------------------------
+// A block's optimisation alternates between its machine (machine.hpp: which points next?) and the evaluation of those points
+// (eigen-systems -> edge scales -> pruning).  Two engines drive the same machines:
+//   device (the default): the machines live in HBM and run in chain.hip's advance_blocks; per round the host reads 64 bytes of counters
+//       and launches the round's kernels with the job lists the device wrote.  Nothing of a block's search crosses PCIe.
+//   host (PCSF_BLOCK_ENGINE=host, rounds 1-3's lock-step engine): the machines run on host threads, the evaluations are queued through
+//       BlockEngine::queue / run with one upload and one download blob per round.  Kept as the A/B reference; same bits.
+
+// the restart points of one search range: libstdc++'s generator and distribution, the host's exp / log -- what MaxLik1D drew itself
+// until round 3 (optimizer.hpp DrawTable)
+std::vector<double> make_draw_table(uint32_t seed, double lo, double hi)
+{
+    std::vector<double> t(DRAW_TABLE_ENTRIES);
+    std::mt19937 g(seed);
+    const double width = std::log(hi) - std::log(lo);
+    for (double& x : t) {
+        std::uniform_real_distribution<> dis(0.0, width);
+        const double r = dis(g);
+        x = std::exp(std::log(lo) + r);
+    }
+    return t;
+}
+
+inline bool use_device_engine()
+{
+    const char* v = std::getenv("PCSF_BLOCK_ENGINE");
+    return !(v && std::string(v) == "host");
+}
+// Random restarts are evaluated ahead of knowing that a search needs any only for short lists: with thousands of blocks a round is
+// bound by its work, not its latency, and a third of OMEGA's evaluations were such restarts that no optimiser ever asked for
+// (PCSF_EAGER_RESTARTS_BELOW overrides).  Decided from the length of the CALL's list; no result depends on it.
+inline size_t eager_restarts_below()
+{
+    static const size_t v = [] {
+        const char* e = std::getenv("PCSF_EAGER_RESTARTS_BELOW");
+        return e ? static_cast<size_t>(std::max(0L, std::atol(e))) : size_t(1024);
+    }();
+    return v;
+}
+
+struct ChainStats {
+    size_t rounds = 0, evals = 0, eig_jobs = 0, tile_jobs = 0;
+    double t_setup = 0.0, t_rounds = 0.0, t_wait = 0.0;
+};
+
+// The device engine: `machines` (initialised by the caller) are uploaded, advanced on the device until none is active, and downloaded.
+template <class Machine>
+void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool want_anc, uint32_t seed, bool eager, uint32_t transient0, bool held_systems,
+               const std::atomic<bool>* stop, ChainStats& st)
+{
+    const auto t_enter = std::chrono::steady_clock::now();
+    constexpr bool MLE = std::is_same<Machine, MleMachine>::value;
+    const LookaheadPolicy look = lookahead_policy(eager);
+    const uint32_t P = static_cast<uint32_t>(MLE ? 2 * look.max_points : look.max_points);   // evaluation slots per block
+    const size_t nb = eng.n_blocks, n_sites = eng.n_sites_total;
+    hipStream_t st0 = eng.stream;
+    size_t total_tiles = 0;
+    for (size_t b = 0; b < nb; ++b) total_tiles += (eng.off[b + 1] - eng.off[b] + 15) / 16;
+    DeviceBuffer d_machines, d_stores, d_off, d_draws, d_counters, d_evals, d_eig_jobs, d_jobs, d_groups, d_lnz, d_anc, d_fail;
+    BlockEngine::PinnedBuffer h_counters;
+    HIP_TRY(d_machines.reserve(nb * sizeof(Machine)));
+    HIP_TRY(d_stores.reserve(nb * (MLE ? 2 : 1) * STORE_ENTRIES * sizeof(StoreEntry)));
+    HIP_TRY(d_off.reserve((nb + 1) * sizeof(uint64_t)));
+    HIP_TRY(d_draws.reserve(3 * DRAW_TABLE_ENTRIES * sizeof(double)));
+    HIP_TRY(d_counters.reserve(sizeof(ChainCounters)));
+    HIP_TRY(h_counters.reserve(sizeof(ChainCounters)));
+    HIP_TRY(d_evals.reserve(nb * P * sizeof(ExpmEval)));
+    if (!MLE) HIP_TRY(d_eig_jobs.reserve(nb * P * sizeof(EigenJob)));
+    HIP_TRY(d_jobs.reserve(std::max<size_t>(1, total_tiles) * P * sizeof(FactoredJob)));
+    const size_t group_cap = std::max<size_t>(1, total_tiles) * P;
+    if (eng.use_tiles) HIP_TRY(d_groups.reserve(4 * group_cap * sizeof(TileGroup)));
+    HIP_TRY(d_lnz.reserve(std::max<size_t>(1, n_sites) * P * sizeof(double)));
+    if (want_anc) HIP_TRY(d_anc.reserve(std::max<size_t>(1, n_sites) * P * sizeof(double)));
+    HIP_TRY(d_fail.reserve(nb * P * sizeof(uint32_t)));
+    eng.reserve_tables(nb * P);   // edge-scale rows, one per evaluation slot
+    const std::vector<double> t_mle = make_draw_table(seed, 1e-2, 10.0), t_rho = make_draw_table(seed, 0.001, 10.0), t_kappa = make_draw_table(seed, 1.0, 10.0);
+    HIP_TRY(hipMemcpyAsync(d_draws.as<double>(), t_mle.data(), DRAW_TABLE_ENTRIES * sizeof(double), hipMemcpyHostToDevice, st0));
+    HIP_TRY(hipMemcpyAsync(d_draws.as<double>() + DRAW_TABLE_ENTRIES, t_rho.data(), DRAW_TABLE_ENTRIES * sizeof(double), hipMemcpyHostToDevice, st0));
+    HIP_TRY(hipMemcpyAsync(d_draws.as<double>() + 2 * DRAW_TABLE_ENTRIES, t_kappa.data(), DRAW_TABLE_ENTRIES * sizeof(double), hipMemcpyHostToDevice, st0));
+    HIP_TRY(hipMemcpyAsync(d_machines.ptr, machines.data(), nb * sizeof(Machine), hipMemcpyHostToDevice, st0));
+    HIP_TRY(hipMemcpyAsync(d_off.ptr, eng.off, (nb + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st0));
+    HIP_TRY(hipMemsetAsync(d_fail.ptr, 0, nb * P * sizeof(uint32_t), st0));
+    HIP_TRY(hipStreamSynchronize(st0));   // the draw tables are locals
+
+    ChainParams cp{};
+    cp.machines = d_machines.ptr;
+    cp.stores = d_stores.as<StoreEntry>();
+    cp.off = d_off.as<uint64_t>();
+    cp.slots_per_block = P;
+    cp.out_lnz = d_lnz.as<double>();
+    cp.out_anc = want_anc ? d_anc.as<double>() : nullptr;
+    cp.fail = d_fail.as<uint32_t>();
+    for (int k = 0; k < 3; ++k) cp.draws[k] = d_draws.as<double>() + k * DRAW_TABLE_ENTRIES;
+    cp.n_draws = DRAW_TABLE_ENTRIES;
+    cp.eager = eager ? 1u : 0u;
+    cp.max_points = static_cast<uint32_t>(look.max_points);
+    cp.max_restarts = static_cast<uint32_t>(look.max_restarts);
+    cp.held_systems = held_systems ? 1u : 0u;
+    cp.transient0 = transient0;
+    cp.use_tiles = eng.use_tiles ? 1u : 0u;
+    cp.split_sizes = (eng.use_tiles && nb >= 1024) ? 1u : 0u;   // short lists: one launch of full work-groups (a launch that does not fill the chip is bound by one tile's latency)
+    cp.counters = d_counters.as<ChainCounters>();
+    cp.evals = d_evals.as<ExpmEval>();
+    cp.eig_jobs = MLE ? nullptr : d_eig_jobs.as<EigenJob>();
+    cp.tile_jobs = d_jobs.as<FactoredJob>();
+    cp.groups = eng.use_tiles ? d_groups.as<TileGroup>() : nullptr;
+    cp.group_capacity = static_cast<uint32_t>(group_cap);
+    // MLE on prune_tiles: every block uses the same two eigen-systems, so the tile jobs of a round go to one list per model and any four
+    // consecutive jobs of a list share a work-group (full work-groups whatever the blocks' lengths); the groups are the same every round
+    const bool pack_models = MLE && eng.use_tiles;
+    cp.pack_models = pack_models ? 1u : 0u;
+    cp.list_capacity = static_cast<uint32_t>(group_cap / 2);
+    if (pack_models) {
+        std::vector<TileGroup> fixed(group_cap / 2 / TILE_JOBS_PER_GROUP + 1);
+        for (size_t g = 0; g < fixed.size(); ++g) fixed[g] = TileGroup{static_cast<uint32_t>(g * TILE_JOBS_PER_GROUP), TILE_JOBS_PER_GROUP};
+        HIP_TRY(hipMemcpyAsync(d_groups.ptr, fixed.data(), fixed.size() * sizeof(TileGroup), hipMemcpyHostToDevice, st0));
+        HIP_TRY(hipStreamSynchronize(st0));   // `fixed` is a local
+    }
+
+    FactoredParams fp{};
+    fp.codons = eng.d_codons.template as<uint8_t>();
+    fp.leaf_stride = n_sites;
+    fp.program = eng.c->d_program.template as<uint32_t>();
+    fp.n_ops = static_cast<int>(eng.c->schedule.program.size());
+    fp.slot_branch = eng.d_slot_branch.template as<int32_t>();
+    fp.op_leaves = eng.c->d_op_meta.ptr ? eng.c->d_op_leaves.template as<uint64_t>() : nullptr;
+    fp.op_meta = eng.c->d_op_meta.ptr ? eng.c->d_op_meta.template as<uint32_t>() : nullptr;
+    fp.n_edges = eng.ne;
+    fp.n_leaves = eng.nl;
+    fp.n_branches = static_cast<uint32_t>(eng.n - 1);
+    fp.eig_right = eng.d_eig_r.template as<double>();
+    fp.eig_left = eng.d_eig_l.template as<double>();
+    fp.eig_w = eng.d_eig_w.template as<double>();
+    fp.prior = eng.d_prior.template as<double>();
+    fp.anc_weight = eng.d_ancw.template as<double>();
+    fp.edge_scale = eng.d_scale.template as<double>();
+    fp.out_lnz = d_lnz.as<double>();
+    fp.out_anc = want_anc ? d_anc.as<double>() : nullptr;
+    fp.deep = eng.c->schedule.stack_depth > MAX_STACK_DEPTH ? 1u : 0u;
+    fp.stamps = eng.d_fact_stamps.ptr ? eng.d_fact_stamps.template as<unsigned long long>() : nullptr;
+    fp.stamp_classes = eng.fact_stamp_classes ? 1u : 0u;
+    fp.product_count = eng.d_products.template as<unsigned long long>();
+    EigenParams gp{};
+    gp.jobs = cp.eig_jobs;
+    gp.eig_right = eng.d_eig_r.template as<double>();
+    gp.eig_left = eng.d_eig_l.template as<double>();
+    gp.eig_lambda = eng.d_eig_lam.template as<double>();
+    gp.eig_basis = eng.d_eig_basis.template as<double>();
+    gp.prior = eng.d_prior.template as<double>();
+    gp.anc_weight = eng.d_ancw.template as<double>();
+    gp.eig_w = eng.d_eig_w.template as<double>();
+    gp.fail = d_fail.as<uint32_t>();
+    st.t_setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count();
+
+    const auto t_loop = std::chrono::steady_clock::now();
+    const ChainCounters* hc = static_cast<const ChainCounters*>(h_counters.ptr);
+    for (;;) {
+        if (stop && stop->load(std::memory_order_relaxed)) throw std::runtime_error("another group of this call failed");
+        HIP_TRY(hipMemsetAsync(d_counters.ptr, 0, sizeof(ChainCounters), st0));
+        HIP_TRY(launch_advance_blocks(cp, MLE ? 0 : 2, static_cast<uint32_t>(nb), st0));
+        HIP_TRY(hipMemcpyAsync(h_counters.ptr, d_counters.ptr, sizeof(ChainCounters), hipMemcpyDeviceToHost, st0));
+        const auto t_w = std::chrono::steady_clock::now();
+        HIP_TRY(hipStreamSynchronize(st0));
+        st.t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w).count();
+        const ChainCounters cnt = *hc;
+        if (cnt.n_active == 0) break;
+        ++st.rounds;
+        st.evals += cnt.n_evals;
+        st.eig_jobs += cnt.n_eig_jobs;
+        st.tile_jobs += cnt.n_tile_jobs;
+        if (cnt.n_evals > nb * P || cnt.n_tile_jobs > group_cap || cnt.n_list[0] > group_cap / 2 || cnt.n_list[1] > group_cap / 2)
+            throw std::runtime_error("advance_blocks: a job list overflowed");
+        if (cnt.n_eig_jobs) {
+            if (eng.host_eigen) throw std::runtime_error("PCSF_EIGEN_HOST needs PCSF_BLOCK_ENGINE=host");
+            gp.n_jobs = cnt.n_eig_jobs;
+            HIP_TRY(launch_eigen_omega(gp, st0));
+        }
+        HIP_TRY(launch_edge_scale(cp.evals, cnt.n_evals, static_cast<uint32_t>(eng.n - 1), eng.d_branch_len.template as<float>(), eng.d_eig_r.template as<double>(),
+                                  eng.d_eig_l.template as<double>(), eng.d_eig_lam.template as<double>(), eng.d_scale.template as<double>(), d_fail.as<uint32_t>(), st0));
+        fp.jobs = cp.tile_jobs;
+        fp.n_jobs = cnt.n_tile_jobs;
+        if (pack_models) {
+            for (int model = 0; model < 2; ++model) {
+                if (!cnt.n_list[model]) continue;
+                st.tile_jobs += cnt.n_list[model];
+                fp.jobs = cp.tile_jobs + static_cast<size_t>(model) * cp.list_capacity;
+                fp.n_jobs = cnt.n_list[model];
+                fp.groups = cp.groups;
+                fp.n_groups = (cnt.n_list[model] + TILE_JOBS_PER_GROUP - 1) / TILE_JOBS_PER_GROUP;
+                HIP_TRY(launch_prune_tiles_sized(fp, static_cast<int>(TILE_JOBS_PER_GROUP), st0));
+            }
+        } else if (eng.use_tiles) {
+            for (int list = 3; list >= 0; --list) {   // largest work-groups first (tiles.hip launch_tiles_impl)
+                if (!cnt.n_groups[list]) continue;
+                fp.groups = cp.groups + static_cast<size_t>(list) * group_cap;
+                fp.n_groups = cnt.n_groups[list];
+                HIP_TRY(launch_prune_tiles_sized(fp, cp.split_sizes ? list + 1 : static_cast<int>(TILE_JOBS_PER_GROUP), st0));
+            }
+        } else if (cnt.n_tile_jobs) {
+            fp.groups = nullptr;
+            fp.n_groups = 0;
+            HIP_TRY(launch_prune_factored(fp, st0));
+        }
+    }
+    st.t_rounds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
+    HIP_TRY(hipMemcpyAsync(machines.data(), d_machines.ptr, nb * sizeof(Machine), hipMemcpyDeviceToHost, st0));
+    HIP_TRY(hipStreamSynchronize(st0));
+}
+
+// The host engine: the same machines, advanced on host threads; a round's requests go through BlockEngine::queue / run.
+// prior values (OMEGA) come from the device's math library like the device engine's (chain.hip), so that both add the same bits.
+struct HostRound {
+    std::vector<EvalRequest> req;      // [n_blocks][max requests]
+    std::vector<int> n_req;
+    std::vector<size_t> eval0;         // index of the block's first evaluation in the engine's run
+    std::vector<EvalResult> res;       // [n_blocks][max requests]
+};
+
+template <class Machine, class Before, class Advance>
+void run_host_rounds(BlockEngine& eng, std::vector<Machine>& machines, uint32_t max_req, bool want_anc, const std::atomic<bool>* stop, ChainStats& st, Before before_round,
+                     Advance advance)
+{
+    const size_t nb = eng.n_blocks;
+    eng.reserve_tables(std::max<size_t>(64, nb * max_req));
+    HostRound hr;
+    hr.req.resize(nb * max_req);
+    hr.n_req.assign(nb, 0);
+    hr.eval0.assign(nb, 0);
+    hr.res.resize(nb * max_req);
+    const auto t_loop = std::chrono::steady_clock::now();
+    for (;;) {
+        if (stop && stop->load(std::memory_order_relaxed)) throw std::runtime_error("another group of this call failed");
+        before_round();
+        parallel_for(nb, [&](size_t b) { hr.n_req[b] = advance(b, hr.res.data() + b * max_req, hr.req.data() + b * max_req); });
+        size_t active = 0, queued = 0;
+        for (size_t b = 0; b < nb; ++b) {
+            active += machines[b].active;
+            hr.eval0[b] = queued;
+            for (int i = 0; i < hr.n_req[b]; ++i, ++queued) {
+                const EvalRequest& r = hr.req[b * max_req + i];
+                eng.queue(b, r.eig, r.tree_scale, r.new_eigen == 1 ? r.qs : nullptr, r.new_eigen == 2, r.warm);
+                st.eig_jobs += r.new_eigen == 1;
+            }
+        }
+        if (!active) break;
+        ++st.rounds;
+        st.evals += queued;
+        const auto t_w = std::chrono::steady_clock::now();
+        eng.run(want_anc);
+        st.t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w).count();
+        parallel_for(nb, [&](size_t b) {
+            for (int i = 0; i < hr.n_req[b]; ++i) {
+                EvalResult& r = hr.res[b * max_req + i];
+                const size_t k = hr.eval0[b] + i;
+                r.lnz = eng.value(k, eng.lnz);
+                r.anc = want_anc ? eng.value(k, eng.anc) : 0.0;
+                r.failed = eng.failed(k) ? 1u : 0u;
+            }
+        });
+    }
+    st.t_rounds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
+}
+
+void print_chain_stats(const char* what, size_t n_blocks, bool device, bool tiles, const ChainStats& st, double whole, unsigned long long products)
+{
+    // executed matrix work of the pruning kernels: a product is 64 x v_mfma_f64_16x16x4_f64 = 131,072 FLOP (the eigen-solver's warm starts and
+    // the element-wise work are not counted)
+    fprintf(stderr, "%s: pruning products %llu = %.4g TFLOP executed on the matrix cores\n", what, products, static_cast<double>(products) * 131072.0 * 1e-12);
+    fprintf(stderr, "%s: %zu blocks, %s engine, %s: %zu rounds, %zu evaluations (%zu with a new eigen-system): set-up %.3f s, rounds %.3f s (of which waiting for the device %.3f s), whole call %.3f s\n",
+            what, n_blocks, device ? "device" : "host", tiles ? "prune_tiles" : "prune_factored", st.rounds, st.evals, st.eig_jobs, st.t_setup, st.t_rounds, st.t_wait, whole);
+}
+
 // ---- MLE ---------------------------------------------------------------------------------------
 int run_mle(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_blocks, size_t leaf_stride, int compute_anc,
-            uint32_t seed, float* out_phylo, float* out_anc, bool tiles, bool own_streams, const std::atomic<bool>* stop)
+            uint32_t seed, float* out_phylo, float* out_anc, bool tiles, bool own_streams, bool eager, const std::atomic<bool>* stop)
 {
-    const auto t_setup = std::chrono::steady_clock::now();
+    const auto t_enter = std::chrono::steady_clock::now();
     BlockEngine eng(c, codons, off, n_blocks, leaf_stride, tiles, own_streams);
-    eng.reserve_tables(std::max<size_t>(64, 2 * n_blocks));
     eng.reserve_eig(2);
     eng.upload_eig(0, c->eig[0], c->pi[0].data());
     eng.upload_eig(1, c->eig[1], c->pi[1].data());
-    std::vector<std::mt19937> gen(n_blocks);
-    std::vector<MaxLik1D> opt[2] = {std::vector<MaxLik1D>(n_blocks), std::vector<MaxLik1D>(n_blocks)};
-    std::vector<EvalStore> store[2] = {std::vector<EvalStore>(n_blocks), std::vector<EvalStore>(n_blocks)};
-    std::vector<double> res_lpr(2 * n_blocks, 0.0), res_anc(2 * n_blocks, 0.0);
-    std::vector<char> failed(n_blocks, 0), started1(n_blocks, 0);
-    for (size_t b = 0; b < n_blocks; ++b) gen[b].seed(seed);
-    struct Pending {
-        size_t block, eval;
-        double x;
-        int model;
-    };
-    // The reference optimises the coding model, then the non-coding one (src/run.hpp:193-194), drawing the random restarts of both
-    // from one generator per block.  The two searches are independent otherwise, and a search draws only BEFORE its Brent iteration
-    // (MaxLik1D::draws_finished): the non-coding search of a block starts as soon as the coding one has drawn its last number, sees
-    // the same numbers as it would afterwards, and the two advance in the same rounds -- half the rounds, the same results.
-    for (size_t b = 0; b < n_blocks; ++b) opt[0][b].start(1.0, 1e-2, 10.0, &gen[b]);
-    const bool timing = std::getenv("PCSF_TIME_BLOCKS") != nullptr;  // diagnostics: where the rounds spend their time
-    const auto t_enter = std::chrono::steady_clock::now();
-    double t_run = 0.0;
-    size_t rounds = 0, n_evals = 0;
-    for (;;) {
-        if (stop && stop->load(std::memory_order_relaxed)) return PCSF_ERR_HIP;   // another group of this call has failed: its error is the one reported
-        // feed every optimiser from its store; blocks without a codon have lpr = 0 at every scale
-        size_t active = 0;
-        for (size_t b = 0; b < n_blocks; ++b) {
-            for (int model = 0; model < 2 && !failed[b]; ++model) {
-                if (model == 1) {
-                    if (!started1[b]) {
-                        if (!opt[0][b].draws_finished()) break;
-                        opt[1][b].start(1.0, 1e-2, 10.0, &gen[b]);
-                        started1[b] = 1;
-                    }
-                }
-                MaxLik1D& o = opt[model][b];
-                while (!o.done()) {
-                    if (off[b + 1] == off[b]) {
-                        o.supply(0.0, 0.0);
-                        continue;
-                    }
-                    const EvalStore::Entry* e = store[model][b].find(o.request());
-                    if (!e) break;
-                    if (e->failed) {  // std::runtime_error in PhyloModel_make -> NaN row
-                        failed[b] = 1;
-                        break;
-                    }
-                    e->used = true;
-                    o.supply(e->lpr, e->anc);
-                }
-            }
-            if (!failed[b] && (!opt[0][b].done() || !started1[b] || !opt[1][b].done())) ++active;
-        }
-        if (!active) break;
-        // queue the points the active optimisers will or may need: rank 0 (certain) for everybody first
-        std::vector<Pending> pending;
-        std::vector<Lookahead> ahead[2] = {std::vector<Lookahead>(n_blocks), std::vector<Lookahead>(n_blocks)};
-        for (size_t b = 0; b < n_blocks; ++b)
-            for (int model = 0; model < 2; ++model)
-                if (!failed[b] && (model == 0 || started1[b]) && !opt[model][b].done())
-                    ahead[model][b].n = opt[model][b].upcoming(ahead[model][b].x, MAX_POINTS_PER_ROUND, MAX_SPECULATIVE_RESTARTS, active < eager_restarts_below());
-        for (int rank = 0; rank < MAX_POINTS_PER_ROUND && eng.free_evaluations() > 0; ++rank) {
-            bool any = false;
-            for (int model = 0; model < 2; ++model)
-                for (size_t b = 0; b < n_blocks && eng.free_evaluations() > 0; ++b) {
-                    if (rank >= ahead[model][b].n) continue;
-                    any = true;
-                    const double x = ahead[model][b].x[rank];
-                    if (store[model][b].find(x) || ahead[model][b].seen_before(rank)) continue;
-                    pending.push_back({b, eng.queue(b, static_cast<uint32_t>(model), x, nullptr), x, model});
-                }
-            if (!any) break;
-        }
-        const auto t_a = std::chrono::steady_clock::now();
-        eng.run(compute_anc != 0);
-        t_run += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count();
-        ++rounds;
-        n_evals += pending.size();
-        for (const Pending& q : pending)
-            store[q.model][q.block].entries.push_back({q.x, eng.value(q.eval, eng.lnz), compute_anc ? eng.value(q.eval, eng.anc) : 0.0, eng.failed(q.eval)});
+    std::vector<MleMachine> machines(n_blocks);
+    for (size_t b = 0; b < n_blocks; ++b) machines[b].init(static_cast<uint32_t>(off[b + 1] - off[b]));
+    ChainStats st;
+    const bool device = use_device_engine() && !eng.host_eigen;
+    if (device) {
+        run_chain(eng, machines, PCSF_MLE, compute_anc != 0, seed, eager, 0u, true, stop, st);
+    } else {
+        const std::vector<double> table = make_draw_table(seed, 1e-2, 10.0);
+        std::vector<StoreEntry> stores(n_blocks * 2 * STORE_ENTRIES);
+        const DrawTable dt{table.data(), DRAW_TABLE_ENTRIES};
+        const LookaheadPolicy look = lookahead_policy(eager);
+        run_host_rounds(eng, machines, 2 * look.max_points, compute_anc != 0, stop, st, [] {}, [&](size_t b, const EvalResult* res, EvalRequest* out) {
+            return machines[b].round(res, stores.data() + b * 2 * STORE_ENTRIES, dt, look.eager, look.max_points, look.max_restarts, compute_anc != 0, out);
+        });
     }
-    if (timing) {
+    if (std::getenv("PCSF_TIME_BLOCKS")) {
         size_t used = 0, unused = 0;
-        for (int model = 0; model < 2; ++model)
-            for (size_t b = 0; b < n_blocks; ++b) {
-                store[model][b].tally();
-                used += store[model][b].n_used;
-                unused += store[model][b].n_unused;
-            }
-        fprintf(stderr, "run_mle: %zu evaluations consumed by the optimisers, %zu speculative ones never asked for\n", used, unused);
-        const double all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count();
-        fprintf(stderr, "run_mle: %zu blocks (%zu on the factored path), %zu rounds, %zu evaluations: host %.3f s, device rounds %.3f s; engine set-up %.3f s\n", n_blocks,
-                static_cast<size_t>(std::count(eng.block_factored.begin(), eng.block_factored.end(), 1)), rounds, n_evals, all - t_run, t_run,
-                std::chrono::duration<double>(t_enter - t_setup).count());
-    }
-    for (int model = 0; model < 2; ++model)
-        for (size_t b = 0; b < n_blocks; ++b) {
-            res_lpr[model * n_blocks + b] = opt[model][b].last_lpr();
-            res_anc[model * n_blocks + b] = opt[model][b].last_anc();
+        for (const MleMachine& m : machines) {
+            used += m.used;
+            unused += m.unused;
         }
+        fprintf(stderr, "run_mle: %zu evaluations consumed by the optimisers, %zu speculative ones never asked for\n", used, unused);
+        print_chain_stats("run_mle", n_blocks, device, eng.use_tiles, st, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count(), eng.products_run());
+    }
     for (size_t b = 0; b < n_blocks; ++b) {
-        if (failed[b]) {
+        const MleMachine& m = machines[b];
+        if (m.failed) {
             out_phylo[b] = NAN;
             if (out_anc) out_anc[b] = NAN;
             continue;
         }
-        out_phylo[b] = decibans(res_lpr[b], res_lpr[n_blocks + b]);
-        if (out_anc) out_anc[b] = decibans(res_anc[b], res_anc[n_blocks + b]);
+        out_phylo[b] = decibans(m.opt[0].last_lpr(), m.opt[1].last_lpr());
+        if (out_anc) out_anc[b] = decibans(m.opt[0].last_anc(), m.opt[1].last_anc());
     }
     return PCSF_OK;
 }
 
 // ---- OMEGA -------------------------------------------------------------------------------------
-// Eigen-systems a block keeps between rounds, by role.  OWN: the model the block is at.  LO / HI: kappa = 1 and kappa = 10, the ends
-// every kappa stage evaluates first -- the three kappa stages of a hypothesis ask for the SAME two rate matrices.  P0 / P1: the last two
-// interior kappa probes (Brent's steps shrink geometrically: the nearest earlier probe is a far better start for the Jacobi iteration
-// than the stage's first point).  A probe whose settings equal a held system is not solved again (a fifth of all solves on the
-// configs[2] list), every other probe starts from the nearest held system of its family (same omega, sigma, frequencies).  Roles map
-// to physical slots through `slot`, so that the system of a stage's last probe BECOMES the block's own by a swap when the stage ends.
-enum EigRole { ROLE_OWN = 0, ROLE_LO = 1, ROLE_HI = 2, ROLE_P0 = 3, ROLE_P1 = 4, N_ROLES = 5 };
-struct OmegaBlock {
-    double q_settings[12];      // kappa, omega, sigma, nine ratios: the model the block is AT (src/run.hpp:75-79)
-    double eig_settings[12];    // settings the block's own eigen-system slot currently holds
-    bool eig_valid = false;
-    uint32_t slot[N_ROLES];     // physical eigen-system slot of every role
-    double held[N_ROLES][12];   // settings the role's slot holds (OWN: eig_settings / eig_valid above)
-    bool held_valid[N_ROLES] = {false, false, false, false, false};
-    int next_p = 0;             // which of P0 / P1 the next interior probe overwrites
-    double tree_scale = 1.0;
-    std::mt19937 gen;
-    MaxLik1D opt;
-    EvalStore store;
-    int stage = 0;  // 0..5: H0 (rho,kappa)x3 ; 6..11: H1 (rho,kappa)x3 ; 12 = finished
-    double lpr_h0 = 0.0, lpr_h1 = 0.0;
-    bool failed = false, done = false;
-    bool needs_validation = false;  // the model was re-instantiated (PhyloModel_make can throw) and must be checked
-};
-
 int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_blocks, size_t leaf_stride, uint32_t seed,
-              float* out_phylo, float* out_anc, bool tiles, bool own_streams, const std::atomic<bool>* stop)
+              float* out_phylo, float* out_anc, bool tiles, bool own_streams, bool eager, const std::atomic<bool>* stop)
 {
     const auto t_enter = std::chrono::steady_clock::now();
     BlockEngine eng(c, codons, off, n_blocks, leaf_stride, tiles, own_streams);
-    const size_t cap = std::max<size_t>(64, 2 * n_blocks);
-    eng.reserve_tables(cap);
-    // slots [role * n_blocks + b]: the eigen-systems block b holds (EigRole; roles are swapped between them, see OmegaBlock);
-    // slots N_ROLES * n_blocks + k: speculative kappa probes of a round (random restarts nobody may ask for)
+    // eigen-system slots [role * n_blocks + b]: what block b holds (EigRole; roles are swapped between them, see OmegaMachine);
+    // slots N_ROLES * n_blocks + b * max_points + k: the probes of a round that are not kept (random restarts)
     const bool held_systems = !(std::getenv("PCSF_OMEGA_HELD_SYSTEMS") && std::atoi(std::getenv("PCSF_OMEGA_HELD_SYSTEMS")) == 0);
     const size_t transient0 = N_ROLES * n_blocks;
-    eng.reserve_eig(transient0 + cap);
-    const double t_setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count();
-    std::vector<std::unique_ptr<OmegaBlock>> blk(n_blocks);
-    const long trace_block = std::getenv("PCSF_TRACE_BLOCK") ? std::atol(std::getenv("PCSF_TRACE_BLOCK")) : -1;  // diagnostics
+    const LookaheadPolicy look = lookahead_policy(eager);
+    eng.reserve_eig(transient0 + n_blocks * look.max_points);
     const size_t nl = static_cast<size_t>(c->n_leaves);
-
-    // Validation-only pass (PhyloModel_make can throw): rebuild the listed blocks' eigen-systems from their
-    // q_settings, build their matrices at their tree scale and read the flags.
-    auto validate_all = [&](const std::vector<size_t>& which) {
-        for (size_t at = 0; at < which.size();) {
-            std::vector<std::pair<size_t, size_t>> queued;
-            for (; at < which.size() && eng.free_evaluations() > 0; ++at) {
-                OmegaBlock& ob = *blk[which[at]];
-                queued.push_back({which[at], eng.queue(which[at], ob.slot[ROLE_OWN], ob.tree_scale, ob.q_settings, false,
-                                                       ob.eig_valid ? static_cast<int32_t>(ob.slot[ROLE_OWN]) : -1)});
-                std::memcpy(ob.eig_settings, ob.q_settings, sizeof ob.q_settings);
-                ob.eig_valid = true;
-            }
-            eng.run(false);
-            for (const auto& q : queued)
-                if (eng.failed(q.second)) blk[q.first]->failed = true;
-        }
-    };
-
-    std::vector<size_t> live;
-    for (size_t b = 0; b < n_blocks; ++b) {
-        blk[b].reset(new OmegaBlock);
-        OmegaBlock& ob = *blk[b];
-        ob.gen.seed(seed);
-        for (int r = 0; r < N_ROLES; ++r) ob.slot[r] = static_cast<uint32_t>(r * n_blocks + b);
-        // POLICY ("OMEGA NaN rows"): the reference yields NaN for every block without a
-        // complete codon (GSL's non-symmetric eigen-solver degrades on the uniform F3x4 matrix)
-        if (off[b + 1] == off[b]) {
-            ob.failed = true;
-            continue;
-        }
-        live.push_back(b);
-        ob.q_settings[0] = 2.5;  // kappa, omega, sigma, nine ratios (src/run.hpp:75-79)
-        ob.q_settings[1] = 1.0;
-        ob.q_settings[2] = 1.0;
-        for (int i = 3; i < 12; ++i) ob.q_settings[i] = 1.0;
-    }
-    const auto tp0 = std::chrono::steady_clock::now();
-    validate_all(live);
-    const auto tp1 = std::chrono::steady_clock::now();
+    std::vector<OmegaMachine> machines(n_blocks);
     // F3x4 nucleotide counts over every non-gap codon of every row (src/run.hpp:105-134)
-    parallel_for(live.size(), [&](size_t i) {
-        OmegaBlock& ob = *blk[live[i]];
-        if (ob.failed) return;
+    parallel_for(n_blocks, [&](size_t b) {
         double cnt[3][4];
         for (auto& r : cnt)
             for (double& v : r) v = 1.0;
-        const size_t b = live[i];
         for (size_t l = 0; l < nl; ++l)
             for (uint64_t s = off[b]; s < off[b + 1]; ++s) {
                 const uint8_t cd = codons[l * leaf_stride + s];
@@ -1027,238 +1102,75 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
                     cnt[2][cd & 3] += 1;
                 }
             }
+        double ratios[9];
         for (int p = 0; p < 3; ++p)
-            for (int j = 0; j < 3; ++j) ob.q_settings[3 + 3 * p + j] = cnt[p][j] / cnt[p][3];
+            for (int j = 0; j < 3; ++j) ratios[3 * p + j] = cnt[p][j] / cnt[p][3];
+        uint32_t slots[N_ROLES];
+        for (int r = 0; r < N_ROLES; ++r) slots[r] = static_cast<uint32_t>(r * n_blocks + b);
+        machines[b].init(static_cast<uint32_t>(off[b + 1] - off[b]), slots, ratios);
     });
-    const auto tp2 = std::chrono::steady_clock::now();
-    {
-        std::vector<size_t> ok;
-        for (size_t b : live)
-            if (!blk[b]->failed) ok.push_back(b);
-        validate_all(ok);
-    }
-    if (std::getenv("PCSF_TIME_BLOCKS"))
-        fprintf(stderr, "run_omega prelude: first validation %.3f s, F3x4 counts %.3f s, second validation %.3f s\n", std::chrono::duration<double>(tp1 - tp0).count(),
-                std::chrono::duration<double>(tp2 - tp1).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - tp2).count());
-
-    auto start_stage = [&](OmegaBlock& ob) {
-        ob.store.clear();
-        if ((ob.stage % 2) == 0) ob.opt.start(ob.tree_scale, 0.001, 10.0, &ob.gen);
-        else ob.opt.start(ob.q_settings[0], 1.0, 10.0, &ob.gen);
-    };
-    for (size_t b : live)
-        if (!blk[b]->failed) start_stage(*blk[b]);
-
-    const bool timing = std::getenv("PCSF_TIME_BLOCKS") != nullptr;  // diagnostics: where the rounds spend their time
-    const double t_prelude = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count() - t_setup;
-    double t_host = 0.0, t_run = 0.0;
-    size_t rounds = 0, evals = 0, eig_evals = 0, eig_reused = 0, eig_adopted = 0;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-    struct Pending {
-        size_t block, eval;
-        double x;
-    };
-    for (;;) {
-        if (stop && stop->load(std::memory_order_relaxed)) return PCSF_ERR_HIP;   // another group of this call has failed: its error is the one reported
-        const auto t0 = now();
-        // (1) feed every optimiser from its store; finished stages move the block on
-        size_t active = 0;
-        for (size_t b : live) {
-            OmegaBlock& ob = *blk[b];
-            while (!ob.failed && !ob.done && !ob.needs_validation) {
-                if (ob.opt.done()) {
-                    // max_lik_lpr_leaves returned: the model stays at the LAST evaluated point
-                    if ((ob.stage % 2) == 0) {
-                        ob.tree_scale = ob.opt.last_x();
-                    } else {
-                        ob.q_settings[0] = ob.opt.last_x();
-                        // the model stays at the stage's LAST probe -- whose eigen-system, if it was kept, becomes the block's own by a
-                        // swap of roles instead of being solved once more at the next rho evaluation
-                        for (int role = ROLE_LO; role < N_ROLES && held_systems; ++role)
-                            if (ob.held_valid[role] && std::memcmp(ob.held[role], ob.q_settings, sizeof ob.q_settings) == 0) {
-                                std::swap(ob.slot[ROLE_OWN], ob.slot[role]);
-                                double tmp[12];
-                                std::memcpy(tmp, ob.eig_settings, sizeof tmp);
-                                std::memcpy(ob.eig_settings, ob.held[role], sizeof tmp);
-                                std::memcpy(ob.held[role], tmp, sizeof tmp);
-                                std::swap(ob.eig_valid, ob.held_valid[role]);
-                                ++eig_adopted;
-                                break;
-                            }
-                    }
-                    (ob.stage < 6 ? ob.lpr_h0 : ob.lpr_h1) = ob.opt.last_lpr();
-                    ++ob.stage;
-                    if (ob.stage == 12) {
-                        ob.done = true;
-                    } else if (ob.stage == 6) {  // omega_H1 = 0.2, sigma_H1 = 0.01, keep rho and kappa (src/run.hpp:161-166)
-                        ob.q_settings[1] = 0.2;
-                        ob.q_settings[2] = 0.01;
-                        ob.needs_validation = true;   // validated in the round that follows
-                    } else {
-                        start_stage(ob);
-                    }
-                    continue;
+    ChainStats st;
+    const bool device = use_device_engine() && !eng.host_eigen;
+    if (device) {
+        run_chain(eng, machines, PCSF_OMEGA, false, seed, eager, static_cast<uint32_t>(transient0), held_systems, stop, st);
+    } else {
+        const std::vector<double> t_rho = make_draw_table(seed, 0.001, 10.0), t_kappa = make_draw_table(seed, 1.0, 10.0);
+        const DrawTable dr{t_rho.data(), DRAW_TABLE_ENTRIES}, dk{t_kappa.data(), DRAW_TABLE_ENTRIES};
+        std::vector<StoreEntry> stores(n_blocks * STORE_ENTRIES);
+        // the log priors of the pending points, by the device (one small launch per round)
+        std::vector<double> prior_x(n_blocks * OMEGA_MAX_REQUESTS), prior_v(n_blocks * OMEGA_MAX_REQUESTS);
+        std::vector<uint32_t> prior_kind(n_blocks * OMEGA_MAX_REQUESTS);
+        DeviceBuffer d_px, d_pk, d_pv;
+        HIP_TRY(d_px.reserve(prior_x.size() * 8));
+        HIP_TRY(d_pk.reserve(prior_x.size() * 4));
+        HIP_TRY(d_pv.reserve(prior_x.size() * 8));
+        const long trace_block = std::getenv("PCSF_TRACE_BLOCK") ? std::atol(std::getenv("PCSF_TRACE_BLOCK")) : -1;  // diagnostics
+        struct HostPrior {
+            const double* v;
+            double operator()(uint32_t i, uint32_t, double) const { return v[i]; }
+        };
+        std::vector<size_t> at(n_blocks + 1, 0);
+        auto fetch_priors = [&]() {   // for every pending point of every block, before the machines take the round's values
+            size_t n = 0;
+            for (size_t b = 0; b < n_blocks; ++b) {
+                at[b] = n;
+                for (uint32_t i = 0; i < machines[b].n_pending; ++i, ++n) {
+                    prior_x[n] = machines[b].pend_x[i];
+                    prior_kind[n] = machines[b].pend_kind[i];
                 }
-                const EvalStore::Entry* e = ob.store.find(ob.opt.request());
-                if (!e) break;
-                if (e->failed) {
-                    ob.failed = true;
-                    break;
-                }
-                if (trace_block >= 0 && static_cast<size_t>(trace_block) == b)
-                    fprintf(stderr, "TRACE omega stage %d x %.17g lpr %.17g\n", ob.stage, e->x, e->lpr);
-                e->used = true;
-                ob.opt.supply(e->lpr, 0.0);
             }
-            if (!ob.failed && !ob.done) ++active;
-        }
-        if (!active) break;
-        // Blocks that switch to H1 need their new model validated (one evaluation whose flags are read) before their next
-        // stage starts.  That evaluation rides along with this round's points of the other blocks -- as a round of its own it
-        // cost a full eigen-solver launch and a synchronisation for a handful of blocks, some forty times per run (0.05 of
-        // 0.36 s on the 516-block file).  Blocks whose validation does not fit this round wait for the next.
-        std::vector<std::pair<size_t, size_t>> validating;  // (block, evaluation)
-        for (size_t b = 0; b < n_blocks; ++b) {
-            OmegaBlock& ob = *blk[b];
-            if (ob.failed || ob.done || !ob.needs_validation || eng.free_evaluations() == 0) continue;
-            validating.push_back({b, eng.queue(b, ob.slot[ROLE_OWN], ob.tree_scale, ob.q_settings, false, ob.eig_valid ? static_cast<int32_t>(ob.slot[ROLE_OWN]) : -1)});
-            std::memcpy(ob.eig_settings, ob.q_settings, sizeof ob.q_settings);
-            ob.eig_valid = true;
-        }
-        // (2) queue the points the optimisers will or may need next: rank 0 (certain) for every block first
-        std::vector<Pending> pending;
-        std::vector<Lookahead> ahead(n_blocks);
-        std::vector<char> rebuilt(n_blocks, 0);  // block's own eigen-system slot is rebuilt in this run
-        std::vector<unsigned char> written(n_blocks, 0);   // bit role: the role's slot is rewritten in this run
-        std::vector<int> ahead_certain(n_blocks, 0);
-        for (size_t b : live) {
-            OmegaBlock& ob = *blk[b];
-            if (!ob.failed && !ob.done && !ob.needs_validation)
-                ahead[b].n = ob.opt.upcoming(ahead[b].x, MAX_POINTS_PER_ROUND, MAX_SPECULATIVE_RESTARTS, active < eager_restarts_below(), &ahead_certain[b]);
-        }
-        for (int rank = 0; rank < MAX_POINTS_PER_ROUND && eng.free_evaluations() > 0; ++rank) {
-            bool any = false;
-            for (size_t b : live) {
-                if (eng.free_evaluations() == 0) break;
-                if (rank >= ahead[b].n) continue;
-                any = true;
-                OmegaBlock& ob = *blk[b];
-                const double x = ahead[b].x[rank];
-                if (ob.store.find(x) || ahead[b].seen_before(rank)) continue;
-                size_t k;
-                if ((ob.stage % 2) == 0) {  // rho: the block's own eigen-system, brought up to date if need be
-                    const bool stale = !ob.eig_valid || std::memcmp(ob.eig_settings, ob.q_settings, sizeof ob.q_settings) != 0;
-                    if (stale && !rebuilt[b]) {
-                        k = eng.queue(b, ob.slot[ROLE_OWN], x, ob.q_settings, false, ob.eig_valid ? static_cast<int32_t>(ob.slot[ROLE_OWN]) : -1);
-                        std::memcpy(ob.eig_settings, ob.q_settings, sizeof ob.q_settings);
-                        ob.eig_valid = true;
-                        rebuilt[b] = 1;
-                        ++eig_evals;
-                    } else {
-                        k = eng.queue(b, ob.slot[ROLE_OWN], x, nullptr, rebuilt[b] != 0);
-                    }
-                } else {  // kappa: a probe model
-                    double qs[12];
-                    std::memcpy(qs, ob.q_settings, sizeof qs);
-                    qs[0] = x;
-                    // Which probes may change what the block holds: the ends of the range, and the probes of the Brent phase (one per
-                    // round, each asked for only after its predecessor was consumed).  Random restarts never do, and always start from
-                    // the block's own system: whether a restart is evaluated ahead of need, and in which round, depends on how many
-                    // blocks share the engine -- no result may (tests/test_gpu_blocks.py, block groups).
-                    const bool certain = rank < ahead_certain[b];
-                    const bool brent_phase = ob.opt.draws_finished();
-                    auto holds = [&](int role) {   // the role's slot holds exactly this model, and is not being rewritten in this run
-                        const bool valid = role == ROLE_OWN ? (ob.eig_valid && !rebuilt[b]) : (ob.held_valid[role] && !(written[b] & (1u << role)));
-                        return valid && std::memcmp(role == ROLE_OWN ? ob.eig_settings : ob.held[role], qs, sizeof qs) == 0;
-                    };
-                    int hit = -1;
-                    for (int role = 0; role < N_ROLES && held_systems && hit < 0; ++role)
-                        if (holds(role)) hit = role;
-                    if (hit >= 0) {   // solved before (the block's own model, or an end of the kappa range in an earlier stage): no new eigen-system
-                        k = eng.queue(b, ob.slot[hit], ob.tree_scale, nullptr, false);
-                        ++eig_reused;
-                    } else {
-                        // where the new system goes: the ends of the range and the certain interior probes are kept, restarts are not
-                        int target = -1;
-                        if (held_systems && certain) {
-                            if (x == 1.0) target = ROLE_LO;
-                            else if (x == 10.0) target = ROLE_HI;
-                            else if (brent_phase) {
-                                target = ROLE_P0 + ob.next_p;
-                                ob.next_p ^= 1;
-                            }
-                        }
-                        // Jacobi starts in the eigenbasis of the nearest held system of the same family (all settings but kappa equal).
-                        // The ends only look at the block's own system and at what their slot held before: what else is complete when
-                        // they are solved depends on how the round was packed, and no result may depend on that.
-                        int32_t warm = -1;
-                        double best = 0.0;
-                        for (int role = 0; role < N_ROLES; ++role) {
-                            if ((!held_systems || target < 0) && role != ROLE_OWN) break;
-                            if ((target == ROLE_LO || target == ROLE_HI) && role != ROLE_OWN && role != target) continue;
-                            const double* hs = role == ROLE_OWN ? ob.eig_settings : ob.held[role];
-                            const bool valid = role == ROLE_OWN ? (ob.eig_valid && !rebuilt[b]) : (ob.held_valid[role] && !(written[b] & (1u << role)));
-                            if (!valid || std::memcmp(hs + 1, qs + 1, 11 * sizeof(double)) != 0) continue;
-                            const double dist = std::fabs(hs[0] - x);
-                            if (warm < 0 || dist < best) {
-                                warm = static_cast<int32_t>(ob.slot[role]);
-                                best = dist;
-                            }
-                        }
-                        if (warm < 0 && ob.eig_valid && !rebuilt[b]) warm = static_cast<int32_t>(ob.slot[ROLE_OWN]);   // another family: still better than a cold start
-                        uint32_t dst;
-                        if (target >= 0 && !(written[b] & (1u << target))) {
-                            dst = ob.slot[target];
-                            std::memcpy(ob.held[target], qs, sizeof qs);
-                            ob.held_valid[target] = true;
-                            written[b] |= 1u << target;
-                        } else {
-                            dst = static_cast<uint32_t>(transient0 + eng.evals.size());
-                        }
-                        k = eng.queue(b, dst, ob.tree_scale, qs, false, warm);
-                        ++eig_evals;
-                    }
-                }
-                pending.push_back({b, k, x});
-            }
-            if (!any) break;
-        }
-        ++rounds;
-        evals += pending.size();
-        const auto t1 = now();
-        eng.run(false);
-        const auto t2 = now();
-        for (const Pending& q : pending) {
-            const OmegaBlock& ob = *blk[q.block];
-            double lpr = eng.value(q.eval, eng.lnz);
-            lpr += ((ob.stage % 2) == 0) ? log_prior_rho(q.x) : log_prior_kappa(q.x);
-            blk[q.block]->store.entries.push_back({q.x, lpr, 0.0, eng.failed(q.eval)});
-        }
-        for (const auto& q : validating) {
-            OmegaBlock& ob = *blk[q.first];
-            ob.needs_validation = false;
-            if (eng.failed(q.second)) ob.failed = true;
-            else start_stage(ob);
-        }
-        t_host += secs(t0, t1) + secs(t2, now());
-        t_run += secs(t1, t2);
+            if (!n) return;
+            HIP_TRY(hipMemcpyAsync(d_px.ptr, prior_x.data(), n * 8, hipMemcpyHostToDevice, eng.stream));
+            HIP_TRY(hipMemcpyAsync(d_pk.ptr, prior_kind.data(), n * 4, hipMemcpyHostToDevice, eng.stream));
+            HIP_TRY(launch_log_priors(d_pk.as<uint32_t>(), d_px.as<double>(), static_cast<uint32_t>(n), d_pv.as<double>(), eng.stream));
+            HIP_TRY(hipMemcpyAsync(prior_v.data(), d_pv.ptr, n * 8, hipMemcpyDeviceToHost, eng.stream));
+            HIP_TRY(hipStreamSynchronize(eng.stream));
+        };
+        run_host_rounds(eng, machines, look.max_points, false, stop, st, fetch_priors, [&](size_t b, const EvalResult* res, EvalRequest* out) {
+            OmegaMachine& m = machines[b];
+            if (trace_block >= 0 && static_cast<size_t>(trace_block) == b)
+                for (uint32_t i = 0; i < m.n_pending; ++i)
+                    fprintf(stderr, "TRACE omega stage %d kind %u x %.17g lnz %.17g prior %.17g\n", m.stage, m.pend_kind[i], m.pend_x[i], res[i].lnz, prior_v[at[b] + i]);
+            return m.round(res, stores.data() + b * STORE_ENTRIES, dr, dk, look.eager, look.max_points, look.max_restarts, held_systems,
+                           static_cast<uint32_t>(transient0 + b * look.max_points), HostPrior{prior_v.data() + at[b]}, out);
+        });
     }
-    if (timing) {
-        size_t used = 0, unused = 0;
-        for (size_t b : live) {
-            blk[b]->store.tally();
-            used += blk[b]->store.n_used;
-            unused += blk[b]->store.n_unused;
+    if (std::getenv("PCSF_TIME_BLOCKS")) {
+        size_t used = 0, unused = 0, e_new = 0, e_reused = 0, e_adopted = 0;
+        for (const OmegaMachine& m : machines) {
+            used += m.used;
+            unused += m.unused;
+            e_new += m.n_eig_new;
+            e_reused += m.n_eig_reused;
+            e_adopted += m.n_eig_adopted;
         }
-        fprintf(stderr, "run_omega: %zu evaluations consumed by the optimisers, %zu speculative ones never asked for\n", used, unused);
+        fprintf(stderr, "run_omega: %zu evaluations consumed by the optimisers, %zu speculative ones never asked for; %zu kappa / stale-model evaluations with a new eigen-system, %zu kappa probes on a held one, %zu stage ends adopted one\n",
+                used, unused, e_new, e_reused, e_adopted);
+        print_chain_stats("run_omega", n_blocks, device, eng.use_tiles, st, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count(), eng.products_run());
     }
-    if (timing)
-        fprintf(stderr, "run_omega: %zu blocks (%zu on the factored path), %zu rounds, %zu evaluations (%zu with a new eigen-system, %zu kappa probes on a held one, %zu stage ends adopted one): host %.3f s, device rounds %.3f s; engine set-up %.3f s, validation passes + F3x4 counts %.3f s, whole call %.3f s\n",
-                n_blocks, static_cast<size_t>(std::count(eng.block_factored.begin(), eng.block_factored.end(), 1)), rounds, evals, eig_evals, eig_reused, eig_adopted, t_host, t_run, t_setup, t_prelude, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count());
     for (size_t b = 0; b < n_blocks; ++b) {
-        const OmegaBlock& ob = *blk[b];
-        out_phylo[b] = ob.failed ? NAN : decibans(ob.lpr_h1, ob.lpr_h0);
+        const OmegaMachine& m = machines[b];
+        out_phylo[b] = m.failed ? NAN : decibans(m.lpr_h1, m.lpr_h0);
         if (out_anc) out_anc[b] = NAN;  // src/run.hpp:181
     }
     return PCSF_OK;
@@ -1266,6 +1178,25 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
 
 }  // namespace
 
+// The AUTO rule: prune_tiles when, on average, at least 16 species have a codon in a block (blocks without a site do not count).
+bool list_prefers_tiles(size_t nl, const uint8_t* codons, size_t stride, const uint64_t* off, size_t n_blocks)
+{
+    if (!codons || n_blocks == 0) return true;
+    std::atomic<uint64_t> present{0}, counted{0};
+    parallel_for(n_blocks, [&](size_t b) {
+        if (off[b + 1] == off[b]) return;
+        uint64_t n = 0;
+        for (size_t l = 0; l < nl; ++l) {
+            const uint8_t* row = codons + l * stride;
+            bool any = false;
+            for (uint64_t s = off[b]; s < off[b + 1] && !any; ++s) any = row[s] < 64;
+            n += any;
+        }
+        present += n;
+        counted += 1;
+    });
+    return counted == 0 || static_cast<double>(present) >= 16.0 * static_cast<double>(counted);
+}
 
 // one objective evaluation per block at caller-chosen parameters (no prior term).  model 3: caller-supplied
 // eigen-systems (custom[n_custom], block b uses custom[n_custom == 1 ? 0 : b]) -- the parity tests feed the ORACLE's
@@ -1277,7 +1208,7 @@ int block_loglik_impl(pcsf_ctx* c, int model, const double* q_settings, const do
     std::vector<uint64_t> off(n_blocks + 1);
     for (size_t b = 0; b <= n_blocks; ++b) off[b] = site_offsets[b] - site_offsets[0];
     BlockEngine eng(c, codons ? codons + site_offsets[0] : nullptr, off.data(), n_blocks, leaf_stride,
-                    model != 3 && list_prefers_tiles(c, codons ? codons + site_offsets[0] : nullptr, leaf_stride, off.data(), n_blocks), false,
+                    model != 3 && call_uses_tiles(c, codons ? codons + site_offsets[0] : nullptr, leaf_stride, off.data(), n_blocks), false,
                     /*explicit_path=*/model == 3);
     eng.reserve_tables(n_blocks);
     if (model == 2) {
@@ -1376,41 +1307,32 @@ int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
         const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
         ~CallTimer() { if (on) fprintf(stderr, "score_blocks: whole call %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
     } call_timer;
-    // MLE / OMEGA keep one set of branch-matrix tables per evaluation of a LONG block in HBM (9.6 MB for a 100-leaf tree),
-    // up to two evaluations per block and round: blocks are independent, so a long list is processed in chunks that bound
-    // that footprint to ~16 GB.
-    // PCSF_BLOCK_GROUPS=g advances g groups of blocks concurrently, one host thread and one pair of streams each.  A round's
-    // time is the latency of its longest dependency chain (eigen-solver sweeps -> edge scales -> pruning -> download) plus the
-    // host's work on the round, and every group needs as many rounds as the whole list (the block with the longest optimiser
-    // path sets it): short lists lose (516 blocks OMEGA 0.32 s as one group, 0.39 s as two), long lists win because one
-    // group's host work and small kernels run beside the other's (8,256 blocks: MLE 0.58 -> 0.31 s, OMEGA 2.85 -> 2.18 s;
-    // four groups add nothing).  Blocks are independent: grouping never changes a result (tests/test_gpu_blocks.py).
+    // Blocks are independent, so a long list is processed in chunks that bound the engines' footprint in HBM: per block and evaluation
+    // slot one row of edge scales, per OMEGA block seventeen eigen-systems, per search a value store (and, only under
+    // PCSF_FACTORED_MAX_TILES -- round 2's explicit path --, 9.6 MB of branch-matrix tables per evaluation of a 100-leaf tree).
+    // PCSF_BLOCK_GROUPS=g advances g groups of blocks concurrently, one host thread and its own streams each: one group's kernels
+    // fill the tails of the other's launches and its host work runs beside them (8,256 blocks: MLE 0.58 -> 0.31 s, OMEGA 2.85 -> 2.18 s
+    // with the host engine; four groups added nothing).  Short lists lose: every group needs as many rounds as the whole list (the block
+    // with the longest optimiser path sets it).  Blocks are independent: grouping never changes a result (tests/test_gpu_blocks.py).
     size_t chunk = n_blocks;
     size_t n_groups = 1;
-    // one pruning kernel for the whole list, decided before it is cut into chunks and groups
-    const bool tiles = algo != PCSF_FIXED && list_prefers_tiles(c, codons, leaf_stride, site_offsets, n_blocks);
+    // one pruning kernel for the whole call, decided before the list is cut into chunks and groups (pinned by the caller: pcsf_set_block_kernel)
+    const bool tiles = algo != PCSF_FIXED && call_uses_tiles(c, codons, leaf_stride, site_offsets, n_blocks);
+    const bool eager = n_blocks < eager_restarts_below();
     if (algo != PCSF_FIXED && std::getenv("PCSF_TIME_BLOCKS")) fprintf(stderr, "pruning kernel of this list: %s\n", tiles ? "prune_tiles" : "prune_factored");
     if (algo != PCSF_FIXED) {
-        const size_t ne = c->schedule.slot_node.size();
-        const size_t per_table = (ne * 4096 + static_cast<size_t>(c->n_leaves) * LEAF_TABLE_DOUBLES_DEV) * sizeof(double);
-        chunk = std::max<size_t>(64, (size_t(16) << 30) / std::max<size_t>(per_table, 1));
-        // Blocks on the factored path keep no tables: when the whole list is factored (score-msa's short, sparse blocks) the chunks
-        // are bounded by the eigen-system slots instead (3 per block, ~100 KB each) -- every chunk costs a full set of rounds.
-        long max_tiles = -1;
-        if (const char* v = std::getenv("PCSF_FACTORED_MAX_TILES")) max_tiles = std::max(0, std::atoi(v));
-        std::atomic<bool> any_explicit{false};
-        if (tiles) {
-            // no block keeps tables
-        } else if (codons)
-            parallel_for(n_blocks, [&](size_t b) {
-                if (!any_explicit.load(std::memory_order_relaxed) &&
-                    !block_prefers_factored(c, codons, leaf_stride, site_offsets[b], site_offsets[b + 1], max_tiles))
-                    any_explicit.store(true, std::memory_order_relaxed);
-            });
-        else any_explicit = true;
-        if (!any_explicit) chunk = std::max<size_t>(chunk, 32768);
-        // two groups once the list is long enough for one group's host work (optimisers, job lists: ~3 ms per round at 8,256
-        // blocks) to matter beside the other's kernels -- measured: MLE from 512 blocks, OMEGA from 1,536 (profiles/r02/blocks_groups.txt)
+        const LookaheadPolicy look = lookahead_policy(eager);
+        const size_t slots = static_cast<size_t>(algo == PCSF_MLE ? 2 * look.max_points : look.max_points);
+        const size_t per_block = slots * static_cast<size_t>(c->n_nodes - 1) * 64 * sizeof(double) +
+                                 (algo == PCSF_OMEGA ? (N_ROLES + static_cast<size_t>(look.max_points)) * size_t(3 * 4096 + 5 * 64) * sizeof(double) : 0) +
+                                 (algo == PCSF_MLE ? 2 : 1) * STORE_ENTRIES * sizeof(StoreEntry);
+        chunk = std::max<size_t>(64, (size_t(48) << 30) / per_block);
+        if (std::getenv("PCSF_FACTORED_MAX_TILES")) {
+            const size_t ne = c->schedule.slot_node.size();
+            const size_t per_table = (ne * 4096 + static_cast<size_t>(c->n_leaves) * LEAF_TABLE_DOUBLES_DEV) * sizeof(double);
+            chunk = std::min(chunk, std::max<size_t>(64, (size_t(16) << 30) / std::max<size_t>(per_table * slots, 1)));
+        }
+        // two groups once the list is long enough -- measured with the host engine: MLE from 512 blocks, OMEGA from 1,536 (profiles/r02/blocks_groups.txt)
         if (const char* v = std::getenv("PCSF_BLOCK_GROUPS")) n_groups = static_cast<size_t>(std::max(1, std::atoi(v)));
         else n_groups = n_blocks >= (algo == PCSF_MLE ? 512u : 1536u) ? 2 : 1;
         n_groups = std::min(n_groups, std::max<size_t>(n_blocks, 1));
@@ -1431,8 +1353,8 @@ int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
         float* an = out_anc ? out_anc + r.b0 : nullptr;
         switch (algo) {
             case PCSF_FIXED: return run_fixed(c, cod, off.data(), r.nb, leaf_stride, compute_anc, ph, an);
-            case PCSF_MLE: return run_mle(c, cod, off.data(), r.nb, leaf_stride, compute_anc, seed, ph, an, tiles, own_streams, &stop_groups);
-            default: return run_omega(c, cod, off.data(), r.nb, leaf_stride, seed, ph, an, tiles, own_streams, &stop_groups);
+            case PCSF_MLE: return run_mle(c, cod, off.data(), r.nb, leaf_stride, compute_anc, seed, ph, an, tiles, own_streams, eager, &stop_groups);
+            default: return run_omega(c, cod, off.data(), r.nb, leaf_stride, seed, ph, an, tiles, own_streams, eager, &stop_groups);
         }
     };
     if (n_groups <= 1 || ranges.size() <= 1) {

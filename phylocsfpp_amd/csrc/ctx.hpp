@@ -167,6 +167,7 @@ struct pcsf_ctx {
     uint32_t stamp_block = 0;
     hipStream_t stream = nullptr;        // private stream for host-pointer entry points
     pcsf::StreamPool block_streams;      // streams of the MLE / OMEGA engines (blocks.cpp)
+    int block_kernel = 0;                // pcsf_block_kernel: AUTO = every pcsf_score_blocks call decides from its own list
     hipEvent_t ev_kernels = nullptr;     // behind the kernels of this context's last six-frame call
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false;
@@ -220,6 +221,8 @@ struct FusedFrontEnd {
 // the codons of fused->segments, formed in the kernel (d_codons is not read)
 int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t leaf_stride, double* d_out, double* d_lnz,
                  double* d_anc, hipStream_t stream, const FusedFrontEnd* fused = nullptr);
+// the AUTO rule of pcsf_block_kernel on a list (blocks.cpp): true = prune_tiles
+bool list_prefers_tiles(size_t n_leaves, const uint8_t* codons, size_t stride, const uint64_t* off, size_t n_blocks);
 // run() for a batch of blocks (blocks.cpp)
 int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64_t* site_offsets, size_t n_blocks,
                       size_t leaf_stride, int compute_anc, uint32_t seed, float* out_phylo, float* out_anc);

@@ -614,6 +614,7 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
             }
         }
     }
+    if (p.product_count && tid == 0) atomicAdd(p.product_count, static_cast<unsigned long long>(nprod));
     if (stamping && tid == 0) {
         atomicAdd(p.stamps + 0, fact_clock() - t_begin);
         atomicAdd(p.stamps + 1, t_load);

@@ -64,6 +64,12 @@ static int smooth_runs(pcsf_ctx* c, const double* init, const double* trans, con
     if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
     hipStream_t st = c->stream;
     pcsf_ctx::HmmBuffers& B = c->hmm;
+    // Every return below -- also the error returns in the middle of the passes -- first waits for what is in flight on the stream: the
+    // asynchronous copies read this function's vectors (chunks, same, todo) and the caller's arrays, all of which may be gone a moment later.
+    struct Drain {
+        hipStream_t s;
+        ~Drain() { (void)hipStreamSynchronize(s); }
+    } drain{st};
 #define HMM_TRY(x, what) \
     if ((e = (x)) != hipSuccess) return c->hip_fail(e, what)
     HMM_TRY(B.emit.reserve(n * sizeof(double)), "hipMalloc(hmm emissions)");
@@ -182,4 +188,15 @@ extern "C" int pcsf_hmm_smooth_runs_binned(pcsf_ctx* c, const double* init, cons
     b.exc_capacity = exc_capacity;
     b.n_exc = n_exceptions;
     return smooth_runs(c, init, trans, emissions, run_offsets, n_runs, nullptr, &b, out_back, out_last, stats);
+}
+
+extern "C" int pcsf_hmm_release(pcsf_ctx* c)
+{
+    if (!c) return PCSF_ERR_INVALID_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return c->fail(PCSF_ERR_HIP, "hipSetDevice");
+    (void)hipStreamSynchronize(c->stream);
+    pcsf_ctx::HmmBuffers& B = c->hmm;
+    for (pcsf::DeviceBuffer* b : {&B.emit, &B.fwd, &B.back, &B.post, &B.chunks, &B.entry, &B.exit_state, &B.same, &B.todo, &B.thresholds, &B.bins, &B.exc_index, &B.exc_value, &B.exc_count})
+        b->release();
+    return PCSF_OK;
 }

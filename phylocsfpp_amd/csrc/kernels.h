@@ -147,6 +147,7 @@ struct FactoredParams {
     uint32_t deep;              // the tree parks more tiles than the register stack holds (schedule.stack_depth > MAX_STACK_DEPTH)
     const uint64_t* op_leaves;  // [n_ops][2] and
     const uint32_t* op_meta;    // [n_ops]: schedule.hpp ProgramFacts of `program` (null: tree of more than 128 leaves -- no op is skipped)
+    unsigned long long* product_count;   // may be null: every tile job adds the 64x64 x 64x16 products it ran (64 MFMAs = 131,072 FLOP each): the executed work of a call, for the roofline of the block strategies
     uint32_t stamp_classes;     // diagnostics: also stamp every op that runs, by class (stamps[8..15]; a stamp costs ~200 cycles: PCSF_FACTORED_STAMPS=2)
     unsigned long long* stamps; // diagnostics (may be null; PCSF_FACTORED_STAMPS): work-groups add cycles -- [0] whole kernel, [1] waiting for
                                 // edge-scale / leaf-column loads, [2] in products, [3] work-groups, [4] loads, [5] products
@@ -159,6 +160,53 @@ hipError_t launch_prune_factored(const FactoredParams& p, hipStream_t stream);
 // the same jobs, one wave per tile with R and L resident in LDS (tiles.hip); jobs sorted so that p.groups cut them by eigen-system
 hipError_t launch_prune_tiles(const FactoredParams& p, hipStream_t stream);
 size_t prune_tiles_lds_bytes(const FactoredParams& p);
+
+// launches groups [0, p.n_groups) with work-groups of `waves` waves (1..TILE_JOBS_PER_GROUP): the caller keeps one list of groups per
+// size (chain.hip writes them that way), largest first
+hipError_t launch_prune_tiles_sized(const FactoredParams& p, int waves, hipStream_t stream);
+
+// ---- the optimiser loop on the device (chain.hip + machine.hpp) ----------------------------------------------------------------------
+struct StoreEntry;
+struct EigenJob;
+struct ChainCounters {       // zeroed before every round; read by the host after advance_blocks to size the round's launches
+    uint32_t n_active;       // blocks that are not finished
+    uint32_t n_evals;        // evaluations requested this round (edge_scale_kernel work-groups)
+    uint32_t n_eig_jobs;     // of which with a new eigen-system (eigen_omega_kernel work-groups)
+    uint32_t n_tile_jobs;
+    uint32_t n_groups[4];    // tile groups by number of tiles: 1, 2, 3, TILE_JOBS_PER_GROUP (all in [0] when !split_sizes)
+    uint32_t n_list[2];      // pack_models: tile jobs of the coding / non-coding model (lists of their own: any four of a list share a work-group)
+    uint32_t pad[6];
+};
+struct ChainParams {
+    void* machines;              // [n_blocks] MleMachine or OmegaMachine
+    StoreEntry* stores;          // [n_blocks][1 or 2][STORE_ENTRIES]
+    const uint64_t* off;         // [n_blocks + 1] sites of the blocks in the codon matrix
+    uint32_t slots_per_block;    // P: evaluation slots (tables, output ranges) per block
+    const double* out_lnz;       // [P * n_sites] written by the pruning kernel of the previous round
+    const double* out_anc;       // or null
+    uint32_t* fail;              // [n_blocks * P]
+    const double* draws[3];      // restart points of the MLE, rho and kappa search ranges (optimizer.hpp DrawTable)
+    uint32_t n_draws;
+    uint32_t eager, max_points, max_restarts, held_systems;   // machine.hpp LookaheadPolicy
+    uint32_t transient0;         // OMEGA: first eigen-system slot of the per-block transient ranges
+    uint32_t use_tiles, split_sizes;
+    uint32_t pack_models;        // MLE + prune_tiles: the two ECM eigen-systems are shared by all blocks -- tile jobs go to one list per model
+                                 // (the second at tile_jobs + list_capacity) and every four consecutive jobs of a list form a work-group
+    uint32_t list_capacity;
+    ChainCounters* counters;
+    ExpmEval* evals;             // [n_blocks * P]
+    EigenJob* eig_jobs;          // [n_blocks * P] (OMEGA)
+    FactoredJob* tile_jobs;      // [P * tiles of all blocks]
+    TileGroup* groups;           // [4][group_capacity]
+    uint32_t group_capacity;
+};
+// algo 0: MLE machines, else OMEGA machines; one wave per block
+hipError_t launch_advance_blocks(const ChainParams& p, int algo, uint32_t n_blocks, hipStream_t stream);
+// out[i] = log prior of the OMEGA objective at xs[i]: kinds[i] == EVAL_RHO (2) the tree-scale prior, else the kappa prior
+hipError_t launch_log_priors(const uint32_t* d_kinds, const double* d_xs, uint32_t n, double* d_out, hipStream_t stream);
+// tests: MaxLik1D on the device, fed with recorded objective values (d_last[0] = last lpr, [1] = last x)
+hipError_t launch_maxlik_replay(double init, double lo, double hi, const double* d_draws, uint32_t n_draws, const double* d_values, int n_values, double* d_xs_out,
+                                int cap, int* d_n_requests, double* d_last, hipStream_t stream);
 
 // ---- the smoothing pass (hmm.hip): chunks of runs of raw scores, one thread per chunk ---------------------------------------------
 struct HmmModel {   // host/hmm.hpp `Hmm`: state 0 = coding, 1..3 = non-coding classes

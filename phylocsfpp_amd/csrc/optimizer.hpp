@@ -1,128 +1,153 @@
-// optimizer.hpp -- the 1-D maximiser of the MLE / OMEGA strategies as a resumable state machine.
+// optimizer.hpp -- the 1-D maximiser of the MLE / OMEGA strategies as a resumable state machine, for the host AND the device.
 //
 // The reference runs, per block, `max_lik_lpr_leaves` (src/fixed_lik.hpp:469-544): a random-restart
 // search for a starting point (fit_find_init) followed by GSL's Brent minimiser, every objective
-// evaluation being a full likelihood pass.  On the GPU thousands of blocks advance in lock-step:
-// each block's optimiser is suspended whenever it needs an objective value, the host batches all
-// requests into one expm + pruning launch, and resumes the optimisers with the results.
+// evaluation being a full likelihood pass.  On the GPU thousands of blocks advance in rounds:
+// each block's optimiser is suspended whenever it needs an objective value, the requests of a round
+// become one batch of eigen / edge-scale / pruning launches, and the optimisers resume with the results.
 // Decision logic (comparison order, the result being the LAST evaluation, Brent's d/e swap on
 // entry, tolerances) follows the reference and GSL's published min/brent.c so that the sequence
 // of evaluation points is the same.
+//
+// One source, two compilations: machine.hpp's per-block machines (built on this class) run inside
+// chain.hip's `advance_blocks` kernel -- the optimiser loop on the device, no host round trip per round --
+// and, unchanged, on the host in blocks.cpp's lock-step engine (kept as the A/B reference: both must give the
+// same bits).  Hence no std::mt19937 in here: see DrawTable.
 #pragma once
 
 #include <cfloat>
 #include <cmath>
-#include <random>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PCSF_HD __host__ __device__
+#else
+#define PCSF_HD
+#endif
 
 namespace pcsf {
+
+// Random restarts.  The reference draws x = exp(log(lo) + U(0, log(hi) - log(lo))) from a std::mt19937 that is seeded once per
+// block and shared by all of the block's searches (src/fixed_lik.hpp:483-491, src/run.hpp:150-179, seed 42 for every block:
+// src/phylocsf++score_msa.hpp:115).  How MANY numbers a block draws depends on its data; WHICH number its k-th draw is does not --
+// it is the k-th draw of the generator, the same for every block of a call.  So the generator runs once, on the host, with
+// libstdc++'s own uniform_real_distribution and the host's exp / log (make_draw_table in blocks.cpp), and a block only keeps
+// a count of its draws: x[k] is the restart point the k-th draw gives for this search range.  Exactly the numbers the host
+// optimiser of rounds 1-3 drew, available to device code.
+struct DrawTable {
+    const double* x = nullptr;   // [n]
+    uint32_t n = 0;
+};
+constexpr uint32_t DRAW_TABLE_ENTRIES = 12 * 250 + 16;   // OMEGA: twelve searches of at most 250 draws, plus the look-ahead
 
 class MaxLik1D {
 public:
     // objective value convention: `lpr` = the quantity being MAXIMISED (log-likelihood [+ log prior])
-    void start(double init, double lo, double hi, std::mt19937* gen)
+    PCSF_HD void start(double init, double lo, double hi)
     {
         init_ = init;
         lo_ = lo;
         hi_ = hi;
-        gen_ = gen;
-        width_ = std::log(hi) - std::log(lo);
         tries_ = 0;
         state_ = S_LO;
         request_ = lo;
         done_ = false;
         evals_ = 0;
     }
-    bool done() const { return done_; }
-    // true once the search will never draw from the generator again (the random restarts precede Brent's iteration): a second
-    // search sharing the generator may start then and still sees the numbers it would have seen after this one had finished
-    bool draws_finished() const { return done_ || state_ >= S_FINAL; }
-    double request() const { return request_; }  // x at which the objective is wanted next
-    double last_x() const { return last_x_; }
-    double last_lpr() const { return last_lpr_; }  // result of max_lik_lpr_leaves = LAST evaluation
-    double last_anc() const { return last_anc_; }
-    int evaluations() const { return evals_; }
+    PCSF_HD bool done() const { return done_; }
+    // true once the search will never draw again (the random restarts precede Brent's iteration): a second
+    // search sharing the block's draw count may start then and still sees the numbers it would have seen after this one had finished
+    PCSF_HD bool draws_finished() const { return done_ || state_ >= S_FINAL; }
+    PCSF_HD double request() const { return request_; }  // x at which the objective is wanted next
+    PCSF_HD double last_x() const { return last_x_; }
+    PCSF_HD double last_lpr() const { return last_lpr_; }  // result of max_lik_lpr_leaves = LAST evaluation
+    PCSF_HD double last_anc() const { return last_anc_; }
+    PCSF_HD int evaluations() const { return evals_; }
 
     // Points whose objective value the search will or may ask for next, in the order it would ask, WITHOUT
     // depending on values not yet supplied: xs[0] == request() (certain); the rest is certain up to the next
     // data-dependent decision (lo, hi, init at the start; chosen, lo, hi, chosen, v when Brent is set up) or
-    // speculative (the next random restarts, drawn from a COPY of the generator: the restart sequence does not
-    // depend on the values, only its length does).  A driver may evaluate all of them in one batch, keep the
-    // results and feed supply() from that store: the sequence of supply() calls -- hence every decision and the
-    // result -- is the same as when evaluating one point at a time.  Returns the number of points written.
+    // speculative (the next random restarts: the restart sequence does not depend on the values, only its length
+    // does).  A driver may evaluate all of them in one batch, keep the results and feed supply() from that store:
+    // the sequence of supply() calls -- hence every decision and the result -- is the same as when evaluating one
+    // point at a time.  Returns the number of points written.
     // eager_restarts: also list random restarts BEFORE it is known that the search needs any (lo, hi and the start not yet
     // evaluated).  Most searches need none -- the start beats both ends -- so those evaluations are usually thrown away: a third
     // of all OMEGA evaluations on a 5,088-block list (profiles/r03).  Worth it only while a round is latency-bound (few blocks).
     // n_certain (optional): how many of the points, from the front, the search WILL ask for whatever the values (the rest are
-    // restarts that may never be consumed)
-    int upcoming(double* xs, int max_points, int max_restarts, bool eager_restarts = true, int* n_certain = nullptr) const
+    // restarts that may never be consumed).  next_draw: the block's draw count (not advanced here).
+    PCSF_HD int upcoming(double* xs, int max_points, int max_restarts, bool eager_restarts, int* n_certain, const DrawTable& draws, uint32_t next_draw) const
     {
         int n = 0, certain = -1;
-        auto push = [&](double x) {
-            if (n < max_points) xs[n++] = x;
-        };
         if (done_ || max_points <= 0) return 0;
-        auto restarts = [&](int already) {  // the next random starting points
-            certain = n;
-            if (!gen_ || max_restarts <= 0) return;
-            std::mt19937 g = *gen_;
-            for (int t = already, k = 0; t < 250 && k < max_restarts && n < max_points; ++t, ++k) {
-                std::uniform_real_distribution<> dis(0.0, width_);
-                push(std::exp(std::log(lo_) + dis(g)));
-            }
-        };
+#define PCSF_PUSH(x_)                       \
+    do {                                    \
+        if (n < max_points) xs[n++] = (x_); \
+    } while (0)
+#define PCSF_RESTARTS(already_)                                                                                    \
+    do {                                                                                                           \
+        certain = n;                                                                                               \
+        if (draws.x && max_restarts > 0)                                                                           \
+            for (int t = (already_), k = 0; t < 250 && k < max_restarts && n < max_points && next_draw + k < draws.n; ++t, ++k) \
+                PCSF_PUSH(draws.x[next_draw + k]);                                                                 \
+    } while (0)
         switch (state_) {
             case S_LO:
-                push(lo_);
-                push(hi_);
-                push(init_);
-                if (eager_restarts) restarts(0);
+                PCSF_PUSH(lo_);
+                PCSF_PUSH(hi_);
+                PCSF_PUSH(init_);
+                if (eager_restarts) PCSF_RESTARTS(0);
                 break;
             case S_HI:
-                push(hi_);
-                push(init_);
-                if (eager_restarts) restarts(0);
+                PCSF_PUSH(hi_);
+                PCSF_PUSH(init_);
+                if (eager_restarts) PCSF_RESTARTS(0);
                 break;
             case S_INIT:
-                push(init_);
-                if (eager_restarts) restarts(0);
+                PCSF_PUSH(init_);
+                if (eager_restarts) PCSF_RESTARTS(0);
                 break;
             case S_RESTART:
-                push(request_);
-                restarts(tries_ + 1);
+                PCSF_PUSH(request_);
+                PCSF_RESTARTS(tries_ + 1);
                 break;
             case S_FINAL:
-                push(chosen_);
+                PCSF_PUSH(chosen_);
                 if (lo_ < chosen_ && chosen_ < hi_) {
-                    push(lo_);
-                    push(hi_);
-                    push(chosen_);
-                    push(lo_ + GOLDEN * (hi_ - lo_));
+                    PCSF_PUSH(lo_);
+                    PCSF_PUSH(hi_);
+                    PCSF_PUSH(chosen_);
+                    PCSF_PUSH(lo_ + GOLDEN * (hi_ - lo_));
                 }
                 break;
             case B_LO:
-                push(lo_);
-                push(hi_);
-                push(b_min_);
-                push(b_lo_ + GOLDEN * (b_up_ - b_lo_));
+                PCSF_PUSH(lo_);
+                PCSF_PUSH(hi_);
+                PCSF_PUSH(b_min_);
+                PCSF_PUSH(b_lo_ + GOLDEN * (b_up_ - b_lo_));
                 break;
             case B_HI:
-                push(hi_);
-                push(b_min_);
-                push(b_lo_ + GOLDEN * (b_up_ - b_lo_));
+                PCSF_PUSH(hi_);
+                PCSF_PUSH(b_min_);
+                PCSF_PUSH(b_lo_ + GOLDEN * (b_up_ - b_lo_));
                 break;
             case B_MIN:
-                push(b_min_);
-                push(b_lo_ + GOLDEN * (b_up_ - b_lo_));
+                PCSF_PUSH(b_min_);
+                PCSF_PUSH(b_lo_ + GOLDEN * (b_up_ - b_lo_));
                 break;
             default:
-                push(request_);
+                PCSF_PUSH(request_);
                 break;
         }
+#undef PCSF_RESTARTS
+#undef PCSF_PUSH
         if (n_certain) *n_certain = certain < 0 ? n : certain;
         return n;
     }
 
-    void supply(double lpr, double anc)
+    // next_draw: the block's draw count, advanced when the search draws a restart point
+    PCSF_HD void supply(double lpr, double anc, const DrawTable& draws, uint32_t& next_draw)
     {
         last_x_ = request_;
         last_lpr_ = lpr;
@@ -142,12 +167,12 @@ public:
             case S_INIT:
                 x_ = init_;
                 fx_ = lpr;
-                search_or_finish();
+                search_or_finish(draws, next_draw);
                 return;
             case S_RESTART:
                 fx_ = lpr;
                 ++tries_;
-                search_or_finish();
+                search_or_finish(draws, next_draw);
                 return;
             case S_FINAL:
                 if (lo_ < chosen_ && chosen_ < hi_) {
@@ -201,12 +226,11 @@ private:
     static constexpr double GOLDEN = 0.3819660;
     enum State { S_LO, S_HI, S_INIT, S_RESTART, S_FINAL, B_LO, B_HI, B_MIN, B_V, B_ITER };
 
-    void search_or_finish()
+    PCSF_HD void search_or_finish(const DrawTable& draws, uint32_t& next_draw)
     {
         if (tries_ < 250 && (fx_ <= flo_ || fx_ <= fhi_)) {
-            std::uniform_real_distribution<> dis(0.0, width_);
-            const double r = dis(*gen_);
-            x_ = std::exp(std::log(lo_) + r);
+            x_ = draws.x[next_draw < draws.n ? next_draw : draws.n - 1];   // (a table always covers a block's draws: DRAW_TABLE_ENTRIES)
+            ++next_draw;
             state_ = S_RESTART;
             request_ = x_;
             return;
@@ -216,15 +240,15 @@ private:
         request_ = chosen_;
     }
 
-    void brent_propose()
+    PCSF_HD void brent_propose()
     {
         const double z = b_min_;
         double d = e_, e = d_;  // GSL loads state.e into d and state.d into e
         const double w_lower = z - b_lo_, w_upper = b_up_ - z;
-        const double tol = 1.4901161193847656e-08 * std::fabs(z);
+        const double tol = 1.4901161193847656e-08 * fabs(z);
         double p = 0, q = 0, r = 0;
         const double mid = 0.5 * (b_lo_ + b_up_);
-        if (std::fabs(e) > tol) {
+        if (fabs(e) > tol) {
             r = (z - w_) * (f_min_ - f_v_);
             q = (z - v_) * (f_min_ - f_w_);
             p = (z - v_) * q - (z - w_) * r;
@@ -235,7 +259,7 @@ private:
             e = d;
         }
         double u;
-        if (std::fabs(p) < std::fabs(0.5 * q * r) && p < q * w_lower && p < q * w_upper) {
+        if (fabs(p) < fabs(0.5 * q * r) && p < q * w_lower && p < q * w_upper) {
             const double t2 = 2 * tol;
             d = p / q;
             u = z + d;
@@ -244,7 +268,7 @@ private:
             e = (z < mid) ? b_up_ - z : -(z - b_lo_);
             d = GOLDEN * e;
         }
-        if (std::fabs(d) >= tol) u = z + d;
+        if (fabs(d) >= tol) u = z + d;
         else u = z + ((d > 0) ? tol : -tol);
         e_ = e;
         d_ = d;
@@ -253,7 +277,7 @@ private:
         request_ = u;
     }
 
-    void brent_update(double f_u)
+    PCSF_HD void brent_update(double f_u)
     {
         const double z = b_min_, u = u_, f_z = f_min_;
         if (f_u <= f_z) {
@@ -274,10 +298,9 @@ private:
         }
     }
 
-    State state_ = S_LO;
+    int state_ = S_LO;
     bool done_ = true;
-    std::mt19937* gen_ = nullptr;
-    double init_ = 0, lo_ = 0, hi_ = 0, width_ = 0, request_ = 0;
+    double init_ = 0, lo_ = 0, hi_ = 0, request_ = 0;
     double flo_ = 0, fhi_ = 0, fx_ = 0, x_ = 0, chosen_ = 0;
     int tries_ = 0, iter_left_ = 0, evals_ = 0;
     double last_x_ = 0, last_lpr_ = 0, last_anc_ = 0;
@@ -287,6 +310,10 @@ private:
 };
 
 // log half-Cauchy(mode 1, scale 0.5) truncated at 0: prior on the tree scale rho (src/omega.hpp:130-141)
+// log Gamma(shape 7, scale 0.25) density at kappa - 1 + eps: prior on kappa (src/omega.hpp:143-149)
+// Both are evaluated ON THE DEVICE by either engine (chain.hip: log_prior_rho_dev / log_prior_kappa_dev, the same functions of the
+// same code object), so that the host engine and the device engine add the same bits.  The host versions below are what rounds 1-3
+// used (glibc); they differ from the device's by at most an ulp and remain for the tests that pin the formulas against the oracle.
 inline double log_prior_rho(double rho)
 {
     const double mode = 1.0, scale = 0.5;
@@ -295,7 +322,6 @@ inline double log_prior_rho(double rho)
     return std::log(numer) - std::log(1.0 - cdf0);
 }
 
-// log Gamma(shape 7, scale 0.25) density at kappa - 1 + eps: prior on kappa (src/omega.hpp:143-149)
 inline double log_prior_kappa(double kappa)
 {
     const double k = kappa - 1.0 + DBL_EPSILON, a = 7.0, b = 0.25;

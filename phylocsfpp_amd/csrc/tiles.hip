@@ -179,7 +179,9 @@ __global__ __launch_bounds__(TILE_WAVES * 64, 2) void prune_tiles(const Factored
     const int cod_bytes = (p.n_leaves * (p.n_leaves > 128 ? 17 : 16) + 15) & ~15;
     unsigned char* lcod_all = reinterpret_cast<unsigned char*>(lslot + ((p.n_edges + 3) & ~3u));
 
-    const TileGroup grp = p.groups[blockIdx.x];
+    TileGroup grp = p.groups[blockIdx.x];
+    if (grp.job0 + grp.n_jobs > p.n_jobs) grp.n_jobs = grp.job0 < p.n_jobs ? p.n_jobs - grp.job0 : 0u;   // (a list of fixed groups of four: the last one of a launch may be short)
+    if (grp.n_jobs == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_threads = blockDim.x, n_waves = n_threads >> 6;   // a work-group has as many waves as its group has jobs (at most TILE_WAVES)
     const int sj = lane & 15, g = lane >> 4;
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64, 2) void prune_tiles(const Factored
         const unsigned long long t_job = tile_clock();
         unsigned long long t_prod = 0, n_prod = 0, t_leaf = 0, t_setup = 0;
 #endif
+        uint32_t products = 0;   // wave-uniform: the products this tile runs (p.product_count)
         // the tile's codons (16 consecutive lanes hold one leaf's columns)
         for (int idx = lane; idx < p.n_leaves * 16; idx += 64) {
             const int leaf = idx >> 4, s = idx & 15;
@@ -304,6 +307,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64, 2) void prune_tiles(const Factored
             Msg out;
             PCSF_TILE_T0()
             product_R(Rs, sj, g, T.v, out.v);
+            ++products;
             PCSF_TILE_T1(out.v)
             const uint32_t tmask = uni(T.mask);
             if (tmask == 0u) {
@@ -333,6 +337,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64, 2) void prune_tiles(const Factored
                 for (int q = 0; q < 16; ++q) wv.v[q] = T.v.v[q] * wl[q];
                 PCSF_TILE_T0()
                 product_Rt(Rs, sj, g, wv, out.v);
+                ++products;
                 PCSF_TILE_T1(out.v)
             } else {
                 out.v = T.v;
@@ -519,6 +524,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64, 2) void prune_tiles(const Factored
             atomicAdd(&g_tile_stamps[5], t_setup);
         }
 #endif
+        if (p.product_count && lane == 0) atomicAdd(p.product_count, static_cast<unsigned long long>(products));
         __builtin_amdgcn_wave_barrier();   // the next job rewrites this wave's codon rows
     }
 }
@@ -565,6 +571,30 @@ static hipError_t launch_tiles_impl(const FactoredParams& p, size_t lds, hipStre
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+template <bool ANC>
+static hipError_t launch_tiles_sized_impl(const FactoredParams& p, int waves, size_t lds, hipStream_t stream)
+{
+    static std::atomic<uint64_t> attr_set{0};
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    if (!(attr_set.load(std::memory_order_acquire) >> (dev & 63) & 1)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prune_tiles<ANC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
+    }
+    hipLaunchKernelGGL((prune_tiles<ANC>), dim3(p.n_groups), dim3(waves * 64), lds, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_prune_tiles_sized(const FactoredParams& p, int waves, hipStream_t stream)
+{
+    if (p.n_groups == 0) return hipSuccess;
+    if (!p.groups || waves < 1 || waves > TILE_WAVES) return hipErrorInvalidValue;
+    const size_t lds = prune_tiles_lds_bytes(p);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    return p.out_anc ? launch_tiles_sized_impl<true>(p, waves, lds, stream) : launch_tiles_sized_impl<false>(p, waves, lds, stream);
 }
 
 hipError_t launch_prune_tiles(const FactoredParams& p, hipStream_t stream)

@@ -47,6 +47,14 @@ public:
         check(pcsf_score_blocks(ctx_, algo, codons, offsets, n_blocks, leaf_stride, compute_anc ? 1 : 0, seed, phylo, anc));
     }
     void prepare_blocks(int algo) override { check(pcsf_prepare_block_scoring(ctx_, algo)); }
+    int choose_block_kernel(const uint8_t* codons, const uint64_t* offsets, size_t n_blocks, size_t leaf_stride) override
+    {
+        const int k = pcsf_choose_block_kernel(pcsf_n_leaves(ctx_), codons, offsets, n_blocks, leaf_stride);
+        if (k < 0) throw std::runtime_error("phylocsf_amd: pcsf_choose_block_kernel: bad argument");
+        return k;
+    }
+    void set_block_kernel(int kernel) override { check(pcsf_set_block_kernel(ctx_, kernel)); }
+    void hmm_release() override { (void)pcsf_hmm_release(ctx_); }
     bool device_hmm() const override { return std::getenv("PCSF_HOST_HMM") == nullptr; }   // PCSF_HOST_HMM=1: the host code (A/B, tests)
     void hmm_smooth_runs(const Hmm& h, const double* emissions, const uint64_t* run_offsets, size_t n_runs, double* posterior, uint8_t* back, double* last) override
     {

@@ -55,6 +55,14 @@ struct ScoringBackend {
                               bool compute_anc, uint32_t seed, float* phylo, float* anc) = 0;
     // score_blocks(algo, ...) is coming: what can be set up meanwhile (the HIP backend's device queues, pcsf_prepare_block_scoring)
     virtual void prepare_blocks(int /*algo*/) {}
+    // the smoothing pass is over: device memory kept for it between calls may go
+    virtual void hmm_release() {}
+    // The MLE / OMEGA engine of the HIP backend has two pruning kernels that round differently, and by default picks one per LIST it is
+    // handed (pcsf_block_kernel).  score_msa cuts a file into one list per backend, so it asks ONCE for the whole file and pins the answer
+    // on every backend: the scores of a file do not depend on how many devices share it (src/phylocsf++score_msa.hpp:115 "make sure that
+    // parallelization does not affect results").  0 = nothing to choose (the CPU oracle backend).
+    virtual int choose_block_kernel(const uint8_t* /*codons*/, const uint64_t* /*offsets*/, size_t /*n_blocks*/, size_t /*leaf_stride*/) { return 0; }
+    virtual void set_block_kernel(int /*kernel*/) {}
     // the six frames of a batch of alignments: nucleotide rows [n_leaves][row_stride], alignment k in columns
     // [col0[k], col0[k]+len[k]); frame f of alignment k gets n_codons[6k+f] scores at out[offsets[6k+f]...] in FORWARD
     // genome order.  Default: translate on the host and call score_sites_fixed (what the CPU oracle backend uses);
@@ -159,6 +167,12 @@ public:
     {
         if (ready()) get().prepare_blocks(algo);   // a backend still being made is not waited for
     }
+    int choose_block_kernel(const uint8_t* codons, const uint64_t* offsets, size_t n_blocks, size_t leaf_stride) override
+    {
+        return get().choose_block_kernel(codons, offsets, n_blocks, leaf_stride);
+    }
+    void set_block_kernel(int kernel) override { get().set_block_kernel(kernel); }
+    void hmm_release() override { get().hmm_release(); }
     bool device_hmm() const override { return get().device_hmm(); }
     void hmm_smooth_runs(const Hmm& h, const double* emissions, const uint64_t* run_offsets, size_t n_runs, double* posterior, uint8_t* back, double* last) override
     {
@@ -645,9 +659,25 @@ inline void smooth_tracks_device(const std::string& out_dir, const Hmm& hmm, boo
             std::vector<uint64_t> exc_index(16);
             std::vector<double> exc_value(16);
             size_t n_exc = 0;
+            // One backend call holds ~60 bytes of device memory per value (emissions, four forward values, posterior, back pointers, bins):
+            // a frame's runs go to the backend in batches of at most GROUP_VALUES values (runs are independent; a single run is never
+            // longer than that here: runs of a million values and more stay on the host, below).
+            auto binned_in_batches = [&](const double* em, const uint64_t* offs, size_t nr, uint16_t* bn, uint8_t* bk, double* ls) -> size_t {
+                size_t total_exc = 0;
+                for (size_t r0 = 0; r0 < nr;) {
+                    size_t r1 = r0 + 1;
+                    while (r1 < nr && offs[r1 + 1] - offs[r0] <= GROUP_VALUES) ++r1;
+                    const uint64_t base = offs[r0];
+                    std::vector<uint64_t> sub(offs + r0, offs + r1 + 1);
+                    for (uint64_t& v : sub) v -= base;
+                    total_exc += backend.hmm_smooth_runs_binned(hmm, em + base, sub.data(), r1 - r0, thresholds.data(), thresholds.size(), bn + base, exc_index.data(),
+                                                                exc_value.data(), exc_index.size(), bk ? bk + base : nullptr, ls ? ls + 4 * r0 : nullptr);
+                    r0 = r1;
+                }
+                return total_exc;
+            };
             if (host_runs.empty()) {
-                n_exc = backend.hmm_smooth_runs_binned(hmm, emit.get(), run_offsets.data(), n_runs, thresholds.data(), thresholds.size(), bins.get(), exc_index.data(),
-                                                       exc_value.data(), exc_index.size(), back.get(), last.get());
+                n_exc = binned_in_batches(emit.get(), run_offsets.data(), n_runs, bins.get(), back.get(), last.get());
             } else {
                 std::vector<uint64_t> d_off{0};
                 for (size_t r : dev_runs) d_off.push_back(d_off.back() + (run_offsets[r + 1] - run_offsets[r]));
@@ -661,8 +691,7 @@ inline void smooth_tracks_device(const std::string& out_dir, const Hmm& hmm, boo
                 });
                 auto device_part = std::async(std::launch::async, [&]() -> size_t {
                     if (dev_runs.empty()) return 0;
-                    return backend.hmm_smooth_runs_binned(hmm, d_emit.get(), d_off.data(), dev_runs.size(), thresholds.data(), thresholds.size(), d_bins.get(), exc_index.data(),
-                                                          exc_value.data(), exc_index.size(), d_back.get(), d_last.get());
+                    return binned_in_batches(d_emit.get(), d_off.data(), dev_runs.size(), d_bins.get(), d_back.get(), d_last.get());
                 });
                 try {
                     parallel_for(host_runs.size(), threads, [&](size_t k) {
@@ -1153,8 +1182,19 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     for (OutFile& f : raw_file) f.commit();
     if (prm.write_smooth || prm.write_regions) {
         sw.lap();
-        if (backend.device_hmm()) smooth_tracks_device(out_dir, prm.hmm, prm.write_smooth, prm.write_regions, /*keep_raw=*/prm.write_raw, threads, backend);
-        else smooth_tracks(out_dir, prm.hmm, prm.write_smooth, prm.write_regions, /*keep_raw=*/prm.write_raw, threads);
+        bool smoothed = false;
+        if (backend.device_hmm()) {
+            // every score is written by now: a failure of the device pass (its memory, say) must not lose the run -- the host pass reads the
+            // same raw tracks and writes the same bytes
+            try {
+                smooth_tracks_device(out_dir, prm.hmm, prm.write_smooth, prm.write_regions, /*keep_raw=*/prm.write_raw, threads, backend);
+                smoothed = true;
+            } catch (const std::exception& ex) {
+                fprintf(stderr, "the smoothing pass on the device failed (%s); running it on the host\n", ex.what());
+            }
+            backend.hmm_release();   // the pass's device buffers (~60 bytes per value of its largest batch)
+        }
+        if (!smoothed) smooth_tracks(out_dir, prm.hmm, prm.write_smooth, prm.write_regions, /*keep_raw=*/prm.write_raw, threads);
         st.smooth_seconds += sw.lap();
     }
     st.total_seconds = total.lap();
@@ -1309,6 +1349,10 @@ inline std::string score_msa(const Model& model, const std::string& maf_path, co
         // blocks are independent: contiguous ranges with about equal site counts (+ a constant per block for its branch
         // matrices) go to the backends, one thread each; CSR offsets are absolute, so every backend sees the same matrix
         const size_t n_dev = std::min(backends.size(), rows.size());
+        if (prm.strategy != ALGO_FIXED) {   // one pruning kernel for the whole FILE, whatever the cut below
+            const int kernel = backend.choose_block_kernel(codons.data(), offsets.data(), rows.size(), stride);
+            for (size_t d = 0; d < n_dev; ++d) backends[d]->set_block_kernel(kernel);
+        }
         std::vector<size_t> cut(n_dev + 1, rows.size());
         cut[0] = 0;
         const double total_cost = static_cast<double>(total) + 16.0 * static_cast<double>(rows.size());

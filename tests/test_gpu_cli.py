@@ -168,6 +168,63 @@ def test_two_scoring_contexts_give_the_same_files(tmp_path):
     assert res[0] == res[1] and len(res[0]) == 50
 
 
+def test_score_msa_scores_do_not_depend_on_how_the_file_is_cut_across_devices(tmp_path):
+    """src/phylocsf++score_msa.hpp:115 "make sure that parallelization does not affect results".  A MIXED file -- dense synthetic blocks
+    (every species present: on their own, prune_tiles' kind of list) followed by the reference's 516 real blocks (4 of 100 species:
+    prune_factored's) -- scored with one context and cut over two and three: the halves of the cut would pick different pruning kernels
+    from their own lists (the kernels round differently), score_msa decides ONCE for the file and pins it (pcsf_set_block_kernel), so
+    the three .scores files are the same bytes, MLE and OMEGA."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_synthetic_maf as gen
+    full = tmp_path / "dense.maf"
+    gen.generate(str(full), bases=60_000, seed=11, tree=os.path.join(GOLD, "models", "100vertebrates"))
+    mixed = tmp_path / "mixed.maf"
+    with open(mixed, "wb") as fo:
+        fo.write(open(full, "rb").read())
+        fo.write(b"\n")
+        with gzip.open(os.path.join(GOLD, "score-msa", "chr22.516alignments.maf.gz"), "rb") as fi:
+            body = fi.read()
+        fo.write(body[body.index(b"\na ") + 1:] if not body.startswith(b"a ") else body)
+    env = dict(os.environ, PCSF_TIME_BLOCKS="1")
+    for strategy, anc in (("mle", "1"), ("omega", "0")):
+        outs, kernels = [], []
+        for i, devs in enumerate((["--device", "0"], ["--devices", "0,0"], ["--devices", "0,0,0"])):
+            out = tmp_path / ("%s_%d" % (strategy, i))
+            os.makedirs(out)
+            p = subprocess.run([_cli(), "score-msa", "--strategy", strategy, "--comp-anc", anc, "--output", str(out)] + devs +
+                               [os.path.join(GOLD, "models", "100vertebrates"), str(mixed)], capture_output=True, text=True, env=env)
+            assert p.returncode == 0, p.stderr[-2000:]
+            outs.append(open(out / "mixed.maf.scores", "rb").read())
+            kernels.append(sorted(set(l.split(": ")[1] for l in p.stderr.splitlines() if l.startswith("pruning kernel of this list"))))
+        rows = outs[0].count(b"\n") - 2
+        assert rows > 550, rows                                         # the dense blocks and the 516 real ones
+        assert all(len(k) == 1 for k in kernels) and kernels[0] == kernels[1] == kernels[2], kernels    # one kernel per FILE
+        assert outs[0] == outs[1] == outs[2], strategy
+    # what the pin is for: left to themselves, the two halves of this file choose different kernels
+    import numpy as np
+    import maf_blocks
+    import oracle_binding as ob
+    import phylocsfpp_amd as pa
+    pm = pa.load_model(os.path.join(GOLD, "models", "100vertebrates"))
+    cod, off = maf_blocks.block_codons(str(mixed), pm.labels, os.path.join(GOLD, "models", "species_aliases.tsv"))
+    ctx = pm.context()
+    try:
+        half = int(np.searchsorted(off, off[-1] // 2))
+        whole = ctx.choose_block_kernel(cod, off)
+        first, second = ctx.choose_block_kernel(cod, off[:half + 1]), ctx.choose_block_kernel(cod, off[half:])
+        assert first != second and whole in (first, second), (whole, first, second)
+        # the same through the library: a list scored whole and cut into two calls, kernel pinned -> the same floats
+        ctx.set_block_kernel(whole)
+        p_all, a_all = ctx.score_blocks(pa.MLE, cod, off)
+        p_a, a_a = ctx.score_blocks(pa.MLE, cod, off[:half + 1])
+        p_b, a_b = ctx.score_blocks(pa.MLE, cod, off[half:])
+        assert p_all.tobytes() == np.concatenate([p_a, p_b]).tobytes() and a_all.tobytes() == np.concatenate([a_a, a_b]).tobytes()
+        ctx.set_block_kernel(pa.ScoringContext.BLOCK_KERNEL_AUTO)
+    finally:
+        ctx.close()
+
+
 def test_score_msa_mle_and_omega_medium_file_on_gpu(tmp_path):
     """The reference's 516-block file (its goldens are shipped but not part of its own test script), MLE and OMEGA.
     PhyloCSF scores: every MLE value within the reference's MLE tolerance (test/tests.sh:41), every OMEGA value within
