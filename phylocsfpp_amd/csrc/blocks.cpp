@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -801,32 +802,95 @@ struct ChainStats {
     double t_setup = 0.0, t_rounds = 0.0, t_wait = 0.0;
 };
 
+// Groups of blocks run as concurrent engines (one host thread each).  hipMalloc while another group's kernels run takes tens of
+// milliseconds per gigabyte (8,256 blocks, MLE: 0.24 s of set-up in the second group while the first was already in its rounds), so
+// every group allocates first and the rounds start together.
+struct StartGate {
+    std::mutex m;
+    std::condition_variable cv;
+    size_t expected = 0, arrived = 0;
+    void arrive_and_wait()
+    {
+        std::unique_lock<std::mutex> g(m);
+        if (++arrived >= expected) cv.notify_all();
+        else cv.wait(g, [&] { return arrived >= expected; });
+    }
+};
+struct GateTicket {   // a group that fails before its rounds must not leave the others waiting
+    StartGate* gate;
+    bool used = false;
+    explicit GateTicket(StartGate* g) : gate(g) {}
+    void pass()
+    {
+        if (gate && !used) {
+            used = true;
+            gate->arrive_and_wait();
+        }
+    }
+    ~GateTicket()
+    {
+        if (gate && !used) {
+            std::lock_guard<std::mutex> g(gate->m);
+            ++gate->arrived;
+            gate->cv.notify_all();
+        }
+    }
+};
+
 // The device engine: `machines` (initialised by the caller) are uploaded, advanced on the device until none is active, and downloaded.
 template <class Machine>
 void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool want_anc, uint32_t seed, bool eager, uint32_t transient0, bool held_systems,
-               const std::atomic<bool>* stop, ChainStats& st)
+               const std::atomic<bool>* stop, StartGate* gate, ChainStats& st)
 {
+    GateTicket ticket(gate);
     const auto t_enter = std::chrono::steady_clock::now();
     constexpr bool MLE = std::is_same<Machine, MleMachine>::value;
+    (void)algo;
     const LookaheadPolicy look = lookahead_policy(eager);
     const uint32_t P = static_cast<uint32_t>(MLE ? 2 * look.max_points : look.max_points);   // evaluation slots per block
     const size_t nb = eng.n_blocks, n_sites = eng.n_sites_total;
-    hipStream_t st0 = eng.stream;
+    hipStream_t st0 = eng.stream, st1 = eng.side;
+    // PCSF_CONTROL_STREAM=1 (experiment, off by default): the small kernels of a round -- advance_blocks, the eigen-solver, the edge scales --
+    // on a control stream of the highest priority, the pruning launches waiting for events.  The idea: on the engine's own streams those
+    // kernels queue behind the OTHER group's pruning work-groups, which fill every SIMD (2 x 250 registers) and leave no room beside them
+    // (advance_blocks 0.40 ms and edge_scale_kernel 0.36 ms per launch on BASELINE.json configs[2] against 0.01-0.03 alone).  Measured: no
+    // gain -- the dispatcher does not hand a freed wave slot to the higher-priority queue first, the kernels take as long, and the events
+    // cost 2-5 % (configs[2] OMEGA 1.41 -> 1.43 s, 8,256 real blocks 0.95 -> 1.06 s; profiles/r04/control_stream.txt).
+    struct ControlStream {
+        pcsf_ctx* c;
+        hipStream_t s = nullptr;
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // edge scales of set 0 / 1 done; pruning of set 0 / 1 done
+        ~ControlStream()
+        {
+            if (s) {
+                (void)hipStreamSynchronize(s);
+                c->control_streams.release(s);
+            }
+            for (hipEvent_t e : ev)
+                if (e) (void)hipEventDestroy(e);
+        }
+    } ctl{eng.c};
+    const bool use_ctl = std::getenv("PCSF_CONTROL_STREAM") && std::atoi(std::getenv("PCSF_CONTROL_STREAM")) != 0;
+    if (use_ctl) {
+        HIP_TRY(eng.c->control_streams.acquire(&ctl.s));
+        for (hipEvent_t& e : ctl.ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    hipStream_t stc = use_ctl ? ctl.s : st0;
     size_t total_tiles = 0;
     for (size_t b = 0; b < nb; ++b) total_tiles += (eng.off[b + 1] - eng.off[b] + 15) / 16;
     DeviceBuffer d_machines, d_stores, d_off, d_draws, d_counters, d_evals, d_eig_jobs, d_jobs, d_groups, d_lnz, d_anc, d_fail;
     BlockEngine::PinnedBuffer h_counters;
+    const size_t eval_cap = nb * P, job_cap = std::max<size_t>(1, total_tiles) * P, group_cap = job_cap;
     HIP_TRY(d_machines.reserve(nb * sizeof(Machine)));
     HIP_TRY(d_stores.reserve(nb * (MLE ? 2 : 1) * STORE_ENTRIES * sizeof(StoreEntry)));
     HIP_TRY(d_off.reserve((nb + 1) * sizeof(uint64_t)));
     HIP_TRY(d_draws.reserve(3 * DRAW_TABLE_ENTRIES * sizeof(double)));
     HIP_TRY(d_counters.reserve(sizeof(ChainCounters)));
     HIP_TRY(h_counters.reserve(sizeof(ChainCounters)));
-    HIP_TRY(d_evals.reserve(nb * P * sizeof(ExpmEval)));
-    if (!MLE) HIP_TRY(d_eig_jobs.reserve(nb * P * sizeof(EigenJob)));
-    HIP_TRY(d_jobs.reserve(std::max<size_t>(1, total_tiles) * P * sizeof(FactoredJob)));
-    const size_t group_cap = std::max<size_t>(1, total_tiles) * P;
-    if (eng.use_tiles) HIP_TRY(d_groups.reserve(4 * group_cap * sizeof(TileGroup)));
+    HIP_TRY(d_evals.reserve(2 * eval_cap * sizeof(ExpmEval)));
+    if (!MLE) HIP_TRY(d_eig_jobs.reserve(eval_cap * sizeof(EigenJob)));
+    HIP_TRY(d_jobs.reserve(2 * job_cap * sizeof(FactoredJob)));
+    if (eng.use_tiles) HIP_TRY(d_groups.reserve(2 * 4 * group_cap * sizeof(TileGroup)));
     HIP_TRY(d_lnz.reserve(std::max<size_t>(1, n_sites) * P * sizeof(double)));
     if (want_anc) HIP_TRY(d_anc.reserve(std::max<size_t>(1, n_sites) * P * sizeof(double)));
     HIP_TRY(d_fail.reserve(nb * P * sizeof(uint32_t)));
@@ -857,19 +921,22 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
     cp.transient0 = transient0;
     cp.use_tiles = eng.use_tiles ? 1u : 0u;
     cp.split_sizes = (eng.use_tiles && nb >= 1024) ? 1u : 0u;   // short lists: one launch of full work-groups (a launch that does not fill the chip is bound by one tile's latency)
+    if (const char* v = std::getenv("PCSF_SPLIT_SIZES")) cp.split_sizes = (eng.use_tiles && std::atoi(v) != 0) ? 1u : 0u;   // A/B knob
     cp.counters = d_counters.as<ChainCounters>();
     cp.evals = d_evals.as<ExpmEval>();
+    cp.eval_capacity = static_cast<uint32_t>(eval_cap);
     cp.eig_jobs = MLE ? nullptr : d_eig_jobs.as<EigenJob>();
     cp.tile_jobs = d_jobs.as<FactoredJob>();
+    cp.job_capacity = static_cast<uint32_t>(job_cap);
     cp.groups = eng.use_tiles ? d_groups.as<TileGroup>() : nullptr;
     cp.group_capacity = static_cast<uint32_t>(group_cap);
     // MLE on prune_tiles: every block uses the same two eigen-systems, so the tile jobs of a round go to one list per model and any four
     // consecutive jobs of a list share a work-group (full work-groups whatever the blocks' lengths); the groups are the same every round
     const bool pack_models = MLE && eng.use_tiles;
     cp.pack_models = pack_models ? 1u : 0u;
-    cp.list_capacity = static_cast<uint32_t>(group_cap / 2);
+    cp.list_capacity = static_cast<uint32_t>(job_cap);
     if (pack_models) {
-        std::vector<TileGroup> fixed(group_cap / 2 / TILE_JOBS_PER_GROUP + 1);
+        std::vector<TileGroup> fixed(job_cap / TILE_JOBS_PER_GROUP + 1);
         for (size_t g = 0; g < fixed.size(); ++g) fixed[g] = TileGroup{static_cast<uint32_t>(g * TILE_JOBS_PER_GROUP), TILE_JOBS_PER_GROUP};
         HIP_TRY(hipMemcpyAsync(d_groups.ptr, fixed.data(), fixed.size() * sizeof(TileGroup), hipMemcpyHostToDevice, st0));
         HIP_TRY(hipStreamSynchronize(st0));   // `fixed` is a local
@@ -909,60 +976,110 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
     gp.eig_w = eng.d_eig_w.template as<double>();
     gp.fail = d_fail.as<uint32_t>();
     st.t_setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count();
+    ticket.pass();   // every group of the call has allocated
 
-    const auto t_loop = std::chrono::steady_clock::now();
-    const ChainCounters* hc = static_cast<const ChainCounters*>(h_counters.ptr);
-    for (;;) {
-        if (stop && stop->load(std::memory_order_relaxed)) throw std::runtime_error("another group of this call failed");
-        HIP_TRY(hipMemsetAsync(d_counters.ptr, 0, sizeof(ChainCounters), st0));
-        HIP_TRY(launch_advance_blocks(cp, MLE ? 0 : 2, static_cast<uint32_t>(nb), st0));
-        HIP_TRY(hipMemcpyAsync(h_counters.ptr, d_counters.ptr, sizeof(ChainCounters), hipMemcpyDeviceToHost, st0));
-        const auto t_w = std::chrono::steady_clock::now();
-        HIP_TRY(hipStreamSynchronize(st0));
-        st.t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w).count();
-        const ChainCounters cnt = *hc;
-        if (cnt.n_active == 0) break;
-        ++st.rounds;
-        st.evals += cnt.n_evals;
-        st.eig_jobs += cnt.n_eig_jobs;
-        st.tile_jobs += cnt.n_tile_jobs;
-        if (cnt.n_evals > nb * P || cnt.n_tile_jobs > group_cap || cnt.n_list[0] > group_cap / 2 || cnt.n_list[1] > group_cap / 2)
-            throw std::runtime_error("advance_blocks: a job list overflowed");
-        if (cnt.n_eig_jobs) {
-            if (eng.host_eigen) throw std::runtime_error("PCSF_EIGEN_HOST needs PCSF_BLOCK_ENGINE=host");
-            gp.n_jobs = cnt.n_eig_jobs;
-            HIP_TRY(launch_eigen_omega(gp, st0));
-        }
-        HIP_TRY(launch_edge_scale(cp.evals, cnt.n_evals, static_cast<uint32_t>(eng.n - 1), eng.d_branch_len.template as<float>(), eng.d_eig_r.template as<double>(),
-                                  eng.d_eig_l.template as<double>(), eng.d_eig_lam.template as<double>(), eng.d_scale.template as<double>(), d_fail.as<uint32_t>(), st0));
-        fp.jobs = cp.tile_jobs;
-        fp.n_jobs = cnt.n_tile_jobs;
+    // the round's evaluations of one set: edge scales (on `scale_stream`), then pruning (on `stream`)
+    auto launch_scales = [&](int set, const ChainCounters& cnt, hipStream_t stream) {
+        HIP_TRY(launch_edge_scale(cp.evals + static_cast<size_t>(set) * eval_cap, cnt.n_evals[set], static_cast<uint32_t>(eng.n - 1), eng.d_branch_len.template as<float>(),
+                                  eng.d_eig_r.template as<double>(), eng.d_eig_l.template as<double>(), eng.d_eig_lam.template as<double>(), eng.d_scale.template as<double>(),
+                                  d_fail.as<uint32_t>(), stream));
+    };
+    auto launch_pruning = [&](int set, const ChainCounters& cnt, hipStream_t stream) {
         if (pack_models) {
-            for (int model = 0; model < 2; ++model) {
+            for (int model = 0; model < 2 && set == 0; ++model) {
                 if (!cnt.n_list[model]) continue;
                 st.tile_jobs += cnt.n_list[model];
                 fp.jobs = cp.tile_jobs + static_cast<size_t>(model) * cp.list_capacity;
                 fp.n_jobs = cnt.n_list[model];
                 fp.groups = cp.groups;
                 fp.n_groups = (cnt.n_list[model] + TILE_JOBS_PER_GROUP - 1) / TILE_JOBS_PER_GROUP;
-                HIP_TRY(launch_prune_tiles_sized(fp, static_cast<int>(TILE_JOBS_PER_GROUP), st0));
+                HIP_TRY(launch_prune_tiles_sized(fp, static_cast<int>(TILE_JOBS_PER_GROUP), stream));
             }
-        } else if (eng.use_tiles) {
+            return;
+        }
+        if (!cnt.n_tile_jobs[set]) return;
+        st.tile_jobs += cnt.n_tile_jobs[set];
+        fp.jobs = cp.tile_jobs + static_cast<size_t>(set) * job_cap;
+        fp.n_jobs = cnt.n_tile_jobs[set];
+        if (eng.use_tiles) {
             for (int list = 3; list >= 0; --list) {   // largest work-groups first (tiles.hip launch_tiles_impl)
-                if (!cnt.n_groups[list]) continue;
-                fp.groups = cp.groups + static_cast<size_t>(list) * group_cap;
-                fp.n_groups = cnt.n_groups[list];
-                HIP_TRY(launch_prune_tiles_sized(fp, cp.split_sizes ? list + 1 : static_cast<int>(TILE_JOBS_PER_GROUP), st0));
+                if (!cnt.n_groups[set][list]) continue;
+                fp.groups = cp.groups + (static_cast<size_t>(set) * 4 + list) * group_cap;
+                fp.n_groups = cnt.n_groups[set][list];
+                HIP_TRY(launch_prune_tiles_sized(fp, cp.split_sizes ? list + 1 : static_cast<int>(TILE_JOBS_PER_GROUP), stream));
             }
-        } else if (cnt.n_tile_jobs) {
+        } else {
             fp.groups = nullptr;
             fp.n_groups = 0;
-            HIP_TRY(launch_prune_factored(fp, st0));
+            HIP_TRY(launch_prune_factored(fp, stream));
+        }
+    };
+    const auto t_loop = std::chrono::steady_clock::now();
+    const bool trace_rounds = std::getenv("PCSF_TRACE_ROUNDS") != nullptr;   // diagnostics: one line per round
+    const ChainCounters* hc = static_cast<const ChainCounters*>(h_counters.ptr);
+    bool pruned[2] = {false, false};   // the previous round launched pruning of the set (its event is recorded)
+    for (;;) {
+        if (stop && stop->load(std::memory_order_relaxed)) throw std::runtime_error("another group of this call failed");
+        // advance_blocks reads what the pruning kernels of the previous round wrote
+        if (use_ctl) {
+            for (int set = 0; set < 2; ++set)
+                if (pruned[set]) HIP_TRY(hipStreamWaitEvent(stc, ctl.ev[2 + set], 0));
+        }
+        HIP_TRY(hipMemsetAsync(d_counters.ptr, 0, sizeof(ChainCounters), stc));
+        HIP_TRY(launch_advance_blocks(cp, MLE ? 0 : 2, static_cast<uint32_t>(nb), stc));
+        HIP_TRY(hipMemcpyAsync(h_counters.ptr, d_counters.ptr, sizeof(ChainCounters), hipMemcpyDeviceToHost, stc));
+        const auto t_w = std::chrono::steady_clock::now();
+        HIP_TRY(hipStreamSynchronize(stc));
+        st.t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w).count();
+        const ChainCounters cnt = *hc;
+        if (trace_rounds)
+            fprintf(stderr, "round %zu at %.3f ms: %u blocks active, %u + %u evaluations, %u eigen-systems, %u + %u tile jobs (waited %.3f ms for the previous round)\n", st.rounds,
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count() * 1e3, cnt.n_active, cnt.n_evals[0], cnt.n_evals[1], cnt.n_eig_jobs,
+                    cnt.n_tile_jobs[0] + cnt.n_list[0] + cnt.n_list[1], cnt.n_tile_jobs[1], std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w).count() * 1e3);
+        if (cnt.n_active == 0) break;
+        ++st.rounds;
+        st.evals += cnt.n_evals[0] + cnt.n_evals[1];
+        st.eig_jobs += cnt.n_eig_jobs;
+        if (cnt.n_evals[0] > eval_cap || cnt.n_evals[1] > eval_cap || cnt.n_tile_jobs[0] > job_cap || cnt.n_tile_jobs[1] > job_cap || cnt.n_list[0] > job_cap || cnt.n_list[1] > job_cap)
+            throw std::runtime_error("advance_blocks: a job list overflowed");
+        if (cnt.n_eig_jobs && eng.host_eigen) throw std::runtime_error("PCSF_EIGEN_HOST needs PCSF_BLOCK_ENGINE=host");
+        gp.n_jobs = cnt.n_eig_jobs;
+        if (use_ctl) {
+            // control stream: edge scales of set 0, the eigen-systems, edge scales of set 1; the pruning launches wait for their set's scales
+            pruned[0] = pruned[1] = false;
+            if (cnt.n_evals[0]) {
+                launch_scales(0, cnt, stc);
+                HIP_TRY(hipEventRecord(ctl.ev[0], stc));
+                HIP_TRY(hipStreamWaitEvent(st0, ctl.ev[0], 0));
+                launch_pruning(0, cnt, st0);
+                HIP_TRY(hipEventRecord(ctl.ev[2], st0));
+                pruned[0] = true;
+            }
+            if (cnt.n_evals[1]) {
+                if (cnt.n_eig_jobs) HIP_TRY(launch_eigen_omega(gp, stc));
+                launch_scales(1, cnt, stc);
+                HIP_TRY(hipEventRecord(ctl.ev[1], stc));
+                HIP_TRY(hipStreamWaitEvent(st1, ctl.ev[1], 0));
+                launch_pruning(1, cnt, st1);
+                HIP_TRY(hipEventRecord(ctl.ev[3], st1));
+                pruned[1] = true;
+            }
+        } else {
+            // set 1 on the side stream: the eigen-solver is bound by the latency of its slowest job and leaves most of the chip to set 0
+            if (cnt.n_evals[1]) {
+                if (cnt.n_eig_jobs) HIP_TRY(launch_eigen_omega(gp, st1));
+                launch_scales(1, cnt, st1);
+                launch_pruning(1, cnt, st1);
+                HIP_TRY(hipEventRecord(eng.ev_side, st1));
+            }
+            launch_scales(0, cnt, st0);
+            launch_pruning(0, cnt, st0);
+            if (cnt.n_evals[1]) HIP_TRY(hipStreamWaitEvent(st0, eng.ev_side, 0));   // the next advance_blocks reads both sets' results
         }
     }
     st.t_rounds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
-    HIP_TRY(hipMemcpyAsync(machines.data(), d_machines.ptr, nb * sizeof(Machine), hipMemcpyDeviceToHost, st0));
-    HIP_TRY(hipStreamSynchronize(st0));
+    HIP_TRY(hipMemcpyAsync(machines.data(), d_machines.ptr, nb * sizeof(Machine), hipMemcpyDeviceToHost, stc));
+    HIP_TRY(hipStreamSynchronize(stc));
 }
 
 // The host engine: the same machines, advanced on host threads; a round's requests go through BlockEngine::queue / run.
@@ -1030,9 +1147,10 @@ void print_chain_stats(const char* what, size_t n_blocks, bool device, bool tile
 
 // ---- MLE ---------------------------------------------------------------------------------------
 int run_mle(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_blocks, size_t leaf_stride, int compute_anc,
-            uint32_t seed, float* out_phylo, float* out_anc, bool tiles, bool own_streams, bool eager, const std::atomic<bool>* stop)
+            uint32_t seed, float* out_phylo, float* out_anc, bool tiles, bool own_streams, bool eager, const std::atomic<bool>* stop, StartGate* gate)
 {
     const auto t_enter = std::chrono::steady_clock::now();
+    GateTicket ticket(gate);   // (the host engine does not wait at the gate, but must not leave others waiting)
     BlockEngine eng(c, codons, off, n_blocks, leaf_stride, tiles, own_streams);
     eng.reserve_eig(2);
     eng.upload_eig(0, c->eig[0], c->pi[0].data());
@@ -1042,14 +1160,15 @@ int run_mle(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_bl
     ChainStats st;
     const bool device = use_device_engine() && !eng.host_eigen;
     if (device) {
-        run_chain(eng, machines, PCSF_MLE, compute_anc != 0, seed, eager, 0u, true, stop, st);
+        ticket.used = true;   // run_chain holds the ticket from here
+        run_chain(eng, machines, PCSF_MLE, compute_anc != 0, seed, eager, 0u, true, stop, gate, st);
     } else {
         const std::vector<double> table = make_draw_table(seed, 1e-2, 10.0);
         std::vector<StoreEntry> stores(n_blocks * 2 * STORE_ENTRIES);
         const DrawTable dt{table.data(), DRAW_TABLE_ENTRIES};
         const LookaheadPolicy look = lookahead_policy(eager);
         run_host_rounds(eng, machines, 2 * look.max_points, compute_anc != 0, stop, st, [] {}, [&](size_t b, const EvalResult* res, EvalRequest* out) {
-            return machines[b].round(res, stores.data() + b * 2 * STORE_ENTRIES, dt, look.eager, look.max_points, look.max_restarts, compute_anc != 0, out);
+            return machines[b].round(res, stores.data() + b * 2 * STORE_ENTRIES, STORE_ENTRIES, dt, look.eager, look.max_points, look.max_restarts, compute_anc != 0, out);
         });
     }
     if (std::getenv("PCSF_TIME_BLOCKS")) {
@@ -1076,9 +1195,10 @@ int run_mle(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_bl
 
 // ---- OMEGA -------------------------------------------------------------------------------------
 int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_blocks, size_t leaf_stride, uint32_t seed,
-              float* out_phylo, float* out_anc, bool tiles, bool own_streams, bool eager, const std::atomic<bool>* stop)
+              float* out_phylo, float* out_anc, bool tiles, bool own_streams, bool eager, const std::atomic<bool>* stop, StartGate* gate)
 {
     const auto t_enter = std::chrono::steady_clock::now();
+    GateTicket ticket(gate);
     BlockEngine eng(c, codons, off, n_blocks, leaf_stride, tiles, own_streams);
     // eigen-system slots [role * n_blocks + b]: what block b holds (EigRole; roles are swapped between them, see OmegaMachine);
     // slots N_ROLES * n_blocks + b * max_points + k: the probes of a round that are not kept (random restarts)
@@ -1112,7 +1232,8 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
     ChainStats st;
     const bool device = use_device_engine() && !eng.host_eigen;
     if (device) {
-        run_chain(eng, machines, PCSF_OMEGA, false, seed, eager, static_cast<uint32_t>(transient0), held_systems, stop, st);
+        ticket.used = true;
+        run_chain(eng, machines, PCSF_OMEGA, false, seed, eager, static_cast<uint32_t>(transient0), held_systems, stop, gate, st);
     } else {
         const std::vector<double> t_rho = make_draw_table(seed, 0.001, 10.0), t_kappa = make_draw_table(seed, 1.0, 10.0);
         const DrawTable dr{t_rho.data(), DRAW_TABLE_ENTRIES}, dk{t_kappa.data(), DRAW_TABLE_ENTRIES};
@@ -1345,7 +1466,7 @@ int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
     std::vector<Range> ranges;
     for (size_t b0 = 0; b0 < n_blocks; b0 += chunk) ranges.push_back({b0, std::min(chunk, n_blocks - b0)});
     std::atomic<bool> stop_groups{false};   // set by the first group that fails: the others leave at their next round
-    auto run_range = [&](const Range& r, bool own_streams) -> int {
+    auto run_range = [&](const Range& r, bool own_streams, StartGate* gate) -> int {
         std::vector<uint64_t> off(r.nb + 1);  // CSR offsets re-based at the range's first site
         for (size_t b = 0; b <= r.nb; ++b) off[b] = site_offsets[r.b0 + b] - site_offsets[r.b0];
         const uint8_t* cod = codons ? codons + site_offsets[r.b0] : nullptr;
@@ -1353,13 +1474,13 @@ int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
         float* an = out_anc ? out_anc + r.b0 : nullptr;
         switch (algo) {
             case PCSF_FIXED: return run_fixed(c, cod, off.data(), r.nb, leaf_stride, compute_anc, ph, an);
-            case PCSF_MLE: return run_mle(c, cod, off.data(), r.nb, leaf_stride, compute_anc, seed, ph, an, tiles, own_streams, eager, &stop_groups);
-            default: return run_omega(c, cod, off.data(), r.nb, leaf_stride, seed, ph, an, tiles, own_streams, eager, &stop_groups);
+            case PCSF_MLE: return run_mle(c, cod, off.data(), r.nb, leaf_stride, compute_anc, seed, ph, an, tiles, own_streams, eager, &stop_groups, gate);
+            default: return run_omega(c, cod, off.data(), r.nb, leaf_stride, seed, ph, an, tiles, own_streams, eager, &stop_groups, gate);
         }
     };
     if (n_groups <= 1 || ranges.size() <= 1) {
         for (const Range& r : ranges) {
-            const int rc = run_range(r, false);
+            const int rc = run_range(r, false, nullptr);
             if (rc != PCSF_OK) return rc;
         }
         return PCSF_OK;
@@ -1370,15 +1491,22 @@ int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
     std::string err;
     int err_rc = PCSF_OK;
     std::vector<std::thread> th;
+    StartGate gate;   // the groups' first ranges allocate, then start their rounds together
+    gate.expected = std::min(n_groups, ranges.size());
     for (size_t g = 0; g < std::min(n_groups, ranges.size()); ++g)
         th.emplace_back([&]() {
             const hipError_t dev_rc = hipSetDevice(c->device);  // the current device is per host thread
+            bool first = true;
+            GateTicket unused_ticket(&gate);   // a thread that never reaches a first range still counts
             for (size_t i = next++; i < ranges.size(); i = next++) {
                 int rc = PCSF_OK;
                 std::string msg;
                 try {
                     if (dev_rc != hipSuccess) throw std::runtime_error(std::string("hipSetDevice: ") + hipGetErrorString(dev_rc));
-                    rc = run_range(ranges[i], true);
+                    StartGate* g_first = first ? &gate : nullptr;
+                    if (first) unused_ticket.used = true;
+                    first = false;
+                    rc = run_range(ranges[i], true, g_first);
                 } catch (const std::exception& ex) {
                     rc = PCSF_ERR_HIP;
                     msg = ex.what();

@@ -57,86 +57,139 @@ template <> struct MachineTraits<OmegaMachine> {
     static constexpr int STORES = 1;
 };
 
+// What the wave works on sits in LDS while it works: the machine (~1 KB), the stores' values (a search has seen 10-40 when it ends) and the
+// per-site values to be added up.  Lane 0's walk through the state machine is a chain of dependent reads -- from HBM it was ~0.4 ms per
+// round whatever the number of blocks (profiles/r04), every round of every group waiting for it.
+constexpr uint32_t LDS_STORE_ENTRIES = 96;   // per store; a search with more values than that (it is exhausting its restarts) works on the store in HBM
+constexpr uint32_t SUM_CHUNK = 64;
+
 template <class M>
 __global__ __launch_bounds__(64) void advance_blocks(const ChainParams p)
 {
     constexpr int MAX_REQ = MachineTraits<M>::MAX_REQ;
+    constexpr int STORES = MachineTraits<M>::STORES;
+    constexpr uint32_t M_WORDS = (sizeof(M) + 3) / 4;
     __shared__ EvalResult res[MAX_REQ];
     __shared__ EvalRequest req[MAX_REQ];
+    __shared__ __attribute__((aligned(16))) uint32_t m_words[M_WORDS];
+    __shared__ StoreEntry st_lds[STORES * LDS_STORE_ENTRIES];
+    __shared__ double sum_buf[MAX_REQ * SUM_CHUNK];
     __shared__ int n_req_s;
     __shared__ uint32_t base_s[4];
     const uint32_t b = blockIdx.x, lane = threadIdx.x;
-    M* m = reinterpret_cast<M*>(p.machines) + b;
+    uint32_t* m_global = reinterpret_cast<uint32_t*>(reinterpret_cast<M*>(p.machines) + b);
+    for (uint32_t w = lane; w < M_WORDS; w += 64) m_words[w] = m_global[w];
+    __syncthreads();
+    M* m = reinterpret_cast<M*>(m_words);
     const uint64_t s0 = p.off[b], s1 = p.off[b + 1], sites = s1 - s0;
     const uint32_t P = p.slots_per_block;
-    // (1) the values of the pending evaluations
-    const uint32_t n_pending = m->n_pending;
-    if (lane < n_pending) {
-        const double* __restrict__ lz = p.out_lnz + static_cast<size_t>(P) * s0 + static_cast<size_t>(lane) * sites;
-        double l = 0.0, a = 0.0;
-        for (uint64_t i = 0; i < sites; ++i) l += lz[i];
-        if (p.out_anc) {
-            const double* __restrict__ az = p.out_anc + static_cast<size_t>(P) * s0 + static_cast<size_t>(lane) * sites;
-            for (uint64_t i = 0; i < sites; ++i) a += az[i];
+    // the stores' values: into LDS when they (and this round's new ones) fit
+    StoreEntry* store_global = p.stores + static_cast<size_t>(b) * STORES * STORE_ENTRIES;
+    uint32_t n_store_in[STORES];
+    bool in_lds = true;
+    for (int k = 0; k < STORES; ++k) {
+        if constexpr (STORES == 2) n_store_in[k] = m->n_store[k];
+        else n_store_in[k] = m->n_store;
+        in_lds = in_lds && n_store_in[k] + MAX_REQ <= LDS_STORE_ENTRIES;
+    }
+    if (in_lds)
+        for (int k = 0; k < STORES; ++k) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(store_global + static_cast<size_t>(k) * STORE_ENTRIES);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(st_lds + k * LDS_STORE_ENTRIES);
+            for (uint32_t w = lane; w < n_store_in[k] * (sizeof(StoreEntry) / 4); w += 64) dst[w] = src[w];
         }
-        res[lane].lnz = l;
-        res[lane].anc = a;
-        res[lane].failed = p.fail[static_cast<size_t>(b) * P + lane];
+    // (1) the values of the pending evaluations: per-site terms through LDS in chunks (coalesced), lane e adds evaluation e's in site order
+    const uint32_t n_pending = m->n_pending;
+    {
+        double l = 0.0, a = 0.0;
+        for (int pass = 0; pass < (p.out_anc ? 2 : 1); ++pass) {
+            const double* __restrict__ src = (pass ? p.out_anc : p.out_lnz) + static_cast<size_t>(P) * s0;
+            double acc = 0.0;
+            for (uint64_t c0 = 0; c0 < sites; c0 += SUM_CHUNK) {
+                const uint32_t len = static_cast<uint32_t>(sites - c0 < SUM_CHUNK ? sites - c0 : SUM_CHUNK);
+                __syncthreads();
+                if (lane < len)
+                    for (uint32_t e = 0; e < n_pending; ++e) sum_buf[e * SUM_CHUNK + lane] = src[static_cast<size_t>(e) * sites + c0 + lane];
+                __syncthreads();
+                if (lane < n_pending)
+                    for (uint32_t i = 0; i < len; ++i) acc += sum_buf[lane * SUM_CHUNK + i];
+            }
+            (pass ? a : l) = acc;
+        }
+        if (lane < n_pending) {
+            res[lane].lnz = l;
+            res[lane].anc = a;
+            res[lane].failed = p.fail[static_cast<size_t>(b) * P + lane];
+        }
     }
     __syncthreads();
     // (2) the block's machine
     if (lane == 0) {
-        StoreEntry* store = p.stores + static_cast<size_t>(b) * MachineTraits<M>::STORES * STORE_ENTRIES;
         int n;
-        if constexpr (MachineTraits<M>::STORES == 2) {
-            n = m->round(res, store, DrawTable{p.draws[0], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points), static_cast<int>(p.max_restarts), p.out_anc != nullptr, req);
+        // (two calls, not one call on a pointer chosen between LDS and HBM: the select of generic pointers trips the gfx950 back end --
+        // "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base", ROCm 7.2)
+        if constexpr (STORES == 2) {
+            if (in_lds) n = m->round(res, st_lds, LDS_STORE_ENTRIES, DrawTable{p.draws[0], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points), static_cast<int>(p.max_restarts), p.out_anc != nullptr, req);
+            else n = m->round(res, store_global, STORE_ENTRIES, DrawTable{p.draws[0], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points), static_cast<int>(p.max_restarts), p.out_anc != nullptr, req);
         } else {
-            n = m->round(res, store, DrawTable{p.draws[1], p.n_draws}, DrawTable{p.draws[2], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points),
-                         static_cast<int>(p.max_restarts), p.held_systems != 0, p.transient0 + b * P, DevicePrior(), req);
+            if (in_lds) n = m->round(res, st_lds, DrawTable{p.draws[1], p.n_draws}, DrawTable{p.draws[2], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points),
+                                     static_cast<int>(p.max_restarts), p.held_systems != 0, p.transient0 + b * P, DevicePrior(), req);
+            else n = m->round(res, store_global, DrawTable{p.draws[1], p.n_draws}, DrawTable{p.draws[2], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points),
+                              static_cast<int>(p.max_restarts), p.held_systems != 0, p.transient0 + b * P, DevicePrior(), req);
         }
         n_req_s = n;
         if (m->active) atomicAdd(&p.counters->n_active, 1u);
     }
     __syncthreads();
-    // (3) this round's job records
+    // the machine and what the stores hold now, back to HBM
+    for (uint32_t w = lane; w < M_WORDS; w += 64) m_global[w] = m_words[w];
+    if (in_lds)
+        for (int k = 0; k < STORES; ++k) {
+            uint32_t n_now;
+            if constexpr (STORES == 2) n_now = m->n_store[k];
+            else n_now = m->n_store;
+            uint32_t* dst = reinterpret_cast<uint32_t*>(store_global + static_cast<size_t>(k) * STORE_ENTRIES);
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(st_lds + k * LDS_STORE_ENTRIES);
+            for (uint32_t w = lane; w < n_now * (sizeof(StoreEntry) / 4); w += 64) dst[w] = src[w];
+        }
+    // (3) this round's job records.  Set 1: evaluations that wait for an eigen-system solved in this round; set 0: the others.
     const int n_req = n_req_s;
     const uint32_t n_tiles = static_cast<uint32_t>((sites + 15) / 16);
-    for (int i = 0; i < n_req; ++i) {
+    for (int i = lane; i < n_req; i += 64) {
         const EvalRequest& r = req[i];
-        const uint32_t table = b * P + static_cast<uint32_t>(i);
-        if (lane == 0) {
-            p.fail[table] = 0u;
-            ExpmEval ev;
-            ev.eig = r.eig;
-            ev.table = table;
-            ev.block = b;
-            ev.pad = p.use_tiles;
-            ev.x = r.tree_scale;
-            p.evals[atomicAdd(&p.counters->n_evals, 1u)] = ev;
-            if (r.new_eigen == 1u) {
-                EigenJob j;
-                j.eig = r.eig;
-                j.table = table;
-                j.warm = r.warm;
-                j.pad = 0;
-                for (int k = 0; k < 12; ++k) j.qs[k] = r.qs[k];
-                p.eig_jobs[atomicAdd(&p.counters->n_eig_jobs, 1u)] = j;
-            }
+        const uint32_t table = b * P + static_cast<uint32_t>(i), set = r.new_eigen ? 1u : 0u;
+        p.fail[table] = 0u;
+        ExpmEval ev;
+        ev.eig = r.eig;
+        ev.table = table;
+        ev.block = b;
+        ev.pad = p.use_tiles;
+        ev.x = r.tree_scale;
+        p.evals[static_cast<size_t>(set) * p.eval_capacity + atomicAdd(&p.counters->n_evals[set], 1u)] = ev;
+        if (r.new_eigen == 1u) {
+            EigenJob j;
+            j.eig = r.eig;
+            j.table = table;
+            j.warm = r.warm;
+            j.pad = 0;
+            for (int k = 0; k < 12; ++k) j.qs[k] = r.qs[k];
+            p.eig_jobs[atomicAdd(&p.counters->n_eig_jobs, 1u)] = j;
         }
     }
     // tile jobs: requests that share an eigen-system (the rho points of a round all use the block's own; MLE: the model's) are laid out
     // together, so that their tiles can share work-groups
     for (int i0 = 0; i0 < n_req;) {
+        const uint32_t eig = req[i0].eig, set = req[i0].new_eigen ? 1u : 0u;
         int i1 = i0 + 1;
-        while (i1 < n_req && req[i1].eig == req[i0].eig && !p.pack_models) ++i1;
+        while (i1 < n_req && req[i1].eig == eig && (req[i1].new_eigen ? 1u : 0u) == set && !p.pack_models) ++i1;
         const uint32_t run_tiles = n_tiles * static_cast<uint32_t>(i1 - i0);
-        const uint32_t eig = req[i0].eig;
         if (lane == 0) {
             if (p.pack_models) base_s[0] = eig * p.list_capacity + atomicAdd(&p.counters->n_list[eig], run_tiles);
-            else base_s[0] = atomicAdd(&p.counters->n_tile_jobs, run_tiles);
+            else base_s[0] = atomicAdd(&p.counters->n_tile_jobs[set], run_tiles);
         }
         __syncthreads();
         const uint32_t job0 = base_s[0];
+        FactoredJob* __restrict__ jobs = p.tile_jobs + (p.pack_models ? 0 : static_cast<size_t>(set) * p.job_capacity);
         for (uint32_t t = lane; t < run_tiles; t += 64) {
             const uint32_t i = static_cast<uint32_t>(i0) + t / n_tiles, tile = t % n_tiles;
             FactoredJob j;
@@ -146,7 +199,7 @@ __global__ __launch_bounds__(64) void advance_blocks(const ChainParams p)
             j.eig = eig;
             j.eval = b * P + i;
             j.pad = 0;
-            p.tile_jobs[job0 + t] = j;
+            jobs[job0 + t] = j;
         }
         if (p.use_tiles && !p.pack_models) {
             // the run's tiles in even parts of at most TILE_JOBS_PER_GROUP (one wave per tile, one eigen-system per work-group);
@@ -155,8 +208,8 @@ __global__ __launch_bounds__(64) void advance_blocks(const ChainParams p)
             for (uint32_t k = lane; k < parts; k += 64) {
                 const uint32_t a = run_tiles * k / parts, e = run_tiles * (k + 1) / parts, size = e - a;
                 const uint32_t list = p.split_sizes ? (size < TILE_JOBS_PER_GROUP ? size - 1 : TILE_JOBS_PER_GROUP - 1) : 0u;
-                const uint32_t g = atomicAdd(&p.counters->n_groups[list], 1u);
-                p.groups[static_cast<size_t>(list) * p.group_capacity + g] = TileGroup{job0 + a, size};
+                const uint32_t g = atomicAdd(&p.counters->n_groups[set][list], 1u);
+                p.groups[(static_cast<size_t>(set) * 4 + list) * p.group_capacity + g] = TileGroup{job0 + a, size};
             }
         }
         __syncthreads();   // base_s is rewritten by the next run

@@ -73,6 +73,18 @@ struct StreamPool {
     std::mutex lock;
     std::vector<hipStream_t> idle;
     std::thread warming;
+    explicit StreamPool(bool high = false) : high_priority(high) {}
+    bool high_priority = false;   // the pool of control streams (blocks.cpp run_chain): created at the device's highest stream priority
+    static hipError_t make_stream(hipStream_t* s, bool high)
+    {
+        if (high) {
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+                return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+            (void)hipGetLastError();
+        }
+        return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    }
     void warm_up(int device, int count)
     {
         std::lock_guard<std::mutex> g(lock);
@@ -84,7 +96,7 @@ struct StreamPool {
             std::vector<hipStream_t> made;
             for (int i = 0; i < count; ++i) {
                 hipStream_t s = nullptr;
-                if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+                if (make_stream(&s, high_priority) != hipSuccess) break;
                 (void)hipMemsetAsync(scratch, 0, 256, s);   // the queue behind a stream is created at its first operation
                 made.push_back(s);
             }
@@ -115,7 +127,7 @@ struct StreamPool {
                 return hipSuccess;
             }
         }
-        return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+        return make_stream(out, high_priority);
     }
     void release(hipStream_t s)   // the caller has synchronised it
     {
@@ -167,6 +179,7 @@ struct pcsf_ctx {
     uint32_t stamp_block = 0;
     hipStream_t stream = nullptr;        // private stream for host-pointer entry points
     pcsf::StreamPool block_streams;      // streams of the MLE / OMEGA engines (blocks.cpp)
+    pcsf::StreamPool control_streams{true};   // ... and their control streams (highest priority: the small kernels between two pruning launches)
     int block_kernel = 0;                // pcsf_block_kernel: AUTO = every pcsf_score_blocks call decides from its own list
     hipEvent_t ev_kernels = nullptr;     // behind the kernels of this context's last six-frame call
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

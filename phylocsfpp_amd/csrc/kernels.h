@@ -168,14 +168,15 @@ hipError_t launch_prune_tiles_sized(const FactoredParams& p, int waves, hipStrea
 // ---- the optimiser loop on the device (chain.hip + machine.hpp) ----------------------------------------------------------------------
 struct StoreEntry;
 struct EigenJob;
+// A round's evaluations come in two sets: set 1 = those that wait for an eigen-system solved in this round (eigen -> edge scales -> pruning
+// on the engine's side stream), set 0 = all others (edge scales -> pruning on its main stream, beside the eigen-solver's launch)
 struct ChainCounters {       // zeroed before every round; read by the host after advance_blocks to size the round's launches
     uint32_t n_active;       // blocks that are not finished
-    uint32_t n_evals;        // evaluations requested this round (edge_scale_kernel work-groups)
-    uint32_t n_eig_jobs;     // of which with a new eigen-system (eigen_omega_kernel work-groups)
-    uint32_t n_tile_jobs;
-    uint32_t n_groups[4];    // tile groups by number of tiles: 1, 2, 3, TILE_JOBS_PER_GROUP (all in [0] when !split_sizes)
+    uint32_t n_eig_jobs;     // evaluations with a new eigen-system (eigen_omega_kernel work-groups)
+    uint32_t n_evals[2];     // evaluations requested this round, by set (edge_scale_kernel work-groups)
+    uint32_t n_tile_jobs[2];
+    uint32_t n_groups[2][4]; // tile groups by set and number of tiles: 1, 2, 3, TILE_JOBS_PER_GROUP (all in [0] when !split_sizes)
     uint32_t n_list[2];      // pack_models: tile jobs of the coding / non-coding model (lists of their own: any four of a list share a work-group)
-    uint32_t pad[6];
 };
 struct ChainParams {
     void* machines;              // [n_blocks] MleMachine or OmegaMachine
@@ -194,10 +195,12 @@ struct ChainParams {
                                  // (the second at tile_jobs + list_capacity) and every four consecutive jobs of a list form a work-group
     uint32_t list_capacity;
     ChainCounters* counters;
-    ExpmEval* evals;             // [n_blocks * P]
-    EigenJob* eig_jobs;          // [n_blocks * P] (OMEGA)
-    FactoredJob* tile_jobs;      // [P * tiles of all blocks]
-    TileGroup* groups;           // [4][group_capacity]
+    ExpmEval* evals;             // [2][eval_capacity]
+    uint32_t eval_capacity;
+    EigenJob* eig_jobs;          // [eval_capacity] (OMEGA)
+    FactoredJob* tile_jobs;      // [2][job_capacity]
+    uint32_t job_capacity;
+    TileGroup* groups;           // [2][4][group_capacity]
     uint32_t group_capacity;
 };
 // algo 0: MLE machines, else OMEGA machines; one wave per block

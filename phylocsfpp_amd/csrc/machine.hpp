@@ -23,17 +23,16 @@ namespace pcsf {
 constexpr int MAX_POINTS_PER_SEARCH = 12;     // per search and round: certain points first, then speculative restarts
 constexpr int MAX_SPECULATIVE_RESTARTS = 8;
 constexpr int MIN_POINTS_PER_SEARCH = 5;      // a Brent set-up asks for chosen, lo, hi, chosen, v: all certain, all in one round
-// How far ahead a search looks.  Short lists are bound by the latency of a round: up to eight random restarts are evaluated before it is known
-// that the search needs them (and while it is restarting).  Long lists are bound by work and memory (every evaluation slot owns a row of edge
-// scales, 29-51 KB): the certain points and two restarts ahead.
+// How far ahead a search looks.  Short lists are bound by the latency of a round: random restarts are also evaluated before it is known that
+// the search needs any (lo, hi and the start not yet evaluated).  Long lists are bound by work: a third of OMEGA's evaluations on a
+// 5,088-block list were such restarts that no optimiser ever asked for.  A search that IS restarting always has its next eight points
+// evaluated with the one it waits for (a block that exhausts its 250 restarts would otherwise set the number of rounds of the whole list:
+// 58 -> 170 rounds for MLE, 233 -> 569 for OMEGA on BASELINE.json configs[2] with two ahead).
 struct LookaheadPolicy {
     int max_points, max_restarts;
     bool eager;
 };
-PCSF_HD inline LookaheadPolicy lookahead_policy(bool eager)
-{
-    return eager ? LookaheadPolicy{MAX_POINTS_PER_SEARCH, MAX_SPECULATIVE_RESTARTS, true} : LookaheadPolicy{MIN_POINTS_PER_SEARCH, 2, false};
-}
+PCSF_HD inline LookaheadPolicy lookahead_policy(bool eager) { return LookaheadPolicy{MAX_POINTS_PER_SEARCH, MAX_SPECULATIVE_RESTARTS, eager}; }
 constexpr int MLE_MAX_REQUESTS = 2 * MAX_POINTS_PER_SEARCH;   // the coding and the non-coding search advance in the same rounds
 constexpr int OMEGA_MAX_REQUESTS = MAX_POINTS_PER_SEARCH;     // a block either validates its model or searches
 constexpr uint32_t STORE_ENTRIES = 544;       // points one search can evaluate: lo, hi, start, <= 250 restarts (+ 8 ahead), v, <= 250 Brent probes
@@ -120,14 +119,16 @@ struct MleMachine {
         opt[0].start(1.0, 1e-2, 10.0);
     }
 
-    // res[i]: the value of pending request i (n_pending of them; none in the first round).  store: [2][STORE_ENTRIES].
+    // res[i]: the value of pending request i (n_pending of them; none in the first round).  store: two stores of up to STORE_ENTRIES values,
+    // store_stride entries apart.
     // max_points (5..MAX_POINTS_PER_SEARCH) / max_restarts: how far a search looks ahead per round -- the five certain points of a Brent set-up
     // always fit; no result depends on either.  Returns the number of requests written to out[2 * max_points]; 0 = the block is finished (or failed).
-    PCSF_HD int round(const EvalResult* res, StoreEntry* store, const DrawTable& draws_table, bool eager, int max_points, int max_restarts, bool compute_anc, EvalRequest* out)
+    PCSF_HD int round(const EvalResult* res, StoreEntry* store, uint32_t store_stride, const DrawTable& draws_table, bool eager, int max_points, int max_restarts, bool compute_anc,
+                      EvalRequest* out)
     {
         for (uint32_t i = 0; i < n_pending; ++i) {
             const uint32_t m = pend_kind[i];
-            store_push(store + m * STORE_ENTRIES, n_store[m], pend_x[i], res[i].lnz, compute_anc ? res[i].anc : 0.0, res[i].failed != 0);
+            store_push(store + m * store_stride, n_store[m], pend_x[i], res[i].lnz, compute_anc ? res[i].anc : 0.0, res[i].failed != 0);
         }
         n_pending = 0;
         // feed every search from its store; blocks without a codon have lpr = 0 at every scale
@@ -143,7 +144,7 @@ struct MleMachine {
                     o.supply(0.0, 0.0, draws_table, draws);
                     continue;
                 }
-                StoreEntry* e = store_find(store + model * STORE_ENTRIES, n_store[model], o.request());
+                StoreEntry* e = store_find(store + model * store_stride, n_store[model], o.request());
                 if (!e) break;
                 if (e->failed) {  // std::runtime_error in PhyloModel_make -> NaN row
                     failed = 1;
@@ -156,7 +157,7 @@ struct MleMachine {
         active = (!failed && (!opt[0].done() || !started1 || !opt[1].done())) ? 1u : 0u;
         if (!active) {
             for (int m = 0; m < 2; ++m)
-                for (uint32_t i = 0; i < n_store[m]; ++i) (store[m * STORE_ENTRIES + i].used ? used : unused) += 1;
+                for (uint32_t i = 0; i < n_store[m]; ++i) (store[m * store_stride + i].used ? used : unused) += 1;
             return 0;
         }
         // the points the searches will or may need next: rank 0 (certain) of both first
@@ -169,7 +170,7 @@ struct MleMachine {
             for (int model = 0; model < 2; ++model) {
                 if (rank >= ahead[model].n) continue;
                 const double x = ahead[model].x[rank];
-                if (store_find(store + model * STORE_ENTRIES, n_store[model], x) || ahead[model].seen_before(rank)) continue;
+                if (store_find(store + model * store_stride, n_store[model], x) || ahead[model].seen_before(rank)) continue;
                 EvalRequest& r = out[n];
                 r.x = r.tree_scale = x;
                 r.eig = static_cast<uint32_t>(model);

@@ -6,5 +6,5 @@ int main(int argc, char** argv)
 {
     return pcsf_host::cli_main(argc, argv, [](const pcsf_host::Model& m, int device) {
         return std::unique_ptr<pcsf_host::ScoringBackend>(new pcsf_host::HipBackend(m, device));
-    });
+    }, /*fast_exit=*/true);
 }

@@ -76,9 +76,24 @@ def test_omega_on_the_dense_blocks_of_config3(prefix_maf, tmp_path):
     rel = d / np.maximum(1e-6, np.abs(w[ok]))
     print("OMEGA: %d finite rows, within 1e-6 relative %d, median |d| %.3g, 90 %% %.3g, max %.3g, rows beyond 0.316: %d" % (
         len(d), int((rel <= 1e-6).sum()), np.median(d), np.percentile(d, 90), d.max(), int((d > 0.316).sum())))
-    # the same statistics as on the reference's golden blocks (tests/test_gpu_parity_blocks.py; DESIGN.md section 5: the twelve chained
-    # Brent runs amplify a 1e-13 difference of the objective, the objective itself agrees to <= 1e-9)
-    assert (rel <= 1e-6).mean() >= 0.07
-    assert np.median(d) <= 2e-2
-    assert (d <= 0.316).mean() >= 0.97                              # the reference's OMEGA tolerance (test/tests.sh:46) for all but the
-    #                                                                 few rows whose chained searches end in another local optimum
+    # What the procedure itself does to a few-ulp difference of the objective: the CONTROL (tests/golden/make_omega_control.py,
+    # profiles/r04/omega_control.txt) is the oracle against itself with the terms of some sums added in another order, on these very
+    # blocks.  The device may differ from the oracle the way the oracle differs from itself, not more: the same share of rows within
+    # 1e-6, the same median and tail, and a row beyond the reference's own tolerance (test/tests.sh:46) only where the control also
+    # moves by a tenth of a deciban or more (twelve chained Brent searches that end in another local optimum of a flat objective).
+    ctl = np.load(os.path.join(ROOT, "tests", "golden", "oracle", "omega_control.npz"))
+    base = ctl["config3_omega_base"]
+    assert np.array_equal(base, w, equal_nan=True)                 # the control was made on these blocks by this oracle
+    perts = [ctl["config3_omega_p%d" % b] for b in (1, 2, 4, 7)]
+    c_frac = [(np.abs(p_ - base)[ok] / np.maximum(1e-6, np.abs(base[ok])) <= 1e-6).mean() for p_ in perts]
+    c_med = [np.median(np.abs(p_ - base)[ok]) for p_ in perts]
+    c_p90 = [np.percentile(np.abs(p_ - base)[ok], 90) for p_ in perts]
+    spread = np.max([np.abs(p_ - base) for p_ in perts], axis=0)[ok]
+    print("control (oracle vs perturbed oracle): within 1e-6 %.0f-%.0f %%, median %.3g-%.3g, 90 %% %.3g-%.3g, rows beyond 0.316: %d" % (
+        100 * min(c_frac), 100 * max(c_frac), min(c_med), max(c_med), min(c_p90), max(c_p90), int((spread > 0.316).sum())))
+    assert (rel <= 1e-6).mean() >= 0.6 * min(c_frac)
+    assert np.median(d) <= 3.0 * max(c_med)
+    assert np.percentile(d, 90) <= 2.0 * max(c_p90)
+    assert (d <= 0.316).mean() >= 0.97
+    beyond = np.flatnonzero(d > 0.316)
+    assert all(spread[i] >= 0.1 for i in beyond), (beyond, d[beyond], spread[beyond])

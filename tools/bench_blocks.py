@@ -5,6 +5,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # OMEGA drives four streams per device at once; before the HIP runtime starts
 import phylocsfpp_amd as pa
 import oracle_binding as ob
 import maf_blocks
