@@ -108,7 +108,10 @@ struct BlockEngine {
     int ne, nl, n;
     DeviceBuffer d_codons;                 // [nl][leaf_stride] compact copy
     DeviceBuffer d_frag, d_leaf;   // table sets, one per evaluation of a run
-    DeviceBuffer d_eig_r, d_eig_l, d_eig_lam, d_eig_basis, d_prior, d_ancw, d_eig_w;  // eigen-systems, their root priors, L = R^T diag(w)
+    DeviceBuffer d_eig_r, d_eig_l, d_eig_lam, d_eig_basis, d_prior, d_ancw, d_eig_w, d_eig_c;  // eigen-systems, their root priors, L = R^T diag(w), c = L 1
+    DeviceBuffer d_eval_x;    // host engine + prune_tiles: the tree scale of every evaluation of a run (the kernel makes its own edge scales)
+    std::vector<double> eval_x;
+    float longest_branch = 0.0f;
     DeviceBuffer d_jobs, d_wg0, d_wg1, d_wgt, d_wgp, d_wgo;
     DeviceBuffer d_branch_slot, d_branch_len, d_leaf_codes;  // per-branch constants; per (block, leaf) row masks
     // factored path (factored.hip): evaluations of blocks of at most fact_max_tiles 16-site tiles never form their
@@ -230,6 +233,7 @@ struct BlockEngine {
         nl = c->n_leaves;
         n = c->n_nodes;
         n_sites_total = offsets[nb];
+        for (float len : c->branch_len) longest_branch = std::max(longest_branch, len);
         if (n_sites_total > 0) {
             HIP_TRY(d_codons.reserve(static_cast<size_t>(nl) * n_sites_total));
             HIP_TRY(upload_rows(d_codons.ptr, codons, stride, n_sites_total, nl, stream));
@@ -357,6 +361,7 @@ struct BlockEngine {
         HIP_TRY(d_prior.reserve_keep(count * 64 * sizeof(double), cap_eig * 64 * sizeof(double), stream));
         HIP_TRY(d_ancw.reserve_keep(count * 64 * sizeof(double), cap_eig * 64 * sizeof(double), stream));
         HIP_TRY(d_eig_w.reserve_keep(count * 64 * sizeof(double), cap_eig * 64 * sizeof(double), stream));
+        HIP_TRY(d_eig_c.reserve_keep(count * 64 * sizeof(double), cap_eig * 64 * sizeof(double), stream));
         cap_eig = count;
     }
     // a host-side eigen-system (the ECM models of the context) and its root prior into slot idx.  pi: the frequencies the rate matrix
@@ -377,6 +382,16 @@ struct BlockEngine {
             to_lane_order(sw.data(), swl.data());
             HIP_TRY(hipMemcpyAsync(d_eig_w.as<double>() + idx * 64, swl.data(), 64 * sizeof(double), hipMemcpyHostToDevice, stream));
             HIP_TRY(hipStreamSynchronize(stream));  // swl is a stack temporary
+        }
+        {
+            Vec cs;   // c_k = sum_i left[k][i]: the row sums of the left eigenvectors (tiles.hip's row-sum check)
+            for (int k = 0; k < 64; ++k) {
+                double acc = 0.0;
+                for (int i = 0; i < 64; ++i) acc += es.left[static_cast<size_t>(k) * 64 + i];
+                cs[k] = acc;
+            }
+            HIP_TRY(hipMemcpyAsync(d_eig_c.as<double>() + idx * 64, cs.data(), 64 * sizeof(double), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipStreamSynchronize(stream));  // cs is a stack temporary
         }
         for (int x = 0; x < 64; ++x) w[x] = std::log(es.prior[x]) * es.prior[x];
         to_lane_order(es.prior.data(), pl.data());
@@ -483,6 +498,7 @@ struct BlockEngine {
                         j.n_sites = static_cast<uint32_t>(std::min<uint64_t>(16, s1 - s));
                         j.eig = ev.eig;
                         j.eval = ev.table;
+                        j.pad = s == s0 ? FACTORED_JOB_VALIDATES : 0u;
                         tjobs[set].push_back(j);
                     }
                 }
@@ -568,6 +584,13 @@ struct BlockEngine {
                 HIP_TRY(hipMemcpyAsync(d_wgp.as<uint32_t>() + at, wgp[set].data(), cnt * 4, hipMemcpyHostToDevice, stream));
             }
         }
+        if (use_tiles) {
+            eval_x.assign(tables, 0.0);
+            for (int set = 0; set < 2; ++set)
+                for (const ExpmEval& ev : fevals[set]) eval_x[ev.table] = ev.x;
+            HIP_TRY(d_eval_x.reserve(tables * sizeof(double)));
+            HIP_TRY(hipMemcpyAsync(d_eval_x.ptr, eval_x.data(), tables * sizeof(double), hipMemcpyHostToDevice, stream));
+        }
         const bool use_side = !eig_jobs.empty() || nj1 || nw1 || nfe1;
         if (use_side) {
             HIP_TRY(hipEventRecord(ev_start, stream));
@@ -614,7 +637,7 @@ struct BlockEngine {
                 HIP_TRY(launch_prune_fixed(p, 16 | (c->schedule.stack_depth > MAX_STACK_DEPTH ? 64 : 0), st, 0));
             }
             const size_t nfe = set ? nfe1 : nfe0, fe_at = set ? nfe0 : 0, nf = set ? nf1 : nf0, f_at = set ? nf0 : 0;
-            if (nfe)
+            if (nfe && !use_tiles)   // prune_tiles makes its own edge scales and runs the row-sum check itself
                 HIP_TRY(launch_edge_scale(p_fevals + fe_at, static_cast<uint32_t>(nfe), static_cast<uint32_t>(n - 1), d_branch_len.as<float>(),
                                           d_eig_r.as<double>(), d_eig_l.as<double>(), d_eig_lam.as<double>(), d_scale.as<double>(), p_fail, st));
             const size_t ntj = set ? nt1 : nt0, t_at = set ? nt0 : 0;
@@ -642,6 +665,14 @@ struct BlockEngine {
                 fp.stamps = d_fact_stamps.ptr ? d_fact_stamps.as<unsigned long long>() : nullptr;
                 fp.stamp_classes = fact_stamp_classes ? 1u : 0u;
                 fp.product_count = d_products.as<unsigned long long>();
+                if (use_tiles) {
+                    fp.eval_x = d_eval_x.as<double>();
+                    fp.eig_lambda = d_eig_lam.as<double>();
+                    fp.eig_c = d_eig_c.as<double>();
+                    fp.branch_len = d_branch_len.as<float>();
+                    fp.longest_branch = longest_branch;
+                    fp.fail = p_fail;
+                }
                 if (ntj) {
                     fp.jobs = p_tjobs + t_at;
                     fp.n_jobs = static_cast<uint32_t>(ntj);
@@ -673,6 +704,7 @@ struct BlockEngine {
                 gp.prior = d_prior.as<double>();
                 gp.anc_weight = d_ancw.as<double>();
                 gp.eig_w = d_eig_w.as<double>();
+                gp.eig_c = d_eig_c.as<double>();
                 gp.fail = p_fail;
                 HIP_TRY(launch_eigen_omega(gp, side));
             }
@@ -878,7 +910,7 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
     hipStream_t stc = use_ctl ? ctl.s : st0;
     size_t total_tiles = 0;
     for (size_t b = 0; b < nb; ++b) total_tiles += (eng.off[b + 1] - eng.off[b] + 15) / 16;
-    DeviceBuffer d_machines, d_stores, d_off, d_draws, d_counters, d_evals, d_eig_jobs, d_jobs, d_groups, d_lnz, d_anc, d_fail;
+    DeviceBuffer d_machines, d_stores, d_off, d_draws, d_counters, d_evals, d_eig_jobs, d_jobs, d_groups, d_lnz, d_anc, d_fail, d_eval_x;
     BlockEngine::PinnedBuffer h_counters;
     const size_t eval_cap = nb * P, job_cap = std::max<size_t>(1, total_tiles) * P, group_cap = job_cap;
     HIP_TRY(d_machines.reserve(nb * sizeof(Machine)));
@@ -894,7 +926,8 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
     HIP_TRY(d_lnz.reserve(std::max<size_t>(1, n_sites) * P * sizeof(double)));
     if (want_anc) HIP_TRY(d_anc.reserve(std::max<size_t>(1, n_sites) * P * sizeof(double)));
     HIP_TRY(d_fail.reserve(nb * P * sizeof(uint32_t)));
-    eng.reserve_tables(nb * P);   // edge-scale rows, one per evaluation slot
+    if (eng.use_tiles) HIP_TRY(d_eval_x.reserve(nb * P * sizeof(double)));   // prune_tiles makes its own edge scales from the evaluation's tree scale
+    else eng.reserve_tables(nb * P);                                          // prune_factored: edge-scale rows, one per evaluation slot
     const std::vector<double> t_mle = make_draw_table(seed, 1e-2, 10.0), t_rho = make_draw_table(seed, 0.001, 10.0), t_kappa = make_draw_table(seed, 1.0, 10.0);
     HIP_TRY(hipMemcpyAsync(d_draws.as<double>(), t_mle.data(), DRAW_TABLE_ENTRIES * sizeof(double), hipMemcpyHostToDevice, st0));
     HIP_TRY(hipMemcpyAsync(d_draws.as<double>() + DRAW_TABLE_ENTRIES, t_rho.data(), DRAW_TABLE_ENTRIES * sizeof(double), hipMemcpyHostToDevice, st0));
@@ -912,6 +945,7 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
     cp.out_lnz = d_lnz.as<double>();
     cp.out_anc = want_anc ? d_anc.as<double>() : nullptr;
     cp.fail = d_fail.as<uint32_t>();
+    cp.eval_x = eng.use_tiles ? d_eval_x.as<double>() : nullptr;
     for (int k = 0; k < 3; ++k) cp.draws[k] = d_draws.as<double>() + k * DRAW_TABLE_ENTRIES;
     cp.n_draws = DRAW_TABLE_ENTRIES;
     cp.eager = eager ? 1u : 0u;
@@ -965,6 +999,14 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
     fp.stamps = eng.d_fact_stamps.ptr ? eng.d_fact_stamps.template as<unsigned long long>() : nullptr;
     fp.stamp_classes = eng.fact_stamp_classes ? 1u : 0u;
     fp.product_count = eng.d_products.template as<unsigned long long>();
+    if (eng.use_tiles) {
+        fp.eval_x = d_eval_x.as<double>();
+        fp.eig_lambda = eng.d_eig_lam.template as<double>();
+        fp.eig_c = eng.d_eig_c.template as<double>();
+        fp.branch_len = eng.d_branch_len.template as<float>();
+        fp.longest_branch = eng.longest_branch;
+        fp.fail = d_fail.as<uint32_t>();
+    }
     EigenParams gp{};
     gp.jobs = cp.eig_jobs;
     gp.eig_right = eng.d_eig_r.template as<double>();
@@ -974,12 +1016,14 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
     gp.prior = eng.d_prior.template as<double>();
     gp.anc_weight = eng.d_ancw.template as<double>();
     gp.eig_w = eng.d_eig_w.template as<double>();
+    gp.eig_c = eng.d_eig_c.template as<double>();
     gp.fail = d_fail.as<uint32_t>();
     st.t_setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count();
     ticket.pass();   // every group of the call has allocated
 
     // the round's evaluations of one set: edge scales (on `scale_stream`), then pruning (on `stream`)
     auto launch_scales = [&](int set, const ChainCounters& cnt, hipStream_t stream) {
+        if (eng.use_tiles) return;   // prune_tiles makes its own edge scales and runs the row-sum check itself
         HIP_TRY(launch_edge_scale(cp.evals + static_cast<size_t>(set) * eval_cap, cnt.n_evals[set], static_cast<uint32_t>(eng.n - 1), eng.d_branch_len.template as<float>(),
                                   eng.d_eig_r.template as<double>(), eng.d_eig_l.template as<double>(), eng.d_eig_lam.template as<double>(), eng.d_scale.template as<double>(),
                                   d_fail.as<uint32_t>(), stream));

@@ -60,7 +60,6 @@ template <> struct MachineTraits<OmegaMachine> {
 // What the wave works on sits in LDS while it works: the machine (~1 KB), the stores' values (a search has seen 10-40 when it ends) and the
 // per-site values to be added up.  Lane 0's walk through the state machine is a chain of dependent reads -- from HBM it was ~0.4 ms per
 // round whatever the number of blocks (profiles/r04), every round of every group waiting for it.
-constexpr uint32_t LDS_STORE_ENTRIES = 96;   // per store; a search with more values than that (it is exhausting its restarts) works on the store in HBM
 constexpr uint32_t SUM_CHUNK = 64;
 
 template <class M>
@@ -72,7 +71,7 @@ __global__ __launch_bounds__(64) void advance_blocks(const ChainParams p)
     __shared__ EvalResult res[MAX_REQ];
     __shared__ EvalRequest req[MAX_REQ];
     __shared__ __attribute__((aligned(16))) uint32_t m_words[M_WORDS];
-    __shared__ StoreEntry st_lds[STORES * LDS_STORE_ENTRIES];
+    __shared__ StoreEntry st_lds[STORES * STORE_ENTRIES];
     __shared__ double sum_buf[MAX_REQ * SUM_CHUNK];
     __shared__ int n_req_s;
     __shared__ uint32_t base_s[4];
@@ -85,19 +84,14 @@ __global__ __launch_bounds__(64) void advance_blocks(const ChainParams p)
     const uint32_t P = p.slots_per_block;
     // the stores' values: into LDS when they (and this round's new ones) fit
     StoreEntry* store_global = p.stores + static_cast<size_t>(b) * STORES * STORE_ENTRIES;
-    uint32_t n_store_in[STORES];
-    bool in_lds = true;
     for (int k = 0; k < STORES; ++k) {
-        if constexpr (STORES == 2) n_store_in[k] = m->n_store[k];
-        else n_store_in[k] = m->n_store;
-        in_lds = in_lds && n_store_in[k] + MAX_REQ <= LDS_STORE_ENTRIES;
+        uint32_t n_in;
+        if constexpr (STORES == 2) n_in = m->n_store[k];
+        else n_in = m->n_store;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(store_global + static_cast<size_t>(k) * STORE_ENTRIES);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(st_lds + k * STORE_ENTRIES);
+        for (uint32_t w = lane; w < n_in * (sizeof(StoreEntry) / 4); w += 64) dst[w] = src[w];
     }
-    if (in_lds)
-        for (int k = 0; k < STORES; ++k) {
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(store_global + static_cast<size_t>(k) * STORE_ENTRIES);
-            uint32_t* dst = reinterpret_cast<uint32_t*>(st_lds + k * LDS_STORE_ENTRIES);
-            for (uint32_t w = lane; w < n_store_in[k] * (sizeof(StoreEntry) / 4); w += 64) dst[w] = src[w];
-        }
     // (1) the values of the pending evaluations: per-site terms through LDS in chunks (coalesced), lane e adds evaluation e's in site order
     const uint32_t n_pending = m->n_pending;
     {
@@ -126,16 +120,13 @@ __global__ __launch_bounds__(64) void advance_blocks(const ChainParams p)
     // (2) the block's machine
     if (lane == 0) {
         int n;
-        // (two calls, not one call on a pointer chosen between LDS and HBM: the select of generic pointers trips the gfx950 back end --
-        // "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base", ROCm 7.2)
+        // (the stores always sit in LDS -- machine.hpp store_compact bounds them: a call on a pointer chosen between LDS and HBM, or two calls
+        // the compiler merges into one, trip the gfx950 back end of ROCm 7.2, "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base")
         if constexpr (STORES == 2) {
-            if (in_lds) n = m->round(res, st_lds, LDS_STORE_ENTRIES, DrawTable{p.draws[0], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points), static_cast<int>(p.max_restarts), p.out_anc != nullptr, req);
-            else n = m->round(res, store_global, STORE_ENTRIES, DrawTable{p.draws[0], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points), static_cast<int>(p.max_restarts), p.out_anc != nullptr, req);
+            n = m->round(res, st_lds, STORE_ENTRIES, DrawTable{p.draws[0], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points), static_cast<int>(p.max_restarts), p.out_anc != nullptr, req);
         } else {
-            if (in_lds) n = m->round(res, st_lds, DrawTable{p.draws[1], p.n_draws}, DrawTable{p.draws[2], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points),
-                                     static_cast<int>(p.max_restarts), p.held_systems != 0, p.transient0 + b * P, DevicePrior(), req);
-            else n = m->round(res, store_global, DrawTable{p.draws[1], p.n_draws}, DrawTable{p.draws[2], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points),
-                              static_cast<int>(p.max_restarts), p.held_systems != 0, p.transient0 + b * P, DevicePrior(), req);
+            n = m->round(res, st_lds, DrawTable{p.draws[1], p.n_draws}, DrawTable{p.draws[2], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points),
+                         static_cast<int>(p.max_restarts), p.held_systems != 0, p.transient0 + b * P, DevicePrior(), req);
         }
         n_req_s = n;
         if (m->active) atomicAdd(&p.counters->n_active, 1u);
@@ -143,15 +134,14 @@ __global__ __launch_bounds__(64) void advance_blocks(const ChainParams p)
     __syncthreads();
     // the machine and what the stores hold now, back to HBM
     for (uint32_t w = lane; w < M_WORDS; w += 64) m_global[w] = m_words[w];
-    if (in_lds)
-        for (int k = 0; k < STORES; ++k) {
-            uint32_t n_now;
-            if constexpr (STORES == 2) n_now = m->n_store[k];
-            else n_now = m->n_store;
-            uint32_t* dst = reinterpret_cast<uint32_t*>(store_global + static_cast<size_t>(k) * STORE_ENTRIES);
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(st_lds + k * LDS_STORE_ENTRIES);
-            for (uint32_t w = lane; w < n_now * (sizeof(StoreEntry) / 4); w += 64) dst[w] = src[w];
-        }
+    for (int k = 0; k < STORES; ++k) {
+        uint32_t n_now;
+        if constexpr (STORES == 2) n_now = m->n_store[k];
+        else n_now = m->n_store;
+        uint32_t* dst = reinterpret_cast<uint32_t*>(store_global + static_cast<size_t>(k) * STORE_ENTRIES);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(st_lds + k * STORE_ENTRIES);
+        for (uint32_t w = lane; w < n_now * (sizeof(StoreEntry) / 4); w += 64) dst[w] = src[w];
+    }
     // (3) this round's job records.  Set 1: evaluations that wait for an eigen-system solved in this round; set 0: the others.
     const int n_req = n_req_s;
     const uint32_t n_tiles = static_cast<uint32_t>((sites + 15) / 16);
@@ -165,6 +155,7 @@ __global__ __launch_bounds__(64) void advance_blocks(const ChainParams p)
         ev.block = b;
         ev.pad = p.use_tiles;
         ev.x = r.tree_scale;
+        if (p.eval_x) p.eval_x[table] = r.tree_scale;
         p.evals[static_cast<size_t>(set) * p.eval_capacity + atomicAdd(&p.counters->n_evals[set], 1u)] = ev;
         if (r.new_eigen == 1u) {
             EigenJob j;
@@ -198,7 +189,7 @@ __global__ __launch_bounds__(64) void advance_blocks(const ChainParams p)
             j.n_sites = static_cast<uint32_t>(sites - 16ull * tile < 16 ? sites - 16ull * tile : 16);
             j.eig = eig;
             j.eval = b * P + i;
-            j.pad = 0;
+            j.pad = tile == 0 ? FACTORED_JOB_VALIDATES : 0u;   // (read by prune_tiles when it makes its own edge scales)
             jobs[job0 + t] = j;
         }
         if (p.use_tiles && !p.pack_models) {

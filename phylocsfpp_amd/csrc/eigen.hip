@@ -841,6 +841,11 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
         if (p.anc_weight) p.anc_weight[static_cast<size_t>(job.eig) * 64 + lane_pos] = log(pr) * pr;
         if (p.prior_plain) p.prior_plain[static_cast<size_t>(job.eig) * 64 + tid] = pr;
         if (p.eig_w) p.eig_w[static_cast<size_t>(job.eig) * 64 + lane_pos] = root[tid] / iroot[tid];
+        if (p.eig_c) {   // c_k = sum_i left[k][i], k = tid
+            double c = 0.0;
+            for (int i = 0; i < 64; ++i) c += V[i * LD + tid] * root[i];
+            p.eig_c[static_cast<size_t>(job.eig) * 64 + tid] = c;
+        }
     }
 }
 

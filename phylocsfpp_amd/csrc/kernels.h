@@ -108,6 +108,7 @@ hipError_t launch_expm(const ExpmParams& p, hipStream_t stream);
 // ---- factored block-mode pruning (factored.hip): no explicit branch matrices --------------------------------------
 // One job = one tile: up to 16 consecutive sites of one evaluation.  e_b[k] = exp(lambda_k t_b) comes from
 // launch_edge_scale (row `eval` of edge_scale, states in row-split order), R / L / priors from the eigen-system `eig`.
+constexpr uint32_t FACTORED_JOB_VALIDATES = 1u;   // FactoredJob::pad: this tile job also runs the evaluation's row-sum check (one job per evaluation)
 struct FactoredJob {
     uint64_t site0;     // first site of the tile in the codon matrix
     uint64_t out0;      // index of the tile's first site in out_lnz / out_anc
@@ -141,7 +142,15 @@ struct FactoredParams {
     const double* eig_w;        // [n_eig][4][16] lane order: w = root / iroot of the symmetrisation, L = R^T diag(w) (tiles.hip only)
     const double* prior;        // [n_eig][4][16] lane order
     const double* anc_weight;   // [n_eig][4][16] lane order (read only if out_anc)
-    const double* edge_scale;   // [n_eval][n_branches][64] row-split order
+    const double* edge_scale;   // [n_eval][n_branches][64] row-split order (prune_factored; prune_tiles only when eval_x is null)
+    // prune_tiles computes its edge scales itself (tiles.hip: one exponential per lane and edge, handed round through LDS) and validates the
+    // evaluation (the row sums of P(t), edge_scale_kernel's check) in the tile job that carries FACTORED_JOB_VALIDATES:
+    const double* eval_x;       // [n_eval] tree scale of the evaluation (null: the scales come from edge_scale, the check from edge_scale_kernel)
+    const double* eig_lambda;   // [n_eig][64]
+    const double* eig_c;        // [n_eig][64] c = L 1 (row sums of the left eigenvectors)
+    const float* branch_len;    // [n_branches]
+    float longest_branch;
+    uint32_t* fail;             // [n_eval]
     double* out_lnz;
     double* out_anc;            // or null
     uint32_t deep;              // the tree parks more tiles than the register stack holds (schedule.stack_depth > MAX_STACK_DEPTH)
@@ -186,6 +195,7 @@ struct ChainParams {
     const double* out_lnz;       // [P * n_sites] written by the pruning kernel of the previous round
     const double* out_anc;       // or null
     uint32_t* fail;              // [n_blocks * P]
+    double* eval_x;              // [n_blocks * P] tree scale of every evaluation slot (prune_tiles computes its edge scales from it), or null
     const double* draws[3];      // restart points of the MLE, rho and kappa search ranges (optimizer.hpp DrawTable)
     uint32_t n_draws;
     uint32_t eager, max_points, max_restarts, held_systems;   // machine.hpp LookaheadPolicy
@@ -251,6 +261,7 @@ struct EigenParams {
     double* anc_weight;   // [n_eig][64] ln(prior)*prior in lane order (may be null)
     double* prior_plain;  // optional [n_eig][64] prior in state order (diagnostics/tests)
     double* eig_w;        // optional [n_eig][64] lane order: root / iroot of the symmetrisation (left = right^T diag(w); tiles.hip)
+    double* eig_c;        // optional [n_eig][64] state order: c = left 1, the row sums of the left eigenvectors (tiles.hip's row-sum check)
     uint32_t* fail;       // [table]: set to 1 when pi has a non-positive entry
     unsigned long long* stamps;  // diagnostics (may be null): job 0 adds its cycle counts -- [0] phase A (B <- J^T B J), [1] wave 0's
                                  // rotations, [2] wave 1's V update, [3] phase B incl. its barrier, [4] steps, [5] sweeps, [6] whole kernel

@@ -35,7 +35,8 @@ struct LookaheadPolicy {
 PCSF_HD inline LookaheadPolicy lookahead_policy(bool eager) { return LookaheadPolicy{MAX_POINTS_PER_SEARCH, MAX_SPECULATIVE_RESTARTS, eager}; }
 constexpr int MLE_MAX_REQUESTS = 2 * MAX_POINTS_PER_SEARCH;   // the coding and the non-coding search advance in the same rounds
 constexpr int OMEGA_MAX_REQUESTS = MAX_POINTS_PER_SEARCH;     // a block either validates its model or searches
-constexpr uint32_t STORE_ENTRIES = 544;       // points one search can evaluate: lo, hi, start, <= 250 restarts (+ 8 ahead), v, <= 250 Brent probes
+constexpr uint32_t STORE_ENTRIES = 96;        // values a search keeps (store_compact): it can evaluate ~520 points -- lo, hi, start, <= 250 restarts, v, <= 250 Brent probes
+constexpr uint32_t STORE_COMPACT_AT = 48;
 
 enum EvalKind : uint32_t { EVAL_MLE_CODING = 0, EVAL_MLE_NONCODING = 1, EVAL_RHO = 2, EVAL_KAPPA = 3, EVAL_VALIDATION = 4 };
 
@@ -61,11 +62,13 @@ struct EvalResult {
     uint32_t failed;     // PhyloModel_make would have thrown (src/instance.hpp:618,635)
 };
 
-PCSF_HD inline StoreEntry* store_find(StoreEntry* e, uint32_t n, double x)
+// index of the value at x, or -1 (an index, not a pointer: on the device the store may sit in LDS, and null tests of generic pointers
+// into LDS trip the gfx950 back end of ROCm 7.2 -- "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base")
+PCSF_HD inline int store_find(const StoreEntry* e, uint32_t n, double x)
 {
     for (uint32_t i = 0; i < n; ++i)
-        if (e[i].x == x) return e + i;
-    return nullptr;
+        if (e[i].x == x) return static_cast<int>(i);
+    return -1;
 }
 PCSF_HD inline void store_push(StoreEntry* e, uint32_t& n, double x, double lpr, double anc, bool failed)
 {
@@ -76,6 +79,28 @@ PCSF_HD inline void store_push(StoreEntry* e, uint32_t& n, double x, double lpr,
     e[n].failed = failed ? 1u : 0u;
     e[n].used = 0u;
     ++n;
+}
+
+// A search that exhausts its random restarts (or a Brent iteration that runs long) would fill hundreds of entries.  Of the values it has
+// CONSUMED it can only ask again for lo, hi and the start (entries 0..2: Brent's set-up re-evaluates the ends and the chosen start) and
+// for the restart point it consumed LAST (the only one that can become the chosen start, src/fixed_lik.hpp:494-512): the others go.
+// Values evaluated ahead and not yet consumed stay.  Bounds a store by ~40 entries, so that the device keeps it in LDS.
+PCSF_HD inline void store_compact(StoreEntry* e, uint32_t& n, uint32_t& tally_used)
+{
+    if (n <= STORE_COMPACT_AT) return;
+    int last_used = -1;
+    for (uint32_t i = 0; i < n; ++i)
+        if (e[i].used) last_used = static_cast<int>(i);
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (i < 3 || !e[i].used || static_cast<int>(i) == last_used) {
+            if (k != i) e[k] = e[i];
+            ++k;
+        } else {
+            ++tally_used;
+        }
+    }
+    n = k;
 }
 
 struct Lookahead {  // MaxLik1D::upcoming() of one search for the current round
@@ -126,6 +151,7 @@ struct MleMachine {
     PCSF_HD int round(const EvalResult* res, StoreEntry* store, uint32_t store_stride, const DrawTable& draws_table, bool eager, int max_points, int max_restarts, bool compute_anc,
                       EvalRequest* out)
     {
+        for (int m = 0; m < 2; ++m) store_compact(store + m * store_stride, n_store[m], used);
         for (uint32_t i = 0; i < n_pending; ++i) {
             const uint32_t m = pend_kind[i];
             store_push(store + m * store_stride, n_store[m], pend_x[i], res[i].lnz, compute_anc ? res[i].anc : 0.0, res[i].failed != 0);
@@ -144,14 +170,15 @@ struct MleMachine {
                     o.supply(0.0, 0.0, draws_table, draws);
                     continue;
                 }
-                StoreEntry* e = store_find(store + model * store_stride, n_store[model], o.request());
-                if (!e) break;
-                if (e->failed) {  // std::runtime_error in PhyloModel_make -> NaN row
+                StoreEntry* st = store + model * store_stride;
+                const int at = store_find(st, n_store[model], o.request());
+                if (at < 0) break;
+                if (st[at].failed) {  // std::runtime_error in PhyloModel_make -> NaN row
                     failed = 1;
                     break;
                 }
-                e->used = 1;
-                o.supply(e->lpr, e->anc, draws_table, draws);
+                st[at].used = 1;
+                o.supply(st[at].lpr, st[at].anc, draws_table, draws);
             }
         }
         active = (!failed && (!opt[0].done() || !started1 || !opt[1].done())) ? 1u : 0u;
@@ -170,7 +197,7 @@ struct MleMachine {
             for (int model = 0; model < 2; ++model) {
                 if (rank >= ahead[model].n) continue;
                 const double x = ahead[model].x[rank];
-                if (store_find(store + model * store_stride, n_store[model], x) || ahead[model].seen_before(rank)) continue;
+                if (store_find(store + model * store_stride, n_store[model], x) >= 0 || ahead[model].seen_before(rank)) continue;
                 EvalRequest& r = out[n];
                 r.x = r.tree_scale = x;
                 r.eig = static_cast<uint32_t>(model);
@@ -278,6 +305,7 @@ struct OmegaMachine {
     PCSF_HD int round(const EvalResult* res, StoreEntry* store, const DrawTable& rho_draws, const DrawTable& kappa_draws, bool eager, int max_points, int max_restarts,
                       bool held_systems, uint32_t transient0, Prior prior, EvalRequest* out)
     {
+        store_compact(store, n_store, used);
         for (uint32_t i = 0; i < n_pending; ++i) {
             if (pend_kind[i] == EVAL_VALIDATION) {
                 needs_validation = 0;
@@ -337,14 +365,14 @@ struct OmegaMachine {
                 }
                 continue;
             }
-            StoreEntry* e = store_find(store, n_store, opt.request());
-            if (!e) break;
-            if (e->failed) {
+            const int at = store_find(store, n_store, opt.request());
+            if (at < 0) break;
+            if (store[at].failed) {
                 failed = 1;
                 break;
             }
-            e->used = 1;
-            opt.supply(e->lpr, 0.0, dt, draws);
+            store[at].used = 1;
+            opt.supply(store[at].lpr, 0.0, dt, draws);
         }
         active = (!failed && !done) ? 1u : 0u;
         if (!active) {
@@ -378,7 +406,7 @@ struct OmegaMachine {
         int n = 0;
         for (int rank = 0; rank < ahead.n; ++rank) {
             const double x = ahead.x[rank];
-            if (store_find(store, n_store, x) || ahead.seen_before(rank)) continue;
+            if (store_find(store, n_store, x) >= 0 || ahead.seen_before(rank)) continue;
             EvalRequest& r = out[n];
             r.x = x;
             r.warm = -1;

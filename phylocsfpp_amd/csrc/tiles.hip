@@ -167,7 +167,8 @@ __device__ __forceinline__ void product_Rt(const double* __restrict__ Rs, int s,
 
 constexpr int TILE_WAVES = 4;
 
-template <bool ANC>
+// OWN: the kernel makes its edge scales itself and validates the evaluation (p.eval_x); otherwise it reads edge_scale_kernel's rows
+template <bool ANC, bool OWN>
 __global__ __launch_bounds__(TILE_WAVES * 64, 2) void prune_tiles(const FactoredParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_tiles[];
@@ -178,6 +179,10 @@ __global__ __launch_bounds__(TILE_WAVES * 64, 2) void prune_tiles(const Factored
     // per wave: [n_leaves][16] codons (+ [n_leaves] "has a codon" for trees of more than 128 leaves)
     const int cod_bytes = (p.n_leaves * (p.n_leaves > 128 ? 17 : 16) + 15) & ~15;
     unsigned char* lcod_all = reinterpret_cast<unsigned char*>(lslot + ((p.n_edges + 3) & ~3u));
+    // in-kernel edge scales (p.eval_x): the branch lengths and, per wave, 64 doubles through which the lanes hand their exponentials round
+    double* lsc_all = reinterpret_cast<double*>(lcod_all + TILE_WAVES * cod_bytes);
+    float* lblen = reinterpret_cast<float*>(lsc_all + TILE_WAVES * 64);
+    constexpr bool own_scales = OWN;
 
     TileGroup grp = p.groups[blockIdx.x];
     if (grp.job0 + grp.n_jobs > p.n_jobs) grp.n_jobs = grp.job0 < p.n_jobs ? p.n_jobs - grp.job0 : 0u;   // (a list of fixed groups of four: the last one of a launch may be short)
@@ -203,6 +208,8 @@ __global__ __launch_bounds__(TILE_WAVES * 64, 2) void prune_tiles(const Factored
     if (tid < 64) wL[tid] = p.eig_w[static_cast<size_t>(eig) * 64 + tid];
     for (int i = tid; i < static_cast<int>((p.n_ops + 63) & ~63u); i += n_threads) lprog[i] = p.program[i < p.n_ops ? i : p.n_ops - 1];
     for (int i = tid; i < p.n_edges; i += n_threads) lslot[i] = p.slot_branch[i];
+    if (own_scales)
+        for (uint32_t i = tid; i < p.n_branches; i += n_threads) lblen[i] = p.branch_len[i];
     __syncthreads();   // the only barrier: from here on the waves are independent
 
     unsigned char* lcod = lcod_all + wave * cod_bytes;
@@ -247,13 +254,67 @@ __global__ __launch_bounds__(TILE_WAVES * 64, 2) void prune_tiles(const Factored
             if (a < 128) return (has1 >> (a - 64)) & 1ull;
             return lany[a] != 0;
         };
-        const double* __restrict__ scale_eval = p.edge_scale + static_cast<size_t>(job.eval) * p.n_branches * 64;
+        const double* __restrict__ scale_eval = own_scales ? nullptr : p.edge_scale + static_cast<size_t>(job.eval) * p.n_branches * 64;
         const double* __restrict__ scale = scale_eval + 4 * g;
+        // Edge scales made here (p.eval_x): e_b[k] = exp(lambda_k t_b), t_b = (double)(float)(len_b x) like the reference's float tree
+        // (src/instance.hpp:299-307,498) -- lane k computes the exponential of eigenvalue k (the same exp() on the same operand as
+        // edge_scale_kernel: the same bits) and the lanes hand them round through 512 bytes of LDS, laid out so that lane (s, g) reads its
+        // sixteen values 4q + g as four ds_read_b128 of one address per g (broadcast).  Replaces a kernel per round and set, 29-51 KB written
+        // and read per evaluation, and the ~1,150 cycles a leaf waited for its row of scales.
+        double* lsc = lsc_all + wave * 64;
+        const double lam = own_scales ? p.eig_lambda[static_cast<size_t>(job.eig) * 64 + lane] : 0.0;
+        const double x_eval = own_scales ? p.eval_x[job.eval] : 0.0;
+        if (own_scales && (job.pad & FACTORED_JOB_VALIDATES)) {
+            // The reference rejects a model whose raw row sums of P(t) are off by more than 1e-6 (src/instance.hpp:632-636): sum_j P_ij(t) =
+            // sum_k R_ik e^{lambda_k t} c_k with c = L 1 (edge_scale_kernel has the argument why one branch, the longest, is enough).
+            // Row i = lane, R from the work-group's LDS image.
+            const double t_long = static_cast<double>(static_cast<float>(static_cast<double>(p.longest_branch) * x_eval));
+            lsc[lane] = exp(lam * t_long) * p.eig_c[static_cast<size_t>(job.eig) * 64 + lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double sum = 0.0;
+            const double* __restrict__ row = Rs + lane * 64;
+            const int sw = swz(lane);
+            for (int k = 0; k < 64; ++k) sum += row[k ^ sw] * lsc[k];
+            if (!(fabs(sum - 1.0) <= 1e-6)) p.fail[job.eval] = 1u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
 
         // e_b in this lane's rows: e[q] = exp(lambda_k t_b), k = 4q + g; row-split position of k is 16(q >> 2) + 4g + (q & 3)
-        auto load_scale = [&](int branch) __attribute__((always_inline)) -> V16 {
-            const double2_t* s2 = reinterpret_cast<const double2_t*>(scale + static_cast<size_t>(branch) * 64);
+        // own scales in two halves, so that the sixteen values are not live across a product: scale_begin(branch) computes this lane's
+        // exponential and stores it, scale_read() fetches the lane's sixteen (no other scale_begin may come between the two)
+        auto scale_begin = [&](int branch) __attribute__((always_inline)) {
+            const double t = static_cast<double>(static_cast<float>(static_cast<double>(lblen[branch]) * x_eval));
+            lsc[(lane & 3) * 16 + (lane >> 2)] = exp(lam * t);   // state k = lane at [g = k & 3][q = k >> 2]
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        auto scale_read = [&]() __attribute__((always_inline)) -> V16 {
             V16 e;
+            const double4_t* s4 = reinterpret_cast<const double4_t*>(lsc + g * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double4_t v = s4[i];
+                e.v[4 * i] = v.x;
+                e.v[4 * i + 1] = v.y;
+                e.v[4 * i + 2] = v.z;
+                e.v[4 * i + 3] = v.w;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next scale_begin's store comes behind these reads
+            __builtin_amdgcn_wave_barrier();
+            return e;
+        };
+        auto load_scale = [&](int branch) __attribute__((always_inline)) -> V16 {
+            V16 e;
+            if (own_scales) {
+                scale_begin(branch);
+                return scale_read();
+            }
+            const double2_t* s2 = reinterpret_cast<const double2_t*>(scale + static_cast<size_t>(branch) * 64);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const double2_t lo = s2[8 * i], hi = s2[8 * i + 1];
@@ -328,7 +389,9 @@ __global__ __launch_bounds__(TILE_WAVES * 64, 2) void prune_tiles(const Factored
         // the edge of program slot slot_index applied to T: y <- e_b o (L x), or e_b o y when T is in eigen form already (L R = I)
         auto edge = [&](int slot_index, const Msg& T) __attribute__((always_inline)) -> Msg {
             if (uni(T.mask) == 0xffffu) return T;
-            const V16 e = load_scale(lslot[slot_index]);
+            V16 e;
+            if (own_scales) scale_begin(lslot[slot_index]);   // the exponential now, its sixteen values after the product
+            else e = load_scale(lslot[slot_index]);
             Msg out;
             if (!uni(T.eig)) {   // L x = R^T (w o x)
                 const double* __restrict__ wl = wL + g * 16;
@@ -342,6 +405,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64, 2) void prune_tiles(const Factored
             } else {
                 out.v = T.v;
             }
+            if (own_scales) e = scale_read();
 #pragma unroll
             for (int q = 0; q < 16; ++q) out.v.v[q] *= e.v[q];
             out.mask = T.mask;
@@ -397,7 +461,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64, 2) void prune_tiles(const Factored
             // wave-wide load touches the four 128-byte lines of this op's leaves and of the next two edges while the op's first
             // product runs; the value is consumed at the end of the op (one register), so the demand loads behind it hit.
             float touched = 0.0f;
-            if (code < F_ROOT_DEV) {
+            if (!own_scales && code < F_ROOT_DEV) {
                 const int which = (lane >> 2) & 3;
                 const int nxt = slot + (which - 1) < p.n_edges ? slot + (which - 1) : p.n_edges - 1;   // which = 2, 3: the next two edges
                 const int br = which == 0 ? a : (which == 1 ? b : lslot[nxt > 0 ? nxt : 0]);
@@ -533,26 +597,27 @@ size_t prune_tiles_lds_bytes(const FactoredParams& p)
 {
     return 4096 * sizeof(double) + 64 * sizeof(double) + ((static_cast<size_t>(p.n_ops) + 63) & ~size_t(63)) * 4 +
            ((static_cast<size_t>(p.n_edges) + 3) & ~size_t(3)) * 4 +
-           TILE_WAVES * ((static_cast<size_t>(p.n_leaves) * (p.n_leaves > 128 ? 17 : 16) + 15) & ~size_t(15));
+           TILE_WAVES * ((static_cast<size_t>(p.n_leaves) * (p.n_leaves > 128 ? 17 : 16) + 15) & ~size_t(15)) +
+           (p.eval_x ? TILE_WAVES * 64 * sizeof(double) + ((static_cast<size_t>(p.n_branches) + 3) & ~size_t(3)) * sizeof(float) : 0);
 }
 
 // groups come sorted by their number of jobs; one launch per work-group size, so that no wave is launched without a tile: the
 // registers of an idle wave would be held until its whole work-group can be placed
-template <bool ANC>
+template <bool ANC, bool OWN>
 static hipError_t launch_tiles_impl(const FactoredParams& p, size_t lds, hipStream_t stream)
 {
     static std::atomic<uint64_t> attr_set{0};   // per (instantiation, device), like kernels.hip launch_impl
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     if (!(attr_set.load(std::memory_order_acquire) >> (dev & 63) & 1)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prune_tiles<ANC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prune_tiles<ANC, OWN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
     }
     // A launch that does not fill the chip a few times over is bound by the latency of one tile, and four launches in a row would
     // pay it four times (the reference's 516-block file: 2,218 launches of ~170 us instead of 850): one launch of full work-groups.
     if (p.n_groups < 2048) {
-        hipLaunchKernelGGL((prune_tiles<ANC>), dim3(p.n_groups), dim3(TILE_WAVES * 64), lds, stream, p);
+        hipLaunchKernelGGL((prune_tiles<ANC, OWN>), dim3(p.n_groups), dim3(TILE_WAVES * 64), lds, stream, p);
         return hipGetLastError();
     }
     // Largest work-groups first: a 4-wave work-group needs four free wave slots on one CU at once, and finds them while the chip is
@@ -567,24 +632,24 @@ static hipError_t launch_tiles_impl(const FactoredParams& p, size_t lds, hipStre
         FactoredParams q = p;
         q.groups = p.groups + first;
         q.n_groups = cnt;
-        hipLaunchKernelGGL((prune_tiles<ANC>), dim3(cnt), dim3(waves * 64), lds, stream, q);
+        hipLaunchKernelGGL((prune_tiles<ANC, OWN>), dim3(cnt), dim3(waves * 64), lds, stream, q);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     }
     return hipSuccess;
 }
 
-template <bool ANC>
+template <bool ANC, bool OWN>
 static hipError_t launch_tiles_sized_impl(const FactoredParams& p, int waves, size_t lds, hipStream_t stream)
 {
     static std::atomic<uint64_t> attr_set{0};
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     if (!(attr_set.load(std::memory_order_acquire) >> (dev & 63) & 1)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prune_tiles<ANC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prune_tiles<ANC, OWN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
     }
-    hipLaunchKernelGGL((prune_tiles<ANC>), dim3(p.n_groups), dim3(waves * 64), lds, stream, p);
+    hipLaunchKernelGGL((prune_tiles<ANC, OWN>), dim3(p.n_groups), dim3(waves * 64), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -594,7 +659,8 @@ hipError_t launch_prune_tiles_sized(const FactoredParams& p, int waves, hipStrea
     if (!p.groups || waves < 1 || waves > TILE_WAVES) return hipErrorInvalidValue;
     const size_t lds = prune_tiles_lds_bytes(p);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    return p.out_anc ? launch_tiles_sized_impl<true>(p, waves, lds, stream) : launch_tiles_sized_impl<false>(p, waves, lds, stream);
+    if (p.eval_x) return p.out_anc ? launch_tiles_sized_impl<true, true>(p, waves, lds, stream) : launch_tiles_sized_impl<false, true>(p, waves, lds, stream);
+    return p.out_anc ? launch_tiles_sized_impl<true, false>(p, waves, lds, stream) : launch_tiles_sized_impl<false, false>(p, waves, lds, stream);
 }
 
 hipError_t launch_prune_tiles(const FactoredParams& p, hipStream_t stream)
@@ -617,7 +683,8 @@ hipError_t launch_prune_tiles(const FactoredParams& p, hipStream_t stream)
     if (!p.groups) return hipErrorInvalidValue;
     const size_t lds = prune_tiles_lds_bytes(p);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    return p.out_anc ? launch_tiles_impl<true>(p, lds, stream) : launch_tiles_impl<false>(p, lds, stream);
+    if (p.eval_x) return p.out_anc ? launch_tiles_impl<true, true>(p, lds, stream) : launch_tiles_impl<false, true>(p, lds, stream);
+    return p.out_anc ? launch_tiles_impl<true, false>(p, lds, stream) : launch_tiles_impl<false, false>(p, lds, stream);
 }
 
 }  // namespace pcsf
