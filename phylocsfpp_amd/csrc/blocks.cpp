@@ -350,14 +350,23 @@ struct BlockEngine {
         HIP_TRY(d_leaf.reserve(cap_tables * nl * LEAF_TABLE_DOUBLES_DEV * sizeof(double)));
         tables_allocated = true;
     }
-    // eigen-systems already resident (uploaded, or solved by an earlier run()) survive a growth
-    void reserve_eig(size_t count)
+    // eigen-systems already resident (uploaded, or solved by an earlier run()) survive a growth.  basis_count: how many of them keep
+    // the orthogonal basis a warm start reads (the held systems of OMEGA: the first N_ROLES * n_blocks; default: all); with_left = false:
+    // no left eigenvectors (prune_tiles uses L = R^T diag(w): a third of the footprint of a slot)
+    size_t cap_basis = 0;
+    bool have_left = true;
+    void reserve_eig(size_t count, size_t basis_count = ~size_t(0), bool with_left = true)
     {
+        if (basis_count == ~size_t(0)) basis_count = count;
+        if (basis_count > cap_basis) {
+            HIP_TRY(d_eig_basis.reserve_keep(basis_count * 4096 * sizeof(double), cap_basis * 4096 * sizeof(double), stream));
+            cap_basis = basis_count;
+        }
         if (count <= cap_eig) return;
+        have_left = with_left;
         HIP_TRY(d_eig_r.reserve_keep(count * 4096 * sizeof(double), cap_eig * 4096 * sizeof(double), stream));
-        HIP_TRY(d_eig_l.reserve_keep(count * 4096 * sizeof(double), cap_eig * 4096 * sizeof(double), stream));
+        if (with_left) HIP_TRY(d_eig_l.reserve_keep(count * 4096 * sizeof(double), cap_eig * 4096 * sizeof(double), stream));
         HIP_TRY(d_eig_lam.reserve_keep(count * 64 * sizeof(double), cap_eig * 64 * sizeof(double), stream));
-        HIP_TRY(d_eig_basis.reserve_keep(count * 4096 * sizeof(double), cap_eig * 4096 * sizeof(double), stream));
         HIP_TRY(d_prior.reserve_keep(count * 64 * sizeof(double), cap_eig * 64 * sizeof(double), stream));
         HIP_TRY(d_ancw.reserve_keep(count * 64 * sizeof(double), cap_eig * 64 * sizeof(double), stream));
         HIP_TRY(d_eig_w.reserve_keep(count * 64 * sizeof(double), cap_eig * 64 * sizeof(double), stream));
@@ -927,7 +936,6 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
     if (want_anc) HIP_TRY(d_anc.reserve(std::max<size_t>(1, n_sites) * P * sizeof(double)));
     HIP_TRY(d_fail.reserve(nb * P * sizeof(uint32_t)));
     if (eng.use_tiles) HIP_TRY(d_eval_x.reserve(nb * P * sizeof(double)));   // prune_tiles makes its own edge scales from the evaluation's tree scale
-    else eng.reserve_tables(nb * P);                                          // prune_factored: edge-scale rows, one per evaluation slot
     const std::vector<double> t_mle = make_draw_table(seed, 1e-2, 10.0), t_rho = make_draw_table(seed, 0.001, 10.0), t_kappa = make_draw_table(seed, 1.0, 10.0);
     HIP_TRY(hipMemcpyAsync(d_draws.as<double>(), t_mle.data(), DRAW_TABLE_ENTRIES * sizeof(double), hipMemcpyHostToDevice, st0));
     HIP_TRY(hipMemcpyAsync(d_draws.as<double>() + DRAW_TABLE_ENTRIES, t_rho.data(), DRAW_TABLE_ENTRIES * sizeof(double), hipMemcpyHostToDevice, st0));
@@ -1018,15 +1026,45 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
     gp.eig_w = eng.d_eig_w.template as<double>();
     gp.eig_c = eng.d_eig_c.template as<double>();
     gp.fail = d_fail.as<uint32_t>();
+    // OMEGA: the eigen-systems a block holds sit in slots [0, transient0) (with their bases, for warm starts); the probes of a round that
+    // are not held (random restarts) take the next slots of a transient range that is dense per round -- one slot per block to begin with,
+    // grown when a round needs more (the host knows before it launches the solver).  Twelve slots per block "for the worst case" were
+    // 1.2 MB a block, and on boxes whose driver clears memory at allocation 19 GB of hipMalloc cost 0.7 s of a 1.5 s call.
+    size_t transient_cap = MLE ? 0 : nb + 64;
+    auto eigen_pointers = [&]() {
+        fp.eig_right = eng.d_eig_r.template as<double>();
+        fp.eig_left = eng.d_eig_l.template as<double>();
+        fp.eig_w = eng.d_eig_w.template as<double>();
+        fp.prior = eng.d_prior.template as<double>();
+        fp.anc_weight = eng.d_ancw.template as<double>();
+        fp.eig_lambda = eng.use_tiles ? eng.d_eig_lam.template as<double>() : nullptr;
+        fp.eig_c = eng.use_tiles ? eng.d_eig_c.template as<double>() : nullptr;
+        gp.eig_right = eng.d_eig_r.template as<double>();
+        gp.eig_left = eng.have_left ? eng.d_eig_l.template as<double>() : nullptr;
+        gp.eig_lambda = eng.d_eig_lam.template as<double>();
+        gp.eig_basis = eng.d_eig_basis.template as<double>();
+        gp.basis_slots = MLE ? 0u : transient0;
+        gp.prior = eng.d_prior.template as<double>();
+        gp.anc_weight = eng.d_ancw.template as<double>();
+        gp.eig_w = eng.d_eig_w.template as<double>();
+        gp.eig_c = eng.d_eig_c.template as<double>();
+    };
+    if (!MLE) eng.reserve_eig(transient0 + transient_cap, transient0, /*with_left=*/!eng.use_tiles);
+    eigen_pointers();
+    // prune_factored's rows of edge scales are dense per round too (a row per evaluation of the round, in list order)
+    size_t row_cap = eng.use_tiles ? 0 : 2 * nb + 64;
+    if (!eng.use_tiles) eng.reserve_tables(row_cap);
+    const size_t row_doubles = static_cast<size_t>(eng.n - 1) * 64;
     st.t_setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count();
     ticket.pass();   // every group of the call has allocated
 
     // the round's evaluations of one set: edge scales (on `scale_stream`), then pruning (on `stream`)
     auto launch_scales = [&](int set, const ChainCounters& cnt, hipStream_t stream) {
         if (eng.use_tiles) return;   // prune_tiles makes its own edge scales and runs the row-sum check itself
+        double* rows = eng.d_scale.template as<double>() + (set ? static_cast<size_t>(cnt.n_evals[0]) * row_doubles : 0);   // set 0's rows, then set 1's
         HIP_TRY(launch_edge_scale(cp.evals + static_cast<size_t>(set) * eval_cap, cnt.n_evals[set], static_cast<uint32_t>(eng.n - 1), eng.d_branch_len.template as<float>(),
-                                  eng.d_eig_r.template as<double>(), eng.d_eig_l.template as<double>(), eng.d_eig_lam.template as<double>(), eng.d_scale.template as<double>(),
-                                  d_fail.as<uint32_t>(), stream));
+                                  eng.d_eig_r.template as<double>(), eng.d_eig_l.template as<double>(), eng.d_eig_lam.template as<double>(), rows,
+                                  d_fail.as<uint32_t>(), stream, /*dense_rows=*/true));
     };
     auto launch_pruning = [&](int set, const ChainCounters& cnt, hipStream_t stream) {
         if (pack_models) {
@@ -1055,6 +1093,7 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
         } else {
             fp.groups = nullptr;
             fp.n_groups = 0;
+            fp.edge_scale = eng.d_scale.template as<double>() + (set ? static_cast<size_t>(cnt.n_evals[0]) * row_doubles : 0);   // FactoredJob::eval = row within the set
             HIP_TRY(launch_prune_factored(fp, stream));
         }
     };
@@ -1087,6 +1126,16 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
         if (cnt.n_evals[0] > eval_cap || cnt.n_evals[1] > eval_cap || cnt.n_tile_jobs[0] > job_cap || cnt.n_tile_jobs[1] > job_cap || cnt.n_list[0] > job_cap || cnt.n_list[1] > job_cap)
             throw std::runtime_error("advance_blocks: a job list overflowed");
         if (cnt.n_eig_jobs && eng.host_eigen) throw std::runtime_error("PCSF_EIGEN_HOST needs PCSF_BLOCK_ENGINE=host");
+        // everything of the previous round has finished (advance_blocks waited for it): buffers may grow here
+        if (cnt.n_transient > transient_cap) {
+            transient_cap = static_cast<size_t>(cnt.n_transient) + cnt.n_transient / 2 + 64;
+            eng.reserve_eig(transient0 + transient_cap, transient0, /*with_left=*/!eng.use_tiles);
+            eigen_pointers();
+        }
+        if (!eng.use_tiles && static_cast<size_t>(cnt.n_evals[0]) + cnt.n_evals[1] > row_cap) {
+            row_cap = (static_cast<size_t>(cnt.n_evals[0]) + cnt.n_evals[1]) * 3 / 2 + 64;
+            eng.reserve_tables(row_cap);
+        }
         gp.n_jobs = cnt.n_eig_jobs;
         if (use_ctl) {
             // control stream: edge scales of set 0, the eigen-systems, edge scales of set 1; the pruning launches wait for their set's scales
@@ -1249,7 +1298,6 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
     const bool held_systems = !(std::getenv("PCSF_OMEGA_HELD_SYSTEMS") && std::atoi(std::getenv("PCSF_OMEGA_HELD_SYSTEMS")) == 0);
     const size_t transient0 = N_ROLES * n_blocks;
     const LookaheadPolicy look = lookahead_policy(eager);
-    eng.reserve_eig(transient0 + n_blocks * look.max_points);
     const size_t nl = static_cast<size_t>(c->n_leaves);
     std::vector<OmegaMachine> machines(n_blocks);
     // F3x4 nucleotide counts over every non-gap codon of every row (src/run.hpp:105-134)
@@ -1279,6 +1327,7 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
         ticket.used = true;
         run_chain(eng, machines, PCSF_OMEGA, false, seed, eager, static_cast<uint32_t>(transient0), held_systems, stop, gate, st);
     } else {
+        eng.reserve_eig(transient0 + n_blocks * look.max_points);   // (the A/B engine: every block its own transient slots)
         const std::vector<double> t_rho = make_draw_table(seed, 0.001, 10.0), t_kappa = make_draw_table(seed, 1.0, 10.0);
         const DrawTable dr{t_rho.data(), DRAW_TABLE_ENTRIES}, dk{t_kappa.data(), DRAW_TABLE_ENTRIES};
         std::vector<StoreEntry> stores(n_blocks * STORE_ENTRIES);
@@ -1316,8 +1365,10 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
             if (trace_block >= 0 && static_cast<size_t>(trace_block) == b)
                 for (uint32_t i = 0; i < m.n_pending; ++i)
                     fprintf(stderr, "TRACE omega stage %d kind %u x %.17g lnz %.17g prior %.17g\n", m.stage, m.pend_kind[i], m.pend_x[i], res[i].lnz, prior_v[at[b] + i]);
-            return m.round(res, stores.data() + b * STORE_ENTRIES, dr, dk, look.eager, look.max_points, look.max_restarts, held_systems,
-                           static_cast<uint32_t>(transient0 + b * look.max_points), HostPrior{prior_v.data() + at[b]}, out);
+            const int n = m.round(res, stores.data() + b * STORE_ENTRIES, dr, dk, look.eager, look.max_points, look.max_restarts, held_systems, HostPrior{prior_v.data() + at[b]}, out);
+            for (int i = 0; i < n; ++i)
+                if (out[i].eig & TRANSIENT_EIG) out[i].eig = static_cast<uint32_t>(transient0 + b * look.max_points + (out[i].eig & ~TRANSIENT_EIG));
+            return n;
         });
     }
     if (std::getenv("PCSF_TIME_BLOCKS")) {

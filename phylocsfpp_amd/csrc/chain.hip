@@ -57,116 +57,219 @@ template <> struct MachineTraits<OmegaMachine> {
     static constexpr int STORES = 1;
 };
 
-// What the wave works on sits in LDS while it works: the machine (~1 KB), the stores' values (a search has seen 10-40 when it ends) and the
-// per-site values to be added up.  Lane 0's walk through the state machine is a chain of dependent reads -- from HBM it was ~0.4 ms per
-// round whatever the number of blocks (profiles/r04), every round of every group waiting for it.
+// What a wave works on sits in LDS while it works: the machine (~1 KB), the stores' values (a search has seen 10-40 when it ends) and the
+// per-site values to be added up.  The round's lists are appended to through a dozen global counters; a block first counts what it will
+// append (lane 0, with the machine's requests in LDS), then sixteen lanes make the block's atomics AT ONCE -- one round trip instead of
+// two per run of requests -- and the records are written from the bases they return.  (ADVANCE_BLOCKS > 1 lets several blocks share a
+// work-group and its atomics: a returning atomic on ONE word is served at ~88 per microsecond chip-wide, MI355X_MICROARCH.md "dequeue".
+// Measured with four: SLOWER -- 0.155 -> 0.28 ms per launch on configs[2], 8,256 real blocks MLE 0.14 -> 0.62 s: a work-group then lives as
+// long as its slowest block and four blocks' LDS images cut the occupancy.  One block per work-group it stays.)
 constexpr uint32_t SUM_CHUNK = 64;
+constexpr int ADVANCE_BLOCKS = 1;
+// counters of a round a block appends to: n_evals[2], n_tile_jobs[2], n_groups[2][4], n_eig_jobs, n_list[2], n_active, n_transient
+enum AdvanceCounter { AC_EVALS = 0, AC_TILE_JOBS = 2, AC_GROUPS = 4, AC_EIG = 12, AC_LIST = 13, AC_ACTIVE = 15, AC_TRANSIENT = 16, AC_COUNT = 17 };
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 template <class M>
-__global__ __launch_bounds__(64) void advance_blocks(const ChainParams p)
+__global__ __launch_bounds__(ADVANCE_BLOCKS * 64) void advance_blocks(const ChainParams p, uint32_t n_blocks)
 {
     constexpr int MAX_REQ = MachineTraits<M>::MAX_REQ;
     constexpr int STORES = MachineTraits<M>::STORES;
     constexpr uint32_t M_WORDS = (sizeof(M) + 3) / 4;
-    __shared__ EvalResult res[MAX_REQ];
-    __shared__ EvalRequest req[MAX_REQ];
-    __shared__ __attribute__((aligned(16))) uint32_t m_words[M_WORDS];
-    __shared__ StoreEntry st_lds[STORES * STORE_ENTRIES];
-    __shared__ double sum_buf[MAX_REQ * SUM_CHUNK];
-    __shared__ int n_req_s;
-    __shared__ uint32_t base_s[4];
-    const uint32_t b = blockIdx.x, lane = threadIdx.x;
-    uint32_t* m_global = reinterpret_cast<uint32_t*>(reinterpret_cast<M*>(p.machines) + b);
-    for (uint32_t w = lane; w < M_WORDS; w += 64) m_words[w] = m_global[w];
-    __syncthreads();
-    M* m = reinterpret_cast<M*>(m_words);
-    const uint64_t s0 = p.off[b], s1 = p.off[b + 1], sites = s1 - s0;
+    __shared__ EvalResult res_all[ADVANCE_BLOCKS][MAX_REQ];
+    __shared__ EvalRequest req_all[ADVANCE_BLOCKS][MAX_REQ];
+    __shared__ __attribute__((aligned(16))) uint32_t m_words_all[ADVANCE_BLOCKS][M_WORDS];
+    __shared__ StoreEntry st_lds_all[ADVANCE_BLOCKS][STORES * STORE_ENTRIES];
+    __shared__ double sum_buf_all[ADVANCE_BLOCKS][MAX_REQ * SUM_CHUNK];
+    __shared__ int n_req_all[ADVANCE_BLOCKS];
+    __shared__ uint32_t cnt_all[ADVANCE_BLOCKS][AC_COUNT];   // what the wave's block appends to every counter; then its offset within the work-group's range
+    __shared__ uint32_t base_all[AC_COUNT];
+    __shared__ uint32_t dense_all[ADVANCE_BLOCKS][MAX_REQ];   // a request's position in its set's list of evaluations (prune_factored's edge-scale row)
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t b = blockIdx.x * ADVANCE_BLOCKS + wave;
+    const bool live = b < n_blocks;
+    EvalResult* res = res_all[wave];
+    EvalRequest* req = req_all[wave];
+    uint32_t* m_words = m_words_all[wave];
+    StoreEntry* st_lds = st_lds_all[wave];
+    double* sum_buf = sum_buf_all[wave];
+    uint32_t* cnt = cnt_all[wave];
+    uint32_t* dense = dense_all[wave];
+    if (lane < AC_COUNT) cnt[lane] = 0u;
+    uint64_t s0 = 0, sites = 0;
     const uint32_t P = p.slots_per_block;
-    // the stores' values: into LDS when they (and this round's new ones) fit
-    StoreEntry* store_global = p.stores + static_cast<size_t>(b) * STORES * STORE_ENTRIES;
-    for (int k = 0; k < STORES; ++k) {
-        uint32_t n_in;
-        if constexpr (STORES == 2) n_in = m->n_store[k];
-        else n_in = m->n_store;
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(store_global + static_cast<size_t>(k) * STORE_ENTRIES);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(st_lds + k * STORE_ENTRIES);
-        for (uint32_t w = lane; w < n_in * (sizeof(StoreEntry) / 4); w += 64) dst[w] = src[w];
-    }
-    // (1) the values of the pending evaluations: per-site terms through LDS in chunks (coalesced), lane e adds evaluation e's in site order
-    const uint32_t n_pending = m->n_pending;
-    {
-        double l = 0.0, a = 0.0;
-        for (int pass = 0; pass < (p.out_anc ? 2 : 1); ++pass) {
-            const double* __restrict__ src = (pass ? p.out_anc : p.out_lnz) + static_cast<size_t>(P) * s0;
-            double acc = 0.0;
-            for (uint64_t c0 = 0; c0 < sites; c0 += SUM_CHUNK) {
-                const uint32_t len = static_cast<uint32_t>(sites - c0 < SUM_CHUNK ? sites - c0 : SUM_CHUNK);
-                __syncthreads();
-                if (lane < len)
-                    for (uint32_t e = 0; e < n_pending; ++e) sum_buf[e * SUM_CHUNK + lane] = src[static_cast<size_t>(e) * sites + c0 + lane];
-                __syncthreads();
-                if (lane < n_pending)
-                    for (uint32_t i = 0; i < len; ++i) acc += sum_buf[lane * SUM_CHUNK + i];
+    uint32_t n_tiles = 0;
+    int n_req = 0;
+    uint32_t* m_global = nullptr;
+    StoreEntry* store_global = nullptr;
+    if (live) {
+        m_global = reinterpret_cast<uint32_t*>(reinterpret_cast<M*>(p.machines) + b);
+        for (uint32_t w = lane; w < M_WORDS; w += 64) m_words[w] = m_global[w];
+        wave_sync();
+        M* m = reinterpret_cast<M*>(m_words);
+        s0 = p.off[b];
+        sites = p.off[b + 1] - s0;
+        n_tiles = static_cast<uint32_t>((sites + 15) / 16);
+        // the stores' values (machine.hpp store_compact bounds them: they always fit)
+        store_global = p.stores + static_cast<size_t>(b) * STORES * STORE_ENTRIES;
+        for (int k = 0; k < STORES; ++k) {
+            uint32_t n_in;
+            if constexpr (STORES == 2) n_in = m->n_store[k];
+            else n_in = m->n_store;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(store_global + static_cast<size_t>(k) * STORE_ENTRIES);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(st_lds + k * STORE_ENTRIES);
+            for (uint32_t w = lane; w < n_in * (sizeof(StoreEntry) / 4); w += 64) dst[w] = src[w];
+        }
+        // (1) the values of the pending evaluations: per-site terms through LDS in chunks of SUM_CHUNK sites (coalesced), then lane e adds
+        // evaluation e's values in site order
+        const uint32_t n_pending = m->n_pending;
+        {
+            double l = 0.0, a = 0.0;
+            constexpr uint32_t ROWS = 64 / SUM_CHUNK;   // evaluations a pass of the wave loads a chunk of
+            const uint32_t e4 = lane / SUM_CHUNK, sl = lane % SUM_CHUNK;
+            for (int pass = 0; pass < (p.out_anc ? 2 : 1); ++pass) {
+                const double* __restrict__ src = (pass ? p.out_anc : p.out_lnz) + static_cast<size_t>(P) * s0;
+                double acc = 0.0;
+                for (uint64_t c0 = 0; c0 < sites; c0 += SUM_CHUNK) {
+                    const uint32_t len = static_cast<uint32_t>(sites - c0 < SUM_CHUNK ? sites - c0 : SUM_CHUNK);
+                    wave_sync();
+                    if (sl < len)
+                        for (uint32_t e = e4; e < n_pending; e += ROWS) sum_buf[e * SUM_CHUNK + sl] = src[static_cast<size_t>(e) * sites + c0 + sl];
+                    wave_sync();
+                    if (lane < n_pending)
+                        for (uint32_t i = 0; i < len; ++i) acc += sum_buf[lane * SUM_CHUNK + i];
+                }
+                (pass ? a : l) = acc;
             }
-            (pass ? a : l) = acc;
+            if (lane < n_pending) {
+                res[lane].lnz = l;
+                res[lane].anc = a;
+                res[lane].failed = p.fail[static_cast<size_t>(b) * P + lane];
+            }
         }
-        if (lane < n_pending) {
-            res[lane].lnz = l;
-            res[lane].anc = a;
-            res[lane].failed = p.fail[static_cast<size_t>(b) * P + lane];
+        wave_sync();
+        // (2) the block's machine
+        if (lane == 0) {
+            int n;
+            // (the stores always sit in LDS: a call on a pointer chosen between LDS and HBM, or two calls the compiler merges into one, trip
+            // the gfx950 back end of ROCm 7.2, "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base")
+            if constexpr (STORES == 2) {
+                n = m->round(res, st_lds, STORE_ENTRIES, DrawTable{p.draws[0], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points), static_cast<int>(p.max_restarts), p.out_anc != nullptr, req);
+            } else {
+                n = m->round(res, st_lds, DrawTable{p.draws[1], p.n_draws}, DrawTable{p.draws[2], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points),
+                             static_cast<int>(p.max_restarts), p.held_systems != 0, DevicePrior(), req);
+            }
+            n_req_all[wave] = n;
+            // what this block appends to the round's lists
+            uint32_t c[AC_COUNT];
+            for (int k = 0; k < AC_COUNT; ++k) c[k] = 0u;
+            c[AC_ACTIVE] = m->active ? 1u : 0u;
+            for (int i0 = 0; i0 < n;) {
+                const uint32_t eig = req[i0].eig, set = req[i0].new_eigen ? 1u : 0u;
+                int i1 = i0 + 1;
+                while (i1 < n && req[i1].eig == eig && (req[i1].new_eigen ? 1u : 0u) == set && !p.pack_models) ++i1;
+                const uint32_t run_tiles = n_tiles * static_cast<uint32_t>(i1 - i0);
+                for (int i = i0; i < i1; ++i) {
+                    c[AC_EVALS + set] += 1u;
+                    if (req[i].new_eigen == 1u) c[AC_EIG] += 1u;
+                    if (req[i].eig & TRANSIENT_EIG) c[AC_TRANSIENT] += 1u;
+                }
+                if (p.pack_models) {
+                    c[AC_LIST + eig] += run_tiles;
+                } else {
+                    c[AC_TILE_JOBS + set] += run_tiles;
+                    if (p.use_tiles) {
+                        const uint32_t parts = (run_tiles + TILE_JOBS_PER_GROUP - 1) / TILE_JOBS_PER_GROUP;
+                        for (uint32_t k = 0; k < parts; ++k) {
+                            const uint32_t size = run_tiles * (k + 1) / parts - run_tiles * k / parts;
+                            c[AC_GROUPS + 4 * set + (p.split_sizes ? (size < TILE_JOBS_PER_GROUP ? size - 1 : TILE_JOBS_PER_GROUP - 1) : 0u)] += 1u;
+                        }
+                    }
+                }
+                i0 = i1;
+            }
+            for (int k = 0; k < AC_COUNT; ++k) cnt[k] = c[k];
         }
+        wave_sync();
+        n_req = n_req_all[wave];
+        // the machine and what the stores hold now, back to HBM
+        for (uint32_t w = lane; w < M_WORDS; w += 64) m_global[w] = m_words[w];
+        for (int k = 0; k < STORES; ++k) {
+            uint32_t n_now;
+            if constexpr (STORES == 2) n_now = m->n_store[k];
+            else n_now = m->n_store;
+            uint32_t* dst = reinterpret_cast<uint32_t*>(store_global + static_cast<size_t>(k) * STORE_ENTRIES);
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(st_lds + k * STORE_ENTRIES);
+            for (uint32_t w = lane; w < n_now * (sizeof(StoreEntry) / 4); w += 64) dst[w] = src[w];
+        }
+    }
+    // (3) one atomic per counter and work-group; a wave's range starts at the base plus what the waves before it append
+    __syncthreads();
+    if (threadIdx.x < AC_COUNT) {
+        const int k = threadIdx.x;
+        uint32_t total = 0;
+        for (int w = 0; w < ADVANCE_BLOCKS; ++w) {
+            const uint32_t mine = cnt_all[w][k];
+            cnt_all[w][k] = total;
+            total += mine;
+        }
+        uint32_t* counter = k < AC_TILE_JOBS ? &p.counters->n_evals[k - AC_EVALS]
+                            : k < AC_GROUPS ? &p.counters->n_tile_jobs[k - AC_TILE_JOBS]
+                            : k < AC_EIG    ? &p.counters->n_groups[(k - AC_GROUPS) >> 2][(k - AC_GROUPS) & 3]
+                            : k < AC_LIST   ? &p.counters->n_eig_jobs
+                            : k < AC_ACTIVE ? &p.counters->n_list[k - AC_LIST]
+                            : k == AC_ACTIVE ? &p.counters->n_active
+                                             : &p.counters->n_transient;
+        base_all[k] = total ? atomicAdd(counter, total) : 0u;
     }
     __syncthreads();
-    // (2) the block's machine
-    if (lane == 0) {
-        int n;
-        // (the stores always sit in LDS -- machine.hpp store_compact bounds them: a call on a pointer chosen between LDS and HBM, or two calls
-        // the compiler merges into one, trip the gfx950 back end of ROCm 7.2, "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base")
-        if constexpr (STORES == 2) {
-            n = m->round(res, st_lds, STORE_ENTRIES, DrawTable{p.draws[0], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points), static_cast<int>(p.max_restarts), p.out_anc != nullptr, req);
-        } else {
-            n = m->round(res, st_lds, DrawTable{p.draws[1], p.n_draws}, DrawTable{p.draws[2], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points),
-                         static_cast<int>(p.max_restarts), p.held_systems != 0, p.transient0 + b * P, DevicePrior(), req);
-        }
-        n_req_s = n;
-        if (m->active) atomicAdd(&p.counters->n_active, 1u);
-    }
-    __syncthreads();
-    // the machine and what the stores hold now, back to HBM
-    for (uint32_t w = lane; w < M_WORDS; w += 64) m_global[w] = m_words[w];
-    for (int k = 0; k < STORES; ++k) {
-        uint32_t n_now;
-        if constexpr (STORES == 2) n_now = m->n_store[k];
-        else n_now = m->n_store;
-        uint32_t* dst = reinterpret_cast<uint32_t*>(store_global + static_cast<size_t>(k) * STORE_ENTRIES);
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(st_lds + k * STORE_ENTRIES);
-        for (uint32_t w = lane; w < n_now * (sizeof(StoreEntry) / 4); w += 64) dst[w] = src[w];
-    }
-    // (3) this round's job records.  Set 1: evaluations that wait for an eigen-system solved in this round; set 0: the others.
-    const int n_req = n_req_s;
-    const uint32_t n_tiles = static_cast<uint32_t>((sites + 15) / 16);
-    for (int i = lane; i < n_req; i += 64) {
-        const EvalRequest& r = req[i];
-        const uint32_t table = b * P + static_cast<uint32_t>(i), set = r.new_eigen ? 1u : 0u;
-        p.fail[table] = 0u;
-        ExpmEval ev;
-        ev.eig = r.eig;
-        ev.table = table;
-        ev.block = b;
-        ev.pad = p.use_tiles;
-        ev.x = r.tree_scale;
-        if (p.eval_x) p.eval_x[table] = r.tree_scale;
-        p.evals[static_cast<size_t>(set) * p.eval_capacity + atomicAdd(&p.counters->n_evals[set], 1u)] = ev;
-        if (r.new_eigen == 1u) {
-            EigenJob j;
-            j.eig = r.eig;
-            j.table = table;
-            j.warm = r.warm;
-            j.pad = 0;
-            for (int k = 0; k < 12; ++k) j.qs[k] = r.qs[k];
-            p.eig_jobs[atomicAdd(&p.counters->n_eig_jobs, 1u)] = j;
+    if (!live) return;
+    // (4) this round's job records.  Set 1: evaluations that wait for an eigen-system solved in this round; set 0: the others.
+    uint32_t at[AC_COUNT];   // next free index of every list for this block (all lanes keep the same values)
+#pragma unroll
+    for (int k = 0; k < AC_COUNT; ++k) at[k] = base_all[k] + cnt[k];
+    // the probes of this round that are not held get the next slots of the round's transient range (machine.hpp TRANSIENT_EIG)
+    if (static_cast<int>(lane) < n_req && (req[lane].eig & TRANSIENT_EIG)) req[lane].eig = p.transient0 + at[AC_TRANSIENT] + (req[lane].eig & ~TRANSIENT_EIG);
+    wave_sync();
+    {
+        // evaluations and eigen jobs: lane i writes request i's records; its indices are the counts of the requests before it
+        uint32_t my_eval = 0, my_eig = 0;
+        if (static_cast<int>(lane) < n_req) {
+            const uint32_t set = req[lane].new_eigen ? 1u : 0u;
+            for (uint32_t i = 0; i < lane; ++i) {
+                if ((req[i].new_eigen ? 1u : 0u) == set) ++my_eval;
+                if (req[i].new_eigen == 1u) ++my_eig;
+            }
+            const EvalRequest& r = req[lane];
+            const uint32_t table = b * P + lane;
+            p.fail[table] = 0u;
+            ExpmEval ev;
+            ev.eig = r.eig;
+            ev.table = table;
+            ev.block = b;
+            ev.pad = p.use_tiles;
+            ev.x = r.tree_scale;
+            if (p.eval_x) p.eval_x[table] = r.tree_scale;
+            p.evals[static_cast<size_t>(set) * p.eval_capacity + at[AC_EVALS + set] + my_eval] = ev;
+            dense[lane] = at[AC_EVALS + set] + my_eval;
+            if (r.new_eigen == 1u) {
+                EigenJob j;
+                j.eig = r.eig;
+                j.table = table;
+                j.warm = r.warm;
+                j.pad = 0;
+                for (int k = 0; k < 12; ++k) j.qs[k] = r.qs[k];
+                p.eig_jobs[at[AC_EIG] + my_eig] = j;
+            }
         }
     }
+    wave_sync();
     // tile jobs: requests that share an eigen-system (the rho points of a round all use the block's own; MLE: the model's) are laid out
     // together, so that their tiles can share work-groups
     for (int i0 = 0; i0 < n_req;) {
@@ -174,12 +277,14 @@ __global__ __launch_bounds__(64) void advance_blocks(const ChainParams p)
         int i1 = i0 + 1;
         while (i1 < n_req && req[i1].eig == eig && (req[i1].new_eigen ? 1u : 0u) == set && !p.pack_models) ++i1;
         const uint32_t run_tiles = n_tiles * static_cast<uint32_t>(i1 - i0);
-        if (lane == 0) {
-            if (p.pack_models) base_s[0] = eig * p.list_capacity + atomicAdd(&p.counters->n_list[eig], run_tiles);
-            else base_s[0] = atomicAdd(&p.counters->n_tile_jobs[set], run_tiles);
+        uint32_t job0;
+        if (p.pack_models) {
+            job0 = eig * p.list_capacity + at[AC_LIST + eig];
+            at[AC_LIST + eig] += run_tiles;
+        } else {
+            job0 = at[AC_TILE_JOBS + set];
+            at[AC_TILE_JOBS + set] += run_tiles;
         }
-        __syncthreads();
-        const uint32_t job0 = base_s[0];
         FactoredJob* __restrict__ jobs = p.tile_jobs + (p.pack_models ? 0 : static_cast<size_t>(set) * p.job_capacity);
         for (uint32_t t = lane; t < run_tiles; t += 64) {
             const uint32_t i = static_cast<uint32_t>(i0) + t / n_tiles, tile = t % n_tiles;
@@ -188,7 +293,7 @@ __global__ __launch_bounds__(64) void advance_blocks(const ChainParams p)
             j.out0 = static_cast<uint64_t>(P) * s0 + static_cast<uint64_t>(i) * sites + 16ull * tile;
             j.n_sites = static_cast<uint32_t>(sites - 16ull * tile < 16 ? sites - 16ull * tile : 16);
             j.eig = eig;
-            j.eval = b * P + i;
+            j.eval = p.use_tiles ? b * P + i : dense[i];   // prune_tiles: the evaluation slot (eval_x, failure flag); prune_factored: the evaluation's row of edge scales, dense per set
             j.pad = tile == 0 ? FACTORED_JOB_VALIDATES : 0u;   // (read by prune_tiles when it makes its own edge scales)
             jobs[job0 + t] = j;
         }
@@ -196,14 +301,13 @@ __global__ __launch_bounds__(64) void advance_blocks(const ChainParams p)
             // the run's tiles in even parts of at most TILE_JOBS_PER_GROUP (one wave per tile, one eigen-system per work-group);
             // a part goes to the list of its size, so that a work-group is launched with as many waves as it has tiles
             const uint32_t parts = (run_tiles + TILE_JOBS_PER_GROUP - 1) / TILE_JOBS_PER_GROUP;
-            for (uint32_t k = lane; k < parts; k += 64) {
+            for (uint32_t k = 0; k < parts; ++k) {   // (every lane walks the parts: `at` stays the same in all of them; lane 0 writes)
                 const uint32_t a = run_tiles * k / parts, e = run_tiles * (k + 1) / parts, size = e - a;
                 const uint32_t list = p.split_sizes ? (size < TILE_JOBS_PER_GROUP ? size - 1 : TILE_JOBS_PER_GROUP - 1) : 0u;
-                const uint32_t g = atomicAdd(&p.counters->n_groups[set][list], 1u);
-                p.groups[(static_cast<size_t>(set) * 4 + list) * p.group_capacity + g] = TileGroup{job0 + a, size};
+                const uint32_t g = at[AC_GROUPS + 4 * set + list]++;
+                if (lane == 0) p.groups[(static_cast<size_t>(set) * 4 + list) * p.group_capacity + g] = TileGroup{job0 + a, size};
             }
         }
-        __syncthreads();   // base_s is rewritten by the next run
         i0 = i1;
     }
 }
@@ -213,8 +317,9 @@ __global__ __launch_bounds__(64) void advance_blocks(const ChainParams p)
 hipError_t launch_advance_blocks(const ChainParams& p, int algo, uint32_t n_blocks, hipStream_t stream)
 {
     if (n_blocks == 0) return hipSuccess;
-    if (algo == 0) hipLaunchKernelGGL(advance_blocks<MleMachine>, dim3(n_blocks), dim3(64), 0, stream, p);
-    else hipLaunchKernelGGL(advance_blocks<OmegaMachine>, dim3(n_blocks), dim3(64), 0, stream, p);
+    const uint32_t grid = (n_blocks + ADVANCE_BLOCKS - 1) / ADVANCE_BLOCKS;
+    if (algo == 0) hipLaunchKernelGGL(advance_blocks<MleMachine>, dim3(grid), dim3(ADVANCE_BLOCKS * 64), 0, stream, p, n_blocks);
+    else hipLaunchKernelGGL(advance_blocks<OmegaMachine>, dim3(grid), dim3(ADVANCE_BLOCKS * 64), 0, stream, p, n_blocks);
     return hipGetLastError();
 }
 

@@ -62,7 +62,7 @@ struct Vec4 {
 __global__ __launch_bounds__(256) void edge_scale_kernel(const ExpmEval* __restrict__ evals, uint32_t n_branches, const float* __restrict__ branch_len,
                                                          const double* __restrict__ eig_right, const double* __restrict__ eig_left,
                                                          const double* __restrict__ eig_lambda, double* __restrict__ scale_out,
-                                                         uint32_t* __restrict__ fail)
+                                                         uint32_t* __restrict__ fail, uint32_t dense_rows)
 {
     // one work-group per evaluation; wave w takes branches w, w+4, ...; lane k the eigenvalue k.  The branch lengths go through LDS
     // first (one coalesced load; reading them one by one in the loops below was ~250 dependent round trips to L2 per thread -- most
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void edge_scale_kernel(const ExpmEval* __restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double lam = eig_lambda[static_cast<size_t>(ev.eig) * 64 + lane];
     const int pos = row_split_pos(lane);
-    double* __restrict__ dst = scale_out + static_cast<size_t>(ev.table) * n_branches * 64;
+    double* __restrict__ dst = scale_out + static_cast<size_t>(dense_rows ? blockIdx.x : ev.table) * n_branches * 64;   // (the failure flag stays at ev.table)
     const bool staged = n_branches <= 512;
     if (staged) {
         for (uint32_t b = tid; b < n_branches; b += 256) lens[b] = branch_len[b];
@@ -631,11 +631,11 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
 }
 
 hipError_t launch_edge_scale(const ExpmEval* d_evals, uint32_t n_evals, uint32_t n_branches, const float* d_branch_len, const double* d_eig_right,
-                             const double* d_eig_left, const double* d_eig_lambda, double* d_scale_out, uint32_t* d_fail, hipStream_t stream)
+                             const double* d_eig_left, const double* d_eig_lambda, double* d_scale_out, uint32_t* d_fail, hipStream_t stream, bool dense_rows)
 {
     if (n_evals == 0) return hipSuccess;
     hipLaunchKernelGGL(edge_scale_kernel, dim3(n_evals), dim3(256), 0, stream, d_evals, n_branches, d_branch_len, d_eig_right, d_eig_left,
-                       d_eig_lambda, d_scale_out, d_fail);
+                       d_eig_lambda, d_scale_out, d_fail, dense_rows ? 1u : 0u);
     return hipGetLastError();
 }
 

@@ -163,8 +163,9 @@ struct FactoredParams {
 };
 
 // evals[i].table selects the output row of d_scale_out and the failure flag; evals[i].eig the eigen-system
+// dense_rows: evaluation i of the list writes row i of d_scale_out (the caller passes the first row of the list) instead of row evals[i].table
 hipError_t launch_edge_scale(const ExpmEval* d_evals, uint32_t n_evals, uint32_t n_branches, const float* d_branch_len, const double* d_eig_right,
-                             const double* d_eig_left, const double* d_eig_lambda, double* d_scale_out, uint32_t* d_fail, hipStream_t stream);
+                             const double* d_eig_left, const double* d_eig_lambda, double* d_scale_out, uint32_t* d_fail, hipStream_t stream, bool dense_rows = false);
 hipError_t launch_prune_factored(const FactoredParams& p, hipStream_t stream);
 // the same jobs, one wave per tile with R and L resident in LDS (tiles.hip); jobs sorted so that p.groups cut them by eigen-system
 hipError_t launch_prune_tiles(const FactoredParams& p, hipStream_t stream);
@@ -182,6 +183,8 @@ struct EigenJob;
 struct ChainCounters {       // zeroed before every round; read by the host after advance_blocks to size the round's launches
     uint32_t n_active;       // blocks that are not finished
     uint32_t n_eig_jobs;     // evaluations with a new eigen-system (eigen_omega_kernel work-groups)
+    uint32_t n_transient;    // of which into a transient slot (transient0 + 0 .. n_transient - 1): the host grows the eigen-system buffers before the launch if need be
+    uint32_t pad_;
     uint32_t n_evals[2];     // evaluations requested this round, by set (edge_scale_kernel work-groups)
     uint32_t n_tile_jobs[2];
     uint32_t n_groups[2][4]; // tile groups by set and number of tiles: 1, 2, 3, TILE_JOBS_PER_GROUP (all in [0] when !split_sizes)
@@ -199,7 +202,7 @@ struct ChainParams {
     const double* draws[3];      // restart points of the MLE, rho and kappa search ranges (optimizer.hpp DrawTable)
     uint32_t n_draws;
     uint32_t eager, max_points, max_restarts, held_systems;   // machine.hpp LookaheadPolicy
-    uint32_t transient0;         // OMEGA: first eigen-system slot of the per-block transient ranges
+    uint32_t transient0;         // OMEGA: first eigen-system slot of the round's transient systems (probes that are not held: dense, counters->n_transient)
     uint32_t use_tiles, split_sizes;
     uint32_t pack_models;        // MLE + prune_tiles: the two ECM eigen-systems are shared by all blocks -- tile jobs go to one list per model
                                  // (the second at tile_jobs + list_capacity) and every four consecutive jobs of a list form a work-group
@@ -254,9 +257,10 @@ struct EigenParams {
     const EigenJob* jobs;
     uint32_t n_jobs;
     double* eig_right;    // [n_eig][64*64]
-    double* eig_left;     // [n_eig][64*64]
+    double* eig_left;     // [n_eig][64*64] (may be null: prune_tiles uses L = R^T diag(w))
     double* eig_lambda;   // [n_eig][64]
-    double* eig_basis;    // [n_eig][64*64] orthogonal eigenvector matrix of the symmetrised rate matrix (warm starts; may be null)
+    double* eig_basis;    // [basis_slots][64*64] orthogonal eigenvector matrix of the symmetrised rate matrix (warm starts; may be null)
+    uint32_t basis_slots; // eigen-systems >= this index keep no basis (nothing warm-starts from them: the probes of a round that are not held); 0 = all do
     double* prior;        // [n_eig][64] equilibrium prior in lane order (may be null)
     double* anc_weight;   // [n_eig][64] ln(prior)*prior in lane order (may be null)
     double* prior_plain;  // optional [n_eig][64] prior in state order (diagnostics/tests)

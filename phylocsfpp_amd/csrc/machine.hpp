@@ -38,6 +38,10 @@ constexpr int OMEGA_MAX_REQUESTS = MAX_POINTS_PER_SEARCH;     // a block either 
 constexpr uint32_t STORE_ENTRIES = 96;        // values a search keeps (store_compact): it can evaluate ~520 points -- lo, hi, start, <= 250 restarts, v, <= 250 Brent probes
 constexpr uint32_t STORE_COMPACT_AT = 48;
 
+// EvalRequest::eig of a probe that is not held (a random restart): TRANSIENT_EIG | k = the k-th such system of the block's round; the engine
+// gives it a slot for the round
+constexpr uint32_t TRANSIENT_EIG = 0x80000000u;
+
 enum EvalKind : uint32_t { EVAL_MLE_CODING = 0, EVAL_MLE_NONCODING = 1, EVAL_RHO = 2, EVAL_KAPPA = 3, EVAL_VALIDATION = 4 };
 
 // values a search has seen: the objective is a pure function of the point, so a point asked for again (the reference
@@ -298,12 +302,11 @@ struct OmegaMachine {
     }
 
     // res[i]: the likelihood part of pending request i; prior(i, kind, x): the log prior the objective adds to it (src/omega.hpp:130-149).
-    // store: [STORE_ENTRIES]; rho_draws / kappa_draws: the restart points of the two search ranges; transient0: the first of
-    // OMEGA_MAX_REQUESTS eigen-system slots for this round's probes that are not kept.
+    // store: [STORE_ENTRIES]; rho_draws / kappa_draws: the restart points of the two search ranges.
     // Returns the number of requests written to out[OMEGA_MAX_REQUESTS]; 0 = the block is finished (or failed).
     template <class Prior>
     PCSF_HD int round(const EvalResult* res, StoreEntry* store, const DrawTable& rho_draws, const DrawTable& kappa_draws, bool eager, int max_points, int max_restarts,
-                      bool held_systems, uint32_t transient0, Prior prior, EvalRequest* out)
+                      bool held_systems, Prior prior, EvalRequest* out)
     {
         store_compact(store, n_store, used);
         for (uint32_t i = 0; i < n_pending; ++i) {
@@ -480,7 +483,7 @@ struct OmegaMachine {
                         held_valid[target] = 1;
                         written |= 1u << target;
                     } else {
-                        r.eig = transient0 + n_transient++;
+                        r.eig = TRANSIENT_EIG | n_transient++;
                     }
                     copy_settings(r.qs, qs);
                     r.warm = warm;

@@ -1,4 +1,5 @@
-cd $GRAFT_REPO_ROOT
+#!/bin/bash
+cd "$(dirname "$0")/.." || exit 1
 W=/tmp/config3_work; mkdir -p $W/out_t $W/out_f
 MAF=$W/syn1mb.maf
 python3 tools/gen_synthetic_maf.py $MAF --bases 1000000 --seed 20261002 > /dev/null 2>&1

@@ -1,4 +1,5 @@
-cd $GRAFT_REPO_ROOT
+#!/bin/bash
+cd "$(dirname "$0")/.." || exit 1
 python tools/diag_determinism.py 20
 cli=phylocsfpp_amd/host/phylocsf-amd; model=tests/golden/models/58mammals; w=/tmp/dg; rm -rf $w; mkdir -p $w
 python tools/gen_synthetic_maf.py $w/seg.maf --bases 1000000 > /dev/null

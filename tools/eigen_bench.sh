@@ -1,4 +1,6 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+#!/bin/bash
+cd "$(dirname "$0")/.." || exit 1
+export TMPDIR=/tmp
 rm -rf /tmp/prof_eb
 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_eb -- python3 tools/eigen_bench.py 200 2>&1 | tail -2
 python3 - <<'PY'

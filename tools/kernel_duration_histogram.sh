@@ -1,4 +1,5 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+cd "$(dirname "$0")/.." || exit 1
+export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_e -- python3 tools/bench_blocks.py - 0 1 nocpu > /dev/null 2>&1
 python3 - <<'PY'
 import csv, glob

@@ -1,4 +1,6 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/pmc_final; mkdir -p $O
+#!/bin/bash
+cd "$(dirname "$0")/.." || exit 1
+export TMPDIR=/tmp; O=gpurun_out/pmc_final; mkdir -p $O
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_blocks -- python3 tools/bench_blocks.py - 0 4 nocpu > /dev/null 2>&1
 python3 - <<PY
 import csv, glob, json
