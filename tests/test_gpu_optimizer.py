@@ -89,3 +89,43 @@ def test_a_blocks_result_does_not_depend_on_the_list_it_is_scored_in(oracle_mode
             assert whole[::7].tobytes() == singles.tobytes(), algo
     finally:
         ctx.close()
+
+
+def test_engines_agree_on_empty_single_site_and_long_blocks(oracle_models, monkeypatch):
+    """Edges of the device engine's bookkeeping: blocks without a site (MLE: lpr = 0 at every scale, the searches exhaust their 250
+    restarts; OMEGA: NaN by policy), a one-site block, a block of one tile and a site, a 700-site block (44 tiles: several work-groups
+    per evaluation, per-site sums over many chunks), a block whose every species shows the same codon (a flat objective: restarts run
+    long and the value store is compacted) -- device engine against host engine bit for bit on both pruning kernels, and against the
+    oracle's own optimiser runs inside the reference's tolerances."""
+    from phylocsfpp_amd import synth
+    m = oracle_models("53birds")
+    lens = [0, 1, 17, 0, 700, 5, 40]
+    cols = synth.synthetic_codon_columns(m.child1, m.child2, m.branch_len, m.S_c, m.pi_c, m.S_nc, m.pi_nc, sum(lens), seed=5, dropout=0.2, gap_rate=0.05)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    cols[:, int(off[5]):int(off[6])] = 17          # the 5-site block: one codon everywhere
+    ctx = pa.load_model(os.path.join(GOLD, "models", "53birds")).context()
+    lib = ob.lib()
+    lib.po_run_blocks.argtypes = [C.POINTER(ob.PoModel), C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.c_size_t, C.c_size_t, C.c_int, C.c_uint32,
+                                  C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
+    try:
+        for kernel in (pa.ScoringContext.BLOCK_KERNEL_TILES, pa.ScoringContext.BLOCK_KERNEL_FACTORED):
+            ctx.set_block_kernel(kernel)
+            for algo, o_algo, anc, tol in ((pa.MLE, ob.MLE, True, 0.001), (pa.OMEGA, ob.OMEGA, False, 0.1)):
+                res = {}
+                for engine in ("device", "host"):
+                    monkeypatch.setenv("PCSF_BLOCK_ENGINE", engine)
+                    res[engine] = ctx.score_blocks(algo, cols, off, compute_anc=anc)
+                assert res["device"][0].tobytes() == res["host"][0].tobytes(), (kernel, algo)
+                assert res["device"][1].tobytes() == res["host"][1].tobytes(), (kernel, algo)
+                oph = np.full(len(lens), np.nan, np.float32)
+                oan = np.full(len(lens), np.nan, np.float32)
+                lib.po_run_blocks(C.byref(m.m), o_algo, cols.ctypes.data_as(C.POINTER(C.c_uint8)), off.ctypes.data_as(C.POINTER(C.c_uint64)), len(lens), cols.shape[1],
+                                  int(anc), 42, oph.ctypes.data_as(C.POINTER(C.c_float)), oan.ctypes.data_as(C.POINTER(C.c_float)), 0)
+                ph = res["device"][0]
+                assert np.array_equal(np.isnan(ph), np.isnan(oph)), (kernel, algo, ph, oph)
+                ok = np.isfinite(oph)
+                assert np.all((ph[ok] - oph[ok]) ** 2 <= tol), (kernel, algo, ph, oph)
+                if algo == pa.MLE:
+                    assert ph[0] == 0.0 and ph[3] == 0.0          # blocks without a site
+    finally:
+        ctx.close()
