@@ -158,6 +158,22 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx *ctx, const char *nucleotides, si
                                       const pcsf_alignment_desc *alignments, size_t n_alignments, double *out_scores,
                                       size_t out_capacity, uint64_t *out_offsets, uint32_t *n_codons,
                                       uint32_t *skip_bases, double *out_bls);
+/* The same call for a caller that only WRITES the results: the scores and the per-base branch-length scores stay on the device and
+ * the text of build-tracks' seven wig files is formatted there (csrc/wig.hip) -- the output loop of
+ * src/phylocsf++build_tracks.hpp:139-156 (PhyloCSFpower.wig: every codon of frame 3 of the + strand, "%.4f" trimmed, one header per
+ * alignment) and :183-217 (PhyloCSFRaw+1..-3: a codon whose three per-base scores sum to less than 3 x power_threshold is left out,
+ * :201-205; a "fixedStep chrom=... start=... step=3 span=3" line wherever a run of written codons starts, :207-210; "%.3f" trimmed,
+ * src/common.hpp:48-68).  chrom_names[n_alignments]: the alignments' chromosome names.  out_bytes[7]: bytes of text per file of THIS
+ * call (0: power track, 1..6: the frames in the order +1 +2 +3 -1 -2 -3); want_power / want_raw = 0 leaves the file(s) empty.  The text
+ * is what the host formatter writes, byte for byte (tests/test_gpu_cli.py).  PCSF_ERR_UNSUPPORTED: a finite |value| >= 9e14 turned up
+ * (never a score): format this batch from pcsf_score_alignments_6frames_bls instead.  Needs pcsf_set_bls_branch_lengths. */
+int pcsf_score_alignments_6frames_wig(pcsf_ctx *ctx, const char *nucleotides, size_t row_stride,
+                                      const pcsf_alignment_desc *alignments, size_t n_alignments, const char *const *chrom_names,
+                                      float power_threshold, int want_power, int want_raw, uint64_t *out_bytes,
+                                      size_t *n_codon_frames);
+/* copies the text of the last pcsf_score_alignments_6frames_wig call of this context: dst[f] has room for out_bytes[f] (page-locked
+ * memory from pcsf_host_alloc_on keeps the copy off the host threads); a file without text may have dst[f] = NULL */
+int pcsf_fetch_wig_text(pcsf_ctx *ctx, char *const *dst);
 
 /* ---- the smoothing pass of build-tracks (--output-phylo / --output-regions) --------------------------------
  * hmm::state_posterior_probabilities and the forward half of get_best_path_by_viterbi (src/create_tracks.hpp:25-159,
@@ -294,6 +310,10 @@ int pcsf_debug_maxlik(double (*objective)(double x, void *user), void *user, dou
  * values than n_values.  A search that takes the decisions of the one that produced `values` asks for exactly its points. */
 int pcsf_debug_maxlik_device(pcsf_ctx *ctx, double init, double lo, double hi, uint32_t seed, int skip_draws, const double *values,
                              int n_values, double *xs_out, int cap, int *n_requests, double *last_lpr);
+/* Test hook: the number formatter of csrc/wig.hip (print_trimmed, src/common.hpp:48-68: "%.3f" / "%.4f" without trailing zeros, one decimal kept)
+ * on n values.  text[32 * i ...]: value i's characters; lens[i]: their number, or 0xffffffff for a finite |value| >= 9e14 (left to the host).
+ * decimals: 3 or 4. */
+int pcsf_debug_wig_format(pcsf_ctx *ctx, const float *values, size_t n, int decimals, char *text, uint32_t *lens);
 const char *pcsf_version(void);
 
 /* Optional: page-locked host memory for the buffers handed to the scoring calls.  Transfers from/to such buffers

@@ -78,6 +78,10 @@ def load_library():
     lib.pcsf_score_alignments_6frames.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(_AlignmentDesc), C.c_size_t, dp, C.c_size_t,
                                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.pcsf_score_alignments_6frames_bls.argtypes = lib.pcsf_score_alignments_6frames.argtypes + [dp]
+    lib.pcsf_score_alignments_6frames_wig.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(_AlignmentDesc), C.c_size_t, C.POINTER(C.c_char_p),
+                                                      C.c_float, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]
+    lib.pcsf_fetch_wig_text.argtypes = [vp, C.POINTER(C.c_char_p)]
+    lib.pcsf_debug_wig_format.argtypes = [vp, fp, C.c_size_t, C.c_int, C.c_char_p, C.POINTER(C.c_uint32)]
     lib.pcsf_set_bls_branch_lengths.argtypes = [vp, dp]
     lib.pcsf_branch_length_scores.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_size_t, dp]
     lib.pcsf_hmm_smooth_runs.argtypes = [vp, dp, dp, dp, C.POINTER(C.c_uint64), C.c_size_t, dp, u8p, dp, C.POINTER(C.c_uint32)]
@@ -335,6 +339,38 @@ class ScoringContext:
         if with_bls:
             return res, skip.reshape(n, 6), bls
         return res, skip.reshape(n, 6)
+
+    def score_alignments_6frames_wig(self, nucleotides, alignments, chroms, power_threshold, want_power=True, want_raw=True):
+        """The same call for a caller that only writes: the text of build-tracks' seven wig files for this batch (formatted on the
+        device, csrc/wig.hip).  chroms: one chromosome name per alignment.  Returns (list of 7 bytes objects -- power track, then
+        +1 +2 +3 -1 -2 -3 --, number of codon-frames scored); None when the device left the batch to the host formatter."""
+        nuc = np.ascontiguousarray(nucleotides, dtype=np.uint8)
+        assert nuc.ndim == 2 and nuc.shape[0] == self.n_leaves
+        n = len(alignments)
+        desc = (_AlignmentDesc * n)(*[_AlignmentDesc(int(a), int(b), int(c), int(d)) for a, b, c, d in alignments])
+        names = (C.c_char_p * n)(*[c.encode() if isinstance(c, str) else bytes(c) for c in chroms])
+        sizes = (C.c_uint64 * 7)()
+        frames = C.c_size_t(0)
+        rc = self._lib.pcsf_score_alignments_6frames_wig(self._h, nuc.ctypes.data_as(C.c_char_p), nuc.strides[0], desc, n, names,
+                                                         float(power_threshold), int(want_power), int(want_raw), sizes, C.byref(frames))
+        if rc == -5:   # PCSF_ERR_UNSUPPORTED
+            return None
+        self._check(rc)
+        bufs = [C.create_string_buffer(max(int(s), 1)) for s in sizes]
+        dst = (C.c_char_p * 7)(*[C.cast(b, C.c_char_p) for b in bufs])
+        if n:
+            self._check(self._lib.pcsf_fetch_wig_text(self._h, dst))
+        return [bufs[f].raw[:int(sizes[f])] for f in range(7)], int(frames.value)
+
+    def debug_wig_format(self, values, decimals):
+        """csrc/wig.hip's number formatter on float32 values: list of bytes (None: a value the device leaves to the host)."""
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        text = C.create_string_buffer(max(32 * len(v), 1))
+        lens = np.zeros(len(v), dtype=np.uint32)
+        self._check(self._lib.pcsf_debug_wig_format(self._h, v.ctypes.data_as(C.POINTER(C.c_float)), len(v), int(decimals), text,
+                                                    lens.ctypes.data_as(C.POINTER(C.c_uint32))))
+        raw = text.raw
+        return [None if int(l) == 0xffffffff else raw[32 * i:32 * i + int(l)] for i, l in enumerate(lens)]
 
     # ---- run -----------------------------------------------------------------------------
     def prepare_block_scoring(self, algo):

@@ -306,6 +306,26 @@ int pcsf_debug_maxlik_device(pcsf_ctx* c, double init, double lo, double hi, uin
     return PCSF_OK;
 }
 
+// wig.hip's number formatter on n values: text[32 * i ...] holds value i's digits, lens[i] their number (0xffffffff: a value the device
+// leaves to the host).  decimals: 3 (raw tracks) or 4 (power track).
+int pcsf_debug_wig_format(pcsf_ctx* c, const float* values, size_t n, int decimals, char* text, uint32_t* lens)
+{
+    if (!c) return PCSF_ERR_INVALID_ARG;
+    if (!values || !text || !lens || (decimals != 3 && decimals != 4) || n >= 0xffffffffull) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_debug_wig_format: bad argument");
+    if (n == 0) return PCSF_OK;
+    hipError_t e;
+    if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
+    pcsf::DeviceBuffer d_v, d_text, d_lens;
+    if ((e = d_v.reserve(n * 4)) != hipSuccess || (e = d_text.reserve(n * 32)) != hipSuccess || (e = d_lens.reserve(n * 4)) != hipSuccess) return c->hip_fail(e, "hipMalloc");
+    if ((e = hipMemcpyAsync(d_v.ptr, values, n * 4, hipMemcpyHostToDevice, c->stream)) != hipSuccess ||
+        (e = hipMemsetAsync(d_text.ptr, 0, n * 32, c->stream)) != hipSuccess ||
+        (e = pcsf::launch_wig_format_debug(d_v.as<float>(), static_cast<uint32_t>(n), decimals, d_text.as<char>(), d_lens.as<uint32_t>(), c->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(text, d_text.ptr, n * 32, hipMemcpyDeviceToHost, c->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(lens, d_lens.ptr, n * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess)
+        return c->hip_fail(e, "pcsf_debug_wig_format");
+    return PCSF_OK;
+}
+
 // host-only helper (no device needed): the pruning program for a tree, for tests and tooling
 int pcsf_build_schedule(int32_t n_nodes, const int16_t* child1, const int16_t* child2, uint32_t* program, int32_t program_cap,
                         int32_t* slot_node, int32_t* n_ops, int32_t* n_slots, int32_t* stack_depth)
@@ -599,6 +619,20 @@ int pcsf_score_alignments_6frames(pcsf_ctx* c, const char* nucleotides, size_t r
                                              nullptr);
 }
 
+namespace {
+struct WigRequest {   // pcsf_score_alignments_6frames_wig: the call's wig text instead of its scores
+    const char* const* chrom_names;
+    float power_threshold;
+    bool want_power, want_raw;
+    uint64_t* out_bytes;       // [7]
+    size_t* n_codon_frames;
+};
+}  // namespace
+
+static int six_frames_impl(pcsf_ctx* c, const char* nucleotides, size_t row_stride, const pcsf_alignment_desc* alns, size_t n_alns,
+                           double* out_scores, size_t out_capacity, uint64_t* out_offsets, uint32_t* n_codons, uint32_t* skip_bases,
+                           double* out_bls, const WigRequest* wig);
+
 int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size_t row_stride, const pcsf_alignment_desc* alns, size_t n_alns,
                                       double* out_scores, size_t out_capacity, uint64_t* out_offsets, uint32_t* n_codons, uint32_t* skip_bases,
                                       double* out_bls)
@@ -606,7 +640,52 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
     if (!c) return PCSF_ERR_INVALID_ARG;
     if (n_alns == 0) return PCSF_OK;
     if (!nucleotides || !alns || !out_scores || !out_offsets || !n_codons) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_alignments_6frames: null argument");
-    if (out_bls && !c->bls_ready) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_alignments_6frames_bls: call pcsf_set_bls_branch_lengths first");
+    return six_frames_impl(c, nucleotides, row_stride, alns, n_alns, out_scores, out_capacity, out_offsets, n_codons, skip_bases, out_bls, nullptr);
+}
+
+// The six-frame call that keeps its results on the device and formats the wig text there (wig.hip): out_bytes[f] = bytes of file f's
+// text of this call (0: PhyloCSFpower.wig, 1..6: PhyloCSFRaw+1 .. PhyloCSFRaw-3); pcsf_fetch_wig_text copies them out.
+int pcsf_score_alignments_6frames_wig(pcsf_ctx* c, const char* nucleotides, size_t row_stride, const pcsf_alignment_desc* alns, size_t n_alns,
+                                      const char* const* chrom_names, float power_threshold, int want_power, int want_raw, uint64_t* out_bytes,
+                                      size_t* n_codon_frames)
+{
+    if (!c) return PCSF_ERR_INVALID_ARG;
+    if (!out_bytes) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_alignments_6frames_wig: null argument");
+    for (int f = 0; f < 7; ++f) out_bytes[f] = 0;
+    if (n_codon_frames) *n_codon_frames = 0;
+    c->wig.ready = false;
+    if (n_alns == 0) return PCSF_OK;
+    if (!nucleotides || !alns || !chrom_names) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_alignments_6frames_wig: null argument");
+    if (!c->bls_ready) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_alignments_6frames_wig: call pcsf_set_bls_branch_lengths first");
+    const WigRequest req{chrom_names, power_threshold, want_power != 0, want_raw != 0, out_bytes, n_codon_frames};
+    std::vector<uint64_t> offsets(n_alns * 6);
+    std::vector<uint32_t> counts(n_alns * 6);
+    return six_frames_impl(c, nucleotides, row_stride, alns, n_alns, nullptr, ~size_t(0), offsets.data(), counts.data(), nullptr, nullptr, &req);
+}
+
+int pcsf_fetch_wig_text(pcsf_ctx* c, char* const* dst)
+{
+    if (!c) return PCSF_ERR_INVALID_ARG;
+    if (!dst) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_fetch_wig_text: null argument");
+    if (!c->wig.ready) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_fetch_wig_text: no text (call pcsf_score_alignments_6frames_wig first)");
+    hipError_t e;
+    if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
+    for (int f = 0; f < 7; ++f) {
+        const uint64_t n = c->wig.file_off[f + 1] - c->wig.file_off[f];
+        if (!n) continue;
+        if (!dst[f]) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_fetch_wig_text: null destination for a file with text");
+        if ((e = hipMemcpyAsync(dst[f], c->wig.text.as<char>() + c->wig.file_off[f], n, hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
+            return c->hip_fail(e, "hipMemcpyAsync(wig text)");
+    }
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return c->hip_fail(e, "hipStreamSynchronize");
+    c->wig.ready = false;
+    return PCSF_OK;
+}
+
+static int six_frames_impl(pcsf_ctx* c, const char* nucleotides, size_t row_stride, const pcsf_alignment_desc* alns, size_t n_alns,
+                           double* out_scores, size_t out_capacity, uint64_t* out_offsets, uint32_t* n_codons, uint32_t* skip_bases,
+                           double* out_bls, const WigRequest* wig)
+{
     std::vector<pcsf::FrameSegment> seg;
     std::vector<pcsf::BlsSpan> spans;  // like seg: source of an asynchronous copy, alive until the stream is synchronised
     seg.reserve(n_alns * 6);
@@ -616,7 +695,7 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
         const pcsf_alignment_desc& a = alns[k];
         if (a.col_offset + a.len > row_stride) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_alignments_6frames: alignment exceeds row_stride");
         max_col = std::max<uint64_t>(max_col, a.col_offset + a.len);
-        if (out_bls && a.len) spans.push_back(pcsf::BlsSpan{a.col_offset, a.len});
+        if ((out_bls || wig) && a.len) spans.push_back(pcsf::BlsSpan{a.col_offset, a.len});
         for (int f = 0; f < 6; ++f) {
             const pcsf::FrameView v = pcsf::frame_view(a.start_pos, a.chrom_len, a.len, f < 3 ? '+' : '-', static_cast<unsigned>(f % 3 + 1));
             pcsf::FrameSegment s{};
@@ -637,9 +716,14 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
     if (total > out_capacity) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_alignments_6frames: out_capacity too small");
     hipError_t e;
     if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
-    if (total == 0) {  // alignments shorter than a codon still have branch-length scores
+    if (total == 0 && !wig) {  // alignments shorter than a codon still have branch-length scores
         if (!out_bls || max_col == 0) return PCSF_OK;
         return pcsf::bls_columns(c, nucleotides, row_stride, max_col, spans, out_bls);
+    }
+    if (wig && max_col == 0) {   // nothing but empty alignments: seven empty texts
+        for (uint64_t& v : c->wig.file_off) v = 0;
+        c->wig.ready = true;
+        return PCSF_OK;
     }
     // One stream, in order: rows up, branch-length kernel, frame extraction, pruning, then ALL downloads (a download
     // between two kernels idles the compute queue while the copy engine works).  Splitting the call into chunks on
@@ -651,7 +735,7 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
     // the separate extract_frames_kernel (A/B measurements; results are identical).
     const bool fused = c->fused_frontend;
     std::vector<uint32_t> wg_first_seg;
-    if (fused) {  // segment that holds site 64 b, for every work-group b
+    if (fused && total) {  // segment that holds site 64 b, for every work-group b
         wg_first_seg.resize((total + 63) / 64);
         size_t k = 0;
         for (size_t b = 0; b < wg_first_seg.size(); ++b) {
@@ -660,15 +744,15 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
         }
     }
     if ((e = c->d_nucl.reserve(nl * max_col)) != hipSuccess) return c->hip_fail(e, "hipMalloc(nucleotides)");
-    if ((e = c->d_segments.reserve(seg.size() * sizeof(pcsf::FrameSegment))) != hipSuccess) return c->hip_fail(e, "hipMalloc(segments)");
+    if ((e = c->d_segments.reserve(std::max<size_t>(seg.size(), 1) * sizeof(pcsf::FrameSegment))) != hipSuccess) return c->hip_fail(e, "hipMalloc(segments)");
     if ((!fused || c->dump_codons) && (e = c->d_codons.reserve(nl * total)) != hipSuccess) return c->hip_fail(e, "hipMalloc(codons)");
     c->last_total_sites = total;
-    if (fused && (e = c->d_wg_seg.reserve(wg_first_seg.size() * sizeof(uint32_t))) != hipSuccess) return c->hip_fail(e, "hipMalloc(work-group segments)");
-    if ((e = c->d_out.reserve(total * sizeof(double))) != hipSuccess) return c->hip_fail(e, "hipMalloc(out)");
+    if (fused && (e = c->d_wg_seg.reserve(std::max<size_t>(wg_first_seg.size(), 1) * sizeof(uint32_t))) != hipSuccess) return c->hip_fail(e, "hipMalloc(work-group segments)");
+    if ((e = c->d_out.reserve(std::max<uint64_t>(total, 1) * sizeof(double))) != hipSuccess) return c->hip_fail(e, "hipMalloc(out)");
     if ((e = pcsf::upload_rows(c->d_nucl.ptr, nucleotides, row_stride, max_col, nl, c->stream)) != hipSuccess) return c->hip_fail(e, "upload(nucleotides)");
-    if ((e = hipMemcpyAsync(c->d_segments.ptr, seg.data(), seg.size() * sizeof(pcsf::FrameSegment), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
+    if (!seg.empty() && (e = hipMemcpyAsync(c->d_segments.ptr, seg.data(), seg.size() * sizeof(pcsf::FrameSegment), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
         return c->hip_fail(e, "hipMemcpyAsync(segments)");
-    if (fused && (e = hipMemcpyAsync(c->d_wg_seg.ptr, wg_first_seg.data(), wg_first_seg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
+    if (fused && !wg_first_seg.empty() && (e = hipMemcpyAsync(c->d_wg_seg.ptr, wg_first_seg.data(), wg_first_seg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
         return c->hip_fail(e, "hipMemcpyAsync(work-group segments)");
     int rc;
     KernelTurn& turn = g_kernel_turn[c->device & 63];
@@ -677,7 +761,7 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
     // the power track's per-base scores from the same resident rows (that kernel also checks every character); without
     // them the translation does the character check itself, so that both entry points reject the same input
     unsigned long long* d_char_flag = nullptr;
-    if (out_bls) {
+    if (out_bls || wig) {
         if ((rc = pcsf::bls_enqueue(c, c->d_nucl.as<unsigned char>(), max_col, max_col, spans)) != PCSF_OK) return rc;
     } else {
         if ((e = c->d_bls_flag.reserve(sizeof(unsigned long long))) != hipSuccess) return c->hip_fail(e, "hipMalloc(character flag)");
@@ -686,7 +770,9 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
         if ((e = hipMemsetAsync(c->d_bls_flag.ptr, 0xff, sizeof(unsigned long long), c->stream)) != hipSuccess) return c->hip_fail(e, "hipMemsetAsync(character flag)");
         d_char_flag = c->d_bls_flag.as<unsigned long long>();
     }
-    if (fused) {
+    if (total == 0) {
+        // (wig request on alignments shorter than a codon: only the power track has text)
+    } else if (fused) {
         pcsf::FusedFrontEnd fe{c->d_nucl.as<unsigned char>(), max_col, c->d_segments.as<pcsf::FrameSegment>(), c->d_wg_seg.as<uint32_t>(), d_char_flag,
                                c->dump_codons ? c->d_codons.as<unsigned char>() : nullptr};
         if ((rc = pcsf::launch_fixed(c, nullptr, total, total, c->d_out.as<double>(), nullptr, nullptr, c->stream, &fe)) != PCSF_OK) return rc;
@@ -700,20 +786,120 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
         }
         if ((rc = pcsf::launch_fixed(c, c->d_codons.as<uint8_t>(), total, total, c->d_out.as<double>(), nullptr, nullptr, c->stream)) != PCSF_OK) return rc;
     }
+    // ---- wig text on the device: the line candidates of the seven files, their lengths and byte offsets (inside this call's turn on the
+    // device), then -- once the sizes are known -- the text itself
+    pcsf::WigParams wp{};
+    std::vector<pcsf::WigFrame> frames;     // sources of asynchronous copies: alive until the stream is synchronised below
+    std::vector<char> chroms;
+    if (wig) {
+        std::vector<uint32_t> chrom0(n_alns), chrom_len(n_alns);
+        for (size_t k = 0; k < n_alns; ++k) {
+            const char* name = wig->chrom_names[k] ? wig->chrom_names[k] : "";
+            chrom0[k] = static_cast<uint32_t>(chroms.size());
+            chrom_len[k] = static_cast<uint32_t>(strlen(name));
+            chroms.insert(chroms.end(), name, name + chrom_len[k]);
+        }
+        uint64_t elems = 0;
+        for (int file = 0; file < 7; ++file) {
+            wp.file_frame0[file] = static_cast<uint32_t>(frames.size());
+            wp.file_elem0[file] = elems;
+            if (file == 0 ? !wig->want_power : !wig->want_raw) continue;
+            for (size_t k = 0; k < n_alns; ++k) {
+                const pcsf_alignment_desc& a = alns[k];
+                pcsf::WigFrame fr{};
+                fr.elem0 = elems;
+                fr.chrom0 = chrom0[k];
+                fr.chrom_len = chrom_len[k];
+                if (file == 0) {   // src/phylocsf++build_tracks.hpp:139-156: frame 3 of the + strand, no filter
+                    int64_t skip = static_cast<int64_t>(3 - static_cast<int64_t>(a.start_pos)) % 3;
+                    if (skip < 0) skip += 3;
+                    fr.n = a.len > static_cast<uint64_t>(skip) + 2 ? static_cast<uint32_t>((a.len - static_cast<uint64_t>(skip)) / 3) : 0u;
+                    fr.bls0 = a.col_offset + static_cast<uint64_t>(skip);
+                    fr.start_pos = static_cast<int64_t>(a.start_pos) + skip;
+                } else {
+                    const int fi = file - 1;
+                    const pcsf::FrameView v = pcsf::frame_view(a.start_pos, a.chrom_len, a.len, fi < 3 ? '+' : '-', static_cast<unsigned>(fi % 3 + 1));
+                    fr.n = static_cast<uint32_t>(v.n_codons);
+                    fr.score0 = out_offsets[k * 6 + fi];
+                    fr.bls0 = a.col_offset + v.bls_offset;
+                    fr.start_pos = static_cast<int64_t>(v.start_pos);
+                }
+                if (fr.n == 0) continue;
+                elems += fr.n;
+                frames.push_back(fr);
+            }
+        }
+        wp.file_frame0[7] = static_cast<uint32_t>(frames.size());
+        wp.file_elem0[7] = elems;
+        wp.n_elems = elems;
+        {   // byte offsets are 32-bit: a call whose text could pass 4 GB (far beyond build-tracks' batches) is the host's
+            uint32_t longest_name = 0;
+            for (uint32_t v : chrom_len) longest_name = std::max(longest_name, v);
+            if (elems >= 0xffffffffull / (static_cast<uint64_t>(longest_name) + 96))
+                return c->fail(PCSF_ERR_UNSUPPORTED, "pcsf_score_alignments_6frames_wig: too many lines in one call -- format this batch on the host");
+        }
+        pcsf_ctx::WigBuffers& W = c->wig;
+        const size_t temp_bytes = pcsf::wig_scan_temp_bytes(elems);
+        if (!W.h_bounds && (e = hipHostMalloc(reinterpret_cast<void**>(&W.h_bounds), 16 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
+            return c->hip_fail(e, "hipHostMalloc(wig bounds)");
+        if ((e = W.frames.reserve(std::max<size_t>(frames.size(), 1) * sizeof(pcsf::WigFrame))) != hipSuccess || (e = W.chroms.reserve(std::max<size_t>(chroms.size(), 1))) != hipSuccess ||
+            (e = W.lens.reserve((elems + 1) * sizeof(uint32_t))) != hipSuccess || (e = W.offsets.reserve((elems + 1) * sizeof(uint32_t))) != hipSuccess ||
+            (e = W.temp.reserve(std::max<size_t>(temp_bytes, 16))) != hipSuccess || (e = W.flag.reserve(sizeof(uint32_t))) != hipSuccess)
+            return c->hip_fail(e, "hipMalloc(wig)");
+        if (!frames.empty() && (e = hipMemcpyAsync(W.frames.ptr, frames.data(), frames.size() * sizeof(pcsf::WigFrame), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
+            return c->hip_fail(e, "hipMemcpyAsync(wig frames)");
+        if (!chroms.empty() && (e = hipMemcpyAsync(W.chroms.ptr, chroms.data(), chroms.size(), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
+            return c->hip_fail(e, "hipMemcpyAsync(wig chromosome names)");
+        if ((e = hipMemsetAsync(W.flag.ptr, 0, sizeof(uint32_t), c->stream)) != hipSuccess) return c->hip_fail(e, "hipMemsetAsync(wig flag)");
+        wp.frames = W.frames.as<pcsf::WigFrame>();
+        wp.scores = c->d_out.as<double>();
+        wp.bls = c->d_bls_out.as<double>();
+        wp.chroms = W.chroms.as<char>();
+        wp.threshold3 = wig->power_threshold * 3;
+        wp.lens = W.lens.as<uint32_t>();
+        wp.offsets = W.offsets.as<uint32_t>();
+        wp.needs_host = W.flag.as<uint32_t>();
+        if ((e = pcsf::launch_wig_lengths(wp, W.temp.ptr, temp_bytes, c->stream)) != hipSuccess) return c->hip_fail(e, "launch wig lengths");
+    }
     if ((e = hipEventRecord(c->ev_kernels, c->stream)) != hipSuccess) return c->hip_fail(e, "hipEventRecord");
     turn.last = c->ev_kernels;
     turn.owner = c;
     my_turn.unlock();
-    if ((e = hipMemcpyAsync(out_scores, c->d_out.ptr, total * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
+    if (!wig && (e = hipMemcpyAsync(out_scores, c->d_out.ptr, total * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
         return c->hip_fail(e, "hipMemcpyAsync(out)");
     if (out_bls && (rc = pcsf::bls_download(c, max_col, out_bls)) != PCSF_OK) return rc;
+    if (wig) {   // the character check of bls_kernel, the byte offsets of the eight file boundaries, the needs-host flag
+        pcsf_ctx::WigBuffers& W = c->wig;
+        *c->bls_first_bad = pcsf::BLS_NO_BAD;
+        if ((e = hipMemcpyAsync(c->bls_first_bad, c->d_bls_flag.ptr, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
+            return c->hip_fail(e, "hipMemcpyAsync(bls flag)");
+        for (int f = 0; f < 8; ++f) {
+            W.h_bounds[f] = 0;
+            if (wp.n_elems && (e = hipMemcpyAsync(W.h_bounds + f, wp.offsets + wp.file_elem0[f], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
+                return c->hip_fail(e, "hipMemcpyAsync(wig bounds)");
+        }
+        if ((e = hipMemcpyAsync(W.h_bounds + 8, W.flag.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return c->hip_fail(e, "hipMemcpyAsync(wig flag)");
+    }
     if (d_char_flag) {
         *c->bls_first_bad = pcsf::BLS_NO_BAD;
         if ((e = hipMemcpyAsync(c->bls_first_bad, d_char_flag, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
             return c->hip_fail(e, "hipMemcpyAsync(character flag)");
     }
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return c->hip_fail(e, "hipStreamSynchronize");
-    return pcsf::bls_check(c, nucleotides, row_stride, max_col);
+    if ((rc = pcsf::bls_check(c, nucleotides, row_stride, max_col)) != PCSF_OK) return rc;
+    if (wig) {
+        pcsf_ctx::WigBuffers& W = c->wig;
+        if (W.h_bounds[8]) return c->fail(PCSF_ERR_UNSUPPORTED, "pcsf_score_alignments_6frames_wig: a value of 9e14 or more -- format this batch on the host");
+        for (int f = 0; f < 8; ++f) W.file_off[f] = W.h_bounds[f];
+        const uint64_t bytes = W.file_off[7];
+        if ((e = W.text.reserve(std::max<uint64_t>(bytes, 1))) != hipSuccess) return c->hip_fail(e, "hipMalloc(wig text)");
+        wp.text = W.text.as<char>();
+        if ((e = pcsf::launch_wig_write(wp, c->stream)) != hipSuccess) return c->hip_fail(e, "launch wig write");
+        for (int f = 0; f < 7; ++f) wig->out_bytes[f] = W.file_off[f + 1] - W.file_off[f];
+        if (wig->n_codon_frames) *wig->n_codon_frames = total;
+        W.ready = true;
+    }
+    return PCSF_OK;
 }
 
 // Gets the context ready for six-frame calls of up to max_columns alignment columns: device scratch reserved, and one

@@ -173,6 +173,13 @@ struct pcsf_ctx {
     struct HmmBuffers {
         pcsf::DeviceBuffer emit, fwd, back, post, chunks, entry, exit_state, same, todo, thresholds, bins, exc_index, exc_value, exc_count;
     } hmm;
+    // pcsf_score_alignments_6frames_wig: the text of the call's seven files stays on the device until pcsf_fetch_wig_text
+    struct WigBuffers {
+        pcsf::DeviceBuffer frames, chroms, lens, offsets, temp, text, flag;
+        uint32_t* h_bounds = nullptr;      // page-locked: byte offsets of the eight file boundaries, then the needs-host flag
+        uint64_t file_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bool ready = false;
+    } wig;
     pcsf::BlsTree bls_tree{};
     bool bls_ready = false;
     unsigned long long* bls_first_bad = nullptr;  // page-locked host copy of the kernel's character check
@@ -194,6 +201,7 @@ struct pcsf_ctx {
     ~pcsf_ctx()
     {
         if (bls_first_bad) (void)hipHostFree(bls_first_bad);
+        if (wig.h_bounds) (void)hipHostFree(wig.h_bounds);
         if (ev_kernels) (void)hipEventDestroy(ev_kernels);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);

@@ -322,3 +322,38 @@ hipError_t launch_bls(const BlsTree& tree, const BlsSpan* d_spans, uint32_t n_sp
                       size_t row_stride, double* d_out, unsigned long long* d_first_bad, hipStream_t stream);
 
 }  // namespace pcsf
+
+namespace pcsf {
+
+// ---- wig text on the device (wig.hip) ---------------------------------------------------------------------------------------------
+// One record per (file, alignment): n line candidates -- the codons of a frame in forward genome order, or the codons of the power
+// track -- whose scores start at scores[score0] (frames) and whose per-base branch-length scores start at bls[bls0] (three per candidate).
+struct WigFrame {
+    uint64_t elem0;       // index of the record's first candidate among all candidates of the call (files in order 0..6, alignments in order)
+    uint64_t score0;
+    uint64_t bls0;
+    int64_t start_pos;    // genome position (1-based) of the first candidate's line
+    uint32_t chrom0, chrom_len;   // the alignment's chromosome name in `chroms`
+    uint32_t n;
+    uint32_t pad;
+};
+struct WigParams {
+    const WigFrame* frames;       // file 0 (power track), then files 1..6 (PhyloCSFRaw+1 .. -3)
+    uint32_t file_frame0[8];      // records of file f: [file_frame0[f], file_frame0[f + 1])
+    uint64_t file_elem0[8];       // candidates of file f: [file_elem0[f], file_elem0[f + 1])
+    uint64_t n_elems;
+    const double* scores;
+    const double* bls;
+    const char* chroms;
+    float threshold3;             // 3 x --power-threshold: a codon whose three per-base scores sum to less is not written
+    uint32_t* lens;               // [n_elems + 1]
+    uint32_t* offsets;            // [n_elems + 1] exclusive prefix sums of lens: byte offset of every candidate's text
+    char* text;
+    uint32_t* needs_host;         // set when a finite |value| >= 9e14 turns up (format_trimmed's snprintf path: the caller formats on the host)
+};
+size_t wig_scan_temp_bytes(uint64_t n_elems);
+hipError_t launch_wig_lengths(const WigParams& p, void* d_temp, size_t temp_bytes, hipStream_t stream);
+hipError_t launch_wig_write(const WigParams& p, hipStream_t stream);
+hipError_t launch_wig_format_debug(const float* v, uint32_t n, int decimals, char* text, uint32_t* lens, hipStream_t stream);
+
+}  // namespace pcsf

@@ -92,6 +92,27 @@ public:
         return total;
     }
 
+    // PCSF_DEVICE_WIG=0: the host formats the tracks (the A/B switch of tests/test_gpu_cli.py and tools/config4_one_gpu.sh)
+    bool device_wig() const override
+    {
+        const char* v = std::getenv("PCSF_DEVICE_WIG");
+        return device_bls_ && !(v && v[0] == '0');
+    }
+    bool score_alignments_6frames_wig(const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0, const std::vector<uint32_t>& len,
+                                      const std::vector<uint64_t>& start_pos, const std::vector<uint64_t>& chrom_len, const std::vector<const char*>& chroms,
+                                      float power_threshold, bool want_power, bool want_raw, uint64_t* bytes, size_t* n_codon_frames) override
+    {
+        const size_t n = col0.size();
+        std::vector<pcsf_alignment_desc> d(n);
+        for (size_t k = 0; k < n; ++k) d[k] = pcsf_alignment_desc{col0[k], len[k], start_pos[k], chrom_len[k]};
+        const int rc = pcsf_score_alignments_6frames_wig(ctx_, nucl, row_stride, d.data(), n, chroms.data(), power_threshold, want_power ? 1 : 0, want_raw ? 1 : 0,
+                                                         bytes, n_codon_frames);
+        if (rc == PCSF_ERR_UNSUPPORTED) return false;
+        check(rc);
+        return true;
+    }
+    void fetch_wig_text(char* const* dst) override { check(pcsf_fetch_wig_text(ctx_, dst)); }
+
     char* staging_alloc(size_t bytes) override
     {
         // on this context's GPU (no primary context on device 0 for a run on another device); never zero bytes

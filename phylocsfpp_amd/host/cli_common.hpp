@@ -346,13 +346,13 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend, b
             const int d = devices[k];
             if (k == 0) owned.push_back(make_backend(model, d));   // owns the staging memory: needed at once
             else owned.push_back(std::unique_ptr<ScoringBackend>(new DeferredBackend([&model, &make_backend, d] { return make_backend(model, d); },
-                                                                                     owned[0]->device_bls(), owned[0]->contexts_per_device())));
+                                                                                     owned[0]->device_bls(), owned[0]->contexts_per_device(), owned[0]->device_wig())));
             backends.push_back(owned.back().get());
             const int wanted = contexts_per_device > 0 ? contexts_per_device : (input_total >= (uint64_t(3) << 28) ? owned[0]->contexts_per_device() : 1);
             const int per = cmd == "build-tracks" ? wanted : 1;
             for (int c = 1; c < per; ++c) {
                 owned.push_back(std::unique_ptr<ScoringBackend>(new DeferredBackend([&model, &make_backend, d] { return make_backend(model, d); },
-                                                                                     owned[0]->device_bls(), owned[0]->contexts_per_device())));
+                                                                                     owned[0]->device_bls(), owned[0]->contexts_per_device(), owned[0]->device_wig())));
                 backends.push_back(owned.back().get());
             }
         }

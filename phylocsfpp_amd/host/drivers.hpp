@@ -99,6 +99,18 @@ struct ScoringBackend {
     {
         throw std::runtime_error("hmm_smooth_runs_binned: this backend does not smooth tracks");
     }
+    // true when the backend can hand back the TEXT of a batch's seven wig files instead of its scores and per-base branch-length scores
+    // (formatted where the scores are: build-tracks then only copies the text down and appends it to the files)
+    virtual bool device_wig() const { return false; }
+    // The batch of score_alignments_6frames, scored and formatted: bytes[7] = the text per file (0: PhyloCSFpower.wig, 1..6: the frames);
+    // chroms[k]: alignment k's chromosome name.  false: a value came up that the backend does not print -- score and format this batch the
+    // usual way.  The text stays with the backend until fetch_wig_text copies it (or the next call replaces it).
+    virtual bool score_alignments_6frames_wig(const char*, size_t, const std::vector<uint64_t>&, const std::vector<uint32_t>&, const std::vector<uint64_t>&,
+                                              const std::vector<uint64_t>&, const std::vector<const char*>&, float, bool, bool, uint64_t*, size_t*)
+    {
+        throw std::runtime_error("score_alignments_6frames_wig: this backend does not format tracks");
+    }
+    virtual void fetch_wig_text(char* const*) { throw std::runtime_error("fetch_wig_text: this backend does not format tracks"); }
     virtual size_t score_alignments_6frames(int n_leaves, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0,
                                             const std::vector<uint32_t>& len, const std::vector<uint64_t>& start_pos,
                                             const std::vector<uint64_t>& chrom_len, double* out, size_t out_capacity, std::vector<uint64_t>& offsets,
@@ -139,8 +151,8 @@ struct ScoringBackend {
 // short run should not wait for): calls block until it exists, ready() tells the dealer not to wait.
 class DeferredBackend : public ScoringBackend {
 public:
-    DeferredBackend(std::function<std::unique_ptr<ScoringBackend>()> make, bool device_bls, int contexts_per_device)
-        : made_(std::async(std::launch::async, std::move(make)).share()), device_bls_(device_bls), contexts_(contexts_per_device) {}
+    DeferredBackend(std::function<std::unique_ptr<ScoringBackend>()> make, bool device_bls, int contexts_per_device, bool device_wig = false)
+        : made_(std::async(std::launch::async, std::move(make)).share()), device_bls_(device_bls), device_wig_(device_wig), contexts_(contexts_per_device) {}
     ~DeferredBackend() override
     {
         try {
@@ -190,10 +202,20 @@ public:
         return get().score_alignments_6frames(n_leaves, nucl, row_stride, col0, len, start_pos, chrom_len, out, out_capacity, offsets, n_codons, bls_out);
     }
 
+    bool device_wig() const override { return device_wig_; }   // like device_bls: what the first backend answered
+    bool score_alignments_6frames_wig(const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0, const std::vector<uint32_t>& len,
+                                      const std::vector<uint64_t>& start_pos, const std::vector<uint64_t>& chrom_len, const std::vector<const char*>& chroms,
+                                      float power_threshold, bool want_power, bool want_raw, uint64_t* bytes, size_t* n_codon_frames) override
+    {
+        return get().score_alignments_6frames_wig(nucl, row_stride, col0, len, start_pos, chrom_len, chroms, power_threshold, want_power, want_raw, bytes, n_codon_frames);
+    }
+    void fetch_wig_text(char* const* dst) override { get().fetch_wig_text(dst); }
+
 private:
     ScoringBackend& get() const { return *made_.get(); }   // rethrows what the construction threw
     std::shared_future<std::unique_ptr<ScoringBackend>> made_;
     bool device_bls_;
+    bool device_wig_;
     int contexts_;
 };
 
@@ -846,6 +868,9 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     // the branch-length scores come from the backend (same uploaded rows as the six frames) when every backend offers that
     bool dev_bls = need_raw && !prm.host_bls;
     for (const ScoringBackend* b : backends) dev_bls = dev_bls && b->device_bls();
+    // ... and so does the text of the seven files: stage 3 then only appends what stage 2 copied down
+    bool dev_wig = dev_bls;
+    for (const ScoringBackend* b : backends) dev_wig = dev_wig && b->device_wig();
     StopWatch total, sw;
 
     // Stage 3 formats a batch's text in PIECES on all host threads -- (file, alignment, range of codons) -- and then appends each file's
@@ -955,7 +980,7 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             std::lock_guard<std::mutex> g(lock);
             free_list.push_back(f);
         }
-    } pool(backend), score_pool(backend);  // batch matrices; score vectors (different sizes: kept apart)
+    } pool(backend), score_pool(backend), text_pool(backend);  // batch matrices; score vectors; wig text (different sizes: kept apart)
     struct Batch {  // alignments scored by one backend call, their nucleotides packed leaf-major
         std::vector<Item*> items;
         size_t stride = 0;
@@ -967,6 +992,9 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         size_t n_scores = 0;
         std::vector<uint64_t> offsets;
         std::vector<uint32_t> n_codons;
+        std::pair<char*, size_t> text_mem{nullptr, 0};  // the backend formatted the batch: the seven files' text back to back, page-locked
+        uint64_t text_bytes[7] = {0, 0, 0, 0, 0, 0, 0};
+        bool has_text = false;
     };
     struct PreparedWindow {
         std::vector<std::vector<Item>> jobs;
@@ -1083,6 +1111,18 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         writing = f;
         writer = std::async(std::launch::async, [&, batch = f.bt]() {
             StopWatch ww;
+            if (batch->has_text) {   // formatted by the backend: the files side by side
+                uint64_t at[8] = {0};
+                for (int t = 0; t < 7; ++t) at[t + 1] = at[t] + batch->text_bytes[t];
+                parallel_for(7, threads, [&](size_t t) {
+                    FILE* f = t == 0 ? f_power : f_raw[t - 1];
+                    const size_t n = static_cast<size_t>(batch->text_bytes[t]);
+                    if (f && n && fwrite(batch->text_mem.first + at[t], 1, n, f) != n) throw std::runtime_error("write failed");
+                });
+                text_pool.put(batch->text_mem);
+                batch->text_mem = {nullptr, 0};
+                return ww.lap();
+            }
             const std::vector<PieceJob> jobs = batch_pieces(batch->items, batch->scores, batch->offsets);
             if (text.size() < jobs.size()) text.resize(jobs.size());   // one writer runs at a time; the buffers keep their memory
             parallel_for(jobs.size(), threads, [&](size_t i) { format_piece(jobs[i], text[i]); });
@@ -1115,6 +1155,24 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         std::shared_future<double> task = std::async(std::launch::async, [&, b = &bt, d, prev]() -> double {
             if (prev.valid()) prev.wait();
             StopWatch bw;
+            if (need_raw && dev_wig) {
+                std::vector<const char*> chroms(b->items.size());
+                for (size_t k = 0; k < chroms.size(); ++k) chroms[k] = b->items[k]->chrom.c_str();
+                b->has_text = backends[d]->score_alignments_6frames_wig(b->nucl.first, b->stride, b->col0, b->len, b->start_pos, b->chrom_len, chroms,
+                                                                        prm.power_threshold, f_power != nullptr, true, b->text_bytes, &b->n_scores);
+                if (b->has_text) {
+                    uint64_t total = 0;
+                    for (uint64_t v : b->text_bytes) total += v;
+                    b->text_mem = text_pool.get(static_cast<size_t>(total));
+                    char* dst[7];
+                    dst[0] = b->text_mem.first;
+                    for (int t = 1; t < 7; ++t) dst[t] = dst[t - 1] + b->text_bytes[t - 1];
+                    backends[d]->fetch_wig_text(dst);
+                    pool.put(b->nucl);
+                    b->nucl = {nullptr, 0};
+                    return bw.lap();
+                }
+            }
             if (need_raw) {
                 const size_t cap_scores = 2 * b->stride;  // six frames of len/3 codons each
                 // one page-locked buffer: the scores, then (device branch-length scores) one value per column

@@ -27,8 +27,13 @@ ls -l $work/c4.pcsfbin >> $out/pack.txt
 for rep in 1 2; do
   $cli build-tracks --output $work/out_packed $model $work/c4.pcsfbin 2> $out/packed_run$rep.txt
 done
-same=yes
-for f in $work/out_text/*.wig; do cmp -s $f $work/out_packed/$(basename $f) || same=no; done
-{ echo "text and packed runs wrote identical files: $same"; ls -l $work/out_text; } > $out/outputs.txt
-cat $out/text_run2.txt $out/pack.txt $out/packed_run2.txt $out/outputs.txt
+# A/B: the seven files' text formatted by the host (round 3's stage 3) instead of on the device (csrc/wig.hip)
+PCSF_DEVICE_WIG=0 $cli build-tracks --output $work/out_hostwig $model $work/c4.pcsfbin 2> $out/packed_hostwig_run.txt
+same=yes; same_wig=yes
+for f in $work/out_text/*.wig; do
+  cmp -s $f $work/out_packed/$(basename $f) || same=no
+  cmp -s $f $work/out_hostwig/$(basename $f) || same_wig=no
+done
+{ echo "text and packed runs wrote identical files: $same"; echo "device-formatted and host-formatted text identical: $same_wig"; ls -l $work/out_text; } > $out/outputs.txt
+cat $out/text_run2.txt $out/pack.txt $out/packed_run2.txt $out/packed_hostwig_run.txt $out/outputs.txt
 rm -rf $work

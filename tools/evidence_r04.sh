@@ -30,6 +30,7 @@ step startup bash -c "bash tools/startup_profile.sh > $O/startup_profile.txt 2>&
 step startup-teardown bash -c "PCSF_FULL_TEARDOWN=1 bash tools/startup_profile.sh 2>&1 | grep -A6 'five runs' > $O/startup_profile_full_teardown.txt"
 # ---- BASELINE.json configs[3] on one GPU (100 Mb, text and packed) and configs[4] at 20 Mb
 step config4 bash -c "bash tools/config4_one_gpu.sh tmp_c4 100 > /dev/null 2>&1; mkdir -p $O/config4; cp gpurun_out/tmp_c4/config4/* $O/config4/; rm -rf gpurun_out/tmp_c4"
+step wig_profile bash -c "bash tools/r04_wig_profile.sh tmp_wig > /dev/null 2>&1; mkdir -p $O/wig_profile; cp gpurun_out/tmp_wig/wig_profile/{kernel_stats.csv,run_wig0.txt,run_wig1.txt} $O/wig_profile/; rm -rf gpurun_out/tmp_wig"
 step config5 bash -c "bash tools/config5_one_gpu.sh $O/c5 20 > /dev/null 2>&1; cp $O/c5/config5.txt $O/config5_one_gpu.txt; rm -rf $O/c5"
 cat "$O/steps.log"
 ls -la "$O"
