@@ -297,6 +297,15 @@ def end_to_end_multi(n_gpus, work_dir):
                       "seconds_all_runs": [r["seconds"] for r in runs], "process_wall_seconds": min(r["process_wall_seconds"] for r in runs),
                       "codon_frames_per_s": b["codon_frames"] / b["seconds"], "backend_calls": b["backend_calls"], "stage_busy": b["stage_busy"]}
     out["speedup_vs_one_device"] = out["all_devices"]["codon_frames_per_s"] / out["one_device"]["codon_frames_per_s"]
+    # what the host side alone allows: stage 1 (parse + branch-length scores + packing, one window ahead of the scoring, all host
+    # threads) and stage 3 (the writers) each run for this long whatever the number of GPUs; the scoring backends share theirs
+    a = out["all_devices"]
+    sb = a["stage_busy"]
+    stage1 = sb["maf_read"] + sb["bls"] + sb["batch_packing"]
+    out["host_ceiling"] = {"stage1_parse_and_pack_seconds": stage1, "stage3_writers_seconds": sb["wig_output"],
+                           "scoring_backends_seconds_per_device": sb["scoring_backend"] / n_gpus,
+                           "codon_frames_per_s": a["codon_frames"] / max(stage1, sb["wig_output"], 1e-9), "host_threads": effective_cpus(),
+                           "reading": "the run cannot be faster than its slowest stage: min(this ceiling, n_gpus x the one-device rate) bounds all_devices"}
     try:
         out["wig_lines_differing_between_the_two"] = differing_lines(os.path.join(work_dir, "gpu_multi_all_devices"), os.path.join(work_dir, "gpu_multi_one_device"))
     except Exception as ex:

@@ -164,13 +164,20 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx *ctx, const char *nucleotides, si
  * alignment) and :183-217 (PhyloCSFRaw+1..-3: a codon whose three per-base scores sum to less than 3 x power_threshold is left out,
  * :201-205; a "fixedStep chrom=... start=... step=3 span=3" line wherever a run of written codons starts, :207-210; "%.3f" trimmed,
  * src/common.hpp:48-68).  chrom_names[n_alignments]: the alignments' chromosome names.  out_bytes[7]: bytes of text per file of THIS
- * call (0: power track, 1..6: the frames in the order +1 +2 +3 -1 -2 -3); want_power / want_raw = 0 leaves the file(s) empty.  The text
- * is what the host formatter writes, byte for byte (tests/test_gpu_cli.py).  PCSF_ERR_UNSUPPORTED: a finite |value| >= 9e14 turned up
- * (never a score): format this batch from pcsf_score_alignments_6frames_bls instead.  Needs pcsf_set_bls_branch_lengths. */
+ * call (0: power track, 1..6: the frames in the order +1 +2 +3 -1 -2 -3); want_power / want_raw = 0 leaves the file(s) empty.
+ * text[text_capacity] (may be NULL / 0): receives the seven files' text back to back -- file f at offset out_bytes[0] + .. +
+ * out_bytes[f - 1] -- IF the sum of out_bytes is at most text_capacity; the copy is queued behind the kernels before the sizes are
+ * known, so give it pcsf_wig_text_estimate() bytes of page-locked memory (pcsf_host_alloc_on).  A caller whose buffer was too small
+ * (or who passed none) fetches the text with pcsf_fetch_wig_text.  The text is what the host formatter writes, byte for byte
+ * (tests/test_gpu_wig.py, tests/test_gpu_cli.py).  PCSF_ERR_UNSUPPORTED: a finite |value| >= 9e14 turned up (never a score): format
+ * this batch from pcsf_score_alignments_6frames_bls instead.  Needs pcsf_set_bls_branch_lengths. */
 int pcsf_score_alignments_6frames_wig(pcsf_ctx *ctx, const char *nucleotides, size_t row_stride,
                                       const pcsf_alignment_desc *alignments, size_t n_alignments, const char *const *chrom_names,
-                                      float power_threshold, int want_power, int want_raw, uint64_t *out_bytes,
-                                      size_t *n_codon_frames);
+                                      float power_threshold, int want_power, int want_raw, char *text, size_t text_capacity,
+                                      uint64_t *out_bytes, size_t *n_codon_frames);
+/* bytes of text buffer that hold the text of a call over n_columns alignment columns in n_alignments alignments unless its lines are
+ * unusually long (12 bytes per line where a line is ~8; no device needed) */
+size_t pcsf_wig_text_estimate(size_t n_columns, size_t n_alignments);
 /* copies the text of the last pcsf_score_alignments_6frames_wig call of this context: dst[f] has room for out_bytes[f] (page-locked
  * memory from pcsf_host_alloc_on keeps the copy off the host threads); a file without text may have dst[f] = NULL */
 int pcsf_fetch_wig_text(pcsf_ctx *ctx, char *const *dst);

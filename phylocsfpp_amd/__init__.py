@@ -79,7 +79,9 @@ def load_library():
                                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.pcsf_score_alignments_6frames_bls.argtypes = lib.pcsf_score_alignments_6frames.argtypes + [dp]
     lib.pcsf_score_alignments_6frames_wig.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(_AlignmentDesc), C.c_size_t, C.POINTER(C.c_char_p),
-                                                      C.c_float, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]
+                                                      C.c_float, C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]
+    lib.pcsf_wig_text_estimate.argtypes = [C.c_size_t, C.c_size_t]
+    lib.pcsf_wig_text_estimate.restype = C.c_size_t
     lib.pcsf_fetch_wig_text.argtypes = [vp, C.POINTER(C.c_char_p)]
     lib.pcsf_debug_wig_format.argtypes = [vp, fp, C.c_size_t, C.c_int, C.c_char_p, C.POINTER(C.c_uint32)]
     lib.pcsf_set_bls_branch_lengths.argtypes = [vp, dp]
@@ -340,10 +342,11 @@ class ScoringContext:
             return res, skip.reshape(n, 6), bls
         return res, skip.reshape(n, 6)
 
-    def score_alignments_6frames_wig(self, nucleotides, alignments, chroms, power_threshold, want_power=True, want_raw=True):
+    def score_alignments_6frames_wig(self, nucleotides, alignments, chroms, power_threshold, want_power=True, want_raw=True, text_capacity=None):
         """The same call for a caller that only writes: the text of build-tracks' seven wig files for this batch (formatted on the
         device, csrc/wig.hip).  chroms: one chromosome name per alignment.  Returns (list of 7 bytes objects -- power track, then
-        +1 +2 +3 -1 -2 -3 --, number of codon-frames scored); None when the device left the batch to the host formatter."""
+        +1 +2 +3 -1 -2 -3 --, number of codon-frames scored); None when the device left the batch to the host formatter.  text_capacity: bytes
+        of the buffer handed to the call (default: pcsf_wig_text_estimate); a text that does not fit is fetched afterwards."""
         nuc = np.ascontiguousarray(nucleotides, dtype=np.uint8)
         assert nuc.ndim == 2 and nuc.shape[0] == self.n_leaves
         n = len(alignments)
@@ -351,15 +354,24 @@ class ScoringContext:
         names = (C.c_char_p * n)(*[c.encode() if isinstance(c, str) else bytes(c) for c in chroms])
         sizes = (C.c_uint64 * 7)()
         frames = C.c_size_t(0)
+        cap = int(text_capacity) if text_capacity is not None else int(self._lib.pcsf_wig_text_estimate(nuc.shape[1], n))
+        text = C.create_string_buffer(max(cap, 1))
         rc = self._lib.pcsf_score_alignments_6frames_wig(self._h, nuc.ctypes.data_as(C.c_char_p), nuc.strides[0], desc, n, names,
-                                                         float(power_threshold), int(want_power), int(want_raw), sizes, C.byref(frames))
+                                                         float(power_threshold), int(want_power), int(want_raw), text if cap else None, cap,
+                                                         sizes, C.byref(frames))
         if rc == -5:   # PCSF_ERR_UNSUPPORTED
             return None
         self._check(rc)
+        total = sum(int(s) for s in sizes)
+        if total <= cap:       # the text came with the call
+            raw, at, out = text.raw, 0, []
+            for s in sizes:
+                out.append(raw[at:at + int(s)])
+                at += int(s)
+            return out, int(frames.value)
         bufs = [C.create_string_buffer(max(int(s), 1)) for s in sizes]
         dst = (C.c_char_p * 7)(*[C.cast(b, C.c_char_p) for b in bufs])
-        if n:
-            self._check(self._lib.pcsf_fetch_wig_text(self._h, dst))
+        self._check(self._lib.pcsf_fetch_wig_text(self._h, dst))
         return [bufs[f].raw[:int(sizes[f])] for f in range(7)], int(frames.value)
 
     def debug_wig_format(self, values, decimals):

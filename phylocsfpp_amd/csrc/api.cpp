@@ -2,6 +2,7 @@
 // Host side of the drop-in boundary: what the reference does in PhyloCSFModel_make /
 // lpr_leaves / run_tracks / run (src/instance.hpp:687-712, src/fixed_lik.hpp:362-449,
 // src/run.hpp:35-211) minus the per-site arithmetic, which runs on the GPU.
+#include <chrono>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -626,6 +627,8 @@ struct WigRequest {   // pcsf_score_alignments_6frames_wig: the call's wig text 
     bool want_power, want_raw;
     uint64_t* out_bytes;       // [7]
     size_t* n_codon_frames;
+    char* text;                // host destination of the seven texts back to back (may be null)
+    size_t text_capacity;
 };
 }  // namespace
 
@@ -646,8 +649,8 @@ int pcsf_score_alignments_6frames_bls(pcsf_ctx* c, const char* nucleotides, size
 // The six-frame call that keeps its results on the device and formats the wig text there (wig.hip): out_bytes[f] = bytes of file f's
 // text of this call (0: PhyloCSFpower.wig, 1..6: PhyloCSFRaw+1 .. PhyloCSFRaw-3); pcsf_fetch_wig_text copies them out.
 int pcsf_score_alignments_6frames_wig(pcsf_ctx* c, const char* nucleotides, size_t row_stride, const pcsf_alignment_desc* alns, size_t n_alns,
-                                      const char* const* chrom_names, float power_threshold, int want_power, int want_raw, uint64_t* out_bytes,
-                                      size_t* n_codon_frames)
+                                      const char* const* chrom_names, float power_threshold, int want_power, int want_raw, char* text, size_t text_capacity,
+                                      uint64_t* out_bytes, size_t* n_codon_frames)
 {
     if (!c) return PCSF_ERR_INVALID_ARG;
     if (!out_bytes) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_alignments_6frames_wig: null argument");
@@ -657,7 +660,7 @@ int pcsf_score_alignments_6frames_wig(pcsf_ctx* c, const char* nucleotides, size
     if (n_alns == 0) return PCSF_OK;
     if (!nucleotides || !alns || !chrom_names) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_alignments_6frames_wig: null argument");
     if (!c->bls_ready) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_alignments_6frames_wig: call pcsf_set_bls_branch_lengths first");
-    const WigRequest req{chrom_names, power_threshold, want_power != 0, want_raw != 0, out_bytes, n_codon_frames};
+    const WigRequest req{chrom_names, power_threshold, want_power != 0, want_raw != 0, out_bytes, n_codon_frames, text, text ? text_capacity : 0};
     std::vector<uint64_t> offsets(n_alns * 6);
     std::vector<uint32_t> counts(n_alns * 6);
     return six_frames_impl(c, nucleotides, row_stride, alns, n_alns, nullptr, ~size_t(0), offsets.data(), counts.data(), nullptr, nullptr, &req);
@@ -670,22 +673,54 @@ int pcsf_fetch_wig_text(pcsf_ctx* c, char* const* dst)
     if (!c->wig.ready) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_fetch_wig_text: no text (call pcsf_score_alignments_6frames_wig first)");
     hipError_t e;
     if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
+    bool contiguous = true;   // the seven destinations back to back, like the text on the device: one copy
+    const char* first = nullptr;
     for (int f = 0; f < 7; ++f) {
         const uint64_t n = c->wig.file_off[f + 1] - c->wig.file_off[f];
         if (!n) continue;
         if (!dst[f]) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_fetch_wig_text: null destination for a file with text");
-        if ((e = hipMemcpyAsync(dst[f], c->wig.text.as<char>() + c->wig.file_off[f], n, hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
+        if (!first) first = dst[f] - (c->wig.file_off[f] - c->wig.file_off[0]);
+        contiguous = contiguous && dst[f] == first + (c->wig.file_off[f] - c->wig.file_off[0]);
+    }
+    if (contiguous && first) {
+        if ((e = hipMemcpyAsync(const_cast<char*>(first), c->wig.text.as<char>() + c->wig.file_off[0], c->wig.file_off[7] - c->wig.file_off[0], hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
             return c->hip_fail(e, "hipMemcpyAsync(wig text)");
+    } else {
+        for (int f = 0; f < 7; ++f) {
+            const uint64_t n = c->wig.file_off[f + 1] - c->wig.file_off[f];
+            if (n && (e = hipMemcpyAsync(dst[f], c->wig.text.as<char>() + c->wig.file_off[f], n, hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
+                return c->hip_fail(e, "hipMemcpyAsync(wig text)");
+        }
     }
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return c->hip_fail(e, "hipStreamSynchronize");
     c->wig.ready = false;
     return PCSF_OK;
 }
 
+// bytes of text buffer per line candidate before the sizes are known (PCSF_WIG_TEXT_ESTIMATE: tests make it too small on purpose)
+static uint64_t wig_text_estimate()
+{
+    static const uint64_t v = [] {
+        const char* s = std::getenv("PCSF_WIG_TEXT_ESTIMATE");
+        return s ? std::max<uint64_t>(strtoull(s, nullptr, 10), 0) : uint64_t(12);
+    }();
+    return v;
+}
+
+size_t pcsf_wig_text_estimate(size_t n_columns, size_t n_alignments)
+{
+    // line candidates: six frames of at most n_columns / 3 codons, and the power track's n_columns / 3
+    return static_cast<size_t>(wig_text_estimate()) * (2 * n_columns + n_columns / 3 + 1) + 128 * 7 * n_alignments + 64;
+}
+
 static int six_frames_impl(pcsf_ctx* c, const char* nucleotides, size_t row_stride, const pcsf_alignment_desc* alns, size_t n_alns,
                            double* out_scores, size_t out_capacity, uint64_t* out_offsets, uint32_t* n_codons, uint32_t* skip_bases,
                            double* out_bls, const WigRequest* wig)
 {
+    static const bool TIMING = std::getenv("PCSF_TIME_6F") != nullptr;   // one line per call on stderr: host milliseconds of its phases
+    const auto T0 = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count() * 1e3; };
+    double t_enq = 0, t_turn = 0, t_sync = 0;
     std::vector<pcsf::FrameSegment> seg;
     std::vector<pcsf::BlsSpan> spans;  // like seg: source of an asynchronous copy, alive until the stream is synchronised
     seg.reserve(n_alns * 6);
@@ -754,41 +789,10 @@ static int six_frames_impl(pcsf_ctx* c, const char* nucleotides, size_t row_stri
         return c->hip_fail(e, "hipMemcpyAsync(segments)");
     if (fused && !wg_first_seg.empty() && (e = hipMemcpyAsync(c->d_wg_seg.ptr, wg_first_seg.data(), wg_first_seg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
         return c->hip_fail(e, "hipMemcpyAsync(work-group segments)");
-    int rc;
-    KernelTurn& turn = g_kernel_turn[c->device & 63];
-    std::unique_lock<std::mutex> my_turn(turn.lock);
-    if (turn.last && turn.owner != c && (e = hipStreamWaitEvent(c->stream, turn.last, 0)) != hipSuccess) return c->hip_fail(e, "hipStreamWaitEvent");
-    // the power track's per-base scores from the same resident rows (that kernel also checks every character); without
-    // them the translation does the character check itself, so that both entry points reject the same input
-    unsigned long long* d_char_flag = nullptr;
-    if (out_bls || wig) {
-        if ((rc = pcsf::bls_enqueue(c, c->d_nucl.as<unsigned char>(), max_col, max_col, spans)) != PCSF_OK) return rc;
-    } else {
-        if ((e = c->d_bls_flag.reserve(sizeof(unsigned long long))) != hipSuccess) return c->hip_fail(e, "hipMalloc(character flag)");
-        if (!c->bls_first_bad && (e = hipHostMalloc(reinterpret_cast<void**>(&c->bls_first_bad), sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
-            return c->hip_fail(e, "hipHostMalloc(character flag)");
-        if ((e = hipMemsetAsync(c->d_bls_flag.ptr, 0xff, sizeof(unsigned long long), c->stream)) != hipSuccess) return c->hip_fail(e, "hipMemsetAsync(character flag)");
-        d_char_flag = c->d_bls_flag.as<unsigned long long>();
-    }
-    if (total == 0) {
-        // (wig request on alignments shorter than a codon: only the power track has text)
-    } else if (fused) {
-        pcsf::FusedFrontEnd fe{c->d_nucl.as<unsigned char>(), max_col, c->d_segments.as<pcsf::FrameSegment>(), c->d_wg_seg.as<uint32_t>(), d_char_flag,
-                               c->dump_codons ? c->d_codons.as<unsigned char>() : nullptr};
-        if ((rc = pcsf::launch_fixed(c, nullptr, total, total, c->d_out.as<double>(), nullptr, nullptr, c->stream, &fe)) != PCSF_OK) return rc;
-    } else {
-        // at most 65535 segments per launch (grid.y)
-        for (size_t s0 = 0; s0 < seg.size(); s0 += 65535) {
-            const uint32_t ns = static_cast<uint32_t>(std::min<size_t>(65535, seg.size() - s0));
-            if ((e = pcsf::launch_extract_frames(c->d_segments.as<pcsf::FrameSegment>() + s0, ns, max_codons, c->d_nucl.as<unsigned char>(), max_col,
-                                                 c->n_leaves, c->d_codons.as<unsigned char>(), total, d_char_flag, c->stream)) != hipSuccess)
-                return c->hip_fail(e, "launch extract_frames");
-        }
-        if ((rc = pcsf::launch_fixed(c, c->d_codons.as<uint8_t>(), total, total, c->d_out.as<double>(), nullptr, nullptr, c->stream)) != PCSF_OK) return rc;
-    }
-    // ---- wig text on the device: the line candidates of the seven files, their lengths and byte offsets (inside this call's turn on the
-    // device), then -- once the sizes are known -- the text itself
+    // ---- wig text on the device: the line candidates of the seven files (records and names uploaded before this call's turn on the device)
     pcsf::WigParams wp{};
+    uint64_t text_copied = 0;               // bytes of text queued for the caller's buffer before the sizes were known
+    size_t wig_temp_bytes = 0;              // scratch of the prefix sum
     std::vector<pcsf::WigFrame> frames;     // sources of asynchronous copies: alive until the stream is synchronised below
     std::vector<char> chroms;
     if (wig) {
@@ -839,18 +843,19 @@ static int six_frames_impl(pcsf_ctx* c, const char* nucleotides, size_t row_stri
                 return c->fail(PCSF_ERR_UNSUPPORTED, "pcsf_score_alignments_6frames_wig: too many lines in one call -- format this batch on the host");
         }
         pcsf_ctx::WigBuffers& W = c->wig;
-        const size_t temp_bytes = pcsf::wig_scan_temp_bytes(elems);
+        const size_t temp_bytes = wig_temp_bytes = pcsf::wig_scan_temp_bytes(elems);
         if (!W.h_bounds && (e = hipHostMalloc(reinterpret_cast<void**>(&W.h_bounds), 16 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
             return c->hip_fail(e, "hipHostMalloc(wig bounds)");
         if ((e = W.frames.reserve(std::max<size_t>(frames.size(), 1) * sizeof(pcsf::WigFrame))) != hipSuccess || (e = W.chroms.reserve(std::max<size_t>(chroms.size(), 1))) != hipSuccess ||
             (e = W.lens.reserve((elems + 1) * sizeof(uint32_t))) != hipSuccess || (e = W.offsets.reserve((elems + 1) * sizeof(uint32_t))) != hipSuccess ||
-            (e = W.temp.reserve(std::max<size_t>(temp_bytes, 16))) != hipSuccess || (e = W.flag.reserve(sizeof(uint32_t))) != hipSuccess)
+            (e = W.temp.reserve(std::max<size_t>(temp_bytes, 16))) != hipSuccess || (e = W.flag.reserve(9 * sizeof(uint32_t))) != hipSuccess ||
+            (e = W.text.reserve(wig_text_estimate() * elems + 128 * frames.size() + 64)) != hipSuccess)   // an estimate: a line is ~8.4 bytes (wig.hip)
             return c->hip_fail(e, "hipMalloc(wig)");
         if (!frames.empty() && (e = hipMemcpyAsync(W.frames.ptr, frames.data(), frames.size() * sizeof(pcsf::WigFrame), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
             return c->hip_fail(e, "hipMemcpyAsync(wig frames)");
         if (!chroms.empty() && (e = hipMemcpyAsync(W.chroms.ptr, chroms.data(), chroms.size(), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
             return c->hip_fail(e, "hipMemcpyAsync(wig chromosome names)");
-        if ((e = hipMemsetAsync(W.flag.ptr, 0, sizeof(uint32_t), c->stream)) != hipSuccess) return c->hip_fail(e, "hipMemsetAsync(wig flag)");
+        if ((e = hipMemsetAsync(W.flag.ptr, 0, 9 * sizeof(uint32_t), c->stream)) != hipSuccess) return c->hip_fail(e, "hipMemsetAsync(wig bounds)");
         wp.frames = W.frames.as<pcsf::WigFrame>();
         wp.scores = c->d_out.as<double>();
         wp.bls = c->d_bls_out.as<double>();
@@ -858,8 +863,51 @@ static int six_frames_impl(pcsf_ctx* c, const char* nucleotides, size_t row_stri
         wp.threshold3 = wig->power_threshold * 3;
         wp.lens = W.lens.as<uint32_t>();
         wp.offsets = W.offsets.as<uint32_t>();
-        wp.needs_host = W.flag.as<uint32_t>();
-        if ((e = pcsf::launch_wig_lengths(wp, W.temp.ptr, temp_bytes, c->stream)) != hipSuccess) return c->hip_fail(e, "launch wig lengths");
+        wp.bounds = W.flag.as<uint32_t>();
+        wp.needs_host = wp.bounds + 8;
+        wp.text = W.text.as<char>();
+        wp.text_capacity = W.text.bytes;
+    }
+    int rc;
+    KernelTurn& turn = g_kernel_turn[c->device & 63];
+    t_enq = since();
+    std::unique_lock<std::mutex> my_turn(turn.lock);
+    t_turn = since();
+    if (turn.last && turn.owner != c && (e = hipStreamWaitEvent(c->stream, turn.last, 0)) != hipSuccess) return c->hip_fail(e, "hipStreamWaitEvent");
+    // the power track's per-base scores from the same resident rows (that kernel also checks every character); without
+    // them the translation does the character check itself, so that both entry points reject the same input
+    unsigned long long* d_char_flag = nullptr;
+    if (out_bls || wig) {
+        if ((rc = pcsf::bls_enqueue(c, c->d_nucl.as<unsigned char>(), max_col, max_col, spans)) != PCSF_OK) return rc;
+    } else {
+        if ((e = c->d_bls_flag.reserve(sizeof(unsigned long long))) != hipSuccess) return c->hip_fail(e, "hipMalloc(character flag)");
+        if (!c->bls_first_bad && (e = hipHostMalloc(reinterpret_cast<void**>(&c->bls_first_bad), sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
+            return c->hip_fail(e, "hipHostMalloc(character flag)");
+        if ((e = hipMemsetAsync(c->d_bls_flag.ptr, 0xff, sizeof(unsigned long long), c->stream)) != hipSuccess) return c->hip_fail(e, "hipMemsetAsync(character flag)");
+        d_char_flag = c->d_bls_flag.as<unsigned long long>();
+    }
+    if (total == 0) {
+        // (wig request on alignments shorter than a codon: only the power track has text)
+    } else if (fused) {
+        pcsf::FusedFrontEnd fe{c->d_nucl.as<unsigned char>(), max_col, c->d_segments.as<pcsf::FrameSegment>(), c->d_wg_seg.as<uint32_t>(), d_char_flag,
+                               c->dump_codons ? c->d_codons.as<unsigned char>() : nullptr};
+        if ((rc = pcsf::launch_fixed(c, nullptr, total, total, c->d_out.as<double>(), nullptr, nullptr, c->stream, &fe)) != PCSF_OK) return rc;
+    } else {
+        // at most 65535 segments per launch (grid.y)
+        for (size_t s0 = 0; s0 < seg.size(); s0 += 65535) {
+            const uint32_t ns = static_cast<uint32_t>(std::min<size_t>(65535, seg.size() - s0));
+            if ((e = pcsf::launch_extract_frames(c->d_segments.as<pcsf::FrameSegment>() + s0, ns, max_codons, c->d_nucl.as<unsigned char>(), max_col,
+                                                 c->n_leaves, c->d_codons.as<unsigned char>(), total, d_char_flag, c->stream)) != hipSuccess)
+                return c->hip_fail(e, "launch extract_frames");
+        }
+        if ((rc = pcsf::launch_fixed(c, c->d_codons.as<uint8_t>(), total, total, c->d_out.as<double>(), nullptr, nullptr, c->stream)) != PCSF_OK) return rc;
+    }
+    if (wig) {   // the line candidates' lengths, their byte offsets, the text: behind the scoring kernels, no host in between
+        pcsf_ctx::WigBuffers& W = c->wig;
+        wp.scores = c->d_out.as<double>();   // (the branch-length kernel's output buffer may have grown since the records were made)
+        wp.bls = c->d_bls_out.as<double>();
+        if ((e = pcsf::launch_wig_lengths(wp, W.temp.ptr, wig_temp_bytes, c->stream)) != hipSuccess) return c->hip_fail(e, "launch wig lengths");
+        if ((e = pcsf::launch_wig_write(wp, c->stream)) != hipSuccess) return c->hip_fail(e, "launch wig write");
     }
     if ((e = hipEventRecord(c->ev_kernels, c->stream)) != hipSuccess) return c->hip_fail(e, "hipEventRecord");
     turn.last = c->ev_kernels;
@@ -873,28 +921,38 @@ static int six_frames_impl(pcsf_ctx* c, const char* nucleotides, size_t row_stri
         *c->bls_first_bad = pcsf::BLS_NO_BAD;
         if ((e = hipMemcpyAsync(c->bls_first_bad, c->d_bls_flag.ptr, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
             return c->hip_fail(e, "hipMemcpyAsync(bls flag)");
-        for (int f = 0; f < 8; ++f) {
-            W.h_bounds[f] = 0;
-            if (wp.n_elems && (e = hipMemcpyAsync(W.h_bounds + f, wp.offsets + wp.file_elem0[f], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
-                return c->hip_fail(e, "hipMemcpyAsync(wig bounds)");
-        }
-        if ((e = hipMemcpyAsync(W.h_bounds + 8, W.flag.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return c->hip_fail(e, "hipMemcpyAsync(wig flag)");
+        if ((e = hipMemcpyAsync(W.h_bounds, W.flag.ptr, 9 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return c->hip_fail(e, "hipMemcpyAsync(wig bounds)");
+        // the text itself, before its size is known: as much as the caller's buffer and the device's hold.  (A copy queued once the
+        // sizes are on the host waits behind the OTHER context's pruning kernel, which was queued meanwhile: 7.5 ms per call measured.)
+        text_copied = std::min<uint64_t>(wig->text_capacity, wp.n_elems ? wp.text_capacity : 0);
+        if (text_copied && (e = hipMemcpyAsync(wig->text, wp.text, text_copied, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return c->hip_fail(e, "hipMemcpyAsync(wig text)");
     }
     if (d_char_flag) {
         *c->bls_first_bad = pcsf::BLS_NO_BAD;
         if ((e = hipMemcpyAsync(c->bls_first_bad, d_char_flag, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
             return c->hip_fail(e, "hipMemcpyAsync(character flag)");
     }
+    const double t_unl = since();
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return c->hip_fail(e, "hipStreamSynchronize");
+    t_sync = since();
+    if (TIMING) fprintf(stderr, "6f %s ctx %p: cols %zu, before turn %.3f, wait turn %.3f, enqueue in turn %.3f, sync %.3f ms\n", wig ? "wig" : "dl", (void*)c, (size_t)max_col, t_enq, t_turn - t_enq, t_unl - t_turn, t_sync - t_unl);
     if ((rc = pcsf::bls_check(c, nucleotides, row_stride, max_col)) != PCSF_OK) return rc;
     if (wig) {
         pcsf_ctx::WigBuffers& W = c->wig;
         if (W.h_bounds[8]) return c->fail(PCSF_ERR_UNSUPPORTED, "pcsf_score_alignments_6frames_wig: a value of 9e14 or more -- format this batch on the host");
         for (int f = 0; f < 8; ++f) W.file_off[f] = W.h_bounds[f];
         const uint64_t bytes = W.file_off[7];
-        if ((e = W.text.reserve(std::max<uint64_t>(bytes, 1))) != hipSuccess) return c->hip_fail(e, "hipMalloc(wig text)");
-        wp.text = W.text.as<char>();
-        if ((e = pcsf::launch_wig_write(wp, c->stream)) != hipSuccess) return c->hip_fail(e, "launch wig write");
+        if (bytes > wp.text_capacity) {   // the estimate was too small (lines of twelve bytes and more on average): write again into enough room
+            if ((e = W.text.reserve(bytes)) != hipSuccess) return c->hip_fail(e, "hipMalloc(wig text)");
+            wp.text = W.text.as<char>();
+            wp.text_capacity = W.text.bytes;
+            if ((e = pcsf::launch_wig_write(wp, c->stream)) != hipSuccess) return c->hip_fail(e, "launch wig write");
+            text_copied = 0;
+        }
+        if (bytes > text_copied && bytes <= wig->text_capacity) {   // the caller's buffer holds it but the early copy did not bring all of it
+            if ((e = hipMemcpyAsync(wig->text, wp.text, bytes, hipMemcpyDeviceToHost, c->stream)) != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess)
+                return c->hip_fail(e, "hipMemcpyAsync(wig text)");
+        }
         for (int f = 0; f < 7; ++f) wig->out_bytes[f] = W.file_off[f + 1] - W.file_off[f];
         if (wig->n_codon_frames) *wig->n_codon_frames = total;
         W.ready = true;

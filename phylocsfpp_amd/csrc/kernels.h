@@ -349,7 +349,9 @@ struct WigParams {
     uint32_t* lens;               // [n_elems + 1]
     uint32_t* offsets;            // [n_elems + 1] exclusive prefix sums of lens: byte offset of every candidate's text
     char* text;
-    uint32_t* needs_host;         // set when a finite |value| >= 9e14 turns up (format_trimmed's snprintf path: the caller formats on the host)
+    uint64_t text_capacity;       // bytes of `text`: a line that would end beyond is not stored (the caller reads the total, grows and writes again)
+    uint32_t* bounds;             // [9], written by the write pass: byte offsets of the eight file boundaries; [8] = needs_host
+    uint32_t* needs_host;         // = bounds + 8: set when a finite |value| >= 9e14 turns up (format_trimmed's snprintf path: the caller formats on the host)
 };
 size_t wig_scan_temp_bytes(uint64_t n_elems);
 hipError_t launch_wig_lengths(const WigParams& p, void* d_temp, size_t temp_bytes, hipStream_t stream);

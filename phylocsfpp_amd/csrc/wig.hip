@@ -10,6 +10,10 @@
 //   exclusive scan      (rocPRIM) of the lengths over all seven files at once: every line's byte offset; a file's text is the
 //                       stretch between the offsets of its first candidates
 //   wig_write_kernel    every thread formats its line again and stores it at its offset
+// All three are enqueued behind the scoring kernels without the host in between: the text buffer is sized from an estimate (12 bytes per
+// candidate: a line is ~8.4), lines that would not fit are left out, and the caller -- who reads the eight file boundaries and so the
+// total afterwards -- grows the buffer and runs the write pass again if that ever happens.  (With the sizes fetched first, the write pass
+// was launched into a device already full of the other context's pruning work-groups and the call waited ~2 ms for it.)
 // The host copies the text down and write()s it.  The value text is format_trimmed's (host/tracks.hpp): the float times 10^D is
 // exact in double, rounded to nearest-even like printf, trailing zeros removed but one decimal kept; NaN and infinities print as
 // glibc prints them; a finite |value| >= 9e14 (never a score) raises a flag and the caller formats that batch on the host.
@@ -157,7 +161,14 @@ __global__ __launch_bounds__(256) void wig_kernel(const WigParams p)
     const WigFrame& f = *c.fr;
     const double* __restrict__ b = p.bls + f.bls0 + 3ull * c.xx;
     uint32_t len = 0;
-    char* dst = WRITE ? p.text + p.offsets[e] : nullptr;
+    char* dst = nullptr;
+    if (WRITE) {
+        if (e < 8) p.bounds[e] = p.offsets[p.file_elem0[e]];   // the eight file boundaries (n_elems >= 8 or not: see launch_wig_write)
+        // a line beyond the buffer (the caller sized it from an estimate) is left out; the total tells the caller, who writes again
+        const uint32_t at = p.offsets[e];
+        if (static_cast<uint64_t>(at) + p.lens[e] > p.text_capacity || p.lens[e] == 0) return;
+        dst = p.text + at;
+    }
     bool big = false;
     if (c.file == 0) {
         // power track (build_tracks.hpp:139-156): one header per alignment, every codon of frame 3 of the + strand
@@ -192,6 +203,11 @@ __global__ __launch_bounds__(256) void wig_kernel(const WigParams p)
         p.lens[e] = len;
         if (big) *p.needs_host = 1u;
     }
+}
+
+__global__ void wig_bounds_kernel(const WigParams p)
+{
+    p.bounds[threadIdx.x] = p.offsets[p.file_elem0[threadIdx.x]];
 }
 
 // tests: one value per thread into a 32-byte slot, its length beside it (0xffffffff: the host formats this one)
@@ -230,11 +246,17 @@ hipError_t launch_wig_lengths(const WigParams& p, void* d_temp, size_t temp_byte
     return rocprim::exclusive_scan(d_temp, temp_bytes, p.lens, p.offsets, 0u, p.n_elems + 1, rocprim::plus<uint32_t>(), stream);
 }
 
+// also fills p.bounds[0..7]; a call with fewer than eight candidates gets them from a second, eight-thread kernel
 hipError_t launch_wig_write(const WigParams& p, hipStream_t stream)
 {
     if (p.n_elems == 0) return hipSuccess;
     hipLaunchKernelGGL(wig_kernel<true>, dim3(static_cast<unsigned>((p.n_elems + 255) / 256)), dim3(256), 0, stream, p);
-    return hipGetLastError();
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    if (p.n_elems < 8) {
+        hipLaunchKernelGGL(wig_bounds_kernel, dim3(1), dim3(8), 0, stream, p);
+        return hipGetLastError();
+    }
+    return hipSuccess;
 }
 
 }  // namespace pcsf

@@ -100,17 +100,19 @@ public:
     }
     bool score_alignments_6frames_wig(const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0, const std::vector<uint32_t>& len,
                                       const std::vector<uint64_t>& start_pos, const std::vector<uint64_t>& chrom_len, const std::vector<const char*>& chroms,
-                                      float power_threshold, bool want_power, bool want_raw, uint64_t* bytes, size_t* n_codon_frames) override
+                                      float power_threshold, bool want_power, bool want_raw, char* text, size_t text_capacity, uint64_t* bytes,
+                                      size_t* n_codon_frames) override
     {
         const size_t n = col0.size();
         std::vector<pcsf_alignment_desc> d(n);
         for (size_t k = 0; k < n; ++k) d[k] = pcsf_alignment_desc{col0[k], len[k], start_pos[k], chrom_len[k]};
         const int rc = pcsf_score_alignments_6frames_wig(ctx_, nucl, row_stride, d.data(), n, chroms.data(), power_threshold, want_power ? 1 : 0, want_raw ? 1 : 0,
-                                                         bytes, n_codon_frames);
+                                                         text, text_capacity, bytes, n_codon_frames);
         if (rc == PCSF_ERR_UNSUPPORTED) return false;
         check(rc);
         return true;
     }
+    size_t wig_text_estimate(size_t n_columns, size_t n_alignments) override { return pcsf_wig_text_estimate(n_columns, n_alignments); }
     void fetch_wig_text(char* const* dst) override { check(pcsf_fetch_wig_text(ctx_, dst)); }
 
     char* staging_alloc(size_t bytes) override

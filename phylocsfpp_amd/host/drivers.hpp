@@ -7,6 +7,7 @@
 // layout follow the reference (PhyloCSFpower.wig, PhyloCSFRaw{+,-}{1,2,3}.wig, <maf>.scores).
 #pragma once
 
+#include <sys/uio.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -103,13 +104,15 @@ struct ScoringBackend {
     // (formatted where the scores are: build-tracks then only copies the text down and appends it to the files)
     virtual bool device_wig() const { return false; }
     // The batch of score_alignments_6frames, scored and formatted: bytes[7] = the text per file (0: PhyloCSFpower.wig, 1..6: the frames);
-    // chroms[k]: alignment k's chromosome name.  false: a value came up that the backend does not print -- score and format this batch the
-    // usual way.  The text stays with the backend until fetch_wig_text copies it (or the next call replaces it).
+    // chroms[k]: alignment k's chromosome name.  text[text_capacity] (staging memory of wig_text_estimate() bytes) receives the seven texts
+    // back to back if they fit; otherwise the text stays with the backend until fetch_wig_text copies it (or the next call replaces it).
+    // false: a value came up that the backend does not print -- score and format this batch the usual way.
     virtual bool score_alignments_6frames_wig(const char*, size_t, const std::vector<uint64_t>&, const std::vector<uint32_t>&, const std::vector<uint64_t>&,
-                                              const std::vector<uint64_t>&, const std::vector<const char*>&, float, bool, bool, uint64_t*, size_t*)
+                                              const std::vector<uint64_t>&, const std::vector<const char*>&, float, bool, bool, char*, size_t, uint64_t*, size_t*)
     {
         throw std::runtime_error("score_alignments_6frames_wig: this backend does not format tracks");
     }
+    virtual size_t wig_text_estimate(size_t, size_t) { throw std::runtime_error("wig_text_estimate: this backend does not format tracks"); }
     virtual void fetch_wig_text(char* const*) { throw std::runtime_error("fetch_wig_text: this backend does not format tracks"); }
     virtual size_t score_alignments_6frames(int n_leaves, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0,
                                             const std::vector<uint32_t>& len, const std::vector<uint64_t>& start_pos,
@@ -205,10 +208,13 @@ public:
     bool device_wig() const override { return device_wig_; }   // like device_bls: what the first backend answered
     bool score_alignments_6frames_wig(const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0, const std::vector<uint32_t>& len,
                                       const std::vector<uint64_t>& start_pos, const std::vector<uint64_t>& chrom_len, const std::vector<const char*>& chroms,
-                                      float power_threshold, bool want_power, bool want_raw, uint64_t* bytes, size_t* n_codon_frames) override
+                                      float power_threshold, bool want_power, bool want_raw, char* text, size_t text_capacity, uint64_t* bytes,
+                                      size_t* n_codon_frames) override
     {
-        return get().score_alignments_6frames_wig(nucl, row_stride, col0, len, start_pos, chrom_len, chroms, power_threshold, want_power, want_raw, bytes, n_codon_frames);
+        return get().score_alignments_6frames_wig(nucl, row_stride, col0, len, start_pos, chrom_len, chroms, power_threshold, want_power, want_raw, text, text_capacity,
+                                                  bytes, n_codon_frames);
     }
+    size_t wig_text_estimate(size_t n_columns, size_t n_alignments) override { return get().wig_text_estimate(n_columns, n_alignments); }
     void fetch_wig_text(char* const* dst) override { get().fetch_wig_text(dst); }
 
 private:
@@ -857,6 +863,7 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         uint64_t start_pos = 0, chrom_len = 0, col0 = 0;
         uint32_t len = 0;
         std::vector<std::string> seqs;
+        const char* rows = nullptr;        // packed input: the species rows where they lie in the mapped file ([n_leaves][len]) instead of seqs
         std::vector<double> bls_host;      // per-base branch-length scores when computed on the host
         const double* bls = nullptr;       // [len]: bls_host, or the alignment's columns of its batch's device result
     };
@@ -1023,6 +1030,21 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             BranchLengthScore bls(model);
             Alignment aln;
             StopWatch jw;
+            if (packed && dev_bls && need_raw) {
+                // nothing of a record is needed on the host: its rows go from the mapped file straight into the batch matrix
+                PackedReader::Record r;
+                while (packed_reader->next_record(r)) {
+                    Item it;
+                    it.chrom.assign(r.chrom, r.chrom_bytes);
+                    it.start_pos = r.start_pos;
+                    it.chrom_len = r.chrom_len;
+                    it.len = r.len;
+                    it.rows = r.rows;
+                    pw->jobs[j].push_back(std::move(it));
+                }
+                job_read[j] += jw.lap();
+                return;
+            }
             while (packed ? packed_reader->next(aln) : text_reader->next(aln)) {
                 job_read[j] += jw.lap();
                 Item it;
@@ -1064,11 +1086,31 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             }
             if (!need_raw) continue;
             bt.nucl = pool.get(nl * bt.stride);
-            parallel_for(bt.items.size() * nl, threads, [&](size_t j) {
-                const Item& p = *bt.items[j / nl];
-                const size_t l = j % nl;
-                memcpy(bt.nucl.first + l * bt.stride + p.col0, p.seqs[l].data(), p.len);
-            });
+            if (!bt.items.empty() && bt.items[0]->rows) {
+                // packed input: one positional scatter read per record, page cache -> batch matrix.  (Copying out of the mapping instead
+                // faults its pages in from sixteen threads at once, neighbours in the same page-table pages: 0.39 -> 1.1 s per 100 Mb.)
+                parallel_for(bt.items.size(), threads, [&](size_t k) {
+                    const Item& p = *bt.items[k];
+                    if (p.len == 0) return;
+                    size_t done_rows = 0;
+                    std::vector<struct iovec> iov(std::min<size_t>(nl, 512));
+                    while (done_rows < nl) {
+                        const size_t n = std::min(iov.size(), nl - done_rows);
+                        for (size_t i = 0; i < n; ++i) iov[i] = {bt.nucl.first + (done_rows + i) * bt.stride + p.col0, p.len};
+                        const off_t at = static_cast<off_t>(p.rows - file.data()) + static_cast<off_t>(done_rows * p.len);
+                        const ssize_t got = preadv(file.fd(), iov.data(), static_cast<int>(n), at);
+                        if (got != static_cast<ssize_t>(n * p.len))   // short read or error: the mapping has the same bytes
+                            for (size_t i = 0; i < n; ++i) memcpy(iov[i].iov_base, p.rows + (done_rows + i) * p.len, p.len);
+                        done_rows += n;
+                    }
+                });
+            } else {
+                parallel_for(bt.items.size() * nl, threads, [&](size_t j) {
+                    const Item& p = *bt.items[j / nl];
+                    const size_t l = j % nl;
+                    memcpy(bt.nucl.first + l * bt.stride + p.col0, p.seqs[l].data(), p.len);
+                });
+            }
             for (Item* p : bt.items) std::vector<std::string>().swap(p->seqs);  // the rows now live in the batch matrix
         }
         pw->pack = pack.lap();
@@ -1158,20 +1200,28 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             if (need_raw && dev_wig) {
                 std::vector<const char*> chroms(b->items.size());
                 for (size_t k = 0; k < chroms.size(); ++k) chroms[k] = b->items[k]->chrom.c_str();
+                // the text is copied down behind the kernels, before its size is known: a buffer from the backend's estimate
+                b->text_mem = text_pool.get(backends[d]->wig_text_estimate(b->stride, b->items.size()));
                 b->has_text = backends[d]->score_alignments_6frames_wig(b->nucl.first, b->stride, b->col0, b->len, b->start_pos, b->chrom_len, chroms,
-                                                                        prm.power_threshold, f_power != nullptr, true, b->text_bytes, &b->n_scores);
+                                                                        prm.power_threshold, f_power != nullptr, true, b->text_mem.first, b->text_mem.second,
+                                                                        b->text_bytes, &b->n_scores);
                 if (b->has_text) {
                     uint64_t total = 0;
                     for (uint64_t v : b->text_bytes) total += v;
-                    b->text_mem = text_pool.get(static_cast<size_t>(total));
-                    char* dst[7];
-                    dst[0] = b->text_mem.first;
-                    for (int t = 1; t < 7; ++t) dst[t] = dst[t - 1] + b->text_bytes[t - 1];
-                    backends[d]->fetch_wig_text(dst);
+                    if (total > b->text_mem.second) {   // unusually long lines: the text waits on the device
+                        text_pool.put(b->text_mem);
+                        b->text_mem = text_pool.get(static_cast<size_t>(total));
+                        char* dst[7];
+                        dst[0] = b->text_mem.first;
+                        for (int t = 1; t < 7; ++t) dst[t] = dst[t - 1] + b->text_bytes[t - 1];
+                        backends[d]->fetch_wig_text(dst);
+                    }
                     pool.put(b->nucl);
                     b->nucl = {nullptr, 0};
                     return bw.lap();
                 }
+                text_pool.put(b->text_mem);
+                b->text_mem = {nullptr, 0};
             }
             if (need_raw) {
                 const size_t cap_scores = 2 * b->stride;  // six frames of len/3 codons each

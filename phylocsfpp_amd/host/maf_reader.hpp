@@ -75,6 +75,7 @@ public:
     MafFile& operator=(const MafFile&) = delete;
     const char* data() const { return data_; }
     size_t size() const { return size_; }
+    int fd() const { return fd_; }   // for positional reads that copy from the page cache without mapping it
 
 private:
     int fd_ = -1;

@@ -169,7 +169,15 @@ public:
         }
         return tail[1];
     }
-    bool next(Alignment& aln)
+    // A record where it lies in the mapped file: nothing is copied.  rows + l * len = species row l (len characters).
+    struct Record {
+        const char* chrom = nullptr;
+        uint32_t chrom_bytes = 0;
+        uint64_t start_pos = 0, chrom_len = 0;
+        uint32_t len = 0, n_rows = 0;
+        const char* rows = nullptr;
+    };
+    bool next_record(Record& r)
     {
         if (next_ >= stop_) return false;
         // nothing of the file is trusted: the record must lie inside the data section before any of it is read
@@ -186,15 +194,27 @@ public:
         if (head[1] > room || chrom_room > room) throw std::runtime_error("packed alignment file: bad record (chromosome name exceeds the file)");
         if (dims[1] != n_leaves_) throw std::runtime_error("packed alignment file: bad record (row count differs from the header's)");
         p += 32;
-        aln.chrom.assign(p, head[1]);
+        r.chrom = p;
+        r.chrom_bytes = head[1];
         p += chrom_room;
-        aln.start_pos = pos[0];
-        aln.chrom_len = pos[1];
+        r.start_pos = pos[0];
+        r.chrom_len = pos[1];
+        r.len = dims[0];
+        r.n_rows = dims[1];
+        if (static_cast<uint64_t>(r.len) * r.n_rows > room - chrom_room) throw std::runtime_error("packed alignment file: record exceeds the file");
+        r.rows = p;
+        return true;
+    }
+    bool next(Alignment& aln)
+    {
+        Record r;
+        if (!next_record(r)) return false;
+        aln.chrom.assign(r.chrom, r.chrom_bytes);
+        aln.start_pos = r.start_pos;
+        aln.chrom_len = r.chrom_len;
         aln.strand = '+';
-        const uint32_t len = dims[0], nl = dims[1];
-        if (static_cast<uint64_t>(len) * nl > room - chrom_room) throw std::runtime_error("packed alignment file: record exceeds the file");
-        aln.seqs.resize(nl);
-        for (uint32_t l = 0; l < nl; ++l) aln.seqs[l].assign(p + static_cast<size_t>(l) * len, len);
+        aln.seqs.resize(r.n_rows);
+        for (uint32_t l = 0; l < r.n_rows; ++l) aln.seqs[l].assign(r.rows + static_cast<size_t>(l) * r.len, r.len);
         return true;
     }
 

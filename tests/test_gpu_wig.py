@@ -104,6 +104,11 @@ def test_wig_text_equals_the_output_loop_on_the_downloaded_scores(model, oracle_
     mid, everything = _expected_text(alns, chroms, res, bls, 0.35), _expected_text(alns, chroms, res, bls, 0.0)
     assert mid[1].count(b"fixedStep") > everything[1].count(b"fixedStep") + 5
     assert mid[1].count(b"\n") - mid[1].count(b"fixedStep") < everything[1].count(b"\n") - everything[1].count(b"fixedStep") - 20
+    # the caller's buffer: none, too small (the text is fetched afterwards), exactly enough
+    total = sum(len(t) for t in _expected_text(alns, chroms, res, bls, 0.1))
+    for cap in (0, 100, total - 1, total):
+        got, _ = ctx.score_alignments_6frames_wig(nuc, alns, chroms, 0.1, text_capacity=cap)
+        assert got == _expected_text(alns, chroms, res, bls, 0.1), cap
     # one family of files only
     got, _ = ctx.score_alignments_6frames_wig(nuc, alns, chroms, 0.1, want_power=False)
     assert got[0] == b"" and got[1:] == _expected_text(alns, chroms, res, bls, 0.1)[1:]
@@ -169,6 +174,33 @@ def test_device_number_text_equals_printf(decimals, oracle_models, gpu_contexts)
             want = _trimmed(x, decimals)
         assert g == want.encode(), (float(x), g, want)
     assert n_big > 1000
+
+
+def test_text_buffer_estimate_too_small_writes_again(golden_dir):
+    """The text buffer is sized before the sizes are known; with an estimate of one byte per line the first write pass leaves lines
+    out and the call must notice and write again.  (The estimate is read once per process and a context's buffer only grows: one
+    process per value.)"""
+    import subprocess
+    import sys
+    code = r"""
+import hashlib, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import phylocsfpp_amd as pa
+m = pa.load_model(os.path.join(sys.argv[2], "models", "53birds"))
+rng = np.random.default_rng(3)
+nuc = np.frombuffer(b"ACGTacgt", dtype=np.uint8)[rng.integers(0, 8, size=(m.nl, 3000))]
+ctx = m.context(device=0, with_bls=True)
+text, frames = ctx.score_alignments_6frames_wig(nuc, [(0, 1000, 17, 10**6), (1000, 2000, 5000, 10**6)], ["chrA", "chrB"], 0.1)
+print("result", hashlib.sha256(b"|".join(text)).hexdigest(), frames, sum(map(len, text)))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = []
+    for est in ("1", "12"):
+        p = subprocess.run([sys.executable, "-c", code, root, golden_dir], capture_output=True, text=True, env=dict(os.environ, PCSF_WIG_TEXT_ESTIMATE=est))
+        assert p.returncode == 0, p.stderr[-2000:]
+        seen.append([l for l in p.stdout.splitlines() if l.startswith("result")][0])
+    assert seen[0] == seen[1] and int(seen[0].split()[3]) > 6 * 3000, seen
 
 
 def test_build_tracks_device_text_equals_host_text_on_a_synthetic_file(tmp_path):

@@ -24,11 +24,11 @@ for rep in 1 2; do   # the second run reads the file from the page cache
 done
 ( time $cli pack-maf $model $work/c4.maf $work/c4.pcsfbin ) 2> $out/pack.txt
 ls -l $work/c4.pcsfbin >> $out/pack.txt
-for rep in 1 2; do
-  $cli build-tracks --output $work/out_packed $model $work/c4.pcsfbin 2> $out/packed_run$rep.txt
-done
-# A/B: the seven files' text formatted by the host (round 3's stage 3) instead of on the device (csrc/wig.hip)
+# A/B between the two packed runs (run order matters on these boxes: the later run of two equal ones is the faster): the seven files'
+# text formatted by the host (round 3's stage 3) instead of on the device (csrc/wig.hip)
+$cli build-tracks --output $work/out_packed $model $work/c4.pcsfbin 2> $out/packed_run1.txt
 PCSF_DEVICE_WIG=0 $cli build-tracks --output $work/out_hostwig $model $work/c4.pcsfbin 2> $out/packed_hostwig_run.txt
+$cli build-tracks --output $work/out_packed $model $work/c4.pcsfbin 2> $out/packed_run2.txt
 same=yes; same_wig=yes
 for f in $work/out_text/*.wig; do
   cmp -s $f $work/out_packed/$(basename $f) || same=no

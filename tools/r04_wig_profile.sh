@@ -16,5 +16,10 @@ export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $work/prof -o wig -- $cli build-tracks --output $work/o1 $model $work/c.pcsfbin > $out/rocprof.log 2>&1
 f=$(find $work/prof -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp $f $out/kernel_stats.csv
-cat $out/run_wig1.txt $out/run_wig0.txt; head -12 $out/kernel_stats.csv
+# the same run with the host formatting the text: what the scoring kernels take without the wig kernels beside them
+export PCSF_DEVICE_WIG=0
+rocprofv3 --kernel-trace --stats --output-format csv -d $work/prof0 -o wig -- $cli build-tracks --output $work/o0 $model $work/c.pcsfbin > $out/rocprof_hostwig.log 2>&1
+f=$(find $work/prof0 -name '*kernel_stats.csv' | head -1)
+[ -n "$f" ] && cp $f $out/kernel_stats_hostwig.csv
+cat $out/run_wig1.txt $out/run_wig0.txt; cut -c1-150 $out/kernel_stats.csv | head -12; cut -c1-150 $out/kernel_stats_hostwig.csv | head -8
 rm -rf $work

@@ -6,6 +6,9 @@ set -u
 cd "$(dirname "$0")/.."
 W=${TMPDIR:-/tmp}/pcsf_startup; mkdir -p $W
 python tools/gen_synthetic_maf.py $W/s.maf --bases 1000000 > /dev/null
+# the floor program is built where it runs (tools/_build/ is not part of the tree)
+mkdir -p tools/_build
+[ -x tools/_build/hip_init_time ] || hipcc -O2 --offload-arch=gfx950 -o tools/_build/hip_init_time tools/hip_init_time.cpp > /dev/null 2>&1
 echo "== floor: a HIP process that initialises the runtime, makes a context, one allocation, one stream (three runs)"
 for k in 1 2 3; do { TIMEFORMAT="   process wall %R s (user %U, sys %S)"; time tools/_build/hip_init_time; } 2>&1; done
 echo "== phylocsf-amd build-tracks 58mammals <1 Mb, 90 MB MAF>, five runs"
