@@ -109,6 +109,7 @@ struct BlockEngine {
     DeviceBuffer d_codons;                 // [nl][leaf_stride] compact copy
     DeviceBuffer d_frag, d_leaf;   // table sets, one per evaluation of a run
     DeviceBuffer d_eig_r, d_eig_l, d_eig_lam, d_eig_basis, d_prior, d_ancw, d_eig_w, d_eig_c;  // eigen-systems, their root priors, L = R^T diag(w), c = L 1
+    DeviceBuffer d_eig_rf, d_eig_lf;   // prune_factored: both matrices once more in its A-operand order (kernels.h FactoredParams::eig_right_frag)
     DeviceBuffer d_eval_x;    // host engine + prune_tiles: the tree scale of every evaluation of a run (the kernel makes its own edge scales)
     std::vector<double> eval_x;
     float longest_branch = 0.0f;
@@ -366,6 +367,10 @@ struct BlockEngine {
         have_left = with_left;
         HIP_TRY(d_eig_r.reserve_keep(count * 4096 * sizeof(double), cap_eig * 4096 * sizeof(double), stream));
         if (with_left) HIP_TRY(d_eig_l.reserve_keep(count * 4096 * sizeof(double), cap_eig * 4096 * sizeof(double), stream));
+        if (!use_tiles) {
+            HIP_TRY(d_eig_rf.reserve_keep(count * 4096 * sizeof(double), cap_eig * 4096 * sizeof(double), stream));
+            HIP_TRY(d_eig_lf.reserve_keep(count * 4096 * sizeof(double), cap_eig * 4096 * sizeof(double), stream));
+        }
         HIP_TRY(d_eig_lam.reserve_keep(count * 64 * sizeof(double), cap_eig * 64 * sizeof(double), stream));
         HIP_TRY(d_prior.reserve_keep(count * 64 * sizeof(double), cap_eig * 64 * sizeof(double), stream));
         HIP_TRY(d_ancw.reserve_keep(count * 64 * sizeof(double), cap_eig * 64 * sizeof(double), stream));
@@ -381,6 +386,17 @@ struct BlockEngine {
         HIP_TRY(hipMemcpyAsync(d_eig_r.as<double>() + idx * 4096, es.right.data(), 4096 * sizeof(double), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(d_eig_l.as<double>() + idx * 4096, es.left.data(), 4096 * sizeof(double), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(d_eig_lam.as<double>() + idx * 64, es.lambda.data(), 64 * sizeof(double), hipMemcpyHostToDevice, stream));
+        if (!use_tiles) {
+            std::vector<double> rf(4096), lf(4096);
+            for (int i = 0; i < 4096; ++i) {
+                const int lane = i & 63, r = 16 * (i >> 10) + (lane & 15), col = 4 * ((i >> 6) & 15) + (lane >> 4);
+                rf[i] = es.right[static_cast<size_t>(r) * 64 + col];
+                lf[i] = es.left[static_cast<size_t>(r) * 64 + col];
+            }
+            HIP_TRY(hipMemcpyAsync(d_eig_rf.as<double>() + idx * 4096, rf.data(), 4096 * sizeof(double), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(d_eig_lf.as<double>() + idx * 4096, lf.data(), 4096 * sizeof(double), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipStreamSynchronize(stream));  // rf / lf are temporaries
+        }
         Vec w, pl, wl;
         if (pi) {
             Vec sw, swl;
@@ -664,6 +680,8 @@ struct BlockEngine {
                 fp.n_branches = static_cast<uint32_t>(n - 1);
                 fp.eig_right = d_eig_r.as<double>();
                 fp.eig_left = d_eig_l.as<double>();
+                fp.eig_right_frag = use_tiles ? nullptr : d_eig_rf.as<double>();
+                fp.eig_left_frag = use_tiles ? nullptr : d_eig_lf.as<double>();
                 fp.eig_w = d_eig_w.as<double>();
                 fp.prior = d_prior.as<double>();
                 fp.anc_weight = d_ancw.as<double>();
@@ -708,6 +726,8 @@ struct BlockEngine {
                 gp.n_jobs = static_cast<uint32_t>(eig_jobs.size());
                 gp.eig_right = d_eig_r.as<double>();
                 gp.eig_left = d_eig_l.as<double>();
+                gp.eig_right_frag = use_tiles ? nullptr : d_eig_rf.as<double>();
+                gp.eig_left_frag = use_tiles ? nullptr : d_eig_lf.as<double>();
                 gp.eig_lambda = d_eig_lam.as<double>();
                 gp.eig_basis = d_eig_basis.as<double>();
                 gp.prior = d_prior.as<double>();
@@ -997,6 +1017,8 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
     fp.n_branches = static_cast<uint32_t>(eng.n - 1);
     fp.eig_right = eng.d_eig_r.template as<double>();
     fp.eig_left = eng.d_eig_l.template as<double>();
+    fp.eig_right_frag = eng.use_tiles ? nullptr : eng.d_eig_rf.template as<double>();
+    fp.eig_left_frag = eng.use_tiles ? nullptr : eng.d_eig_lf.template as<double>();
     fp.eig_w = eng.d_eig_w.template as<double>();
     fp.prior = eng.d_prior.template as<double>();
     fp.anc_weight = eng.d_ancw.template as<double>();
@@ -1019,6 +1041,8 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
     gp.jobs = cp.eig_jobs;
     gp.eig_right = eng.d_eig_r.template as<double>();
     gp.eig_left = eng.d_eig_l.template as<double>();
+    gp.eig_right_frag = eng.use_tiles ? nullptr : eng.d_eig_rf.template as<double>();
+    gp.eig_left_frag = eng.use_tiles ? nullptr : eng.d_eig_lf.template as<double>();
     gp.eig_lambda = eng.d_eig_lam.template as<double>();
     gp.eig_basis = eng.d_eig_basis.template as<double>();
     gp.prior = eng.d_prior.template as<double>();
@@ -1034,6 +1058,10 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
     auto eigen_pointers = [&]() {
         fp.eig_right = eng.d_eig_r.template as<double>();
         fp.eig_left = eng.d_eig_l.template as<double>();
+        fp.eig_right_frag = eng.use_tiles ? nullptr : eng.d_eig_rf.template as<double>();
+        fp.eig_left_frag = eng.use_tiles ? nullptr : eng.d_eig_lf.template as<double>();
+    fp.eig_right_frag = eng.use_tiles ? nullptr : eng.d_eig_rf.template as<double>();
+    fp.eig_left_frag = eng.use_tiles ? nullptr : eng.d_eig_lf.template as<double>();
         fp.eig_w = eng.d_eig_w.template as<double>();
         fp.prior = eng.d_prior.template as<double>();
         fp.anc_weight = eng.d_ancw.template as<double>();
@@ -1041,6 +1069,8 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
         fp.eig_c = eng.use_tiles ? eng.d_eig_c.template as<double>() : nullptr;
         gp.eig_right = eng.d_eig_r.template as<double>();
         gp.eig_left = eng.have_left ? eng.d_eig_l.template as<double>() : nullptr;
+        gp.eig_right_frag = eng.use_tiles ? nullptr : eng.d_eig_rf.template as<double>();
+        gp.eig_left_frag = eng.use_tiles ? nullptr : eng.d_eig_lf.template as<double>();
         gp.eig_lambda = eng.d_eig_lam.template as<double>();
         gp.eig_basis = eng.d_eig_basis.template as<double>();
         gp.basis_slots = MLE ? 0u : transient0;

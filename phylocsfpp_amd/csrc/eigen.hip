@@ -820,6 +820,15 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
         if (L) L[idx] = V[c * LD + r] * root[c];    // left[k][i],  k = r, i = c
         if (basis) basis[idx] = V[r * LD + c];
     }
+    if (p.eig_right_frag) {   // ... and in prune_factored's A-operand order (kernels.h FactoredParams): coalesced loads for every tile that uses the system
+        double* __restrict__ Rf = p.eig_right_frag + static_cast<size_t>(job.eig) * 4096;
+        double* __restrict__ Lf = p.eig_left_frag + static_cast<size_t>(job.eig) * 4096;
+        for (int idx = tid; idx < 4096; idx += NT) {
+            const int lane = idx & 63, r = 16 * (idx >> 10) + (lane & 15), c = 4 * ((idx >> 6) & 15) + (lane >> 4);
+            Rf[idx] = iroot[r] * V[r * LD + c];
+            Lf[idx] = V[c * LD + r] * root[c];
+        }
+    }
     if (tid < 64) lam[tid] = A[tid * LD + tid];
     // equilibrium: left eigenvector of the eigenvalue closest to zero, scaled to sum 1 (index order)
     if (tid == 0) {

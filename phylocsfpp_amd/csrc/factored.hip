@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
@@ -161,10 +162,20 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
     const double* __restrict__ Rg = p.eig_right + static_cast<size_t>(job.eig) * 4096;
     const double* __restrict__ Lg = p.eig_left + static_cast<size_t>(job.eig) * 4096;
     double RA[16], LA[16];
+    if (p.eig_right_frag) {   // the same values from the images stored in this order: 512 contiguous bytes per wave and k-step
+        const double* __restrict__ Rf = p.eig_right_frag + static_cast<size_t>(job.eig) * 4096 + wave * 1024 + lane;
+        const double* __restrict__ Lf = p.eig_left_frag + static_cast<size_t>(job.eig) * 4096 + wave * 1024 + lane;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        RA[q] = Rg[(16 * wave + sj) * 64 + 4 * q + g];
-        LA[q] = Lg[(16 * wave + sj) * 64 + 4 * q + g];
+        for (int q = 0; q < 16; ++q) {
+            RA[q] = Rf[64 * q];
+            LA[q] = Lf[64 * q];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            RA[q] = Rg[(16 * wave + sj) * 64 + 4 * q + g];
+            LA[q] = Lg[(16 * wave + sj) * 64 + 4 * q + g];
+        }
     }
     // (b) the static facts of ops 64 k + lane (schedule.hpp `program_facts`; trees of at most 128 leaves)
     const int n_ops = static_cast<int>(p.n_ops);
@@ -639,9 +650,12 @@ hipError_t launch_edge_scale(const ExpmEval* d_evals, uint32_t n_evals, uint32_t
     return hipGetLastError();
 }
 
-hipError_t launch_prune_factored(const FactoredParams& p, hipStream_t stream)
+hipError_t launch_prune_factored(const FactoredParams& params, hipStream_t stream)
 {
-    if (p.n_jobs == 0) return hipSuccess;
+    if (params.n_jobs == 0) return hipSuccess;
+    FactoredParams p = params;
+    static const bool strided = [] { const char* v = getenv("PCSF_EIGEN_FRAG"); return v && v[0] == '0'; }();   // A/B: the operands from the row-major images
+    if (strided) p.eig_right_frag = p.eig_left_frag = nullptr;
     const size_t lds = 2 * 4 * 2 * 64 * 16 + 2 * 4 * 16 * 8 + 64 * 8 + ((static_cast<size_t>(p.n_ops) + 63) & ~size_t(63)) * 4 +
                        ((static_cast<size_t>(p.n_edges) + 3) & ~size_t(3)) * 4 + 128 * 4 + static_cast<size_t>(p.n_leaves) * 17 + 128;
     if (lds > 64 * 1024) return hipErrorInvalidValue;

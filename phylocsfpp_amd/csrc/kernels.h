@@ -139,6 +139,11 @@ struct FactoredParams {
     uint32_t n_branches;
     const double* eig_right;    // [n_eig][64*64]
     const double* eig_left;     // [n_eig][64*64]
+    // the same two matrices in the order prune_factored's waves take them as MFMA A operands (may be null: strided loads from the
+    // row-major images): element ((w * 16 + q) * 64 + lane) = M[16 w + (lane & 15)][4 q + (lane >> 4)] -- a wave's 16 loads are
+    // 512 contiguous bytes each instead of 64 pieces of 8
+    const double* eig_right_frag;
+    const double* eig_left_frag;
     const double* eig_w;        // [n_eig][4][16] lane order: w = root / iroot of the symmetrisation, L = R^T diag(w) (tiles.hip only)
     const double* prior;        // [n_eig][4][16] lane order
     const double* anc_weight;   // [n_eig][4][16] lane order (read only if out_anc)
@@ -258,6 +263,8 @@ struct EigenParams {
     uint32_t n_jobs;
     double* eig_right;    // [n_eig][64*64]
     double* eig_left;     // [n_eig][64*64] (may be null: prune_tiles uses L = R^T diag(w))
+    double* eig_right_frag;   // [n_eig][64*64] in prune_factored's A-operand order (FactoredParams; may be null)
+    double* eig_left_frag;
     double* eig_lambda;   // [n_eig][64]
     double* eig_basis;    // [basis_slots][64*64] orthogonal eigenvector matrix of the symmetrised rate matrix (warm starts; may be null)
     uint32_t basis_slots; // eigen-systems >= this index keep no basis (nothing warm-starts from them: the probes of a round that are not held); 0 = all do

@@ -12,11 +12,13 @@ import argparse
 import re
 
 
-def tile(src, dst, copies, shift=1_100_000):
+def tile(src, dst, copies, shift=1_100_000, chrom_len=None):
+    """chrom_len: the reference chromosome length to write (default: twice the end of the last copy, + 200 kb); a caller that compares
+    the copies with a run on one of them passes the same value to both (the frames of the - strand are counted from the chromosome's end)"""
     class A:
         pass
     args = A()
-    args.src, args.dst, args.copies, args.shift = src, dst, copies, shift
+    args.src, args.dst, args.copies, args.shift, args.chrom_len = src, dst, copies, shift, chrom_len
     return _tile(args)
 
 
@@ -26,6 +28,7 @@ def main():
     ap.add_argument("dst")
     ap.add_argument("--copies", type=int, default=100)
     ap.add_argument("--shift", type=int, default=1_100_000)
+    ap.add_argument("--chrom-len", type=int, default=None, help="reference chromosome length to write (default: from the last copy's end)")
     _tile(ap.parse_args())
 
 
@@ -43,7 +46,7 @@ def _tile(args):
         max_end = max(max_end, int(m.group(2)) + size)
         at = m.end()
     tail = body[at:]
-    chrom_len = str(2 * (max_end + (args.copies - 1) * args.shift + 100_000)).encode()
+    chrom_len = str(args.chrom_len if getattr(args, "chrom_len", None) else 2 * (max_end + (args.copies - 1) * args.shift + 100_000)).encode()
     with open(args.dst, "wb") as f:
         f.write(header)
         for k in range(args.copies):
