@@ -1570,7 +1570,7 @@ int score_blocks_impl(pcsf_ctx* c, int algo, const uint8_t* codons, const uint64
         const LookaheadPolicy look = lookahead_policy(eager);
         const size_t slots = static_cast<size_t>(algo == PCSF_MLE ? 2 * look.max_points : look.max_points);
         const size_t per_block = slots * static_cast<size_t>(c->n_nodes - 1) * 64 * sizeof(double) +
-                                 (algo == PCSF_OMEGA ? (N_ROLES + static_cast<size_t>(look.max_points)) * size_t(3 * 4096 + 5 * 64) * sizeof(double) : 0) +
+                                 (algo == PCSF_OMEGA ? (N_ROLES + static_cast<size_t>(look.max_points)) * size_t((tiles ? 3 : 5) * 4096 + 5 * 64) * sizeof(double) : 0) +   // R, L, basis (+ prune_factored's two fragment-ordered copies)
                                  (algo == PCSF_MLE ? 2 : 1) * STORE_ENTRIES * sizeof(StoreEntry);
         chunk = std::max<size_t>(64, (size_t(48) << 30) / per_block);
         if (std::getenv("PCSF_FACTORED_MAX_TILES")) {
