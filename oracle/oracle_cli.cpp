@@ -11,8 +11,16 @@ namespace {
 
 class OracleBackend : public pcsf_host::ScoringBackend {
 public:
-    explicit OracleBackend(const pcsf_host::Model& m) : model_(new po_model)
+    explicit OracleBackend(const pcsf_host::Model& m) : host_model_(&m), model_(new po_model)
     {
+        // tests: the driver's "the backend computes the branch-length scores from the uploaded rows" form -- which also switches its
+        // stage 1 to measuring the alignments and parsing them straight into the batch matrices -- on the CPU
+        const char* v = std::getenv("PCSF_ORACLE_BACKEND_BLS");
+        bls_from_rows_ = v && v[0] == '1';
+        // tests of the driver's pipeline alone: a "score" that is a cheap checksum of the codon column (every byte of every batch matrix
+        // still decides the output files; a 1 GB input takes seconds)
+        const char* f = std::getenv("PCSF_ORACLE_BACKEND_FAKE");
+        fake_scores_ = f && f[0] == '1';
         po_tree& t = model_->tree;
         memset(&t, 0, sizeof t);
         t.n = m.n_nodes;
@@ -31,6 +39,15 @@ public:
     }
     void score_sites_fixed(const uint8_t* codons, size_t n_sites, size_t leaf_stride, double* out) override
     {
+        if (fake_scores_) {
+            const size_t nl = static_cast<size_t>(model_->tree.nl);
+            for (size_t s = 0; s < n_sites; ++s) {
+                uint64_t h = 1469598103934665603ull;
+                for (size_t l = 0; l < nl; ++l) h = (h ^ codons[l * leaf_stride + s]) * 1099511628211ull;
+                out[s] = static_cast<double>(static_cast<int64_t>(h % 200001) - 100000) / 1000.0;
+            }
+            return;
+        }
         // one "alignment" per 4096 sites so that OpenMP has work; results do not depend on the split
         std::vector<uint64_t> off;
         for (size_t s = 0; s < n_sites; s += 4096) off.push_back(s);
@@ -44,7 +61,29 @@ public:
         po_run_blocks(model_.get(), algo, codons, offsets, n_blocks, leaf_stride, compute_anc ? 1 : 0, seed, phylo, anc, 0);
     }
 
+    bool device_bls() const override { return bls_from_rows_; }
+    size_t score_alignments_6frames(int n_leaves, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0, const std::vector<uint32_t>& len,
+                                    const std::vector<uint64_t>& start_pos, const std::vector<uint64_t>& chrom_len, double* out, size_t out_capacity,
+                                    std::vector<uint64_t>& offsets, std::vector<uint32_t>& n_codons, double* bls_out) override
+    {
+        if (bls_out) {   // the host's own branch-length score on the rows of every alignment (like the power track's loop in the driver)
+            std::fill(bls_out, bls_out + row_stride, 0.0);
+            pcsf_host::BranchLengthScore bls(*host_model_);
+            pcsf_host::Alignment aln;
+            std::vector<double> v;
+            for (size_t k = 0; k < col0.size(); ++k) {
+                aln.seqs.assign(static_cast<size_t>(n_leaves), std::string());
+                for (int l = 0; l < n_leaves; ++l) aln.seqs[static_cast<size_t>(l)].assign(nucl + static_cast<size_t>(l) * row_stride + col0[k], len[k]);
+                bls.per_base(aln, &v);
+                std::copy(v.begin(), v.end(), bls_out + col0[k]);
+            }
+        }
+        return pcsf_host::ScoringBackend::score_alignments_6frames(n_leaves, nucl, row_stride, col0, len, start_pos, chrom_len, out, out_capacity, offsets, n_codons, nullptr);
+    }
+
 private:
+    const pcsf_host::Model* host_model_;
+    bool bls_from_rows_ = false, fake_scores_ = false;
     std::unique_ptr<po_model> model_;
 };
 

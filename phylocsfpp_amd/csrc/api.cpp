@@ -484,7 +484,13 @@ int pcsf_create(pcsf_ctx** out, const pcsf_model_desc* m, int device_id)
         pcsf::DeviceBuffer d_gaps;
         const size_t nl = static_cast<size_t>(c->n_leaves);
         if ((e = c->d_gap_tab.reserve(doubles * sizeof(double))) != hipSuccess || (e = d_gaps.reserve(nl * 64)) != hipSuccess ||
-            (e = hipMemset(c->d_gap_tab.ptr, 0, doubles * sizeof(double))) != hipSuccess || (e = hipMemset(d_gaps.ptr, 64, nl * 64)) != hipSuccess) {
+            // on the stream the kernel below runs on: a hipMemset is a fill kernel on the NULL stream that returns before it has run, and
+            // c->stream (non-blocking) does not wait for the null stream -- on a device busy with other contexts' work the kernel read
+            // the all-gap columns before they were written and the table was zeroed after it had been filled: a context set up beside
+            // a running one (build-tracks --devices, two contexts per GPU) then scored the work-groups that skip subtrees wrongly
+            // (found by tests/test_gpu_full_size.py: four contexts on one GPU)
+            (e = hipMemsetAsync(c->d_gap_tab.ptr, 0, doubles * sizeof(double), c->stream)) != hipSuccess ||
+            (e = hipMemsetAsync(d_gaps.ptr, 64, nl * 64, c->stream)) != hipSuccess) {
             g_create_error = std::string("pcsf_create (all-gap messages): ") + hipGetErrorString(e);
             return PCSF_ERR_HIP;
         }
@@ -546,7 +552,7 @@ int pcsf_debug_stamps(pcsf_ctx* c, int block, unsigned long long* out, int cap)
     if (!out) {  // arm
         if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
         if ((e = c->d_stamps.reserve(n * 8)) != hipSuccess) return c->hip_fail(e, "hipMalloc(stamps)");
-        if ((e = hipMemset(c->d_stamps.ptr, 0, n * 8)) != hipSuccess) return c->hip_fail(e, "hipMemset(stamps)");
+        if ((e = hipMemsetAsync(c->d_stamps.ptr, 0, n * 8, c->stream)) != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess) return c->hip_fail(e, "hipMemset(stamps)");
         c->stamp_block = static_cast<uint32_t>(block);
         return static_cast<int>(n);
     }

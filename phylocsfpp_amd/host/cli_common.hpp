@@ -121,12 +121,13 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend, b
         return (bad || !ascending) ? 1 : 0;
     }
     if (cmd == "dump-alignments") {  // diagnostics/tests: what the MAF reader yields (build-tracks semantics unless --blocks 1)
-        bool blocks = false;
+        bool blocks = false, matrix = false;
         size_t jobs = 1;
         int j = 2;
         for (; j + 1 < argc && strncmp(argv[j], "--", 2) == 0; j += 2) {
             if (std::string(argv[j]) == "--blocks") blocks = parse_bool(argv[j + 1]);
             else if (std::string(argv[j]) == "--jobs") jobs = static_cast<size_t>(atoll(argv[j + 1]));  // byte-range jobs, concatenated in order
+            else if (std::string(argv[j]) == "--matrix") matrix = parse_bool(argv[j + 1]);   // measure() + fill() into a matrix instead of next()
             else return usage(argv[0]);
         }
         if (argc - j < 2) return usage(argv[0]);
@@ -141,6 +142,34 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend, b
                 const size_t nj = std::max<size_t>(jobs, 1);
                 MafReader rd(file, file.size() * job / nj, file.size() * (job + 1) / nj, model.name_to_leaf, model.n_leaves, !blocks, false);
                 Alignment aln;
+                if (matrix) {   // the job's alignments measured first, then parsed side by side into one matrix (what build-tracks does)
+                    std::vector<AlignmentSpan> spans;
+                    AlignmentSpan sp;
+                    while (rd.measure(sp)) spans.push_back(sp);
+                    size_t stride = 7;   // columns that belong to no alignment, left and right: nothing may be written there
+                    std::vector<size_t> col0;
+                    for (const AlignmentSpan& a : spans) {
+                        col0.push_back(stride);
+                        stride += a.len + 3;
+                    }
+                    std::vector<char> m(static_cast<size_t>(model.n_leaves) * stride, '#');
+                    for (size_t k = spans.size(); k-- > 0;) rd.fill(spans[k], m.data() + col0[k], stride);   // any order
+                    size_t untouched = 0;
+                    for (char c : m) untouched += c == '#';
+                    size_t expect = static_cast<size_t>(model.n_leaves) * stride;
+                    for (const AlignmentSpan& a : spans) expect -= static_cast<size_t>(model.n_leaves) * a.len;
+                    if (untouched != expect) {
+                        fprintf(stderr, "error: fill() wrote outside its alignments' columns (%zu padding bytes left of %zu)\n", untouched, expect);
+                        return 1;
+                    }
+                    for (size_t k = 0; k < spans.size(); ++k) {
+                        const AlignmentSpan& a = spans[k];
+                        printf("%s\t%" PRIu64 "\t%zu\t%c\t%" PRIu64, a.chrom.c_str(), a.start_pos, static_cast<size_t>(a.len), a.strand, a.chrom_len);
+                        for (int l = 0; l < model.n_leaves; ++l) printf("\t%.*s", static_cast<int>(a.len), m.data() + static_cast<size_t>(l) * stride + col0[k]);
+                        printf("\n");
+                    }
+                    continue;
+                }
                 while (rd.next(aln)) {
                     printf("%s\t%" PRIu64 "\t%zu\t%c\t%" PRIu64, aln.chrom.c_str(), aln.start_pos, aln.length(), aln.strand, aln.chrom_len);
                     for (const auto& r : aln.seqs) printf("\t%s", r.c_str());

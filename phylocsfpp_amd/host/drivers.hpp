@@ -864,6 +864,10 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         uint32_t len = 0;
         std::vector<std::string> seqs;
         const char* rows = nullptr;        // packed input: the species rows where they lie in the mapped file ([n_leaves][len]) instead of seqs
+        AlignmentSpan span;                // text input, rows not needed on the host: where the alignment lies in the file (measured, not read)
+        bool measured = false;
+        char* dst = nullptr;               // ... and where its first column goes in its batch's matrix (row stride dst_stride)
+        size_t dst_stride = 0;
         std::vector<double> bls_host;      // per-base branch-length scores when computed on the host
         const double* bls = nullptr;       // [len]: bls_host, or the alignment's columns of its batch's device result
     };
@@ -946,6 +950,8 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         return jobs;
     };
 
+    // PCSF_DIRECT_PARSE=0: text input through strings and a packing copy (rounds 1-3; A/B and tests -- same files)
+    const bool direct_parse_off = [] { const char* v = std::getenv("PCSF_DIRECT_PARSE"); return v && v[0] == '0'; }();
     MafFile file(maf_path);
     // a packed alignment file (pack-maf, packed_reader.hpp) holds the reader's alignments ready-made: stage 1 only copies rows
     const bool packed = is_packed_file(file);
@@ -1021,6 +1027,10 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         const size_t n_jobs = std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(threads) * 4, (w1 - w0 + (1 << 16) - 1) >> 16));
         pw->jobs.resize(n_jobs);
         std::vector<double> job_read(n_jobs, 0.0), job_bls(n_jobs, 0.0);
+        // text input whose rows nothing on the host needs: the jobs only MEASURE their alignments (reference rows alone), and once every
+        // alignment has its columns the same readers parse the rows straight into the batch matrices -- no strings, no packing copy
+        const bool direct = !packed && dev_bls && need_raw && !direct_parse_off;
+        std::vector<std::unique_ptr<MafReader>> direct_readers(direct ? n_jobs : 0);
         parallel_for(n_jobs, threads, [&](size_t j) {
             const size_t b = w0 + (w1 - w0) * j / n_jobs, e = w0 + (w1 - w0) * (j + 1) / n_jobs;
             std::unique_ptr<MafReader> text_reader;
@@ -1030,6 +1040,20 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             BranchLengthScore bls(model);
             Alignment aln;
             StopWatch jw;
+            if (direct) {
+                Item it;
+                while (text_reader->measure(it.span)) {
+                    it.chrom = it.span.chrom;
+                    it.start_pos = it.span.start_pos;
+                    it.chrom_len = it.span.chrom_len;
+                    it.len = it.span.len;
+                    it.measured = true;
+                    pw->jobs[j].push_back(it);
+                }
+                direct_readers[j] = std::move(text_reader);
+                job_read[j] += jw.lap();
+                return;
+            }
             if (packed && dev_bls && need_raw) {
                 // nothing of a record is needed on the host: its rows go from the mapped file straight into the batch matrix
                 PackedReader::Record r;
@@ -1086,6 +1110,13 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             }
             if (!need_raw) continue;
             bt.nucl = pool.get(nl * bt.stride);
+            if (direct) {   // filled below, by the jobs that measured the alignments
+                for (Item* p : bt.items) {
+                    p->dst = bt.nucl.first + p->col0;
+                    p->dst_stride = bt.stride;
+                }
+                continue;
+            }
             if (!bt.items.empty() && bt.items[0]->rows) {
                 // packed input: one positional scatter read per record, page cache -> batch matrix.  (Copying out of the mapping instead
                 // faults its pages in from sixteen threads at once, neighbours in the same page-table pages: 0.39 -> 1.1 s per 100 Mb.)
@@ -1113,6 +1144,10 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             }
             for (Item* p : bt.items) std::vector<std::string>().swap(p->seqs);  // the rows now live in the batch matrix
         }
+        if (direct && need_raw)
+            parallel_for(n_jobs, threads, [&](size_t j) {
+                for (const Item& it : pw->jobs[j]) direct_readers[j]->fill(it.span, it.dst, it.dst_stride);
+            });
         pw->pack = pack.lap();
         return pw;
     };

@@ -35,3 +35,15 @@ def test_library_exports_every_declared_symbol():
     assert pa.load_library() is not None
     lib.pcsf_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.pcsf_version()      # host-only call: no device is touched
+
+
+def test_wig_text_estimate_needs_no_device():
+    """pcsf_wig_text_estimate: a host-side bound the caller sizes its text buffer with before pcsf_score_alignments_6frames_wig"""
+    import ctypes as C
+    import phylocsfpp_amd as pa
+    lib = C.CDLL(pa._LIB_PATH)
+    lib.pcsf_wig_text_estimate.argtypes = [C.c_size_t, C.c_size_t]
+    lib.pcsf_wig_text_estimate.restype = C.c_size_t
+    small, big = lib.pcsf_wig_text_estimate(1000, 1), lib.pcsf_wig_text_estimate(1_000_000, 120)
+    # at least 12 bytes per possible line (six frames of n / 3 codons and the power track's n / 3) and a header per file and alignment
+    assert small >= 12 * (2000 + 333) + 7 * 60 and big >= 12 * (2_000_000 + 333_333) + 7 * 120 * 60 and big < 40_000_000

@@ -19,15 +19,16 @@ def _cli():
     return CLI
 
 
-# branch-length scores from the device kernel (default) / on the host; the files' text formatted on the device (default) / by the host
-@pytest.mark.parametrize("host_bls,device_wig", [("0", "1"), ("0", "0"), ("1", "1")])
-def test_build_tracks_golden_wigs_on_gpu(tmp_path, host_bls, device_wig):
+# branch-length scores from the device kernel (default) / on the host; the files' text formatted on the device (default) / by the host;
+# the MAF's rows parsed straight into the batch matrices (default) / through strings and a packing copy
+@pytest.mark.parametrize("host_bls,device_wig,direct_parse", [("0", "1", "1"), ("0", "0", "1"), ("1", "1", "1"), ("0", "1", "0")])
+def test_build_tracks_golden_wigs_on_gpu(tmp_path, host_bls, device_wig, direct_parse):
     maf = tmp_path / "galGal6.maf"
     with gzip.open(os.path.join(GOLD, "build-tracks", "galGal6_chr22_25_28_each_30k_bases.maf.gz"), "rb") as fi, open(maf, "wb") as fo:
         shutil.copyfileobj(fi, fo)
     out = tmp_path / "out"
     subprocess.check_call([_cli(), "build-tracks", "--output", str(out), "--host-bls", host_bls, os.path.join(GOLD, "models", "53birds"), str(maf)],
-                          env=dict(os.environ, PCSF_DEVICE_WIG=device_wig))
+                          env=dict(os.environ, PCSF_DEVICE_WIG=device_wig, PCSF_DIRECT_PARSE=direct_parse))
     for n in ["PhyloCSFpower"] + ["PhyloCSFRaw%s%d" % (s, f) for s in "+-" for f in (1, 2, 3)]:
         want = gzip.open(os.path.join(GOLD, "build-tracks", n + ".wig.gz"), "rb").read()
         got = open(out / (n + ".wig"), "rb").read()

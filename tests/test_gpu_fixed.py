@@ -149,6 +149,63 @@ def test_all_gap_subtrees_are_skipped_without_changing_a_score(oracle_models, mo
     assert np.array_equal(got["1"], got["0"])
 
 
+def test_a_context_set_up_beside_a_busy_one_scores_like_it(golden_dir):
+    """Regression (round 4; found by tests/test_gpu_full_size.py with four contexts on one GPU): pcsf_create filled the all-gap columns
+    and zeroed the table of all-gap messages with hipMemset -- a fill kernel on the NULL stream that returns before it has run -- and
+    recorded the messages with a kernel on the context's non-blocking stream, which does not wait for the null stream.  On an idle device
+    the fills ran first; on a device busy with another context's scoring the kernel could overtake them and the new context then scored
+    every work-group that skips an all-gap subtree wrongly (-inf, or finite and wrong).  The end-to-end test reproduced it in four of nine
+    runs with the old library and in none of thirteen with the fix, same boxes.  Here the same situation through the binding: contexts
+    are created, four at a time on threads of their own, while two threads keep the device busy; each must score a drop-out-heavy batch
+    exactly like the first context.  (This form has not reproduced the failure by itself: it guards the property, the end-to-end test
+    the bug.)"""
+    import threading
+    import phylocsfpp_amd as pa
+    m = pa.load_model(os.path.join(golden_dir, "models", "58mammals"))
+    from phylocsfpp_amd import synth
+    cod = synth.synthetic_codon_columns(m.child1, m.child2, m.branch_len, m.S_c, m.pi_c, m.S_nc, m.pi_nc, 64 * 700, seed=3, dropout=0.6, gap_rate=0.05)
+    busy = np.tile(synth.synthetic_codon_columns(m.child1, m.child2, m.branch_len, m.S_c, m.pi_c, m.S_nc, m.pi_nc, 100_000, seed=4, dropout=0.3), (1, 12))   # 1.2 M sites: ~16 ms of kernel per call
+    first = m.context(device=0)
+    want = first.score_sites_fixed(cod)
+    assert np.isfinite(want).all()
+    second = m.context(device=0)
+    stop = threading.Event()
+
+    def keep_busy(ctx):                    # (the C call releases the interpreter lock)
+        while not stop.is_set():
+            ctx.score_sites_fixed(busy)
+    threads = [threading.Thread(target=keep_busy, args=(c,)) for c in (first, second)]
+    for t in threads:
+        t.start()
+    others, bad = [], []
+    lock = threading.Lock()
+
+    def make_and_score(k):                 # like build-tracks --devices: several contexts set up at once, on threads of their own
+        c = m.context(device=0)            # its set-up work queues up behind the busy contexts' (and the other new contexts')
+        got = c.score_sites_fixed(cod)
+        with lock:
+            others.append(c)
+            if not np.array_equal(got, want):
+                bad.append((k, int((got != want).sum()), int((~np.isfinite(got)).sum())))
+    try:
+        for rnd in range(3):
+            makers = [threading.Thread(target=make_and_score, args=(4 * rnd + k,)) for k in range(4)]
+            for t in makers:
+                t.start()
+            for t in makers:
+                t.join()
+    finally:
+        stop.set()
+        for t in threads:
+            t.join()
+    second.close()
+    assert not bad, bad
+    for c in others:
+        assert np.array_equal(c.score_sites_fixed(cod), want)
+        c.close()
+    first.close()
+
+
 def test_bench_sized_batch_of_two_million_sites(oracle_models, gpu_contexts):
     """BASELINE.json configs[2]'s batch as bench.py scores it (2,000,000 codon-frames in one call, 31,250 work-groups): the oracle on a
     strided sample of 64,516 sites, and for ALL sites the size-independent property that a site's score depends on its column alone --

@@ -87,6 +87,11 @@ def test_one_gpus_share_of_the_node_run_equals_the_oracle_copy_by_copy(tmp_path,
         parts = _copies_of(got, copies, "bed" if n.endswith(".bed") else "wig")
         ref = _copies_of(want, 1, "bed" if n.endswith(".bed") else "wig")[0]
         for k, part in enumerate(parts):
+            if part != ref and os.environ.get("PCSF_TEST_DUMP"):
+                os.makedirs(os.environ["PCSF_TEST_DUMP"], exist_ok=True)
+                open(os.path.join(os.environ["PCSF_TEST_DUMP"], "%s.copy%d.got" % (n, k)), "wb").write(part)
+                open(os.path.join(os.environ["PCSF_TEST_DUMP"], "%s.ref" % n), "wb").write(ref)
+                open(os.path.join(os.environ["PCSF_TEST_DUMP"], "log.txt"), "w").write(log)
             assert part == ref, (n, k, len(part), len(ref))
         total += len(got)
     assert total > copies * 1_000_000

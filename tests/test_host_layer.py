@@ -21,6 +21,8 @@ def cli():
 
 def _dump(cli, path, blocks=False):
     out = subprocess.check_output([cli, "dump-alignments"] + (["--blocks", "1"] if blocks else []) + [MODEL, path], text=True)
+    # the same alignments measured and then parsed straight into a matrix (MafReader::measure / fill: what build-tracks does with text input)
+    assert subprocess.check_output([cli, "dump-alignments", "--matrix", "1"] + (["--blocks", "1"] if blocks else []) + [MODEL, path], text=True) == out
     rows = []
     for line in out.splitlines():
         f = line.split("\t")
@@ -206,7 +208,9 @@ def test_reduced_model_scores_like_the_full_model_on_the_same_rows(cli, tmp_path
 
 # ---- parallel ingest: byte-range jobs (reference src/parallel_file_reader.hpp:283-350,396-425) and fast text ----
 def _dump_text(cli, model, path, jobs):
-    return subprocess.check_output([cli, "dump-alignments", "--jobs", str(jobs), model, path], text=True)
+    out = subprocess.check_output([cli, "dump-alignments", "--jobs", str(jobs), model, path], text=True)
+    assert subprocess.check_output([cli, "dump-alignments", "--matrix", "1", "--jobs", str(jobs), model, path], text=True) == out   # measure() + fill()
+    return out
 
 
 def test_byte_range_jobs_do_not_change_the_alignments(cli, tmp_path):

@@ -65,7 +65,11 @@ CASES = {"corner": ("53birds", True), "corner_blocks": ("53birds", False), "gal"
 
 def _dump(case, path, jobs=1):
     model, concat = CASES[case]
-    return subprocess.check_output([CLI, "dump-alignments", "--jobs", str(jobs)] + ([] if concat else ["--blocks", "1"]) + [os.path.join(MODELS, model), path], text=True)
+    tail = ([] if concat else ["--blocks", "1"]) + [os.path.join(MODELS, model), path]
+    out = subprocess.check_output([CLI, "dump-alignments", "--jobs", str(jobs)] + tail, text=True)
+    # the reader's second form (alignments measured, then parsed straight into a matrix: build-tracks with text input) gives the same rows
+    assert subprocess.check_output([CLI, "dump-alignments", "--matrix", "1", "--jobs", str(jobs)] + tail, text=True) == out
+    return out
 
 
 def _hashed(text, plain):
