@@ -249,6 +249,36 @@ def test_printed_value_bins_of_the_smoothing_pass_equal_the_printing_code(cli):
     assert "ascending: yes" in out and out.strip().endswith(" 0 mismatches"), out
 
 
+def test_rows_parsed_straight_into_the_batch_matrices_give_the_same_tracks(cli, tmp_path):
+    """The driver's stage 1 in the form it takes with a backend that computes the branch-length scores itself (the GPU): text input is
+    measured first (MafReader::measure: reference rows only) and then parsed straight into the batch matrices (fill) -- no strings, no
+    packing copy.  Run here on the CPU: the test backend computes the branch-length scores from the matrix rows
+    (PCSF_ORACLE_BACKEND_BLS=1) and replaces the scores by a checksum of every codon column (PCSF_ORACLE_BACKEND_FAKE=1: every byte of
+    every matrix still decides the seven files).  A generated alignment across the 1 Mb break point, windows of 150 kB and batches of
+    ~3,000 columns on three backends against the strings-and-copy form (PCSF_DIRECT_PARSE=0) and the default one-window run."""
+    import sys
+    syn = tmp_path / "syn.maf"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_synthetic_maf.py"), str(syn), "--bases", "60000", "--start", "970000",
+                           "--seed", "13"], stdout=subprocess.DEVNULL)
+    model = os.path.join(ROOT, "tests", "golden", "models", "58mammals")
+    env = dict(os.environ, PCSF_ORACLE_BACKEND_FAKE="1")
+    outs = {}
+    for name, extra, more in (("plain", [], {}),
+                              ("direct", ["--devices", "0,0,0", "--batch-sites", "6000", "--window-bytes", "150000", "--threads", "5"], {"PCSF_ORACLE_BACKEND_BLS": "1"}),
+                              ("strings", ["--devices", "0,0,0", "--batch-sites", "6000", "--window-bytes", "150000", "--threads", "5"],
+                               {"PCSF_ORACLE_BACKEND_BLS": "1", "PCSF_DIRECT_PARSE": "0"})):
+        out = tmp_path / name
+        subprocess.check_call([cli, "build-tracks", "--output", str(out)] + extra + [model, str(syn)], stderr=subprocess.DEVNULL, env=dict(env, **more))
+        outs[name] = out
+    names = sorted(os.listdir(outs["plain"]))
+    assert len(names) == 7
+    for n in names:
+        want = open(outs["plain"] / n, "rb").read()
+        assert len(want) > 10000
+        assert open(outs["direct"] / n, "rb").read() == want, n
+        assert open(outs["strings"] / n, "rb").read() == want, n
+
+
 def test_several_backends_small_batches_and_windows_do_not_change_the_output(cli, tmp_path):
     """build-tracks with three scoring backends (--devices; one per GPU in production), batches of ~2,000 columns and
     100 kB windows -- dozens of batches retired in order behind concurrent backends -- against the one-batch run; and
