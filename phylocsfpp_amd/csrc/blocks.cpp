@@ -955,7 +955,9 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
     HIP_TRY(d_lnz.reserve(std::max<size_t>(1, n_sites) * P * sizeof(double)));
     if (want_anc) HIP_TRY(d_anc.reserve(std::max<size_t>(1, n_sites) * P * sizeof(double)));
     HIP_TRY(d_fail.reserve(nb * P * sizeof(uint32_t)));
-    if (eng.use_tiles) HIP_TRY(d_eval_x.reserve(nb * P * sizeof(double)));   // prune_tiles makes its own edge scales from the evaluation's tree scale
+    // PCSF_FACTORED_OWN_SCALES=0: prune_factored reads rows of edge scales written by edge_scale_kernel (rounds 2-4's form; A/B, same bits)
+    const bool own_scales = !eng.use_tiles && !([] { const char* v = std::getenv("PCSF_FACTORED_OWN_SCALES"); return v && v[0] == '0'; }());
+    if (eng.use_tiles || own_scales) HIP_TRY(d_eval_x.reserve(nb * P * sizeof(double)));   // prune_tiles makes its own edge scales from the evaluation's tree scale
     const std::vector<double> t_mle = make_draw_table(seed, 1e-2, 10.0), t_rho = make_draw_table(seed, 0.001, 10.0), t_kappa = make_draw_table(seed, 1.0, 10.0);
     HIP_TRY(hipMemcpyAsync(d_draws.as<double>(), t_mle.data(), DRAW_TABLE_ENTRIES * sizeof(double), hipMemcpyHostToDevice, st0));
     HIP_TRY(hipMemcpyAsync(d_draws.as<double>() + DRAW_TABLE_ENTRIES, t_rho.data(), DRAW_TABLE_ENTRIES * sizeof(double), hipMemcpyHostToDevice, st0));
@@ -973,7 +975,7 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
     cp.out_lnz = d_lnz.as<double>();
     cp.out_anc = want_anc ? d_anc.as<double>() : nullptr;
     cp.fail = d_fail.as<uint32_t>();
-    cp.eval_x = eng.use_tiles ? d_eval_x.as<double>() : nullptr;
+    cp.eval_x = (eng.use_tiles || own_scales) ? d_eval_x.as<double>() : nullptr;
     for (int k = 0; k < 3; ++k) cp.draws[k] = d_draws.as<double>() + k * DRAW_TABLE_ENTRIES;
     cp.n_draws = DRAW_TABLE_ENTRIES;
     cp.eager = eager ? 1u : 0u;
@@ -982,6 +984,7 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
     cp.held_systems = held_systems ? 1u : 0u;
     cp.transient0 = transient0;
     cp.use_tiles = eng.use_tiles ? 1u : 0u;
+    cp.own_scales = own_scales ? 1u : 0u;
     cp.split_sizes = (eng.use_tiles && nb >= 1024) ? 1u : 0u;   // short lists: one launch of full work-groups (a launch that does not fill the chip is bound by one tile's latency)
     if (const char* v = std::getenv("PCSF_SPLIT_SIZES")) cp.split_sizes = (eng.use_tiles && std::atoi(v) != 0) ? 1u : 0u;   // A/B knob
     cp.counters = d_counters.as<ChainCounters>();
@@ -1029,7 +1032,7 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
     fp.stamps = eng.d_fact_stamps.ptr ? eng.d_fact_stamps.template as<unsigned long long>() : nullptr;
     fp.stamp_classes = eng.fact_stamp_classes ? 1u : 0u;
     fp.product_count = eng.d_products.template as<unsigned long long>();
-    if (eng.use_tiles) {
+    if (eng.use_tiles || own_scales) {
         fp.eval_x = d_eval_x.as<double>();
         fp.eig_lambda = eng.d_eig_lam.template as<double>();
         fp.eig_c = eng.d_eig_c.template as<double>();
@@ -1065,8 +1068,8 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
         fp.eig_w = eng.d_eig_w.template as<double>();
         fp.prior = eng.d_prior.template as<double>();
         fp.anc_weight = eng.d_ancw.template as<double>();
-        fp.eig_lambda = eng.use_tiles ? eng.d_eig_lam.template as<double>() : nullptr;
-        fp.eig_c = eng.use_tiles ? eng.d_eig_c.template as<double>() : nullptr;
+        fp.eig_lambda = (eng.use_tiles || own_scales) ? eng.d_eig_lam.template as<double>() : nullptr;
+        fp.eig_c = (eng.use_tiles || own_scales) ? eng.d_eig_c.template as<double>() : nullptr;
         gp.eig_right = eng.d_eig_r.template as<double>();
         gp.eig_left = eng.have_left ? eng.d_eig_l.template as<double>() : nullptr;
         gp.eig_right_frag = eng.use_tiles ? nullptr : eng.d_eig_rf.template as<double>();
@@ -1082,15 +1085,15 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
     if (!MLE) eng.reserve_eig(transient0 + transient_cap, transient0, /*with_left=*/!eng.use_tiles);
     eigen_pointers();
     // prune_factored's rows of edge scales are dense per round too (a row per evaluation of the round, in list order)
-    size_t row_cap = eng.use_tiles ? 0 : 2 * nb + 64;
-    if (!eng.use_tiles) eng.reserve_tables(row_cap);
+    size_t row_cap = (eng.use_tiles || own_scales) ? 0 : 2 * nb + 64;
+    if (row_cap) eng.reserve_tables(row_cap);
     const size_t row_doubles = static_cast<size_t>(eng.n - 1) * 64;
     st.t_setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count();
     ticket.pass();   // every group of the call has allocated
 
     // the round's evaluations of one set: edge scales (on `scale_stream`), then pruning (on `stream`)
     auto launch_scales = [&](int set, const ChainCounters& cnt, hipStream_t stream) {
-        if (eng.use_tiles) return;   // prune_tiles makes its own edge scales and runs the row-sum check itself
+        if (eng.use_tiles || own_scales) return;   // the pruning kernel makes its own edge scales and runs the row-sum check itself
         double* rows = eng.d_scale.template as<double>() + (set ? static_cast<size_t>(cnt.n_evals[0]) * row_doubles : 0);   // set 0's rows, then set 1's
         HIP_TRY(launch_edge_scale(cp.evals + static_cast<size_t>(set) * eval_cap, cnt.n_evals[set], static_cast<uint32_t>(eng.n - 1), eng.d_branch_len.template as<float>(),
                                   eng.d_eig_r.template as<double>(), eng.d_eig_l.template as<double>(), eng.d_eig_lam.template as<double>(), rows,
@@ -1162,7 +1165,7 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
             eng.reserve_eig(transient0 + transient_cap, transient0, /*with_left=*/!eng.use_tiles);
             eigen_pointers();
         }
-        if (!eng.use_tiles && static_cast<size_t>(cnt.n_evals[0]) + cnt.n_evals[1] > row_cap) {
+        if (!eng.use_tiles && !own_scales && static_cast<size_t>(cnt.n_evals[0]) + cnt.n_evals[1] > row_cap) {
             row_cap = (static_cast<size_t>(cnt.n_evals[0]) + cnt.n_evals[1]) * 3 / 2 + 64;
             eng.reserve_tables(row_cap);
         }

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(ADVANCE_BLOCKS * 64) void advance_blocks(const Chai
             j.out0 = static_cast<uint64_t>(P) * s0 + static_cast<uint64_t>(i) * sites + 16ull * tile;
             j.n_sites = static_cast<uint32_t>(sites - 16ull * tile < 16 ? sites - 16ull * tile : 16);
             j.eig = eig;
-            j.eval = p.use_tiles ? b * P + i : dense[i];   // prune_tiles: the evaluation slot (eval_x, failure flag); prune_factored: the evaluation's row of edge scales, dense per set
+            j.eval = (p.use_tiles || p.own_scales) ? b * P + i : dense[i];   // prune_tiles: the evaluation slot (eval_x, failure flag); prune_factored: the evaluation's row of edge scales, dense per set
             j.pad = tile == 0 ? FACTORED_JOB_VALIDATES : 0u;   // (read by prune_tiles when it makes its own edge scales)
             jobs[job0 + t] = j;
         }

@@ -134,7 +134,10 @@ __device__ __forceinline__ unsigned long long fact_clock()
 // ---- the pruning kernel ----------------------------------------------------------------------------------------------
 // DEEP: the tree parks more than MAX_STACK_DEPTH_DEV tiles (none of the reference's eleven trees does): the parked tiles live in
 // scratch memory, dynamically indexed; otherwise in three register sets written and read with value selects (no scratch at all).
-template <bool ANC, bool DEEP>
+// OWN: the kernel makes its edge scales itself (p.eval_x: e_b[k] = exp(lambda_k t_b) for the lane's four states) and checks the evaluation's
+// row sums in the tile flagged FACTORED_JOB_VALIDATES -- no edge_scale_kernel, no rows of scales in HBM (99 KB per evaluation of a round for
+// 100 leaves); otherwise it reads edge_scale_kernel's rows.  Same exp() on the same operands: the same bits either way.
+template <bool ANC, bool DEEP, bool OWN>
 __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_fact[];
@@ -147,6 +150,8 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
     unsigned char* lcod = reinterpret_cast<unsigned char*>(lrow_edge + 128);                  // [n_leaves][16]
     unsigned char* lany = lcod + static_cast<size_t>(p.n_leaves) * 16;             // [n_leaves]: the leaf has a codon in the tile
     unsigned char* lpush = lany + p.n_leaves;                                      // [128]: the push op only carries its message across an all-gap subtree
+    float* lblen = reinterpret_cast<float*>(lds_fact + ((static_cast<size_t>(lpush + 128 - lds_fact) + 15) & ~size_t(15)));   // OWN: [n_branches rounded up to 4] branch lengths
+    double* lec = reinterpret_cast<double*>(lblen + ((p.n_branches + 3) & ~3u));    // OWN: [4 waves][64] e^{lambda_k t_long} c_k of the row-sum check
 
     const FactoredJob job = p.jobs[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -226,9 +231,43 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
             if (s == 0) lany[leaf] = ((has >> (16 * (lane >> 4))) & 0xffffull) != 0;
         }
     }
-    const double* __restrict__ scale = p.edge_scale + static_cast<size_t>(job.eval) * p.n_branches * 64 + (wave * 4 + g) * 4;
+    const double* __restrict__ scale = OWN ? nullptr : p.edge_scale + static_cast<size_t>(job.eval) * p.n_branches * 64 + (wave * 4 + g) * 4;
+    // OWN: this lane's four eigenvalues (states 16 wave + g + 4r), the evaluation's tree scale, the branch lengths
+    double lam4[4] = {0.0, 0.0, 0.0, 0.0};
+    double x_eval = 0.0;
+    if (OWN) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lam4[r] = p.eig_lambda[static_cast<size_t>(job.eig) * 64 + 16 * wave + g + 4 * r];
+        x_eval = p.eval_x[job.eval];
+        for (uint32_t b = tid; b < p.n_branches; b += 256) lblen[b] = p.branch_len[b];
+    }
+    // e_b for this lane's rows: t_b = (double)(float)(len_b x) like the reference's float tree (src/instance.hpp:299-307,498)
+    auto own_scale = [&](int branch) __attribute__((always_inline)) -> Vec4 {
+        const double t = static_cast<double>(static_cast<float>(static_cast<double>(lblen[branch]) * x_eval));
+        Vec4 e;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e.v[r] = exp(lam4[r] * t);
+        return e;
+    };
     const double* __restrict__ Lrows = Lg + static_cast<size_t>(16 * wave + g) * 64;  // + 4r * 64 + codon
     __syncthreads();
+    if (OWN && (job.pad & FACTORED_JOB_VALIDATES)) {
+        // The reference rejects a model whose raw row sums of P(t) are off by more than 1e-6 (src/instance.hpp:632-636): sum_j P_ij(t) =
+        // sum_k R_ik e^{lambda_k t} c_k with c = L 1, at the longest branch (edge_scale_kernel has the argument).  Every wave makes the 64
+        // products e^{lambda_k t} c_k for itself and checks its sixteen rows of R, which it holds as MFMA operands.
+        const double t_long = static_cast<double>(static_cast<float>(static_cast<double>(p.longest_branch) * x_eval));
+        double* ec = lec + wave * 64;
+        ec[lane] = exp(p.eig_lambda[static_cast<size_t>(job.eig) * 64 + lane] * t_long) * p.eig_c[static_cast<size_t>(job.eig) * 64 + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double sum = 0.0;   // row 16 wave + sj, this lane's k = 4q + g
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sum += RA[q] * ec[4 * q + g];
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        if (!(fabs(sum - 1.0) <= 1e-6)) p.fail[job.eval] = 1u;
+    }
     // leaves 0..127 as two wave-uniform bit masks: most ops of a sparse tile then cost a few scalar instructions (the op loop's LDS
     // look-ups, not the products, were 70 % of a tile's time: PCSF_FACTORED_STAMPS)
     const unsigned long long t_prologue = stamping ? fact_clock() - t_begin : 0ull;
@@ -311,9 +350,15 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
         const int idx = rank0 + sj < n_active ? rank0 + sj : n_active - 1;
         const uint32_t row = lrow_edge[idx];
         chain16 = static_cast<uint32_t>(__ballot((row >> 31) != 0u && rank0 + sj < n_active)) & 0xffffu;   // lanes 0..15: sj = 0..15 of lane group 0
-        const double2_t* s0 = reinterpret_cast<const double2_t*>(scale + static_cast<size_t>(row & 0x7fffffffu) * 64);
-        const double2_t a0 = s0[0], a1 = s0[1];
-        pre[0] = a0.x; pre[1] = a0.y; pre[2] = a1.x; pre[3] = a1.y;
+        if (OWN) {
+            const Vec4 e = own_scale(static_cast<int>(row & 0x7fffffffu));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pre[r] = e.v[r];
+        } else {
+            const double2_t* s0 = reinterpret_cast<const double2_t*>(scale + static_cast<size_t>(row & 0x7fffffffu) * 64);
+            const double2_t a0 = s0[0], a1 = s0[1];
+            pre[0] = a0.x; pre[1] = a0.y; pre[2] = a1.x; pre[3] = a1.y;
+        }
         if (stamping) {
             t_load += fact_clock() - t_in;   // fact_clock waits for the loads
             ++n_load;
@@ -330,6 +375,7 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
                 return e;
             }
         }
+        if (OWN) return own_scale(branch);
         const unsigned long long t_in = stamping ? fact_clock() : 0ull;
         const double2_t* s2 = reinterpret_cast<const double2_t*>(scale + static_cast<size_t>(branch) * 64);
         const double2_t lo = s2[0], hi = s2[1];
@@ -656,16 +702,25 @@ hipError_t launch_prune_factored(const FactoredParams& params, hipStream_t strea
     FactoredParams p = params;
     static const bool strided = [] { const char* v = getenv("PCSF_EIGEN_FRAG"); return v && v[0] == '0'; }();   // A/B: the operands from the row-major images
     if (strided) p.eig_right_frag = p.eig_left_frag = nullptr;
+    const bool own = p.eval_x != nullptr;   // the kernel makes its own edge scales (needs eig_lambda, eig_c, branch_len, longest_branch, fail)
     const size_t lds = 2 * 4 * 2 * 64 * 16 + 2 * 4 * 16 * 8 + 64 * 8 + ((static_cast<size_t>(p.n_ops) + 63) & ~size_t(63)) * 4 +
-                       ((static_cast<size_t>(p.n_edges) + 3) & ~size_t(3)) * 4 + 128 * 4 + static_cast<size_t>(p.n_leaves) * 17 + 128;
+                       ((static_cast<size_t>(p.n_edges) + 3) & ~size_t(3)) * 4 + 128 * 4 + static_cast<size_t>(p.n_leaves) * 17 + 128 +
+                       16 + ((static_cast<size_t>(p.n_branches) + 3) & ~size_t(3)) * 4 + 4 * 64 * 8;
     if (lds > 64 * 1024) return hipErrorInvalidValue;
+    if (own && (!p.eig_lambda || !p.eig_c || !p.branch_len || !p.fail)) return hipErrorInvalidValue;
+#define PCSF_LAUNCH_FACTORED(ANC, DEEP)                                                                                         \
+    do {                                                                                                                        \
+        if (own) hipLaunchKernelGGL((prune_factored<ANC, DEEP, true>), dim3(p.n_jobs), dim3(256), lds, stream, p);             \
+        else hipLaunchKernelGGL((prune_factored<ANC, DEEP, false>), dim3(p.n_jobs), dim3(256), lds, stream, p);                \
+    } while (0)
     if (p.deep) {
-        if (p.out_anc) hipLaunchKernelGGL((prune_factored<true, true>), dim3(p.n_jobs), dim3(256), lds, stream, p);
-        else hipLaunchKernelGGL((prune_factored<false, true>), dim3(p.n_jobs), dim3(256), lds, stream, p);
+        if (p.out_anc) PCSF_LAUNCH_FACTORED(true, true);
+        else PCSF_LAUNCH_FACTORED(false, true);
     } else {
-        if (p.out_anc) hipLaunchKernelGGL((prune_factored<true, false>), dim3(p.n_jobs), dim3(256), lds, stream, p);
-        else hipLaunchKernelGGL((prune_factored<false, false>), dim3(p.n_jobs), dim3(256), lds, stream, p);
+        if (p.out_anc) PCSF_LAUNCH_FACTORED(true, false);
+        else PCSF_LAUNCH_FACTORED(false, false);
     }
+#undef PCSF_LAUNCH_FACTORED
     return hipGetLastError();
 }
 

@@ -209,6 +209,7 @@ struct ChainParams {
     uint32_t eager, max_points, max_restarts, held_systems;   // machine.hpp LookaheadPolicy
     uint32_t transient0;         // OMEGA: first eigen-system slot of the round's transient systems (probes that are not held: dense, counters->n_transient)
     uint32_t use_tiles, split_sizes;
+    uint32_t own_scales;         // prune_factored makes its own edge scales: FactoredJob::eval = the evaluation slot (eval_x, failure flag) like prune_tiles', not a row of scales
     uint32_t pack_models;        // MLE + prune_tiles: the two ECM eigen-systems are shared by all blocks -- tile jobs go to one list per model
                                  // (the second at tile_jobs + list_capacity) and every four consecutive jobs of a list form a work-group
     uint32_t list_capacity;

@@ -35,6 +35,18 @@ def test_build_tracks_golden_wigs_on_gpu(tmp_path, host_bls, device_wig, direct_
         assert got == want, n                      # the reference's own test is `diff -r`
 
 
+def test_build_tracks_without_the_power_track_on_gpu(tmp_path):
+    """--output-power 0: six files, formatted on the device without the power track's lines (want_power = 0 of the C-ABI call)"""
+    maf = tmp_path / "galGal6.maf"
+    with gzip.open(os.path.join(GOLD, "build-tracks", "galGal6_chr22_25_28_each_30k_bases.maf.gz"), "rb") as fi, open(maf, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    out = tmp_path / "out"
+    subprocess.check_call([_cli(), "build-tracks", "--output", str(out), "--output-power", "0", os.path.join(GOLD, "models", "53birds"), str(maf)])
+    assert sorted(os.listdir(out)) == sorted("PhyloCSFRaw%s%d.wig" % (s, f) for s in "+-" for f in (1, 2, 3))
+    for n in os.listdir(out):
+        assert open(out / n, "rb").read() == gzip.open(os.path.join(GOLD, "build-tracks", n + ".gz"), "rb").read(), n
+
+
 def _scores(path):
     return [l.rstrip("\n").split("\t") for l in open(path) if not l.startswith("#")][1:]
 

@@ -68,6 +68,12 @@ def test_device_engine_equals_the_host_engine_bit_for_bit(oracle_models, kernel,
             assert res["device"][0].tobytes() == res["host"][0].tobytes(), (kernel, algo)
             assert res["device"][1].tobytes() == res["host"][1].tobytes(), (kernel, algo)
             assert np.isfinite(res["device"][0]).sum() >= 40
+            if kernel == "factored":   # the device engine's prune_factored makes its own edge scales; with edge_scale_kernel's rows: the same bits
+                monkeypatch.setenv("PCSF_BLOCK_ENGINE", "device")
+                monkeypatch.setenv("PCSF_FACTORED_OWN_SCALES", "0")
+                rows = ctx.score_blocks(algo, cod, off, compute_anc=anc)
+                monkeypatch.delenv("PCSF_FACTORED_OWN_SCALES")
+                assert rows[0].tobytes() == res["device"][0].tobytes() and rows[1].tobytes() == res["device"][1].tobytes(), algo
     finally:
         ctx.close()
 
