@@ -355,8 +355,9 @@ struct BlockEngine {
     // the orthogonal basis a warm start reads (the held systems of OMEGA: the first N_ROLES * n_blocks; default: all); with_left = false:
     // no left eigenvectors (prune_tiles uses L = R^T diag(w): a third of the footprint of a slot)
     size_t cap_basis = 0;
-    bool have_left = true;
-    void reserve_eig(size_t count, size_t basis_count = ~size_t(0), bool with_left = true)
+    bool have_left = true, have_right = true;
+    // with_right = false: no row-major right eigenvectors either (prune_factored with its own edge scales reads the fragment-ordered copies only)
+    void reserve_eig(size_t count, size_t basis_count = ~size_t(0), bool with_left = true, bool with_right = true)
     {
         if (basis_count == ~size_t(0)) basis_count = count;
         if (basis_count > cap_basis) {
@@ -365,7 +366,8 @@ struct BlockEngine {
         }
         if (count <= cap_eig) return;
         have_left = with_left;
-        HIP_TRY(d_eig_r.reserve_keep(count * 4096 * sizeof(double), cap_eig * 4096 * sizeof(double), stream));
+        have_right = with_right;
+        if (with_right) HIP_TRY(d_eig_r.reserve_keep(count * 4096 * sizeof(double), cap_eig * 4096 * sizeof(double), stream));
         if (with_left) HIP_TRY(d_eig_l.reserve_keep(count * 4096 * sizeof(double), cap_eig * 4096 * sizeof(double), stream));
         if (!use_tiles) {
             HIP_TRY(d_eig_rf.reserve_keep(count * 4096 * sizeof(double), cap_eig * 4096 * sizeof(double), stream));
@@ -1059,18 +1061,16 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
     // 1.2 MB a block, and on boxes whose driver clears memory at allocation 19 GB of hipMalloc cost 0.7 s of a 1.5 s call.
     size_t transient_cap = MLE ? 0 : nb + 64;
     auto eigen_pointers = [&]() {
-        fp.eig_right = eng.d_eig_r.template as<double>();
-        fp.eig_left = eng.d_eig_l.template as<double>();
+        fp.eig_right = eng.have_right ? eng.d_eig_r.template as<double>() : nullptr;
+        fp.eig_left = eng.have_left ? eng.d_eig_l.template as<double>() : nullptr;
         fp.eig_right_frag = eng.use_tiles ? nullptr : eng.d_eig_rf.template as<double>();
         fp.eig_left_frag = eng.use_tiles ? nullptr : eng.d_eig_lf.template as<double>();
-    fp.eig_right_frag = eng.use_tiles ? nullptr : eng.d_eig_rf.template as<double>();
-    fp.eig_left_frag = eng.use_tiles ? nullptr : eng.d_eig_lf.template as<double>();
         fp.eig_w = eng.d_eig_w.template as<double>();
         fp.prior = eng.d_prior.template as<double>();
         fp.anc_weight = eng.d_ancw.template as<double>();
         fp.eig_lambda = (eng.use_tiles || own_scales) ? eng.d_eig_lam.template as<double>() : nullptr;
         fp.eig_c = (eng.use_tiles || own_scales) ? eng.d_eig_c.template as<double>() : nullptr;
-        gp.eig_right = eng.d_eig_r.template as<double>();
+        gp.eig_right = eng.have_right ? eng.d_eig_r.template as<double>() : nullptr;
         gp.eig_left = eng.have_left ? eng.d_eig_l.template as<double>() : nullptr;
         gp.eig_right_frag = eng.use_tiles ? nullptr : eng.d_eig_rf.template as<double>();
         gp.eig_left_frag = eng.use_tiles ? nullptr : eng.d_eig_lf.template as<double>();
@@ -1082,7 +1082,7 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
         gp.eig_w = eng.d_eig_w.template as<double>();
         gp.eig_c = eng.d_eig_c.template as<double>();
     };
-    if (!MLE) eng.reserve_eig(transient0 + transient_cap, transient0, /*with_left=*/!eng.use_tiles);
+    if (!MLE) eng.reserve_eig(transient0 + transient_cap, transient0, /*with_left=*/!eng.use_tiles && !own_scales, /*with_right=*/!own_scales);
     eigen_pointers();
     // prune_factored's rows of edge scales are dense per round too (a row per evaluation of the round, in list order)
     size_t row_cap = (eng.use_tiles || own_scales) ? 0 : 2 * nb + 64;
@@ -1162,7 +1162,7 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
         // everything of the previous round has finished (advance_blocks waited for it): buffers may grow here
         if (cnt.n_transient > transient_cap) {
             transient_cap = static_cast<size_t>(cnt.n_transient) + cnt.n_transient / 2 + 64;
-            eng.reserve_eig(transient0 + transient_cap, transient0, /*with_left=*/!eng.use_tiles);
+            eng.reserve_eig(transient0 + transient_cap, transient0, /*with_left=*/!eng.use_tiles && !own_scales, /*with_right=*/!own_scales);
             eigen_pointers();
         }
         if (!eng.use_tiles && !own_scales && static_cast<size_t>(cnt.n_evals[0]) + cnt.n_evals[1] > row_cap) {

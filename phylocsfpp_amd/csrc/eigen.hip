@@ -810,13 +810,13 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
     }
 
     // eigen-system of Q: right = D^-1/2 V (eigenvectors in columns), left = V^T D^1/2 (in rows)
-    double* __restrict__ R = p.eig_right + static_cast<size_t>(job.eig) * 4096;
+    double* __restrict__ R = p.eig_right ? p.eig_right + static_cast<size_t>(job.eig) * 4096 : nullptr;   // (null: only the fragment-ordered copies are wanted)
     double* __restrict__ L = p.eig_left ? p.eig_left + static_cast<size_t>(job.eig) * 4096 : nullptr;
     double* __restrict__ lam = p.eig_lambda + static_cast<size_t>(job.eig) * 64;
     double* __restrict__ basis = (p.eig_basis && (p.basis_slots == 0 || job.eig < p.basis_slots)) ? p.eig_basis + static_cast<size_t>(job.eig) * 4096 : nullptr;
     for (int idx = tid; idx < 4096; idx += NT) {
         const int r = idx >> 6, c = idx & 63;
-        R[idx] = iroot[r] * V[r * LD + c];   // right[i][k], i = r, k = c
+        if (R) R[idx] = iroot[r] * V[r * LD + c];   // right[i][k], i = r, k = c
         if (L) L[idx] = V[c * LD + r] * root[c];    // left[k][i],  k = r, i = c
         if (basis) basis[idx] = V[r * LD + c];
     }

@@ -164,8 +164,8 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
     // round trips for the codon bytes alone -- each iteration's ballot waited for its own load -- then the program, then the operand
     // rows, then the op facts: 16 k cycles before the first op of a tile whose ten products take 14 k).
     // (a) this wave's 16 rows of R and L as MFMA A operands: k-step q needs M[16 wave + (lane & 15)][4q + (lane >> 4)]
-    const double* __restrict__ Rg = p.eig_right + static_cast<size_t>(job.eig) * 4096;
-    const double* __restrict__ Lg = p.eig_left + static_cast<size_t>(job.eig) * 4096;
+    const double* __restrict__ Rg = p.eig_right ? p.eig_right + static_cast<size_t>(job.eig) * 4096 : nullptr;   // (the row-major images may be absent when the
+    const double* __restrict__ Lg = p.eig_left ? p.eig_left + static_cast<size_t>(job.eig) * 4096 : nullptr;     //  fragment-ordered ones are there)
     double RA[16], LA[16];
     if (p.eig_right_frag) {   // the same values from the images stored in this order: 512 contiguous bytes per wave and k-step
         const double* __restrict__ Rf = p.eig_right_frag + static_cast<size_t>(job.eig) * 4096 + wave * 1024 + lane;
@@ -249,7 +249,13 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
         for (int r = 0; r < 4; ++r) e.v[r] = exp(lam4[r] * t);
         return e;
     };
-    const double* __restrict__ Lrows = Lg + static_cast<size_t>(16 * wave + g) * 64;  // + 4r * 64 + codon
+    // a leaf's column of L for this lane's rows 16 wave + g + 4r: L[row][codon], from the row-major image (+ 4r * 64 + codon) or from the
+    // fragment-ordered one, where element [row][col] sits at ((row >> 4) * 16 + (col >> 2)) * 64 + (col & 3) * 16 + (row & 15)
+    const bool l_frag = p.eig_left_frag != nullptr;
+    const double* __restrict__ Lrows = l_frag ? p.eig_left_frag + static_cast<size_t>(job.eig) * 4096 + wave * 1024 + g : Lg + static_cast<size_t>(16 * wave + g) * 64;
+    auto l_entry = [&](int r, unsigned col) __attribute__((always_inline)) -> double {
+        return l_frag ? Lrows[(col >> 2) * 64 + (col & 3) * 16 + 4 * r] : Lrows[r * 256 + col];
+    };
     __syncthreads();
     if (OWN && (job.pad & FACTORED_JOB_VALIDATES)) {
         // The reference rejects a model whose raw row sums of P(t) are off by more than 1e-6 (src/instance.hpp:632-636): sum_j P_ij(t) =
@@ -435,7 +441,7 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
         const unsigned col = code == 64u ? 0u : code;
         Msg out{Vec4{}, mask, true};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out.v.v[r] = e.v[r] * (code == 64u ? my_cgap[4 * r] : Lrows[r * 256 + col]);
+        for (int r = 0; r < 4; ++r) out.v.v[r] = e.v[r] * (code == 64u ? my_cgap[4 * r] : l_entry(r, col));
         return out;
     };
     auto mul = [&](const Msg& x, const Msg& y) __attribute__((always_inline)) -> Msg {
