@@ -992,6 +992,22 @@ int pcsf_prepare_tracks(pcsf_ctx* c, size_t max_columns)
     const pcsf_alignment_desc aln{0, 192, 1, 1000};
     uint64_t offsets[6];
     uint32_t n_codons[6];
+    if (c->bls_ready) {
+        // ... and the text path (wig.hip): its buffers for max_columns, its kernels and the scan's loaded by a call of that form -- the first
+        // real call of a 1 Mb run otherwise spent 6-7 ms loading them and the next two 5 + 1 ms growing the buffers
+        const uint64_t elems = 2 * static_cast<uint64_t>(cols) + cols / 3 + 8;
+        pcsf_ctx::WigBuffers& W = c->wig;
+        if ((e = W.lens.reserve((elems + 1) * sizeof(uint32_t))) != hipSuccess || (e = W.offsets.reserve((elems + 1) * sizeof(uint32_t))) != hipSuccess ||
+            (e = W.temp.reserve(std::max<size_t>(pcsf::wig_scan_temp_bytes(elems), 16))) != hipSuccess ||
+            (e = W.text.reserve(pcsf_wig_text_estimate(cols, 4096))) != hipSuccess || (e = W.frames.reserve(7 * 4096 * sizeof(pcsf::WigFrame))) != hipSuccess ||
+            (e = W.chroms.reserve(1 << 16)) != hipSuccess)
+            return c->hip_fail(e, "hipMalloc(wig)");
+        const char* name = "x";
+        uint64_t bytes[7];
+        size_t frames = 0;
+        const int rc = pcsf_score_alignments_6frames_wig(c, rows.data(), 192, &aln, 1, &name, 0.1f, 1, 1, nullptr, 0, bytes, &frames);
+        if (rc != PCSF_OK) return rc;
+    }
     return pcsf_score_alignments_6frames_bls(c, rows.data(), 192, &aln, 1, scores.data(), scores.size(), offsets, n_codons, nullptr,
                                              c->bls_ready ? bls.data() : nullptr);
 }

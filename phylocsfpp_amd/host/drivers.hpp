@@ -235,7 +235,7 @@ struct BuildTracksParams {
     bool verbose = false;
     bool host_bls = false;           // branch-length scores on the host even when the backend offers them (--host-bls)
     int threads = 0;                 // host threads for ingest / BLS / text output (0 = all the process may use)
-    size_t window_bytes = size_t(32) << 20;   // MAF bytes parsed (in parallel) per pipeline step
+    size_t window_bytes = 0;                  // MAF bytes parsed (in parallel) per pipeline step; 0: from the input's size (32 MiB for inputs of 256 MiB and more)
 };
 
 // CPUs this process may actually use: hardware threads, capped by the cgroup CPU quota (a container on a
@@ -956,7 +956,10 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     // a packed alignment file (pack-maf, packed_reader.hpp) holds the reader's alignments ready-made: stage 1 only copies rows
     const bool packed = is_packed_file(file);
     const size_t input_bytes = packed ? static_cast<size_t>(PackedReader::data_bytes(file)) : file.size();
-    const size_t window = std::max<size_t>(prm.window_bytes, 1 << 16);
+    // 32 MiB steps; a short input gets about eight (and the two smaller ones in front), so that the stages overlap inside it too: the last
+    // step's scoring runs with nothing beside it, and with four steps that was a fifth of a 90 MB run (0.060 -> 0.050 s)
+    const size_t window = prm.window_bytes ? std::max<size_t>(prm.window_bytes, 1 << 16)
+                                           : std::min<size_t>(size_t(32) << 20, std::max<size_t>(size_t(4) << 20, (input_bytes / 8 + 0xfffff) & ~size_t(0xfffff)));
     // the first windows are smaller (1/4, 1/2 of the size) so that the scoring stage starts after a short parse
     std::vector<size_t> window_begin;
     for (size_t at = 0, k = 0; at < input_bytes; ++k) {
