@@ -275,6 +275,18 @@ def end_to_end(device, runs, cpu_rate_all_cores, work_dir):
     return e2e, cpu
 
 
+def host_ceiling(run, n_gpus):
+    """What the host side alone allows a build-tracks run (`run`: run_cli's statistics): stage 1 (parse + branch-length scores + packing,
+    one window ahead of the scoring, all host threads) and stage 3 (the writers) each take this long whatever the number of GPUs; the
+    scoring backends share theirs."""
+    sb = run["stage_busy"]
+    stage1 = sb["maf_read"] + sb["bls"] + sb["batch_packing"]
+    return {"stage1_parse_and_pack_seconds": stage1, "stage3_writers_seconds": sb["wig_output"],
+            "scoring_backends_seconds_per_device": sb["scoring_backend"] / max(n_gpus, 1),
+            "codon_frames_per_s": run["codon_frames"] / max(stage1, sb["wig_output"], 1e-9), "host_threads": effective_cpus(),
+            "reading": "the run cannot be faster than its slowest stage: min(this ceiling, n_gpus x the one-device rate) bounds all_devices"}
+
+
 def end_to_end_multi(n_gpus, work_dir):
     """BASELINE.json configs[3] in the form the C++ driver runs it: ONE process, `phylocsf-amd build-tracks --devices 0,..,N-1` on the
     synthetic segment tiled along the chromosome (10 Mb per GPU, at most 40 Mb), text in, seven wig files out; the same file on one
@@ -297,15 +309,7 @@ def end_to_end_multi(n_gpus, work_dir):
                       "seconds_all_runs": [r["seconds"] for r in runs], "process_wall_seconds": min(r["process_wall_seconds"] for r in runs),
                       "codon_frames_per_s": b["codon_frames"] / b["seconds"], "backend_calls": b["backend_calls"], "stage_busy": b["stage_busy"]}
     out["speedup_vs_one_device"] = out["all_devices"]["codon_frames_per_s"] / out["one_device"]["codon_frames_per_s"]
-    # what the host side alone allows: stage 1 (parse + branch-length scores + packing, one window ahead of the scoring, all host
-    # threads) and stage 3 (the writers) each run for this long whatever the number of GPUs; the scoring backends share theirs
-    a = out["all_devices"]
-    sb = a["stage_busy"]
-    stage1 = sb["maf_read"] + sb["bls"] + sb["batch_packing"]
-    out["host_ceiling"] = {"stage1_parse_and_pack_seconds": stage1, "stage3_writers_seconds": sb["wig_output"],
-                           "scoring_backends_seconds_per_device": sb["scoring_backend"] / n_gpus,
-                           "codon_frames_per_s": a["codon_frames"] / max(stage1, sb["wig_output"], 1e-9), "host_threads": effective_cpus(),
-                           "reading": "the run cannot be faster than its slowest stage: min(this ceiling, n_gpus x the one-device rate) bounds all_devices"}
+    out["host_ceiling"] = host_ceiling(out["all_devices"], n_gpus)
     try:
         out["wig_lines_differing_between_the_two"] = differing_lines(os.path.join(work_dir, "gpu_multi_all_devices"), os.path.join(work_dir, "gpu_multi_one_device"))
     except Exception as ex:

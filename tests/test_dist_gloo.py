@@ -131,3 +131,19 @@ def test_bench_site_stream_is_the_same_for_every_sharding():
         assert bounds[0][0] == 0 and bounds[-1][1] == total and all(b[0] % 64 == 0 for b in bounds)
         parts = [bench.sample_columns(pool, lo, hi, seed=7) for lo, hi in bounds]
         assert torch.equal(torch.cat(parts, dim=1), whole)
+
+
+def test_bench_host_ceiling_of_a_multi_device_run():
+    """bench.py --gpus N puts the host stages' ceiling next to end_to_end_multi (stage 1 and the writers run once whatever the number of
+    GPUs, the scoring backends share theirs): the arithmetic on a made-up run's statistics."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    run = {"codon_frames": 200_000_000, "stage_busy": {"maf_read": 0.34, "bls": 0.0, "batch_packing": 0.6, "scoring_backend": 5.5, "wig_output": 0.15, "smoothing": 0.0}}
+    c = bench.host_ceiling(run, 8)
+    assert abs(c["stage1_parse_and_pack_seconds"] - 0.94) < 1e-12 and c["stage3_writers_seconds"] == 0.15
+    assert abs(c["codon_frames_per_s"] - 200_000_000 / 0.94) < 1e-3 and abs(c["scoring_backends_seconds_per_device"] - 5.5 / 8) < 1e-12
+    assert c["host_threads"] >= 1
+    run["stage_busy"]["wig_output"] = 2.0          # the writers as the slowest stage
+    assert abs(bench.host_ceiling(run, 2)["codon_frames_per_s"] - 1e8) < 1e-3
