@@ -757,6 +757,13 @@ static int six_frames_impl(pcsf_ctx* c, const char* nucleotides, size_t row_stri
     if (total > out_capacity) return c->fail(PCSF_ERR_INVALID_ARG, "pcsf_score_alignments_6frames: out_capacity too small");
     hipError_t e;
     if ((e = hipSetDevice(c->device)) != hipSuccess) return c->hip_fail(e, "hipSetDevice");
+    // every return below that leaves work queued -- an error half way -- waits for it first: the queued copies read vectors of this frame
+    // and write the caller's buffers
+    struct Drain {
+        hipStream_t s;
+        bool armed = true;
+        ~Drain() { if (armed) (void)hipStreamSynchronize(s); }
+    } drain{c->stream};
     if (total == 0 && !wig) {  // alignments shorter than a codon still have branch-length scores
         if (!out_bls || max_col == 0) return PCSF_OK;
         return pcsf::bls_columns(c, nucleotides, row_stride, max_col, spans, out_bls);
@@ -963,6 +970,7 @@ static int six_frames_impl(pcsf_ctx* c, const char* nucleotides, size_t row_stri
         if (wig->n_codon_frames) *wig->n_codon_frames = total;
         W.ready = true;
     }
+    drain.armed = false;   // (everything has been waited for, but a second write pass of the text, which pcsf_fetch_wig_text waits for)
     return PCSF_OK;
 }
 
