@@ -144,29 +144,31 @@ public:
                     continue;
                 }
                 SLine s = parse_s_line();
-                if (!first_block && block_ref == -1 && !((aln.start_pos - 1) + ref_bases == s.start && s.chrom_is(aln.chrom))) {
+                if (!first_block && block_ref == -1 && !((aln.start_pos - 1) + ref_bases == s.start() && s.chrom_is(aln.chrom))) {
                     stop = true;  // not contiguous: this block starts the next alignment
                     break;
                 }
                 const int leaf = leaf_of(s);
                 if (leaf < 0) continue;  // not part of the model
                 if (first_block && ref_leaf == -1) {
-                    aln.start_pos = s.start + 1;
+                    aln.start_pos = s.start() + 1;
                     aln.chrom = s.chrom_str();
-                    aln.chrom_len = s.src_size;
+                    aln.chrom_len = s.src_size();
                     aln.strand = s.strand;
                     ref_leaf = leaf;
-                    ref_bases = s.size;
+                    const uint64_t ref_size = s.size();
+                    ref_bases = ref_size;
                     check_strand(s);
-                    if (!reached_bp && aln.start_pos / BREAKPOINT_INTERVAL < (aln.start_pos + s.size) / BREAKPOINT_INTERVAL) {
+                    if (!reached_bp && aln.start_pos / BREAKPOINT_INTERVAL < (aln.start_pos + ref_size) / BREAKPOINT_INTERVAL) {
                         reached_bp = true;
                         ref_bases_at_bp = ref_bases;
                     }
                 } else if (!first_block && block_ref == -1) {
                     block_ref = leaf;
                     const uint64_t prev_end = aln.start_pos + ref_bases;
-                    ref_bases += s.size;
-                    if (!reached_bp && prev_end / BREAKPOINT_INTERVAL < (prev_end + s.size) / BREAKPOINT_INTERVAL) {
+                    const uint64_t block_size = s.size();
+                    ref_bases += block_size;
+                    if (!reached_bp && prev_end / BREAKPOINT_INTERVAL < (prev_end + block_size) / BREAKPOINT_INTERVAL) {
                         reached_bp = true;
                         ref_bases_at_bp = ref_bases;
                     }
@@ -372,7 +374,22 @@ private:
         }
         std::string chrom_str() const { return std::string(chrom, chrom_len); }
         bool chrom_is(const std::string& c) const { return c.size() == chrom_len && memcmp(c.data(), chrom, chrom_len) == 0; }
-        uint64_t start = 0, size = 0, src_size = 0;
+        // start, size, srcSize where they stand in the line: converted when asked for -- only a block's reference row is (three numbers of
+        // ~20 digits were a third of the time spent on every other row)
+        const char* num[3] = {nullptr, nullptr, nullptr};
+        size_t num_len[3] = {0, 0, 0};
+        static uint64_t number(const char* p, size_t n)   // atoi semantics for the plain non-negative integers of a MAF
+        {
+            uint64_t v = 0;
+            size_t i = 0;
+            bool neg = false;
+            if (i < n && (p[i] == '-' || p[i] == '+')) neg = p[i++] == '-';
+            for (; i < n && p[i] >= '0' && p[i] <= '9'; ++i) v = v * 10 + static_cast<uint64_t>(p[i] - '0');
+            return neg ? static_cast<uint64_t>(-static_cast<int64_t>(v)) : v;
+        }
+        uint64_t start() const { return number(num[0], num_len[0]); }
+        uint64_t size() const { return number(num[1], num_len[1]); }
+        uint64_t src_size() const { return number(num[2], num_len[2]); }
         char strand = '.';
         const char* text = nullptr;
         size_t text_len = 0;
@@ -438,18 +455,10 @@ private:
         s.species_len = static_cast<size_t>(dot - tok[1]);
         s.chrom = dot + 1;
         s.chrom_len = len[1] - static_cast<size_t>(dot + 1 - tok[1]);
-        auto number = [](const char* p, size_t n) {  // atoi semantics for the plain non-negative integers of a MAF
-            uint64_t v = 0;
-            size_t i = 0;
-            bool neg = false;
-            if (i < n && (p[i] == '-' || p[i] == '+')) neg = p[i++] == '-';
-            for (; i < n && p[i] >= '0' && p[i] <= '9'; ++i) v = v * 10 + static_cast<uint64_t>(p[i] - '0');
-            return neg ? static_cast<uint64_t>(-static_cast<int64_t>(v)) : v;
-        };
-        s.start = number(tok[2], len[2]);
-        s.size = number(tok[3], len[3]);
+        s.num[0] = tok[2]; s.num_len[0] = len[2];
+        s.num[1] = tok[3]; s.num_len[1] = len[3];
         s.strand = tok[4][0];
-        s.src_size = number(tok[5], len[5]);
+        s.num[2] = tok[5]; s.num_len[2] = len[5];
         s.text = tok[6];
         s.text_len = len[6];
         if (s.text_len && s.text[s.text_len - 1] == '\r') --s.text_len;
@@ -462,8 +471,18 @@ private:
     // lower-casing and the hash look-ups happen only for a name not seen recently.
     int leaf_of(const SLine& s)
     {
-        uint64_t h = s.species_len;
-        for (size_t i = 0; i < s.species_len; ++i) h = (h ^ static_cast<unsigned char>(s.species[i])) * 0x100000001b3ull;
+        // key of the slot: the name's first and last eight bytes and its length, mixed (a byte-wise hash cost as much as the rest of the
+        // look-up; the slot's name is compared in full below, so a collision only costs a miss)
+        uint64_t h = 0;
+        if (s.species_len >= 8) {
+            uint64_t tail;
+            memcpy(&h, s.species, 8);
+            memcpy(&tail, s.species + s.species_len - 8, 8);
+            h ^= tail * 0x9e3779b97f4a7c15ull;
+        } else {
+            memcpy(&h, s.species, s.species_len);
+        }
+        h = (h ^ (static_cast<uint64_t>(s.species_len) << 56)) * 0xff51afd7ed558ccdull;
         if (recent_.empty()) recent_.resize(RECENT_SLOTS);
         Recent& r = recent_[(h ^ (h >> 29)) & (RECENT_SLOTS - 1)];
         if (r.used && r.name.size() == s.species_len && memcmp(r.name.data(), s.species, s.species_len) == 0) return r.leaf;
@@ -482,7 +501,7 @@ private:
     void check_strand(const SLine& s) const
     {
         if (concatenate_ && s.strand != '+')
-            throw std::runtime_error("reference sequence is not on the + strand (" + s.species_str() + "." + s.chrom_str() + " at " + std::to_string(s.start) + ")");
+            throw std::runtime_error("reference sequence is not on the + strand (" + s.species_str() + "." + s.chrom_str() + " at " + std::to_string(s.start()) + ")");
     }
 
     const std::unordered_map<std::string, int>& names_;
