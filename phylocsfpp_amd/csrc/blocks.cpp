@@ -1156,8 +1156,14 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
         ++st.rounds;
         st.evals += cnt.n_evals[0] + cnt.n_evals[1];
         st.eig_jobs += cnt.n_eig_jobs;
-        if (cnt.n_evals[0] > eval_cap || cnt.n_evals[1] > eval_cap || cnt.n_tile_jobs[0] > job_cap || cnt.n_tile_jobs[1] > job_cap || cnt.n_list[0] > job_cap || cnt.n_list[1] > job_cap)
-            throw std::runtime_error("advance_blocks: a job list overflowed");
+        // An ASSERTION of an invariant, not a guard: the capacities are worst cases by construction (every block asks for at most P
+        // evaluations per round: nb * P evaluations and eigen jobs, total_tiles * P tile jobs and groups), and advance_blocks has already
+        // written the round's records when these counters are read.
+        bool overflow = cnt.n_evals[0] > eval_cap || cnt.n_evals[1] > eval_cap || cnt.n_tile_jobs[0] > job_cap || cnt.n_tile_jobs[1] > job_cap ||
+                        cnt.n_list[0] > job_cap || cnt.n_list[1] > job_cap || cnt.n_eig_jobs > eval_cap;
+        for (int set = 0; set < 2; ++set)
+            for (int sz = 0; sz < 4; ++sz) overflow = overflow || cnt.n_groups[set][sz] > group_cap;
+        if (overflow) throw std::runtime_error("advance_blocks: a job list overflowed (an invariant of the engine's capacities is broken)");
         if (cnt.n_eig_jobs && eng.host_eigen) throw std::runtime_error("PCSF_EIGEN_HOST needs PCSF_BLOCK_ENGINE=host");
         // everything of the previous round has finished (advance_blocks waited for it): buffers may grow here
         if (cnt.n_transient > transient_cap) {

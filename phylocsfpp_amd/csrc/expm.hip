@@ -4,6 +4,12 @@
 // 1 - off-diagonal row sum, validation of entries and raw row sums; src/instance.hpp:602-640) and
 // a scatter into the layout the pruning kernel reads (fragment order for internal children,
 // leaf-message table incl. the row-sum row for leaves).  One work-group of 4 waves per job.
+//
+// OFF THE PRODUCT PATH since round 3: no block of pcsf_score_blocks forms a branch matrix any more (prune_tiles / prune_factored apply
+// R, diag(e^{lambda t}) and L factor by factor; FIXED tracks build their tables once per context on the host, api.cpp).  This kernel
+// only serves the debug / test entry points that need the reference's ENTRY-WISE post-processing of P: pcsf_block_loglik_eig (the
+// parity tests' layer 1: the oracle's eigen-system injected), pcsf_debug_branch_matrices, and PCSF_BLOCK_KERNEL=factored with
+// PCSF_FACTORED_MAX_TILES (round 2's explicit path, kept for A/B).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -707,7 +707,8 @@ hipError_t launch_prune_factored(const FactoredParams& params, hipStream_t strea
     if (params.n_jobs == 0) return hipSuccess;
     FactoredParams p = params;
     static const bool strided = [] { const char* v = getenv("PCSF_EIGEN_FRAG"); return v && v[0] == '0'; }();   // A/B: the operands from the row-major images
-    if (strided) p.eig_right_frag = p.eig_left_frag = nullptr;
+    if (strided && p.eig_right && p.eig_left) p.eig_right_frag = p.eig_left_frag = nullptr;   // only where the row-major images exist (the device engine's OMEGA lists hold none)
+    if (!p.eig_right_frag && !p.eig_right) return hipErrorInvalidValue;
     const bool own = p.eval_x != nullptr;   // the kernel makes its own edge scales (needs eig_lambda, eig_c, branch_len, longest_branch, fail)
     const size_t lds = 2 * 4 * 2 * 64 * 16 + 2 * 4 * 16 * 8 + 64 * 8 + ((static_cast<size_t>(p.n_ops) + 63) & ~size_t(63)) * 4 +
                        ((static_cast<size_t>(p.n_edges) + 3) & ~size_t(3)) * 4 + 128 * 4 + static_cast<size_t>(p.n_leaves) * 17 + 128 +

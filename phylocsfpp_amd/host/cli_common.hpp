@@ -39,7 +39,9 @@ inline int usage(const char* prog)
             "                  (build-tracks also reads the packed file: same tracks, no text parsing)\n"
             "--hmm-params: coding prior, mean coding length (codons), 3 non-coding weights, 3 non-coding mean lengths (codons)\n"
             "--species reduces the model's tree to the named species (tree labels or their other names)\n"
-            "<model prefix> names <prefix>_coding.ECM, <prefix>_noncoding.ECM and <prefix>.nh\n",
+            "<model prefix> names <prefix>_coding.ECM, <prefix>_noncoding.ECM and <prefix>.nh\n"
+            "environment: PCSF_FULL_TEARDOWN=1 keeps the orderly exit (scoring contexts and the HIP runtime torn down instead of _exit once every\n"
+            "             output file is closed; automatic under LD_PRELOAD / rocprofv3, whose tools write their files at exit)\n",
             prog, prog, prog, prog);
     return 2;
 }
@@ -339,7 +341,7 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend, b
                 // --context-model <name or prefix> (any model will do) the pass runs as build-tracks runs it, otherwise as host code.
                 std::unique_ptr<ScoringBackend> ctx_backend;
                 if (!context_model.empty()) ctx_backend = make_backend(load_model(context_model, aliases, "", ""), devices[0]);
-                if (ctx_backend && ctx_backend->device_hmm()) smooth_tracks_device(argv[i], bt.hmm, bt.write_smooth, bt.write_regions, /*keep_raw=*/true, threads, *ctx_backend);
+                if (ctx_backend && ctx_backend->device_hmm()) smooth_tracks_device(argv[i], bt.hmm, bt.write_smooth, bt.write_regions, threads, *ctx_backend);
                 else smooth_tracks(argv[i], bt.hmm, bt.write_smooth, bt.write_regions, /*keep_raw=*/true, threads);
                 return 0;
             }
@@ -410,9 +412,13 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend, b
         // operating system does as well when the process ends.  PCSF_FULL_TEARDOWN=1 keeps the orderly exit (leak checkers, profilers
         // that write their files at exit).
         const char* preload = std::getenv("LD_PRELOAD");
-        const bool profiled = std::getenv("ROCP_TOOL_LIBRARIES") != nullptr || (preload && strstr(preload, "rocprof") != nullptr);   // rocprofv3 writes its files at exit
+        // Any preloaded library may be a tool that writes its results at exit (rocprofv3, rocprof-sys, coverage): take the orderly exit then.
+        const bool profiled = std::getenv("ROCP_TOOL_LIBRARIES") != nullptr || (preload && preload[0] != '\0');
         if (fast_exit && !profiled && !std::getenv("PCSF_FULL_TEARDOWN")) {
-            fflush(nullptr);
+            if (fflush(nullptr) != 0) {   // a full disk or a closed pipe behind stdout / stderr must not end in status 0
+                perror("error: flushing the output streams");
+                _exit(1);
+            }
             _exit(0);
         }
     } catch (const std::exception& e) {

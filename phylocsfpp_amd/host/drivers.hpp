@@ -11,6 +11,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <array>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -421,13 +422,23 @@ struct TextPiece {
     }
 };
 
+inline void remove_raw_tracks(const std::string& out_dir)
+{
+    for (int fi = 0; fi < 6; ++fi)
+        unlink((out_dir + "/PhyloCSFRaw" + std::string(1, fi < 3 ? '+' : '-') + std::to_string(fi % 3 + 1) + ".wig").c_str());
+}
+
 // The smoothing pass (reference src/phylocsf++build_tracks.hpp:262-366): every PhyloCSFRaw<strand><frame>.wig of
 // out_dir is read back as text, cut into maximal contiguous runs, and each run goes through the HMM:
 // PhyloCSF<strand><frame>.wig gets the log-odds of the coding posterior per codon ("%.3f", trimmed),
 // PhyloCSF<strand><frame>Regions.bed the coding stretches of the Viterbi path.  Six frames, six threads.
-inline void smooth_tracks(const std::string& out_dir, const Hmm& hmm, bool write_smooth, bool write_regions, bool keep_raw, int threads)
+// `done` (optional): frames whose smoothed files are already committed (by a device pass that failed later on) are left alone.  The raw
+// tracks are only removed once ALL six frames are finished: a failure half-way leaves every raw track in place.
+inline void smooth_tracks(const std::string& out_dir, const Hmm& hmm, bool write_smooth, bool write_regions, bool keep_raw, int threads,
+                          const std::array<bool, 6>* done = nullptr)
 {
     parallel_for(6, threads, [&](size_t fi) {
+        if (done && (*done)[fi]) return;
         const char strand = fi < 3 ? '+' : '-';
         const std::string tag = std::string(1, strand) + std::to_string(fi % 3 + 1);
         const std::string raw = out_dir + "/PhyloCSFRaw" + tag + ".wig";
@@ -458,8 +469,8 @@ inline void smooth_tracks(const std::string& out_dir, const Hmm& hmm, bool write
         }
         wig_file.commit();
         bed_file.commit();
-        if (!keep_raw) unlink(raw.c_str());
     });
+    if (!keep_raw) remove_raw_tracks(out_dir);
 }
 
 // What the smoothed track prints for a coding posterior p is a monotone step function of p: log-odds (hmm_log_odds), narrowed to
@@ -516,11 +527,20 @@ inline std::vector<double> printed_code_thresholds(int threads)
 // a multiple goes through pow() itself; (3) ONE backend call returns the coding posterior and the Viterbi back pointers of all runs
 // of the group; (4) log-odds, text and regions are made on all host threads, the files appended side by side.  Output files are
 // byte-identical to smooth_tracks' (tests/test_gpu_hmm.py).
-inline void smooth_tracks_device(const std::string& out_dir, const Hmm& hmm, bool write_smooth, bool write_regions, bool keep_raw, int threads,
-                                 ScoringBackend& backend)
+//
+// The pass NEVER removes a raw track: it marks in `done` the frames whose smoothed files it has committed, so that a caller whose later
+// group failed (device memory on a large genome) can hand the REMAINING frames to the host pass -- which must neither truncate the
+// finished files nor look for raw tracks that are gone -- and removes the raw tracks itself once everything is written.
+inline void smooth_tracks_device(const std::string& out_dir, const Hmm& hmm, bool write_smooth, bool write_regions, int threads,
+                                 ScoringBackend& backend, std::array<bool, 6>* done = nullptr)
 {
     constexpr int TABLE_HALF = 200000;   // scores in [-200, 200] decibans by look-up
-    constexpr size_t GROUP_VALUES = size_t(64) << 20;
+    // tests: PCSF_HMM_GROUP_VALUES cuts the six tracks into several groups, PCSF_HMM_FAIL_GROUP=k makes group k throw before it writes
+    const char* gv = std::getenv("PCSF_HMM_GROUP_VALUES");
+    const size_t GROUP_VALUES = gv ? std::max<size_t>(1, strtoull(gv, nullptr, 10)) : size_t(64) << 20;
+    const char* fg = std::getenv("PCSF_HMM_FAIL_GROUP");
+    const int fail_group = fg ? atoi(fg) : -1;
+    int group_index = 0;
     const bool verbose = std::getenv("PCSF_HMM_STATS") != nullptr;
     const std::vector<double> thresholds = printed_code_thresholds(threads);
     std::vector<double> table(2 * TABLE_HALF + 1);
@@ -560,6 +580,7 @@ inline void smooth_tracks_device(const std::string& out_dir, const Hmm& hmm, boo
             estimate += est;
             group.push_back(std::move(fr));
         }
+        if (group_index++ == fail_group) throw std::runtime_error("PCSF_HMM_FAIL_GROUP: injected failure");
         // (1) parse: pieces of every file of the group
         std::vector<std::pair<size_t, size_t>> piece_jobs;   // (frame, piece)
         for (size_t g = 0; g < group.size(); ++g) {
@@ -824,7 +845,7 @@ inline void smooth_tracks_device(const std::string& out_dir, const Hmm& hmm, boo
             fr->wig_file.commit();
             fr->bed_file.commit();
             fr->text.reset();
-            if (!keep_raw) unlink(fr->raw.c_str());
+            if (done) (*done)[static_cast<size_t>(fr->fi)] = true;
         }
         if (verbose)
             fprintf(stderr, "smooth_tracks_device, tracks %s..%s: %zu values in %zu runs; parse %.3f s, emissions %.3f, recurrences (backend) %.3f, log-odds + text %.3f, paths + regions %.3f\n",
@@ -1329,18 +1350,20 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     if (prm.write_smooth || prm.write_regions) {
         sw.lap();
         bool smoothed = false;
+        std::array<bool, 6> done{};   // frames whose smoothed files the device pass committed before it failed
         if (backend.device_hmm()) {
             // every score is written by now: a failure of the device pass (its memory, say) must not lose the run -- the host pass reads the
             // same raw tracks and writes the same bytes
             try {
-                smooth_tracks_device(out_dir, prm.hmm, prm.write_smooth, prm.write_regions, /*keep_raw=*/prm.write_raw, threads, backend);
+                smooth_tracks_device(out_dir, prm.hmm, prm.write_smooth, prm.write_regions, threads, backend, &done);
                 smoothed = true;
+                if (!prm.write_raw) remove_raw_tracks(out_dir);
             } catch (const std::exception& ex) {
-                fprintf(stderr, "the smoothing pass on the device failed (%s); running it on the host\n", ex.what());
+                fprintf(stderr, "the smoothing pass on the device failed (%s); running the remaining tracks on the host\n", ex.what());
             }
             backend.hmm_release();   // the pass's device buffers (~60 bytes per value of its largest batch)
         }
-        if (!smoothed) smooth_tracks(out_dir, prm.hmm, prm.write_smooth, prm.write_regions, /*keep_raw=*/prm.write_raw, threads);
+        if (!smoothed) smooth_tracks(out_dir, prm.hmm, prm.write_smooth, prm.write_regions, /*keep_raw=*/prm.write_raw, threads, &done);
         st.smooth_seconds += sw.lap();
     }
     st.total_seconds = total.lap();

@@ -128,6 +128,7 @@ public:
         size_t restart_pos = pos_;
         int ref_leaf = -1;
         uint64_t ref_bases = 0, ref_bases_at_bp = 0;
+        size_t block_base = 0;   // length of every row before the current block
 
         while ((!stop || first_block) && pos_ < size_) {
             if (!freeze_restart) {
@@ -186,7 +187,12 @@ public:
                     skip_to_next_block();
                     break;
                 }
+                // malformed blocks are refused, by both forms of the reader alike (fill() below): a second row of a species, a row longer
+                // than its block's reference row.  A SHORTER row is padded with 'N' like a missing one (both forms).
+                if (aln.seqs[leaf].size() > block_base) throw std::runtime_error("species " + s.species_str() + " has two rows in one alignment block");
                 aln.seqs[leaf].append(s.text, s.text_len);
+                if (aln.seqs[leaf].size() > aln.seqs[ref_leaf].size())
+                    throw std::runtime_error("the row of species " + s.species_str() + " is longer than its block's reference row");
             }
             if (ref_leaf < 0) throw std::runtime_error("alignment block without any species of the model");
             first_block = false;
@@ -194,6 +200,7 @@ public:
             const size_t L = aln.seqs[ref_leaf].size();
             for (auto& row : aln.seqs)
                 if (row.size() != L) row.append(L - row.size(), 'N');
+            block_base = L;
         }
         if (reached_bp && ref_bases >= ref_bases_at_bp + 2) stop = true;
         if (stop && concatenate_) pos_ = restart_pos;
@@ -273,6 +280,9 @@ public:
         for (uint32_t b = 0; b < sp.n_blocks && pos_ < size_; ++b) {
             skip_line();  // the "a ..." line
             bool have_ref = false;
+            int ref_row_leaf = -1;
+            const char* ref_text = nullptr;
+            size_t ref_text_len = 0;
             size_t block_kept = 0;
             while (pos_ < size_ && data_[pos_] != 'a') {
                 if (data_[pos_] != 's') {
@@ -284,6 +294,9 @@ public:
                 if (leaf < 0) continue;
                 if (!have_ref) {   // the reference row: the runs of columns that stay
                     have_ref = true;
+                    ref_row_leaf = leaf;
+                    ref_text = s.text;
+                    ref_text_len = s.text_len;
                     runs_.clear();
                     for (size_t i = 0; i < s.text_len;) {
                         const void* g = memchr(s.text + i, '-', s.text_len - i);
@@ -294,7 +307,9 @@ public:
                         while (i < s.text_len && s.text[i] == '-') ++i;
                     }
                 }
-                if (filled_[static_cast<size_t>(leaf)] > written) throw std::runtime_error("species " + s.species_str() + " has two rows in one alignment block");
+                if (filled_[static_cast<size_t>(leaf)] > written || (leaf == ref_row_leaf && &s.text[0] != ref_text))
+                    throw std::runtime_error("species " + s.species_str() + " has two rows in one alignment block");
+                if (s.text_len > ref_text_len) throw std::runtime_error("the row of species " + s.species_str() + " is longer than its block's reference row");
                 char* row = base + static_cast<size_t>(leaf) * stride;
                 size_t at = written;
                 for (const auto& r : runs_) {

@@ -163,6 +163,32 @@ def test_synthetic_maf_across_the_break_point_matches_oracle_driver(tmp_path):
             assert got == want, n
 
 
+def test_a_failure_of_the_device_smoothing_pass_half_way_loses_nothing(tmp_path):
+    """--output-raw-phylo 0 (the raw tracks are removed once they are smoothed): the device pass is cut into groups of one track
+    (PCSF_HMM_GROUP_VALUES) and made to throw in its third group (PCSF_HMM_FAIL_GROUP): the two finished tracks must be kept as they
+    are, the other four come from the host pass, and the result equals an undisturbed run byte for byte -- no truncated file, no
+    missing raw track under the host pass, raw tracks removed only at the very end."""
+    import sys
+    maf = tmp_path / "syn.maf"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_synthetic_maf.py"), str(maf), "--bases", "24000", "--seed", "5"], stdout=subprocess.DEVNULL)
+    hmm = "0.004,55,0.45,0.45,0.1,800,9000,60"
+    outs = {}
+    for name, env in (("plain", {}), ("failing", {"PCSF_HMM_GROUP_VALUES": "1", "PCSF_HMM_FAIL_GROUP": "2"}), ("host", {"PCSF_HOST_HMM": "1"})):
+        out = tmp_path / name
+        r = subprocess.run([_cli(), "build-tracks", "--output", str(out), "--output-phylo", "1", "--output-regions", "1", "--output-raw-phylo", "0", "--hmm-params", hmm,
+                            os.path.join(GOLD, "models", "58mammals"), str(maf)], env=dict(os.environ, **env), stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr
+        assert ("the smoothing pass on the device failed" in r.stderr) == (name == "failing"), r.stderr
+        outs[name] = out
+    names = sorted(os.listdir(outs["plain"]))
+    assert len(names) == 13 and not any(n.startswith("PhyloCSFRaw") for n in names)      # power + 6 smoothed + 6 region files
+    for other in ("failing", "host"):
+        assert sorted(os.listdir(outs[other])) == names
+        for n in names:
+            a, b = open(outs["plain"] / n, "rb").read(), open(outs[other] / n, "rb").read()
+            assert len(a) > 100 and a == b, (other, n)
+
+
 def test_two_scoring_contexts_give_the_same_files(tmp_path):
     """--devices 0,0: two contexts (two host threads, two streams) share the batches of build-tracks and the block ranges
     of score-msa -- the multi-GPU code path of the driver, exercised on one GPU; outputs must not change."""

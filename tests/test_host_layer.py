@@ -87,6 +87,24 @@ def test_minus_strand_reference_is_rejected_in_build_tracks_mode(cli, tmp_path):
     assert _dump(cli, path, blocks=True)[0]["strand"] == "-"
 
 
+def test_malformed_blocks_are_refused_by_both_forms_of_the_reader(cli, tmp_path):
+    """A row longer than its block's reference row and a second row of a species in one block (the reference species included, also when
+    its first row is all gaps) are errors -- in next() (strings) and in measure() + fill() (the direct parse build-tracks uses) alike; a
+    SHORTER row is padded with N by both (the two forms had diverged on malformed input)."""
+    ok = "a score=0\ns chicken.chr1 10 4 + 1000 ACGT\ns turkey.chr1 10 2 + 1000 AC\n"
+    rows = _dump(cli, _write(tmp_path, ok, "ok.maf"))                       # _dump compares the two forms
+    assert rows[0]["seqs"][:2] == ["ACGT", "ACNN"] or "ACNN" in rows[0]["seqs"]
+    cases = {"long": ("a score=0\ns chicken.chr1 10 4 + 1000 ACGT\ns turkey.chr1 10 6 + 1000 ACGTAC\n", "longer than"),
+             "twice": ("a score=0\ns chicken.chr1 10 4 + 1000 ACGT\ns turkey.chr1 10 4 + 1000 ACGT\ns turkey.chr1 50 4 + 1000 ACGT\n", "two rows"),
+             "ref_twice": ("a score=0\ns chicken.chr1 10 4 + 1000 ACGT\ns chicken.chr1 20 4 + 1000 ACGT\n", "two rows"),
+             "gap_ref_twice": ("a score=0\ns chicken.chr1 10 4 + 1000 ACGT\n\na score=0\ns chicken.chr1 14 0 + 1000 ----\ns chicken.chr1 14 0 + 1000 ----\ns turkey.chr1 1 4 + 1000 ACGT\n", "two rows")}
+    for name, (maf, message) in cases.items():
+        path = _write(tmp_path, maf, name + ".maf")
+        for extra in ([], ["--matrix", "1"]):
+            r = subprocess.run([cli, "dump-alignments"] + extra + [MODEL, path], capture_output=True, text=True)
+            assert r.returncode != 0 and message in r.stderr, (name, extra, r.returncode, r.stderr)
+
+
 def test_frames_and_wig_text_on_a_tiny_alignment(cli, tmp_path):
     # 14 columns at 1-based position 101 on a chromosome of length 1000, three species with bases everywhere
     seq = "ATGGCCAAGTTTGA"
