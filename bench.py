@@ -18,6 +18,9 @@ Prints ONE JSON line on rank 0.  Extra objects:
   "strong"        the same path in STRONG scaling: BASELINE.json configs[3]'s total (100 Mb = 200 M codon-frames) cut into
                   contiguous 64-aligned ranges by phylocsfpp_amd.dist.shard_bounds, scores gathered to rank 0
                   (--scaling strong makes this the headline line instead)
+  "gather_check"  (N > 1; also inside "strong") the gather of the last step PROVEN outside the timed region: ranks_seen, equal (each rank's
+                  hash of its own scores == rank 0's hash of what RCCL delivered from it), recomputed_equal (rank 0 scored every rank's
+                  columns again: bit-identical) -- phylocsfpp_amd.dist.ScoreGatherPipeline.check
   "end_to_end"    (N = 1) `phylocsf-amd build-tracks 58mammals <synthetic 1 Mb 100-species MAF>` -- text in, seven wig
                   files out -- run in child processes (reference: src/phylocsf++build_tracks.hpp:55-260, README.rst:116)
   "blocks"        (N = 1) the other half of BASELINE.json configs[2]: `phylocsf-amd score-msa --strategy mle|omega` on the same
@@ -314,6 +317,8 @@ def end_to_end_multi(n_gpus, work_dir):
         out["wig_lines_differing_between_the_two"] = differing_lines(os.path.join(work_dir, "gpu_multi_all_devices"), os.path.join(work_dir, "gpu_multi_one_device"))
     except Exception as ex:
         out["wig_lines_differing_between_the_two"] = str(ex)[-200:]
+    # the multi-device run is only a measurement if it wrote what one device writes
+    out["outputs_check"] = {"devices_seen": n_gpus, "equal": out["wig_lines_differing_between_the_two"] == 0}
     os.remove(big)
     return out
 
@@ -429,6 +434,9 @@ def main():
     ap.add_argument("--end-to-end-runs", type=int, default=3, help="build-tracks CLI runs on the synthetic 1 Mb MAF (0 disables; N = 1 only)")
     ap.add_argument("--block-runs", type=int, default=2, help="score-msa --strategy mle / omega runs on the same MAF (0 disables; N = 1 only)")
     ap.add_argument("--other-models", type=int, default=1, help="1: also time prune_fixed on 53birds and 100vertebrates (three steps each; N = 1 only)")
+    ap.add_argument("--force-gather", type=int, default=0,
+                    help="1: at N = 1, run the N > 1 code path anyway (a world-size-1 RCCL process group, the pipelined gather and its "
+                         "gather_check) -- the one-GPU rehearsal of a SCALE run; changes what `value` times, so never the driver's line")
     ap.add_argument("--keep-files", default=None, help="directory for the synthetic MAF and the wig files (default: a temporary one)")
     args = ap.parse_args()
 
@@ -443,9 +451,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    gathered = world > 1 or bool(args.force_gather)     # the scores travel through an RCCL gather to rank 0
+    if gathered:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29655")
         if rank == 0:
             try:
                 os.remove("/tmp/pcsf_bench_done_%s" % os.environ.get("MASTER_PORT", "0"))
@@ -469,31 +479,33 @@ def main():
             step()
         fence()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if gathered:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed
 
-    def run_leg(n_local, lo, steps, warmup):
+    def run_leg(n_local, lo, steps, warmup, shard_lows=None):
         """Scores columns [lo, lo + n_local) of the synthetic stream `steps` times; N > 1: two score buffers per rank, the
         gather of step k (RCCL, its own stream) runs while step k+1 is scored.  Ragged strong-scaling shards are padded to
         the widest shard for the gather (like dist.gather_to_root)."""
         codons = sample_columns(pool, lo, lo + n_local, E2E_SEED)
         width = n_local
-        if world > 1:
+        if gathered:
             w = torch.tensor([n_local], dtype=torch.int64, device=dev)
             dist.all_reduce(w, op=dist.ReduceOp.MAX)
             width = int(w.item())
-        pipe = pdist.ScoreGatherPipeline(width, torch.float64, dev, depth=2, dst=0) if world > 1 else None
+        pipe = pdist.ScoreGatherPipeline(width, torch.float64, dev, depth=2, dst=0) if gathered else None
         scores = torch.empty(width, dtype=torch.float64, device=dev) if pipe is None else None
+
+        last_slot = [None]
 
         def step():
             if pipe is None:
                 ctx.score_sites_fixed_torch(codons, out=scores[:n_local])
             else:
                 ctx.score_sites_fixed_torch(codons, out=pipe.acquire()[:n_local])
-                pipe.submit()
+                last_slot[0] = pipe.submit()
 
         def fence():
             if pipe is not None:
@@ -502,17 +514,33 @@ def main():
             torch.cuda.synchronize()
 
         elapsed = timed(step, fence, steps, warmup)
-        return elapsed, codons
+        # Outside the timed region, N > 1: PROVE the gather of the last step.  Every rank hashes its own score buffer, the hashes are
+        # all-gathered, rank 0 hashes what RCCL delivered from every rank and compares; and rank 0 scores every rank's columns again
+        # itself (the site stream is a counter-based generator: any rank can make any range) and compares bit for bit.
+        check = None
+        if pipe is not None:
+            def recompute(r, n):
+                r_lo = r * n_local if shard_lows is None else shard_lows[r]
+                again = torch.empty(n, dtype=torch.float64, device=dev)
+                ctx.score_sites_fixed_torch(sample_columns(pool, r_lo, r_lo + n, E2E_SEED), out=again)
+                torch.cuda.synchronize()
+                return again
+            check = pipe.check(last_slot[0], n_local, recompute=recompute if rank == 0 else None)
+            if check is not None:
+                check["backend"] = dist.get_backend()
+                check["what"] = ("last step: hash of each rank's own scores == hash of what rank 0 received from it (ranks_seen of %d); "
+                                 "recomputed_equal: rank 0 scored every rank's columns again, bit-identical to what arrived" % world)
+        return elapsed, codons, check
 
     bounds = pdist.shard_bounds(args.total_sites, world, 64)
     if args.scaling == "weak":
         n_sites = args.sites
-        elapsed, codons = run_leg(n_sites, rank * n_sites, args.steps, args.warmup)
+        elapsed, codons, gather_check = run_leg(n_sites, rank * n_sites, args.steps, args.warmup)
         total_per_step = n_sites * world
     else:
         lo, hi = bounds[rank]
         n_sites = hi - lo
-        elapsed, codons = run_leg(n_sites, lo, args.steps, args.warmup)
+        elapsed, codons, gather_check = run_leg(n_sites, lo, args.steps, args.warmup, shard_lows=[b[0] for b in bounds])
         total_per_step = args.total_sites
 
     # dominant-kernel duration: HIP events recorded on the launch stream around each launch
@@ -564,13 +592,15 @@ def main():
     strong = None
     if args.scaling == "weak" and args.strong_steps > 0:
         lo, hi = bounds[rank]
-        s_elapsed, c2 = run_leg(hi - lo, lo, args.strong_steps, 1)
+        s_elapsed, c2, s_check = run_leg(hi - lo, lo, args.strong_steps, 1, shard_lows=[b[0] for b in bounds])
         del c2
         strong = {"scaling": "strong", "workload": "BASELINE.json configs[3] total: %d codon-frames (100 Mb x 6 frames) cut into contiguous "
                   "64-aligned ranges by dist.shard_bounds, one shared site stream, scores gathered to rank 0" % args.total_sites,
                   "total_codon_frames": args.total_sites, "steps": args.strong_steps, "warmup": 1,
                   "ms_per_step": s_elapsed / args.strong_steps * 1e3, "value": args.total_sites * args.strong_steps / s_elapsed,
                   "unit": "codon-frames/s", "n_gpus": world}
+        if s_check is not None:
+            strong["gather_check"] = s_check
     torch.cuda.empty_cache()
 
     if rank == 0:
@@ -596,12 +626,14 @@ def main():
                                    % (n_sites, "1 Mb per GPU, BASELINE.json configs[2]" if args.scaling == "weak" else
                                       "its contiguous share of %d = BASELINE.json configs[3]" % args.total_sites),
                        "model": MODEL, "n_leaves": int(m.nl), "sites_per_gpu": n_sites,
-                       "unique_columns": POOL_SITES, "sharding": "columns, gather of scores to rank 0" if world > 1 else "none",
+                       "unique_columns": POOL_SITES, "sharding": "columns, gather of scores to rank 0" if gathered else "none",
                        "ref_bases_per_s": total_per_step * args.steps / elapsed / 2.0},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "pcsf::prune_fixed", "kernel_ms": kernel_ms, "flop_per_codon_frame": fl},
         }
+        if gather_check is not None:
+            out["gather_check"] = gather_check
         if strong is not None:
             out["strong"] = strong
         if other_models:
@@ -648,6 +680,8 @@ def main():
                 if not args.keep_files:
                     shutil.rmtree(work, ignore_errors=True)
         print(json.dumps(out), flush=True)
+    if world == 1 and gathered:
+        dist.destroy_process_group()
     if world > 1:
         # ranks 1.. wait for rank 0's CLI leg on the HOST (a file, not a collective: an RCCL barrier would keep a spinning kernel on
         # the very GPUs the driver is being timed on)

@@ -103,6 +103,46 @@ class ScoreGatherPipeline:
     def result(self, slot):
         return self.recv[slot]
 
+    def check(self, slot, n_valid, recompute=None):
+        """Proves the gather of `slot` AFTER drain(): every rank hashes the first n_valid items of ITS OWN buffer of that slot (64-bit,
+        position-weighted, wrapping), the (hash, n_valid) pairs are all-gathered, and rank `dst` hashes what it RECEIVED from every
+        rank and compares.  recompute(rank, n) -> tensor (optional, rank dst only): the items rank `rank` should have produced,
+        computed again on `dst` -- compared bit for bit with what arrived.  Returns on dst a dict
+        {"ranks_seen", "equal", "ranks_differing", "recomputed_equal"}; None elsewhere.  A collective: every rank must call it."""
+        import torch
+        own = torch.stack([content_hash(self.bufs[slot][:n_valid]), torch.tensor(int(n_valid), dtype=torch.int64, device=self.bufs[slot].device)])
+        pairs = [torch.empty_like(own) for _ in range(self.world)]
+        self._dist.all_gather(pairs, own, group=self.group)
+        if self.rank != self.dst:
+            return None
+        differing, recomputed = [], (True if recompute is not None else None)
+        for r in range(self.world):
+            want, n = int(pairs[r][0].item()), int(pairs[r][1].item())
+            if int(content_hash(self.recv[slot][r][:n]).item()) != want:
+                differing.append(r)
+            if recompute is not None:
+                again = recompute(r, n)
+                if not torch.equal(again.contiguous().view(torch.uint8), self.recv[slot][r][:n].contiguous().view(torch.uint8)):   # bytes: NaN == NaN
+                    recomputed = False
+        return {"ranks_seen": len(pairs), "equal": not differing, "ranks_differing": differing, "recomputed_equal": recomputed,
+                "items_per_rank": [int(p_[1].item()) for p_ in pairs]}
+
+
+def content_hash(t):
+    """A 64-bit hash of a tensor's BYTES as a 0-d int64 tensor on its device: the 8-byte words times odd position weights, summed with
+    wrap-around (any changed, missing or misplaced word changes it with probability 1 - 2^-64 for random data)."""
+    import torch
+    if t.numel() == 0:
+        return torch.zeros((), dtype=torch.int64, device=t.device)
+    raw = t.contiguous().view(torch.uint8)
+    pad = (-raw.numel()) % 8
+    if pad:
+        raw = torch.cat([raw, torch.zeros(pad, dtype=torch.uint8, device=raw.device)])
+    w = raw.view(torch.int64)
+    weights = torch.arange(w.numel(), dtype=torch.int64, device=w.device) * 2 + 1
+    weights = weights * -7046029254386353131      # 0x9E3779B97F4A7C15 as int64: odd, so every weight stays odd
+    return (w * weights).sum()
+
 
 def score_sites_sharded(score_fn, codons, group=None, align=64, to_device=None):
     """run_tracks over `codons` (uint8 [n_leaves, n_sites], the same array on every rank or at least

@@ -53,6 +53,49 @@ def cli_scores(strategy, maf, out_dir, perturb):
     return np.array([float(r[4]) for r in rows], dtype=np.float64)
 
 
+def cli_scores_both(strategy, maf, out_dir, perturb):
+    """Both score columns (PhyloCSF score, ancestral score) of every row."""
+    os.makedirs(out_dir, exist_ok=True)
+    cli = os.path.join(ROOT, "oracle", "_build", "oracle_cli")
+    env = dict(os.environ, PO_PERTURB=str(perturb))
+    subprocess.check_call([cli, "score-msa", "--strategy", strategy, "--comp-anc", "1", "--output", out_dir,
+                           os.path.join(HERE, "models", "58mammals"), maf], env=env, stderr=subprocess.DEVNULL)
+    rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(out_dir, os.path.basename(maf) + ".scores")) if not l.startswith("#")][1:]
+    return np.array([[float(r[4]), float(r[5])] for r in rows], dtype=np.float64)
+
+
+def mle_full():
+    """the MLE control on ALL blocks of the bench's MAF (BASELINE.json configs[2]: 5,088 blocks), both score
+    columns -- the driver's bench line had shown a row at 0.040 > the reference's own MLE tolerance (test/tests.sh:41: d^2 <= 0.001)
+    beyond the 197-block prefix the first control covered.  Writes tests/golden/oracle/mle_control_full.npz (float32 text values are
+    exact in float64; ~400 KB) and profiles/r05/mle_control_full.txt."""
+    import tempfile
+    import gen_synthetic_maf as gen
+    tol = 0.001 ** 0.5
+    report = ["# tests/golden/make_omega_control.py --mle-full: oracle_cli score-msa --strategy mle --comp-anc 1 on the whole synthetic 1 Mb MAF",
+              "# (tools/gen_synthetic_maf.py --bases 1000000 --seed 20261002, 58mammals), against itself under po_set_perturbation 1, 2, 4, 7",
+              "# tolerance: the reference's own, test/tests.sh:41 (d^2 <= 0.001, i.e. |d| <= 0.0316)", ""]
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        maf = os.path.join(tmp, "synthetic_1mb.maf")
+        gen.generate(maf, bases=1_000_000, seed=20261002)
+        base = cli_scores_both("mle", maf, os.path.join(tmp, "mle_0"), 0)
+        res["base"] = base
+        print("base: %d rows" % len(base), flush=True)
+        for b in PERTURBATIONS:
+            res["p%d" % b] = cli_scores_both("mle", maf, os.path.join(tmp, "mle_%d" % b), b)
+            print("perturbation %d done" % b, flush=True)
+    for col, name in ((0, "PhyloCSF score"), (1, "ancestral score")):
+        spread = describe("configs[2], all blocks, 58mammals, MLE, %s" % name, base[:, col], {b: res["p%d" % b][:, col] for b in PERTURBATIONS}, tol, report)
+        report.append("  rows whose spread is >= 0.01: %s" % list(np.flatnonzero(spread >= 0.01)))
+        report.append("")
+    np.savez_compressed(os.path.join(HERE, "oracle", "mle_control_full.npz"), **res)
+    os.makedirs(os.path.join(ROOT, "profiles", "r05"), exist_ok=True)
+    with open(os.path.join(ROOT, "profiles", "r05", "mle_control_full.txt"), "w") as f:
+        f.write("\n".join(report) + "\n")
+    print("\n".join(report))
+
+
 def describe(name, base, pert, tol, out):
     ok = np.isfinite(base)
     out.append("%s: %d rows (%d finite)" % (name, len(base), int(ok.sum())))
@@ -106,4 +149,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--mle-full" in sys.argv:
+        mle_full()
+    else:
+        main()

@@ -113,6 +113,64 @@ def test_overlapped_gather_pipeline(tmp_path, world):
     assert np.load(out)[0] == 1.0
 
 
+def _gather_check_worker(rank, world, port, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    width = 1000
+    n_local = width - 37 * rank                      # ragged shards, padded for the gather like bench.py's strong leg
+    pipe = pdist.ScoreGatherPipeline(width, torch.float64, torch.device("cpu"), depth=2)
+
+    def produce(r, n, step):                          # what rank r computes in a step (stands for the scoring kernel)
+        g = torch.Generator().manual_seed(1000 * step + r)
+        v = torch.randn(n, dtype=torch.float64, generator=g)
+        v[::97] = float("nan")                        # NaN scores must compare equal to themselves
+        return v
+
+    last = None
+    for step in range(3):
+        buf = pipe.acquire()
+        buf[:n_local] = produce(rank, n_local, step)
+        last = pipe.submit()
+    pipe.drain()
+    good = pipe.check(last, n_local, recompute=(lambda r, n: produce(r, n, 2)) if rank == 0 else None)
+    wrong_recompute = pipe.check(last, n_local, recompute=(lambda r, n: produce(r, n, 1)) if rank == 0 else None)
+    if rank == 0:
+        pipe.result(last)[world - 1][5] += 1.0        # one word of the last rank's received buffer changes
+    bad = pipe.check(last, n_local)
+    if rank == 0:
+        ok = (good == {"ranks_seen": world, "equal": True, "ranks_differing": [], "recomputed_equal": True,
+                       "items_per_rank": [width - 37 * r for r in range(world)]}
+              and wrong_recompute["equal"] and wrong_recompute["recomputed_equal"] is False
+              and bad["equal"] is False and bad["ranks_differing"] == [world - 1] and bad["recomputed_equal"] is None)
+        np.save(out_path, np.array([float(ok)]))
+    else:
+        assert good is None and bad is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_check_proves_what_rank_0_received(tmp_path, world):
+    """bench.py --gpus N, after the timed region: every rank's hash of its own last buffer against rank 0's hash of what it received
+    from that rank, and rank 0's recomputation of every rank's shard (ScoreGatherPipeline.check)."""
+    out = str(tmp_path / "check.npy")
+    mp.spawn(_gather_check_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert np.load(out)[0] == 1.0
+
+
+def test_content_hash_sees_every_word_and_its_position():
+    x = torch.arange(1, 1001, dtype=torch.float64)
+    h = int(pdist.content_hash(x))
+    y = x.clone(); y[123] += 1e-9
+    z = x.clone(); z[[10, 11]] = z[[11, 10]]
+    assert int(pdist.content_hash(x.clone())) == h and int(pdist.content_hash(y)) != h and int(pdist.content_hash(z)) != h
+    assert int(pdist.content_hash(x[:999])) != h and int(pdist.content_hash(torch.zeros(0))) == 0
+    assert int(pdist.content_hash(torch.arange(13, dtype=torch.uint8))) != int(pdist.content_hash(torch.arange(14, dtype=torch.uint8)))
+
+
 def test_bench_site_stream_is_the_same_for_every_sharding():
     """bench.py materialises its synthetic site stream per rank on the rank's own GPU from a counter-based generator
     (column i = pool column hash(i, seed)): the strong-scaling shards of any world size must tile the one-GPU stream."""

@@ -41,6 +41,17 @@ pipe.drain()
 torch.cuda.synchronize()
 for slot in range(2):
     assert np.array_equal(pipe.result(slot)[0].cpu().numpy(), direct)
+# bench.py's proof of the gather (device hashes through an RCCL all-gather, rank 0's recomputation)
+def again(r, n):
+    o = torch.empty(n, dtype=torch.float64, device="cuda")
+    ctx.score_sites_fixed_torch(d, out=o)
+    torch.cuda.synchronize()
+    return o
+chk = pipe.check(slot, cod.shape[1], recompute=again)
+assert chk["ranks_seen"] == 1 and chk["equal"] and chk["recomputed_equal"] is True and chk["items_per_rank"] == [cod.shape[1]], chk
+pipe.result(slot)[0][17] += 1.0
+chk = pipe.check(slot, cod.shape[1])
+assert chk["equal"] is False and chk["ranks_differing"] == [0], chk
 # whole-block strategies through the block sharding (two floats per block gathered)
 off = np.array([0, 40, 41, 300, 5000], dtype=np.uint64)
 ph, an = pdist.score_blocks_sharded(lambda c, o: ctx.score_blocks(pa.FIXED, c, o, compute_anc=True), cod, off)
