@@ -209,6 +209,7 @@ def end_to_end(device, runs, cpu_rate_all_cores, work_dir):
            "seconds": best["seconds"], "seconds_all_runs": [r["seconds"] for r in gpu_runs],
            "process_wall_seconds": min(r["process_wall_seconds"] for r in gpu_runs),
            "process_wall_seconds_all_runs": [r["process_wall_seconds"] for r in gpu_runs],
+           "process_wall_seconds_median": float(np.median([r["process_wall_seconds"] for r in gpu_runs])),
            "startup_seconds_all_runs": [r["startup_seconds"] for r in gpu_runs],
            "codon_frames_per_s": best["codon_frames"] / best["seconds"],
            "codon_frames_per_s_process_wall": best["codon_frames"] / min(r["process_wall_seconds"] for r in gpu_runs),
@@ -358,6 +359,57 @@ def read_scores(path):
     return np.array([[float(x) for x in r[4:]] for r in rows], dtype=np.float64)
 
 
+def block_parity(strategy, gpu, cpu):
+    """Rows of the GPU .scores against the oracle's, BOTH score columns (PhyloCSF score; ancestral score where it is computed), with the
+    CONTROL beside them (tests/golden/oracle/*.npz: the oracle against itself under few-ulp perturbations of its sums, on the first rows of
+    this very file; tests/golden/make_omega_control.py): rows beyond the reference's own tolerance (test/tests.sh:41 MLE d^2 <= 0.001,
+    :46 OMEGA d^2 <= 0.1) and how many of those the control moves as well (spread >= 0.01 MLE / 0.1 OMEGA) -- a row beyond the tolerance
+    that the control does NOT move would be an arithmetic difference.  cpu None: the committed oracle results of the whole file (MLE)."""
+    gold = os.path.join(ROOT, "tests", "golden", "oracle")
+    tol, moved_at = (0.001 ** 0.5, 0.01) if strategy == "mle" else (0.1 ** 0.5, 0.1)
+    spread = base = None
+    try:
+        if strategy == "mle":
+            ctl = np.load(os.path.join(gold, "mle_control_full.npz"))
+            base = ctl["base"]
+            spread = np.max([np.abs(ctl["p%d" % b] - base) for b in (1, 2, 4, 7)], axis=0)
+        else:
+            ctl = np.load(os.path.join(gold, "omega_control.npz"))
+            base = ctl["config3_omega_base"][:, None]
+            spread = np.max([np.abs(ctl["config3_omega_p%d" % b][:, None] - base) for b in (1, 2, 4, 7)], axis=0)
+    except Exception:
+        pass
+    if cpu is None:
+        cpu = base
+    out = {"rows": int(len(cpu)), "reference_tolerance_decibans": tol}
+    names = ["phylocsf", "anc"] if strategy == "mle" else ["phylocsf"]
+    for col, name in enumerate(names):
+        g, o = gpu[:len(cpu), col], cpu[:, col]
+        both = np.isfinite(g) & np.isfinite(o)
+        d = np.where(both, np.abs(g - o), 0.0)
+        rel = d / np.maximum(1e-6, np.abs(np.where(both, o, 1.0)))
+        beyond = np.flatnonzero(d > tol)
+        col_out = {"nan_pattern_equal": bool(np.array_equal(np.isnan(g), np.isnan(o))), "finite_rows": int(both.sum()),
+                   "rows_within_1e-6_relative": int((rel[both] <= 1e-6).sum()), "max_abs_diff_decibans": float(d.max()) if len(d) else 0.0,
+                   "median_abs_diff_decibans": float(np.median(d[both])) if both.any() else 0.0, "rows_beyond_reference_tolerance": [int(i) for i in beyond]}
+        if spread is not None and base is not None and col < spread.shape[1]:
+            n_ctl = min(len(cpu), spread.shape[0])
+            same = bool(np.array_equal(o[:n_ctl], base[:n_ctl, col], equal_nan=True))     # the control was made on these rows by this oracle
+            col_out["control_rows"] = n_ctl
+            col_out["control_is_of_these_rows"] = same
+            col_out["of_which_moved_in_control"] = int(sum(1 for i in beyond if i < n_ctl and spread[i, col] >= moved_at))
+            col_out["beyond_tolerance_where_the_control_is_still"] = [int(i) for i in beyond if i < n_ctl and spread[i, col] < moved_at]
+            col_out["rows_the_control_itself_moves_beyond_tolerance"] = int((np.nan_to_num(spread[:n_ctl, col]) > tol).sum())
+        out[name] = col_out
+    # (kept at the top level for continuity with rounds 3-4: the PhyloCSF score column)
+    out["rows_within_1e-6_relative"] = out["phylocsf"]["rows_within_1e-6_relative"]
+    out["finite_rows"] = out["phylocsf"]["finite_rows"]
+    out["nan_pattern_equal"] = out["phylocsf"]["nan_pattern_equal"]
+    out["max_abs_diff_decibans"] = out["phylocsf"]["max_abs_diff_decibans"]
+    out["median_abs_diff_decibans"] = out["phylocsf"]["median_abs_diff_decibans"]
+    return out
+
+
 def block_strategies(device, maf, work_dir, runs):
     """configs[2], "fixed + omega MLE": score-msa --strategy mle and omega on the synthetic MAF (GPU CLI), and the oracle driver on a
     prefix of the same file sized for ~20 s per strategy; rows of the prefix compared between the two."""
@@ -380,6 +432,7 @@ def block_strategies(device, maf, work_dir, runs):
                "seconds": best["seconds"], "scoring_seconds": best["scoring_seconds"], "read_seconds": best["read_seconds"],
                "scoring_seconds_all_runs": [r["scoring_seconds"] for r in gpu_runs],
                "process_wall_seconds": min(r["process_wall_seconds"] for r in gpu_runs),
+               "process_wall_seconds_median": float(np.median([r["process_wall_seconds"] for r in gpu_runs])),
                "blocks_per_s": best["blocks"] / best["scoring_seconds"], "codon_columns_per_s": best["codon_columns"] / best["scoring_seconds"],
                "blocks_per_s_process_wall": best["blocks"] / min(r["process_wall_seconds"] for r in gpu_runs),
                "rounds": best["rounds_max"], "evaluations": best["evaluations"], "eigen_solves": best["eigen_solves"], "block_groups": best["groups"],
@@ -406,15 +459,14 @@ def block_strategies(device, maf, work_dir, runs):
         leg["vs_cpu"] = leg["codon_columns_per_s"] / leg["cpu"]["codon_columns_per_s"]
         # the prefix's rows, GPU against oracle
         try:
-            g, o = read_scores(best["scores"])[:cr["blocks"], 0], read_scores(cr["scores"])[:, 0]
-            both = np.isfinite(g) & np.isfinite(o)
-            d = np.abs(g[both] - o[both])
-            rel = d / np.maximum(1e-6, np.abs(o[both]))
-            leg["parity_on_cpu_sample"] = {"rows": int(len(o)), "nan_pattern_equal": bool(np.array_equal(np.isnan(g), np.isnan(o))),
-                                           "rows_within_1e-6_relative": int((rel <= 1e-6).sum()), "finite_rows": int(both.sum()),
-                                           "max_abs_diff_decibans": float(d.max()) if len(d) else 0.0, "median_abs_diff_decibans": float(np.median(d)) if len(d) else 0.0}
+            leg["parity_on_cpu_sample"] = block_parity(strategy, read_scores(best["scores"])[:cr["blocks"]], read_scores(cr["scores"]))
         except Exception as ex:
             leg["parity_on_cpu_sample"] = {"error": str(ex)[-300:]}
+        if strategy == "mle":   # ... and ALL rows against the committed oracle results of this very file (no CPU time in the bench)
+            try:
+                leg["parity_on_the_whole_file"] = block_parity(strategy, read_scores(best["scores"]), None)
+            except Exception as ex:
+                leg["parity_on_the_whole_file"] = {"error": str(ex)[-300:]}
         out[strategy] = leg
     return out
 

@@ -202,6 +202,20 @@ def test_omega_control_the_oracle_against_itself(oracle_models):
             assert frac <= 0.5 and d.max() >= 0.1, (tag, bits, frac, d.max())
     spread = np.max([np.abs(ctl["config3_omega_p%d" % b] - ctl["config3_omega_base"]) for b in (1, 2, 4, 7)], axis=0)
     assert (spread > 0.316).sum() >= 1          # the oracle misses the reference's OMEGA tolerance against ITSELF on a dense block
+    # The MLE control on ALL 5,088 blocks of configs[2] (round 5, make_omega_control.py --mle-full; both score columns): its first rows are the
+    # prefix's rows above -- the same oracle on the same blocks, so the live-oracle samples above vouch for it too -- and it says what
+    # README / DESIGN.md section 5 say: 99.6 % of the rows do not move at all, 18 move by more than 1e-6, FOUR beyond the reference's own
+    # MLE tolerance (test/tests.sh:41), the ancestral score never does.
+    full = np.load(os.path.join(GOLD, "oracle", "mle_control_full.npz"))
+    n = len(ctl["config3_mle_base"])
+    assert full["base"].shape == (5088, 2) and np.array_equal(full["base"][:n, 0], ctl["config3_mle_base"])
+    for bits in (1, 2, 4, 7):
+        assert np.array_equal(full["p%d" % bits][:n, 0], ctl["config3_mle_p%d" % bits])
+    fs = np.max([np.abs(full["p%d" % b] - full["base"]) for b in (1, 2, 4, 7)], axis=0)
+    rel = fs / np.maximum(1e-6, np.abs(full["base"]))
+    assert (rel[:, 0] > 1e-6).sum() == 18 and (rel[:, 1] > 1e-6).sum() == 15
+    assert list(np.flatnonzero(fs[:, 0] > 0.001 ** 0.5)) == [302, 2024, 3604, 4857] and 0.14 <= fs[:, 0].max() <= 0.16
+    assert fs[:, 1].max() < 0.01
 
 
 def test_omega_nan_policy_is_pinned(oracle_models):
