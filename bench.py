@@ -367,12 +367,13 @@ def block_parity(strategy, gpu, cpu):
     that the control does NOT move would be an arithmetic difference.  cpu None: the committed oracle results of the whole file (MLE)."""
     gold = os.path.join(ROOT, "tests", "golden", "oracle")
     tol, moved_at = (0.001 ** 0.5, 0.01) if strategy == "mle" else (0.1 ** 0.5, 0.1)
-    spread = base = None
+    spread = base = sized = None
     try:
         if strategy == "mle":
             ctl = np.load(os.path.join(gold, "mle_control_full.npz"))
             base = ctl["base"]
             spread = np.max([np.abs(ctl["p%d" % b] - base) for b in (1, 2, 4, 7)], axis=0)
+            sized = [np.abs(ctl["p%d" % b] - base) for b in (8, 16)]   # the oracle against itself, every site's ln z moved by <= 1.1e-13 relative
         else:
             ctl = np.load(os.path.join(gold, "omega_control.npz"))
             base = ctl["config3_omega_base"][:, None]
@@ -400,6 +401,9 @@ def block_parity(strategy, gpu, cpu):
             col_out["of_which_moved_in_control"] = int(sum(1 for i in beyond if i < n_ctl and spread[i, col] >= moved_at))
             col_out["beyond_tolerance_where_the_control_is_still"] = [int(i) for i in beyond if i < n_ctl and spread[i, col] < moved_at]
             col_out["rows_the_control_itself_moves_beyond_tolerance"] = int((np.nan_to_num(spread[:n_ctl, col]) > tol).sum())
+            if sized is not None:   # a perturbation of the size measured between the HIP path and the oracle: which rows it moves is random, how many is not
+                col_out["rows_beyond_tolerance_in_the_implementation_sized_control"] = [int((x[:n_ctl, col] > tol).sum()) for x in sized]
+                col_out["rows_within_1e-6_in_the_implementation_sized_control"] = [int((x[:n_ctl, col] / np.maximum(1e-6, np.abs(base[:n_ctl, col])) <= 1e-6).sum()) for x in sized]
         out[name] = col_out
     # (kept at the top level for continuity with rounds 3-4: the PhyloCSF score column)
     out["rows_within_1e-6_relative"] = out["phylocsf"]["rows_within_1e-6_relative"]

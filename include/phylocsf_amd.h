@@ -314,7 +314,7 @@ int pcsf_debug_maxlik(double (*objective)(double x, void *user), void *user, dou
                       uint32_t seed, int skip_draws, double *xs_out, int cap, int *n_evals, double *last_lpr);
 /* The same search ON THE DEVICE (the state machine the MLE / OMEGA engine runs per block, csrc/chain.hip), fed with a RECORDED sequence of
  * objective values: the points it asks for go to xs_out (at most cap), *n_requests = how many it asked for, or -1 when it wanted more
- * values than n_values.  A search that takes the decisions of the one that produced `values` asks for exactly its points. */
+ * values than n_values (xs_out[n_values] is then the point it is waiting for).  A search that takes the decisions of the one that produced `values` asks for exactly its points. */
 int pcsf_debug_maxlik_device(pcsf_ctx *ctx, double init, double lo, double hi, uint32_t seed, int skip_draws, const double *values,
                              int n_values, double *xs_out, int cap, int *n_requests, double *last_lpr);
 /* Test hook: the number formatter of csrc/wig.hip (print_trimmed, src/common.hpp:48-68: "%.3f" / "%.4f" without trailing zeros, one decimal kept)

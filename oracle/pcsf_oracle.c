@@ -431,6 +431,11 @@ int po_make_all_P(const po_qdiag *qd, const po_tree *tree, double x, double *P)
  * (this oracle and the HIP path; two builds of the reference) the procedure itself accounts for.  Bits: 1 = the 64-term sums of
  * internal-node and gap messages run from state 63 down to 0; 2 = the root sum runs backwards; 4 = a block's site log-likelihoods are
  * added from the last site to the first.  0 (the default, and what every parity test uses) = the reference's order.
+ * Round 5, bits 8 and 16: a perturbation of the SIZE measured between the HIP path and this oracle instead of an ulp -- every site's
+ * ln z is multiplied by 1 + r 2^-43 (|r| <= 1, a hash of the site, of the bits of the tree scale and of the bit set: two independent
+ * draws), i.e. moved by up to 1.1e-13 relative; per-codon scores of the two implementations agree to 6e-14 (tests/test_gpu_fixed.py),
+ * objective values to 1.3e-13 (layer 2).  The few-ulp control understates how often an MLE search ends a Brent
+ * step apart between two IMPLEMENTATIONS (profiles/r05/mle_control_full.txt).
  * PO_PERTURB=<bits> in the environment sets it for the command-line driver. */
 static int g_perturb = -1;
 void po_set_perturbation(int bits) { g_perturb = bits; }
@@ -521,7 +526,16 @@ int po_lpr_leaves(const po_qdiag *qd, const po_tree *tree, double x, const uint8
     for (size_t k = 0; k < n_sites; ++k) {
         const size_t s = backwards ? n_sites - 1 - k : k;
         const double z = po_prune_site(tree, P, qd->prior, codons, leaf_stride, s, compute_anc ? ar : NULL);
-        const double lz = log(z);
+        double lz = log(z);
+        if (perturbation() & 24) {   /* control experiment only: an implementation-sized relative difference, see po_set_perturbation */
+            uint64_t h, xb;
+            memcpy(&xb, &x, sizeof xb);
+            h = (xb ^ (uint64_t)s * 0x9E3779B97F4A7C15ull ^ (uint64_t)(perturbation() & 24) << 56) * 0xD6E8FEB86659FD93ull;
+            h ^= h >> 32;
+            h *= 0xD6E8FEB86659FD93ull;
+            h ^= h >> 32;
+            lz *= 1.0 + ((double)(int64_t)h / 9223372036854775808.0) * 0x1p-43;
+        }
         l += lz;
         if (per_codon) per_codon[s] = lz;
         if (compute_anc) {

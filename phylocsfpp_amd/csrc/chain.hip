@@ -348,6 +348,7 @@ __global__ void maxlik_replay_kernel(double init, double lo, double hi, const do
         opt.supply(values[n], 0.0, dt, next);
         ++n;
     }
+    if (!opt.done() && n < cap) xs_out[n] = opt.request();   // the point it is waiting for (tools/mle_divergence.py drives a search step by step)
     *n_requests = opt.done() ? n : -1;   // -1: the search wanted more values than the recording holds (it took another path)
     last[0] = opt.last_lpr();
     last[1] = opt.last_x();

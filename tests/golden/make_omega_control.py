@@ -30,6 +30,7 @@ import oracle_binding as ob
 
 ALIASES = os.path.join(HERE, "models", "species_aliases.tsv")
 PERTURBATIONS = (1, 2, 4, 7)     # bits of po_set_perturbation: message sums reversed, root sum reversed, site sums reversed, all three
+IMPLEMENTATION_SIZED = (8, 16)   # every site's ln z moved by <= 1.1e-13 relative: two independent draws (round 5, the whole-file MLE control)
 PREFIX_BYTES = 3_600_000         # tests/test_gpu_config3_blocks.py
 
 
@@ -75,21 +76,28 @@ def mle_full():
     report = ["# tests/golden/make_omega_control.py --mle-full: oracle_cli score-msa --strategy mle --comp-anc 1 on the whole synthetic 1 Mb MAF",
               "# (tools/gen_synthetic_maf.py --bases 1000000 --seed 20261002, 58mammals), against itself under po_set_perturbation 1, 2, 4, 7",
               "# tolerance: the reference's own, test/tests.sh:41 (d^2 <= 0.001, i.e. |d| <= 0.0316)", ""]
-    res = {}
+    out_npz = os.path.join(HERE, "oracle", "mle_control_full.npz")
+    res = dict(np.load(out_npz)) if os.path.exists(out_npz) and "--extend" in sys.argv else {}   # --extend: only the perturbations not in the file yet
     with tempfile.TemporaryDirectory() as tmp:
         maf = os.path.join(tmp, "synthetic_1mb.maf")
         gen.generate(maf, bases=1_000_000, seed=20261002)
-        base = cli_scores_both("mle", maf, os.path.join(tmp, "mle_0"), 0)
-        res["base"] = base
+        if "base" not in res:
+            res["base"] = cli_scores_both("mle", maf, os.path.join(tmp, "mle_0"), 0)
+        base = res["base"]
         print("base: %d rows" % len(base), flush=True)
-        for b in PERTURBATIONS:
-            res["p%d" % b] = cli_scores_both("mle", maf, os.path.join(tmp, "mle_%d" % b), b)
+        for b in PERTURBATIONS + IMPLEMENTATION_SIZED:
+            if "p%d" % b not in res:
+                res["p%d" % b] = cli_scores_both("mle", maf, os.path.join(tmp, "mle_%d" % b), b)
             print("perturbation %d done" % b, flush=True)
     for col, name in ((0, "PhyloCSF score"), (1, "ancestral score")):
-        spread = describe("configs[2], all blocks, 58mammals, MLE, %s" % name, base[:, col], {b: res["p%d" % b][:, col] for b in PERTURBATIONS}, tol, report)
-        report.append("  rows whose spread is >= 0.01: %s" % list(np.flatnonzero(spread >= 0.01)))
+        spread = describe("configs[2], all blocks, 58mammals, MLE, %s; perturbations of a few ulp (sums in another order)" % name, base[:, col],
+                          {b: res["p%d" % b][:, col] for b in PERTURBATIONS}, tol, report)
+        report.append("  rows whose spread is >= 0.01: %s" % [int(i) for i in np.flatnonzero(spread >= 0.01)])
+        spread2 = describe("the same; perturbations of the size measured between the HIP path and the oracle (every site's ln z moved by <= 1.1e-13 relative)",
+                           base[:, col], {b: res["p%d" % b][:, col] for b in IMPLEMENTATION_SIZED}, tol, report)
+        report.append("  rows whose spread is >= 0.01: %s" % [int(i) for i in np.flatnonzero(spread2 >= 0.01)])
         report.append("")
-    np.savez_compressed(os.path.join(HERE, "oracle", "mle_control_full.npz"), **res)
+    np.savez_compressed(out_npz, **res)
     os.makedirs(os.path.join(ROOT, "profiles", "r05"), exist_ok=True)
     with open(os.path.join(ROOT, "profiles", "r05", "mle_control_full.txt"), "w") as f:
         f.write("\n".join(report) + "\n")

@@ -113,27 +113,61 @@ def test_omega_on_the_dense_blocks_of_config3(prefix_maf, tmp_path):
 def test_mle_on_the_whole_config3_list_against_the_control(full_maf, tmp_path):
     """VERDICT r04 item 1.  ALL 5,088 blocks of BASELINE.json configs[2], MLE, both score columns, against the oracle's results on the
     same file (tests/golden/oracle/mle_control_full.npz, made by tests/golden/make_omega_control.py --mle-full; the CPU suite ties the
-    fixture to the live oracle) and against the CONTROL in the same fixture -- the oracle against itself with the terms of a few sums added
-    in another order.  The control moves 18 rows by more than 1e-6 and FOUR beyond the reference's own tolerance (test/tests.sh:41:
-    d^2 <= 0.001), up to 0.15: searches that end one Brent step apart (profiles/r05/mle_control_full.txt).  So: >= 98 % of the device's
-    rows within north_star's 1e-6, and a device row beyond the reference's tolerance ONLY where the control moves too -- a row beyond
-    it where the control is still would be an arithmetic difference, not the procedure's."""
+    fixture to the live oracle) and against the two CONTROLS in the same fixture -- the oracle against itself
+      (a) with the terms of a few sums added in another order (a few ulp): 18 rows move by more than 1e-6, FOUR beyond the reference's own
+          tolerance (test/tests.sh:41: d^2 <= 0.001), up to 0.15;
+      (b) with every site's ln z moved by <= 1.1e-13 relative, the size measured between the HIP path and the oracle (two independent
+          draws): ~10 % of the rows move by more than 1e-6, 26 and 29 beyond the tolerance -- DIFFERENT rows in the two draws.
+    (profiles/r05/mle_control_full.txt.)  The objective is a step function of the tree scale at that level -- branch lengths are rounded
+    to float after scaling, src/instance.hpp:299-307 -- and a search reports its LAST probe, so which rows end a Brent step apart is a
+    property of the perturbation, not of the row.  Asserted: >= 98 % of the device's rows within north_star's 1e-6; no more rows beyond
+    the reference's tolerance, and none further out, than control (b) has; and for EVERY device row beyond the tolerance that control (a)
+    does not move, the difference is found: the oracle's search is traced and the device evaluates the objective at each of its points --
+    the values agree to <= 1e-9 relative along the whole path (observed <= 3e-11; tools/mle_divergence.py prints where the searches part)."""
     (coords, got), log = _run(CLI, "mle", full_maf, str(tmp_path / "gpu"), "1")
     assert "pruning kernel of this list: prune_tiles" in log
     ctl = np.load(os.path.join(ROOT, "tests", "golden", "oracle", "mle_control_full.npz"))
     base = ctl["base"]
     assert got.shape[0] == base.shape[0] == 5088
-    perts = [ctl["p%d" % b] for b in (1, 2, 4, 7)]
+    few_ulp = [ctl["p%d" % b] for b in (1, 2, 4, 7)]
+    sized = [ctl["p%d" % b] for b in (8, 16)]
     tol = 0.001 ** 0.5
+    unexplained = set()
     for col, name in ((0, "phylocsf"), (1, "anc")):
         d = np.abs(got[:, col] - base[:, col])
         rel = d / np.maximum(1e-6, np.abs(base[:, col]))
-        spread = np.max([np.abs(p_[:, col] - base[:, col]) for p_ in perts], axis=0)
+        spread = np.max([np.abs(p_[:, col] - base[:, col]) for p_ in few_ulp], axis=0)
         beyond = np.flatnonzero(d > tol)
-        print("MLE %s, %d rows: within 1e-6 relative %d (%.2f %%), rows beyond %.4f: %s (|d| %s; the control's spread there %s); the control itself moves %d rows beyond it"
-              % (name, len(d), int((rel <= 1e-6).sum()), 100.0 * (rel <= 1e-6).mean(), tol, list(beyond), np.round(d[beyond], 4), np.round(spread[beyond], 4), int((spread > tol).sum())))
+        c_beyond = [int((np.abs(p_[:, col] - base[:, col]) > tol).sum()) for p_ in sized]
+        c_max = max(float(np.abs(p_[:, col] - base[:, col]).max()) for p_ in sized)
+        c_frac = min(float((np.abs(p_[:, col] - base[:, col]) / np.maximum(1e-6, np.abs(base[:, col])) <= 1e-6).mean()) for p_ in sized)
+        print("MLE %s, %d rows: within 1e-6 relative %d (%.2f %%; control (b): %.1f %%), rows beyond %.4f: %s (|d| %s; control (a)'s spread there %s); control (b): %s rows beyond it, max %.3f"
+              % (name, len(d), int((rel <= 1e-6).sum()), 100.0 * (rel <= 1e-6).mean(), 100.0 * c_frac, tol, list(beyond), np.round(d[beyond], 4), np.round(spread[beyond], 4), c_beyond, c_max))
         assert (rel <= 1e-6).mean() >= 0.98
-        assert all(spread[i] >= 0.01 for i in beyond), (name, beyond, d[beyond], spread[beyond])
-        moved = np.flatnonzero(rel > 1e-6)
-        # rows that differ at all are, in their great majority, rows the control moves as well or rows a last Brent probe apart
-        assert len(moved) <= 0.02 * len(d)
+        assert len(beyond) <= max(c_beyond) and d.max() <= max(c_max, tol)
+        unexplained.update(int(i) for i in beyond if spread[i] < 0.01)
+    if unexplained:
+        # find the difference: the oracle's own search, every point of it evaluated on the device
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import maf_blocks
+        import oracle_binding as ob
+        import phylocsfpp_amd as pa
+        m = ob.OracleModel(MODEL)
+        cod, off = maf_blocks.block_codons(full_maf, m.labels, os.path.join(ROOT, "tests", "golden", "models", "species_aliases.tsv"), max_blocks=max(unexplained) + 1)
+        ctx = pa.load_model(MODEL).context()
+        try:
+            for b in sorted(unexplained):
+                block = np.ascontiguousarray(cod[:, int(off[b]):int(off[b + 1])])
+                _, _, entries = m.run_trace(ob.MLE, block, compute_anc=True)
+                worst = 0.0
+                for kind in (0, 1):
+                    E = [e for e in entries if e.kind == kind and not e.failed]
+                    xs, vo = np.array([e.x for e in E]), np.array([e.lpr for e in E])
+                    tiled = np.ascontiguousarray(np.tile(block, (1, len(E))))
+                    vd, failed = ctx.block_loglik(kind, tiled, (np.arange(len(E) + 1) * block.shape[1]).astype(np.uint64), xs)
+                    assert not failed.any()
+                    worst = max(worst, float((np.abs(vd - vo) / np.abs(vo))[xs >= 0.05].max()))
+                print("  row %d (control (a) is still): %d evaluations of the oracle's two searches replayed on the device, worst relative difference %.1e" % (b, len(entries), worst))
+                assert worst <= 1e-9, (b, worst)
+        finally:
+            ctx.close()
