@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "hmm.hpp"
+#include "parallel.hpp"
 #include "maf_reader.hpp"
 #include "packed_reader.hpp"
 #include "model_io.hpp"
@@ -259,35 +260,6 @@ inline int effective_threads()
         if (v >= 1) n = v;
     }
     return n;
-}
-
-// fn(i) for i in [0, n) on up to `threads` threads (dynamic schedule); the first exception is rethrown
-template <class Fn>
-inline void parallel_for(size_t n, int threads, Fn&& fn)
-{
-    if (n == 0) return;
-    const size_t nt = std::min<size_t>(n, static_cast<size_t>(std::max(threads, 1)));
-    if (nt == 1) {
-        for (size_t i = 0; i < n; ++i) fn(i);
-        return;
-    }
-    std::atomic<size_t> next{0};
-    std::exception_ptr error;
-    std::mutex error_lock;
-    auto work = [&]() {
-        try {
-            for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
-        } catch (...) {
-            std::lock_guard<std::mutex> g(error_lock);
-            if (!error) error = std::current_exception();
-            next.store(n);
-        }
-    };
-    std::vector<std::thread> pool;
-    for (size_t t = 1; t < nt; ++t) pool.emplace_back(work);
-    work();
-    for (auto& t : pool) t.join();
-    if (error) std::rethrow_exception(error);
 }
 
 inline std::string dirname_of(const std::string& path)

@@ -38,9 +38,67 @@
 
 #include "model_io.hpp"
 
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
 namespace pcsf_host {
 
 constexpr uint64_t BREAKPOINT_INTERVAL = 1000000;
+
+// ---- byte scanners of the text path (round 5: stage 1 of build-tracks was ~400 ns of thread time per ~240-byte line -- two libc calls and
+// two byte-wise walks per line; reference: the tokenizer of src/parallel_file_reader.hpp:180-245 is a malloc + strtok_r per row) ----
+namespace scan {
+// first '\n' or ' ' in [p, e), or e: ONE pass over a row's sequence finds its end (and a stray space, which ends the token)
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) inline const char* newline_or_space_avx2(const char* p, const char* e)
+{
+    const __m256i nl = _mm256_set1_epi8('\n'), sp = _mm256_set1_epi8(' ');
+    while (p + 32 <= e) {
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p));
+        const unsigned m = static_cast<unsigned>(_mm256_movemask_epi8(_mm256_or_si256(_mm256_cmpeq_epi8(v, nl), _mm256_cmpeq_epi8(v, sp))));
+        if (m) return p + __builtin_ctz(m);
+        p += 32;
+    }
+    while (p < e && *p != '\n' && *p != ' ') ++p;
+    return p;
+}
+// first position q in [p, e) with q[0] == '\n' and q[1] == 'a' (the line AFTER q starts a block), or e
+__attribute__((target("avx2"))) inline const char* newline_a_avx2(const char* p, const char* e)
+{
+    const __m256i nl = _mm256_set1_epi8('\n'), a = _mm256_set1_epi8('a');
+    while (p + 33 <= e) {
+        const __m256i v0 = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p)), v1 = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p + 1));
+        const unsigned m = static_cast<unsigned>(_mm256_movemask_epi8(_mm256_and_si256(_mm256_cmpeq_epi8(v0, nl), _mm256_cmpeq_epi8(v1, a))));
+        if (m) return p + __builtin_ctz(m);
+        p += 32;
+    }
+    while (p + 1 < e && !(p[0] == '\n' && p[1] == 'a')) ++p;
+    return p + 1 < e ? p : e;
+}
+inline bool have_avx2()
+{
+    static const bool yes = __builtin_cpu_supports("avx2");
+    return yes;
+}
+#endif
+inline const char* newline_or_space(const char* p, const char* e)
+{
+#if defined(__x86_64__)
+    if (have_avx2()) return newline_or_space_avx2(p, e);
+#endif
+    while (p < e && *p != '\n' && *p != ' ') ++p;
+    return p;
+}
+inline const char* newline_a(const char* p, const char* e)
+{
+#if defined(__x86_64__)
+    if (have_avx2()) return newline_a_avx2(p, e);
+#endif
+    while (p + 1 < e && !(p[0] == '\n' && p[1] == 'a')) ++p;
+    return p + 1 < e ? p : e;
+}
+}  // namespace scan
 
 struct Alignment {
     std::string chrom;
@@ -410,26 +468,14 @@ private:
         size_t text_len = 0;
     };
 
-    // to the next line that starts a block ('a'), from the start of a line
+    // to the next line that starts a block ('a'), from the start of a line: one streaming scan for "\na" (line by line with memchr it
+    // was ~40 ns per line of a walk that only wants the block's end; glibc's memmem with that needle runs at a fifth of memchr's speed)
     void skip_to_next_block()
     {
         if (pos_ >= size_ || data_[pos_] == 'a') return;
-        // line by line with memchr: glibc's memmem with a two-byte needle runs at a fifth of memchr's speed (7.8 against 36 GB/s on
-        // eight threads), and this walk is all that measure() does with most of the file
-        const char* p = data_ + pos_;
         const char* const end = data_ + size_;
-        for (;;) {
-            const void* nl = memchr(p, '\n', static_cast<size_t>(end - p));
-            if (!nl) {
-                pos_ = size_;
-                return;
-            }
-            p = static_cast<const char*>(nl) + 1;
-            if (p >= end || *p == 'a') {
-                pos_ = static_cast<size_t>(p - data_);
-                return;
-            }
-        }
+        const char* q = scan::newline_a(data_ + pos_, end);
+        pos_ = q < end ? static_cast<size_t>(q - data_) + 1 : size_;
     }
 
     void skip_line()
@@ -438,29 +484,36 @@ private:
         pos_ = nl ? static_cast<size_t>(static_cast<const char*>(nl) - data_) + 1 : size_;
     }
 
-    // "s <src> <start> <size> <strand> <srcSize> <text>", fields separated by runs of spaces
+    // "s <src> <start> <size> <strand> <srcSize> <text>", fields separated by runs of spaces.  The six short fields are walked byte by
+    // byte (~40 bytes), the sequence -- almost the whole line -- in ONE vector scan for its end (a newline, or a space: a stray field
+    // behind the sequence is ignored as before).
     SLine parse_s_line()
     {
-        const void* nl = memchr(data_ + pos_, '\n', size_ - pos_);
-        const size_t end = nl ? static_cast<size_t>(static_cast<const char*>(nl) - data_) : size_;
+        const char* const e = data_ + size_;   // (a line never runs past its newline: every walk below stops there)
         const char* p = data_ + pos_;
-        const char* e = data_ + end;
         const char* tok[7] = {nullptr};
         size_t len[7] = {0};
         int k = 0;
-        while (p < e && k < 7) {
+        while (k < 6) {
             while (p < e && *p == ' ') ++p;
-            if (p >= e) break;
+            if (p >= e || *p == '\n') break;
             const char* b = p;
-            if (k == 6) {  // the sequence: almost the whole line, searched with memchr instead of byte by byte
-                const void* sp = memchr(p, ' ', static_cast<size_t>(e - p));
-                p = sp ? static_cast<const char*>(sp) : e;
-            } else {
-                while (p < e && *p != ' ') ++p;
-            }
+            while (p < e && *p != ' ' && *p != '\n') ++p;
             tok[k] = b;
             len[k] = static_cast<size_t>(p - b);
             ++k;
+        }
+        const char* nl = nullptr;
+        if (k == 6) {
+            while (p < e && *p == ' ') ++p;
+            if (p < e && *p != '\n') {
+                const char* b = p;
+                p = scan::newline_or_space(p, e);
+                tok[6] = b;
+                len[6] = static_cast<size_t>(p - b);
+                k = 7;
+                nl = (p < e && *p == '\n') ? p : static_cast<const char*>(memchr(p, '\n', static_cast<size_t>(e - p)));
+            }
         }
         if (k < 7) throw std::runtime_error("malformed 's' line in MAF at byte " + std::to_string(pos_));
         SLine s;
@@ -477,7 +530,7 @@ private:
         s.text = tok[6];
         s.text_len = len[6];
         if (s.text_len && s.text[s.text_len - 1] == '\r') --s.text_len;
-        pos_ = nl ? end + 1 : size_;
+        pos_ = nl ? static_cast<size_t>(nl - data_) + 1 : size_;
         return s;
     }
 
