@@ -1042,6 +1042,26 @@ void run_chain(BlockEngine& eng, std::vector<Machine>& machines, int algo, bool 
         fp.longest_branch = eng.longest_branch;
         fp.fail = d_fail.as<uint32_t>();
     }
+    // prune_factored: every tile's op list compiled once, before the first round (PCSF_FACTORED_COMPILED=0: the work-groups derive it
+    // themselves at every evaluation, rounds 2-4's form -- A/B, same bits)
+    DeviceBuffer d_tile_desc, d_tile_programs, d_site_tile;
+    const bool compile_tiles = !eng.use_tiles && fp.op_meta && fp.n_ops <= 128 && eng.nl <= 128 && total_tiles > 0 &&
+                               !([] { const char* v = std::getenv("PCSF_FACTORED_COMPILED"); return v && v[0] == '0'; }());
+    if (compile_tiles) {
+        std::vector<TileDesc> tiles;
+        tiles.reserve(total_tiles);
+        for (size_t b = 0; b < nb; ++b)
+            for (uint64_t s0 = eng.off[b]; s0 < eng.off[b + 1]; s0 += 16)
+                tiles.push_back(TileDesc{s0, static_cast<uint32_t>(std::min<uint64_t>(16, eng.off[b + 1] - s0)), 0u});
+        HIP_TRY(d_tile_desc.reserve(tiles.size() * sizeof(TileDesc)));
+        HIP_TRY(d_tile_programs.reserve(tiles.size() * TILE_PROGRAM_WORDS * sizeof(uint32_t)));
+        HIP_TRY(d_site_tile.reserve(std::max<size_t>(1, n_sites) * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpyAsync(d_tile_desc.ptr, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, st0));
+        HIP_TRY(launch_compile_tiles(fp, d_tile_desc.as<TileDesc>(), static_cast<uint32_t>(tiles.size()), d_tile_programs.as<uint32_t>(), d_site_tile.as<uint32_t>(), st0));
+        HIP_TRY(hipStreamSynchronize(st0));   // `tiles` is a local; every stream of the rounds reads the programs
+        fp.tile_programs = d_tile_programs.as<uint32_t>();
+        fp.site_tile = d_site_tile.as<uint32_t>();
+    }
     EigenParams gp{};
     gp.jobs = cp.eig_jobs;
     gp.eig_right = eng.d_eig_r.template as<double>();

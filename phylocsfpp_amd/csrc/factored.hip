@@ -131,6 +131,113 @@ __device__ __forceinline__ unsigned long long fact_clock()
     return t;
 }
 
+// ---- a tile's op list, compiled once per call -------------------------------------------------------------------------
+// What prune_factored's work-groups derived from the op facts at the start of EVERY evaluation of a tile (rounds 2-4: a block of the
+// reference's test file is evaluated ~400 times under OMEGA, always with the same species present): which ops leave the all-ones tile
+// (skipped), which pushes only carry a message across an all-gap subtree (with their pops: one scaling), which ops only scale a message
+// in eigen form, the branch of every remaining op's edge by the op's rank, and per op whether the message before it / the tile its pop
+// takes back is all ones.  One wave per tile, the passes of the kernel below moved here word for word; the work-group of an evaluation
+// then loads 1.5 KB and walks the ops by rank ("compile the op list once per (block, tile)").
+__global__ __launch_bounds__(64) void compile_tiles_kernel(const FactoredParams p, const TileDesc* __restrict__ tiles, uint32_t n_tiles, uint32_t* __restrict__ programs,
+                                                           uint32_t* __restrict__ site_tile)
+{
+    __shared__ unsigned char lpush[128];
+    __shared__ uint32_t lout[3 * 128];
+    const uint32_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    const TileDesc td = tiles[tile];
+    const int lane = threadIdx.x;
+    const int n_ops = p.n_ops;
+    // the leaves with a codon in the tile: lane = leaf (two passes for 128)
+    unsigned long long has[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int leaf = 64 * k + lane;
+        bool any = false;
+        if (leaf < p.n_leaves)
+            for (uint32_t s2 = 0; s2 < td.n_sites; ++s2) any |= p.codons[static_cast<size_t>(leaf) * p.leaf_stride + td.site0 + s2] < 64u;
+        has[k] = __ballot(any);
+    }
+    const unsigned long long has0 = has[0], has1 = has[1];
+    uint32_t opw[2], mt[2];
+    unsigned long long ol0[2], ol1[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int j = 64 * k + lane;
+        const bool valid = j < n_ops;
+        opw[k] = valid ? p.program[j] : (static_cast<uint32_t>(F_ROOT_DEV) << 28);
+        mt[k] = valid ? p.op_meta[j] : 0u;
+        ol0[k] = valid ? p.op_leaves[2 * j] : 0ull;
+        ol1[k] = valid ? p.op_leaves[2 * j + 1] : 0ull;
+    }
+    lpush[lane] = 0;
+    lpush[64 + lane] = 0;
+    for (int i = lane; i < 3 * 128; i += 64) lout[i] = i < 128 ? (static_cast<uint32_t>(F_ROOT_DEV) << 28) : 0u;
+    __syncthreads();
+    unsigned long long ones_after[2], active[2], carried[2], push_carries[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int j = 64 * k + lane;
+        ones_after[k] = __ballot(j < n_ops && ((ol0[k] & has0) | (ol1[k] & has1)) == 0ull);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int j = 64 * k + lane;
+        const uint32_t code = opw[k] >> 28;
+        const bool before = lane > 0 ? ((ones_after[k] >> (lane - 1)) & 1ull) : (k == 1 && (ones_after[0] >> 63));   // op j - 1 left all ones
+        const int parking = static_cast<int>(mt[k] >> 18);   // the parking op of a pop (>= 1)
+        const bool parked_ones = parking > 0 && ((((parking - 1) >> 6) ? ones_after[1] : ones_after[0]) >> ((parking - 1) & 63) & 1ull);
+        const bool c = j < n_ops && code >= F_MM_POP0_DEV && code < F_ROOT_DEV && before && !parked_ones && parking < 128;
+        carried[k] = __ballot(c);
+        if (c) lpush[parking] = 1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) push_carries[k] = __ballot(64 * k + lane < n_ops && lpush[64 * k + lane] != 0);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int j = 64 * k + lane;
+        const uint32_t code = opw[k] >> 28;
+        const bool is_push = code >= F_MM_PUSH_CHERRY0_DEV && code < F_MM_POP0_DEV, is_root = code >= F_ROOT_DEV;
+        const bool after = (ones_after[k] >> lane) & 1ull;
+        const bool before = lane > 0 ? ((ones_after[k] >> (lane - 1)) & 1ull) : (k == 1 && (ones_after[0] >> 63));
+        const bool trivial = j < n_ops && ((after && !is_root && (!is_push || before)) || ((carried[k] >> lane) & 1ull));
+        active[k] = __ballot(j < n_ops && !trivial);
+    }
+    const int n_act0 = __popcll(active[0]);
+    const int n_active = n_act0 + __popcll(active[1]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if ((active[k] >> lane) & 1ull) {
+            const int j = 64 * k + lane;
+            const int at = (k ? n_act0 : 0) + __popcll(active[k] & ((1ull << lane) - 1ull));
+            const uint32_t code = opw[k] >> 28;
+            const bool has_edge = code != F_CHERRY_DEV && code < F_ROOT_DEV;
+            const int a = static_cast<int>((opw[k] >> 14) & 0x3fffu);
+            const bool a_has = ((a < 64 ? has0 >> a : has1 >> (a - 64)) & 1ull) != 0;
+            const int parking = static_cast<int>(mt[k] >> 18);
+            const bool parked_ones = parking > 0 && ((((parking - 1) >> 6) ? ones_after[1] : ones_after[0]) >> ((parking - 1) & 63) & 1ull);
+            const bool before = lane > 0 ? ((ones_after[k] >> (lane - 1)) & 1ull) : (k == 1 && (ones_after[0] >> 63));
+            const bool scales_only = !before && ((code == F_MM_LEAF_DEV && !a_has) || (code >= F_MM_POP0_DEV && code < F_ROOT_DEV && parked_ones) || ((push_carries[k] >> lane) & 1ull));
+            const bool ones_before = j > 0 && before;
+            lout[at] = opw[k];
+            lout[128 + at] = (has_edge ? static_cast<uint32_t>(p.slot_branch[mt[k] & 0x3fffu]) : 0u) | (scales_only ? 0x80000000u : 0u);
+            lout[256 + at] = (mt[k] & 0x3fffu) | (((mt[k] >> 14) & 0xfu) << 14) | (ones_before ? 1u << 18 : 0u) | (parked_ones ? 1u << 19 : 0u);
+        }
+    __syncthreads();
+    uint32_t* __restrict__ out = programs + static_cast<size_t>(tile) * TILE_PROGRAM_WORDS;
+    if (lane == 0) {
+        out[0] = static_cast<uint32_t>(n_active);
+        out[1] = out[2] = out[3] = 0u;
+        out[4] = static_cast<uint32_t>(has0);
+        out[5] = static_cast<uint32_t>(has0 >> 32);
+        out[6] = static_cast<uint32_t>(has1);
+        out[7] = static_cast<uint32_t>(has1 >> 32);
+        site_tile[td.site0] = tile;
+    }
+    for (int i = lane; i < 3 * 128; i += 64) out[8 + i] = lout[i];
+}
+
 // ---- the pruning kernel ----------------------------------------------------------------------------------------------
 // DEEP: the tree parks more than MAX_STACK_DEPTH_DEV tiles (none of the reference's eleven trees does): the parked tiles live in
 // scratch memory, dynamically indexed; otherwise in three register sets written and read with value selects (no scratch at all).
@@ -190,11 +297,23 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int j = 64 * k + lane;
-        const bool valid = facts && j < n_ops;
+        const bool valid = facts && j < n_ops && p.tile_programs == nullptr;
         opw[k] = valid ? p.program[j] : (static_cast<uint32_t>(F_ROOT_DEV) << 28);
         mt[k] = valid ? p.op_meta[j] : 0u;
         ol0[k] = valid ? p.op_leaves[2 * j] : 0ull;
         ol1[k] = valid ? p.op_leaves[2 * j + 1] : 0ull;
+    }
+    // (b') ... or the tile's compiled op list (round 5): by rank, 64 k + lane
+    const bool compiled = p.tile_programs != nullptr;
+    const uint32_t* __restrict__ tprog = compiled ? p.tile_programs + static_cast<size_t>(p.site_tile[job.site0]) * TILE_PROGRAM_WORDS : nullptr;
+    uint32_t cop[2] = {0, 0}, ci0[2] = {0, 0}, ci1[2] = {0, 0};
+    if (compiled) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            cop[k] = tprog[8 + 64 * k + lane];
+            ci0[k] = tprog[8 + 128 + 64 * k + lane];
+            ci1[k] = tprog[8 + 256 + 64 * k + lane];
+        }
     }
     // (c) the tile's codons (16 consecutive lanes hold one leaf's columns): the first 128 leaves in registers, ...
     unsigned cc[8];
@@ -277,8 +396,10 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
     // leaves 0..127 as two wave-uniform bit masks: most ops of a sparse tile then cost a few scalar instructions (the op loop's LDS
     // look-ups, not the products, were 70 % of a tile's time: PCSF_FACTORED_STAMPS)
     const unsigned long long t_prologue = stamping ? fact_clock() - t_begin : 0ull;
-    const unsigned long long has0 = __ballot(lane < p.n_leaves && lany[lane] != 0);
-    const unsigned long long has1 = __ballot(64 + lane < p.n_leaves && lany[64 + lane < p.n_leaves ? 64 + lane : 0] != 0);
+    const unsigned long long has0 = compiled ? (static_cast<unsigned long long>(tprog[4]) | (static_cast<unsigned long long>(tprog[5]) << 32))
+                                             : __ballot(lane < p.n_leaves && lany[lane] != 0);
+    const unsigned long long has1 = compiled ? (static_cast<unsigned long long>(tprog[6]) | (static_cast<unsigned long long>(tprog[7]) << 32))
+                                             : __ballot(64 + lane < p.n_leaves && lany[64 + lane < p.n_leaves ? 64 + lane : 0] != 0);
     auto leaf_has = [&](int a) __attribute__((always_inline)) -> bool {
         if (a < 64) return (has0 >> a) & 1ull;
         if (a < 128) return (has1 >> (a - 64)) & 1ull;
@@ -354,7 +475,7 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
     auto load_batch = [&](int rank0) __attribute__((always_inline)) {
         const unsigned long long t_in = stamping ? fact_clock() : 0ull;
         const int idx = rank0 + sj < n_active ? rank0 + sj : n_active - 1;
-        const uint32_t row = lrow_edge[idx];
+        const uint32_t row = compiled ? (idx < 64 ? __shfl(ci0[0], idx) : __shfl(ci0[1], idx - 64)) : lrow_edge[idx];
         chain16 = static_cast<uint32_t>(__ballot((row >> 31) != 0u && rank0 + sj < n_active)) & 0xffffu;   // lanes 0..15: sj = 0..15 of lane group 0
         if (OWN) {
             const Vec4 e = own_scale(static_cast<int>(row & 0x7fffffffu));
@@ -509,7 +630,57 @@ __global__ __launch_bounds__(256, 3) void prune_factored(const FactoredParams p)
 
     using std::false_type;
     using std::true_type;
-    if (facts) {
+    if (compiled) {
+        // the tile's compiled list: the ops that run, by rank (compile_tiles_kernel made what the passes of the next branch make)
+        n_active = static_cast<int>(__builtin_amdgcn_readfirstlane(tprog[0]));
+        while (rank < n_active) {
+            if ((rank & 15) == 0) load_batch(rank);
+            if ((chain16 >> (rank & 15)) & 1u) {   // an op that only applies its edge (see the next branch)
+                if (cur.mask == 0xffffu) {
+                    ++rank;
+                    continue;
+                }
+                if (!cur.eig) {   // real form: the L-product, then the scale
+                    const uint32_t i1 = rank < 64 ? __builtin_amdgcn_readlane(ci1[0], rank & 63) : __builtin_amdgcn_readlane(ci1[1], rank & 63);
+                    cur = apply_edge(static_cast<int>(i1 & 0x3fffu), cur, true_type{});
+                    ++rank;
+                    continue;
+                }
+                const uint32_t run_bits = ~(chain16 >> (rank & 15));
+                int n_run = run_bits ? __builtin_ctz(run_bits) : 16;
+                n_run = n_run < 16 - (rank & 15) ? n_run : 16 - (rank & 15);
+                n_run = n_run < n_active - rank ? n_run : n_active - rank;
+                for (int j = 0; j < n_run; ++j) {
+                    const int src = (lane & 48) | ((rank + j) & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cur.v.v[r] *= __shfl(pre[r], src);
+                }
+                rank += n_run;
+                continue;
+            }
+            const uint32_t op = rank < 64 ? __builtin_amdgcn_readlane(cop[0], rank & 63) : __builtin_amdgcn_readlane(cop[1], rank & 63);
+            const uint32_t i1 = rank < 64 ? __builtin_amdgcn_readlane(ci1[0], rank & 63) : __builtin_amdgcn_readlane(ci1[1], rank & 63);
+            if (i1 & (1u << 18)) {   // whatever cur holds is from before a run of skipped ops
+                cur.mask = 0xffffu;
+                cur.eig = false;
+            }
+            const bool stamp_op = stamping && p.stamp_classes != 0;
+            const unsigned long long t_op = stamp_op ? fact_clock() : 0ull;
+            run_op(op, static_cast<int>(i1 & 0x3fffu), static_cast<int>((i1 >> 14) & 0xfu), (i1 & (1u << 19)) != 0u, true_type{});
+            if (stamp_op) {
+                const uint32_t cls = (op >> 28) == F_CHERRY_DEV ? 0u : ((op >> 28) == F_MM_LEAF_DEV ? 1u : ((op >> 28) < F_MM_POP0_DEV ? 2u : 3u));
+                if ((op >> 28) < F_ROOT_DEV) {
+                    const unsigned long long dt = fact_clock() - t_op;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        t_class[k] += cls == k ? dt : 0ull;
+                        n_class[k] += cls == k ? 1ull : 0ull;
+                    }
+                }
+            }
+            ++rank;
+        }
+    } else if (facts) {
         // Skipping the ops of all-gap subtrees.  A trivial op still costs ~430 cycles of branchy scalar code, and 70 of the 100 ops of
         // a real tile (4 of 100 species present) are trivial.  schedule.hpp `program_facts` knows every op's leaf set, start slot,
         // stack depth and, for a pop, the parking op; with the tile's leaf bits a lane-parallel pass marks the ops whose result is
@@ -699,6 +870,14 @@ hipError_t launch_edge_scale(const ExpmEval* d_evals, uint32_t n_evals, uint32_t
     if (n_evals == 0) return hipSuccess;
     hipLaunchKernelGGL(edge_scale_kernel, dim3(n_evals), dim3(256), 0, stream, d_evals, n_branches, d_branch_len, d_eig_right, d_eig_left,
                        d_eig_lambda, d_scale_out, d_fail, dense_rows ? 1u : 0u);
+    return hipGetLastError();
+}
+
+hipError_t launch_compile_tiles(const FactoredParams& p, const TileDesc* d_tiles, uint32_t n_tiles, uint32_t* d_programs, uint32_t* d_site_tile, hipStream_t stream)
+{
+    if (n_tiles == 0) return hipSuccess;
+    if (!p.op_meta || !p.op_leaves || p.n_ops > 128 || p.n_leaves > 128) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(compile_tiles_kernel, dim3(n_tiles), dim3(64), 0, stream, p, d_tiles, n_tiles, d_programs, d_site_tile);
     return hipGetLastError();
 }
 

@@ -161,11 +161,28 @@ struct FactoredParams {
     uint32_t deep;              // the tree parks more tiles than the register stack holds (schedule.stack_depth > MAX_STACK_DEPTH)
     const uint64_t* op_leaves;  // [n_ops][2] and
     const uint32_t* op_meta;    // [n_ops]: schedule.hpp ProgramFacts of `program` (null: tree of more than 128 leaves -- no op is skipped)
+    // prune_factored, round 5: the tile's op list COMPILED once per call (compile_tiles_kernel) instead of derived from the op facts by every
+    // evaluation's work-group -- a tile's species set is fixed for its block's whole optimisation.  tile_programs[site_tile[job.site0]]:
+    // TILE_PROGRAM_WORDS words per tile (layout at compile_tiles_kernel); null: the work-group runs the facts passes itself (rounds 2-4).
+    const uint32_t* tile_programs;
+    const uint32_t* site_tile;  // [sites of the codon matrix]: the tile that starts at a site
     unsigned long long* product_count;   // may be null: every tile job adds the 64x64 x 64x16 products it ran (64 MFMAs = 131,072 FLOP each): the executed work of a call, for the roofline of the block strategies
     uint32_t stamp_classes;     // diagnostics: also stamp every op that runs, by class (stamps[8..15]; a stamp costs ~200 cycles: PCSF_FACTORED_STAMPS=2)
     unsigned long long* stamps; // diagnostics (may be null; PCSF_FACTORED_STAMPS): work-groups add cycles -- [0] whole kernel, [1] waiting for
                                 // edge-scale / leaf-column loads, [2] in products, [3] work-groups, [4] loads, [5] products
 };
+
+// One compiled tile: words [0] = ops that run, [4..7] = the leaves with a codon in the tile (two 64-bit sets), then three arrays of 128 by the
+// op's RANK among those that run: the op word; the branch of its edge | bit 31: it only scales a message in eigen form; its program slot |
+// stack depth << 14 | bit 18: the message before it is all ones | bit 19: the tile its pop takes back is all ones.
+constexpr uint32_t TILE_PROGRAM_WORDS = 8 + 3 * 128;
+struct TileDesc {
+    uint64_t site0;
+    uint32_t n_sites, pad;
+};
+// compiles tiles [0, n_tiles) of p's codon matrix and tree (p.op_meta must be there: trees of at most 128 leaves) into d_programs and
+// fills d_site_tile[tile.site0] = tile
+hipError_t launch_compile_tiles(const FactoredParams& p, const TileDesc* d_tiles, uint32_t n_tiles, uint32_t* d_programs, uint32_t* d_site_tile, hipStream_t stream);
 
 // evals[i].table selects the output row of d_scale_out and the failure flag; evals[i].eig the eigen-system
 // dense_rows: evaluation i of the list writes row i of d_scale_out (the caller passes the first row of the list) instead of row evals[i].table

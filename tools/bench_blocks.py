@@ -11,7 +11,7 @@ import oracle_binding as ob
 import maf_blocks
 
 maf = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] != "-" else os.path.join(ROOT, "tests/golden/score-msa/chr22.516alignments.maf.gz")
-max_blocks = int(sys.argv[2]) if len(sys.argv) > 2 else None
+max_blocks = (int(sys.argv[2]) or None) if len(sys.argv) > 2 else None
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 with_cpu = not (len(sys.argv) > 4 and sys.argv[4] == "nocpu")   # the oracle sample costs ~2 minutes of one host core
 m = ob.OracleModel(os.path.join(ROOT, "tests/golden/models/100vertebrates"))
