@@ -399,12 +399,16 @@ def block_parity(strategy, gpu, cpu):
             col_out["control_rows"] = n_ctl
             col_out["control_is_of_these_rows"] = same
             col_out["of_which_moved_in_control"] = int(sum(1 for i in beyond if i < n_ctl and spread[i, col] >= moved_at))
-            col_out["beyond_tolerance_where_the_control_is_still"] = [int(i) for i in beyond if i < n_ctl and spread[i, col] < moved_at]
+            col_out["beyond_tolerance_where_the_few_ulp_control_is_still"] = [int(i) for i in beyond if i < n_ctl and spread[i, col] < moved_at]
             col_out["rows_the_control_itself_moves_beyond_tolerance"] = int((np.nan_to_num(spread[:n_ctl, col]) > tol).sum())
             if sized is not None:   # a perturbation of the size measured between the HIP path and the oracle: which rows it moves is random, how many is not
                 col_out["rows_beyond_tolerance_in_the_implementation_sized_control"] = [int((x[:n_ctl, col] > tol).sum()) for x in sized]
                 col_out["rows_within_1e-6_in_the_implementation_sized_control"] = [int((x[:n_ctl, col] / np.maximum(1e-6, np.abs(base[:n_ctl, col])) <= 1e-6).sum()) for x in sized]
         out[name] = col_out
+    out["note"] = ("of_which_moved_in_control: rows the oracle itself moves under a few-ulp reordering of its sums; the rows where that control is still are "
+                   "searches that part from the oracle's in their last Brent steps with objective values equal to 5e-14 -- the GPU suite replays the oracle's "
+                   "search on the device for every such row (tests/test_gpu_config3_blocks.py; profiles/r05/mle_divergence.txt); the implementation-sized "
+                   "control (ln z of every site moved by <= 1.1e-13, independently per evaluation) moves far more rows than the device does")
     # (kept at the top level for continuity with rounds 3-4: the PhyloCSF score column)
     out["rows_within_1e-6_relative"] = out["phylocsf"]["rows_within_1e-6_relative"]
     out["finite_rows"] = out["phylocsf"]["finite_rows"]

@@ -186,7 +186,7 @@ def test_a_failure_of_the_device_smoothing_pass_half_way_loses_nothing(tmp_path)
         assert sorted(os.listdir(outs[other])) == names
         for n in names:
             a, b = open(outs["plain"] / n, "rb").read(), open(outs[other] / n, "rb").read()
-            assert len(a) > 100 and a == b, (other, n)
+            assert a == b and (len(a) > 100 or n.endswith("Regions.bed")), (other, n)      # (a frame may have no coding region)
 
 
 def test_two_scoring_contexts_give_the_same_files(tmp_path):
