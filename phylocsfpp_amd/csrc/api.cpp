@@ -569,6 +569,11 @@ void pcsf_debug_eigen_schedule(int32_t* pairs, int32_t* located)
     pcsf::eigen_schedule_for_tests(pairs, located);
 }
 
+int pcsf_debug_eigen_schedule_quads(int32_t* pairs)
+{
+    return pcsf::eigen_schedule_quads_for_tests(pairs);
+}
+
 int pcsf_debug_codon_matrix(pcsf_ctx* c, uint8_t* out, size_t capacity, size_t* n_sites)
 {
     if (!c || !out || !n_sites) return PCSF_ERR_INVALID_ARG;

@@ -20,6 +20,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "kernels.h"
 
@@ -123,11 +124,99 @@ __host__ __device__ __forceinline__ constexpr int shift_source(int G, int half)
 }
 }  // namespace rr
 
-// REG: 128 threads (wave 0: B, wave 1: V; two work-groups fit a CU); otherwise 256 threads with B and V in LDS
-template <bool REG>
-__global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const EigenParams p)
+// ---- seven-wave variant (FORM 2, round 5): the same schedule on QUADS of lanes ------------------------------------------------------
+// rr's rounds and step patterns, but a round's seating is refined into PHASES so that every step is a "cross" step on the seats a lane
+// holds: in phase 3 (rr's own seating) pattern 3 + t pairs seat k with seat 4 + ((k + t) & 3); the three steps of round 0 for the pairs
+// inside the groups (rr patterns 0..2) each get a phase of their own (0..2) in which the pattern's pair k is seated on (k, 4 + k) and
+// the step is the cross step t = 0.  tau(ph, q) = rr's seat on the physical seat q of a super-group, sigma = its inverse.
+namespace rq {
+__host__ __device__ __forceinline__ constexpr int tau(int ph, int q) { return ph == 3 ? q : (q < 4 ? rr::pair_a(ph, q) : rr::pair_b(ph, q - 4)); }
+__host__ __device__ __forceinline__ constexpr int sigma(int ph, int s)
 {
-    constexpr int NT = REG ? 128 : 256;     // threads
+    if (ph == 3) return s;
+    for (int q = 0; q < 8; ++q)
+        if (tau(ph, q) == s) return q;
+    return -1;
+}
+// canonical index of the physical seat (8 G + q) in round r, phase ph
+__host__ __device__ __forceinline__ int canon(int r, int ph, int seat)
+{
+    const int s = tau(ph, seat & 7);
+    return 4 * rr::group_of(r, seat >> 3, s >> 2) + (s & 3);
+}
+// the physical seat of (round r0, phase ph0) whose occupant sits on `seat` in (r1, ph1)
+__host__ __device__ __forceinline__ int source(int r0, int ph0, int r1, int ph1, int seat)
+{
+    const int s1 = tau(ph1, seat & 7);
+    const int loc = rr::locate(r0, rr::group_of(r1, seat >> 3, s1 >> 2));
+    return 8 * (loc & 7) + sigma(ph0, 4 * (loc >> 3) + (s1 & 3));
+}
+// The five re-seatings of a sweep: 0 = end of a round (every round: the same permutation), 1 = end of round 14 into phase 0 of round 0,
+// 2..4 = phase 0 -> 1 -> 2 -> 3 inside round 0
+__host__ __device__ __forceinline__ int reseat_source(int type, int seat)
+{
+    return type == 0 ? source(0, 3, 1, 3, seat) : type == 1 ? source(14, 3, 0, 0, seat) : source(0, type - 2, 0, type - 1, seat);
+}
+constexpr int quad_rot(int t) { return ((0 + t) & 3) | (((1 + t) & 3) << 2) | (((2 + t) & 3) << 4) | (((3 + t) & 3) << 6); }   // DPP quad_perm: lane j reads lane (j + t) & 3
+template <int CTRL>
+__device__ __forceinline__ double quad_perm(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// a phase change inside a round permutes the seats of a super-group: seat q of phase PH1 takes over from seat sigma(PH0, tau(PH1, q))
+template <int PH0, int PH1, typename T, int... Q>
+__host__ __device__ __forceinline__ void permute_seats(T* v8, std::integer_sequence<int, Q...>)
+{
+    const T t8[8] = {v8[std::integral_constant<int, sigma(PH0, tau(PH1, Q))>::value]...};
+    ((v8[Q] = t8[Q]), ...);
+}
+// The end of a round as a V wave sees it (W = 0: seats of the super-groups 0..3, W = 1: 4..7, 8 G + q each): every group of four seats
+// but (0, 1) moves one place round the table (rr::shift_source); the cycle (0,0) <- (1,0) <- ... <- (7,0) <- (7,1) <- (6,1) <- ... <- (1,1)
+// <- (0,0) crosses the two waves at (3,0) <- (4,0) and (4,1) <- (3,1): `leaving` is what the wave hands over, `arriving` what it receives.
+template <int W>
+__host__ __device__ __forceinline__ constexpr int leaving_group() { return W == 0 ? 28 : 0; }   // first seat of (3,1) / of (4,0), wave-local
+template <int W, typename T>
+__host__ __device__ __forceinline__ void shift_groups(T* v, const T* arriving)
+{
+    auto mv = [&](int to, int from) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[to + q] = v[from + q];
+    };
+    if constexpr (W == 0) {
+        T keep[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) keep[q] = v[q];
+        mv(0, 8);     // (0,0) <- (1,0)
+        mv(8, 16);    // (1,0) <- (2,0)
+        mv(16, 24);   // (2,0) <- (3,0)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[24 + q] = arriving[q];   // (3,0) <- (4,0)
+        mv(28, 20);   // (3,1) <- (2,1)
+        mv(20, 12);   // (2,1) <- (1,1)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[12 + q] = keep[q];       // (1,1) <- (0,0)
+    } else {
+        mv(0, 8);     // (4,0) <- (5,0)
+        mv(8, 16);    // (5,0) <- (6,0)
+        mv(16, 24);   // (6,0) <- (7,0)
+        mv(24, 28);   // (7,0) <- (7,1)
+        mv(28, 20);   // (7,1) <- (6,1)
+        mv(20, 12);   // (6,1) <- (5,1)
+        mv(12, 4);    // (5,1) <- (4,1)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[4 + q] = arriving[q];    // (4,1) <- (3,1)
+    }
+}
+}  // namespace rq
+
+// FORM 0: 256 threads, B and V in LDS (the first version).  FORM 1: 128 threads, wave 0 holds B, wave 1 V, in registers (rounds 2-4; two
+// work-groups fit a CU).  FORM 2 (round 5): 448 threads -- a rotation wave, four waves of B in quads of lanes, two waves of V (see there).
+template <int FORM>
+__global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 ? 4 : 1) void eigen_omega_kernel(const EigenParams p)
+{
+    constexpr int NT = FORM == 1 ? 128 : FORM == 2 ? 448 : 256;     // threads
     const bool stamping = p.stamps != nullptr && blockIdx.x == 0;
     const unsigned long long t_kernel = stamping ? eig_clock() : 0ull;
     unsigned long long acc_a = 0, acc_rot = 0, acc_v = 0, acc_b = 0, n_steps = 0, n_sweeps = 0;
@@ -225,7 +314,8 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
         // operands read from the two LDS matrices (row length 65: two lanes per bank at worst).  As scalar loops -- 32 entries and 4,096
         // LDS reads per thread and product -- they were 50 us of a 0.31 ms warm solve (profiles/r03/eigen_kernel.txt, variant R0).
         typedef double double4_loc __attribute__((ext_vector_type(4)));
-        constexpr int TI = 4 / (NT / 64);   // row tiles per wave
+        constexpr int TI = NT >= 256 ? 1 : 4 / (NT / 64);   // row tiles per wave
+        const int mw = wave * TI < 4 ? wave : 4 / TI - 1;     // (waves beyond the fourth repeat its tile: the same values to the same places)
         const int ms = lane & 15, mg = lane >> 4;
         double4_loc acc[TI][4];
         // T = B V0
@@ -237,7 +327,7 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
         for (int kk = 0; kk < 16; ++kk) {
             double fa[TI], fb[4];
 #pragma unroll
-            for (int a = 0; a < TI; ++a) fa[a] = A[(16 * (wave * TI + a) + ms) * LD + 4 * kk + mg];
+            for (int a = 0; a < TI; ++a) fa[a] = A[(16 * (mw * TI + a) + ms) * LD + 4 * kk + mg];
 #pragma unroll
             for (int b = 0; b < 4; ++b) fb[b] = V[(4 * kk + mg) * LD + 16 * b + ms];
 #pragma unroll
@@ -251,7 +341,7 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) A[(16 * (wave * TI + a) + 4 * r + mg) * LD + 16 * b + ms] = acc[a][b][r];
+                for (int r = 0; r < 4; ++r) A[(16 * (mw * TI + a) + 4 * r + mg) * LD + 16 * b + ms] = acc[a][b][r];
         __syncthreads();
         // C = V0^T T: A operand V0^T[i][k] = V0[k][i]
 #pragma unroll
@@ -262,7 +352,7 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
         for (int kk = 0; kk < 16; ++kk) {
             double fa[TI], fb[4];
 #pragma unroll
-            for (int a = 0; a < TI; ++a) fa[a] = V[(4 * kk + mg) * LD + 16 * (wave * TI + a) + ms];
+            for (int a = 0; a < TI; ++a) fa[a] = V[(4 * kk + mg) * LD + 16 * (mw * TI + a) + ms];
 #pragma unroll
             for (int b = 0; b < 4; ++b) fb[b] = A[(4 * kk + mg) * LD + 16 * b + ms];
 #pragma unroll
@@ -276,7 +366,7 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) A[(16 * (wave * TI + a) + 4 * r + mg) * LD + 16 * b + ms] = acc[a][b][r];
+                for (int r = 0; r < 4; ++r) A[(16 * (mw * TI + a) + 4 * r + mg) * LD + 16 * b + ms] = acc[a][b][r];
         __syncthreads();
         for (int idx = tid; idx < 4096; idx += NT) {  // exact symmetry again
             const int i = idx >> 6, j = idx & 63;
@@ -288,7 +378,7 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
         }
         __syncthreads();
     }
-    if constexpr (!REG) {
+    if constexpr (FORM == 0) {
     // rotations of one step into buffer `buf`: tournament pairing of 0..63 (63 stays, the others rotate), lanes 0..31 of wave 0
     auto rotations = [&](int step, int buf) {
         if (tid < 32) {
@@ -440,7 +530,7 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
         }
     }
     if (!lds_converged && tid == 0) p.fail[job.table] = 1u;   // sweeps used up (a NaN makes the stop test false for ever): flagged, see below
-    } else {
+    } else if constexpr (FORM == 1) {
     // ================= register-resident sweeps: wave 0 owns B, wave 1 owns V ==================
     double2_loc* rt = reinterpret_cast<double2_loc*>(rot);   // [buf][super-group * 4 + pair] = (cos, sin)
     __shared__ __attribute__((aligned(16))) double dg[32 * 2];  // [super-group * 4 + pair] = (B[b][b] - B[a][a], 2 B[a][b]) of the next step's pairs
@@ -796,6 +886,403 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
             for (int sl = 0; sl < 8; ++sl) V[lane * LD + 4 * rr::group_of(r, G, sl >> 2) + (sl & 3)] = v[8 * G + sl];
     }
     __syncthreads();
+    } else {
+    // ================= seven waves: a rotation wave, four waves of B (a quad of lanes per 8x8 block), two waves of rows of V =================
+    // Why (profiles/r05/eigen_forms/README.txt): a step of FORM 1 is ONE wave's serial instruction stream -- 256 fp64 instructions of B
+    // update, the next pairs' operands to LDS and back, the rotation chain, the rotations to LDS, a barrier: ~2,450 cycles.  Here
+    //  * the 8x8 block (R, C) of B lives in a QUAD of lanes: lane j holds the block's column j and ONE column of the second group, in
+    //    step t column 4 + ((j + t) & 3) -- the two columns of the lane's rotation pair -- with the rows in the lane's own order
+    //    (position m = row (j + m) & 3 of either group), so that every operand of a step sits in a register known at compile time: 32
+    //    FMAs per lane and step, and between two steps the moving column travels one lane round the quad (DPP quad_perm, no LDS);
+    //  * wave 0 keeps COPIES of the eight diagonal blocks (updated with the same instructions as the originals: same bits) and makes
+    //    each step's 32 rotations from them, one per lane, all three operands in the lane's own registers; it owns D;
+    //  * waves 5-6, lane = row of V, 32 columns each in seat order.
+    // Scaled ("fast") rotations: B = D Bs D, V = Vs D with a diagonal D that absorbs every cosine, so a rotation by tan t is
+    // x <- x - alpha y, y <- y + beta x (alpha = t d_b / d_a, beta = t d_a / d_b; d <- d cos): two FMAs per element pair, and t, which
+    // only decides how well the pair is annihilated, never orthogonality, comes from an fp32 chain.
+    // One LDS hand-over (the rotations) and one barrier per step; every fourth step the blocks of B pass through LDS to their next seats.
+    double2_loc* rt = reinterpret_cast<double2_loc*>(rot);         // [buf][super-group * 4 + pair] = (alpha, beta)
+    __shared__ __attribute__((aligned(16))) double dtab[64 * 2];   // (d, 1/d) per physical seat: written for a re-seating
+    __shared__ double dtab2[64];                                   // d per physical seat: written for a stop test
+    __shared__ int zfl[2 * 32];                                    // [buf][super-group * 4 + pair]: the pair is set to zero behind its rotation
+    __shared__ unsigned char seat_tab[5 * 64];                     // rq::reseat_source
+    __shared__ int tflag;                                          // wave 0 -> all: run the stop test after this re-seating
+    if (tid < 320) seat_tab[tid] = static_cast<unsigned char>(rq::reseat_source(tid >> 6, tid & 63));
+    auto rsqrt_nr = [](double x) {
+        double y = __builtin_amdgcn_rsq(x);
+        const double hx = 0.5 * x;
+#pragma unroll
+        for (int it = 0; it < 3; ++it) y = y * __builtin_fma(-hx, y * y, 1.5);
+        return y;
+    };
+    // tangent of the annihilating rotation from the SCALED entries and rho = d_b / d_a, irho = d_a / d_b: B[b][b] - B[a][a] and 2 B[a][b], both
+    // divided by d_a d_b > 0, are rho Bs[b][b] - irho Bs[a][a] and 2 Bs[a][b]; t = h sgn(d) / (|d| + sqrt(d^2 + h^2)) as in FORM 1's rotation_of,
+    // on operands scaled by a power of two, in fp32.  Returns (alpha, beta).
+    auto rotation_scaled = [&](double baa, double bbb, double bab, double rho, double irho) {
+        const double d = __builtin_fma(rho, bbb, -(irho * baa));
+        const double h = bab + bab;
+        const int e = __builtin_amdgcn_frexp_exp(fabs(d) + fabs(h));
+        const float df = static_cast<float>(__builtin_amdgcn_ldexp(d, -e)), hf = static_cast<float>(__builtin_amdgcn_ldexp(h, -e));
+        const float x = __builtin_fmaf(df, df, hf * hf);                      // in [1/8, 1) unless both vanish
+        const float w = __builtin_fabsf(df) + __builtin_amdgcn_sqrtf(x);
+        float t = (df < 0.0f ? -hf : hf) * __builtin_amdgcn_rcpf(w);         // sgn(0) = +1: 45 degrees
+        t = (hf == 0.0f) ? hf : t;                                            // no rotation (0 / 0 otherwise); a NaN is not == 0 and stays
+        const double td = static_cast<double>(t);
+        return double2_loc{td * rho, td * irho};
+    };
+    using std::integral_constant;
+    // The roles run the SAME sequence of barriers from specialisations of one body (ROLE 0: the rotation wave, 1: blocks of B, 2 / 3: the
+    // first / second four super-groups of V's columns), so that a wave's registers hold only what its role needs.
+    auto body = [&](auto role_tag) {
+    constexpr int ROLE = decltype(role_tag)::value;
+    constexpr bool MK = ROLE == 0, BW = ROLE == 1, VW = ROLE >= 2;
+    constexpr int W = VW ? ROLE - 2 : 0;
+    const int j = lane & 3;
+    const int blk = MK ? 9 * ((lane >> 2) & 7) : ((tid - 64) >> 2);   // 8 R + C (wave 0: the diagonal blocks, twice)
+    const int R = blk >> 3, C = blk & 7;
+    const bool diag = R == C;
+    auto rowseat = [&](int pos) { return (pos & 4) + ((j + pos) & 3); };   // the row (physical seat within the super-group) at a lane's position
+    double c0[8], c1[8];   // column j / the moving column of the block, by position
+    double v[32];          // V waves: row `lane`, seats 8 Gl + q of the super-groups 4 W + Gl
+    if constexpr (!VW) {
+#pragma unroll
+        for (int pos = 0; pos < 8; ++pos) {
+            const int rc = rq::canon(0, 0, 8 * R + rowseat(pos));
+            c0[pos] = A[rc * LD + rq::canon(0, 0, 8 * C + j)];
+            c1[pos] = A[rc * LD + rq::canon(0, 0, 8 * C + 4 + j)];
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) v[s] = V[lane * LD + rq::canon(0, 0, 32 * W + s)];
+    }
+    __syncthreads();   // everything is in registers: A becomes the staging matrix of the re-seatings (by physical seat), V the exchange buffer
+    double* S = A;
+    double2_loc* xch = reinterpret_cast<double2_loc*>(V);   // [V wave][row][2]: the group of four columns that changes waves at a round's end
+    int crow[8], ccol[2];   // re-seating 0 (every round's end): where the lane's next rows / columns sit in the staged matrix
+    if constexpr (!VW) {
+#pragma unroll
+        for (int pos = 0; pos < 8; ++pos) crow[pos] = seat_tab[8 * R + rowseat(pos)] * LD;
+        ccol[0] = seat_tab[8 * C + j];
+        ccol[1] = seat_tab[8 * C + 4 + j];
+    }
+    double dA = 1.0, idA = 1.0, dB = 1.0, idB = 1.0;   // wave 0: (d, 1/d) of the seats j and 4 + j of super-group R
+    double pc = 1.0, pic = 1.0;                         // ... and (cos, 1 / cos) of the rotation made for the coming step (D follows when it is applied)
+    double2_loc ab = double2_loc{0.0, 0.0};             // ... its (alpha, beta)
+    int zn = 0;                                         // ... and whether the pair is small enough to be set to zero behind it
+    double hmax = 0.0, fro2 = 0.0;
+    int buf = 0;
+    // B <- J^T B J of the cross step T on the scaled entries
+    auto update = [&](auto t_tag) {
+        constexpr int T = decltype(t_tag)::value;
+        double ac, bc, al[4], bl[4];
+        int zl;
+        if constexpr (MK) {
+            ac = ab.x;
+            bc = ab.y;
+            zl = zn;
+            al[0] = ab.x;
+            bl[0] = ab.y;
+            al[1] = rq::quad_perm<rq::quad_rot(1)>(ab.x);
+            bl[1] = rq::quad_perm<rq::quad_rot(1)>(ab.y);
+            al[2] = rq::quad_perm<rq::quad_rot(2)>(ab.x);
+            bl[2] = rq::quad_perm<rq::quad_rot(2)>(ab.y);
+            al[3] = rq::quad_perm<rq::quad_rot(3)>(ab.x);
+            bl[3] = rq::quad_perm<rq::quad_rot(3)>(ab.y);
+            // D <- D cos: seat j is this lane's pair's first seat; seat 4 + j is the second seat of the pair of lane (j - T) & 3
+            dA *= pc;
+            idA *= pic;
+            dB *= rq::quad_perm<rq::quad_rot((4 - T) & 3)>(pc);
+            idB *= rq::quad_perm<rq::quad_rot((4 - T) & 3)>(pic);
+        } else {
+            const double2_loc cc = rt[32 * buf + 4 * C + j];
+            ac = cc.x;
+            bc = cc.y;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const double2_loc rw = rt[32 * buf + 4 * R + ((j + m) & 3)];
+                al[m] = rw.x;
+                bl[m] = rw.y;
+            }
+            zl = zfl[32 * buf + 4 * R + j];
+        }
+#pragma unroll
+        for (int pos = 0; pos < 8; ++pos) {   // columns (j, 4 + ((j + T) & 3)): the lane's pair
+            const double x = c0[pos], y = c1[pos];
+            c0[pos] = __builtin_fma(-ac, y, x);
+            c1[pos] = __builtin_fma(bc, x, y);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {         // rows: position m of the first group with position (m + T) & 3 of the second = pair (j + m) & 3
+            const int pb = 4 + ((m + T) & 3);
+            const double x0 = c0[m], y0 = c0[pb], x1 = c1[m], y1 = c1[pb];
+            c0[m] = __builtin_fma(-al[m], y0, x0);
+            c0[pb] = __builtin_fma(bl[m], x0, y0);
+            c1[m] = __builtin_fma(-al[m], y1, x1);
+            c1[pb] = __builtin_fma(bl[m], x1, y1);
+        }
+        // the rotated pair itself, once it is small (see FORM 1 / zn below): (row j, moving column) and (row of the moving column, column j)
+        const bool z = diag && zl != 0;
+        c1[0] = z ? 0.0 : c1[0];
+        c0[4 + T] = z ? 0.0 : c0[4 + T];
+#pragma unroll
+        for (int pos = 0; pos < 8; ++pos) asm volatile("" : "+v"(c0[pos]), "+v"(c1[pos]));   // (see v_step)
+    };
+    // the moving column goes one lane round the quad: lane j takes over from lane (j + 1) & 3, whose position m - 1 is this lane's m
+    auto shift = [&]() {
+        double n[8];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            n[m] = rq::quad_perm<rq::quad_rot(1)>(c1[(m + 3) & 3]);
+            n[4 + m] = rq::quad_perm<rq::quad_rot(1)>(c1[4 + ((m + 3) & 3)]);
+        }
+#pragma unroll
+        for (int pos = 0; pos < 8; ++pos) c1[pos] = n[pos];
+    };
+    // wave 0: the rotation of the lane's pair (j, 4 + ((j + T) & 3)) of the coming step T from its copy of the diagonal block
+    auto rotations = [&](auto t_tag, int to_buf) {
+        constexpr int T = decltype(t_tag)::value;
+        const double db = rq::quad_perm<rq::quad_rot(T)>(dB), idb = rq::quad_perm<rq::quad_rot(T)>(idB);
+        const double baa = c0[0], bab = c1[0], bbb = c1[4 + T];
+        const double h_true = fabs((bab + bab) * (dA * db));   // |2 B[a][b]| of the unscaled matrix
+        hmax = fmax(hmax, h_true);
+        // t is an fp32 value: the two FMAs leave ~6e-8 of the entry, and setting THAT to zero is harmless once the entry itself is below
+        // 1e-12 |B|_F (without it the entries inside a degenerate cluster are re-made at rounding level in every sweep and the stop rule is never met)
+        zn = h_true * h_true <= 1e-24 * fro2;
+        ab = rotation_scaled(baa, bbb, bab, db * idA, dA * idb);
+        rt[32 * to_buf + 4 * R + j] = ab;
+        zfl[32 * to_buf + 4 * R + j] = zn;
+        const double x = __builtin_fma(ab.x, ab.y, 1.0);   // 1 + tan^2
+        pc = rsqrt_nr(x);
+        pic = x * pc;
+    };
+    // V <- V J of the cross step T: the rotations are broadcast reads, fetched a super-group ahead of the arithmetic
+    auto v_step = [&](auto t_tag) {
+        constexpr int T = decltype(t_tag)::value;
+        double2_loc rn[2][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rn[0][k] = rt[32 * buf + 16 * W + k];
+#pragma unroll
+        for (int Gl = 0; Gl < 4; ++Gl) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (Gl + 1 < 4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rn[(Gl + 1) & 1][k] = rt[32 * buf + 16 * W + 4 * (Gl + 1) + k];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double2_loc r2 = rn[Gl & 1][k];
+                const int a = 8 * Gl + k, bq = 8 * Gl + 4 + ((k + T) & 3);
+                const double x = v[a], y = v[bq];
+                v[a] = __builtin_fma(-r2.x, y, x);
+                v[bq] = __builtin_fma(r2.y, x, y);
+            }
+        }
+        // (the step's results are "used" here: left alone, the compiler sinks the FMAs of several steps into a later basic block and keeps
+        // the steps' rotations alive until then -- 200 spilled registers)
+#pragma unroll
+        for (int s = 0; s < 32; ++s) asm volatile("" : "+v"(v[s]));
+    };
+    // V: a phase change inside a round permutes the seats of every super-group
+    auto v_permute = [&](auto ph0_tag, auto ph1_tag) {
+        constexpr int PH0 = decltype(ph0_tag)::value, PH1 = decltype(ph1_tag)::value;
+#pragma unroll
+        for (int Gl = 0; Gl < 4; ++Gl) rq::permute_seats<PH0, PH1>(&v[8 * Gl], std::make_integer_sequence<int, 8>{});
+    };
+    // V: the end of a round (rq::shift_groups): the group that changes waves goes through LDS
+    auto v_shift_out = [&]() {
+        constexpr int g = rq::leaving_group<W>();
+        xch[(W * 64 + lane) * 2 + 0] = double2_loc{v[g], v[g + 1]};
+        xch[(W * 64 + lane) * 2 + 1] = double2_loc{v[g + 2], v[g + 3]};
+    };
+    auto v_shift_in = [&]() {
+        const double2_loc i0 = xch[((1 - W) * 64 + lane) * 2 + 0], i1 = xch[((1 - W) * 64 + lane) * 2 + 1];
+        const double arriving[4] = {i0.x, i0.y, i1.x, i1.y};
+        rq::shift_groups<W>(v, arriving);
+    };
+    // Stop test (every wave takes part: two barriers): squared off-diagonal mass of the UNSCALED matrix against its squared diagonal mass
+    auto stop_test = [&]() -> bool {
+        if constexpr (MK) {
+            dtab2[8 * R + j] = dA;
+            dtab2[8 * R + 4 + j] = dB;
+        }
+        __syncthreads();
+        if constexpr (BW) {
+            double off = 0.0, total = 0.0;
+            const double dc0 = dtab2[8 * C + j], dc1 = dtab2[8 * C + 4 + j];
+#pragma unroll
+            for (int pos = 0; pos < 8; ++pos) {
+                const double dr = dtab2[8 * R + rowseat(pos)];
+                const double e0 = c0[pos] * (dr * dc0), e1 = c1[pos] * (dr * dc1);
+                const double x0 = e0 * e0, x1 = e1 * e1;
+                // (moving column in its t = 0 place: 4 + j.)  Diagonal entries: (row j, column j) at position 0, (row 4 + j, column 4 + j) at position 4
+                if (pos == 0) {
+                    total += diag ? x0 : 0.0;
+                    off += diag ? x1 : x0 + x1;
+                } else if (pos == 4) {
+                    total += diag ? x1 : 0.0;
+                    off += diag ? x0 : x0 + x1;
+                } else {
+                    off += x0 + x1;
+                }
+            }
+            for (int sft = 32; sft > 0; sft >>= 1) {
+                off += __shfl_xor(off, sft);
+                total += __shfl_xor(total, sft);
+            }
+            if (lane == 0) {
+                red[wave - 1] = off;
+                red[4 + wave - 1] = total;
+            }
+        }
+        __syncthreads();
+        const double off = red[0] + red[1] + red[2] + red[3], total = red[4] + red[5] + red[6] + red[7];
+        fro2 = off + total;
+#ifdef PCSF_EIG_FIXED_ROUNDS
+        return false;
+#endif
+        return off <= 1e-36 * total;   // FORM 1's stop rule
+    };
+    // Everybody moves to the next seating (TYPE: rq::reseat_source; TEND: the place of the moving column after the segment's last step):
+    // the B waves stage their entries by physical seat, wave 0 its seats' (d, 1/d); behind the barrier everybody collects what sits on
+    // its seats next (wave 0: its new copies), a stop test runs if the round's rotations were all small, wave 0 makes the first
+    // rotations of the new seating.  Returns whether the iteration has converged.
+    auto reseat = [&](auto type_tag, auto tend_tag) -> bool {
+        constexpr int TYPE = decltype(type_tag)::value, TEND = decltype(tend_tag)::value;
+        constexpr bool round_end = TYPE <= 1;
+        if constexpr (BW) {
+#pragma unroll
+            for (int pos = 0; pos < 8; ++pos) {
+                const int row = (8 * R + rowseat(pos)) * LD + 8 * C;
+                S[row + j] = c0[pos];
+                S[row + 4 + ((j + TEND) & 3)] = c1[pos];
+            }
+        } else if constexpr (MK) {
+            *reinterpret_cast<double2_loc*>(&dtab[2 * (8 * R + j)]) = double2_loc{dA, idA};
+            *reinterpret_cast<double2_loc*>(&dtab[2 * (8 * R + 4 + j)]) = double2_loc{dB, idB};
+            if constexpr (round_end) {
+                // the stop test proper is only worth running once every rotation of a round stayed below 1e-12 |B|_F (see FORM 1)
+                const bool quiet = __builtin_amdgcn_ballot_w64(hmax * hmax > 1e-24 * fro2) == 0ull;
+                hmax = 0.0;
+                if (lane == 0) tflag = quiet ? 1 : 0;
+            }
+        } else {
+            if constexpr (round_end) v_shift_out();
+        }
+        __syncthreads();
+        if constexpr (!VW) {
+            int sr[8], sc[2];
+#pragma unroll
+            for (int pos = 0; pos < 8; ++pos) sr[pos] = TYPE == 0 ? crow[pos] : seat_tab[64 * TYPE + 8 * R + rowseat(pos)] * LD;
+            sc[0] = TYPE == 0 ? ccol[0] : seat_tab[64 * TYPE + 8 * C + j];
+            sc[1] = TYPE == 0 ? ccol[1] : seat_tab[64 * TYPE + 8 * C + 4 + j];
+#pragma unroll
+            for (int pos = 0; pos < 8; ++pos) {
+                c0[pos] = S[sr[pos] + sc[0]];
+                c1[pos] = S[sr[pos] + sc[1]];
+            }
+            if constexpr (MK) {   // (C = R: the lane's two seats are its two columns)
+                const double2_loc e0 = *reinterpret_cast<const double2_loc*>(&dtab[2 * sc[0]]), e1 = *reinterpret_cast<const double2_loc*>(&dtab[2 * sc[1]]);
+                dA = e0.x;
+                idA = e0.y;
+                dB = e1.x;
+                idB = e1.y;
+            }
+        } else {
+            if constexpr (round_end) v_shift_in();
+            if constexpr (TYPE == 1) v_permute(integral_constant<int, 3>{}, integral_constant<int, 0>{});
+            if constexpr (TYPE >= 2) v_permute(integral_constant<int, TYPE - 2>{}, integral_constant<int, TYPE - 1>{});
+        }
+        if constexpr (round_end) {
+            if (tflag) {
+                if (stop_test()) return true;
+            }
+        }
+        if constexpr (MK) rotations(integral_constant<int, 0>{}, buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+        return false;
+    };
+    // one step: apply the rotations in the registers; unless a re-seating follows, move on to the next pattern and hand its rotations over
+    auto step = [&](auto t_tag, auto last_tag) {
+        constexpr int T = decltype(t_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value;
+        if constexpr (VW) v_step(t_tag);
+        else update(t_tag);
+        if constexpr (!LAST) {
+            if constexpr (!VW) shift();
+            if constexpr (MK) rotations(integral_constant<int, (T + 1) & 3>{}, buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    };
+    int r = 0;
+    bool converged = stop_test();   // (also |B|_F^2 for the rotations' zero flags)
+    if (!converged) {
+        if constexpr (MK) rotations(integral_constant<int, 0>{}, 0);
+        __syncthreads();
+        using T0 = integral_constant<int, 0>;
+        using T1 = integral_constant<int, 1>;
+        using T2 = integral_constant<int, 2>;
+        using T3 = integral_constant<int, 3>;
+        for (int round = 0; round < 60 * 15; ++round) {
+            if (r == 0) {   // the pairs inside the groups: three phases of one step each
+                if constexpr (MK) n_sweeps += 1;
+                step(T0{}, std::true_type{});
+                reseat(integral_constant<int, 2>{}, T0{});
+                step(T0{}, std::true_type{});
+                reseat(integral_constant<int, 3>{}, T0{});
+                step(T0{}, std::true_type{});
+                reseat(integral_constant<int, 4>{}, T0{});
+            }
+            step(T0{}, std::false_type{});
+            step(T1{}, std::false_type{});
+            step(T2{}, std::false_type{});
+            step(T3{}, std::true_type{});
+            const bool done = r == 14 ? reseat(integral_constant<int, 1>{}, T3{}) : reseat(integral_constant<int, 0>{}, T3{});
+            if constexpr (MK) n_steps += r == 0 ? 7 : 4;
+            r = r == 14 ? 0 : r + 1;
+            if (done) {
+                converged = true;
+                break;
+            }
+        }
+    }
+    if (!converged && tid == 0) p.fail[job.table] = 1u;   // rounds used up (a NaN makes the stop test false for ever): flagged, see FORM 1
+    __syncthreads();   // nobody reads the staging buffers any more
+    // eigenvalues and (scaled) eigenvectors back into the canonical matrices, in the seating the iteration stopped in
+    const int ph = r == 0 ? 0 : 3;
+    if constexpr (MK) {
+        if (lane < 32) {
+            const int ca = rq::canon(r, ph, 8 * R + j), cb = rq::canon(r, ph, 8 * R + 4 + j);
+            A[ca * LD + ca] = c0[0] * (dA * dA);
+            A[cb * LD + cb] = c1[4] * (dB * dB);
+        }
+    } else if constexpr (VW) {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) V[lane * LD + rq::canon(r, ph, 32 * W + s)] = v[s];
+    }
+    };   // body
+#ifdef PCSF_F2_ONLY_ROLE
+    body(integral_constant<int, PCSF_F2_ONLY_ROLE>{});
+#else
+    if (wave == 0) body(integral_constant<int, 0>{});
+    else if (wave <= 4) body(integral_constant<int, 1>{});
+    else if (wave == 5) body(integral_constant<int, 2>{});
+    else body(integral_constant<int, 3>{});
+#endif
+    __syncthreads();
+    {   // V = Vs D: the columns of Vs are orthogonal by construction (every step an orthogonal transformation times a diagonal one), so D is
+        // their norms' reciprocals -- taken from the columns themselves rather than from the tracked products of cosines (~500 factors each)
+        if (tid < 64) {
+            double n2 = 0.0;
+            for (int i = 0; i < 64; ++i) n2 = __builtin_fma(V[i * LD + tid], V[i * LD + tid], n2);
+            pi[tid] = 1.0 / sqrt(n2);   // (pi is free: root / iroot hold what the outputs need)
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 4096; idx += NT) V[(idx >> 6) * LD + (idx & 63)] *= pi[idx & 63];
+        __syncthreads();
+    }
     }
     if (stamping) {
         if (tid == 0) {
@@ -806,7 +1293,7 @@ __global__ __launch_bounds__(REG ? 128 : 256) void eigen_omega_kernel(const Eige
             atomicAdd(p.stamps + 5, n_sweeps);
             atomicAdd(p.stamps + 6, eig_clock() - t_kernel);
         }
-        if (tid == (REG ? 0 : 64)) atomicAdd(p.stamps + 2, acc_v);
+        if (tid == (FORM == 0 ? 64 : 0)) atomicAdd(p.stamps + 2, acc_v);
     }
 
     // eigen-system of Q: right = D^-1/2 V (eigenvectors in columns), left = V^T D^1/2 (in rows)
@@ -866,9 +1353,11 @@ hipError_t launch_eigen_omega(const EigenParams& p, hipStream_t stream)
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     if (!(attr_set.load(std::memory_order_acquire) >> (dev & 63) & 1)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eigen_omega_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eigen_omega_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eigen_omega_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eigen_omega_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eigen_omega_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
         attr_set.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
     }
@@ -877,8 +1366,11 @@ hipError_t launch_eigen_omega(const EigenParams& p, hipStream_t stream)
     // first version (matrices in LDS, 256 threads), kept for A/B runs and tests.
     const char* lds_env = getenv("PCSF_EIGEN_LDS");   // read at every launch: tests switch forms inside one process
     const bool in_lds = lds_env && lds_env[0] == '1';
-    if (in_lds) hipLaunchKernelGGL(eigen_omega_kernel<false>, dim3(p.n_jobs), dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL(eigen_omega_kernel<true>, dim3(p.n_jobs), dim3(128), lds, stream, p);
+    const char* form_env = getenv("PCSF_EIGEN_FORM");   // 0 | 1 | 2, read at every launch like PCSF_EIGEN_LDS (A/B runs, tests)
+    const int form = in_lds ? 0 : (form_env && form_env[0] >= '0' && form_env[0] <= '2') ? form_env[0] - '0' : 1;
+    if (form == 0) hipLaunchKernelGGL(eigen_omega_kernel<0>, dim3(p.n_jobs), dim3(256), lds, stream, p);
+    else if (form == 1) hipLaunchKernelGGL(eigen_omega_kernel<1>, dim3(p.n_jobs), dim3(128), lds, stream, p);
+    else hipLaunchKernelGGL(eigen_omega_kernel<2>, dim3(p.n_jobs), dim3(448), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -896,6 +1388,63 @@ void eigen_schedule_for_tests(int* pairs /* [63][32][2] */, int* located /* [15]
                 }
     for (int r = 0; r < 15; ++r)
         for (int g = 0; g < 16; ++g) located[r * 16 + g] = rr::locate(r, g);
+}
+
+
+// tests: FORM 2's bookkeeping replayed on indices -- the 63 x 32 pairs of one sweep in step order as the kernel's seats give them, and
+// whether every re-seating (the staged matrix's look-up table for B, the register moves for V) lands where rq::canon says: returns the
+// number of disagreements (0), over two sweeps.
+int eigen_schedule_quads_for_tests(int* pairs /* [63][32][2] */)
+{
+    int arr[64], vv[2][32], bad = 0, step = 0;
+    for (int s = 0; s < 64; ++s) arr[s] = vv[s >> 5][s & 31] = rq::canon(0, 0, s);
+    auto emit = [&](int t, bool record) {
+        for (int G = 0; G < 8; ++G)
+            for (int k = 0; k < 4; ++k) {
+                const int a = 8 * G + k, b = 8 * G + 4 + ((k + t) & 3);
+                if (vv[a >> 5][a & 31] != arr[a] || vv[b >> 5][b & 31] != arr[b]) ++bad;
+                if (record) {
+                    pairs[(step * 32 + G * 4 + k) * 2 + 0] = arr[a];
+                    pairs[(step * 32 + G * 4 + k) * 2 + 1] = arr[b];
+                }
+            }
+        if (record) ++step;
+    };
+    auto reseat = [&](int type, int r1, int ph1) {
+        int next[64];
+        for (int s = 0; s < 64; ++s) next[s] = arr[rq::reseat_source(type, s)];
+        for (int s = 0; s < 64; ++s) arr[s] = next[s];
+        if (type <= 1) {
+            int out0[4], out1[4];
+            for (int q = 0; q < 4; ++q) {
+                out0[q] = vv[0][rq::leaving_group<0>() + q];
+                out1[q] = vv[1][rq::leaving_group<1>() + q];
+            }
+            rq::shift_groups<0>(vv[0], out1);
+            rq::shift_groups<1>(vv[1], out0);
+        }
+        for (int w = 0; w < 2; ++w)
+            for (int Gl = 0; Gl < 4; ++Gl) {
+                if (type == 1) rq::permute_seats<3, 0>(&vv[w][8 * Gl], std::make_integer_sequence<int, 8>{});
+                if (type == 2) rq::permute_seats<0, 1>(&vv[w][8 * Gl], std::make_integer_sequence<int, 8>{});
+                if (type == 3) rq::permute_seats<1, 2>(&vv[w][8 * Gl], std::make_integer_sequence<int, 8>{});
+                if (type == 4) rq::permute_seats<2, 3>(&vv[w][8 * Gl], std::make_integer_sequence<int, 8>{});
+            }
+        for (int s = 0; s < 64; ++s)
+            if (arr[s] != rq::canon(r1, ph1, s) || vv[s >> 5][s & 31] != arr[s]) ++bad;
+    };
+    for (int sweep = 0; sweep < 2; ++sweep)
+        for (int r = 0; r < 15; ++r) {
+            if (r == 0)
+                for (int ph = 0; ph < 3; ++ph) {
+                    emit(0, sweep == 0);
+                    reseat(2 + ph, 0, ph + 1);
+                }
+            for (int t = 0; t < 4; ++t) emit(t, sweep == 0);
+            if (r == 14) reseat(1, 0, 0);
+            else reseat(0, r + 1, 3);
+        }
+    return bad;
 }
 
 }  // namespace pcsf

@@ -298,6 +298,7 @@ struct EigenParams {
 
 hipError_t launch_eigen_omega(const EigenParams& p, hipStream_t stream);
 void eigen_schedule_for_tests(int* pairs, int* located);   // host: the register-resident variant's pair schedule
+int eigen_schedule_quads_for_tests(int* pairs);               // host: the seven-wave variant's seats replayed on indices; returns the number of inconsistencies
 
 }  // namespace pcsf
 

@@ -245,6 +245,13 @@ def test_device_eigen_solver_in_its_lds_form(gpu_contexts, monkeypatch):
     test_device_eigen_solver_of_the_omega_rate_matrix(gpu_contexts)
 
 
+def test_device_eigen_solver_in_its_seven_wave_form(gpu_contexts, monkeypatch):
+    """PCSF_EIGEN_FORM=2 (read at every launch): a rotation wave, B in quads of lanes over four waves, V on two waves, scaled rotations --
+    the same accuracy test."""
+    monkeypatch.setenv("PCSF_EIGEN_FORM", "2")
+    test_device_eigen_solver_of_the_omega_rate_matrix(gpu_contexts)
+
+
 def test_eigen_solver_flags_a_matrix_it_cannot_diagonalise(gpu_contexts, monkeypatch):
     """A NaN among the settings makes every stop test of the Jacobi iteration false: both device forms must use up their rounds and
     FLAG the job (fail -> NaN row) instead of handing whatever the registers hold to the pruning kernels."""
@@ -254,6 +261,9 @@ def test_eigen_solver_flags_a_matrix_it_cannot_diagonalise(gpu_contexts, monkeyp
         monkeypatch.setenv("PCSF_EIGEN_LDS", form)
         failed = ctx.debug_eigen_omega(qs)[-1]
         assert list(failed) == [0, 1], (form, failed)
+    monkeypatch.setenv("PCSF_EIGEN_FORM", "2")
+    failed = ctx.debug_eigen_omega(qs)[-1]
+    assert list(failed) == [0, 1], ("seven waves", failed)
 
 
 def test_block_groups_do_not_change_any_result(oracle_models, golden_dir):

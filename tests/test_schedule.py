@@ -239,3 +239,26 @@ def test_program_facts_match_an_independent_walk_of_the_program():
             assert got == cur, (trial, i)
             assert meta[i] == want_slot | (want_depth << 14) | (want_parking << 18), (trial, i)
         assert cur == set(range(nl)) and not parked
+
+
+def test_eigen_solver_quad_form_seats_follow_the_same_schedule():
+    """The seven-wave form of the Jacobi kernel (PCSF_EIGEN_FORM=2) keeps the indices on physical seats: B is re-seated through a
+    look-up table, V by register moves and a four-column exchange between its two waves.  Replayed on indices over two sweeps, both
+    must agree with the seat -> index map after every re-seating, and the pairs the seats give must be, step by step, the SETS of pairs
+    of the register-resident form's schedule (same sweep, same order of steps)."""
+    import ctypes as C
+    import phylocsfpp_amd as pa
+    lib = pa.load_library()
+    quads = (C.c_int32 * (63 * 32 * 2))()
+    lib.pcsf_debug_eigen_schedule_quads.restype = C.c_int
+    assert lib.pcsf_debug_eigen_schedule_quads(quads) == 0
+    pairs = (C.c_int32 * (63 * 32 * 2))()
+    located = (C.c_int32 * (15 * 16))()
+    lib.pcsf_debug_eigen_schedule.restype = None
+    lib.pcsf_debug_eigen_schedule(pairs, located)
+    quads = np.array(quads).reshape(63, 32, 2)
+    pairs = np.array(pairs).reshape(63, 32, 2)
+    for step in range(63):
+        a = {(min(p, q), max(p, q)) for p, q in quads[step]}
+        b = {(min(p, q), max(p, q)) for p, q in pairs[step]}
+        assert a == b and len(a) == 32, step
