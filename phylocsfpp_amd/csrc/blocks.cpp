@@ -1558,8 +1558,8 @@ int debug_eigen_omega_impl(pcsf_ctx* c, const double* q_settings, const double* 
             unsigned long long h[8];
             HIP_TRY(hipMemcpy(h, d_stamps.ptr, sizeof h, hipMemcpyDeviceToHost));
             const double st = static_cast<double>(std::max<unsigned long long>(h[4], 1));
-            fprintf(stderr, "eigen stamps (job 0, %s start; s_memtime cycles): %llu sweeps, %llu steps, kernel %llu; per step: phase A %.0f, phase B %.0f (wave 0 rotations %.0f, wave 1 V update %.0f)\n",
-                    pass == 0 ? "cold" : (warm_settings ? "warm" : "cold"), h[5], h[4], h[6], h[0] / st, h[3] / st, h[1] / st, h[2] / st);
+            fprintf(stderr, "eigen stamps (job 0, %s start; s_memtime cycles): %llu sweeps, %llu steps, kernel %llu (%llu before the sweeps); per step: phase A %.0f, phase B %.0f (wave 0 rotations %.0f, wave 1 V update %.0f)\n",
+                    pass == 0 ? "cold" : (warm_settings ? "warm" : "cold"), h[5], h[4], h[6], h[7], h[0] / st, h[3] / st, h[1] / st, h[2] / st);
         }
     }
     std::vector<uint32_t> f(n);

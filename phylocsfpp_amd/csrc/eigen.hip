@@ -32,6 +32,15 @@
 #ifndef PCSF_EIGEN_STEP_STAMPS
 #define PCSF_EIGEN_STEP_STAMPS 0
 #endif
+#ifndef PCSF_F2_PIN
+#define PCSF_F2_PIN 0   // (1: the B and rotation waves also pin their step results like the V waves do -- measured 7 % slower)
+#endif
+#ifndef PCSF_F2_SLEEP
+#define PCSF_F2_SLEEP 0
+#endif
+#ifndef PCSF_F2_RESEAT_STAMPS
+#define PCSF_F2_RESEAT_STAMPS 0   // FORM 2, with the step-stamps build: the stamps' four slots split wave 0's re-seatings instead of its steps
+#endif
 #if PCSF_EIGEN_STEP_STAMPS
 #define EIG_STEP_STAMPS true
 #define EIG_STEP_CLOCK() (stamping ? eig_clock() : 0ull)
@@ -378,6 +387,7 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
         }
         __syncthreads();
     }
+    const unsigned long long t_sweeps = stamping ? eig_clock() : 0ull;   // (the rate matrix, its symmetric form and a warm start's two products are behind)
     if constexpr (FORM == 0) {
     // rotations of one step into buffer `buf`: tournament pairing of 0..63 (63 stays, the others rotate), lanes 0..31 of wave 0
     auto rotations = [&](int step, int buf) {
@@ -957,16 +967,34 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
     }
     __syncthreads();   // everything is in registers: A becomes the staging matrix of the re-seatings (by physical seat), V the exchange buffer
     double* S = A;
+    const int lds_base_S = static_cast<int>(reinterpret_cast<size_t>(S));   // (LDS byte address, for the hand-written loads of a round's end)
     double2_loc* xch = reinterpret_cast<double2_loc*>(V);   // [V wave][row][2]: the group of four columns that changes waves at a round's end
-    int crow[8], ccol[2];   // re-seating 0 (every round's end): where the lane's next rows / columns sit in the staged matrix
+    // Staging for a re-seating is LANE-MAJOR -- the B lane k stores position pos of its column slot at (2 pos + slot) * 256 + k, always in
+    // the t = 0 layout (moving column = 4 + j) -- so stores and loads of a round's end are free of bank conflicts (consecutive lanes,
+    // consecutive double-words; a load's 32-lane half covers the eight blocks of a block row) and all addresses are one register plus a
+    // constant.  (Row-major by seat, the first version: 16 lane-dependent addresses, seven of them spilled to scratch and reloaded behind
+    // every re-seating's barrier, and the blocks' 8 R' and 8 C' left one bit each in the bank number.)
+    // A round's end (type 0) keeps the within-group index: the new half x of the rows comes from the half h'x of super-group R'x, the new
+    // column slot y from slot g'y of super-group C'y, same lane j of the quad, same positions: smap0[x][y] + 512 m.
+    int smap0[2][2] = {{0, 0}, {0, 0}};
+    int dseat0[2] = {0, 0};   // wave 0: where the lane's two seats' (d, 1/d) come from
     if constexpr (!VW) {
 #pragma unroll
-        for (int pos = 0; pos < 8; ++pos) crow[pos] = seat_tab[8 * R + rowseat(pos)] * LD;
-        ccol[0] = seat_tab[8 * C + j];
-        ccol[1] = seat_tab[8 * C + 4 + j];
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const int sr = rr::shift_source(R, x), sc = rr::shift_source(C, y);
+                smap0[x][y] = 2048 * (sr >> 3) + 32 * (sr & 7) + 256 * (sc >> 3) + 4 * (sc & 7) + j;
+                if (x == 0) dseat0[y] = 8 * (sc & 7) + 4 * (sc >> 3) + j;
+            }
     }
+    // the four other re-seatings of a sweep: the staged address of (row seat, column seat) from the look-up table
+    auto staged = [&](int row_src, int col_src) {
+        const int jj = col_src & 3, rs = row_src & 7;   // the lane of the quad that staged the column; the row's seat within its super-group
+        const int pos = (rs & 4) + ((rs - jj) & 3);
+        return (2 * pos + ((col_src >> 2) & 1)) * 256 + 32 * (row_src >> 3) + 4 * (col_src >> 3) + jj;
+    };
     double dA = 1.0, idA = 1.0, dB = 1.0, idB = 1.0;   // wave 0: (d, 1/d) of the seats j and 4 + j of super-group R
-    double pc = 1.0, pic = 1.0;                         // ... and (cos, 1 / cos) of the rotation made for the coming step (D follows when it is applied)
     double2_loc ab = double2_loc{0.0, 0.0};             // ... its (alpha, beta)
     int zn = 0;                                         // ... and whether the pair is small enough to be set to zero behind it
     double hmax = 0.0, fro2 = 0.0;
@@ -988,11 +1016,19 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
             bl[2] = rq::quad_perm<rq::quad_rot(2)>(ab.y);
             al[3] = rq::quad_perm<rq::quad_rot(3)>(ab.x);
             bl[3] = rq::quad_perm<rq::quad_rot(3)>(ab.y);
-            // D <- D cos: seat j is this lane's pair's first seat; seat 4 + j is the second seat of the pair of lane (j - T) & 3
+            // D <- D cos: seat j is this lane's pair's first seat; seat 4 + j is the second seat of the pair of lane (j - T) & 3.  (Here, not
+            // where the rotation is made: the other waves wait for the hand-over, and nothing needs the cosine before the next rotation.)
+            const double x = __builtin_fma(ab.x, ab.y, 1.0);   // 1 + tan^2
+            const double pc = rsqrt_nr(x), pic = x * pc;
             dA *= pc;
             idA *= pic;
-            dB *= rq::quad_perm<rq::quad_rot((4 - T) & 3)>(pc);
-            idB *= rq::quad_perm<rq::quad_rot((4 - T) & 3)>(pic);
+            if constexpr (T == 0) {
+                dB *= pc;
+                idB *= pic;
+            } else {
+                dB *= rq::quad_perm<rq::quad_rot((4 - T) & 3)>(pc);
+                idB *= rq::quad_perm<rq::quad_rot((4 - T) & 3)>(pic);
+            }
         } else {
             const double2_loc cc = rt[32 * buf + 4 * C + j];
             ac = cc.x;
@@ -1024,8 +1060,10 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
         const bool z = diag && zl != 0;
         c1[0] = z ? 0.0 : c1[0];
         c0[4 + T] = z ? 0.0 : c0[4 + T];
+#if PCSF_F2_PIN
 #pragma unroll
         for (int pos = 0; pos < 8; ++pos) asm volatile("" : "+v"(c0[pos]), "+v"(c1[pos]));   // (see v_step)
+#endif
     };
     // the moving column goes one lane round the quad: lane j takes over from lane (j + 1) & 3, whose position m - 1 is this lane's m
     auto shift = [&]() {
@@ -1041,7 +1079,7 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
     // wave 0: the rotation of the lane's pair (j, 4 + ((j + T) & 3)) of the coming step T from its copy of the diagonal block
     auto rotations = [&](auto t_tag, int to_buf) {
         constexpr int T = decltype(t_tag)::value;
-        const double db = rq::quad_perm<rq::quad_rot(T)>(dB), idb = rq::quad_perm<rq::quad_rot(T)>(idB);
+        const double db = T == 0 ? dB : rq::quad_perm<rq::quad_rot(T)>(dB), idb = T == 0 ? idB : rq::quad_perm<rq::quad_rot(T)>(idB);
         const double baa = c0[0], bab = c1[0], bbb = c1[4 + T];
         const double h_true = fabs((bab + bab) * (dA * db));   // |2 B[a][b]| of the unscaled matrix
         hmax = fmax(hmax, h_true);
@@ -1051,9 +1089,7 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
         ab = rotation_scaled(baa, bbb, bab, db * idA, dA * idb);
         rt[32 * to_buf + 4 * R + j] = ab;
         zfl[32 * to_buf + 4 * R + j] = zn;
-        const double x = __builtin_fma(ab.x, ab.y, 1.0);   // 1 + tan^2
-        pc = rsqrt_nr(x);
-        pic = x * pc;
+        // (the rotation's cosine, for D, is made behind the hand-over's barrier: see update)
     };
     // V <- V J of the cross step T: the rotations are broadcast reads, fetched a super-group ahead of the arithmetic
     auto v_step = [&](auto t_tag) {
@@ -1150,39 +1186,83 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
     auto reseat = [&](auto type_tag, auto tend_tag) -> bool {
         constexpr int TYPE = decltype(type_tag)::value, TEND = decltype(tend_tag)::value;
         constexpr bool round_end = TYPE <= 1;
+        bool quiet = false;
+        const unsigned long long t0 = EIG_STEP_CLOCK();   // (wave 0's re-seatings as a whole -> the "V update" slot of the stamps)
         if constexpr (BW) {
+            if constexpr (TEND != 0) shift();   // (TEND = 3: once more round the quad, the moving column is 4 + j again)
 #pragma unroll
             for (int pos = 0; pos < 8; ++pos) {
-                const int row = (8 * R + rowseat(pos)) * LD + 8 * C;
-                S[row + j] = c0[pos];
-                S[row + 4 + ((j + TEND) & 3)] = c1[pos];
+                S[(2 * pos) * 256 + (tid - 64)] = c0[pos];
+                S[(2 * pos + 1) * 256 + (tid - 64)] = c1[pos];
             }
         } else if constexpr (MK) {
             *reinterpret_cast<double2_loc*>(&dtab[2 * (8 * R + j)]) = double2_loc{dA, idA};
             *reinterpret_cast<double2_loc*>(&dtab[2 * (8 * R + 4 + j)]) = double2_loc{dB, idB};
             if constexpr (round_end) {
                 // the stop test proper is only worth running once every rotation of a round stayed below 1e-12 |B|_F (see FORM 1)
-                const bool quiet = __builtin_amdgcn_ballot_w64(hmax * hmax > 1e-24 * fro2) == 0ull;
+                quiet = __builtin_amdgcn_ballot_w64(hmax * hmax > 1e-24 * fro2) == 0ull;
                 hmax = 0.0;
                 if (lane == 0) tflag = quiet ? 1 : 0;
             }
         } else {
             if constexpr (round_end) v_shift_out();
         }
+        const unsigned long long q1 = EIG_STEP_CLOCK();
         __syncthreads();
+        const unsigned long long q2 = EIG_STEP_CLOCK();
         if constexpr (!VW) {
-            int sr[8], sc[2];
+            int seat0, seat1;
+            if constexpr (TYPE == 0) {
+                seat0 = dseat0[0];
+                seat1 = dseat0[1];
+                if constexpr (MK) {   // what the next rotation is made of first (LDS returns in order): D, then B[a][a], B[a][b], B[b][b]
+                    const double2_loc e0 = *reinterpret_cast<const double2_loc*>(&dtab[2 * seat0]), e1 = *reinterpret_cast<const double2_loc*>(&dtab[2 * seat1]);
+                    dA = e0.x;
+                    idA = e0.y;
+                    dB = e1.x;
+                    idB = e1.y;
+                    c0[0] = S[smap0[0][0]];
+                    c1[0] = S[smap0[0][1]];
+                    c1[4] = S[smap0[1][1]];
+#if PCSF_F2_PIN
+                    asm volatile("" : "+v"(dA), "+v"(idA), "+v"(dB), "+v"(idB), "+v"(c0[0]), "+v"(c1[0]), "+v"(c1[4]));
+#endif
+                }
+#if PCSF_F2_SLEEP
+                if constexpr (BW) __builtin_amdgcn_s_sleep(PCSF_F2_SLEEP);   // (wave 0's loads go first: the step waits for its rotations, not for these)
+#endif
+                if constexpr (MK) {
 #pragma unroll
-            for (int pos = 0; pos < 8; ++pos) sr[pos] = TYPE == 0 ? crow[pos] : seat_tab[64 * TYPE + 8 * R + rowseat(pos)] * LD;
-            sc[0] = TYPE == 0 ? ccol[0] : seat_tab[64 * TYPE + 8 * C + j];
-            sc[1] = TYPE == 0 ? ccol[1] : seat_tab[64 * TYPE + 8 * C + 4 + j];
+                    for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int pos = 0; pos < 8; ++pos) {
-                c0[pos] = S[sr[pos] + sc[0]];
-                c1[pos] = S[sr[pos] + sc[1]];
+                        for (int m = 0; m < 4; ++m) {
+                            if (m != 0 || x == 1) c0[4 * x + m] = S[smap0[x][0] + 512 * m];
+                            if (m != 0) c1[4 * x + m] = S[smap0[x][1] + 512 * m];
+                        }
+                } else {
+                    // sixteen ds_read_b64 as written: the compiler pairs loads a constant apart into ds_read2st64_b64, which the LDS serves
+                    // at half the rate (MI355X_MICROARCH.md: 8 cycles against 2 x 2) -- with four waves collecting at once, 160 cycles a round
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(c0[4 * x + m]) : "v"(8 * smap0[x][0] + lds_base_S), "n"(4096 * m));
+                            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(c1[4 * x + m]) : "v"(8 * smap0[x][1] + lds_base_S), "n"(4096 * m));
+                        }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            } else {
+                seat0 = seat_tab[64 * TYPE + 8 * C + j];
+                seat1 = seat_tab[64 * TYPE + 8 * C + 4 + j];
+#pragma unroll
+                for (int pos = 0; pos < 8; ++pos) {
+                    const int row_src = seat_tab[64 * TYPE + 8 * R + rowseat(pos)];
+                    c0[pos] = S[staged(row_src, seat0)];
+                    c1[pos] = S[staged(row_src, seat1)];
+                }
             }
-            if constexpr (MK) {   // (C = R: the lane's two seats are its two columns)
-                const double2_loc e0 = *reinterpret_cast<const double2_loc*>(&dtab[2 * sc[0]]), e1 = *reinterpret_cast<const double2_loc*>(&dtab[2 * sc[1]]);
+            if constexpr (MK && TYPE != 0) {   // (C = R: the lane's two seats are its two columns)
+                const double2_loc e0 = *reinterpret_cast<const double2_loc*>(&dtab[2 * seat0]), e1 = *reinterpret_cast<const double2_loc*>(&dtab[2 * seat1]);
                 dA = e0.x;
                 idA = e0.y;
                 dB = e1.x;
@@ -1193,27 +1273,60 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
             if constexpr (TYPE == 1) v_permute(integral_constant<int, 3>{}, integral_constant<int, 0>{});
             if constexpr (TYPE >= 2) v_permute(integral_constant<int, TYPE - 2>{}, integral_constant<int, TYPE - 1>{});
         }
+        unsigned long long q3 = 0;
+        if constexpr (MK && PCSF_F2_RESEAT_STAMPS != 0) {
+            if (EIG_STEP_STAMPS && stamping) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                q3 = eig_clock();
+            }
+        }
         if constexpr (round_end) {
-            if (tflag) {
+            if (MK ? quiet : tflag != 0) {   // (wave 0 knows without the trip through LDS)
                 if (stop_test()) return true;
             }
         }
         if constexpr (MK) rotations(integral_constant<int, 0>{}, buf ^ 1);
         __syncthreads();
         buf ^= 1;
+        if constexpr (MK) {
+            if (EIG_STEP_STAMPS && stamping) {
+                if (PCSF_F2_RESEAT_STAMPS) {   // staging / barrier / collecting / rotations and hand-over
+                    acc_a += q1 - t0;
+                    acc_rot += q2 - q1;
+                    acc_b += q3 - q2;
+                    acc_v += eig_clock() - q3;
+                } else {
+                    acc_v += eig_clock() - t0;
+                }
+            }
+        }
         return false;
     };
     // one step: apply the rotations in the registers; unless a re-seating follows, move on to the next pattern and hand its rotations over
     auto step = [&](auto t_tag, auto last_tag) {
         constexpr int T = decltype(t_tag)::value;
         constexpr bool LAST = decltype(last_tag)::value;
+        const unsigned long long t0 = EIG_STEP_CLOCK();   // diagnostics (-DPCSF_EIGEN_STEP_STAMPS=1), wave 0: update + shift / rotations / barrier
         if constexpr (VW) v_step(t_tag);
         else update(t_tag);
         if constexpr (!LAST) {
             if constexpr (!VW) shift();
+            const unsigned long long t1 = EIG_STEP_CLOCK();
             if constexpr (MK) rotations(integral_constant<int, (T + 1) & 3>{}, buf ^ 1);
+            const unsigned long long t2 = EIG_STEP_CLOCK();
             __syncthreads();
             buf ^= 1;
+            if constexpr (MK) {
+                if (EIG_STEP_STAMPS && !PCSF_F2_RESEAT_STAMPS && stamping) {
+                    acc_a += t1 - t0;
+                    acc_rot += t2 - t1;
+                    acc_b += eig_clock() - t2;
+                }
+            }
+        } else {
+            if constexpr (MK) {
+                if (EIG_STEP_STAMPS && !PCSF_F2_RESEAT_STAMPS && stamping) acc_a += eig_clock() - t0;
+            }
         }
     };
     int r = 0;
@@ -1292,6 +1405,7 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
             atomicAdd(p.stamps + 4, n_steps);
             atomicAdd(p.stamps + 5, n_sweeps);
             atomicAdd(p.stamps + 6, eig_clock() - t_kernel);
+            atomicAdd(p.stamps + 7, t_sweeps - t_kernel);
         }
         if (tid == (FORM == 0 ? 64 : 0)) atomicAdd(p.stamps + 2, acc_v);
     }

@@ -20,6 +20,7 @@ PY
 }
 export PCSF_EIGEN_STAMPS=1
 for form in ${FORMS:-reg lds}; do
+    [ "$form" = none ] && continue
     echo "== form $form, $N jobs"
     if [ "$form" = lds ]; then PCSF_EIGEN_LDS=1 run; elif [ "$form" = quad ]; then PCSF_EIGEN_FORM=2 run; else run; fi
 done
