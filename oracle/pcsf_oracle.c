@@ -296,6 +296,7 @@ void po_q_from_omega(const double *v, double *Q, double *pi)
  * B = D^{1/2} Q D^{-1/2}, D = diag(pi), is symmetric: B = U L U^T by cyclic Jacobi, and
  * Sr = D^{-1/2} U, Sinv = U^T D^{1/2}.
  * ---------------------------------------------------------------------------------------- */
+static inline int perturbation(void);   /* control experiments, see po_set_perturbation */
 static void jacobi_sym(double *a /*KxK, destroyed*/, double *w, double *v)
 {
     for (int i = 0; i < K; ++i)
@@ -307,8 +308,13 @@ static void jacobi_sym(double *a /*KxK, destroyed*/, double *w, double *v)
             for (int q = p + 1; q < K; ++q) off += a[p * K + q] * a[p * K + q];
         }
         if (off <= 1e-60 * diag || off == 0.0) break;
-        for (int p = 0; p < K - 1; ++p) {
-            for (int q = p + 1; q < K; ++q) {
+        /* control experiment only (po_set_perturbation bit 32): the same sweeps with the pairs visited in the opposite order -- an equally
+         * valid cyclic Jacobi whose eigen-system differs from this one's the way two solvers' do */
+        const int reversed = (perturbation() & 32) != 0;
+        for (int pp = 0; pp < K - 1; ++pp) {
+            const int p = reversed ? K - 2 - pp : pp;
+            for (int qq = p + 1; qq < K; ++qq) {
+                const int q = reversed ? K - 1 - (qq - (p + 1)) : qq;
                 const double apq = a[p * K + q];
                 if (apq == 0.0) continue;
                 const double app = a[p * K + p], aqq = a[q * K + q];
@@ -436,6 +442,9 @@ int po_make_all_P(const po_qdiag *qd, const po_tree *tree, double x, double *P)
  * draws), i.e. moved by up to 1.1e-13 relative; per-codon scores of the two implementations agree to 6e-14 (tests/test_gpu_fixed.py),
  * objective values to 1.3e-13 (layer 2).  The few-ulp control understates how often an MLE search ends a Brent
  * step apart between two IMPLEMENTATIONS (profiles/r05/mle_control_full.txt).
+ * Bit 32 (OMEGA): the cyclic Jacobi sweeps of the eigen-solver visit their pairs in the opposite order -- another valid solver.  At small
+ * tree scales the objective sees the solver's rounding (the reference clamps noise-level entries of P to zero and rebuilds the diagonal):
+ * two solvers agree to ~1e-7 relative at a tree scale of 0.02, not to 1e-13, which no other bit reproduces.
  * PO_PERTURB=<bits> in the environment sets it for the command-line driver. */
 static int g_perturb = -1;
 void po_set_perturbation(int bits) { g_perturb = bits; }

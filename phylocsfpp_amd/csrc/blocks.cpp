@@ -1422,8 +1422,15 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
         run_host_rounds(eng, machines, look.max_points, false, stop, st, fetch_priors, [&](size_t b, const EvalResult* res, EvalRequest* out) {
             OmegaMachine& m = machines[b];
             if (trace_block >= 0 && static_cast<size_t>(trace_block) == b)
-                for (uint32_t i = 0; i < m.n_pending; ++i)
-                    fprintf(stderr, "TRACE omega stage %d kind %u x %.17g lnz %.17g prior %.17g\n", m.stage, m.pend_kind[i], m.pend_x[i], res[i].lnz, prior_v[at[b] + i]);
+                for (uint32_t i = 0; i < m.n_pending; ++i) {
+                    // (the evaluation's tree scale and model, as the machine formed them: rho probes move the tree scale, kappa probes the
+                    // first setting -- tests replay the line through the oracle's objective)
+                    const bool kappa = m.pend_kind[i] == EVAL_KAPPA;
+                    fprintf(stderr, "TRACE omega stage %d kind %u x %.17g lnz %.17g prior %.17g scale %.17g qs", m.stage, m.pend_kind[i], m.pend_x[i], res[i].lnz,
+                            prior_v[at[b] + i], kappa ? m.tree_scale : m.pend_x[i]);
+                    for (int k = 0; k < 12; ++k) fprintf(stderr, " %.17g", (k == 0 && kappa) ? m.pend_x[i] : m.q_settings[k]);
+                    fprintf(stderr, "\n");
+                }
             const int n = m.round(res, stores.data() + b * STORE_ENTRIES, dr, dk, look.eager, look.max_points, look.max_restarts, held_systems, HostPrior{prior_v.data() + at[b]}, out);
             for (int i = 0; i < n; ++i)
                 if (out[i].eig & TRANSIENT_EIG) out[i].eig = static_cast<uint32_t>(transient0 + b * look.max_points + (out[i].eig & ~TRANSIENT_EIG));

@@ -1475,13 +1475,15 @@ hipError_t launch_eigen_omega(const EigenParams& p, hipStream_t stream)
         if (e != hipSuccess) return e;
         attr_set.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
     }
-    // Two forms of the same iteration.  Default: blocks in registers (128 threads: wave 0 holds B, wave 1 V; two work-groups per CU) --
-    // 0.69 ms per cold launch against 0.98 ms, and OMEGA 1.16-1.22x faster at 516 / 2,064 / 8,256 blocks.  PCSF_EIGEN_LDS=1: the
-    // first version (matrices in LDS, 256 threads), kept for A/B runs and tests.
+    // Three forms of the same iteration (one form per process setting, whatever a launch's size: a block's result must not depend on the
+    // list it is scored in).  Default since round 5: FORM 2, seven waves -- 0.31 ms per cold launch of 200 jobs against FORM 1's 0.56 ms,
+    // 1.9 against 2.3 ms at 2,048 jobs, OMEGA end to end 0.140 / 0.223 / 0.703 s against 0.179 / 0.267 / 0.797 s at 516 / 2,064 / 8,256
+    // blocks (profiles/r05/eigen_forms).  PCSF_EIGEN_FORM=1: rounds 2-4's form (128 threads: wave 0 holds B, wave 1 V);
+    // PCSF_EIGEN_FORM=0 or PCSF_EIGEN_LDS=1: the first version (matrices in LDS, 256 threads).  Both kept for A/B runs and tests.
     const char* lds_env = getenv("PCSF_EIGEN_LDS");   // read at every launch: tests switch forms inside one process
     const bool in_lds = lds_env && lds_env[0] == '1';
-    const char* form_env = getenv("PCSF_EIGEN_FORM");   // 0 | 1 | 2, read at every launch like PCSF_EIGEN_LDS (A/B runs, tests)
-    const int form = in_lds ? 0 : (form_env && form_env[0] >= '0' && form_env[0] <= '2') ? form_env[0] - '0' : 1;
+    const char* form_env = getenv("PCSF_EIGEN_FORM");
+    const int form = in_lds ? 0 : (form_env && form_env[0] >= '0' && form_env[0] <= '2') ? form_env[0] - '0' : 2;
     if (form == 0) hipLaunchKernelGGL(eigen_omega_kernel<0>, dim3(p.n_jobs), dim3(256), lds, stream, p);
     else if (form == 1) hipLaunchKernelGGL(eigen_omega_kernel<1>, dim3(p.n_jobs), dim3(128), lds, stream, p);
     else hipLaunchKernelGGL(eigen_omega_kernel<2>, dim3(p.n_jobs), dim3(448), lds, stream, p);

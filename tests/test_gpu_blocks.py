@@ -239,16 +239,16 @@ def test_mle_and_omega_on_trees_whose_branch_count_is_not_a_chunk_multiple(oracl
 
 
 def test_device_eigen_solver_in_its_lds_form(gpu_contexts, monkeypatch):
-    """launch_eigen_omega runs the register-resident form of the Jacobi kernel unless PCSF_EIGEN_LDS=1 (read at every launch) asks for
-    the first version, matrices in LDS: the same accuracy test under that setting."""
+    """launch_eigen_omega runs the seven-wave form of the Jacobi kernel unless PCSF_EIGEN_LDS=1 / PCSF_EIGEN_FORM (read at every launch)
+    ask for an earlier one; the first version, matrices in LDS: the same accuracy test under that setting."""
     monkeypatch.setenv("PCSF_EIGEN_LDS", "1")
     test_device_eigen_solver_of_the_omega_rate_matrix(gpu_contexts)
 
 
-def test_device_eigen_solver_in_its_seven_wave_form(gpu_contexts, monkeypatch):
-    """PCSF_EIGEN_FORM=2 (read at every launch): a rotation wave, B in quads of lanes over four waves, V on two waves, scaled rotations --
-    the same accuracy test."""
-    monkeypatch.setenv("PCSF_EIGEN_FORM", "2")
+def test_device_eigen_solver_in_its_two_wave_form(gpu_contexts, monkeypatch):
+    """PCSF_EIGEN_FORM=1: rounds 2-4's register-resident form (wave 0 holds B in 8x8 blocks, wave 1 V; plain rotations) -- the same
+    accuracy test.  (The default, FORM 2: a rotation wave, B in quads of lanes over four waves, V on two waves, scaled rotations.)"""
+    monkeypatch.setenv("PCSF_EIGEN_FORM", "1")
     test_device_eigen_solver_of_the_omega_rate_matrix(gpu_contexts)
 
 
@@ -261,9 +261,11 @@ def test_eigen_solver_flags_a_matrix_it_cannot_diagonalise(gpu_contexts, monkeyp
         monkeypatch.setenv("PCSF_EIGEN_LDS", form)
         failed = ctx.debug_eigen_omega(qs)[-1]
         assert list(failed) == [0, 1], (form, failed)
-    monkeypatch.setenv("PCSF_EIGEN_FORM", "2")
-    failed = ctx.debug_eigen_omega(qs)[-1]
-    assert list(failed) == [0, 1], ("seven waves", failed)
+    monkeypatch.delenv("PCSF_EIGEN_LDS")
+    for form in ("1", "2"):
+        monkeypatch.setenv("PCSF_EIGEN_FORM", form)
+        failed = ctx.debug_eigen_omega(qs)[-1]
+        assert list(failed) == [0, 1], ("PCSF_EIGEN_FORM", form, failed)
 
 
 def test_block_groups_do_not_change_any_result(oracle_models, golden_dir):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # eigen_omega_kernel alone (tools/eigen_bench.py under rocprofv3 --kernel-trace), one line per form of the kernel: launch durations in
 # launch order -- warm-up, N cold, [cold, warm 1 %], [cold, warm 10 %], [cold, warm anywhere] -- and job 0's sweeps / steps / cycles
-# (PCSF_EIGEN_STAMPS).  FORMS="reg lds quad" (reg = the register-resident form, lds = PCSF_EIGEN_LDS=1, quad = PCSF_EIGEN_FORM=2), EIGEN_JOBS=200; extra arguments:
+# (PCSF_EIGEN_STAMPS).  FORMS="reg lds quad" (reg = PCSF_EIGEN_FORM=1, two waves; lds = PCSF_EIGEN_LDS=1; quad = PCSF_EIGEN_FORM=2, seven waves, the default), EIGEN_JOBS=200; extra arguments:
 # other builds of the library (tools/build_variant.sh), run with the default form.
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
@@ -22,7 +22,7 @@ export PCSF_EIGEN_STAMPS=1
 for form in ${FORMS:-reg lds}; do
     [ "$form" = none ] && continue
     echo "== form $form, $N jobs"
-    if [ "$form" = lds ]; then PCSF_EIGEN_LDS=1 run; elif [ "$form" = quad ]; then PCSF_EIGEN_FORM=2 run; else run; fi
+    if [ "$form" = lds ]; then PCSF_EIGEN_LDS=1 run; elif [ "$form" = quad ]; then PCSF_EIGEN_FORM=2 run; else PCSF_EIGEN_FORM=1 run; fi
 done
 for lib in "$@"; do
     echo "== $lib, $N jobs"
