@@ -40,6 +40,11 @@ __device__ double log_prior_kappa_dev(double kappa)
 struct DevicePrior {
     __device__ double operator()(uint32_t, uint32_t kind, double x) const { return kind == EVAL_RHO ? log_prior_rho_dev(x) : log_prior_kappa_dev(x); }
 };
+// ... made by one lane per pending evaluation before lane 0 runs the machine (pow, atan, lgamma: ~2,000 cycles each, up to twelve per round)
+struct LanePrior {
+    const double* v;
+    __device__ double operator()(uint32_t i, uint32_t, double) const { return v[i]; }
+};
 
 __global__ void prior_kernel(const uint32_t* __restrict__ kinds, const double* __restrict__ xs, uint32_t n, double* __restrict__ out)
 {
@@ -64,7 +69,7 @@ template <> struct MachineTraits<OmegaMachine> {
 // work-group and its atomics: a returning atomic on ONE word is served at ~88 per microsecond chip-wide, MI355X_MICROARCH.md "dequeue".
 // Measured with four: SLOWER -- 0.155 -> 0.28 ms per launch on configs[2], 8,256 real blocks MLE 0.14 -> 0.62 s: a work-group then lives as
 // long as its slowest block and four blocks' LDS images cut the occupancy.  One block per work-group it stays.)
-constexpr uint32_t SUM_CHUNK = 64;
+constexpr uint32_t SUM_CHUNK = 64;      // the per-site sums' buffer holds SUM_CHUNK sites of MAX_REQ evaluations
 constexpr int ADVANCE_BLOCKS = 1;
 // counters of a round a block appends to: n_evals[2], n_tile_jobs[2], n_groups[2][4], n_eig_jobs, n_list[2], n_active, n_transient
 enum AdvanceCounter { AC_EVALS = 0, AC_TILE_JOBS = 2, AC_GROUPS = 4, AC_EIG = 12, AC_LIST = 13, AC_ACTIVE = 15, AC_TRANSIENT = 16, AC_COUNT = 17 };
@@ -76,9 +81,25 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// diagnostics (-DPCSF_ADVANCE_STAMPS=1, tools/build_variant.sh): work-group PCSF_ADVANCE_STAMP_BLOCK prints the s_memtime cycles of its phases at every launch
+#ifndef PCSF_ADVANCE_STAMPS
+#define PCSF_ADVANCE_STAMPS 0
+#endif
+#ifndef PCSF_ADVANCE_STAMP_BLOCK
+#define PCSF_ADVANCE_STAMP_BLOCK 0
+#endif
+__device__ __forceinline__ unsigned long long adv_clock()
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define ADV_STAMP(var) const unsigned long long var = PCSF_ADVANCE_STAMPS ? adv_clock() : 0ull
+
 template <class M>
 __global__ __launch_bounds__(ADVANCE_BLOCKS * 64) void advance_blocks(const ChainParams p, uint32_t n_blocks)
 {
+    ADV_STAMP(t_start);
     constexpr int MAX_REQ = MachineTraits<M>::MAX_REQ;
     constexpr int STORES = MachineTraits<M>::STORES;
     constexpr uint32_t M_WORDS = (sizeof(M) + 3) / 4;
@@ -86,7 +107,8 @@ __global__ __launch_bounds__(ADVANCE_BLOCKS * 64) void advance_blocks(const Chai
     __shared__ EvalRequest req_all[ADVANCE_BLOCKS][MAX_REQ];
     __shared__ __attribute__((aligned(16))) uint32_t m_words_all[ADVANCE_BLOCKS][M_WORDS];
     __shared__ StoreEntry st_lds_all[ADVANCE_BLOCKS][STORES * STORE_ENTRIES];
-    __shared__ double sum_buf_all[ADVANCE_BLOCKS][MAX_REQ * SUM_CHUNK];
+    __shared__ __attribute__((aligned(16))) double sum_buf_all[ADVANCE_BLOCKS][MAX_REQ * SUM_CHUNK + 2 * MAX_REQ];
+    __shared__ double prior_all[ADVANCE_BLOCKS][MAX_REQ];
     __shared__ int n_req_all[ADVANCE_BLOCKS];
     __shared__ uint32_t cnt_all[ADVANCE_BLOCKS][AC_COUNT];   // what the wave's block appends to every counter; then its offset within the work-group's range
     __shared__ uint32_t base_all[AC_COUNT];
@@ -99,6 +121,7 @@ __global__ __launch_bounds__(ADVANCE_BLOCKS * 64) void advance_blocks(const Chai
     uint32_t* m_words = m_words_all[wave];
     StoreEntry* st_lds = st_lds_all[wave];
     double* sum_buf = sum_buf_all[wave];
+    double* prior_lds = prior_all[wave];
     uint32_t* cnt = cnt_all[wave];
     uint32_t* dense = dense_all[wave];
     if (lane < AC_COUNT) cnt[lane] = 0u;
@@ -129,21 +152,62 @@ __global__ __launch_bounds__(ADVANCE_BLOCKS * 64) void advance_blocks(const Chai
         // (1) the values of the pending evaluations: per-site terms through LDS in chunks of SUM_CHUNK sites (coalesced), then lane e adds
         // evaluation e's values in site order
         const uint32_t n_pending = m->n_pending;
+        ADV_STAMP(t_loaded);
         {
+            // A chunk of sites of every pending evaluation goes global -> LDS rows (coalesced; rows an even number of doubles plus two apart:
+            // the adding lanes' 16-byte reads do not collide), and lane e adds row e in site order -- the order is the result's definition
+            // (the host engine and the oracle add a block's sites first to last), so the adds are one dependent chain per evaluation; what
+            // can overlap does: sixteen values per LDS round trip instead of one (the first version: 64 dependent LDS reads per 64-site
+            // chunk, 6,000 cycles a chunk, 54,000 for a 542-site block with ONE pending evaluation), and the chunk is as long as the
+            // buffer allows for the evaluations there are -- SUM_CHUNK * MAX_REQ doubles: a whole 700-site block when one is pending,
+            // 64 sites when twelve are -- so a typical round pays the trip to HBM once.
             double l = 0.0, a = 0.0;
-            constexpr uint32_t ROWS = 64 / SUM_CHUNK;   // evaluations a pass of the wave loads a chunk of
-            const uint32_t e4 = lane / SUM_CHUNK, sl = lane % SUM_CHUNK;
-            for (int pass = 0; pass < (p.out_anc ? 2 : 1); ++pass) {
+            const uint32_t chunk = n_pending ? (SUM_CHUNK * MAX_REQ / n_pending) & ~63u : 0u, stride = chunk + 2;
+            for (int pass = 0; pass < ((p.out_anc && n_pending) ? 2 : (n_pending ? 1 : 0)); ++pass) {
                 const double* __restrict__ src = (pass ? p.out_anc : p.out_lnz) + static_cast<size_t>(P) * s0;
                 double acc = 0.0;
-                for (uint64_t c0 = 0; c0 < sites; c0 += SUM_CHUNK) {
-                    const uint32_t len = static_cast<uint32_t>(sites - c0 < SUM_CHUNK ? sites - c0 : SUM_CHUNK);
+                for (uint64_t c0 = 0; c0 < sites; c0 += chunk) {
+                    const uint32_t len = static_cast<uint32_t>(sites - c0 < chunk ? sites - c0 : chunk);
+                    wave_sync();   // the rows of the chunk before have been added
+                    // (64-site pieces, evaluation by evaluation, eight loads in flight: left to a loop per evaluation the compiler waits for
+                    // every load before it issues the next -- with eleven evaluations pending that was the whole phase)
+                    const uint32_t kpe = chunk >> 6, pieces = n_pending * kpe;
+                    uint32_t e_at = 0, k_at = 0;
+                    for (uint32_t q0 = 0; q0 < pieces; q0 += 8) {
+                        double t[8];
+                        uint32_t to[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const uint32_t i = k_at * 64 + lane;
+                            const bool in = q0 + u < pieces && i < len;
+                            to[u] = in ? e_at * stride + i : 0xffffffffu;
+                            t[u] = in ? src[static_cast<size_t>(e_at) * sites + c0 + i] : 0.0;
+                            if (++k_at == kpe) {
+                                k_at = 0;
+                                ++e_at;
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (to[u] != 0xffffffffu) sum_buf[to[u]] = t[u];
+                    }
                     wave_sync();
-                    if (sl < len)
-                        for (uint32_t e = e4; e < n_pending; e += ROWS) sum_buf[e * SUM_CHUNK + sl] = src[static_cast<size_t>(e) * sites + c0 + sl];
-                    wave_sync();
-                    if (lane < n_pending)
-                        for (uint32_t i = 0; i < len; ++i) acc += sum_buf[lane * SUM_CHUNK + i];
+                    if (lane < n_pending) {
+                        typedef double double2_sum __attribute__((ext_vector_type(2)));
+                        const double* row = sum_buf + lane * stride;
+                        uint32_t i = 0;
+                        for (; i + 16 <= len; i += 16) {
+                            double2_sum v[8];
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const double2_sum*>(row + i + 2 * k);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                acc += v[k].x;
+                                acc += v[k].y;
+                            }
+                        }
+                        for (; i < len; ++i) acc += row[i];
+                    }
                 }
                 (pass ? a : l) = acc;
             }
@@ -151,9 +215,11 @@ __global__ __launch_bounds__(ADVANCE_BLOCKS * 64) void advance_blocks(const Chai
                 res[lane].lnz = l;
                 res[lane].anc = a;
                 res[lane].failed = p.fail[static_cast<size_t>(b) * P + lane];
+                if constexpr (STORES == 1) prior_lds[lane] = DevicePrior()(lane, m->pend_kind[lane], m->pend_x[lane]);   // (OMEGA: the objective's log prior)
             }
         }
         wave_sync();
+        ADV_STAMP(t_summed);
         // (2) the block's machine
         if (lane == 0) {
             int n;
@@ -163,7 +229,7 @@ __global__ __launch_bounds__(ADVANCE_BLOCKS * 64) void advance_blocks(const Chai
                 n = m->round(res, st_lds, STORE_ENTRIES, DrawTable{p.draws[0], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points), static_cast<int>(p.max_restarts), p.out_anc != nullptr, req);
             } else {
                 n = m->round(res, st_lds, DrawTable{p.draws[1], p.n_draws}, DrawTable{p.draws[2], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points),
-                             static_cast<int>(p.max_restarts), p.held_systems != 0, DevicePrior(), req);
+                             static_cast<int>(p.max_restarts), p.held_systems != 0, LanePrior{prior_lds}, req);
             }
             n_req_all[wave] = n;
             // what this block appends to the round's lists
@@ -197,6 +263,10 @@ __global__ __launch_bounds__(ADVANCE_BLOCKS * 64) void advance_blocks(const Chai
             for (int k = 0; k < AC_COUNT; ++k) cnt[k] = c[k];
         }
         wave_sync();
+        ADV_STAMP(t_machine);
+        if (PCSF_ADVANCE_STAMPS && b == PCSF_ADVANCE_STAMP_BLOCK && lane == 0)
+            printf("advance_blocks block %u (%u sites, %u pending): load %llu, sums %llu, machine %llu cycles; %d requests\n", b, static_cast<unsigned>(sites), n_pending,
+                   t_loaded - t_start, t_summed - t_loaded, t_machine - t_summed, n_req_all[wave]);
         n_req = n_req_all[wave];
         // the machine and what the stores hold now, back to HBM
         for (uint32_t w = lane; w < M_WORDS; w += 64) m_global[w] = m_words[w];

@@ -32,6 +32,22 @@
 #ifndef PCSF_EIGEN_STEP_STAMPS
 #define PCSF_EIGEN_STEP_STAMPS 0
 #endif
+// diagnostics (-DPCSF_EIGEN_PHASE_PRINT=1): work-group 0 prints the s_memtime cycles between the marks of its prologue and epilogue
+#ifndef PCSF_EIGEN_PHASE_PRINT
+#define PCSF_EIGEN_PHASE_PRINT 0
+#endif
+#if PCSF_EIGEN_PHASE_PRINT
+#define EIG_PHASE(name)                                                                                  \
+    do {                                                                                                 \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                                       \
+            const unsigned long long now_ = eig_clock();                                                 \
+            printf("eigen phase %llu cycles: " name "\n", now_ - phase_clock);                           \
+            phase_clock = eig_clock();                                                                   \
+        }                                                                                                \
+    } while (0)
+#else
+#define EIG_PHASE(name) do { } while (0)
+#endif
 #ifndef PCSF_F2_PIN
 #define PCSF_F2_PIN 0   // (1: the B and rotation waves also pin their step results like the V waves do -- measured 7 % slower)
 #endif
@@ -228,6 +244,9 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
     constexpr int NT = FORM == 1 ? 128 : FORM == 2 ? 448 : 256;     // threads
     const bool stamping = p.stamps != nullptr && blockIdx.x == 0;
     const unsigned long long t_kernel = stamping ? eig_clock() : 0ull;
+#if PCSF_EIGEN_PHASE_PRINT
+    unsigned long long phase_clock = eig_clock();
+#endif
     unsigned long long acc_a = 0, acc_rot = 0, acc_v = 0, acc_b = 0, n_steps = 0, n_sweeps = 0;
     extern __shared__ __attribute__((aligned(16))) double lds_eig[];  // 2 x 64 x 65 doubles = 66,560 B
     double* A = lds_eig;
@@ -253,6 +272,7 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
         aa_s[tid] = amino_acid_dev(tid);
     }
     __syncthreads();
+    EIG_PHASE("pi");
     if (tid < 64) {
         if (!(pi[tid] > 0.0)) flag = 1;
         root[tid] = sqrt(pi[tid]);
@@ -277,28 +297,32 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
         V[i * LD + j] = i == j ? 1.0 : 0.0;
     }
     __syncthreads();
+    EIG_PHASE("rate fill");
     if (flag) {  // pi has a non-positive entry: the model is invalid (host: eigen_reversible returns false)
         if (tid == 0) p.fail[job.table] = 1u;
         return;
     }
     if (tid < 64) {
-        double diag = 0.0;
-        for (int j = 0; j < 64; ++j)
-            if (j != tid) diag -= A[tid * LD + j];
+        double diag = 0.0;   // (in index order like the host; the row's own place holds 0 and x - 0 = x: no branch between the loads)
+#pragma unroll 16
+        for (int j = 0; j < 64; ++j) diag -= j != tid ? A[tid * LD + j] : 0.0;
         A[tid * LD + tid] = diag;
     }
     __syncthreads();
+    EIG_PHASE("diagonal");
     if (tid == 0) {
         double norm = 0.0;
         for (int i = 0; i < 64; ++i) norm -= pi[i] * A[i * LD + i];
         norm_s = norm;
     }
     __syncthreads();
+    EIG_PHASE("normaliser");
     for (int idx = tid; idx < 4096; idx += NT) {
         const int i = idx >> 6, j = idx & 63;
         A[i * LD + j] = root[i] * (A[i * LD + j] / norm_s) * iroot[j];
     }
     __syncthreads();
+    EIG_PHASE("scaling");
     for (int idx = tid; idx < 4096; idx += NT) {
         const int i = idx >> 6, j = idx & 63;
         if (i < j) {
@@ -308,6 +332,7 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
         }
     }
     __syncthreads();
+    EIG_PHASE("symmetric form");
 
     const int lane = tid & 63, wave = tid >> 6;
     // Warm start: an optimiser moves kappa in small steps, so the eigenbasis V0 of an earlier matrix nearly diagonalises
@@ -318,6 +343,7 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
         const double* __restrict__ V0 = p.eig_basis + static_cast<size_t>(job.warm) * 4096;
         for (int idx = tid; idx < 4096; idx += NT) V[(idx >> 6) * LD + (idx & 63)] = V0[idx];
         __syncthreads();
+    EIG_PHASE("V0 from HBM");
         // Both 64^3 products on the matrix cores (v_mfma_f64_16x16x4_f64: A operand lane (s, g) = A[s][g], B operand = B[g][s], result
         // register r = row 4r + g, column s): wave w owns the output tiles of rows 16 TI w .. 16 TI (w + 1) - 1, 16 k-steps per tile, the
         // operands read from the two LDS matrices (row length 65: two lanes per bank at worst).  As scalar loops -- 32 entries and 4,096
@@ -352,6 +378,7 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) A[(16 * (mw * TI + a) + 4 * r + mg) * LD + 16 * b + ms] = acc[a][b][r];
         __syncthreads();
+    EIG_PHASE("product 1");
         // C = V0^T T: A operand V0^T[i][k] = V0[k][i]
 #pragma unroll
         for (int a = 0; a < TI; ++a)
@@ -377,6 +404,7 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) A[(16 * (mw * TI + a) + 4 * r + mg) * LD + 16 * b + ms] = acc[a][b][r];
         __syncthreads();
+    EIG_PHASE("product 2");
         for (int idx = tid; idx < 4096; idx += NT) {  // exact symmetry again
             const int i = idx >> 6, j = idx & 63;
             if (i < j) {
@@ -386,8 +414,10 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
             }
         }
         __syncthreads();
+    EIG_PHASE("symmetry again");
     }
-    const unsigned long long t_sweeps = stamping ? eig_clock() : 0ull;   // (the rate matrix, its symmetric form and a warm start's two products are behind)
+    const unsigned long long t_sweeps = stamping ? eig_clock() : 0ull;
+    EIG_PHASE("(before the sweeps)");   // (the rate matrix, its symmetric form and a warm start's two products are behind)
     if constexpr (FORM == 0) {
     // rotations of one step into buffer `buf`: tournament pairing of 0..63 (63 stays, the others rotate), lanes 0..31 of wave 0
     auto rotations = [&](int step, int buf) {
@@ -1410,6 +1440,7 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
         if (tid == (FORM == 0 ? 64 : 0)) atomicAdd(p.stamps + 2, acc_v);
     }
 
+    EIG_PHASE("sweeps, back to the canonical matrices");
     // eigen-system of Q: right = D^-1/2 V (eigenvectors in columns), left = V^T D^1/2 (in rows)
     double* __restrict__ R = p.eig_right ? p.eig_right + static_cast<size_t>(job.eig) * 4096 : nullptr;   // (null: only the fragment-ordered copies are wanted)
     double* __restrict__ L = p.eig_left ? p.eig_left + static_cast<size_t>(job.eig) * 4096 : nullptr;
@@ -1421,6 +1452,7 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
         if (L) L[idx] = V[c * LD + r] * root[c];    // left[k][i],  k = r, i = c
         if (basis) basis[idx] = V[r * LD + c];
     }
+    EIG_PHASE("right / left / basis out");
     if (p.eig_right_frag) {   // ... and in prune_factored's A-operand order (kernels.h FactoredParams): coalesced loads for every tile that uses the system
         double* __restrict__ Rf = p.eig_right_frag + static_cast<size_t>(job.eig) * 4096;
         double* __restrict__ Lf = p.eig_left_frag + static_cast<size_t>(job.eig) * 4096;
@@ -1430,18 +1462,36 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
             Lf[idx] = V[c * LD + r] * root[c];
         }
     }
+    EIG_PHASE("fragment-ordered copies out");
     if (tid < 64) lam[tid] = A[tid * LD + tid];
     // equilibrium: left eigenvector of the eigenvalue closest to zero, scaled to sum 1 (index order)
-    if (tid == 0) {
-        int z = 0;
-        for (int k = 1; k < 64; ++k)
-            if (fabs(A[k * LD + k]) < fabs(A[z * LD + z])) z = k;
-        double mass = 0.0;
-        for (int j = 0; j < 64; ++j) mass += V[j * LD + z] * root[j];
-        norm_s = mass;
-        pp[0] = z;
+    // (z = the FIRST index of the smallest |lambda|, as a scan from index 0 finds it -- one lane per eigenvalue and a wave reduction; the
+    // mass is the sum of the 64 products in index order, the products made by 64 lanes.  As two loops of one thread: 10,000 cycles.)
+    if (tid < 64) {
+        double key = fabs(A[tid * LD + tid]);
+        key = key == key ? key : __builtin_huge_val();   // a NaN never wins a scan's comparison ...
+        int idx = tid;
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            const double ok = __shfl_xor(key, sft);
+            const int oi = __shfl_xor(idx, sft);
+            const bool take = ok < key || (ok == key && oi < idx);
+            key = take ? ok : key;
+            idx = take ? oi : idx;
+        }
+        const double a0 = A[0];
+        const int z = a0 == a0 ? idx : 0;                // ... and one at index 0 never loses it
+        pi[tid] = V[tid * LD + z] * root[tid];           // (pi is free: root / iroot hold what the outputs need)
+        if (tid == 0) pp[0] = z;
     }
     __syncthreads();
+    if (tid == 0) {
+        double mass = 0.0;
+#pragma unroll 16
+        for (int j = 0; j < 64; ++j) mass += pi[j];
+        norm_s = mass;
+    }
+    __syncthreads();
+    EIG_PHASE("smallest eigenvalue, its vector's mass");
     if (tid < 64) {
         const int z = pp[0];
         const double pr = (V[tid * LD + z] * root[tid]) / norm_s;
@@ -1457,6 +1507,7 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
             p.eig_c[static_cast<size_t>(job.eig) * 64 + tid] = c;
         }
     }
+    EIG_PHASE("prior, weights");
 }
 
 hipError_t launch_eigen_omega(const EigenParams& p, hipStream_t stream)

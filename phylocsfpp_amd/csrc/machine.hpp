@@ -68,11 +68,14 @@ struct EvalResult {
 
 // index of the value at x, or -1 (an index, not a pointer: on the device the store may sit in LDS, and null tests of generic pointers
 // into LDS trip the gfx950 back end of ROCm 7.2 -- "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base")
+// (No early exit: on the device the store sits in LDS and ONE lane runs the machine -- a loop that tests each entry before it loads the next
+// costs an LDS round trip per entry, ~4,000 cycles for a store of forty, and a round that looks twelve points ahead searches twelve times.
+// Scanned from the back with a select, the loads are independent of the compares and the first match still wins.)
 PCSF_HD inline int store_find(const StoreEntry* e, uint32_t n, double x)
 {
-    for (uint32_t i = 0; i < n; ++i)
-        if (e[i].x == x) return static_cast<int>(i);
-    return -1;
+    int found = -1;
+    for (uint32_t i = n; i-- > 0;) found = (e[i].x == x) ? static_cast<int>(i) : found;
+    return found;
 }
 PCSF_HD inline void store_push(StoreEntry* e, uint32_t& n, double x, double lpr, double anc, bool failed)
 {
