@@ -51,6 +51,9 @@
 #ifndef PCSF_F2_PIN
 #define PCSF_F2_PIN 0   // (1: the B and rotation waves also pin their step results like the V waves do -- measured 7 % slower)
 #endif
+#ifndef PCSF_F2_PRIO
+#define PCSF_F2_PRIO 0
+#endif
 #ifndef PCSF_F2_SLEEP
 #define PCSF_F2_SLEEP 0
 #endif
@@ -1024,6 +1027,9 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
         const int pos = (rs & 4) + ((rs - jj) & 3);
         return (2 * pos + ((col_src >> 2) & 1)) * 256 + 32 * (row_src >> 3) + 4 * (col_src >> 3) + jj;
     };
+#if PCSF_F2_PRIO
+    if constexpr (MK) __builtin_amdgcn_s_setprio(PCSF_F2_PRIO);   // the step waits for this wave: it issues first on the SIMD it shares
+#endif
     double dA = 1.0, idA = 1.0, dB = 1.0, idB = 1.0;   // wave 0: (d, 1/d) of the seats j and 4 + j of super-group R
     double2_loc ab = double2_loc{0.0, 0.0};             // ... its (alpha, beta)
     int zn = 0;                                         // ... and whether the pair is small enough to be set to zero behind it
@@ -1409,8 +1415,12 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
 #ifdef PCSF_F2_ONLY_ROLE
     body(integral_constant<int, PCSF_F2_ONLY_ROLE>{});
 #else
-    if (wave == 0) body(integral_constant<int, 0>{});
-    else if (wave <= 4) body(integral_constant<int, 1>{});
+    if (wave == 0) {
+        body(integral_constant<int, 0>{});
+#if PCSF_F2_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    } else if (wave <= 4) body(integral_constant<int, 1>{});
     else if (wave == 5) body(integral_constant<int, 2>{});
     else body(integral_constant<int, 3>{});
 #endif

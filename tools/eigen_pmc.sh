@@ -3,9 +3,9 @@
 # s_waitcnt / s_barrier (WAIT_ANY), stalled at issue (WAIT_INST_ANY) -- and how many instructions it issues.  Counters only (no trace options).
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-for form in ${FORMS:-reg lds}; do
+for form in ${FORMS:-quad reg lds}; do   # quad = PCSF_EIGEN_FORM=2 (seven waves, the default), reg = 1 (two waves), lds = 0
     rm -rf /tmp/prof_ep
-    PCSF_EIGEN_LDS=$([ "$form" = lds ] && echo 1 || echo 0) rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --output-format csv -d /tmp/prof_ep -- python3 tools/eigen_bench.py ${EIGEN_JOBS:-200} > /dev/null 2>&1
+    PCSF_EIGEN_FORM=$([ "$form" = lds ] && echo 0 || { [ "$form" = reg ] && echo 1 || echo 2; }) rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --output-format csv -d /tmp/prof_ep -- python3 tools/eigen_bench.py ${EIGEN_JOBS:-200} > /dev/null 2>&1
     python3 - $form <<'PY'
 import csv, glob, sys, collections
 f = glob.glob('/tmp/prof_ep/**/*counter_collection.csv', recursive=True)[0]
