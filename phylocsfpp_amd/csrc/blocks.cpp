@@ -1320,7 +1320,8 @@ int run_mle(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_bl
         const DrawTable dt{table.data(), DRAW_TABLE_ENTRIES};
         const LookaheadPolicy look = lookahead_policy(eager);
         run_host_rounds(eng, machines, 2 * look.max_points, compute_anc != 0, stop, st, [] {}, [&](size_t b, const EvalResult* res, EvalRequest* out) {
-            return machines[b].round(res, stores.data() + b * 2 * STORE_ENTRIES, STORE_ENTRIES, dt, look.eager, look.max_points, look.max_restarts, compute_anc != 0, out);
+            Lookahead ahead[2];
+            return machines[b].round(res, stores.data() + b * 2 * STORE_ENTRIES, STORE_ENTRIES, dt, look.eager, look.max_points, look.max_restarts, compute_anc != 0, out, ahead);
         });
     }
     if (std::getenv("PCSF_TIME_BLOCKS")) {
@@ -1431,7 +1432,8 @@ int run_omega(pcsf_ctx* c, const uint8_t* codons, const uint64_t* off, size_t n_
                     for (int k = 0; k < 12; ++k) fprintf(stderr, " %.17g", (k == 0 && kappa) ? m.pend_x[i] : m.q_settings[k]);
                     fprintf(stderr, "\n");
                 }
-            const int n = m.round(res, stores.data() + b * STORE_ENTRIES, dr, dk, look.eager, look.max_points, look.max_restarts, held_systems, HostPrior{prior_v.data() + at[b]}, out);
+            Lookahead ahead;
+            const int n = m.round(res, stores.data() + b * STORE_ENTRIES, dr, dk, look.eager, look.max_points, look.max_restarts, held_systems, HostPrior{prior_v.data() + at[b]}, out, &ahead);
             for (int i = 0; i < n; ++i)
                 if (out[i].eig & TRANSIENT_EIG) out[i].eig = static_cast<uint32_t>(transient0 + b * look.max_points + (out[i].eig & ~TRANSIENT_EIG));
             return n;

@@ -16,6 +16,13 @@
 #include <stdint.h>
 
 #include "kernels.h"
+// diagnostics (-DPCSF_ADVANCE_STAMPS=1, tools/build_variant.sh): work-group PCSF_ADVANCE_STAMP_BLOCK prints the s_memtime cycles of its phases at every launch
+#ifndef PCSF_ADVANCE_STAMPS
+#define PCSF_ADVANCE_STAMPS 0
+#endif
+#ifndef PCSF_ADVANCE_STAMP_BLOCK
+#define PCSF_ADVANCE_STAMP_BLOCK 0
+#endif
 #include "machine.hpp"
 
 namespace pcsf {
@@ -109,6 +116,7 @@ __global__ __launch_bounds__(ADVANCE_BLOCKS * 64) void advance_blocks(const Chai
     __shared__ StoreEntry st_lds_all[ADVANCE_BLOCKS][STORES * STORE_ENTRIES];
     __shared__ __attribute__((aligned(16))) double sum_buf_all[ADVANCE_BLOCKS][MAX_REQ * SUM_CHUNK + 2 * MAX_REQ];
     __shared__ double prior_all[ADVANCE_BLOCKS][MAX_REQ];
+    __shared__ Lookahead ahead_all[ADVANCE_BLOCKS][2];   // the machine's list of upcoming points (as a local of round(): scratch memory, ~500 cycles an access)
     __shared__ int n_req_all[ADVANCE_BLOCKS];
     __shared__ uint32_t cnt_all[ADVANCE_BLOCKS][AC_COUNT];   // what the wave's block appends to every counter; then its offset within the work-group's range
     __shared__ uint32_t base_all[AC_COUNT];
@@ -166,31 +174,40 @@ __global__ __launch_bounds__(ADVANCE_BLOCKS * 64) void advance_blocks(const Chai
             for (int pass = 0; pass < ((p.out_anc && n_pending) ? 2 : (n_pending ? 1 : 0)); ++pass) {
                 const double* __restrict__ src = (pass ? p.out_anc : p.out_lnz) + static_cast<size_t>(P) * s0;
                 double acc = 0.0;
-                for (uint64_t c0 = 0; c0 < sites; c0 += chunk) {
-                    const uint32_t len = static_cast<uint32_t>(sites - c0 < chunk ? sites - c0 : chunk);
-                    wave_sync();   // the rows of the chunk before have been added
-                    // (64-site pieces, evaluation by evaluation, eight loads in flight: left to a loop per evaluation the compiler waits for
-                    // every load before it issues the next -- with eleven evaluations pending that was the whole phase)
-                    const uint32_t kpe = chunk >> 6, pieces = n_pending * kpe;
+                // 64-site pieces, evaluation by evaluation: at most MAX_REQ of them per chunk and lane, all in flight at once, and the NEXT chunk's
+                // while this one is added (left to a loop per evaluation the compiler waits for every load before it issues the next)
+                const uint32_t kpe = chunk >> 6, pieces = n_pending * kpe;
+                double pre[MAX_REQ];
+                auto fetch = [&](uint64_t c0, uint32_t len) {
                     uint32_t e_at = 0, k_at = 0;
-                    for (uint32_t q0 = 0; q0 < pieces; q0 += 8) {
-                        double t[8];
-                        uint32_t to[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
+                    for (int q = 0; q < MAX_REQ; ++q) {
+                        const uint32_t i = k_at * 64 + lane;
+                        pre[q] = (static_cast<uint32_t>(q) < pieces && i < len) ? src[static_cast<size_t>(e_at) * sites + c0 + i] : 0.0;
+                        if (++k_at == kpe) {
+                            k_at = 0;
+                            ++e_at;
+                        }
+                    }
+                };
+                auto chunk_len = [&](uint64_t c0) { return static_cast<uint32_t>(sites - c0 < chunk ? sites - c0 : chunk); };
+                if (sites) fetch(0, chunk_len(0));
+                for (uint64_t c0 = 0; c0 < sites; c0 += chunk) {
+                    const uint32_t len = chunk_len(c0);
+                    wave_sync();   // the rows of the chunk before have been added
+                    {
+                        uint32_t e_at = 0, k_at = 0;
+#pragma unroll
+                        for (int q = 0; q < MAX_REQ; ++q) {
                             const uint32_t i = k_at * 64 + lane;
-                            const bool in = q0 + u < pieces && i < len;
-                            to[u] = in ? e_at * stride + i : 0xffffffffu;
-                            t[u] = in ? src[static_cast<size_t>(e_at) * sites + c0 + i] : 0.0;
+                            if (static_cast<uint32_t>(q) < pieces && i < len) sum_buf[e_at * stride + i] = pre[q];
                             if (++k_at == kpe) {
                                 k_at = 0;
                                 ++e_at;
                             }
                         }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            if (to[u] != 0xffffffffu) sum_buf[to[u]] = t[u];
                     }
+                    if (c0 + chunk < sites) fetch(c0 + chunk, chunk_len(c0 + chunk));
                     wave_sync();
                     if (lane < n_pending) {
                         typedef double double2_sum __attribute__((ext_vector_type(2)));
@@ -226,15 +243,15 @@ __global__ __launch_bounds__(ADVANCE_BLOCKS * 64) void advance_blocks(const Chai
             // (the stores always sit in LDS: a call on a pointer chosen between LDS and HBM, or two calls the compiler merges into one, trip
             // the gfx950 back end of ROCm 7.2, "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base")
             if constexpr (STORES == 2) {
-                n = m->round(res, st_lds, STORE_ENTRIES, DrawTable{p.draws[0], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points), static_cast<int>(p.max_restarts), p.out_anc != nullptr, req);
+                n = m->round(res, st_lds, STORE_ENTRIES, DrawTable{p.draws[0], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points), static_cast<int>(p.max_restarts), p.out_anc != nullptr, req,
+                             ahead_all[wave]);
             } else {
                 n = m->round(res, st_lds, DrawTable{p.draws[1], p.n_draws}, DrawTable{p.draws[2], p.n_draws}, p.eager != 0, static_cast<int>(p.max_points),
-                             static_cast<int>(p.max_restarts), p.held_systems != 0, LanePrior{prior_lds}, req);
+                             static_cast<int>(p.max_restarts), p.held_systems != 0, LanePrior{prior_lds}, req, ahead_all[wave]);
             }
             n_req_all[wave] = n;
             // what this block appends to the round's lists
-            uint32_t c[AC_COUNT];
-            for (int k = 0; k < AC_COUNT; ++k) c[k] = 0u;
+            uint32_t* c = cnt;   // (zeroed at the kernel's start; a local array indexed at run time would live in scratch memory)
             c[AC_ACTIVE] = m->active ? 1u : 0u;
             for (int i0 = 0; i0 < n;) {
                 const uint32_t eig = req[i0].eig, set = req[i0].new_eigen ? 1u : 0u;
@@ -260,13 +277,19 @@ __global__ __launch_bounds__(ADVANCE_BLOCKS * 64) void advance_blocks(const Chai
                 }
                 i0 = i1;
             }
-            for (int k = 0; k < AC_COUNT; ++k) cnt[k] = c[k];
         }
         wave_sync();
         ADV_STAMP(t_machine);
         if (PCSF_ADVANCE_STAMPS && b == PCSF_ADVANCE_STAMP_BLOCK && lane == 0)
+        {
             printf("advance_blocks block %u (%u sites, %u pending): load %llu, sums %llu, machine %llu cycles; %d requests\n", b, static_cast<unsigned>(sites), n_pending,
                    t_loaded - t_start, t_summed - t_loaded, t_machine - t_summed, n_req_all[wave]);
+#if PCSF_ADVANCE_STAMPS
+            if constexpr (STORES == 1)
+                printf("   machine: values in %llu, searches fed %llu, (validation / set-up) %llu, upcoming points %llu, requests built %llu\n", g_machine_stamp[1] - g_machine_stamp[0],
+                       g_machine_stamp[2] - g_machine_stamp[1], 0ull, g_machine_stamp[3] - g_machine_stamp[2], g_machine_stamp[4] - g_machine_stamp[3]);
+#endif
+        }
         n_req = n_req_all[wave];
         // the machine and what the stores hold now, back to HBM
         for (uint32_t w = lane; w < M_WORDS; w += 64) m_global[w] = m_words[w];

@@ -20,6 +20,22 @@
 
 namespace pcsf {
 
+// diagnostics of the device engine (-DPCSF_ADVANCE_STAMPS=1, chain.hip): where OmegaMachine::round spends one lane's cycles
+#if defined(__HIPCC__) && defined(PCSF_ADVANCE_STAMPS) && PCSF_ADVANCE_STAMPS
+__device__ unsigned long long g_machine_stamp[8];
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PCSF_ADVANCE_STAMPS) && PCSF_ADVANCE_STAMPS
+#define PCSF_MACHINE_STAMP(i_)                                                            \
+    do {                                                                                  \
+        if (blockIdx.x == PCSF_ADVANCE_STAMP_BLOCK) {                                     \
+            unsigned long long t_;                                                        \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");    \
+            g_machine_stamp[i_] = t_;                                                     \
+        }                                                                                 \
+    } while (0)
+#else
+#define PCSF_MACHINE_STAMP(i_) do { } while (0)
+#endif
 constexpr int MAX_POINTS_PER_SEARCH = 12;     // per search and round: certain points first, then speculative restarts
 constexpr int MAX_SPECULATIVE_RESTARTS = 8;
 constexpr int MIN_POINTS_PER_SEARCH = 5;      // a Brent set-up asks for chosen, lo, hi, chosen, v: all certain, all in one round
@@ -111,13 +127,14 @@ PCSF_HD inline void store_compact(StoreEntry* e, uint32_t& n, uint32_t& tally_us
 }
 
 struct Lookahead {  // MaxLik1D::upcoming() of one search for the current round
-    int n = 0;
+    int n;   // (set by whoever fills the list: the struct sits in LDS on the device, which takes no initialisers)
     double x[MAX_POINTS_PER_SEARCH];
     PCSF_HD bool seen_before(int rank) const  // the same point earlier in the list (lo, hi, chosen recur when Brent is set up)
     {
-        for (int i = 0; i < rank; ++i)
-            if (x[i] == x[rank]) return true;
-        return false;
+        int seen = 0;   // (no early exit, like store_find)
+        const double xr = x[rank];
+        for (int i = 0; i < MAX_POINTS_PER_SEARCH; ++i) seen |= static_cast<int>(i < rank) & static_cast<int>(x[i] == xr);
+        return seen != 0;
     }
 };
 
@@ -156,7 +173,7 @@ struct MleMachine {
     // max_points (5..MAX_POINTS_PER_SEARCH) / max_restarts: how far a search looks ahead per round -- the five certain points of a Brent set-up
     // always fit; no result depends on either.  Returns the number of requests written to out[2 * max_points]; 0 = the block is finished (or failed).
     PCSF_HD int round(const EvalResult* res, StoreEntry* store, uint32_t store_stride, const DrawTable& draws_table, bool eager, int max_points, int max_restarts, bool compute_anc,
-                      EvalRequest* out)
+                      EvalRequest* out, Lookahead* ahead /* [2], work space: on the device in LDS -- as a local it is indexed at run time and lives in scratch memory */)
     {
         for (int m = 0; m < 2; ++m) store_compact(store + m * store_stride, n_store[m], used);
         for (uint32_t i = 0; i < n_pending; ++i) {
@@ -195,7 +212,8 @@ struct MleMachine {
             return 0;
         }
         // the points the searches will or may need next: rank 0 (certain) of both first
-        Lookahead ahead[2];
+        ahead[0].n = ahead[1].n = 0;
+        for (int i = 0; i < MAX_POINTS_PER_SEARCH; ++i) ahead[0].x[i] = ahead[1].x[i] = 0.0;   // (seen_before scans the whole list)
         for (int model = 0; model < 2; ++model)
             if ((model == 0 || started1) && !opt[model].done())
                 ahead[model].n = opt[model].upcoming(ahead[model].x, max_points, max_restarts, eager, nullptr, draws_table, draws);
@@ -231,9 +249,11 @@ enum EigRole { ROLE_OWN = 0, ROLE_LO = 1, ROLE_HI = 2, ROLE_P0 = 3, ROLE_P1 = 4,
 
 PCSF_HD inline bool same_settings(const double* a, const double* b, int from = 0)
 {
-    for (int i = from; i < 12; ++i)
-        if (!(a[i] == b[i])) return false;   // (settings are never NaN)
-    return true;
+    // (no early exit: like store_find -- on the device both sides sit in LDS and one lane compares; a loop that tests each pair before it
+    // loads the next pays a round trip per setting, and a kappa stage's round compares eleven probes with five held systems)
+    int same = 1;
+    for (int i = 0; i < 12; ++i) same &= static_cast<int>(i < from) | static_cast<int>(a[i] == b[i]);   // (settings are never NaN)
+    return same != 0;
 }
 PCSF_HD inline void copy_settings(double* dst, const double* src)
 {
@@ -309,8 +329,9 @@ struct OmegaMachine {
     // Returns the number of requests written to out[OMEGA_MAX_REQUESTS]; 0 = the block is finished (or failed).
     template <class Prior>
     PCSF_HD int round(const EvalResult* res, StoreEntry* store, const DrawTable& rho_draws, const DrawTable& kappa_draws, bool eager, int max_points, int max_restarts,
-                      bool held_systems, Prior prior, EvalRequest* out)
+                      bool held_systems, Prior prior, EvalRequest* out, Lookahead* ahead_buf /* work space, see MleMachine::round */)
     {
+        PCSF_MACHINE_STAMP(0);
         store_compact(store, n_store, used);
         for (uint32_t i = 0; i < n_pending; ++i) {
             if (pend_kind[i] == EVAL_VALIDATION) {
@@ -331,6 +352,7 @@ struct OmegaMachine {
             }
         }
         n_pending = 0;
+        PCSF_MACHINE_STAMP(1);
         // (1) feed the search from the store; a finished stage moves the block on
         while (!failed && !done && !needs_validation) {
             const DrawTable& dt = (stage % 2) == 0 ? rho_draws : kappa_draws;
@@ -402,10 +424,18 @@ struct OmegaMachine {
             return 1;
         }
         // (2) the points the search will or may need next
-        Lookahead ahead;
+        PCSF_MACHINE_STAMP(2);
+        Lookahead& ahead = *ahead_buf;
+        ahead.n = 0;
+        for (int i = 0; i < MAX_POINTS_PER_SEARCH; ++i) ahead.x[i] = 0.0;   // (seen_before scans the whole list)
         int ahead_certain = 0;
         const bool rho_stage = (stage % 2) == 0;
         ahead.n = opt.upcoming(ahead.x, max_points, max_restarts, eager, &ahead_certain, rho_stage ? rho_draws : kappa_draws, draws);
+        PCSF_MACHINE_STAMP(3);
+        bool family_known = false;     // kappa stages: family[] / kappa_of[] / qbase are set (see there)
+        uint32_t family = 0u;          // bit role: the role's system is of the probes' family
+        double k_own = 0.0, k_lo = 0.0, k_hi = 0.0, k_p0 = 0.0, k_p1 = 0.0, qbase[12];   // (scalars and selects: an array indexed by the role lives in scratch memory on the device)
+        auto kappa_of = [&](int role) { return role == ROLE_OWN ? k_own : role == ROLE_LO ? k_lo : role == ROLE_HI ? k_hi : role == ROLE_P0 ? k_p0 : k_p1; };
         bool rebuilt = false;          // the block's own eigen-system slot is rebuilt in this round
         uint32_t written = 0;          // bit role: the role's slot is rewritten in this round
         uint32_t n_transient = 0;
@@ -436,8 +466,26 @@ struct OmegaMachine {
             } else {  // kappa: a probe model
                 r.kind = EVAL_KAPPA;
                 r.tree_scale = tree_scale;
+                // Every probe of the round is the block's model with another kappa, and a slot written in this round is out of the comparisons
+                // for the rest of it: which held systems are of the probes' FAMILY (all settings but kappa equal), and their kappas, are the
+                // same for every probe -- looked up once (five comparisons of twelve settings per round instead of ten per probe; on the
+                // device one lane walks this against LDS latency, and a stage's first round lists eleven probes).
+                if (!family_known) {
+                    copy_settings(qbase, q_settings);
+                    family = 0u;
+                    for (int role = 0; role < N_ROLES; ++role) {
+                        const double* hs = role == ROLE_OWN ? eig_settings : held[role];
+                        family |= same_settings(hs, q_settings, 1) ? 1u << role : 0u;
+                    }
+                    k_own = eig_settings[0];
+                    k_lo = held[ROLE_LO][0];
+                    k_hi = held[ROLE_HI][0];
+                    k_p0 = held[ROLE_P0][0];
+                    k_p1 = held[ROLE_P1][0];
+                    family_known = true;
+                }
                 double qs[12];
-                copy_settings(qs, q_settings);
+                copy_settings(qs, qbase);
                 qs[0] = x;
                 // Which probes may change what the block holds: the ends of the range, and the probes of the Brent phase (each asked
                 // for only after its predecessor was consumed).  Random restarts never do, and always start from the block's own
@@ -447,7 +495,7 @@ struct OmegaMachine {
                 int hit = -1;
                 for (int role = 0; role < N_ROLES && held_systems && hit < 0; ++role) {   // the role's slot holds exactly this model, and is not being rewritten in this round
                     const bool valid = role == ROLE_OWN ? (eig_valid && !rebuilt) : (held_valid[role] && !(written & (1u << role)));
-                    if (valid && same_settings(role == ROLE_OWN ? eig_settings : held[role], qs)) hit = role;
+                    if (valid && (family >> role & 1u) && kappa_of(role) == x) hit = role;   // = same_settings(the role's settings, qs)
                 }
                 if (hit >= 0) {   // solved before (the block's own model, or an end of the kappa range in an earlier stage): no new eigen-system
                     r.eig = slot[hit];
@@ -470,10 +518,9 @@ struct OmegaMachine {
                     for (int role = 0; role < N_ROLES; ++role) {
                         if ((!held_systems || target < 0) && role != ROLE_OWN) break;
                         if ((target == ROLE_LO || target == ROLE_HI) && role != ROLE_OWN && role != target) continue;
-                        const double* hs = role == ROLE_OWN ? eig_settings : held[role];
                         const bool valid = role == ROLE_OWN ? (eig_valid && !rebuilt) : (held_valid[role] && !(written & (1u << role)));
-                        if (!valid || !same_settings(hs, qs, 1)) continue;
-                        const double dist = fabs(hs[0] - x);
+                        if (!valid || !(family >> role & 1u)) continue;   // = same_settings(the role's settings, qs, 1)
+                        const double dist = fabs(kappa_of(role) - x);
                         if (warm < 0 || dist < best) {
                             warm = static_cast<int32_t>(slot[role]);
                             best = dist;
@@ -498,6 +545,7 @@ struct OmegaMachine {
             pend_kind[n] = r.kind;
             ++n;
         }
+        PCSF_MACHINE_STAMP(4);
         n_pending = static_cast<uint32_t>(n);
         return n;
     }
