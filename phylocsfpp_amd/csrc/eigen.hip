@@ -48,15 +48,6 @@
 #else
 #define EIG_PHASE(name) do { } while (0)
 #endif
-#ifndef PCSF_F2_PIN
-#define PCSF_F2_PIN 0   // (1: the B and rotation waves also pin their step results like the V waves do -- measured 7 % slower)
-#endif
-#ifndef PCSF_F2_PRIO
-#define PCSF_F2_PRIO 0
-#endif
-#ifndef PCSF_F2_SLEEP
-#define PCSF_F2_SLEEP 0
-#endif
 #ifndef PCSF_F2_RESEAT_STAMPS
 #define PCSF_F2_RESEAT_STAMPS 0   // FORM 2, with the step-stamps build: the stamps' four slots split wave 0's re-seatings instead of its steps
 #endif
@@ -153,52 +144,28 @@ __host__ __device__ __forceinline__ constexpr int shift_source(int G, int half)
 }  // namespace rr
 
 // ---- seven-wave variant (FORM 2, round 5): the same schedule on QUADS of lanes ------------------------------------------------------
-// rr's rounds and step patterns, but a round's seating is refined into PHASES so that every step is a "cross" step on the seats a lane
-// holds: in phase 3 (rr's own seating) pattern 3 + t pairs seat k with seat 4 + ((k + t) & 3); the three steps of round 0 for the pairs
-// inside the groups (rr patterns 0..2) each get a phase of their own (0..2) in which the pattern's pair k is seated on (k, 4 + k) and
-// the step is the cross step t = 0.  tau(ph, q) = rr's seat on the physical seat q of a super-group, sigma = its inverse.
+// rr's rounds, seating and step patterns.  A cross step (pattern 3 + t) pairs seat k with seat 4 + ((k + t) & 3): the two columns a lane
+// holds.  The three steps of round 0 for the pairs inside the groups (patterns 0..2) pair seat e of a group with seat e ^ X, X = 1, 2, 3:
+// they run in the t = 0 layout, the partner column in lane j ^ X of the quad.
 namespace rq {
-__host__ __device__ __forceinline__ constexpr int tau(int ph, int q) { return ph == 3 ? q : (q < 4 ? rr::pair_a(ph, q) : rr::pair_b(ph, q - 4)); }
-__host__ __device__ __forceinline__ constexpr int sigma(int ph, int s)
+// canonical index of the seat (8 G + q) in round r -- rr's own seating
+__host__ __device__ __forceinline__ int canon(int r, int seat) { return 4 * rr::group_of(r, seat >> 3, (seat >> 2) & 1) + (seat & 3); }
+// DPP quad_perm controls: lane j reads lane (j + t) & 3 / lane j ^ x
+constexpr int quad_rot(int t) { return ((0 + t) & 3) | (((1 + t) & 3) << 2) | (((2 + t) & 3) << 4) | (((3 + t) & 3) << 6); }
+constexpr int quad_xor(int x) { return (0 ^ x) | ((1 ^ x) << 2) | ((2 ^ x) << 4) | ((3 ^ x) << 6); }
+// one of two REGISTERS: written as `c ? a[i] : a[k]` the compiler makes it one load from a selected address -- and an array that is
+// indexed at run time lives in scratch memory
+__device__ __forceinline__ double pick(bool c, double a, double b)
 {
-    if (ph == 3) return s;
-    for (int q = 0; q < 8; ++q)
-        if (tau(ph, q) == s) return q;
-    return -1;
+    asm("" : "+v"(a), "+v"(b));
+    return c ? a : b;
 }
-// canonical index of the physical seat (8 G + q) in round r, phase ph
-__host__ __device__ __forceinline__ int canon(int r, int ph, int seat)
-{
-    const int s = tau(ph, seat & 7);
-    return 4 * rr::group_of(r, seat >> 3, s >> 2) + (s & 3);
-}
-// the physical seat of (round r0, phase ph0) whose occupant sits on `seat` in (r1, ph1)
-__host__ __device__ __forceinline__ int source(int r0, int ph0, int r1, int ph1, int seat)
-{
-    const int s1 = tau(ph1, seat & 7);
-    const int loc = rr::locate(r0, rr::group_of(r1, seat >> 3, s1 >> 2));
-    return 8 * (loc & 7) + sigma(ph0, 4 * (loc >> 3) + (s1 & 3));
-}
-// The five re-seatings of a sweep: 0 = end of a round (every round: the same permutation), 1 = end of round 14 into phase 0 of round 0,
-// 2..4 = phase 0 -> 1 -> 2 -> 3 inside round 0
-__host__ __device__ __forceinline__ int reseat_source(int type, int seat)
-{
-    return type == 0 ? source(0, 3, 1, 3, seat) : type == 1 ? source(14, 3, 0, 0, seat) : source(0, type - 2, 0, type - 1, seat);
-}
-constexpr int quad_rot(int t) { return ((0 + t) & 3) | (((1 + t) & 3) << 2) | (((2 + t) & 3) << 4) | (((3 + t) & 3) << 6); }   // DPP quad_perm: lane j reads lane (j + t) & 3
 template <int CTRL>
 __device__ __forceinline__ double quad_perm(double x)
 {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
-}
-// a phase change inside a round permutes the seats of a super-group: seat q of phase PH1 takes over from seat sigma(PH0, tau(PH1, q))
-template <int PH0, int PH1, typename T, int... Q>
-__host__ __device__ __forceinline__ void permute_seats(T* v8, std::integer_sequence<int, Q...>)
-{
-    const T t8[8] = {v8[std::integral_constant<int, sigma(PH0, tau(PH1, Q))>::value]...};
-    ((v8[Q] = t8[Q]), ...);
 }
 // The end of a round as a V wave sees it (W = 0: seats of the super-groups 0..3, W = 1: 4..7, 8 G + q each): every group of four seats
 // but (0, 1) moves one place round the table (rr::shift_source); the cycle (0,0) <- (1,0) <- ... <- (7,0) <- (7,1) <- (6,1) <- ... <- (1,1)
@@ -944,13 +911,17 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
     // x <- x - alpha y, y <- y + beta x (alpha = t d_b / d_a, beta = t d_a / d_b; d <- d cos): two FMAs per element pair, and t, which
     // only decides how well the pair is annihilated, never orthogonality, comes from an fp32 chain.
     // One LDS hand-over (the rotations) and one barrier per step; every fourth step the blocks of B pass through LDS to their next seats.
+    // The three steps of round 0 for the pairs INSIDE the groups (seat e with seat e ^ X of the same group) run in place, in the t = 0 layout:
+    // the partner column is in lane j ^ X of the quad, the partner row in the lane's own registers -- at a position that depends on the
+    // lane, so these steps select between two registers where a cross step names one (~2x a cross step's instructions, three steps of 63;
+    // their first version gave each of them a seating of its own in which it WAS a cross step: three more re-seatings per sweep, 2,000
+    // cycles each against ~700 for the selects).  Their rotations travel as one coefficient per SEAT: new[s] = old[s] + coef[s] old[s ^ X].
     double2_loc* rt = reinterpret_cast<double2_loc*>(rot);         // [buf][super-group * 4 + pair] = (alpha, beta)
     __shared__ __attribute__((aligned(16))) double dtab[64 * 2];   // (d, 1/d) per physical seat: written for a re-seating
     __shared__ double dtab2[64];                                   // d per physical seat: written for a stop test
-    __shared__ int zfl[2 * 32];                                    // [buf][super-group * 4 + pair]: the pair is set to zero behind its rotation
-    __shared__ unsigned char seat_tab[5 * 64];                     // rq::reseat_source
+    __shared__ int zfl[2 * 64];                                    // [buf][super-group * 4 + pair] (inside steps: [buf][seat]): the pair is set to zero behind its rotation
     __shared__ int tflag;                                          // wave 0 -> all: run the stop test after this re-seating
-    if (tid < 320) seat_tab[tid] = static_cast<unsigned char>(rq::reseat_source(tid >> 6, tid & 63));
+    double* coef = rot;                                            // inside steps: [buf][seat], the same 1 KB as rt
     auto rsqrt_nr = [](double x) {
         double y = __builtin_amdgcn_rsq(x);
         const double hx = 0.5 * x;
@@ -990,13 +961,13 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
     if constexpr (!VW) {
 #pragma unroll
         for (int pos = 0; pos < 8; ++pos) {
-            const int rc = rq::canon(0, 0, 8 * R + rowseat(pos));
-            c0[pos] = A[rc * LD + rq::canon(0, 0, 8 * C + j)];
-            c1[pos] = A[rc * LD + rq::canon(0, 0, 8 * C + 4 + j)];
+            const int rc = rq::canon(0, 8 * R + rowseat(pos));
+            c0[pos] = A[rc * LD + rq::canon(0, 8 * C + j)];
+            c1[pos] = A[rc * LD + rq::canon(0, 8 * C + 4 + j)];
         }
     } else {
 #pragma unroll
-        for (int s = 0; s < 32; ++s) v[s] = V[lane * LD + rq::canon(0, 0, 32 * W + s)];
+        for (int s = 0; s < 32; ++s) v[s] = V[lane * LD + rq::canon(0, 32 * W + s)];
     }
     __syncthreads();   // everything is in registers: A becomes the staging matrix of the re-seatings (by physical seat), V the exchange buffer
     double* S = A;
@@ -1021,15 +992,6 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
                 if (x == 0) dseat0[y] = 8 * (sc & 7) + 4 * (sc >> 3) + j;
             }
     }
-    // the four other re-seatings of a sweep: the staged address of (row seat, column seat) from the look-up table
-    auto staged = [&](int row_src, int col_src) {
-        const int jj = col_src & 3, rs = row_src & 7;   // the lane of the quad that staged the column; the row's seat within its super-group
-        const int pos = (rs & 4) + ((rs - jj) & 3);
-        return (2 * pos + ((col_src >> 2) & 1)) * 256 + 32 * (row_src >> 3) + 4 * (col_src >> 3) + jj;
-    };
-#if PCSF_F2_PRIO
-    if constexpr (MK) __builtin_amdgcn_s_setprio(PCSF_F2_PRIO);   // the step waits for this wave: it issues first on the SIMD it shares
-#endif
     double dA = 1.0, idA = 1.0, dB = 1.0, idB = 1.0;   // wave 0: (d, 1/d) of the seats j and 4 + j of super-group R
     double2_loc ab = double2_loc{0.0, 0.0};             // ... its (alpha, beta)
     int zn = 0;                                         // ... and whether the pair is small enough to be set to zero behind it
@@ -1075,7 +1037,7 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
                 al[m] = rw.x;
                 bl[m] = rw.y;
             }
-            zl = zfl[32 * buf + 4 * R + j];
+            zl = zfl[64 * buf + 4 * R + j];
         }
 #pragma unroll
         for (int pos = 0; pos < 8; ++pos) {   // columns (j, 4 + ((j + T) & 3)): the lane's pair
@@ -1096,10 +1058,7 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
         const bool z = diag && zl != 0;
         c1[0] = z ? 0.0 : c1[0];
         c0[4 + T] = z ? 0.0 : c0[4 + T];
-#if PCSF_F2_PIN
-#pragma unroll
-        for (int pos = 0; pos < 8; ++pos) asm volatile("" : "+v"(c0[pos]), "+v"(c1[pos]));   // (see v_step)
-#endif
+        // (no pins like v_step's here: the B and rotation waves do not spill, and pinned they were 7 % slower)
     };
     // the moving column goes one lane round the quad: lane j takes over from lane (j + 1) & 3, whose position m - 1 is this lane's m
     auto shift = [&]() {
@@ -1124,8 +1083,127 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
         zn = h_true * h_true <= 1e-24 * fro2;
         ab = rotation_scaled(baa, bbb, bab, db * idA, dA * idb);
         rt[32 * to_buf + 4 * R + j] = ab;
-        zfl[32 * to_buf + 4 * R + j] = zn;
+        zfl[64 * to_buf + 4 * R + j] = zn;
         // (the rotation's cosine, for D, is made behind the hand-over's barrier: see update)
+    };
+    // ---- the steps for the pairs inside the groups: seat e of a group with seat e ^ X (X = 1, 2, 3 = rr's patterns 0, 1, 2), t = 0 layout ----
+    // new[s] = old[s] + coef[s] old[s ^ X] for columns, then for rows (coef = -alpha on a pair's first seat, +beta on its second).
+    // (delta1: which of two registers holds the partner's entry depends on the lane for X = 1 and 3; for X = 2 it is position + 2.)
+    auto update_inside = [&](auto x_tag) {
+        constexpr int X = decltype(x_tag)::value;
+        const int L = j ^ X;
+        if constexpr (MK) {   // D <- D cos: this lane's rotation belongs to its seat j (L > j) or 4 + j (L < j), the partner lane's to the other one
+            const double x1 = __builtin_fma(ab.x, ab.y, 1.0);   // 1 + tan^2
+            const double pc = rsqrt_nr(x1), pic = x1 * pc;
+            const double qc = rq::quad_perm<rq::quad_xor(X)>(pc), qic = rq::quad_perm<rq::quad_xor(X)>(pic);
+            const bool first = j < L;
+            dA *= first ? pc : qc;
+            idA *= first ? pic : qic;
+            dB *= first ? qc : pc;
+            idB *= first ? qic : pic;
+        }
+        const double cc0 = coef[64 * buf + 8 * C + j], cc1 = coef[64 * buf + 8 * C + 4 + j];
+        double cr[8];
+#pragma unroll
+        for (int pos = 0; pos < 8; ++pos) cr[pos] = coef[64 * buf + 8 * R + rowseat(pos)];
+        const int z0 = zfl[64 * buf + 8 * R + j], z1 = zfl[64 * buf + 8 * R + 4 + j];
+        // columns: the partner column sits in lane L, the same row at L's position (pos + j - L) & 3: the SENDER turns its column for its
+        // receiver (the lane it receives from), one DPP move per entry
+        {
+            const bool send1 = ((L - j) & 3) == 1;   // the receiver's (pos + delta): delta = (receiver - sender) & 3 = (L - j) & 3, 1 or 3 (X = 2: 2)
+            double n0[8], n1[8];
+#pragma unroll
+            for (int pos = 0; pos < 8; ++pos) {
+                const int h = pos & 4, m = pos & 3;
+                const double s0 = X == 2 ? c0[h + ((m + 2) & 3)] : rq::pick(send1, c0[h + ((m + 1) & 3)], c0[h + ((m + 3) & 3)]);
+                const double s1 = X == 2 ? c1[h + ((m + 2) & 3)] : rq::pick(send1, c1[h + ((m + 1) & 3)], c1[h + ((m + 3) & 3)]);
+                n0[pos] = __builtin_fma(cc0, rq::quad_perm<rq::quad_xor(X)>(s0), c0[pos]);
+                n1[pos] = __builtin_fma(cc1, rq::quad_perm<rq::quad_xor(X)>(s1), c1[pos]);
+            }
+#pragma unroll
+            for (int pos = 0; pos < 8; ++pos) {
+                c0[pos] = n0[pos];
+                c1[pos] = n1[pos];
+            }
+        }
+        // rows: row e = (j + pos) & 3 of a group with row e ^ X of the same group, at position ((e ^ X) - j) & 3
+        {
+            const bool up = (j & 1) == 0;   // even lanes take the first of the two candidate positions below
+            double n0[8], n1[8];
+#pragma unroll
+            for (int pos = 0; pos < 8; ++pos) {
+                const int h = pos & 4, m = pos & 3;
+                // X = 1: e even -> m + 1, e odd -> m + 3, e = (j + m) & 3: for even j that is m's parity, for odd j the opposite
+                // X = 3: (3 - 2 j - m) & 3: even j -> 3 - m, odd j -> (1 - m) & 3
+                const int pa = X == 1 ? ((m & 1) == 0 ? (m + 1) & 3 : (m + 3) & 3) : X == 2 ? (m + 2) & 3 : (3 - m) & 3;   // even j
+                const int pb = X == 1 ? ((m & 1) == 0 ? (m + 3) & 3 : (m + 1) & 3) : X == 2 ? (m + 2) & 3 : (5 - m) & 3;   // odd j
+                const double y0 = X == 2 ? c0[h + pa] : rq::pick(up, c0[h + pa], c0[h + pb]);
+                const double y1 = X == 2 ? c1[h + pa] : rq::pick(up, c1[h + pa], c1[h + pb]);
+                n0[pos] = __builtin_fma(cr[pos], y0, c0[pos]);
+                n1[pos] = __builtin_fma(cr[pos], y1, c1[pos]);
+            }
+#pragma unroll
+            for (int pos = 0; pos < 8; ++pos) {
+                c0[pos] = n0[pos];
+                c1[pos] = n1[pos];
+            }
+        }
+        // the rotated pairs themselves, once they are small: in this lane's columns the entry of the partner's row, position (L - j) & 3
+        {
+            const int pz = (L - j) & 3;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                c0[m] = (diag && z0 != 0 && m == pz) ? 0.0 : c0[m];
+                c1[4 + m] = (diag && z1 != 0 && m == pz) ? 0.0 : c1[4 + m];
+            }
+        }
+    };
+    // wave 0: the lane with the smaller index of a quad's lane pair (j, j ^ X) makes the rotation of the first group's pair (seats j, j ^ X),
+    // the other one the second group's (4 + (j ^ X), 4 + j); both publish the two seats' coefficients and flags
+    auto rotations_inside = [&](auto x_tag, int to_buf) {
+        constexpr int X = decltype(x_tag)::value;
+        const int L = j ^ X;
+        const bool first = j < L;
+        const int pm = (L - j) & 3;   // where the partner's row sits in this lane's columns
+        const double dg0 = c0[0], dg1 = c1[4];
+        const double other = rq::quad_perm<rq::quad_xor(X)>(first ? dg1 : dg0);   // the partner sends the diagonal entry this lane's pair needs
+        const double baa = first ? dg0 : other, bbb = first ? other : dg1;
+        const double e0 = X == 2 ? c0[2] : rq::pick(pm == 1, c0[1], c0[3]), e1 = X == 2 ? c1[6] : rq::pick(pm == 1, c1[5], c1[7]);
+        const double bab = first ? e0 : e1;
+        const double od = rq::quad_perm<rq::quad_xor(X)>(first ? dB : dA), oid = rq::quad_perm<rq::quad_xor(X)>(first ? idB : idA);
+        const double da = first ? dA : od, ida = first ? idA : oid, db = first ? od : dB, idb = first ? oid : idB;
+        const double h_true = fabs((bab + bab) * (da * db));
+        hmax = fmax(hmax, h_true);
+        zn = h_true * h_true <= 1e-24 * fro2;
+        ab = rotation_scaled(baa, bbb, bab, db * ida, da * idb);
+        const int sa = 8 * R + (first ? j : 4 + L), sb = 8 * R + (first ? L : 4 + j);   // the pair's first and second seat
+        coef[64 * to_buf + sa] = -ab.x;
+        coef[64 * to_buf + sb] = ab.y;
+        zfl[64 * to_buf + sa] = zn;
+        zfl[64 * to_buf + sb] = zn;
+    };
+    // V: every seat with its partner of the same group
+    auto v_inside = [&](auto x_tag) {
+        constexpr int X = decltype(x_tag)::value;
+        double cf[2][8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cf[0][q] = coef[64 * buf + 32 * W + q];
+#pragma unroll
+        for (int Gl = 0; Gl < 4; ++Gl) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (Gl + 1 < 4) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) cf[(Gl + 1) & 1][q] = coef[64 * buf + 32 * W + 8 * (Gl + 1) + q];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            double n[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) n[q] = __builtin_fma(cf[Gl & 1][q], v[8 * Gl + (q ^ X)], v[8 * Gl + q]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[8 * Gl + q] = n[q];
+        }
+#pragma unroll
+        for (int s = 0; s < 32; ++s) asm volatile("" : "+v"(v[s]));   // (see v_step)
     };
     // V <- V J of the cross step T: the rotations are broadcast reads, fetched a super-group ahead of the arithmetic
     auto v_step = [&](auto t_tag) {
@@ -1154,12 +1232,6 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
         // the steps' rotations alive until then -- 200 spilled registers)
 #pragma unroll
         for (int s = 0; s < 32; ++s) asm volatile("" : "+v"(v[s]));
-    };
-    // V: a phase change inside a round permutes the seats of every super-group
-    auto v_permute = [&](auto ph0_tag, auto ph1_tag) {
-        constexpr int PH0 = decltype(ph0_tag)::value, PH1 = decltype(ph1_tag)::value;
-#pragma unroll
-        for (int Gl = 0; Gl < 4; ++Gl) rq::permute_seats<PH0, PH1>(&v[8 * Gl], std::make_integer_sequence<int, 8>{});
     };
     // V: the end of a round (rq::shift_groups): the group that changes waves goes through LDS
     auto v_shift_out = [&]() {
@@ -1215,17 +1287,16 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
 #endif
         return off <= 1e-36 * total;   // FORM 1's stop rule
     };
-    // Everybody moves to the next seating (TYPE: rq::reseat_source; TEND: the place of the moving column after the segment's last step):
-    // the B waves stage their entries by physical seat, wave 0 its seats' (d, 1/d); behind the barrier everybody collects what sits on
-    // its seats next (wave 0: its new copies), a stop test runs if the round's rotations were all small, wave 0 makes the first
-    // rotations of the new seating.  Returns whether the iteration has converged.
-    auto reseat = [&](auto type_tag, auto tend_tag) -> bool {
-        constexpr int TYPE = decltype(type_tag)::value, TEND = decltype(tend_tag)::value;
-        constexpr bool round_end = TYPE <= 1;
+    // A round's end: everybody moves to the next seating.  The B waves stage their entries (after one more turn of the moving column: the
+    // t = 0 layout), wave 0 its seats' (d, 1/d); behind the barrier everybody collects what sits on its seats next (wave 0: its new copies),
+    // a stop test runs if the round's rotations were all small, wave 0 makes the first rotations of the new round (NEXT_INSIDE: round 0
+    // begins with the pairs inside the groups).  Returns whether the iteration has converged.
+    auto reseat = [&](auto next_inside_tag) -> bool {
+        constexpr bool NEXT_INSIDE = decltype(next_inside_tag)::value;
         bool quiet = false;
         const unsigned long long t0 = EIG_STEP_CLOCK();   // (wave 0's re-seatings as a whole -> the "V update" slot of the stamps)
         if constexpr (BW) {
-            if constexpr (TEND != 0) shift();   // (TEND = 3: once more round the quad, the moving column is 4 + j again)
+            shift();   // (once more round the quad: the moving column is 4 + j again)
 #pragma unroll
             for (int pos = 0; pos < 8; ++pos) {
                 S[(2 * pos) * 256 + (tid - 64)] = c0[pos];
@@ -1234,80 +1305,42 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
         } else if constexpr (MK) {
             *reinterpret_cast<double2_loc*>(&dtab[2 * (8 * R + j)]) = double2_loc{dA, idA};
             *reinterpret_cast<double2_loc*>(&dtab[2 * (8 * R + 4 + j)]) = double2_loc{dB, idB};
-            if constexpr (round_end) {
-                // the stop test proper is only worth running once every rotation of a round stayed below 1e-12 |B|_F (see FORM 1)
-                quiet = __builtin_amdgcn_ballot_w64(hmax * hmax > 1e-24 * fro2) == 0ull;
-                hmax = 0.0;
-                if (lane == 0) tflag = quiet ? 1 : 0;
-            }
+            // the stop test proper is only worth running once every rotation of a round stayed below 1e-12 |B|_F (see FORM 1)
+            quiet = __builtin_amdgcn_ballot_w64(hmax * hmax > 1e-24 * fro2) == 0ull;
+            hmax = 0.0;
+            if (lane == 0) tflag = quiet ? 1 : 0;
         } else {
-            if constexpr (round_end) v_shift_out();
+            v_shift_out();
         }
         const unsigned long long q1 = EIG_STEP_CLOCK();
         __syncthreads();
         const unsigned long long q2 = EIG_STEP_CLOCK();
-        if constexpr (!VW) {
-            int seat0, seat1;
-            if constexpr (TYPE == 0) {
-                seat0 = dseat0[0];
-                seat1 = dseat0[1];
-                if constexpr (MK) {   // what the next rotation is made of first (LDS returns in order): D, then B[a][a], B[a][b], B[b][b]
-                    const double2_loc e0 = *reinterpret_cast<const double2_loc*>(&dtab[2 * seat0]), e1 = *reinterpret_cast<const double2_loc*>(&dtab[2 * seat1]);
-                    dA = e0.x;
-                    idA = e0.y;
-                    dB = e1.x;
-                    idB = e1.y;
-                    c0[0] = S[smap0[0][0]];
-                    c1[0] = S[smap0[0][1]];
-                    c1[4] = S[smap0[1][1]];
-#if PCSF_F2_PIN
-                    asm volatile("" : "+v"(dA), "+v"(idA), "+v"(dB), "+v"(idB), "+v"(c0[0]), "+v"(c1[0]), "+v"(c1[4]));
-#endif
+        if constexpr (MK) {   // what the next rotation is made of first (LDS returns in order): D, then B[a][a], B[a][b], B[b][b]
+            const double2_loc e0 = *reinterpret_cast<const double2_loc*>(&dtab[2 * dseat0[0]]), e1 = *reinterpret_cast<const double2_loc*>(&dtab[2 * dseat0[1]]);
+            dA = e0.x;
+            idA = e0.y;
+            dB = e1.x;
+            idB = e1.y;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    c0[4 * x + m] = S[smap0[x][0] + 512 * m];
+                    c1[4 * x + m] = S[smap0[x][1] + 512 * m];
                 }
-#if PCSF_F2_SLEEP
-                if constexpr (BW) __builtin_amdgcn_s_sleep(PCSF_F2_SLEEP);   // (wave 0's loads go first: the step waits for its rotations, not for these)
-#endif
-                if constexpr (MK) {
+        } else if constexpr (BW) {
+            // sixteen ds_read_b64 as written: the compiler pairs loads a constant apart into ds_read2st64_b64, which the LDS serves
+            // at half the rate (MI355X_MICROARCH.md: 8 cycles against 2 x 2) -- with four waves collecting at once, 160 cycles a round
 #pragma unroll
-                    for (int x = 0; x < 2; ++x)
+            for (int x = 0; x < 2; ++x)
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            if (m != 0 || x == 1) c0[4 * x + m] = S[smap0[x][0] + 512 * m];
-                            if (m != 0) c1[4 * x + m] = S[smap0[x][1] + 512 * m];
-                        }
-                } else {
-                    // sixteen ds_read_b64 as written: the compiler pairs loads a constant apart into ds_read2st64_b64, which the LDS serves
-                    // at half the rate (MI355X_MICROARCH.md: 8 cycles against 2 x 2) -- with four waves collecting at once, 160 cycles a round
-#pragma unroll
-                    for (int x = 0; x < 2; ++x)
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(c0[4 * x + m]) : "v"(8 * smap0[x][0] + lds_base_S), "n"(4096 * m));
-                            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(c1[4 * x + m]) : "v"(8 * smap0[x][1] + lds_base_S), "n"(4096 * m));
-                        }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int m = 0; m < 4; ++m) {
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(c0[4 * x + m]) : "v"(8 * smap0[x][0] + lds_base_S), "n"(4096 * m));
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(c1[4 * x + m]) : "v"(8 * smap0[x][1] + lds_base_S), "n"(4096 * m));
                 }
-            } else {
-                seat0 = seat_tab[64 * TYPE + 8 * C + j];
-                seat1 = seat_tab[64 * TYPE + 8 * C + 4 + j];
-#pragma unroll
-                for (int pos = 0; pos < 8; ++pos) {
-                    const int row_src = seat_tab[64 * TYPE + 8 * R + rowseat(pos)];
-                    c0[pos] = S[staged(row_src, seat0)];
-                    c1[pos] = S[staged(row_src, seat1)];
-                }
-            }
-            if constexpr (MK && TYPE != 0) {   // (C = R: the lane's two seats are its two columns)
-                const double2_loc e0 = *reinterpret_cast<const double2_loc*>(&dtab[2 * seat0]), e1 = *reinterpret_cast<const double2_loc*>(&dtab[2 * seat1]);
-                dA = e0.x;
-                idA = e0.y;
-                dB = e1.x;
-                idB = e1.y;
-            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else {
-            if constexpr (round_end) v_shift_in();
-            if constexpr (TYPE == 1) v_permute(integral_constant<int, 3>{}, integral_constant<int, 0>{});
-            if constexpr (TYPE >= 2) v_permute(integral_constant<int, TYPE - 2>{}, integral_constant<int, TYPE - 1>{});
+            v_shift_in();
         }
         unsigned long long q3 = 0;
         if constexpr (MK && PCSF_F2_RESEAT_STAMPS != 0) {
@@ -1316,12 +1349,13 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
                 q3 = eig_clock();
             }
         }
-        if constexpr (round_end) {
-            if (MK ? quiet : tflag != 0) {   // (wave 0 knows without the trip through LDS)
-                if (stop_test()) return true;
-            }
+        if (MK ? quiet : tflag != 0) {   // (wave 0 knows without the trip through LDS)
+            if (stop_test()) return true;
         }
-        if constexpr (MK) rotations(integral_constant<int, 0>{}, buf ^ 1);
+        if constexpr (MK) {
+            if constexpr (NEXT_INSIDE) rotations_inside(integral_constant<int, 1>{}, buf ^ 1);
+            else rotations(integral_constant<int, 0>{}, buf ^ 1);
+        }
         __syncthreads();
         buf ^= 1;
         if constexpr (MK) {
@@ -1365,30 +1399,49 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
             }
         }
     };
+    // a step for the pairs inside the groups (no turn of the moving column: these steps and the first cross step share the t = 0 layout)
+    auto step_inside = [&](auto x_tag) {
+        constexpr int X = decltype(x_tag)::value;
+        const unsigned long long t0 = EIG_STEP_CLOCK();
+        if constexpr (VW) v_inside(x_tag);
+        else update_inside(x_tag);
+        const unsigned long long t1 = EIG_STEP_CLOCK();
+        if constexpr (MK) {
+            if constexpr (X < 3) rotations_inside(integral_constant<int, X + 1>{}, buf ^ 1);
+            else rotations(integral_constant<int, 0>{}, buf ^ 1);
+        }
+        const unsigned long long t2 = EIG_STEP_CLOCK();
+        __syncthreads();
+        buf ^= 1;
+        if constexpr (MK) {
+            if (EIG_STEP_STAMPS && !PCSF_F2_RESEAT_STAMPS && stamping) {
+                acc_a += t1 - t0;
+                acc_rot += t2 - t1;
+                acc_b += eig_clock() - t2;
+            }
+        }
+    };
     int r = 0;
     bool converged = stop_test();   // (also |B|_F^2 for the rotations' zero flags)
     if (!converged) {
-        if constexpr (MK) rotations(integral_constant<int, 0>{}, 0);
+        if constexpr (MK) rotations_inside(integral_constant<int, 1>{}, 0);
         __syncthreads();
         using T0 = integral_constant<int, 0>;
         using T1 = integral_constant<int, 1>;
         using T2 = integral_constant<int, 2>;
         using T3 = integral_constant<int, 3>;
         for (int round = 0; round < 60 * 15; ++round) {
-            if (r == 0) {   // the pairs inside the groups: three phases of one step each
+            if (r == 0) {   // the pairs inside the groups
                 if constexpr (MK) n_sweeps += 1;
-                step(T0{}, std::true_type{});
-                reseat(integral_constant<int, 2>{}, T0{});
-                step(T0{}, std::true_type{});
-                reseat(integral_constant<int, 3>{}, T0{});
-                step(T0{}, std::true_type{});
-                reseat(integral_constant<int, 4>{}, T0{});
+                step_inside(T1{});
+                step_inside(T2{});
+                step_inside(T3{});
             }
             step(T0{}, std::false_type{});
             step(T1{}, std::false_type{});
             step(T2{}, std::false_type{});
             step(T3{}, std::true_type{});
-            const bool done = r == 14 ? reseat(integral_constant<int, 1>{}, T3{}) : reseat(integral_constant<int, 0>{}, T3{});
+            const bool done = r == 14 ? reseat(std::true_type{}) : reseat(std::false_type{});
             if constexpr (MK) n_steps += r == 0 ? 7 : 4;
             r = r == 14 ? 0 : r + 1;
             if (done) {
@@ -1400,30 +1453,21 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
     if (!converged && tid == 0) p.fail[job.table] = 1u;   // rounds used up (a NaN makes the stop test false for ever): flagged, see FORM 1
     __syncthreads();   // nobody reads the staging buffers any more
     // eigenvalues and (scaled) eigenvectors back into the canonical matrices, in the seating the iteration stopped in
-    const int ph = r == 0 ? 0 : 3;
     if constexpr (MK) {
         if (lane < 32) {
-            const int ca = rq::canon(r, ph, 8 * R + j), cb = rq::canon(r, ph, 8 * R + 4 + j);
+            const int ca = rq::canon(r, 8 * R + j), cb = rq::canon(r, 8 * R + 4 + j);
             A[ca * LD + ca] = c0[0] * (dA * dA);
             A[cb * LD + cb] = c1[4] * (dB * dB);
         }
     } else if constexpr (VW) {
 #pragma unroll
-        for (int s = 0; s < 32; ++s) V[lane * LD + rq::canon(r, ph, 32 * W + s)] = v[s];
+        for (int s = 0; s < 32; ++s) V[lane * LD + rq::canon(r, 32 * W + s)] = v[s];
     }
     };   // body
-#ifdef PCSF_F2_ONLY_ROLE
-    body(integral_constant<int, PCSF_F2_ONLY_ROLE>{});
-#else
-    if (wave == 0) {
-        body(integral_constant<int, 0>{});
-#if PCSF_F2_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-    } else if (wave <= 4) body(integral_constant<int, 1>{});
+    if (wave == 0) body(integral_constant<int, 0>{});
+    else if (wave <= 4) body(integral_constant<int, 1>{});
     else if (wave == 5) body(integral_constant<int, 2>{});
     else body(integral_constant<int, 3>{});
-#endif
     __syncthreads();
     {   // V = Vs D: the columns of Vs are orthogonal by construction (every step an orthogonal transformation times a diagonal one), so D is
         // their norms' reciprocals -- taken from the columns themselves rather than from the tracked products of cosines (~500 factors each)
@@ -1568,30 +1612,43 @@ void eigen_schedule_for_tests(int* pairs /* [63][32][2] */, int* located /* [15]
 }
 
 
-// tests: FORM 2's bookkeeping replayed on indices -- the 63 x 32 pairs of one sweep in step order as the kernel's seats give them, and
-// whether every re-seating (the staged matrix's look-up table for B, the register moves for V) lands where rq::canon says: returns the
-// number of disagreements (0), over two sweeps.
+// tests: FORM 2's bookkeeping replayed on indices -- the 63 x 32 pairs of one sweep in step order as the kernel's seats give them (inside
+// steps: seat e of a group with seat e ^ X; cross steps: seat k with seat 4 + ((k + t) & 3)), and whether every round's end (the staged
+// look-up of B: rr::shift_source as smap0 uses it; the register moves and the four-column exchange of V) lands where rq::canon says:
+// returns the number of disagreements (0), over two sweeps.
 int eigen_schedule_quads_for_tests(int* pairs /* [63][32][2] */)
 {
     int arr[64], vv[2][32], bad = 0, step = 0;
-    for (int s = 0; s < 64; ++s) arr[s] = vv[s >> 5][s & 31] = rq::canon(0, 0, s);
-    auto emit = [&](int t, bool record) {
-        for (int G = 0; G < 8; ++G)
-            for (int k = 0; k < 4; ++k) {
-                const int a = 8 * G + k, b = 8 * G + 4 + ((k + t) & 3);
-                if (vv[a >> 5][a & 31] != arr[a] || vv[b >> 5][b & 31] != arr[b]) ++bad;
-                if (record) {
-                    pairs[(step * 32 + G * 4 + k) * 2 + 0] = arr[a];
-                    pairs[(step * 32 + G * 4 + k) * 2 + 1] = arr[b];
-                }
-            }
-        if (record) ++step;
+    for (int s = 0; s < 64; ++s) arr[s] = vv[s >> 5][s & 31] = rq::canon(0, s);
+    auto emit = [&](int a, int b, bool record, int slot) {
+        if (vv[a >> 5][a & 31] != arr[a] || vv[b >> 5][b & 31] != arr[b]) ++bad;
+        if (record) {
+            pairs[(step * 32 + slot) * 2 + 0] = arr[a];
+            pairs[(step * 32 + slot) * 2 + 1] = arr[b];
+        }
     };
-    auto reseat = [&](int type, int r1, int ph1) {
-        int next[64];
-        for (int s = 0; s < 64; ++s) next[s] = arr[rq::reseat_source(type, s)];
-        for (int s = 0; s < 64; ++s) arr[s] = next[s];
-        if (type <= 1) {
+    for (int sweep = 0; sweep < 2; ++sweep)
+        for (int r = 0; r < 15; ++r) {
+            if (r == 0)
+                for (int X = 1; X <= 3; ++X) {
+                    int slot = 0;
+                    for (int G = 0; G < 8; ++G)
+                        for (int q = 0; q < 8; ++q)
+                            if (q < (q ^ X)) emit(8 * G + q, 8 * G + (q ^ X), sweep == 0, slot++);
+                    if (sweep == 0) ++step;
+                }
+            for (int t = 0; t < 4; ++t) {
+                for (int G = 0; G < 8; ++G)
+                    for (int k = 0; k < 4; ++k) emit(8 * G + k, 8 * G + 4 + ((k + t) & 3), sweep == 0, 4 * G + k);
+                if (sweep == 0) ++step;
+            }
+            // the round's end
+            int next[64];
+            for (int s = 0; s < 64; ++s) {
+                const int src = rr::shift_source(s >> 3, (s >> 2) & 1);
+                next[s] = arr[8 * (src & 7) + 4 * (src >> 3) + (s & 3)];
+            }
+            for (int s = 0; s < 64; ++s) arr[s] = next[s];
             int out0[4], out1[4];
             for (int q = 0; q < 4; ++q) {
                 out0[q] = vv[0][rq::leaving_group<0>() + q];
@@ -1599,27 +1656,9 @@ int eigen_schedule_quads_for_tests(int* pairs /* [63][32][2] */)
             }
             rq::shift_groups<0>(vv[0], out1);
             rq::shift_groups<1>(vv[1], out0);
-        }
-        for (int w = 0; w < 2; ++w)
-            for (int Gl = 0; Gl < 4; ++Gl) {
-                if (type == 1) rq::permute_seats<3, 0>(&vv[w][8 * Gl], std::make_integer_sequence<int, 8>{});
-                if (type == 2) rq::permute_seats<0, 1>(&vv[w][8 * Gl], std::make_integer_sequence<int, 8>{});
-                if (type == 3) rq::permute_seats<1, 2>(&vv[w][8 * Gl], std::make_integer_sequence<int, 8>{});
-                if (type == 4) rq::permute_seats<2, 3>(&vv[w][8 * Gl], std::make_integer_sequence<int, 8>{});
-            }
-        for (int s = 0; s < 64; ++s)
-            if (arr[s] != rq::canon(r1, ph1, s) || vv[s >> 5][s & 31] != arr[s]) ++bad;
-    };
-    for (int sweep = 0; sweep < 2; ++sweep)
-        for (int r = 0; r < 15; ++r) {
-            if (r == 0)
-                for (int ph = 0; ph < 3; ++ph) {
-                    emit(0, sweep == 0);
-                    reseat(2 + ph, 0, ph + 1);
-                }
-            for (int t = 0; t < 4; ++t) emit(t, sweep == 0);
-            if (r == 14) reseat(1, 0, 0);
-            else reseat(0, r + 1, 3);
+            const int r1 = r == 14 ? 0 : r + 1;
+            for (int s = 0; s < 64; ++s)
+                if (arr[s] != rq::canon(r1, s) || vv[s >> 5][s & 31] != arr[s]) ++bad;
         }
     return bad;
 }
