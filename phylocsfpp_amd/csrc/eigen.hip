@@ -973,14 +973,16 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
     double* S = A;
     const int lds_base_S = static_cast<int>(reinterpret_cast<size_t>(S));   // (LDS byte address, for the hand-written loads of a round's end)
     double2_loc* xch = reinterpret_cast<double2_loc*>(V);   // [V wave][row][2]: the group of four columns that changes waves at a round's end
-    // Staging for a re-seating is LANE-MAJOR -- the B lane k stores position pos of its column slot at (2 pos + slot) * 256 + k, always in
-    // the t = 0 layout (moving column = 4 + j) -- so stores and loads of a round's end are free of bank conflicts (consecutive lanes,
-    // consecutive double-words; a load's 32-lane half covers the eight blocks of a block row) and all addresses are one register plus a
-    // constant.  (Row-major by seat, the first version: 16 lane-dependent addresses, seven of them spilled to scratch and reloaded behind
-    // every re-seating's barrier, and the blocks' 8 R' and 8 C' left one bit each in the bank number.)
-    // A round's end (type 0) keeps the within-group index: the new half x of the rows comes from the half h'x of super-group R'x, the new
-    // column slot y from slot g'y of super-group C'y, same lane j of the quad, same positions: smap0[x][y] + 512 m.
-    int smap0[2][2] = {{0, 0}, {0, 0}};
+    // Staging for a round's end is LANE-MAJOR -- the B lane k stores position pos of its column slot at (2 pos + slot) * 256 + k, as it stands
+    // after the round's last step (t = 3: the moving column of lane j is 4 + ((j + 3) & 3)) -- so stores and loads are free of bank conflicts
+    // (consecutive lanes, consecutive double-words; a load's 32-lane half covers the eight blocks of a block row) and all addresses are a
+    // register plus a constant.  (Row-major by seat, the first version: 16 lane-dependent addresses, seven of them spilled to scratch and
+    // reloaded behind every barrier, and the blocks' 8 R' and 8 C' left one bit each in the bank number.)
+    // A round's end keeps the within-group index: the new half x of the rows comes from the half h'x of super-group R'x, the new column
+    // slot y from the group g'y of super-group C'y.  A first group's column e is column slot 0 of lane e, same positions.  A second group's
+    // column e was the moving column of lane (e + 1) & 3, whose position m - 1 is this lane's m: the lane's position 0 comes from smapP, the
+    // positions 1..3 from smapQ + 512 (m - 1) -- two registers per (x, y) instead of a turn of the moving column before the staging.
+    int smapP[2][2] = {{0, 0}, {0, 0}}, smapQ[2][2] = {{0, 0}, {0, 0}};
     int dseat0[2] = {0, 0};   // wave 0: where the lane's two seats' (d, 1/d) come from
     if constexpr (!VW) {
 #pragma unroll
@@ -988,8 +990,11 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
 #pragma unroll
             for (int y = 0; y < 2; ++y) {
                 const int sr = rr::shift_source(R, x), sc = rr::shift_source(C, y);
-                smap0[x][y] = 2048 * (sr >> 3) + 32 * (sr & 7) + 256 * (sc >> 3) + 4 * (sc & 7) + j;
-                if (x == 0) dseat0[y] = 8 * (sc & 7) + 4 * (sc >> 3) + j;
+                const int second = sc >> 3;
+                const int base = 2048 * (sr >> 3) + 32 * (sr & 7) + 256 * second + 4 * (sc & 7) + (second ? (j + 1) & 3 : j);
+                smapP[x][y] = second ? base + 1536 : base;
+                smapQ[x][y] = second ? base : base + 512;
+                if (x == 0) dseat0[y] = 8 * (sc & 7) + 4 * second + j;
             }
     }
     double dA = 1.0, idA = 1.0, dB = 1.0, idB = 1.0;   // wave 0: (d, 1/d) of the seats j and 4 + j of super-group R
@@ -1287,8 +1292,7 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
 #endif
         return off <= 1e-36 * total;   // FORM 1's stop rule
     };
-    // A round's end: everybody moves to the next seating.  The B waves stage their entries (after one more turn of the moving column: the
-    // t = 0 layout), wave 0 its seats' (d, 1/d); behind the barrier everybody collects what sits on its seats next (wave 0: its new copies),
+    // A round's end: everybody moves to the next seating.  The B waves stage their entries, wave 0 its seats' (d, 1/d); behind the barrier everybody collects what sits on its seats next (wave 0: its new copies),
     // a stop test runs if the round's rotations were all small, wave 0 makes the first rotations of the new round (NEXT_INSIDE: round 0
     // begins with the pairs inside the groups).  Returns whether the iteration has converged.
     auto reseat = [&](auto next_inside_tag) -> bool {
@@ -1296,7 +1300,6 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
         bool quiet = false;
         const unsigned long long t0 = EIG_STEP_CLOCK();   // (wave 0's re-seatings as a whole -> the "V update" slot of the stamps)
         if constexpr (BW) {
-            shift();   // (once more round the quad: the moving column is 4 + j again)
 #pragma unroll
             for (int pos = 0; pos < 8; ++pos) {
                 S[(2 * pos) * 256 + (tid - 64)] = c0[pos];
@@ -1325,8 +1328,8 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int x = 0; x < 2; ++x) {
-                    c0[4 * x + m] = S[smap0[x][0] + 512 * m];
-                    c1[4 * x + m] = S[smap0[x][1] + 512 * m];
+                    c0[4 * x + m] = m == 0 ? S[smapP[x][0]] : S[smapQ[x][0] + 512 * (m - 1)];
+                    c1[4 * x + m] = m == 0 ? S[smapP[x][1]] : S[smapQ[x][1] + 512 * (m - 1)];
                 }
         } else if constexpr (BW) {
             // sixteen ds_read_b64 as written: the compiler pairs loads a constant apart into ds_read2st64_b64, which the LDS serves
@@ -1335,8 +1338,8 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
             for (int x = 0; x < 2; ++x)
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(c0[4 * x + m]) : "v"(8 * smap0[x][0] + lds_base_S), "n"(4096 * m));
-                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(c1[4 * x + m]) : "v"(8 * smap0[x][1] + lds_base_S), "n"(4096 * m));
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(c0[4 * x + m]) : "v"(8 * (m == 0 ? smapP[x][0] : smapQ[x][0]) + lds_base_S), "n"(m == 0 ? 0 : 4096 * (m - 1)));
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(c1[4 * x + m]) : "v"(8 * (m == 0 ? smapP[x][1] : smapQ[x][1]) + lds_base_S), "n"(m == 0 ? 0 : 4096 * (m - 1)));
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else {
@@ -1614,7 +1617,7 @@ void eigen_schedule_for_tests(int* pairs /* [63][32][2] */, int* located /* [15]
 
 // tests: FORM 2's bookkeeping replayed on indices -- the 63 x 32 pairs of one sweep in step order as the kernel's seats give them (inside
 // steps: seat e of a group with seat e ^ X; cross steps: seat k with seat 4 + ((k + t) & 3)), and whether every round's end (the staged
-// look-up of B: rr::shift_source as smap0 uses it; the register moves and the four-column exchange of V) lands where rq::canon says:
+// look-up of B: rr::shift_source as smapP / smapQ use it; the register moves and the four-column exchange of V) lands where rq::canon says:
 // returns the number of disagreements (0), over two sweeps.
 int eigen_schedule_quads_for_tests(int* pairs /* [63][32][2] */)
 {
