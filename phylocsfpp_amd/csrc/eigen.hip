@@ -231,10 +231,25 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
     __shared__ double norm_s;
     __shared__ int flag;
 
-    const EigenJob job = p.jobs[blockIdx.x];
-    const double* qs = job.qs;
+    // (the job's fields are read where they are used -- uniform scalar loads; its twelve settings go through LDS: a local copy of the
+    // struct is indexed at run time by f3x4_weight and lives in scratch memory)
+    const EigenJob& job_ref = p.jobs[blockIdx.x];
+    struct { uint32_t eig, table; int32_t warm; } job{job_ref.eig, job_ref.table, job_ref.warm};
+    __shared__ double qs_s[12];
+    const double* qs = qs_s;
     const int tid = threadIdx.x;
+    if (tid < 12) qs_s[tid] = job_ref.qs[tid];
     if (tid == 0) flag = 0;
+    // a warm start's eigenbasis is on its way from HBM while the rate matrix is built (it used to be fetched behind it: 7,600 cycles)
+    constexpr int V0_PER_THREAD = (4096 + NT - 1) / NT;
+    const bool warm_start = job.warm >= 0 && p.eig_basis != nullptr;
+    double v0_pre[V0_PER_THREAD];
+    if (warm_start) {
+        const double* __restrict__ V0 = p.eig_basis + static_cast<size_t>(job.warm) * 4096;
+#pragma unroll
+        for (int k = 0; k < V0_PER_THREAD; ++k) v0_pre[k] = tid + k * NT < 4096 ? V0[tid + k * NT] : 0.0;
+    }
+    __syncthreads();
     if (tid < 64) {
         const double stop_mass = f3x4_weight(qs, 48) + f3x4_weight(qs, 50) + f3x4_weight(qs, 56);  // TAA, TAG, TGA
         const double denom = 1.0 - ((1.0 - qs[2]) * stop_mass);
@@ -309,9 +324,12 @@ __global__ __launch_bounds__(FORM == 1 ? 128 : FORM == 2 ? 448 : 256, FORM == 2 
     // this one.  B <- V0^T B V0 (two 64^3 products, each thread 16 entries), V <- V0, and the sweeps below finish the
     // job in 2-4 rounds instead of ~9.  V0 is exactly as orthogonal as the iteration left it, so the result is an
     // eigen-decomposition of B to the same accuracy as a cold start.
-    if (job.warm >= 0 && p.eig_basis) {
-        const double* __restrict__ V0 = p.eig_basis + static_cast<size_t>(job.warm) * 4096;
-        for (int idx = tid; idx < 4096; idx += NT) V[(idx >> 6) * LD + (idx & 63)] = V0[idx];
+    if (warm_start) {
+#pragma unroll
+        for (int k = 0; k < V0_PER_THREAD; ++k) {
+            const int idx = tid + k * NT;
+            if (idx < 4096) V[(idx >> 6) * LD + (idx & 63)] = v0_pre[k];
+        }
         __syncthreads();
     EIG_PHASE("V0 from HBM");
         // Both 64^3 products on the matrix cores (v_mfma_f64_16x16x4_f64: A operand lane (s, g) = A[s][g], B operand = B[g][s], result
