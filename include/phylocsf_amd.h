@@ -286,9 +286,10 @@ int pcsf_debug_program_facts(int32_t n_nodes, const int16_t *child1, const int16
  * pairs[63][32][2]: the index pairs every step of one sweep rotates; located[15][16]: where each group of four indices
  * sits in each round (super-group | half << 3).  For tests/test_schedule.py: every pair exactly once, disjoint per step. */
 void pcsf_debug_eigen_schedule(int32_t *pairs, int32_t *located);
-/* host-only: the seven-wave form of the same kernel (PCSF_EIGEN_FORM=2) keeps the schedule on physical seats that are re-seated through a
- * look-up table (B) and register moves (V); this replays both on indices over two sweeps -- pairs[63][32][2] as the seats give them --
- * and returns the number of places where a re-seating and the seat -> index map disagree (0). */
+/* host-only: the seven-wave form of the same kernel (the default; PCSF_EIGEN_FORM=2) keeps the schedule on the seats of quads of lanes: a round's
+ * end re-seats B through a staged look-up (rr::shift_source) and V by register moves and a four-column exchange.  This replays both on indices over
+ * two sweeps -- pairs[63][32][2] as the seats give them (inside steps: seat e with e ^ X; cross steps: seat k with 4 + ((k + t) & 3)) -- and returns
+ * the number of places where a round's end and the seat -> index map disagree (0). */
 int pcsf_debug_eigen_schedule_quads(int32_t *pairs);
 /* milliseconds spent in the pruning kernel by the last *_fixed / *_fixed_dev call that was
  * timed; pcsf_set_timing(ctx,1) brackets each launch with HIP events ON THE LAUNCH STREAM. */
