@@ -182,6 +182,38 @@ size_t pcsf_wig_text_estimate(size_t n_columns, size_t n_alignments);
  * memory from pcsf_host_alloc_on keeps the copy off the host threads); a file without text may have dst[f] = NULL */
 int pcsf_fetch_wig_text(pcsf_ctx *ctx, char *const *dst);
 
+/* ---- build-tracks as one process per GPU: the output wig stream gathered over RCCL --------------------------
+ * The reference runs its byte-range jobs in ONE parallel loop, every job writing files of its own, and then merges the jobs' files in
+ * job order (src/phylocsf++build_tracks.hpp:88 "#pragma omp parallel for", :93-124 "PhyloCSFpower.wig.<job_id>" ...,
+ * merge_job_output_files :27-53, called :246-259).  With one process ("rank") per GPU the jobs' ranges of the file go to the ranks in
+ * rank order, a rank's text stays in its GPU's memory (pcsf_wig_retain_*), and ONE grouped send/receive over RCCL (xGMI between the
+ * GPUs of a node) brings every rank's text to the root's GPU, where the root copies it down file by file, rank by rank -- the merge.
+ * librccl.so is loaded when pcsf_comm_unique_id / pcsf_comm_create is first called (a process that never calls them does not map it).
+ *
+ * pcsf_comm_unique_id: rank 0 makes the 128-byte identifier (ncclGetUniqueId) and hands it to the other processes out of band (a file,
+ * a pipe).  pcsf_comm_create: collective over the `world` processes, each with a context on a GPU of its own (ncclCommInitRank on the
+ * context's device).  One communicator per context; pcsf_destroy releases it. */
+#define PCSF_COMM_ID_BYTES 128
+int pcsf_comm_unique_id(void *id);
+int pcsf_comm_create(pcsf_ctx *ctx, int rank, int world, const void *id);
+int pcsf_comm_destroy(pcsf_ctx *ctx);
+/* Keeps the text of this context's LAST pcsf_score_alignments_6frames_wig call on the device (a device-to-device copy into the
+ * context's arena) under the caller's key `order`; pcsf_wig_retain_host adds text formatted on the host the same way (text[f] may be
+ * NULL where bytes[f] is 0).  The gather sends a context's kept texts in ascending `order`, whatever order they were kept in.
+ * pcsf_wig_retained_bytes: bytes kept per file so far.  pcsf_wig_retain_reset drops them (the gather does that itself). */
+int pcsf_wig_retain_last(pcsf_ctx *ctx, uint64_t order);
+int pcsf_wig_retain_host(pcsf_ctx *ctx, uint64_t order, const char *const *text, const uint64_t *bytes);
+int pcsf_wig_retained_bytes(pcsf_ctx *ctx, uint64_t *bytes /* [7] */);
+int pcsf_wig_retain_reset(pcsf_ctx *ctx);
+/* Collective.  Every rank but the root -- and the root too if include_root is set (a rehearsal on one GPU: the root's text then
+ * travels through RCCL to itself) -- sends what it kept: its seven files' texts, each file's kept pieces joined in `order`.  An
+ * all-gather of the 7 sizes per rank first (bytes[world][7] is filled on every rank), then one ncclSend per sender and one ncclRecv per
+ * sender on the root inside one group.  Afterwards the root's device holds every sender's text and pcsf_comm_fetch_gathered copies the
+ * text of `file` sent by `rank` to dst (bytes[rank][file] bytes; page-locked memory keeps the copy off the host threads).  The kept
+ * texts of the calling context are dropped. */
+int pcsf_comm_gather_wig(pcsf_ctx *ctx, int root, int include_root, uint64_t *bytes);
+int pcsf_comm_fetch_gathered(pcsf_ctx *ctx, int rank, int file, char *dst);
+
 /* ---- the smoothing pass of build-tracks (--output-phylo / --output-regions) --------------------------------
  * hmm::state_posterior_probabilities and the forward half of get_best_path_by_viterbi (src/create_tracks.hpp:25-159,
  * called per run of a raw track by process_scores, src/create_tracks.hpp:226-314) for a batch of runs at once.

@@ -87,11 +87,79 @@ private:
     std::unique_ptr<po_model> model_;
 };
 
+// --ranks on the CPU: the ranks' text meets in files of the launcher's directory (the product's gather is RCCL between GPUs,
+// phylocsfpp_amd/host/backend_hip.hpp).  What the tests pin with it: the byte ranges of the ranks, the order keys of the batches and the
+// order of the merge -- the driver's half of the multi-process mode, which is the same code over either gather.
+class FileGather : public pcsf_host::RankGather {
+public:
+    FileGather(int rank, int world, const std::string& dir) : rank_(rank), world_(world), dir_(dir) {}
+    int rank() const override { return rank_; }
+    int world() const override { return world_; }
+    void begin() override
+    {
+        kept_.clear();
+        ++round_;
+    }
+    void keep_backend_text(pcsf_host::ScoringBackend&, uint64_t) override { throw std::runtime_error("FileGather: the oracle backend formats nothing"); }
+    void keep_host_text(uint64_t order, const char* const* text, const uint64_t* bytes) override
+    {
+        std::lock_guard<std::mutex> g(lock_);
+        Kept k;
+        k.order = order;
+        for (int f = 0; f < 7; ++f) k.text[f].assign(text[f] ? text[f] : "", static_cast<size_t>(bytes[f]));
+        kept_.push_back(std::move(k));
+    }
+    void gather(bool include_root, const std::function<void(int, const char*, size_t)>& sink) override
+    {
+        const std::string stem = dir_ + "/text." + std::to_string(round_) + ".";
+        if (rank_ != 0 || include_root) {
+            std::stable_sort(kept_.begin(), kept_.end(), [](const Kept& a, const Kept& b) { return a.order < b.order; });
+            for (int f = 0; f < 7; ++f) {
+                const std::string path = stem + std::to_string(rank_) + "." + std::to_string(f);
+                FILE* out = fopen((path + ".tmp").c_str(), "wb");
+                if (!out) throw std::runtime_error("FileGather: cannot create '" + path + "'");
+                for (const Kept& k : kept_)
+                    if (!k.text[f].empty() && fwrite(k.text[f].data(), 1, k.text[f].size(), out) != k.text[f].size()) throw std::runtime_error("FileGather: write failed");
+                if (fclose(out) != 0 || rename((path + ".tmp").c_str(), path.c_str()) != 0) throw std::runtime_error("FileGather: write failed");
+            }
+            kept_.clear();
+        }
+        if (rank_ != 0) return;
+        for (int f = 0; f < 7; ++f)
+            for (int r = include_root ? 0 : 1; r < world_; ++r) {
+                const std::string path = stem + std::to_string(r) + "." + std::to_string(f);
+                FILE* in = nullptr;
+                for (int spins = 0; !(in = fopen(path.c_str(), "rb")); ++spins) {
+                    if (spins > 300000) throw std::runtime_error("FileGather: rank " + std::to_string(r) + " never delivered '" + path + "'");
+                    std::this_thread::sleep_for(std::chrono::milliseconds(2));
+                }
+                std::vector<char> buf(1 << 20);
+                for (size_t n; (n = fread(buf.data(), 1, buf.size(), in)) > 0;) sink(f, buf.data(), n);
+                fclose(in);
+                unlink(path.c_str());
+            }
+    }
+
+private:
+    struct Kept {
+        uint64_t order = 0;
+        std::string text[7];
+    };
+    int rank_, world_;
+    std::string dir_;
+    int round_ = 0;
+    std::mutex lock_;
+    std::vector<Kept> kept_;
+};
+
 }  // namespace
 
 int main(int argc, char** argv)
 {
     return pcsf_host::cli_main(argc, argv, [](const pcsf_host::Model& m, int) {
         return std::unique_ptr<pcsf_host::ScoringBackend>(new OracleBackend(m));
+    }, /*fast_exit=*/false,
+    [](pcsf_host::ScoringBackend&, int rank, int world, const std::string& rendezvous, int) {
+        return std::unique_ptr<pcsf_host::RankGather>(new FileGather(rank, world, rendezvous));
     });
 }

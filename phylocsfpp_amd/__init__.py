@@ -84,6 +84,15 @@ def load_library():
     lib.pcsf_wig_text_estimate.restype = C.c_size_t
     lib.pcsf_fetch_wig_text.argtypes = [vp, C.POINTER(C.c_char_p)]
     lib.pcsf_debug_wig_format.argtypes = [vp, fp, C.c_size_t, C.c_int, C.c_char_p, C.POINTER(C.c_uint32)]
+    lib.pcsf_comm_unique_id.argtypes = [C.c_char_p]
+    lib.pcsf_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
+    lib.pcsf_comm_destroy.argtypes = [vp]
+    lib.pcsf_wig_retain_last.argtypes = [vp, C.c_uint64]
+    lib.pcsf_wig_retain_host.argtypes = [vp, C.c_uint64, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
+    lib.pcsf_wig_retained_bytes.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.pcsf_wig_retain_reset.argtypes = [vp]
+    lib.pcsf_comm_gather_wig.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+    lib.pcsf_comm_fetch_gathered.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
     lib.pcsf_set_bls_branch_lengths.argtypes = [vp, dp]
     lib.pcsf_branch_length_scores.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_size_t, dp]
     lib.pcsf_hmm_smooth_runs.argtypes = [vp, dp, dp, dp, C.POINTER(C.c_uint64), C.c_size_t, dp, u8p, dp, C.POINTER(C.c_uint32)]
@@ -342,7 +351,53 @@ class ScoringContext:
             return res, skip.reshape(n, 6), bls
         return res, skip.reshape(n, 6)
 
-    def score_alignments_6frames_wig(self, nucleotides, alignments, chroms, power_threshold, want_power=True, want_raw=True, text_capacity=None):
+    # ---- build-tracks as one process per GPU: the text kept on the device, gathered over RCCL (csrc/comm.cpp) ----
+    @staticmethod
+    def comm_unique_id():
+        """rank 0: the communicator's 128-byte identifier (ncclGetUniqueId), to be handed to the other ranks out of band"""
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        rc = lib.pcsf_comm_unique_id(buf)
+        if rc != 0:
+            raise PcsfError(rc, "pcsf_comm_unique_id failed (librccl.so not found?)")
+        return buf.raw
+
+    def comm_create(self, rank, world, comm_id):
+        self._world = int(world)
+        self._check(self._lib.pcsf_comm_create(self._h, int(rank), int(world), bytes(comm_id)))
+
+    def comm_destroy(self):
+        self._check(self._lib.pcsf_comm_destroy(self._h))
+
+    def wig_retain_last(self, order):
+        """keeps the text of the last score_alignments_6frames_wig call on the device under the key `order`"""
+        self._check(self._lib.pcsf_wig_retain_last(self._h, int(order)))
+
+    def wig_retain_host(self, order, texts):
+        """adds host-formatted text (7 bytes objects) to the kept stream under the key `order`"""
+        assert len(texts) == 7
+        ptr = (C.c_char_p * 7)(*[bytes(t) if len(t) else None for t in texts])
+        n = (C.c_uint64 * 7)(*[len(t) for t in texts])
+        self._check(self._lib.pcsf_wig_retain_host(self._h, int(order), ptr, n))
+
+    def wig_retained_bytes(self):
+        n = (C.c_uint64 * 7)()
+        self._check(self._lib.pcsf_wig_retained_bytes(self._h, n))
+        return [int(v) for v in n]
+
+    def comm_gather_wig(self, root=0, include_root=False):
+        """collective: every sender's kept text to the root's GPU; returns bytes[world][7]"""
+        n = (C.c_uint64 * (7 * self._world))()
+        self._check(self._lib.pcsf_comm_gather_wig(self._h, int(root), int(bool(include_root)), n))
+        return [[int(n[r * 7 + f]) for f in range(7)] for r in range(self._world)]
+
+    def comm_fetch_gathered(self, rank, file, n_bytes):
+        buf = C.create_string_buffer(max(int(n_bytes), 1))
+        self._check(self._lib.pcsf_comm_fetch_gathered(self._h, int(rank), int(file), buf))
+        return buf.raw[:int(n_bytes)]
+
+    def score_alignments_6frames_wig(self, nucleotides, alignments, chroms, power_threshold, want_power=True, want_raw=True, text_capacity=None,
+                                     retain_order=None):
         """The same call for a caller that only writes: the text of build-tracks' seven wig files for this batch (formatted on the
         device, csrc/wig.hip).  chroms: one chromosome name per alignment.  Returns (list of 7 bytes objects -- power track, then
         +1 +2 +3 -1 -2 -3 --, number of codon-frames scored); None when the device left the batch to the host formatter.  text_capacity: bytes
@@ -362,6 +417,8 @@ class ScoringContext:
         if rc == -5:   # PCSF_ERR_UNSUPPORTED
             return None
         self._check(rc)
+        if retain_order is not None:   # the call's text also stays on the device for the ranks' gather (wig_retain_last)
+            self.wig_retain_last(retain_order)
         total = sum(int(s) for s in sizes)
         if total <= cap:       # the text came with the call
             raw, at, out = text.raw, 0, []

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libphylocsf_amd.so")
-SOURCES = ["kernels.hip", "expm.hip", "eigen.hip", "frontend.hip", "factored.hip", "tiles.hip", "chain.hip", "wig.hip", "hmm.hip", "api.cpp", "blocks.cpp", "model_abi.cpp", "hmm_abi.cpp"]
+SOURCES = ["kernels.hip", "expm.hip", "eigen.hip", "frontend.hip", "factored.hip", "tiles.hip", "chain.hip", "wig.hip", "hmm.hip", "api.cpp", "blocks.cpp", "model_abi.cpp", "hmm_abi.cpp", "comm.cpp"]
 HEADERS = ["kernels.h", "hostmath.hpp", "schedule.hpp", "ctx.hpp", "optimizer.hpp", "machine.hpp", "frames.hpp", os.path.join("..", "..", "include", "phylocsf_amd.h"),
            os.path.join("..", "host", "model_io.hpp")]
 

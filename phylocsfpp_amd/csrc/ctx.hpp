@@ -180,6 +180,21 @@ struct pcsf_ctx {
         uint64_t file_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         bool ready = false;
     } wig;
+    // pcsf_wig_retain (comm.cpp): the text of six-frame wig calls kept on the device, in the caller's order, until the ranks' gather
+    struct WigRetain {
+        bool on = false;
+        pcsf::DeviceBuffer arena;          // the kept calls' texts, each as the call left it (seven files back to back)
+        uint64_t used = 0;
+        struct Record {
+            uint64_t order;                // the caller's key: records are gathered in ascending order
+            uint64_t at;                   // offset of the record's text in the arena
+            uint64_t file_off[8];          // its seven files' boundaries, relative to `at`
+        };
+        std::vector<Record> records;
+    } retain;
+    struct CommState;                      // comm.cpp: the RCCL communicator of a multi-process run (library loaded on demand)
+    CommState* comm = nullptr;
+    void (*comm_free)(CommState*) = nullptr;
     pcsf::BlsTree bls_tree{};
     bool bls_ready = false;
     unsigned long long* bls_first_bad = nullptr;  // page-locked host copy of the kernel's character check
@@ -200,6 +215,7 @@ struct pcsf_ctx {
 
     ~pcsf_ctx()
     {
+        if (comm && comm_free) comm_free(comm);
         if (bls_first_bad) (void)hipHostFree(bls_first_bad);
         if (wig.h_bounds) (void)hipHostFree(wig.h_bounds);
         if (ev_kernels) (void)hipEventDestroy(ev_kernels);

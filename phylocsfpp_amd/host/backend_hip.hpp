@@ -114,6 +114,8 @@ public:
     }
     size_t wig_text_estimate(size_t n_columns, size_t n_alignments) override { return pcsf_wig_text_estimate(n_columns, n_alignments); }
     void fetch_wig_text(char* const* dst) override { check(pcsf_fetch_wig_text(ctx_, dst)); }
+    void retain_wig_text(uint64_t order) override { check(pcsf_wig_retain_last(ctx_, order)); }
+    pcsf_ctx* context() const { return ctx_; }
 
     char* staging_alloc(size_t bytes) override
     {
@@ -131,6 +133,103 @@ private:
     }
     pcsf_ctx* ctx_ = nullptr;
     bool device_bls_ = false;
+};
+
+// The ranks' gather of the product: RCCL between the GPUs (csrc/comm.cpp).  A rank's text is formatted on its GPU, kept there, and moves
+// to rank 0's GPU in one grouped send / receive; rank 0 copies it down file by file.  The communicator's identifier travels through
+// a file in `rendezvous` (a directory the launcher made): rank 0 writes it, the others wait for it.  The communicator is set up on a
+// thread of its own while the rank scores.
+class RcclGather : public RankGather {
+public:
+    RcclGather(HipBackend& backend, int rank, int world, const std::string& rendezvous, int threads)
+        : ctx_(backend.context()), rank_(rank), world_(world), threads_(threads)
+    {
+        auto init = [this, rendezvous]() {
+            char id[PCSF_COMM_ID_BYTES];
+            const std::string path = rendezvous + "/rccl_id";
+            if (rank_ == 0) {
+                if (pcsf_comm_unique_id(id) != PCSF_OK) throw std::runtime_error("pcsf_comm_unique_id failed (is librccl.so there?)");
+                const std::string tmp = path + ".tmp";
+                FILE* f = fopen(tmp.c_str(), "wb");
+                if (!f || fwrite(id, 1, sizeof id, f) != sizeof id || fclose(f) != 0 || rename(tmp.c_str(), path.c_str()) != 0)
+                    throw std::runtime_error("cannot write the communicator's identifier to '" + path + "'");
+            } else {
+                const char* t = std::getenv("PCSF_RENDEZVOUS_TIMEOUT");
+                const double limit = t ? atof(t) : 300.0;
+                StopWatch waited;
+                double total = 0.0;
+                for (;;) {
+                    if (FILE* f = fopen(path.c_str(), "rb")) {
+                        const size_t got = fread(id, 1, sizeof id, f);
+                        fclose(f);
+                        if (got == sizeof id) break;
+                    }
+                    if ((total += waited.lap()) > limit) throw std::runtime_error("rank 0 did not publish the communicator's identifier in '" + path + "'");
+                    std::this_thread::sleep_for(std::chrono::milliseconds(2));
+                }
+            }
+            if (pcsf_comm_create(ctx_, rank_, world_, id) != PCSF_OK) throw std::runtime_error(std::string("pcsf_comm_create: ") + pcsf_last_error(ctx_));
+        };
+        const char* sync = std::getenv("PCSF_COMM_INIT_SYNC");
+        if (sync && sync[0] == '1') {
+            init();
+        } else {
+            ready_ = std::async(std::launch::async, init);
+        }
+    }
+    ~RcclGather() override
+    {
+        try {
+            if (ready_.valid()) ready_.get();
+        } catch (...) {
+        }
+        for (char* p : staging_)
+            if (p) pcsf_host_free(p);
+    }
+    int rank() const override { return rank_; }
+    int world() const override { return world_; }
+    void begin() override { check(pcsf_wig_retain_reset(ctx_)); }
+    void keep_backend_text(ScoringBackend& backend, uint64_t order) override { backend.retain_wig_text(order); }
+    void keep_host_text(uint64_t order, const char* const* text, const uint64_t* bytes) override { check(pcsf_wig_retain_host(ctx_, order, text, bytes)); }
+    void gather(bool include_root, const std::function<void(int, const char*, size_t)>& sink) override
+    {
+        if (ready_.valid()) ready_.get();   // rethrows what the set-up threw
+        std::vector<uint64_t> bytes(static_cast<size_t>(world_) * 7, 0);
+        check(pcsf_comm_gather_wig(ctx_, 0, include_root ? 1 : 0, bytes.data()));
+        if (rank_ != 0) return;
+        // the seven files side by side: each copies its senders' pieces down in rank order through a page-locked buffer of its own
+        staging_.resize(7, nullptr);
+        staging_bytes_.resize(7, 0);
+        parallel_for(7, threads_, [&](size_t f) {
+            uint64_t largest = 0;
+            for (int r = 0; r < world_; ++r) largest = std::max(largest, bytes[static_cast<size_t>(r) * 7 + f]);
+            if (!largest) return;
+            if (staging_bytes_[f] < largest) {
+                if (staging_[f]) pcsf_host_free(staging_[f]);
+                staging_[f] = static_cast<char*>(pcsf_host_alloc_on(ctx_, largest));
+                staging_bytes_[f] = staging_[f] ? largest : 0;
+                if (!staging_[f]) throw std::runtime_error("pcsf_host_alloc_on failed");
+            }
+            for (int r = 0; r < world_; ++r) {
+                const uint64_t n = bytes[static_cast<size_t>(r) * 7 + f];
+                if (!n) continue;
+                if (pcsf_comm_fetch_gathered(ctx_, r, static_cast<int>(f), staging_[f]) != PCSF_OK)
+                    throw std::runtime_error(std::string("phylocsf_amd: ") + pcsf_last_error(ctx_));
+                sink(static_cast<int>(f), staging_[f], static_cast<size_t>(n));
+            }
+        });
+    }
+
+private:
+    void check(int rc)
+    {
+        if (rc != PCSF_OK) throw std::runtime_error(std::string("phylocsf_amd: ") + pcsf_last_error(ctx_));
+    }
+    pcsf_ctx* ctx_;
+    int rank_, world_, threads_;
+    std::future<void> ready_;
+    std::vector<char*> staging_;
+    std::vector<uint64_t> staging_bytes_;
 };
 
 }  // namespace pcsf_host

@@ -4,7 +4,10 @@
 // for the options that reach the scoring path; options must precede the positionals.
 #pragma once
 
+#include <dirent.h>
+#include <signal.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <cstdio>
@@ -30,6 +33,7 @@ inline int usage(const char* prog)
             "                  [--output-phylo 0|1] [--output-regions 0|1] [--genome-length N --coding-exons FILE | --hmm-params P]\n"
             "                  [--species A,B,...] [--mapping FILE] [--species-aliases FILE] [--device N | --devices N,M,...]\n"
             "                  [--threads N] [--window-bytes N] [--batch-sites N] [--contexts-per-device N] [--host-bls 0|1]\n"
+            "                  [--ranks N [--gather-root-text 0|1]]\n"
             "                  <model prefix> <alignment.maf>...\n"
             "  %s score-msa    [--strategy fixed|mle|omega|fixed_mean] [--comp-phylo 0|1] [--comp-anc 0|1] [--comp-bls 0|1]\n"
             "                  [--output DIR] [--species A,B,...] [--mapping FILE] [--species-aliases FILE] [--device N | --devices N,M,...]\n"
@@ -39,6 +43,8 @@ inline int usage(const char* prog)
             "                  (build-tracks also reads the packed file: same tracks, no text parsing)\n"
             "--hmm-params: coding prior, mean coding length (codons), 3 non-coding weights, 3 non-coding mean lengths (codons)\n"
             "--species reduces the model's tree to the named species (tree labels or their other names)\n"
+            "--ranks N: build-tracks as N processes, one per GPU (--devices lists them; default 0..N-1): rank r scores the r-th of N byte ranges\n"
+            "           of every input, the ranks' text is gathered onto rank 0's GPU over RCCL and rank 0 writes the files\n"
             "<model prefix> names <prefix>_coding.ECM, <prefix>_noncoding.ECM and <prefix>.nh\n"
             "environment: PCSF_FULL_TEARDOWN=1 keeps the orderly exit (scoring contexts and the HIP runtime torn down instead of _exit once every\n"
             "             output file is closed; automatic under LD_PRELOAD / rocprofv3, whose tools write their files at exit)\n",
@@ -47,8 +53,59 @@ inline int usage(const char* prog)
 }
 
 using BackendFactory = std::function<std::unique_ptr<ScoringBackend>(const Model&, int device)>;
+// the ranks' gather of a build (--ranks): over `backend`, for rank `rank` of `world`; `rendezvous` is a directory all ranks see
+using GatherFactory = std::function<std::unique_ptr<RankGather>(ScoringBackend& backend, int rank, int world, const std::string& rendezvous, int threads)>;
 
-inline int cli_main(int argc, char** argv, const BackendFactory& make_backend, bool fast_exit = false)
+// --ranks N, the launcher: N copies of this command line, told apart by PCSF_RANK / PCSF_WORLD, with a fresh directory to meet in
+// (PCSF_RENDEZVOUS).  The launcher itself never touches a GPU.  The first rank that fails ends the others (they would wait for it in
+// the gather for ever); the launcher's status is that rank's.
+inline int launch_ranks(char** argv, int n_ranks)
+{
+    char rdv[] = "/tmp/pcsf_ranks_XXXXXX";
+    if (!mkdtemp(rdv)) {
+        perror("error: mkdtemp");
+        return 1;
+    }
+    std::vector<pid_t> pids(static_cast<size_t>(n_ranks), -1);
+    for (int r = 0; r < n_ranks; ++r) {
+        const pid_t pid = fork();
+        if (pid < 0) {
+            perror("error: fork");
+            for (pid_t p : pids) if (p > 0) kill(p, SIGTERM);
+            return 1;
+        }
+        if (pid == 0) {
+            setenv("PCSF_RANK", std::to_string(r).c_str(), 1);
+            setenv("PCSF_WORLD", std::to_string(n_ranks).c_str(), 1);
+            setenv("PCSF_RENDEZVOUS", rdv, 1);
+            execv("/proc/self/exe", argv);
+            perror("error: execv");
+            _exit(127);
+        }
+        pids[static_cast<size_t>(r)] = pid;
+    }
+    int status_out = 0;
+    for (int left = n_ranks; left > 0; --left) {
+        int st = 0;
+        const pid_t done = wait(&st);
+        if (done < 0) break;
+        const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+        for (pid_t& p : pids) if (p == done) p = -1;
+        if (rc != 0 && status_out == 0) {
+            status_out = rc;
+            for (pid_t p : pids) if (p > 0) kill(p, SIGTERM);
+        }
+    }
+    if (DIR* d = opendir(rdv)) {   // what the ranks left in the meeting place
+        while (struct dirent* e = readdir(d))
+            if (strcmp(e->d_name, ".") != 0 && strcmp(e->d_name, "..") != 0) unlink((std::string(rdv) + "/" + e->d_name).c_str());
+        closedir(d);
+    }
+    rmdir(rdv);
+    return status_out;
+}
+
+inline int cli_main(int argc, char** argv, const BackendFactory& make_backend, bool fast_exit = false, const GatherFactory& make_gather = nullptr)
 {
     const auto t_main = std::chrono::steady_clock::now();
     auto since_main = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main).count(); };
@@ -243,7 +300,9 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend, b
     ScoreMsaParams sm;
     std::string aliases, species, mapping, context_model;
     std::vector<int> devices{0};
+    bool devices_given = false;
     int contexts_per_device = 0;
+    int n_ranks = 0;   // --ranks
     int i = 2;
     for (; i < argc && strncmp(argv[i], "--", 2) == 0; i += 2) {
         if (i + 1 >= argc) return usage(argv[0]);
@@ -268,8 +327,11 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend, b
         else if (k == "--species") species = v;
         else if (k == "--mapping") mapping = v;
         else if (k == "--context-model") context_model = v;   // smooth-tracks: a model to make a scoring context with, for the device recurrences
-        else if (k == "--device") devices = {atoi(v.c_str())};
-        else if (k == "--devices") {  // one scoring context per listed GPU; batches / block ranges are dealt to them
+        else if (k == "--ranks") n_ranks = atoi(v.c_str());
+        else if (k == "--gather-root-text") bt.gather_root_text = parse_bool(v);   // rank 0's own text through the gather too (a rehearsal on one GPU)
+        else if (k == "--device") { devices = {atoi(v.c_str())}; devices_given = true; }
+        else if (k == "--devices") {
+            devices_given = true;  // one scoring context per listed GPU; batches / block ranges are dealt to them
             devices.clear();
             const char* q = v.c_str();
             char* end = nullptr;
@@ -297,6 +359,29 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend, b
     }
     if (cmd == "smooth-tracks" && !bt.write_smooth && !bt.write_regions) bt.write_smooth = true;
     if (argc - i < (cmd == "smooth-tracks" ? 1 : 2)) return usage(argv[0]);
+    // one process per GPU: the command line as given is the launcher; its copies find their rank in the environment
+    int rank = 0, world = 0;
+    std::string rendezvous;
+    if (n_ranks != 0) {
+        if (cmd != "build-tracks" || n_ranks < 1) {
+            fprintf(stderr, "--ranks N (N >= 1) is a build-tracks option\n");
+            return usage(argv[0]);
+        }
+        const char* er = std::getenv("PCSF_RANK");
+        const char* ew = std::getenv("PCSF_WORLD");
+        const char* ed = std::getenv("PCSF_RENDEZVOUS");
+        if (!er || !ew || !ed) return launch_ranks(argv, n_ranks);
+        rank = atoi(er);
+        world = atoi(ew);
+        rendezvous = ed;
+        if (world != n_ranks || rank < 0 || rank >= world) {
+            fprintf(stderr, "error: PCSF_RANK / PCSF_WORLD do not fit --ranks %d\n", n_ranks);
+            return 1;
+        }
+        // this rank's GPU: the rank-th of --devices (taken round the list), or GPU `rank`
+        devices = {devices_given ? devices[static_cast<size_t>(rank) % devices.size()] : rank};
+        contexts_per_device = 1;
+    }
     try {
         {
             if (cmd == "score-msa" ? sm.strategy == ALGO_FIXED_MEAN : (bt.write_smooth || bt.write_regions)) {
@@ -390,10 +475,17 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend, b
         // start-up, before any input is read: the first context pays for the HIP runtime and the code object
         fprintf(stderr, "start-up seconds: options + model files %.3f, first scoring context %.3f (%zu more being set up beside the run)\n", t_model,
                 since_main() - t_model, backends.size() - 1);
+        std::unique_ptr<RankGather> gather;
+        if (world > 0) {
+            if (!make_gather) throw std::runtime_error("--ranks: this command line has no gather");
+            gather = make_gather(*backends[0], rank, world, rendezvous, bt.threads > 0 ? bt.threads : effective_threads());
+            bt.ranks = gather.get();
+        }
         bool first = true;
         for (; i < argc; ++i) {
             if (cmd == "build-tracks") {
                 const BuildTracksStats st = build_tracks(model, argv[i], bt, backends, !first);
+                if (world > 0) fprintf(stderr, "[rank %d of %d, device %d] gather %.3f s | ", rank, world, devices[0], st.gather_seconds);
                 fprintf(stderr, "%s: %zu alignments, %zu reference bases, %zu codon-frames, %zu backend calls\n", argv[i], st.alignments,
                         st.ref_bases, st.codon_frames, st.backend_calls);
                 fprintf(stderr, "  seconds: total %.3f; busy per stage (the stages overlap): MAF read %.3f, BLS %.3f, batch packing %.3f | scoring backend %.3f | wig output %.3f | smoothing %.3f\n",

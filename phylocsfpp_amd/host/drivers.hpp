@@ -116,6 +116,9 @@ struct ScoringBackend {
     }
     virtual size_t wig_text_estimate(size_t, size_t) { throw std::runtime_error("wig_text_estimate: this backend does not format tracks"); }
     virtual void fetch_wig_text(char* const*) { throw std::runtime_error("fetch_wig_text: this backend does not format tracks"); }
+    // build-tracks as one process per GPU (RankGather below): the text of the last score_alignments_6frames_wig call stays where the
+    // backend formatted it, under the caller's key (the HIP backend: in its GPU's memory, pcsf_wig_retain_last)
+    virtual void retain_wig_text(uint64_t /*order*/) { throw std::runtime_error("retain_wig_text: this backend does not keep text"); }
     virtual size_t score_alignments_6frames(int n_leaves, const char* nucl, size_t row_stride, const std::vector<uint64_t>& col0,
                                             const std::vector<uint32_t>& len, const std::vector<uint64_t>& start_pos,
                                             const std::vector<uint64_t>& chrom_len, double* out, size_t out_capacity, std::vector<uint64_t>& offsets,
@@ -227,6 +230,26 @@ private:
     int contexts_;
 };
 
+// build-tracks as one process ("rank") per GPU: rank r scores the r-th of `world` byte ranges of the input -- the ranks stand in for
+// the reference's byte-range jobs (src/phylocsf++build_tracks.hpp:88) -- and the text of ranks 1.. reaches rank 0, which owns the
+// files, through ONE gather in rank order: the reference's merge_job_output_files (:27-53, :246-259).  The HIP backend's gather is
+// RCCL between the GPUs (backend_hip.hpp RcclGather: the text never visits a sender's host); the test-only oracle command line has
+// a file-based one (oracle/oracle_cli.cpp).
+struct RankGather {
+    virtual ~RankGather() = default;
+    virtual int rank() const = 0;
+    virtual int world() const = 0;
+    // a new input file begins: nothing is kept yet
+    virtual void begin() = 0;
+    // a batch of this rank's text (order = the batch's index in the rank's stream): where the backend's last wig call left it ...
+    virtual void keep_backend_text(ScoringBackend& backend, uint64_t order) = 0;
+    // ... or formatted on the host: bytes[7], text[f] = file f's text of the batch
+    virtual void keep_host_text(uint64_t order, const char* const* text, const uint64_t* bytes) = 0;
+    // Collective, once per input file.  On rank 0: sink(file, text, n) receives the senders' text, for every file in rank order (files
+    // may be served from different threads at once, one file never from two).  include_root: rank 0 kept its text too (a rehearsal).
+    virtual void gather(bool include_root, const std::function<void(int file, const char* text, size_t n)>& sink) = 0;
+};
+
 struct BuildTracksParams {
     std::string output_dir;          // empty: next to the alignment file
     float power_threshold = 0.1f;    // TrackCLIParams::phylo_threshold
@@ -238,6 +261,8 @@ struct BuildTracksParams {
     bool host_bls = false;           // branch-length scores on the host even when the backend offers them (--host-bls)
     int threads = 0;                 // host threads for ingest / BLS / text output (0 = all the process may use)
     size_t window_bytes = 0;                  // MAF bytes parsed (in parallel) per pipeline step; 0: from the input's size (32 MiB for inputs of 256 MiB and more)
+    RankGather* ranks = nullptr;              // --ranks: this process is one of several, each on a GPU of its own
+    bool gather_root_text = false;            // ... and rank 0's own text takes the gather's path too instead of going straight to the files
 };
 
 // CPUs this process may actually use: hardware threads, capped by the cgroup CPU quota (a container on a
@@ -317,6 +342,7 @@ struct BuildTracksStats {
     size_t alignments = 0, ref_bases = 0, codon_frames = 0, backend_calls = 0;
     double backend_seconds = 0.0;                       // inside ScoringBackend::score_sites_fixed (H2D + kernel + D2H)
     double read_seconds = 0.0, bls_seconds = 0.0, extract_seconds = 0.0, write_seconds = 0.0, smooth_seconds = 0.0, total_seconds = 0.0;
+    double gather_seconds = 0.0;                        // one process per GPU: the collective at the end of a file (waiting for the slowest rank included)
 };
 
 struct StopWatch {
@@ -838,14 +864,22 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     const std::string out_dir = prm.output_dir.empty() ? dirname_of(maf_path) : prm.output_dir;
     mkdir(out_dir.c_str(), 0764);
     const char* mode = append ? "a" : "w";
+    // one process per GPU: this one scores the rank-th byte range; only rank 0 has files, the others keep their text for the gather
+    RankGather* const ranks = prm.ranks;
+    const int rank = ranks ? ranks->rank() : 0, world = ranks ? ranks->world() : 1;
+    const bool owns_files = rank == 0;
+    const bool keeps_text = ranks && (rank != 0 || prm.gather_root_text);   // this rank's text goes through the gather
+    if (ranks && backends.size() != 1) throw std::runtime_error("build_tracks: a rank scores on one backend");
+    if (ranks) ranks->begin();
     OutFile power_file, raw_file[6];  // closed on every path; files created by a failed run are removed
-    if (prm.write_power) power_file.open(out_dir + "/PhyloCSFpower.wig", mode);
+    if (prm.write_power && owns_files) power_file.open(out_dir + "/PhyloCSFpower.wig", mode);
     FILE* f_power = power_file.get();
     FILE* f_raw[6] = {nullptr};
+    const bool want_power = prm.write_power;   // (a rank without files still makes the text)
     // the smoothing pass reads the raw tracks back (as text, like the reference), so they are written even when
     // they were not asked for, and removed afterwards
     const bool need_raw = prm.write_raw || prm.write_smooth || prm.write_regions;
-    if (need_raw)
+    if (need_raw && owns_files)
         for (int i = 0; i < 6; ++i) {
             raw_file[i].open(out_dir + "/PhyloCSFRaw" + std::string(1, i < 3 ? '+' : '-') + std::to_string(i % 3 + 1) + ".wig", mode);
             f_raw[i] = raw_file[i].get();
@@ -919,7 +953,7 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     // the pieces of one batch, file by file in the order their text goes to the file
     auto batch_pieces = [&](const std::vector<Item*>& items, const double* scores, const std::vector<uint64_t>& offsets) {
         std::vector<PieceJob> jobs;
-        if (f_power)
+        if (want_power)
             for (const Item* it : items) {
                 int64_t skip = static_cast<int64_t>(3 - static_cast<int64_t>(it->start_pos)) % 3;
                 if (skip < 0) skip += 3;
@@ -949,17 +983,21 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     // a packed alignment file (pack-maf, packed_reader.hpp) holds the reader's alignments ready-made: stage 1 only copies rows
     const bool packed = is_packed_file(file);
     const size_t input_bytes = packed ? static_cast<size_t>(PackedReader::data_bytes(file)) : file.size();
+    // (a rank's byte range is cut like the reference cuts its jobs': an alignment belongs to the range its first block's "a" line starts in)
+    const size_t range_begin = static_cast<size_t>(static_cast<unsigned __int128>(input_bytes) * static_cast<unsigned>(rank) / static_cast<unsigned>(world));
+    const size_t range_end = static_cast<size_t>(static_cast<unsigned __int128>(input_bytes) * static_cast<unsigned>(rank + 1) / static_cast<unsigned>(world));
+    const size_t range_bytes = range_end - range_begin;
     // 32 MiB steps; a short input gets about eight (and the two smaller ones in front), so that the stages overlap inside it too: the last
     // step's scoring runs with nothing beside it, and with four steps that was a fifth of a 90 MB run (0.060 -> 0.050 s)
     const size_t window = prm.window_bytes ? std::max<size_t>(prm.window_bytes, 1 << 16)
-                                           : std::min<size_t>(size_t(32) << 20, std::max<size_t>(size_t(4) << 20, (input_bytes / 8 + 0xfffff) & ~size_t(0xfffff)));
+                                           : std::min<size_t>(size_t(32) << 20, std::max<size_t>(size_t(4) << 20, (range_bytes / 8 + 0xfffff) & ~size_t(0xfffff)));
     // the first windows are smaller (1/4, 1/2 of the size) so that the scoring stage starts after a short parse
     std::vector<size_t> window_begin;
-    for (size_t at = 0, k = 0; at < input_bytes; ++k) {
+    for (size_t at = range_begin, k = 0; at < range_end; ++k) {
         window_begin.push_back(at);
         at += k == 0 ? std::max<size_t>(window / 4, 1 << 16) : (k == 1 ? std::max<size_t>(window / 2, 1 << 16) : window);
     }
-    window_begin.push_back(input_bytes);
+    window_begin.push_back(range_end);
     // batch matrices come from the backend (page-locked for the GPU) and are recycled: allocating them is slow
     struct StagingPool {
         ScoringBackend& backend;
@@ -1004,6 +1042,8 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         std::pair<char*, size_t> text_mem{nullptr, 0};  // the backend formatted the batch: the seven files' text back to back, page-locked
         uint64_t text_bytes[7] = {0, 0, 0, 0, 0, 0, 0};
         bool has_text = false;
+        uint64_t order = 0;      // the batch's index in this process's stream of batches
+        bool kept = false;       // one process per GPU: the backend keeps the text for the gather, nothing comes down here
     };
     struct PreparedWindow {
         std::vector<std::vector<Item>> jobs;
@@ -1184,6 +1224,7 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         writing = f;
         writer = std::async(std::launch::async, [&, batch = f.bt]() {
             StopWatch ww;
+            if (batch->kept) return ww.lap();   // the text waits for the gather where the backend formatted it
             if (batch->has_text) {   // formatted by the backend: the files side by side
                 uint64_t at[8] = {0};
                 for (int t = 0; t < 7; ++t) at[t + 1] = at[t] + batch->text_bytes[t];
@@ -1199,6 +1240,24 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             const std::vector<PieceJob> jobs = batch_pieces(batch->items, batch->scores, batch->offsets);
             if (text.size() < jobs.size()) text.resize(jobs.size());   // one writer runs at a time; the buffers keep their memory
             parallel_for(jobs.size(), threads, [&](size_t i) { format_piece(jobs[i], text[i]); });
+            if (keeps_text) {   // one process per GPU: every file's pieces joined, handed to the gather under the batch's index
+                std::vector<char> joined[7];
+                parallel_for(7, threads, [&](size_t t) {
+                    size_t n = 0;
+                    for (size_t i = 0; i < jobs.size(); ++i)
+                        if (jobs[i].file == static_cast<int>(t)) n += text[i].len;
+                    joined[t].reserve(n);
+                    for (size_t i = 0; i < jobs.size(); ++i)
+                        if (jobs[i].file == static_cast<int>(t)) joined[t].insert(joined[t].end(), text[i].buf.data(), text[i].buf.data() + text[i].len);
+                });
+                const char* ptr[7];
+                uint64_t bytes[7];
+                for (int t = 0; t < 7; ++t) {
+                    ptr[t] = joined[t].data();
+                    bytes[t] = joined[t].size();
+                }
+                ranks->keep_host_text(batch->order, ptr, bytes);
+            } else
             parallel_for(7, threads, [&](size_t t) {   // every file's pieces in order; the files side by side
                 FILE* f = t == 0 ? f_power : f_raw[t - 1];
                 if (!f) return;
@@ -1212,7 +1271,9 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
             return ww.lap();
         });
     };
+    uint64_t next_order = 0;
     auto submit = [&](Batch& bt, WindowSlot* ws) {
+        bt.order = next_order++;
         // round robin over the backends that exist (one still being set up -- DeferredBackend -- and its prepare_tracks are skipped)
         size_t d = next_dev % n_dev;
         for (size_t k = 0; k < n_dev; ++k) {
@@ -1232,10 +1293,18 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
                 std::vector<const char*> chroms(b->items.size());
                 for (size_t k = 0; k < chroms.size(); ++k) chroms[k] = b->items[k]->chrom.c_str();
                 // the text is copied down behind the kernels, before its size is known: a buffer from the backend's estimate
-                b->text_mem = text_pool.get(backends[d]->wig_text_estimate(b->stride, b->items.size()));
+                // (one process per GPU: no buffer -- the text stays with the backend until the gather)
+                if (!keeps_text) b->text_mem = text_pool.get(backends[d]->wig_text_estimate(b->stride, b->items.size()));
                 b->has_text = backends[d]->score_alignments_6frames_wig(b->nucl.first, b->stride, b->col0, b->len, b->start_pos, b->chrom_len, chroms,
-                                                                        prm.power_threshold, f_power != nullptr, true, b->text_mem.first, b->text_mem.second,
+                                                                        prm.power_threshold, want_power, true, b->text_mem.first, b->text_mem.second,
                                                                         b->text_bytes, &b->n_scores);
+                if (b->has_text && keeps_text) {
+                    ranks->keep_backend_text(*backends[d], b->order);
+                    b->kept = true;
+                    pool.put(b->nucl);
+                    b->nucl = {nullptr, 0};
+                    return bw.lap();
+                }
                 if (b->has_text) {
                     uint64_t total = 0;
                     for (uint64_t v : b->text_bytes) total += v;
@@ -1251,7 +1320,7 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
                     b->nucl = {nullptr, 0};
                     return bw.lap();
                 }
-                text_pool.put(b->text_mem);
+                if (b->text_mem.first) text_pool.put(b->text_mem);
                 b->text_mem = {nullptr, 0};
             }
             if (need_raw) {
@@ -1276,7 +1345,7 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
         while (inflight.size() > n_dev) retire_front();
     };
     std::future<std::unique_ptr<PreparedWindow>> next;
-    if (input_bytes > 0) next = std::async(std::launch::async, prepare_window, size_t(0));
+    if (range_bytes > 0) next = std::async(std::launch::async, prepare_window, size_t(0));
     if (need_raw)
         for (size_t d = 0; d < n_dev; ++d)
             dev_prepared[d] = dev_last[d] = std::async(std::launch::async, [&, d]() -> double {
@@ -1307,6 +1376,16 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     }
     while (!inflight.empty()) retire_front();
     finish_writer();
+    if (ranks) {
+        // ONE gather per input file: every other rank's text, in rank order = file order, behind what rank 0 wrote itself (the
+        // reference appends its jobs' files in job order, src/phylocsf++build_tracks.hpp:27-53)
+        StopWatch gw;
+        ranks->gather(prm.gather_root_text, [&](int file, const char* p, size_t n) {
+            FILE* f = file == 0 ? f_power : f_raw[file - 1];
+            if (f && n && fwrite(p, 1, n, f) != n) throw std::runtime_error("write failed");
+        });
+        st.gather_seconds += gw.lap();
+    }
     } catch (...) {  // the background stages reference this frame: let them finish before it unwinds
         for (auto& f : inflight)
             if (f.scored.valid()) f.scored.wait();
@@ -1319,7 +1398,7 @@ inline BuildTracksStats build_tracks(const Model& model, const std::string& maf_
     alive.clear();
     power_file.commit();
     for (OutFile& f : raw_file) f.commit();
-    if (prm.write_smooth || prm.write_regions) {
+    if (owns_files && (prm.write_smooth || prm.write_regions)) {
         sw.lap();
         bool smoothed = false;
         std::array<bool, 6> done{};   // frames whose smoothed files the device pass committed before it failed

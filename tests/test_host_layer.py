@@ -389,3 +389,70 @@ def test_packed_alignment_file_gives_the_same_tracks(cli, tmp_path):
         f.write_bytes(bytes(b))
         r = subprocess.run([cli, "build-tracks", "--output", str(tmp_path / "c"), MODEL, str(f)], capture_output=True, text=True)
         assert r.returncode == 1 and "packed alignment file" in r.stderr, (what, r.returncode, r.stderr[-300:])
+
+
+def test_one_process_per_rank_writes_the_files_of_a_single_process(cli, tmp_path):
+    """build-tracks --ranks N: the launcher starts N copies of the command line, rank r scores the r-th of N byte ranges of the input (the
+    reference's byte-range jobs, src/phylocsf++build_tracks.hpp:88), rank 0 owns the files and appends the others' text in rank order
+    (merge_job_output_files, :27-53).  The product's gather is RCCL between GPUs (tests/test_gpu_ranks.py); here the test command line's
+    file-based gather carries the same driver code: byte ranges, batch order keys, the merge.  Small batches and windows so that every
+    rank keeps dozens of batches; both forms of stage 1; rank 0's own text through the gather as well (--gather-root-text 1)."""
+    import gzip
+    import sys
+    maf = tmp_path / "g.maf"
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "build-tracks", "galGal6_chr22_25_28_each_30k_bases.maf.gz"), "rt") as fi:
+        blocks = fi.read().split("\n\n")
+    maf.write_text("\n\n".join(blocks[:1500]) + "\n\n")
+    env = dict(os.environ, PCSF_ORACLE_BACKEND_FAKE="1")
+    plain = tmp_path / "plain"
+    subprocess.check_call([cli, "build-tracks", "--output", str(plain), MODEL, str(maf)], stderr=subprocess.DEVNULL, env=env)
+    names = sorted(os.listdir(plain))
+    assert len(names) == 7
+    small = ["--batch-sites", "4000", "--window-bytes", "100000", "--threads", "3"]
+    for tag, extra, more in (("r2", ["--ranks", "2"] + small, {}),
+                             ("r3", ["--ranks", "3"] + small, {"PCSF_ORACLE_BACKEND_BLS": "1"}),
+                             ("r7", ["--ranks", "7"], {}),
+                             ("r1root", ["--ranks", "1", "--gather-root-text", "1"] + small, {}),
+                             ("r3root", ["--ranks", "3", "--gather-root-text", "1"] + small, {"PCSF_ORACLE_BACKEND_BLS": "1"})):
+        out = tmp_path / tag
+        err = subprocess.run([cli, "build-tracks", "--output", str(out)] + extra + [MODEL, str(maf)], stderr=subprocess.PIPE, env=dict(env, **more), check=True, text=True).stderr
+        assert sorted(os.listdir(out)) == names, tag
+        for n in names:
+            assert open(out / n, "rb").read() == open(plain / n, "rb").read(), (tag, n)
+        n_ranks = int(extra[1])
+        assert all("[rank %d of %d" % (r, n_ranks) in err for r in range(n_ranks)), err
+    # two input files: one gather per file, the second appended behind the first
+    syn = tmp_path / "syn.maf"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_synthetic_maf.py"), str(syn), "--bases", "30000", "--start", "985000", "--seed", "5"],
+                          stdout=subprocess.DEVNULL)
+    model58 = os.path.join(ROOT, "tests", "golden", "models", "58mammals")
+    outs = []
+    for extra in ([], ["--ranks", "3", "--batch-sites", "6000", "--window-bytes", "150000"]):
+        out = tmp_path / ("two%d" % len(outs))
+        subprocess.check_call([cli, "build-tracks", "--output", str(out)] + extra + [model58, str(syn), str(syn)], stderr=subprocess.DEVNULL, env=env)
+        outs.append(out)
+    for n in names:
+        a = open(outs[0] / n, "rb").read()
+        assert a == open(outs[1] / n, "rb").read() and len(a) > 1000, n
+
+
+def test_a_failing_rank_ends_the_run(cli, tmp_path):
+    """A rank that fails (here: a character the reference rejects, in the last third of the file) would leave the others waiting in the
+    gather for ever: the launcher ends them and reports the failure; rank 0's unfinished files are removed."""
+    import gzip
+    import time
+    maf = tmp_path / "g.maf"
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "build-tracks", "galGal6_chr22_25_28_each_30k_bases.maf.gz"), "rt") as fi:
+        blocks = fi.read().split("\n\n")[:900]
+    lines = blocks[800].split("\n")
+    row = lines[1].split()
+    row[-1] = row[-1][:5] + "!" + row[-1][6:]
+    lines[1] = " ".join(row)
+    blocks[800] = "\n".join(lines)
+    maf.write_text("\n\n".join(blocks) + "\n\n")
+    out = tmp_path / "out"
+    t0 = time.time()
+    r = subprocess.run([cli, "build-tracks", "--output", str(out), "--ranks", "3", MODEL, str(maf)], stderr=subprocess.PIPE, text=True,
+                       env=dict(os.environ, PCSF_ORACLE_BACKEND_FAKE="1"))
+    assert r.returncode != 0 and "error" in r.stderr, r.stderr
+    assert time.time() - t0 < 60
