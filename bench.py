@@ -138,6 +138,7 @@ SECONDS_RE = re.compile(r"seconds: total ([\d.]+); .*MAF read ([\d.]+), BLS ([\d
                         r"wig output ([\d.]+) \| smoothing ([\d.]+)")
 
 
+RANK_RE = re.compile(r"\[rank (\d+) of (\d+), device (\d+)\] gather ([\d.]+) s")
 STARTUP_RE = re.compile(r"start-up seconds: options \+ model files ([\d.]+), first scoring context ([\d.]+)")
 
 
@@ -153,6 +154,19 @@ def run_cli(binary, maf, out_dir, extra_args=(), env=None):
     a, s = STATS_RE.search(p.stderr), SECONDS_RE.search(p.stderr)
     if not a or not s:
         raise RuntimeError("cannot parse the statistics of %s: %s" % (binary, p.stderr[-2000:]))
+    ranks = RANK_RE.findall(p.stderr)
+    if ranks:   # --ranks N: one statistics line per process; the run lasts as long as its slowest rank, the ranks' work adds up
+        al, se = STATS_RE.findall(p.stderr), SECONDS_RE.findall(p.stderr)
+        if not (len(ranks) == len(al) == len(se)):
+            raise RuntimeError("cannot parse the ranks' statistics of %s: %s" % (binary, p.stderr[-2000:]))
+        slowest = max(range(len(se)), key=lambda i: float(se[i][0]))
+        busy = ["maf_read", "bls", "batch_packing", "scoring_backend", "wig_output", "smoothing"]
+        return {"alignments": sum(int(x[0]) for x in al), "ref_bases": sum(int(x[1]) for x in al), "codon_frames": sum(int(x[2]) for x in al),
+                "backend_calls": sum(int(x[3]) for x in al), "seconds": float(se[slowest][0]), "process_wall_seconds": wall,
+                "startup_seconds": None, "ranks": len(ranks), "devices": sorted(set(int(r[2]) for r in ranks)),
+                "seconds_per_rank": [float(x[0]) for x in se], "gather_seconds_per_rank": [float(r[3]) for r in ranks],
+                "codon_frames_per_rank": [int(x[2]) for x in al],
+                "stage_busy": {k: sum(float(x[1 + i]) for x in se) for i, k in enumerate(busy)}}
     return {"alignments": int(a.group(1)), "ref_bases": int(a.group(2)), "codon_frames": int(a.group(3)), "backend_calls": int(a.group(4)),
             "seconds": float(s.group(1)), "process_wall_seconds": wall,
             "startup_seconds": (lambda u: float(u.group(1)) + float(u.group(2)) if u else None)(STARTUP_RE.search(p.stderr)),
@@ -257,6 +271,19 @@ def end_to_end(device, runs, cpu_rate_all_cores, work_dir):
                                "codon_frames": b["codon_frames"], "seconds": b["seconds"], "seconds_all_runs": [r["seconds"] for r in big_runs],
                                "codon_frames_per_s": b["codon_frames"] / b["seconds"], "backend_calls": b["backend_calls"],
                                "maf_gigabytes_per_s": os.path.getsize(big) / b["seconds"] / 1e9, "stage_busy": b["stage_busy"]}
+        # north_star's "single RCCL gather ... for the output wig stream" in the command a user runs, rehearsed on this one GPU: one process
+        # per GPU (--ranks 1), every batch's text kept on the device, one grouped RCCL send / receive (the root's text to itself), the files
+        # written from what came back -- against the plain run's files
+        try:
+            rk = min([run_cli(CLI, big, os.path.join(work_dir, "gpu_big_ranks"), ["--devices", str(device), "--ranks", "1", "--gather-root-text", "1"]) for _ in range(2)],
+                     key=lambda r: r["process_wall_seconds"])
+            e2e["steady_state"]["ranks_rehearsal"] = {
+                "command": "phylocsf-amd build-tracks --ranks 1 --gather-root-text 1 58mammals <maf>", "ranks": rk["ranks"], "seconds": rk["seconds"],
+                "gather_seconds": rk["gather_seconds_per_rank"][0], "process_wall_seconds": rk["process_wall_seconds"],
+                "plain_run_process_wall_seconds": min(r["process_wall_seconds"] for r in big_runs),
+                "wig_lines_differing_from_the_plain_run": differing_lines(os.path.join(work_dir, "gpu_big_ranks"), os.path.join(work_dir, "gpu_big"))}
+        except Exception as ex:
+            e2e["steady_state"]["ranks_rehearsal"] = {"error": str(ex)[-500:]}
         # the smoothing pass on the same file (--output-phylo 1 --output-regions 1, BASELINE.json configs[4]'s addition): the recurrences
         # on the device (default) and on the host (PCSF_HOST_HMM=1: host/hmm.hpp, six threads), the twelve smoothed files compared
         try:
@@ -306,9 +333,28 @@ def end_to_end_multi(n_gpus, work_dir):
     with contextlib.redirect_stdout(sys.stderr):
         replicate_maf.tile(maf, big, tiles, 1_100_000)
     out = {"maf": "the 1 Mb synthetic segment tiled %d times (tools/replicate_maf.py), %d bytes" % (tiles, os.path.getsize(big)), "n_gpus": n_gpus}
-    for label, devs in (("all_devices", ",".join(str(d) for d in range(n_gpus))), ("one_device", "0")):
-        runs = [run_cli(CLI, big, os.path.join(work_dir, "gpu_multi_" + label), ["--devices", devs]) for _ in range(2)]
-        b = min(runs, key=lambda r: r["seconds"])
+    all_devs = ",".join(str(d) for d in range(n_gpus))
+    for label, devs, extra in (("all_devices", all_devs, []), ("one_device", "0", []),
+                               # one PROCESS per GPU, the ranks' wig text gathered onto rank 0's GPU over RCCL (csrc/comm.cpp): north_star's form
+                               ("ranks_rccl", all_devs, ["--ranks", str(n_gpus)])):
+        try:
+            runs = [run_cli(CLI, big, os.path.join(work_dir, "gpu_multi_" + label), ["--devices", devs] + extra) for _ in range(2)]
+        except Exception as ex:
+            if label != "ranks_rccl":
+                raise
+            out[label] = {"error": str(ex)[-1500:]}
+            continue
+        b = min(runs, key=lambda r: r["seconds"] if label != "ranks_rccl" else r["process_wall_seconds"])
+        if label == "ranks_rccl":
+            out[label] = {"command": "phylocsf-amd build-tracks --devices %s --ranks %d %s <maf>" % (devs, n_gpus, MODEL_PREFIX), "codon_frames": b["codon_frames"],
+                          "ranks": b["ranks"], "devices": b["devices"], "seconds_slowest_rank": b["seconds"], "seconds_per_rank": b["seconds_per_rank"],
+                          "gather_seconds_per_rank": b["gather_seconds_per_rank"], "codon_frames_per_rank": b["codon_frames_per_rank"],
+                          "process_wall_seconds": b["process_wall_seconds"], "process_wall_seconds_all_runs": [r["process_wall_seconds"] for r in runs],
+                          "codon_frames_per_s_process_wall": b["codon_frames"] / b["process_wall_seconds"],
+                          "wig_lines_differing_from_one_device": differing_lines(os.path.join(work_dir, "gpu_multi_ranks_rccl"), os.path.join(work_dir, "gpu_multi_one_device")),
+                          "note": "rates by process wall: the launcher's N processes each pay their own HIP start-up (~0.2 s) beside the others'"}
+            out[label]["outputs_check"] = {"ranks_seen": b["ranks"], "devices_seen": len(b["devices"]), "equal": out[label]["wig_lines_differing_from_one_device"] == 0}
+            continue
         out[label] = {"command": "phylocsf-amd build-tracks --devices %s %s <maf>" % (devs, MODEL_PREFIX), "codon_frames": b["codon_frames"], "seconds": b["seconds"],
                       "seconds_all_runs": [r["seconds"] for r in runs], "process_wall_seconds": min(r["process_wall_seconds"] for r in runs),
                       "codon_frames_per_s": b["codon_frames"] / b["seconds"], "backend_calls": b["backend_calls"], "stage_busy": b["stage_busy"]}

@@ -381,6 +381,8 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend, b
         // this rank's GPU: the rank-th of --devices (taken round the list), or GPU `rank`
         devices = {devices_given ? devices[static_cast<size_t>(rank) % devices.size()] : rank};
         contexts_per_device = 1;
+        // the ranks share the host: each takes its part of the threads the process group may use
+        if (bt.threads <= 0) bt.threads = std::max(2, effective_threads() / world);
     }
     try {
         {

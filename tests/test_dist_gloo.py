@@ -205,3 +205,23 @@ def test_bench_host_ceiling_of_a_multi_device_run():
     assert c["host_threads"] >= 1
     run["stage_busy"]["wig_output"] = 2.0          # the writers as the slowest stage
     assert abs(bench.host_ceiling(run, 2)["codon_frames_per_s"] - 1e8) < 1e-3
+
+
+def test_bench_reads_the_statistics_of_a_ranks_run(tmp_path):
+    """bench.py's run_cli on a --ranks run (one statistics line per process): the ranks' work adds up to the plain run's, the run lasts as
+    long as its slowest rank.  On the test command line (CPU, file-based gather): the same driver output the GPU command line prints."""
+    import subprocess
+    import sys
+    import bench
+    syn = tmp_path / "syn.maf"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_synthetic_maf.py"), str(syn), "--bases", "30000", "--start", "985000", "--seed", "5"],
+                          stdout=subprocess.DEVNULL)
+    env = dict(os.environ, PCSF_ORACLE_BACKEND_FAKE="1")
+    plain = bench.run_cli(bench.ORACLE_CLI, str(syn), str(tmp_path / "plain"), env=env)
+    ranks = bench.run_cli(bench.ORACLE_CLI, str(syn), str(tmp_path / "ranks"), ["--ranks", "3", "--batch-sites", "6000", "--window-bytes", "150000"], env=env)
+    assert "ranks" not in plain and ranks["ranks"] == 3 and ranks["devices"] == [0, 1, 2]
+    for k in ("alignments", "ref_bases", "codon_frames"):
+        assert ranks[k] == plain[k], k
+    assert len(ranks["seconds_per_rank"]) == 3 and ranks["seconds"] == max(ranks["seconds_per_rank"])
+    assert sum(ranks["codon_frames_per_rank"]) == plain["codon_frames"]
+    assert bench.differing_lines(str(tmp_path / "plain"), str(tmp_path / "ranks")) == 0
