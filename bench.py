@@ -138,7 +138,7 @@ SECONDS_RE = re.compile(r"seconds: total ([\d.]+); .*MAF read ([\d.]+), BLS ([\d
                         r"wig output ([\d.]+) \| smoothing ([\d.]+)")
 
 
-RANK_RE = re.compile(r"\[rank (\d+) of (\d+), device (\d+)\] gather ([\d.]+) s")
+RANK_RE = re.compile(r"\[rank (\d+) of (\d+), device (\d+)\] gather ([\d.]+) s(?: \(communicator set-up ([\d.]+) s\))?")
 STARTUP_RE = re.compile(r"start-up seconds: options \+ model files ([\d.]+), first scoring context ([\d.]+)")
 
 
@@ -165,6 +165,7 @@ def run_cli(binary, maf, out_dir, extra_args=(), env=None):
                 "backend_calls": sum(int(x[3]) for x in al), "seconds": float(se[slowest][0]), "process_wall_seconds": wall,
                 "startup_seconds": None, "ranks": len(ranks), "devices": sorted(set(int(r[2]) for r in ranks)),
                 "seconds_per_rank": [float(x[0]) for x in se], "gather_seconds_per_rank": [float(r[3]) for r in ranks],
+                "communicator_setup_seconds_per_rank": [float(r[4]) if r[4] else None for r in ranks],
                 "codon_frames_per_rank": [int(x[2]) for x in al],
                 "stage_busy": {k: sum(float(x[1 + i]) for x in se) for i, k in enumerate(busy)}}
     return {"alignments": int(a.group(1)), "ref_bases": int(a.group(2)), "codon_frames": int(a.group(3)), "backend_calls": int(a.group(4)),
@@ -279,7 +280,8 @@ def end_to_end(device, runs, cpu_rate_all_cores, work_dir):
                      key=lambda r: r["process_wall_seconds"])
             e2e["steady_state"]["ranks_rehearsal"] = {
                 "command": "phylocsf-amd build-tracks --ranks 1 --gather-root-text 1 58mammals <maf>", "ranks": rk["ranks"], "seconds": rk["seconds"],
-                "gather_seconds": rk["gather_seconds_per_rank"][0], "process_wall_seconds": rk["process_wall_seconds"],
+                "gather_seconds": rk["gather_seconds_per_rank"][0], "communicator_setup_seconds": rk["communicator_setup_seconds_per_rank"][0],
+                "process_wall_seconds": rk["process_wall_seconds"],
                 "plain_run_process_wall_seconds": min(r["process_wall_seconds"] for r in big_runs),
                 "wig_lines_differing_from_the_plain_run": differing_lines(os.path.join(work_dir, "gpu_big_ranks"), os.path.join(work_dir, "gpu_big"))}
         except Exception as ex:
@@ -348,7 +350,8 @@ def end_to_end_multi(n_gpus, work_dir):
         if label == "ranks_rccl":
             out[label] = {"command": "phylocsf-amd build-tracks --devices %s --ranks %d %s <maf>" % (devs, n_gpus, MODEL_PREFIX), "codon_frames": b["codon_frames"],
                           "ranks": b["ranks"], "devices": b["devices"], "seconds_slowest_rank": b["seconds"], "seconds_per_rank": b["seconds_per_rank"],
-                          "gather_seconds_per_rank": b["gather_seconds_per_rank"], "codon_frames_per_rank": b["codon_frames_per_rank"],
+                          "gather_seconds_per_rank": b["gather_seconds_per_rank"], "communicator_setup_seconds_per_rank": b["communicator_setup_seconds_per_rank"],
+                          "codon_frames_per_rank": b["codon_frames_per_rank"],
                           "process_wall_seconds": b["process_wall_seconds"], "process_wall_seconds_all_runs": [r["process_wall_seconds"] for r in runs],
                           "codon_frames_per_s_process_wall": b["codon_frames"] / b["process_wall_seconds"],
                           "wig_lines_differing_from_one_device": differing_lines(os.path.join(work_dir, "gpu_multi_ranks_rccl"), os.path.join(work_dir, "gpu_multi_one_device")),

@@ -145,6 +145,7 @@ public:
         : ctx_(backend.context()), rank_(rank), world_(world), threads_(threads)
     {
         auto init = [this, rendezvous]() {
+            StopWatch set_up;
             char id[PCSF_COMM_ID_BYTES];
             const std::string path = rendezvous + "/rccl_id";
             if (rank_ == 0) {
@@ -169,6 +170,7 @@ public:
                 }
             }
             if (pcsf_comm_create(ctx_, rank_, world_, id) != PCSF_OK) throw std::runtime_error(std::string("pcsf_comm_create: ") + pcsf_last_error(ctx_));
+            setup_seconds_ = set_up.lap();
         };
         const char* sync = std::getenv("PCSF_COMM_INIT_SYNC");
         if (sync && sync[0] == '1') {
@@ -188,6 +190,7 @@ public:
     }
     int rank() const override { return rank_; }
     int world() const override { return world_; }
+    double setup_seconds() const override { return setup_seconds_; }
     void begin() override { check(pcsf_wig_retain_reset(ctx_)); }
     void keep_backend_text(ScoringBackend& backend, uint64_t order) override { backend.retain_wig_text(order); }
     void keep_host_text(uint64_t order, const char* const* text, const uint64_t* bytes) override { check(pcsf_wig_retain_host(ctx_, order, text, bytes)); }
@@ -227,6 +230,7 @@ private:
     }
     pcsf_ctx* ctx_;
     int rank_, world_, threads_;
+    double setup_seconds_ = 0.0;   // identifier exchange + ncclCommInitRank
     std::future<void> ready_;
     std::vector<char*> staging_;
     std::vector<uint64_t> staging_bytes_;

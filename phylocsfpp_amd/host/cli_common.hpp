@@ -487,7 +487,7 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend, b
         for (; i < argc; ++i) {
             if (cmd == "build-tracks") {
                 const BuildTracksStats st = build_tracks(model, argv[i], bt, backends, !first);
-                if (world > 0) fprintf(stderr, "[rank %d of %d, device %d] gather %.3f s | ", rank, world, devices[0], st.gather_seconds);
+                if (world > 0) fprintf(stderr, "[rank %d of %d, device %d] gather %.3f s (communicator set-up %.3f s) | ", rank, world, devices[0], st.gather_seconds, gather->setup_seconds());
                 fprintf(stderr, "%s: %zu alignments, %zu reference bases, %zu codon-frames, %zu backend calls\n", argv[i], st.alignments,
                         st.ref_bases, st.codon_frames, st.backend_calls);
                 fprintf(stderr, "  seconds: total %.3f; busy per stage (the stages overlap): MAF read %.3f, BLS %.3f, batch packing %.3f | scoring backend %.3f | wig output %.3f | smoothing %.3f\n",

@@ -239,6 +239,7 @@ struct RankGather {
     virtual ~RankGather() = default;
     virtual int rank() const = 0;
     virtual int world() const = 0;
+    virtual double setup_seconds() const { return 0.0; }   // what bringing the ranks together took (RCCL: the communicator), once known
     // a new input file begins: nothing is kept yet
     virtual void begin() = 0;
     // a batch of this rank's text (order = the batch's index in the rank's stream): where the backend's last wig call left it ...
