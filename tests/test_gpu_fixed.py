@@ -316,3 +316,50 @@ def test_tree_of_more_than_128_leaves(tmp_path, golden_dir):
     ph, an = ctx.score_blocks(pa.MLE, cod, off, compute_anc=True)
     assert np.isfinite(ph).all() and np.isfinite(an).all()
     ctx.close()
+
+
+OTHER_MODELS = ["20flies", "26worms", "12flies", "23flies", "49birds", "7yeast", "21mosquitoes", "29mammals"]
+
+
+@pytest.mark.parametrize("model", OTHER_MODELS)
+def test_the_references_other_built_in_models_score_like_the_oracle(model):
+    """The eight other models the reference compiles in (src/models.hpp:1443-1455; shipped as files, tests/golden/make_models.py): trees of
+    7 to 49 species, rate tables of their own (flies, worms, yeast, mosquitoes).  Per-codon FIXED scores against the oracle at the same
+    1e-9, six frames + branch-length scores through the fused front end, and the block strategies FIXED / MLE against the oracle's."""
+    import oracle_binding as ob
+    import phylocsfpp_amd as pa
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m = ob.OracleModel(os.path.join(root, "phylocsfpp_amd", "models", model))
+    ctx = pa.load_model(model).context(device=0, with_bls=True)
+    try:
+        cod = _columns(m, 333, seed=len(model) * 7)
+        cod[:, 5] = 64
+        cod[::3, 40:60] = 64
+        got = ctx.score_sites_fixed(cod)
+        want = m.run_tracks(cod)
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+        # six frames of two alignments from nucleotide rows, with the per-base branch-length scores
+        rng = np.random.default_rng(5)
+        nuc = np.frombuffer(b"ACGTacgtN-", dtype=np.uint8)[rng.integers(0, 10, size=(m.nl, 400))]
+        alns = [(0, 250, 1001, 5000), (250, 150, 77, 9000)]
+        from test_gpu_frontend import _frames_reference
+        res, skip, bls = ctx.score_alignments_6frames(nuc, alns, with_bls=True)
+        for k, (c0, L, sp, cl) in enumerate(alns):
+            _, want_bls = m.bls(np.ascontiguousarray(nuc[:, c0:c0 + L]))
+            assert np.array_equal(bls[c0:c0 + L], want_bls)
+            ref = _frames_reference([bytes(nuc[l, c0:c0 + L]).decode() for l in range(m.nl)], sp, cl)
+            for f in range(6):
+                rskip, fc = ref[f]
+                assert skip[k, f] == rskip and len(res[k][f]) == fc.shape[1]
+                want6 = m.run_tracks(fc)
+                np.testing.assert_allclose(res[k][f], want6[::-1] if f >= 3 else want6, rtol=RTOL, atol=ATOL)
+        # whole blocks: FIXED and MLE
+        off = np.array([0, 40, 41, 140, 333], dtype=np.uint64)
+        for algo, tol in ((1, 1e-5), (0, 0.0316)):
+            ph, an = ctx.score_blocks(algo, cod, off, compute_anc=True)
+            wph, wan = m.run_blocks(algo, cod, off, compute_anc=True)
+            assert np.array_equal(np.isnan(ph), np.isnan(wph))
+            ok = ~np.isnan(wph)
+            assert np.all(np.abs(ph[ok] - wph[ok]) <= tol + 1e-6 * np.abs(wph[ok])), (model, algo, ph, wph)
+    finally:
+        ctx.close()

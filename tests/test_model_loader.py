@@ -10,7 +10,8 @@ import pytest
 import oracle_binding as ob
 import phylocsfpp_amd as pa
 
-GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
 FIELDS = ("child1", "child2", "parent", "branch_len", "branch_len_d", "S_c", "pi_c", "S_nc", "pi_nc")
 
 
@@ -105,3 +106,36 @@ def test_shipped_models_resolve_by_name_like_the_references_command_line(tmp_pat
         shutil.copyfile(os.path.join(GOLD, "models", "53birds" + ext), str(d / ("mymodel" + ext)))
     monkeypatch.setenv("PCSF_MODEL_DIR", str(d))
     assert pa.load_model("mymodel").nl == 53
+
+
+ALL_MODELS = {"20flies": 20, "26worms": 26, "12flies": 12, "23flies": 23, "100vertebrates": 100, "49birds": 49, "53birds": 53, "7yeast": 7, "58mammals": 58,
+              "21mosquitoes": 21, "29mammals": 29}
+
+
+@pytest.mark.parametrize("name", sorted(ALL_MODELS))
+def test_every_model_the_reference_compiles_in_resolves_by_name(name):
+    """The reference's command line takes any of its eleven built-in models by name (src/models.hpp:1443-1455); they ship here as files in
+    the reference's own format (tests/golden/make_models.py wrote them from the reference's literals, digit for digit).  Every one loads
+    through the package's reader AND the oracle's independent readers with the same arrays; the tables are what an ECM must be (symmetric,
+    zero diagonal, frequencies that sum to 1); the oracle scores columns under it."""
+    import numpy as np
+    import phylocsfpp_amd as pa
+    import oracle_binding as ob
+    m = pa.load_model(name)
+    assert m.nl == ALL_MODELS[name] and m.n == 2 * m.nl - 1
+    prefix = os.path.join(ROOT, "phylocsfpp_amd", "models", name)
+    o = ob.OracleModel(prefix)
+    assert o.nl == m.nl and o.labels == m.labels
+    for a, b in ((m.S_c, o.S_c), (m.S_nc, o.S_nc), (m.pi_c, o.pi_c), (m.pi_nc, o.pi_nc), (m.branch_len, o.branch_len), (m.child1, o.child1), (m.child2, o.child2)):
+        assert np.array_equal(np.asarray(a).reshape(-1), np.asarray(b).reshape(-1))
+    for S, pi in ((o.S_c, o.pi_c), (o.S_nc, o.pi_nc)):
+        assert np.array_equal(S, S.T) and not S.diagonal().any() and (S >= 0).all() and abs(pi.sum() - 1.0) < 1e-4 and (pi > 0).all()
+    from phylocsfpp_amd import synth
+    cod = synth.synthetic_codon_columns(o.child1, o.child2, o.branch_len, o.S_c, o.pi_c, o.S_nc, o.pi_nc, 50, seed=len(name))   # columns evolved down the tree
+    s = o.run_tracks(cod)
+    assert np.all(np.isfinite(s)) and np.abs(s).max() > 0.1
+    # every tree label has its row in the name table (a MAF may use any of the species' other names)
+    aliases = {l.split("\t")[0] for l in open(os.path.join(ROOT, "phylocsfpp_amd", "models", "species_aliases.tsv"))}
+    leaves = [l for l in m.labels if l]
+    assert len(leaves) == m.nl and all(m.leaf_of(l) >= 0 for l in leaves)
+    assert sum(l in aliases for l in leaves) >= m.nl - 2, [l for l in leaves if l not in aliases]
