@@ -65,9 +65,31 @@ CLI = os.path.join(ROOT, "phylocsfpp_amd", "host", "phylocsf-amd")
 ORACLE_CLI = os.path.join(ROOT, "oracle", "_build", "oracle_cli")
 
 
-def flop_per_site(nl):
-    """both models; internal edges as 64x64 mat-vec, element-wise products, root dot."""
-    return 2 * ((nl - 2) * 2 * 64 * 64 + (nl - 1) * 64 + 2 * 64)
+def flop_per_site(nl, cherries=0):
+    """both models; internal edges as 64x64 mat-vec, element-wise products, root dot.  cherries: cherries whose message
+    comes from a pair table (kernels.hip PAIRS) -- one product and one element-wise product less each: the work of the algorithm the
+    kernel runs (every MFMA it executes is in this count: the PMC's SQ_VALU_MFMA_BUSY_CYCLES / 64 x 2,048 agrees)."""
+    return 2 * ((nl - 2 - cherries) * 2 * 64 * 64 + (nl - 1 - cherries) * 64 + 2 * 64)
+
+
+def roofline_of(ctx_info, nl, n_sites, kernel_ms):
+    """the roofline object of a prune_fixed launch: achieved on the work the kernel's algorithm does, and -- when cherry tables removed
+    products -- what the same time means in SURVEY 8(d)'s count of the table-free algorithm"""
+    cherries = ctx_info["cherries"]
+    fl, fl_full = flop_per_site(nl, cherries), flop_per_site(nl)
+    tf = n_sites * fl / (kernel_ms * 1e-3) / 1e12
+    r = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_MFMA_TFLOPS,
+         "kernel": "pcsf::prune_fixed", "kernel_ms": kernel_ms, "flop_per_codon_frame": fl}
+    if cherries:
+        tf_full = n_sites * fl_full / (kernel_ms * 1e-3) / 1e12
+        r["cherry_tables"] = {"cherries": cherries, "products_per_model": ctx_info["products_run"], "products_per_model_without_tables": ctx_info["products_full"],
+                              "table_rows_per_model": ctx_info["rows_per_table_set"], "table_bytes": ctx_info["rows_per_table_set"] * 512 * 2,
+                              "survey_8d_flop_per_codon_frame": fl_full, "survey_8d_equivalent_tflops": tf_full,
+                              "survey_8d_equivalent_frac": tf_full / PEAK_FP64_MFMA_TFLOPS,
+                              "note": "a cherry's message to its parent is looked up per codon pair (65 x 65 rows per cherry and model, made once per "
+                                      "context by the product the kernel would run: same bits): `achieved` / `frac` count the products the kernel runs; the "
+                                      "survey_8d_* figures price the same time with SURVEY 8(d)'s table-free count and can exceed the peak"}
+    return r
 
 
 def make_pool(m, seed):
@@ -662,6 +684,7 @@ def main():
     ctx.set_timing(False)
     torch.cuda.synchronize()
     kernel_ms = float(np.mean(durs))
+    tracks_info = ctx.tracks_program_info()
     codons_host = codons[:, :min(n_sites, 1 << 20)].cpu().numpy() if rank == 0 else None
     del codons, scores
 
@@ -686,12 +709,9 @@ def main():
                 c2.set_timing(False)
                 torch.cuda.synchronize()
                 ms = float(np.mean(d2))
-                fl2 = flop_per_site(m2.nl)
-                tf = args.sites * fl2 / (ms * 1e-3) / 1e12
+                r2 = roofline_of(c2.tracks_program_info(), m2.nl, args.sites, ms)
                 other_models[name] = {"n_leaves": int(m2.nl), "codon_frames": args.sites, "steps": 3, "kernel_ms": ms, "codon_frames_per_s": args.sites / (ms * 1e-3),
-                                      "flop_per_codon_frame": fl2,
-                                      "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_MFMA_TFLOPS,
-                                                   "kernel": "pcsf::prune_fixed"}}
+                                      "flop_per_codon_frame": r2["flop_per_codon_frame"], "roofline": r2}
                 c2.close()
                 del pool2, cod2, sc2
             except Exception as ex:
@@ -713,8 +733,7 @@ def main():
     torch.cuda.empty_cache()
 
     if rank == 0:
-        fl = flop_per_site(m.nl)
-        achieved = n_sites * fl / (kernel_ms * 1e-3) / 1e12
+        roof = roofline_of(tracks_info, m.nl, n_sites, kernel_ms)
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")  # per-launch HBM bytes from the committed PMC passes
         if os.path.exists(tpath):
@@ -737,9 +756,7 @@ def main():
                        "model": MODEL, "n_leaves": int(m.nl), "sites_per_gpu": n_sites,
                        "unique_columns": POOL_SITES, "sharding": "columns, gather of scores to rank 0" if gathered else "none",
                        "ref_bases_per_s": total_per_step * args.steps / elapsed / 2.0},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "pcsf::prune_fixed", "kernel_ms": kernel_ms, "flop_per_codon_frame": fl},
+            "roofline": dict(roof, traffic=traffic, traffic_source=traffic_source),
         }
         if gather_check is not None:
             out["gather_check"] = gather_check

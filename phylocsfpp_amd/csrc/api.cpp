@@ -79,6 +79,8 @@ int upload_model_tables(pcsf_ctx* c, const double* P, const pcsf::Vec prior[2])
     return PCSF_OK;
 }
 
+int build_cherry_tables(pcsf_ctx* c, const pcsf::Vec prior[2]);
+
 }  // namespace
 
 namespace pcsf {
@@ -106,10 +108,32 @@ PruneParams base_prune_params(const pcsf_ctx* c)
     return p;
 }
 
+PruneParams tracks_prune_params(const pcsf_ctx* c, int* variant_flags)
+{
+    PruneParams p = base_prune_params(c);
+    if (!c->cherry.on) return p;
+    const pcsf_ctx::CherryTables& t = c->cherry;
+    p.program = t.d_program.as<uint32_t>();
+    p.op_leaves = t.d_op_meta.ptr ? t.d_op_leaves.as<uint64_t>() : nullptr;
+    p.op_meta = t.d_op_meta.ptr ? t.d_op_meta.as<uint32_t>() : nullptr;
+    p.gap_tab = t.d_gap_tab.as<double>();
+    p.n_ops = static_cast<int>(t.schedule.program.size());
+    p.n_edges = static_cast<int>(t.schedule.slot_node.size());
+    p.frag = t.d_frag.as<double>();
+    p.leaf_tab = t.d_leaf_tab.as<double>();
+    p.pair_leaves = t.d_pair_leaves.as<uint16_t>();
+    p.n_pairs = static_cast<int>(t.pairs.size());
+    p.leaf_rows = t.leaf_rows;
+    if (variant_flags) *variant_flags |= 256;
+    return p;
+}
+
 int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t leaf_stride, double* d_out, double* d_lnz,
                  double* d_anc, hipStream_t stream, const FusedFrontEnd* fused)
 {
-    PruneParams p = base_prune_params(c);
+    int cherry_flag = 0;
+    PruneParams p = tracks_prune_params(c, &cherry_flag);
+    const int stack_depth = cherry_flag ? c->cherry.schedule.stack_depth : c->schedule.stack_depth;
     p.codons = d_codons;
     p.n_sites = n_sites;
     p.leaf_stride = leaf_stride;
@@ -126,13 +150,15 @@ int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t le
         p.dump_codons = fused->dump_codons;
         variant = 32;
     }
-    if (c->schedule.stack_depth > pcsf::MAX_STACK_DEPTH) variant = (variant == 32 ? 32 : 0) | 64;  // parked tiles in scratch memory
+    if (cherry_flag && variant != 0 && variant != 32) cherry_flag = 0, p = base_prune_params(c);   // (the 8-wave / stamped forms: the full program)
+    if (stack_depth > pcsf::MAX_STACK_DEPTH) variant = (variant == 32 ? 32 : 0) | 64;  // parked tiles in scratch memory
     // All-gap subtrees of a work-group's 64 columns cost nothing (kernels.hip SKIP).  Default: on where the columns come from
     // alignments (the six-frame entry points: species missing from a block are missing for hundreds of columns; 1.7x on a MAF with
     // clade-level drop-out, neutral on the bench's), off for the raw codon-matrix entry points, whose columns have no such structure
     // and would only pay the compaction (1.3 %).  PCSF_SKIP_ALLGAP=1 / 0 forces it on / off everywhere; scores are bit-identical.
     const bool skip = c->skip_allgap_forced ? c->skip_allgap : (fused != nullptr);
     if (skip && p.op_meta && p.gap_tab && p.n_ops <= 128 && p.n_leaves <= 128 && (variant & ~(32 | 64)) == 0) variant |= 128;
+    variant |= cherry_flag;
     hipError_t e;
     if (c->timing && (e = hipEventRecord(c->ev0, stream)) != hipSuccess) return c->hip_fail(e, "hipEventRecord");
     if ((e = launch_prune_fixed(p, variant, stream, c->extra_lds)) != hipSuccess) return c->hip_fail(e, "launch prune_fixed");
@@ -147,6 +173,107 @@ int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t le
 }
 
 }  // namespace pcsf
+
+namespace {
+
+// Cherry tables of a context (ctx.hpp CherryTables): the reduced tree's program and facts, its fragment images, the table sets --
+// leaves' rows from the host, pair rows by pair_table_kernel -- and the reduced program's all-gap messages, recorded like the full
+// program's.  Leaves the context without them (tracks mode then runs the full program) when the tree has no cherry below the root or the
+// rows would take more than a gigabyte.
+int build_cherry_tables(pcsf_ctx* c, const pcsf::Vec prior[2])
+{
+    (void)prior;
+    const int n = c->n_nodes, nl = c->n_leaves;
+    pcsf::CherryReduction red;
+    try {
+        red = pcsf::reduce_cherries(pcsf::TreeView{n, c->child1.data(), c->child2.data()});
+    } catch (const std::exception&) {
+        return PCSF_OK;
+    }
+    if (!red.any()) return PCSF_OK;
+    const size_t np = red.pairs.size();
+    const size_t leaf_rows = static_cast<size_t>(nl) * 65 + np * pcsf::PAIR_CODES;
+    if (leaf_rows * 64 * sizeof(double) * 2 > (size_t(1) << 30) || leaf_rows >= 0xffffffffull / 65) return PCSF_OK;
+    pcsf_ctx::CherryTables& t = c->cherry;
+    try {
+        t.schedule = pcsf::build_reduced_schedule(red);
+    } catch (const std::exception&) {
+        return PCSF_OK;
+    }
+    t.pairs = red.pairs;
+    t.leaf_rows = static_cast<uint32_t>(leaf_rows);
+    hipError_t e;
+    const auto& prog = t.schedule.program;
+    const int ne = static_cast<int>(t.schedule.slot_node.size());
+    if ((e = t.d_program.reserve(prog.size() * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMemcpyAsync(t.d_program.ptr, prog.data(), prog.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
+        return c->hip_fail(e, "pcsf_create (cherry tables: program)");
+    const pcsf::ProgramFacts facts = pcsf::program_facts(t.schedule, &t.pairs, nl);
+    if (facts.ok) {
+        if ((e = t.d_op_leaves.reserve(facts.leaves.size() * sizeof(uint64_t))) != hipSuccess ||
+            (e = hipMemcpyAsync(t.d_op_leaves.ptr, facts.leaves.data(), facts.leaves.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream)) != hipSuccess ||
+            (e = t.d_op_meta.reserve(facts.meta.size() * sizeof(uint32_t))) != hipSuccess ||
+            (e = hipMemcpyAsync(t.d_op_meta.ptr, facts.meta.data(), facts.meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
+            return c->hip_fail(e, "pcsf_create (cherry tables: program facts)");
+    }
+    // fragment images: the reduced program's slots, then (scratch) the cherry nodes' for the table kernel
+    std::vector<double> frag(static_cast<size_t>(2) * std::max(ne, 1) * pcsf::FRAG_DOUBLES), cfrag(2 * np * pcsf::FRAG_DOUBLES);
+    std::vector<double> leaf(static_cast<size_t>(nl) * pcsf::LEAF_TABLE_DOUBLES);
+    std::vector<uint16_t> pl(2 * np);
+    for (size_t p = 0; p < np; ++p) {
+        pl[2 * p] = static_cast<uint16_t>(red.pairs[p][0]);
+        pl[2 * p + 1] = static_cast<uint16_t>(red.pairs[p][1]);
+    }
+    pcsf::DeviceBuffer d_cfrag;
+    if ((e = t.d_frag.reserve(frag.size() * sizeof(double))) != hipSuccess || (e = d_cfrag.reserve(cfrag.size() * sizeof(double))) != hipSuccess ||
+        (e = t.d_leaf_tab.reserve(leaf_rows * 64 * sizeof(double) * 2)) != hipSuccess || (e = t.d_pair_leaves.reserve(pl.size() * sizeof(uint16_t))) != hipSuccess)
+        return c->hip_fail(e, "hipMalloc(cherry tables)");
+    for (int m = 0; m < 2; ++m) {
+        const double* Pm = c->host_P.data() + static_cast<size_t>(m) * (n - 1) * 4096;
+        for (int s = 0; s < ne; ++s)
+            pcsf::to_fragment_order(Pm + static_cast<size_t>(t.schedule.slot_node[s]) * 4096, frag.data() + (static_cast<size_t>(m) * ne + s) * pcsf::FRAG_DOUBLES);
+        for (size_t p = 0; p < np; ++p)
+            pcsf::to_fragment_order(Pm + static_cast<size_t>(red.pairs[p][2]) * 4096, cfrag.data() + (static_cast<size_t>(m) * np + p) * pcsf::FRAG_DOUBLES);
+        for (int l = 0; l < nl; ++l) pcsf::to_leaf_table(Pm + static_cast<size_t>(l) * 4096, leaf.data() + static_cast<size_t>(l) * pcsf::LEAF_TABLE_DOUBLES);
+        // (a synchronous copy: `leaf` is filled again for the second model)
+        if ((e = hipMemcpy(t.d_leaf_tab.as<double>() + static_cast<size_t>(m) * leaf_rows * 64, leaf.data(), leaf.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess)
+            return c->hip_fail(e, "hipMemcpy(cherry tables: leaf rows)");
+    }
+    if ((e = hipMemcpy(t.d_frag.ptr, frag.data(), frag.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(d_cfrag.ptr, cfrag.data(), cfrag.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(t.d_pair_leaves.ptr, pl.data(), pl.size() * sizeof(uint16_t), hipMemcpyHostToDevice)) != hipSuccess)
+        return c->hip_fail(e, "hipMemcpy(cherry tables)");
+    if ((e = pcsf::launch_pair_tables(d_cfrag.as<double>(), t.d_leaf_tab.as<double>(), t.leaf_rows, nl, static_cast<int>(np), t.d_pair_leaves.as<uint16_t>(), c->stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(c->stream)) != hipSuccess)
+        return c->hip_fail(e, "pair_table_kernel");
+    t.on = true;
+    if (c->skip_allgap && t.d_op_meta.ptr) {   // the reduced program's all-gap messages, by the reduced program itself (like the full program's above)
+        const size_t doubles = 2 * (static_cast<size_t>(ne) + 1) * 64;
+        pcsf::DeviceBuffer d_gaps;
+        if ((e = t.d_gap_tab.reserve(doubles * sizeof(double))) != hipSuccess || (e = d_gaps.reserve(static_cast<size_t>(nl) * 64)) != hipSuccess ||
+            (e = hipMemsetAsync(t.d_gap_tab.ptr, 0, doubles * sizeof(double), c->stream)) != hipSuccess ||
+            (e = hipMemsetAsync(d_gaps.ptr, 64, static_cast<size_t>(nl) * 64, c->stream)) != hipSuccess) {
+            t.on = false;
+            return c->hip_fail(e, "pcsf_create (cherry tables: all-gap messages)");
+        }
+        int flag = 0;
+        pcsf::PruneParams gp = pcsf::tracks_prune_params(c, &flag);
+        gp.gap_tab = nullptr;
+        gp.gap_dump = t.d_gap_tab.as<double>();
+        gp.stamps = nullptr;
+        gp.codons = d_gaps.as<uint8_t>();
+        gp.n_sites = 64;
+        gp.leaf_stride = 64;
+        if ((e = pcsf::launch_prune_fixed(gp, 256 | (t.schedule.stack_depth > pcsf::MAX_STACK_DEPTH ? 66 : 2), c->stream, 0)) != hipSuccess ||
+            (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
+            t.on = false;
+            return c->hip_fail(e, "pcsf_create (cherry tables: all-gap messages)");
+        }
+    }
+    return PCSF_OK;
+}
+
+}  // namespace
 
 namespace pcsf {
 // Branch-length scores of the columns in `spans` of the DEVICE-resident rows d_nucl[n_leaves][d_stride]: enqueues
@@ -347,6 +474,40 @@ int pcsf_build_schedule(int32_t n_nodes, const int16_t* child1, const int16_t* c
     return PCSF_OK;
 }
 
+int pcsf_tracks_program_info(const pcsf_ctx* c, int64_t* out)
+{
+    if (!c || !out) return PCSF_ERR_INVALID_ARG;
+    out[0] = static_cast<int64_t>(c->schedule.slot_node.size());
+    out[1] = c->cherry.on ? static_cast<int64_t>(c->cherry.schedule.slot_node.size()) : out[0];
+    out[2] = c->cherry.on ? static_cast<int64_t>(c->cherry.pairs.size()) : 0;
+    out[3] = c->cherry.on ? static_cast<int64_t>(c->cherry.leaf_rows) : static_cast<int64_t>(c->n_leaves) * 65;
+    return PCSF_OK;
+}
+
+int pcsf_debug_cherry_schedule(int32_t n_nodes, const int16_t* child1, const int16_t* child2, uint32_t* program, int32_t program_cap, int32_t* slot_node, int32_t* n_ops,
+                               int32_t* n_slots, int32_t* stack_depth, int32_t* pairs, int32_t* n_pairs)
+{
+    if (!child1 || !child2 || !program || !slot_node || !n_ops || !n_slots || !stack_depth || !pairs || !n_pairs) return PCSF_ERR_INVALID_ARG;
+    try {
+        const pcsf::CherryReduction red = pcsf::reduce_cherries(pcsf::TreeView{n_nodes, child1, child2});
+        *n_pairs = static_cast<int32_t>(red.pairs.size());
+        if (!red.any()) return PCSF_OK;
+        const pcsf::Schedule s = pcsf::build_reduced_schedule(red);
+        if (static_cast<int32_t>(s.program.size()) > program_cap) return PCSF_ERR_INVALID_ARG;
+        std::copy(s.program.begin(), s.program.end(), program);
+        std::copy(s.slot_node.begin(), s.slot_node.end(), slot_node);
+        *n_ops = static_cast<int32_t>(s.program.size());
+        *n_slots = static_cast<int32_t>(s.slot_node.size());
+        *stack_depth = s.stack_depth;
+        for (size_t p = 0; p < red.pairs.size(); ++p)
+            for (int k = 0; k < 3; ++k) pairs[3 * p + k] = red.pairs[p][k];
+    } catch (const std::exception& ex) {
+        g_create_error = std::string("pcsf_debug_cherry_schedule: ") + ex.what();
+        return PCSF_ERR_INVALID_ARG;
+    }
+    return PCSF_OK;
+}
+
 int pcsf_debug_program_facts(int32_t n_nodes, const int16_t* child1, const int16_t* child2, uint64_t* leaves, uint32_t* meta, int32_t cap_ops)
 {
     if (!child1 || !child2 || !leaves || !meta) return PCSF_ERR_INVALID_ARG;
@@ -510,6 +671,13 @@ int pcsf_create(pcsf_ctx** out, const pcsf_model_desc* m, int device_id)
     if (const char* v = std::getenv("PCSF_PRUNE_VARIANT")) {
         const int vi = std::atoi(v);
         if (vi >= 0 && vi < pcsf::prune_variant_count()) c->variant = vi;
+    }
+    {   // cherry tables (PCSF_CHERRY_TABLES=0: tracks mode runs the full program -- the A/B switch; same bits either way)
+        const char* v = std::getenv("PCSF_CHERRY_TABLES");
+        if (!(v && v[0] == '0') && (rc = build_cherry_tables(c.get(), prior)) != PCSF_OK) {
+            g_create_error = c->error;
+            return rc;
+        }
     }
     *out = c.release();
     return PCSF_OK;

@@ -159,6 +159,16 @@ struct pcsf_ctx {
     pcsf::DeviceBuffer d_program, d_frag, d_leaf_tab, d_prior, d_anc_weight;
     pcsf::DeviceBuffer d_op_leaves, d_op_meta;  // schedule.hpp ProgramFacts of the program (empty for trees of more than 128 leaves)
     pcsf::DeviceBuffer d_gap_tab;               // [2][n_edges + 1][64] messages of all-gap subtrees, recorded by the full kernel (kernels.hip SKIP)
+    // Cherry tables (kernels.hip PAIRS, schedule.hpp reduce_cherries): what tracks mode runs when the tree has cherries -- the program of
+    // the tree whose cherries are leaves, its fragment images, the leaves' rows followed by the cherries' pair rows, its all-gap messages.
+    // The block kernels (per-evaluation branch lengths) keep the full program above.
+    struct CherryTables {
+        bool on = false;
+        pcsf::Schedule schedule;
+        std::vector<std::array<int, 3>> pairs;
+        uint32_t leaf_rows = 0;             // per table set: n_leaves * 65 + pairs * 65 * 65
+        pcsf::DeviceBuffer d_program, d_op_leaves, d_op_meta, d_frag, d_leaf_tab, d_gap_tab, d_pair_leaves;
+    } cherry;
     // scratch for the host-pointer entry points
     pcsf::DeviceBuffer d_codons, d_out, d_lnz, d_anc, d_stamps, d_nucl, d_segments, d_wg_seg;
     bool dump_codons = false;            // diagnostics (PCSF_DUMP_CODONS=1): the fused front end also writes its codons to d_codons
@@ -243,8 +253,10 @@ inline hipError_t upload_rows(void* dst, const void* src, size_t src_pitch, size
     if (src_pitch == width || rows <= 1) return hipMemcpyAsync(dst, src, width * rows, hipMemcpyHostToDevice, stream);
     return hipMemcpy2DAsync(dst, width, src, src_pitch, width, rows, hipMemcpyHostToDevice, stream);
 }
-// fills the kernel parameters that describe the resident model (tables of sets 0 and 1)
+// fills the kernel parameters that describe the resident model (tables of sets 0 and 1): the full program (block kernels, per-block tables)
 PruneParams base_prune_params(const pcsf_ctx* c);
+// ... and what tracks mode runs: the cherry-table form when the context has one (*variant_flags |= 256), else the same
+PruneParams tracks_prune_params(const pcsf_ctx* c, int* variant_flags);
 // the six-frame front end fused into the pruning kernel: device pointers of one call
 struct FusedFrontEnd {
     const unsigned char* nucl;

@@ -41,6 +41,14 @@ __device__ __forceinline__ const double2_t* leaf_row_ptr(const double* __restric
     return reinterpret_cast<const double2_t*>(leaf_tab + (static_cast<size_t>(leaf) * 65 + code) * 64) + g4;
 }
 
+// PAIRS: `code` is the row of the table set (leaves' rows, then the cherries' pair rows)
+template <bool PAIRS>
+__device__ __forceinline__ const double2_t* operand_row_ptr(const double* __restrict__ leaf_tab, int leaf, uint32_t code, int g4)
+{
+    if constexpr (PAIRS) return reinterpret_cast<const double2_t*>(leaf_tab + static_cast<size_t>(code) * 64) + g4;
+    else return leaf_row_ptr(leaf_tab, leaf, code, g4);
+}
+
 __device__ __forceinline__ LeafRow load_leaf_row(const double* __restrict__ leaf_tab, int leaf, uint32_t code, int g4)
 {
     const double2_t* r2 = leaf_row_ptr(leaf_tab, leaf, code, g4);
@@ -132,7 +140,11 @@ __device__ __forceinline__ unsigned long long stamp_now()
 // message instead of its product (`gap_before`).  Every score is BIT-IDENTICAL to the full program's: the recorded vectors are the
 // full program's own values.
 
-template <int NW, bool STAMP, bool BLOCKS, bool FUSED, bool DEEP, bool SKIP>
+// PAIRS (tracks mode, the context's own branch lengths): cherry tables.  A cherry's message to its parent depends on the column only
+// through its two codons: the context holds it per codon pair (pair_table_kernel below made the rows with this kernel's own product), the
+// program is the one of the tree whose cherries are leaves, and a leaf operand is a ROW of the table set -- leaf l: row 65 l + codon; cherry
+// p: row 65 n_leaves + 4225 p + 65 a + b.  One product less per cherry and model; the same bits as the full program.
+template <int NW, bool STAMP, bool BLOCKS, bool FUSED, bool DEEP, bool SKIP, bool PAIRS>
 __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -245,6 +257,29 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     for (int i = tid; i < p.n_ops; i += NW * 64) lprog[i] = p.program[i];
     const unsigned char* my_cod = lcod + wave * 16 + sl;  // + leaf*SITES
     __syncthreads();
+    // PAIRS: the pair code 65 a + b of every cherry and site
+    uint16_t* lpair = reinterpret_cast<uint16_t*>(lds_raw + p.pair_lds_offset);
+    const uint16_t* my_pair = lpair + wave * 16 + sl;     // + pair*SITES
+    (void)my_pair;
+    if constexpr (PAIRS) {
+        static_assert(!BLOCKS, "per-block table sets have no pair rows");
+        for (int idx = tid; idx < p.n_pairs * SITES; idx += NW * 64) {
+            const int pp = idx / SITES, s = idx - pp * SITES;
+            const unsigned la = p.pair_leaves[2 * pp], lb = p.pair_leaves[2 * pp + 1];
+            lpair[idx] = static_cast<uint16_t>(lcod[la * SITES + s] * 65u + lcod[lb * SITES + s]);
+        }
+        if constexpr (!SKIP) __syncthreads();   // (SKIP: its own barriers below come before the first use)
+    }
+    // a leaf operand of an op word -> what the row look-up takes: the codon, or with PAIRS the row itself
+    auto operand_row = [&](uint32_t x) __attribute__((always_inline)) -> uint32_t {
+        if constexpr (!PAIRS) {
+            return my_cod[x * SITES];
+        } else {
+            if (x < PAIR_OPERAND_BASE_DEV) return x * 65u + my_cod[x * SITES];
+            const uint32_t pp = x - PAIR_OPERAND_BASE_DEV;
+            return static_cast<uint32_t>(p.n_leaves) * 65u + pp * PAIR_CODES_DEV + my_pair[pp * SITES];
+        }
+    };
     // SKIP: the work-group's own program (see above), built by wave 0 from the leaves that have a codon in any of its columns
     __shared__ unsigned long long lhas[2];
     __shared__ uint32_t lprog2[SKIP ? 128 : 1];
@@ -438,7 +473,8 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     };
     (void)gap_message;
     for (int model = 0; model < p.n_passes; ++model) {
-        const double* __restrict__ leaf_tab = p.leaf_tab + static_cast<size_t>(table0 + model) * p.n_leaves * LEAF_TABLE_DOUBLES_DEV;
+        const double* __restrict__ leaf_tab = p.leaf_tab + (PAIRS ? static_cast<size_t>(table0 + model) * p.leaf_rows * 64
+                                                                  : static_cast<size_t>(table0 + model) * p.n_leaves * LEAF_TABLE_DOUBLES_DEV);
         const double* __restrict__ prior = p.prior + static_cast<size_t>(prior0 + model) * 64 + g4 * 16;
 
         double cur[16];
@@ -463,7 +499,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
         uint32_t word_ahead = prog[n_run > 1 ? 1 : 0];
         uint32_t info = SKIP ? __builtin_amdgcn_readfirstlane(linfo2[0]) : 0u, info_ahead = SKIP ? linfo2[n_run > 1 ? 1 : 0] : 0u;
         (void)info_ahead;
-        uint32_t ca = my_cod[((op >> 14) & 0x3fff) * SITES], cb = my_cod[(op & 0x3fff) * SITES];
+        uint32_t ca = operand_row((op >> 14) & 0x3fff), cb = operand_row(op & 0x3fff);
         for (int ip = 0; ip < n_run; ++ip) {
             PCSF_STAMP_RAW(7)
             const uint32_t code = op >> 28;
@@ -480,8 +516,8 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
             info = __builtin_amdgcn_readfirstlane(info_ahead);                       \
             info_ahead = linfo2[ip + 2 < n_run ? ip + 2 : n_run - 1];                \
         }                                                                            \
-        ca = my_cod[((op >> 14) & 0x3fff) * SITES];                                  \
-        cb = my_cod[(op & 0x3fff) * SITES];                                          \
+        ca = operand_row((op >> 14) & 0x3fff);                                       \
+        cb = operand_row(op & 0x3fff);                                               \
     }
             // SKIP: table slot of the op's edge | 0x8000: the op runs a product | 0x4000: the walk's message before the op is all gaps
             const uint32_t op_flags = info & 0xffffu, op_next = info >> 16;   // of THIS op: `info` moves on to the next op with `op`
@@ -544,8 +580,8 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     }
 #define PCSF_PUSH_CHERRY(D)                                                          \
     {                                                                                \
-        const double2_t* pa = leaf_row_ptr(leaf_tab, a, cod_a, g4);                  \
-        const double2_t* pb = leaf_row_ptr(leaf_tab, b, cod_b, g4);                  \
+        const double2_t* pa = operand_row_ptr<PAIRS>(leaf_tab, a, cod_a, g4);        \
+        const double2_t* pb = operand_row_ptr<PAIRS>(leaf_tab, b, cod_b, g4);        \
         LeafRow ra, rb;                                                              \
         if (gap_before) {   /* SKIP: the recorded message of the all-gap subtree is parked instead of a product */ \
             gap_message(model * (p.n_edges + 1) + static_cast<int>(op_flags & 0x3fffu), stk[D]); \
@@ -590,8 +626,14 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     }
             switch (code) {
                 case F_CHERRY_DEV: {
-                    const LeafRow ra = load_leaf_row(leaf_tab, a, cod_a, g4);
-                    const LeafRow rb = load_leaf_row(leaf_tab, b, cod_b, g4);
+                    const double2_t* pa = operand_row_ptr<PAIRS>(leaf_tab, a, cod_a, g4);
+                    const double2_t* pb = operand_row_ptr<PAIRS>(leaf_tab, b, cod_b, g4);
+                    LeafRow ra, rb;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        ra.v[i] = pa[i * ROW_PIECE_STRIDE];
+                        rb.v[i] = pb[i * ROW_PIECE_STRIDE];
+                    }
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         cur[2 * i] = ra.v[i].x * rb.v[i].x;
@@ -600,7 +642,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
                     break;
                 }
                 case F_MM_LEAF_DEV: {
-                    const double2_t* pa = leaf_row_ptr(leaf_tab, a, cod_a, g4);
+                    const double2_t* pa = operand_row_ptr<PAIRS>(leaf_tab, a, cod_a, g4);
                     LeafRow ra;
                     if (gap_before) {   // SKIP: the subtree below is all gaps: its recorded message, then the leaf as usual
                         gap_message(model * (p.n_edges + 1) + static_cast<int>(op_flags & 0x3fffu), acc);
@@ -719,20 +761,29 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     }
 }
 
-template <int NW, bool STAMP, bool BLOCKS, bool FUSED = false, bool DEEP = false, bool SKIP = false>
-static hipError_t launch_impl(const PruneParams& p, hipStream_t stream, size_t extra_lds)
+template <int NW, bool STAMP, bool BLOCKS, bool FUSED = false, bool DEEP = false, bool SKIP = false, bool PAIRS = false>
+static hipError_t launch_impl(const PruneParams& p_in, hipStream_t stream, size_t extra_lds)
 {
+    PruneParams p = p_in;
     if (SKIP && (!p.op_leaves || !p.op_meta || p.n_ops > 128 || p.n_leaves > 128)) return hipErrorInvalidValue;
+    if (PAIRS && (!p.pair_leaves || p.n_pairs <= 0 || p.leaf_rows != static_cast<uint32_t>(p.n_leaves) * 65u + static_cast<uint32_t>(p.n_pairs) * PAIR_CODES_DEV)) return hipErrorInvalidValue;
     const size_t sites_per_block = static_cast<size_t>(NW) * 16;
     const size_t blocks = BLOCKS ? p.n_wgs : (p.n_sites + sites_per_block - 1) / sites_per_block;
     if (blocks == 0) return hipSuccess;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     size_t lds = 2 * FRAG_DOUBLES_DEV * sizeof(double) + ((static_cast<size_t>(p.n_ops) + 3) & ~size_t(3)) * 4 +
-                 static_cast<size_t>(p.n_leaves) * sites_per_block + extra_lds;
+                 static_cast<size_t>(p.n_leaves) * sites_per_block;
     if (FUSED) {
         if (!p.nucl || !p.segments || !p.wg_first_seg) return hipErrorInvalidValue;
         lds = ((lds + 15) & ~size_t(15)) + 256 + sites_per_block * 9 + 16;  // character classes, codon starts, strands
     }
+    p.pair_lds_offset = 0;
+    if (PAIRS) {   // the work-group's pair codes: two bytes per cherry and site
+        lds = (lds + 15) & ~size_t(15);
+        p.pair_lds_offset = static_cast<uint32_t>(lds);
+        lds += static_cast<size_t>(p.n_pairs) * sites_per_block * 2;
+    }
+    lds += extra_lds;
     if (lds > 160 * 1024 - (SKIP ? 2048 : 0)) return hipErrorInvalidValue;   // SKIP: 1 KiB of static LDS beside the dynamic array
     // the attribute belongs to the (function, device) pair: one flag per template instantiation AND device.  Setting it
     // twice is harmless, so concurrent first launches from two host threads need no lock, only an atomic bit mask.
@@ -740,11 +791,11 @@ static hipError_t launch_impl(const PruneParams& p, hipStream_t stream, size_t e
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     if (!(attr_set.load(std::memory_order_acquire) >> (dev & 63) & 1)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prune_fixed<NW, STAMP, BLOCKS, FUSED, DEEP, SKIP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (SKIP ? 2048 : 0));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prune_fixed<NW, STAMP, BLOCKS, FUSED, DEEP, SKIP, PAIRS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (SKIP ? 2048 : 0));
         if (e != hipSuccess) return e;
         attr_set.fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
     }
-    hipLaunchKernelGGL((prune_fixed<NW, STAMP, BLOCKS, FUSED, DEEP, SKIP>), dim3(static_cast<unsigned>(blocks)), dim3(NW * 64), lds, stream, p);
+    hipLaunchKernelGGL((prune_fixed<NW, STAMP, BLOCKS, FUSED, DEEP, SKIP, PAIRS>), dim3(static_cast<unsigned>(blocks)), dim3(NW * 64), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -765,8 +816,58 @@ hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t str
         case 128 + 32: return launch_impl<4, false, false, true, false, true>(p, stream, extra_lds);
         case 128 + 64: return launch_impl<4, false, false, false, true, true>(p, stream, extra_lds);
         case 128 + 64 + 32: return launch_impl<4, false, false, true, true, true>(p, stream, extra_lds);
+        // + 256: cherry tables (the reduced tree's program; the context's own branch lengths)
+        case 256: return launch_impl<4, false, false, false, false, false, true>(p, stream, extra_lds);
+        case 256 + 2: return launch_impl<4, true, false, false, false, false, true>(p, stream, extra_lds);
+        case 256 + 32: return launch_impl<4, false, false, true, false, false, true>(p, stream, extra_lds);
+        case 256 + 64: return launch_impl<4, false, false, false, true, false, true>(p, stream, extra_lds);
+        case 256 + 64 + 2: return launch_impl<4, true, false, false, true, false, true>(p, stream, extra_lds);
+        case 256 + 64 + 32: return launch_impl<4, false, false, true, true, false, true>(p, stream, extra_lds);
+        case 256 + 128: return launch_impl<4, false, false, false, false, true, true>(p, stream, extra_lds);
+        case 256 + 128 + 32: return launch_impl<4, false, false, true, false, true, true>(p, stream, extra_lds);
+        case 256 + 128 + 64: return launch_impl<4, false, false, false, true, true, true>(p, stream, extra_lds);
+        case 256 + 128 + 64 + 32: return launch_impl<4, false, false, true, true, true, true>(p, stream, extra_lds);
         default: return hipErrorInvalidValue;
     }
+}
+
+// The pair rows of the cherries (PAIRS): one work-group = 64 pair codes of one cherry and model; a lane multiplies the two leaf rows of
+// its pair like the CHERRY arm above does and runs product() -- the instruction sequence the full program runs on the cherry's edge,
+// so the row holds the bits the full program would compute -- and stores the result as a leaf row.
+__global__ __launch_bounds__(256) void pair_table_kernel(const double* __restrict__ frag, double* __restrict__ leaf_tab_all, uint32_t leaf_rows, int n_leaves, int n_pairs,
+                                                         const uint16_t* __restrict__ pair_leaves)
+{
+    __shared__ __attribute__((aligned(16))) double2_t lfrag[FRAG_DOUBLES_DEV / 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sl = lane & 15, g4 = lane >> 4;
+    const int model = blockIdx.z, pp = blockIdx.y;
+    const double2_t* src = reinterpret_cast<const double2_t*>(frag + (static_cast<size_t>(model) * n_pairs + pp) * FRAG_DOUBLES_DEV);
+    for (int i = tid; i < FRAG_DOUBLES_DEV / 2; i += 256) lfrag[i] = src[i];
+    __syncthreads();
+    const uint32_t code = blockIdx.x * 64u + wave * 16u + sl;
+    const bool valid = code < PAIR_CODES_DEV;
+    const uint32_t cc = valid ? code : 0u, ca = cc / 65u, cb = cc % 65u;
+    double* leaf_tab = leaf_tab_all + static_cast<size_t>(model) * leaf_rows * 64;
+    const LeafRow ra = load_leaf_row(leaf_tab, pair_leaves[2 * pp], ca, g4), rb = load_leaf_row(leaf_tab, pair_leaves[2 * pp + 1], cb, g4);
+    double cur[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        cur[2 * i] = ra.v[i].x * rb.v[i].x;
+        cur[2 * i + 1] = ra.v[i].y * rb.v[i].y;
+    }
+    double4_t acc[4];
+    product(lfrag, lane, cur, acc, [](auto, auto) {});
+    if (valid) {
+        double2_t* dst = reinterpret_cast<double2_t*>(leaf_tab + (static_cast<size_t>(n_leaves) * 65 + static_cast<size_t>(pp) * PAIR_CODES_DEV + code) * 64) + g4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i * ROW_PIECE_STRIDE] = double2_t{acc[(2 * i) >> 2][(2 * i) & 3], acc[(2 * i + 1) >> 2][(2 * i + 1) & 3]};
+    }
+}
+
+hipError_t launch_pair_tables(const double* frag, double* leaf_tab, uint32_t leaf_rows, int n_leaves, int n_pairs, const uint16_t* pair_leaves, hipStream_t stream)
+{
+    if (n_pairs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pair_table_kernel, dim3((PAIR_CODES_DEV + 63) / 64, static_cast<unsigned>(n_pairs), 2), dim3(256), 0, stream, frag, leaf_tab, leaf_rows, n_leaves, n_pairs, pair_leaves);
+    return hipGetLastError();
 }
 
 int prune_variant_count() { return 3; }   // variants selectable with PCSF_VARIANT (0, 1, 2); block / fused / deep-tree forms are chosen by the entry points

@@ -9,6 +9,7 @@
 #pragma once
 
 #include <algorithm>
+#include <array>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -207,15 +208,97 @@ struct ProgramFacts {
     std::vector<uint32_t> meta;     // [n_ops]: slot | depth << 14 | parking op << 18
 };
 
-inline ProgramFacts program_facts(const Schedule& s)
+// Cherry tables (round 6; tracks mode, the model's own branch lengths): a cherry -- an internal node whose two children are leaves --
+// sends its parent P_c (P_A[:, a] o P_B[:, b]), a vector that depends on the column only through the codon PAIR (a, b): 65 x 65 rows
+// of 64 doubles per cherry and model, made once per context by the product the kernel would run (kernels.hip pair_table_kernel:
+// the same multiplies, the same MFMA sequence, so the same bits).  The cherry then IS a leaf -- of a reduced tree whose program has
+// one product less per cherry (58mammals: 39 instead of 56 per model) -- with the pair code as its "codon".  An op-word operand
+// below PAIR_OPERAND_BASE is a leaf of the original tree, PAIR_OPERAND_BASE + p the p-th cherry.
+constexpr int PAIR_OPERAND_BASE = 8192;
+constexpr int PAIR_CODES = 65 * 65;
+
+struct CherryReduction {
+    std::vector<std::array<int, 3>> pairs;   // leaf A (child1), leaf B (child2), the cherry node
+    std::vector<int16_t> child1, child2;     // the reduced tree, numbered like newick_flatten numbers a tree (leaves first, children before parents, root last)
+    std::vector<int> operand;                // [reduced leaf]: what the op words name
+    std::vector<int> node;                   // [reduced node] -> node of the original tree (its branch matrix; a pair leaf: the cherry node)
+    bool any() const { return !pairs.empty(); }
+};
+
+inline CherryReduction reduce_cherries(const TreeView& t)
+{
+    validate_tree(t);
+    CherryReduction r;
+    const int n = t.n_nodes, nl = t.n_leaves();
+    std::vector<int> cherry_of(n, -1);   // leaf -> its cherry node
+    for (int v = nl; v < n - 1; ++v)     // (the root sends no message: a two-leaf tree keeps its cherry)
+        if (t.child1[v] < nl && t.child2[v] < nl) {
+            cherry_of[t.child1[v]] = cherry_of[t.child2[v]] = v;
+            r.pairs.push_back({t.child1[v], t.child2[v], v});
+        }
+    if (r.pairs.empty() || nl >= PAIR_OPERAND_BASE || static_cast<int>(r.pairs.size()) >= 16384 - PAIR_OPERAND_BASE) {
+        r.pairs.clear();
+        return r;
+    }
+    std::vector<int> new_id(n, -1);
+    for (int l = 0; l < nl; ++l)
+        if (cherry_of[l] < 0) {
+            new_id[l] = static_cast<int>(r.node.size());
+            r.operand.push_back(l);
+            r.node.push_back(l);
+        }
+    for (size_t p = 0; p < r.pairs.size(); ++p) {
+        new_id[r.pairs[p][2]] = static_cast<int>(r.node.size());
+        r.operand.push_back(PAIR_OPERAND_BASE + static_cast<int>(p));
+        r.node.push_back(r.pairs[p][2]);
+    }
+    const size_t n_red_leaves = r.node.size();
+    r.child1.assign(n_red_leaves, -1);
+    r.child2.assign(n_red_leaves, -1);
+    for (int v = nl; v < n; ++v) {
+        if (new_id[v] >= 0) continue;    // a cherry: already a leaf
+        new_id[v] = static_cast<int>(r.node.size());
+        r.node.push_back(v);
+        r.child1.push_back(static_cast<int16_t>(new_id[t.child1[v]]));
+        r.child2.push_back(static_cast<int16_t>(new_id[t.child2[v]]));
+    }
+    return r;
+}
+
+// the program of the reduced tree, its leaf operands renamed to what the kernel looks up, its slots to the original tree's nodes
+inline Schedule build_reduced_schedule(const CherryReduction& r)
+{
+    Schedule s = build_schedule(TreeView{static_cast<int>(r.node.size()), r.child1.data(), r.child2.data()});
+    for (uint32_t& op : s.program) {
+        const uint32_t code = op >> 28;
+        const int a = static_cast<int>((op >> 14) & 0x3fff), b = static_cast<int>(op & 0x3fff);
+        if (code == F_CHERRY || (code >= F_MM_PUSH_CHERRY0 && code < F_MM_POP0)) op = (code << 28) | (static_cast<uint32_t>(r.operand[a]) << 14) | static_cast<uint32_t>(r.operand[b]);
+        else if (code == F_MM_LEAF) op = (code << 28) | (static_cast<uint32_t>(r.operand[a]) << 14);
+    }
+    for (int& v : s.slot_node) v = r.node[v];
+    return s;
+}
+
+// (pairs: the cherries behind operands >= PAIR_OPERAND_BASE of a reduced program; n_leaves: leaves of the ORIGINAL tree, which the sets are over)
+inline ProgramFacts program_facts(const Schedule& s, const std::vector<std::array<int, 3>>* pairs = nullptr, int n_leaves = -1)
 {
     ProgramFacts f;
     const size_t n_ops = s.program.size();
-    if (s.n_leaves > 128 || n_ops >= (1u << 14)) return f;
+    if ((n_leaves < 0 ? s.n_leaves : n_leaves) > 128 || n_ops >= (1u << 14)) return f;
     f.leaves.assign(2 * n_ops, 0);
     f.meta.assign(n_ops, 0);
     struct Set { uint64_t w[2] = {0, 0}; };
-    auto with = [](Set x, int leaf) { x.w[leaf >> 6] |= uint64_t(1) << (leaf & 63); return x; };
+    auto with = [pairs](Set x, int leaf) {
+        if (leaf >= PAIR_OPERAND_BASE && pairs) {
+            for (int k = 0; k < 2; ++k) {
+                const int l = (*pairs)[static_cast<size_t>(leaf - PAIR_OPERAND_BASE)][k];
+                x.w[l >> 6] |= uint64_t(1) << (l & 63);
+            }
+            return x;
+        }
+        x.w[leaf >> 6] |= uint64_t(1) << (leaf & 63);
+        return x;
+    };
     Set cur;
     std::vector<std::pair<Set, uint32_t>> parked;   // (leaves of the parked message, index of the parking op)
     uint32_t slot = 0;

@@ -1,0 +1,102 @@
+"""GPU: cherry tables (csrc/schedule.hpp reduce_cherries, kernels.hip PAIRS / pair_table_kernel).  Tracks mode runs the program of the tree
+whose cherries are leaves: a cherry's message to its parent is a row of a 65 x 65 table per cherry and model, made once per context by the
+product the full program would run.  The claim is BIT-IDENTITY with the full program (PCSF_CHERRY_TABLES=0), on every entry point that
+runs prune_fixed in tracks mode; parity with the oracle is what every other GPU test of the FIXED path already holds the default form to."""
+import os
+
+import numpy as np
+import pytest
+
+from phylocsfpp_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _two_contexts(name, monkeypatch, **kw):
+    import phylocsfpp_amd as pa
+    model = pa.load_model(name)
+    monkeypatch.setenv("PCSF_CHERRY_TABLES", "0")
+    full = model.context(device=0, **kw)
+    monkeypatch.delenv("PCSF_CHERRY_TABLES")
+    tab = model.context(device=0, **kw)
+    return model, full, tab
+
+
+@pytest.mark.parametrize("name", ["53birds", "58mammals", "100vertebrates", "7yeast", "12flies", "29mammals"])
+def test_cherry_tables_give_the_full_programs_bits(name, monkeypatch):
+    model, full, tab = _two_contexts(name, monkeypatch, with_bls=True)
+    try:
+        assert model.nl >= 7
+        red = __import__("phylocsfpp_amd").build_cherry_schedule(model.child1, model.child2)
+        assert red is not None and len(red[3]) >= 1
+        cod = synth.synthetic_codon_columns(model.child1, model.child2, model.branch_len, model.S_c, model.pi_c, model.S_nc, model.pi_nc, 4000, seed=3)
+        rng = np.random.default_rng(1)
+        cod[:, 100:140] = 64                                   # all-gap columns
+        cod[rng.integers(0, model.nl, 500), rng.integers(0, 4000, 500)] = 64
+        cod[::2, 200:300] = 64                                 # one leaf of many cherries a gap
+        cod[:, 300:400] = rng.integers(0, 65, size=(model.nl, 100))   # unrelated codons: every pair row is somebody's
+        a, b = full.score_sites_fixed(cod), tab.score_sites_fixed(cod)
+        assert np.array_equal(a, b, equal_nan=True), np.abs(a - b).max()
+        assert np.isfinite(a[:100]).all()
+        # the six-frame entry point (fused front end, all-gap subtrees skipped per work-group) and the branch-length scores beside it
+        nuc = np.frombuffer(b"ACGTacgtN-", dtype=np.uint8)[rng.integers(0, 10, size=(model.nl, 3000))]
+        nuc[model.nl // 2:, 500:1500] = ord("-")               # half the species missing over a long stretch
+        nuc[:, 2000:2200] = ord("N")
+        alns = [(0, 1700, 1001, 50000), (1700, 1300, 77, 90000)]
+        ra, _, ba = full.score_alignments_6frames(nuc, alns, with_bls=True)
+        rb, _, bb = tab.score_alignments_6frames(nuc, alns, with_bls=True)
+        assert np.array_equal(ba, bb)
+        for k in range(2):
+            for f in range(6):
+                assert np.array_equal(ra[k][f], rb[k][f], equal_nan=True), (k, f)
+        # FIXED block scores run the same kernel
+        off = np.array([0, 40, 41, 140, 1000, 4000], dtype=np.uint64)
+        pa_, aa = full.score_blocks(1, cod, off, compute_anc=True)
+        pb_, ab = tab.score_blocks(1, cod, off, compute_anc=True)
+        assert np.array_equal(pa_, pb_, equal_nan=True) and np.array_equal(aa, ab, equal_nan=True)
+    finally:
+        full.close()
+        tab.close()
+
+
+def test_cherry_tables_on_a_tree_deeper_than_the_register_stack(monkeypatch):
+    """a balanced 64-leaf tree: 32 cherries, five parked tiles in the full program (the DEEP variants), fewer in the reduced one"""
+    import phylocsfpp_amd as pa
+    m = pa.load_model("58mammals")
+    nl = 64
+    c1, c2 = [-1] * (2 * nl - 1), [-1] * (2 * nl - 1)
+    nxt = [nl]
+
+    def build(lo, hi):
+        if hi - lo == 1:
+            return lo
+        mid = (lo + hi) // 2
+        a, b = build(lo, mid), build(mid, hi)
+        i = nxt[0]
+        nxt[0] += 1
+        c1[i], c2[i] = a, b
+        return i
+    build(0, nl)
+    rng = np.random.default_rng(4)
+    bl = rng.uniform(0.01, 0.3, size=2 * nl - 1).astype(np.float32)
+    c1, c2 = np.array(c1, np.int16), np.array(c2, np.int16)
+    prog, slots, depth, pairs = pa.build_cherry_schedule(c1, c2)
+    assert len(pairs) == 32 and pa.build_schedule(c1, c2)[2] == 5 and depth == 4
+    ctxs = []
+    for env in ("0", None):
+        if env is None:
+            monkeypatch.delenv("PCSF_CHERRY_TABLES", raising=False)
+        else:
+            monkeypatch.setenv("PCSF_CHERRY_TABLES", env)
+        ctxs.append(pa.ScoringContext(c1, c2, bl, m.S_c, m.pi_c, m.S_nc, m.pi_nc, device=0))
+    try:
+        cod = synth.synthetic_codon_columns(c1, c2, bl, m.S_c, m.pi_c, m.S_nc, m.pi_nc, 1000, seed=8)
+        cod[:, 10:20] = 64
+        cod[:32, 20:90] = 64
+        a, b = ctxs[0].score_sites_fixed(cod), ctxs[1].score_sites_fixed(cod)
+        assert np.array_equal(a, b) and np.isfinite(a).all()
+    finally:
+        for c in ctxs:
+            c.close()

@@ -262,3 +262,119 @@ def test_eigen_solver_quad_form_seats_follow_the_same_schedule():
         a = {(min(p, q), max(p, q)) for p, q in quads[step]}
         b = {(min(p, q), max(p, q)) for p, q in pairs[step]}
         assert a == b and len(a) == 32, step
+
+
+# ---- cherry tables (csrc/schedule.hpp reduce_cherries; kernels.hip PAIRS): the program of the tree whose cherries are leaves ----
+PAIR_BASE = 8192
+
+
+def interpret_with_pair_tables(prog, slots, pairs, P, prior, cod_col):
+    """the reduced program in numpy: an operand >= 8192 is a cherry, whose message is P_c (leafmsg(A) o leafmsg(B)) -- what the context
+    keeps per codon pair"""
+    def leafmsg(l):
+        c = cod_col[l]
+        return P[l][:, c] if c < 64 else np.array([P[l][a, :].sum() for a in range(64)])
+
+    def operand(x):
+        if x < PAIR_BASE:
+            return leafmsg(x)
+        la, lb, node = pairs[x - PAIR_BASE]
+        return P[node] @ (leafmsg(la) * leafmsg(lb))
+    cur, stk, slot, z, products = None, {}, 0, None, 0
+    for o in prog:
+        code, a, b = int(o >> 28), int((o >> 14) & 0x3fff), int(o & 0x3fff)
+        if code == F_CHERRY:
+            cur = operand(a) * operand(b)
+            continue
+        if code == F_ROOT:
+            z = float(prior @ cur)
+            continue
+        acc = P[slots[slot]] @ cur
+        slot += 1
+        products += 1
+        if code == F_MM_LEAF:
+            cur = acc * operand(a)
+        elif F_PUSH0 <= code < F_POP0:
+            stk[code - F_PUSH0] = acc
+            cur = operand(a) * operand(b)
+        else:
+            cur = stk[code - F_POP0] * acc
+    assert slot == len(slots)
+    return z, products
+
+
+@pytest.mark.parametrize("model", ["53birds", "58mammals", "100vertebrates"])
+def test_cherry_table_program_reproduces_oracle(model, oracle_models):
+    m = oracle_models(model)
+    prog, slots, depth, pairs = pa.build_cherry_schedule(m.child1, m.child2)
+    full_prog, full_slots, full_depth = pa.build_schedule(m.child1, m.child2)
+    cherries = [v for v in range(m.nl, m.n - 1) if m.child1[v] < m.nl and m.child2[v] < m.nl]
+    assert [int(p[2]) for p in pairs] == cherries and all(m.child1[p[2]] == p[0] and m.child2[p[2]] == p[1] for p in pairs)
+    assert len(slots) == len(full_slots) - len(pairs) and depth <= full_depth      # one product less per cherry
+    assert sorted(slots.tolist() + cherries) == sorted(full_slots.tolist())
+    qd = m.qdiag(True)
+    rc, P = m.all_P(qd, 1.0)
+    assert rc == 0
+    prior = np.array(qd.prior)
+    cod = synth.synthetic_codon_columns(m.child1, m.child2, m.branch_len, m.S_c, m.pi_c, m.S_nc, m.pi_nc, 12, seed=5)
+    cod[::3, 2] = 64
+    cod[:, 3] = 64
+    lpr, anc = C.c_double(), C.c_double()
+    per = np.empty(cod.shape[1])
+    ob.lib().po_lpr_leaves(C.byref(qd), C.byref(m.m.tree), 1.0, cod.ctypes.data_as(C.POINTER(C.c_uint8)), cod.shape[1],
+                           cod.shape[1], 0, C.byref(lpr), C.byref(anc), per.ctypes.data_as(C.POINTER(C.c_double)))
+    for s in range(cod.shape[1]):
+        z, products = interpret_with_pair_tables(prog, slots, pairs, P, prior, cod[:, s])
+        assert products == m.nl - 2 - len(pairs)
+        assert abs(np.log(z) - per[s]) < 1e-11
+
+
+def test_cherry_table_programs_of_random_trees_use_every_leaf_once():
+    rng = np.random.default_rng(11)
+    with_cherries = 0
+    for _ in range(300):
+        nl = int(rng.integers(2, 40))
+        c1, c2 = _random_tree(nl, rng)
+        red = pa.build_cherry_schedule(c1, c2)
+        n = 2 * nl - 1
+        cherries = [v for v in range(nl, n - 1) if c1[v] < nl and c2[v] < nl]
+        if not cherries:
+            assert red is None
+            continue
+        with_cherries += 1
+        prog, slots, depth, pairs = red
+        assert [int(p[2]) for p in pairs] == cherries
+        deep = depth > 3
+
+        def leaves_of(x):
+            return {x} if x < PAIR_BASE else {int(pairs[x - PAIR_BASE][0]), int(pairs[x - PAIR_BASE][1])}
+        used, slot, stk, cur, deep_stk = [], 0, {}, None, []
+        for o in prog:
+            code, a, b = int(o >> 28), int((o >> 14) & 0x3fff), int(o & 0x3fff)
+            if code == F_CHERRY:
+                cur = leaves_of(a) | leaves_of(b)
+                used += sorted(leaves_of(a)) + sorted(leaves_of(b))
+            elif code == F_ROOT:
+                assert cur == set(range(nl))
+            else:
+                node = slots[slot]
+                slot += 1
+                assert c1[node] >= nl or c2[node] >= nl          # never a cherry: its product is in the table
+
+                def below(v):
+                    return {v} if v < nl else below(c1[v]) | below(c2[v])
+                assert below(node) == cur                         # the product of an edge is applied to the message of the subtree below it
+                if code == F_MM_LEAF:
+                    used += sorted(leaves_of(a))
+                    cur = cur | leaves_of(a)
+                elif code < F_POP0:
+                    if deep:
+                        deep_stk.append(cur)
+                    else:
+                        stk[code - F_PUSH0] = cur
+                    used += sorted(leaves_of(a)) + sorted(leaves_of(b))
+                    cur = leaves_of(a) | leaves_of(b)
+                else:
+                    cur = cur | (deep_stk.pop() if deep else stk[code - F_POP0])
+        assert sorted(used) == list(range(nl)) and slot == len(slots) == nl - 2 - len(cherries)
+    assert with_cherries > 250
