@@ -65,29 +65,32 @@ CLI = os.path.join(ROOT, "phylocsfpp_amd", "host", "phylocsf-amd")
 ORACLE_CLI = os.path.join(ROOT, "oracle", "_build", "oracle_cli")
 
 
-def flop_per_site(nl, cherries=0):
+def flop_per_site(nl, cherries=0, triples=0):
     """both models; internal edges as 64x64 mat-vec, element-wise products, root dot.  cherries: cherries whose message
     comes from a pair table (kernels.hip PAIRS) -- one product and one element-wise product less each: the work of the algorithm the
     kernel runs (every MFMA it executes is in this count: the PMC's SQ_VALU_MFMA_BUSY_CYCLES / 64 x 2,048 agrees)."""
-    return 2 * ((nl - 2 - cherries) * 2 * 64 * 64 + (nl - 1 - cherries) * 64 + 2 * 64)
+    absorbed = cherries + triples   # table nodes: the nodes over a cherry and a leaf too (every cherry has a table, also those inside a triple)
+    return 2 * ((nl - 2 - absorbed) * 2 * 64 * 64 + (nl - 1 - absorbed) * 64 + 2 * 64)
 
 
 def roofline_of(ctx_info, nl, n_sites, kernel_ms):
     """the roofline object of a prune_fixed launch: achieved on the work the kernel's algorithm does, and -- when cherry tables removed
     products -- what the same time means in SURVEY 8(d)'s count of the table-free algorithm"""
-    cherries = ctx_info["cherries"]
-    fl, fl_full = flop_per_site(nl, cherries), flop_per_site(nl)
+    cherries, triples = ctx_info["cherries"], ctx_info.get("triples", 0)
+    fl, fl_full = flop_per_site(nl, cherries, triples), flop_per_site(nl)
     tf = n_sites * fl / (kernel_ms * 1e-3) / 1e12
     r = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_MFMA_TFLOPS,
          "kernel": "pcsf::prune_fixed", "kernel_ms": kernel_ms, "flop_per_codon_frame": fl}
     if cherries:
         tf_full = n_sites * fl_full / (kernel_ms * 1e-3) / 1e12
-        r["cherry_tables"] = {"cherries": cherries, "products_per_model": ctx_info["products_run"], "products_per_model_without_tables": ctx_info["products_full"],
+        assert ctx_info["products_run"] == nl - 2 - cherries - triples
+        r["cherry_tables"] = {"cherries": cherries, "triples": triples, "products_per_model": ctx_info["products_run"], "products_per_model_without_tables": ctx_info["products_full"],
                               "table_rows_per_model": ctx_info["rows_per_table_set"], "table_bytes": ctx_info["rows_per_table_set"] * 512 * 2,
                               "survey_8d_flop_per_codon_frame": fl_full, "survey_8d_equivalent_tflops": tf_full,
                               "survey_8d_equivalent_frac": tf_full / PEAK_FP64_MFMA_TFLOPS,
-                              "note": "a cherry's message to its parent is looked up per codon pair (65 x 65 rows per cherry and model, made once per "
-                                      "context by the product the kernel would run: same bits): `achieved` / `frac` count the products the kernel runs; the "
+                              "note": "a cherry's message to its parent is looked up per codon pair (65 x 65 rows per cherry and model; one level up, a node over a "
+                                      "cherry and a leaf: 65^3 rows), made once per "
+                                      "context by the product the kernel would run: same bits: `achieved` / `frac` count the products the kernel runs; the "
                                       "survey_8d_* figures price the same time with SURVEY 8(d)'s table-free count and can exceed the peak"}
     return r
 

@@ -345,16 +345,18 @@ int pcsf_build_schedule(int32_t n_nodes, const int16_t *child1, const int16_t *c
                         int32_t program_cap, int32_t *slot_node, int32_t *n_ops, int32_t *n_slots,
                         int32_t *stack_depth);
 /* what this context's tracks-mode kernel runs: out[0] = products per site and model of the full program (internal non-root nodes), out[1] = of
- * the program it runs (cherry tables: one less per cherry), out[2] = cherries with a pair table (0: the full program), out[3] = rows of
- * 64 doubles per table set (leaves' rows + pair rows) */
+ * the program it runs (subtree tables: one less per cherry, one more less per node over a cherry and a leaf), out[2] = cherries with a pair
+ * table (0: the full program), out[3] = rows of 64 doubles per table set (leaves' rows + pair rows + triple rows), out[4] = triples */
 int pcsf_tracks_program_info(const pcsf_ctx *ctx, int64_t *out);
 /* host-only: the program tracks mode runs when the tree has cherries (csrc/schedule.hpp reduce_cherries: every cherry below the root is a
- * leaf whose "codon" is the pair of its leaves' codons; its message comes from a table of 65 x 65 rows made once per context).  An operand
- * below 8192 is a leaf of the tree, 8192 + p the p-th cherry; pairs[3 p ..]: its leaves and its node; slot_node: the ORIGINAL tree's nodes.
- * *n_pairs = 0 and nothing else written when the tree has no such cherry.  pairs needs 3 (n_nodes + 1) / 2 entries. */
+ * leaf whose "codon" is the pair of its leaves' codons; its message comes from a table of 65 x 65 rows made once per context; with
+ * triples != NULL also every node over a cherry and a leaf, 65^3 rows).  An operand below 8192 is a leaf of the tree, 8192 + p the p-th
+ * cherry, 12288 + t the t-th triple; pairs[3 p ..]: its leaves and its node; triples[3 t ..]: its pair, its third leaf, its node;
+ * slot_node: the ORIGINAL tree's nodes.  *n_pairs = 0 and nothing else written when the tree has no such cherry.  pairs and triples
+ * need 3 (n_nodes + 1) / 2 entries each. */
 int pcsf_debug_cherry_schedule(int32_t n_nodes, const int16_t *child1, const int16_t *child2, uint32_t *program,
                                int32_t program_cap, int32_t *slot_node, int32_t *n_ops, int32_t *n_slots,
-                               int32_t *stack_depth, int32_t *pairs, int32_t *n_pairs);
+                               int32_t *stack_depth, int32_t *pairs, int32_t *n_pairs, int32_t *triples, int32_t *n_triples);
 /* host-only: runs the lock-step optimiser (fit_find_init + Brent, src/fixed_lik.hpp:469-544) on a
  * caller-supplied objective (to be MAXIMISED), mt19937 seeded with `seed` and advanced by
  * `skip_draws` 32-bit draws; returns the evaluation points in order and the value of the LAST one. */

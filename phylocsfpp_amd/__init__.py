@@ -202,10 +202,12 @@ def build_schedule(child1, child2):
     return prog[:n_ops.value].copy(), slots[:n_slots.value].copy(), depth.value
 
 
-def build_cherry_schedule(child1, child2):
-    """Host-only: the program tracks mode runs when the tree has cherries (every cherry below the root a leaf with a pair table).
-    Returns (program, slot_node -- nodes of the ORIGINAL tree --, stack_depth, pairs int32[n_pairs, 3] = leaf A, leaf B, cherry node), or
-    None when the tree has no such cherry.  An operand >= 8192 in an op word names cherry operand - 8192."""
+def build_cherry_schedule(child1, child2, triples=False):
+    """Host-only: the program tracks mode runs when the tree has cherries (every cherry below the root a leaf with a pair table; with
+    triples=True also every node over a cherry and a leaf, a 65^3 table).
+    Returns (program, slot_node -- nodes of the ORIGINAL tree --, stack_depth, pairs int32[n_pairs, 3] = leaf A, leaf B, cherry node[,
+    triples int32[n_triples, 3] = pair index, third leaf, node]), or None when the tree has no such cherry.  An operand >= 8192 in an op
+    word names pair operand - 8192, >= 12288 triple operand - 12288."""
     lib = load_library()
     c1 = np.ascontiguousarray(child1, dtype=np.int16)
     c2 = np.ascontiguousarray(child2, dtype=np.int16)
@@ -213,16 +215,19 @@ def build_cherry_schedule(child1, child2):
     prog = np.zeros(4 * n + 8, dtype=np.uint32)
     slots = np.zeros(n, dtype=np.int32)
     pairs = np.zeros(3 * ((n + 1) // 2), dtype=np.int32)
-    n_ops, n_slots, depth, n_pairs = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    trips = np.zeros(3 * ((n + 1) // 2), dtype=np.int32)
+    n_ops, n_slots, depth, n_pairs, n_trips = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
     i16, i32 = C.POINTER(C.c_int16), C.POINTER(C.c_int32)
-    lib.pcsf_debug_cherry_schedule.argtypes = [C.c_int32, i16, i16, C.POINTER(C.c_uint32), C.c_int32, i32, i32, i32, i32, i32, i32]
+    lib.pcsf_debug_cherry_schedule.argtypes = [C.c_int32, i16, i16, C.POINTER(C.c_uint32), C.c_int32, i32, i32, i32, i32, i32, i32, i32, i32]
     rc = lib.pcsf_debug_cherry_schedule(n, c1.ctypes.data_as(i16), c2.ctypes.data_as(i16), prog.ctypes.data_as(C.POINTER(C.c_uint32)), len(prog),
-                                        slots.ctypes.data_as(i32), C.byref(n_ops), C.byref(n_slots), C.byref(depth), pairs.ctypes.data_as(i32), C.byref(n_pairs))
+                                        slots.ctypes.data_as(i32), C.byref(n_ops), C.byref(n_slots), C.byref(depth), pairs.ctypes.data_as(i32), C.byref(n_pairs),
+                                        trips.ctypes.data_as(i32) if triples else None, C.byref(n_trips) if triples else None)
     if rc:
         raise PcsfError(rc, lib.pcsf_last_error(None).decode())
     if n_pairs.value == 0:
         return None
-    return prog[:n_ops.value].copy(), slots[:n_slots.value].copy(), depth.value, pairs[:3 * n_pairs.value].reshape(-1, 3).copy()
+    out = (prog[:n_ops.value].copy(), slots[:n_slots.value].copy(), depth.value, pairs[:3 * n_pairs.value].reshape(-1, 3).copy())
+    return out + (trips[:3 * n_trips.value].reshape(-1, 3).copy(),) if triples else out
 
 
 class ScoringContext:
@@ -278,10 +283,10 @@ class ScoringContext:
     def tracks_program_info(self):
         """what the tracks-mode kernel of this context runs: products per site and model of the full program and of the program it runs, cherries
         with a pair table (0: the full program), rows per table set"""
-        out = (C.c_int64 * 4)()
+        out = (C.c_int64 * 5)()
         self._lib.pcsf_tracks_program_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         self._check(self._lib.pcsf_tracks_program_info(self._h, out))
-        return {"products_full": int(out[0]), "products_run": int(out[1]), "cherries": int(out[2]), "rows_per_table_set": int(out[3])}
+        return {"products_full": int(out[0]), "products_run": int(out[1]), "cherries": int(out[2]), "rows_per_table_set": int(out[3]), "triples": int(out[4])}
 
     def score_sites_fixed(self, codons):
         """codons: uint8 ndarray [n_leaves, n_sites] (host) -> float64 ndarray [n_sites] of

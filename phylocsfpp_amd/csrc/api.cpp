@@ -122,7 +122,10 @@ PruneParams tracks_prune_params(const pcsf_ctx* c, int* variant_flags)
     p.frag = t.d_frag.as<double>();
     p.leaf_tab = t.d_leaf_tab.as<double>();
     p.pair_leaves = t.d_pair_leaves.as<uint16_t>();
+    p.trip_info = t.d_trip_info.as<uint32_t>();
     p.n_pairs = static_cast<int>(t.pairs.size());
+    p.n_free_pairs = t.n_free_pairs;
+    p.n_triples = static_cast<int>(t.triples.size());
     p.leaf_rows = t.leaf_rows;
     if (variant_flags) *variant_flags |= 256;
     return p;
@@ -176,24 +179,35 @@ int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t le
 
 namespace {
 
-// Cherry tables of a context (ctx.hpp CherryTables): the reduced tree's program and facts, its fragment images, the table sets --
-// leaves' rows from the host, pair rows by pair_table_kernel -- and the reduced program's all-gap messages, recorded like the full
-// program's.  Leaves the context without them (tracks mode then runs the full program) when the tree has no cherry below the root or the
-// rows would take more than a gigabyte.
+// Subtree tables of a context (ctx.hpp CherryTables): the reduced tree's program and facts, its fragment images, the table sets --
+// leaves' rows from the host, the cherries' pair rows and the triples' rows by combine_table_kernel -- and the reduced program's all-gap
+// messages, recorded like the full program's.  Leaves the context without them (tracks mode then runs the full program) when the tree
+// has no cherry below the root.  PCSF_TABLE_BYTES bounds the rows of both models (default 8 GiB: every tree the reference ships gets its
+// triples -- 58mammals 2.6 GB, 100vertebrates 4.4 GB); a tree whose triples do not fit keeps its cherries, one whose cherries do not fit
+// runs the full program.
 int build_cherry_tables(pcsf_ctx* c, const pcsf::Vec prior[2])
 {
     (void)prior;
     const int n = c->n_nodes, nl = c->n_leaves;
+    size_t budget = size_t(8) << 30;
+    if (const char* v = std::getenv("PCSF_TABLE_BYTES")) budget = static_cast<size_t>(std::strtoull(v, nullptr, 10));
+    int max_leaves = 3;
+    if (const char* v = std::getenv("PCSF_TABLE_LEAVES")) max_leaves = std::atoi(v);   // 2: cherries only (A/B)
     pcsf::CherryReduction red;
-    try {
-        red = pcsf::reduce_cherries(pcsf::TreeView{n, c->child1.data(), c->child2.data()});
-    } catch (const std::exception&) {
-        return PCSF_OK;
+    size_t leaf_rows = 0;
+    for (; max_leaves >= 2; --max_leaves) {
+        try {
+            red = pcsf::reduce_cherries(pcsf::TreeView{n, c->child1.data(), c->child2.data()}, max_leaves);
+        } catch (const std::exception&) {
+            return PCSF_OK;
+        }
+        if (!red.any()) return PCSF_OK;
+        leaf_rows = static_cast<size_t>(nl) * 65 + red.pairs.size() * pcsf::PAIR_CODES + red.triples.size() * pcsf::TRIPLE_CODES;
+        if (leaf_rows * 64 * sizeof(double) * 2 <= budget && leaf_rows < 0xffffffffull) break;
+        if (red.triples.empty()) return PCSF_OK;   // not even the cherries fit
     }
-    if (!red.any()) return PCSF_OK;
-    const size_t np = red.pairs.size();
-    const size_t leaf_rows = static_cast<size_t>(nl) * 65 + np * pcsf::PAIR_CODES;
-    if (leaf_rows * 64 * sizeof(double) * 2 > (size_t(1) << 30) || leaf_rows >= 0xffffffffull / 65) return PCSF_OK;
+    if (max_leaves < 2) return PCSF_OK;
+    const size_t np = red.pairs.size(), nt = red.triples.size();
     pcsf_ctx::CherryTables& t = c->cherry;
     try {
         t.schedule = pcsf::build_reduced_schedule(red);
@@ -201,51 +215,78 @@ int build_cherry_tables(pcsf_ctx* c, const pcsf::Vec prior[2])
         return PCSF_OK;
     }
     t.pairs = red.pairs;
+    t.triples = red.triples;
+    t.n_free_pairs = red.n_free_pairs;
     t.leaf_rows = static_cast<uint32_t>(leaf_rows);
     hipError_t e;
     const auto& prog = t.schedule.program;
     const int ne = static_cast<int>(t.schedule.slot_node.size());
     if ((e = t.d_program.reserve(prog.size() * sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMemcpyAsync(t.d_program.ptr, prog.data(), prog.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
-        return c->hip_fail(e, "pcsf_create (cherry tables: program)");
-    const pcsf::ProgramFacts facts = pcsf::program_facts(t.schedule, &t.pairs, nl);
+        (e = hipMemcpy(t.d_program.ptr, prog.data(), prog.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess)
+        return c->hip_fail(e, "pcsf_create (subtree tables: program)");
+    const pcsf::ProgramFacts facts = pcsf::program_facts(t.schedule, &red, nl);
     if (facts.ok) {
         if ((e = t.d_op_leaves.reserve(facts.leaves.size() * sizeof(uint64_t))) != hipSuccess ||
-            (e = hipMemcpyAsync(t.d_op_leaves.ptr, facts.leaves.data(), facts.leaves.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream)) != hipSuccess ||
+            (e = hipMemcpy(t.d_op_leaves.ptr, facts.leaves.data(), facts.leaves.size() * sizeof(uint64_t), hipMemcpyHostToDevice)) != hipSuccess ||
             (e = t.d_op_meta.reserve(facts.meta.size() * sizeof(uint32_t))) != hipSuccess ||
-            (e = hipMemcpyAsync(t.d_op_meta.ptr, facts.meta.data(), facts.meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
-            return c->hip_fail(e, "pcsf_create (cherry tables: program facts)");
+            (e = hipMemcpy(t.d_op_meta.ptr, facts.meta.data(), facts.meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess)
+            return c->hip_fail(e, "pcsf_create (subtree tables: program facts)");
     }
-    // fragment images: the reduced program's slots, then (scratch) the cherry nodes' for the table kernel
-    std::vector<double> frag(static_cast<size_t>(2) * std::max(ne, 1) * pcsf::FRAG_DOUBLES), cfrag(2 * np * pcsf::FRAG_DOUBLES);
+    // fragment images: the reduced program's slots, then (scratch) the table nodes' -- cherries, then triples -- for the table kernel
+    const size_t n_tab = np + nt;
+    std::vector<double> frag(static_cast<size_t>(2) * std::max(ne, 1) * pcsf::FRAG_DOUBLES), cfrag(2 * n_tab * pcsf::FRAG_DOUBLES);
     std::vector<double> leaf(static_cast<size_t>(nl) * pcsf::LEAF_TABLE_DOUBLES);
     std::vector<uint16_t> pl(2 * np);
     for (size_t p = 0; p < np; ++p) {
         pl[2 * p] = static_cast<uint16_t>(red.pairs[p][0]);
         pl[2 * p + 1] = static_cast<uint16_t>(red.pairs[p][1]);
     }
-    pcsf::DeviceBuffer d_cfrag;
+    const uint32_t pair_row0 = static_cast<uint32_t>(nl) * 65u, trip_row0 = pair_row0 + static_cast<uint32_t>(np) * pcsf::PAIR_CODES;
+    std::vector<uint32_t> ti(3 * std::max<size_t>(nt, 1), 0);
+    std::vector<pcsf::CombineTable> pair_tabs(np), trip_tabs(nt);
+    for (size_t p = 0; p < np; ++p)
+        pair_tabs[p] = pcsf::CombineTable{static_cast<uint32_t>(red.pairs[p][0]) * 65u, 65u, static_cast<uint32_t>(red.pairs[p][1]) * 65u, 65u,
+                                          pair_row0 + static_cast<uint32_t>(p) * pcsf::PAIR_CODES, static_cast<uint32_t>(p)};
+    for (size_t k = 0; k < nt; ++k) {
+        const uint32_t p = static_cast<uint32_t>(red.triples[k][0]), leaf_c = static_cast<uint32_t>(red.triples[k][1]);
+        const uint32_t base = trip_row0 + static_cast<uint32_t>(k) * pcsf::TRIPLE_CODES;
+        ti[3 * k] = static_cast<uint32_t>(red.pairs[p][0]) | (static_cast<uint32_t>(red.pairs[p][1]) << 16);
+        ti[3 * k + 1] = leaf_c;
+        ti[3 * k + 2] = base;
+        trip_tabs[k] = pcsf::CombineTable{pair_row0 + p * pcsf::PAIR_CODES, pcsf::PAIR_CODES, leaf_c * 65u, 65u, base, static_cast<uint32_t>(np + k)};
+    }
+    pcsf::DeviceBuffer d_cfrag, d_tabs;
     if ((e = t.d_frag.reserve(frag.size() * sizeof(double))) != hipSuccess || (e = d_cfrag.reserve(cfrag.size() * sizeof(double))) != hipSuccess ||
-        (e = t.d_leaf_tab.reserve(leaf_rows * 64 * sizeof(double) * 2)) != hipSuccess || (e = t.d_pair_leaves.reserve(pl.size() * sizeof(uint16_t))) != hipSuccess)
-        return c->hip_fail(e, "hipMalloc(cherry tables)");
+        (e = t.d_leaf_tab.reserve(leaf_rows * 64 * sizeof(double) * 2)) != hipSuccess || (e = t.d_pair_leaves.reserve(pl.size() * sizeof(uint16_t))) != hipSuccess ||
+        (e = t.d_trip_info.reserve(ti.size() * sizeof(uint32_t))) != hipSuccess || (e = d_tabs.reserve(n_tab * sizeof(pcsf::CombineTable))) != hipSuccess)
+        return c->hip_fail(e, "hipMalloc(subtree tables)");
     for (int m = 0; m < 2; ++m) {
         const double* Pm = c->host_P.data() + static_cast<size_t>(m) * (n - 1) * 4096;
         for (int s = 0; s < ne; ++s)
             pcsf::to_fragment_order(Pm + static_cast<size_t>(t.schedule.slot_node[s]) * 4096, frag.data() + (static_cast<size_t>(m) * ne + s) * pcsf::FRAG_DOUBLES);
         for (size_t p = 0; p < np; ++p)
-            pcsf::to_fragment_order(Pm + static_cast<size_t>(red.pairs[p][2]) * 4096, cfrag.data() + (static_cast<size_t>(m) * np + p) * pcsf::FRAG_DOUBLES);
+            pcsf::to_fragment_order(Pm + static_cast<size_t>(red.pairs[p][2]) * 4096, cfrag.data() + (static_cast<size_t>(m) * n_tab + p) * pcsf::FRAG_DOUBLES);
+        for (size_t k = 0; k < nt; ++k)
+            pcsf::to_fragment_order(Pm + static_cast<size_t>(red.triples[k][2]) * 4096, cfrag.data() + (static_cast<size_t>(m) * n_tab + np + k) * pcsf::FRAG_DOUBLES);
         for (int l = 0; l < nl; ++l) pcsf::to_leaf_table(Pm + static_cast<size_t>(l) * 4096, leaf.data() + static_cast<size_t>(l) * pcsf::LEAF_TABLE_DOUBLES);
         // (a synchronous copy: `leaf` is filled again for the second model)
         if ((e = hipMemcpy(t.d_leaf_tab.as<double>() + static_cast<size_t>(m) * leaf_rows * 64, leaf.data(), leaf.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess)
-            return c->hip_fail(e, "hipMemcpy(cherry tables: leaf rows)");
+            return c->hip_fail(e, "hipMemcpy(subtree tables: leaf rows)");
     }
     if ((e = hipMemcpy(t.d_frag.ptr, frag.data(), frag.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(d_cfrag.ptr, cfrag.data(), cfrag.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(t.d_pair_leaves.ptr, pl.data(), pl.size() * sizeof(uint16_t), hipMemcpyHostToDevice)) != hipSuccess)
-        return c->hip_fail(e, "hipMemcpy(cherry tables)");
-    if ((e = pcsf::launch_pair_tables(d_cfrag.as<double>(), t.d_leaf_tab.as<double>(), t.leaf_rows, nl, static_cast<int>(np), t.d_pair_leaves.as<uint16_t>(), c->stream)) != hipSuccess ||
+        (e = hipMemcpy(t.d_pair_leaves.ptr, pl.data(), pl.size() * sizeof(uint16_t), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(t.d_trip_info.ptr, ti.data(), ti.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(d_tabs.ptr, pair_tabs.data(), np * sizeof(pcsf::CombineTable), hipMemcpyHostToDevice)) != hipSuccess ||
+        (nt && (e = hipMemcpy(d_tabs.as<pcsf::CombineTable>() + np, trip_tabs.data(), nt * sizeof(pcsf::CombineTable), hipMemcpyHostToDevice)) != hipSuccess))
+        return c->hip_fail(e, "hipMemcpy(subtree tables)");
+    // the cherries' rows, then the triples' (which read them)
+    if ((e = pcsf::launch_combine_tables(d_tabs.as<pcsf::CombineTable>(), static_cast<int>(np), pcsf::PAIR_CODES, d_cfrag.as<double>(), static_cast<int>(n_tab), t.d_leaf_tab.as<double>(),
+                                         t.leaf_rows, c->stream)) != hipSuccess ||
+        (e = pcsf::launch_combine_tables(d_tabs.as<pcsf::CombineTable>() + np, static_cast<int>(nt), pcsf::TRIPLE_CODES, d_cfrag.as<double>(), static_cast<int>(n_tab),
+                                         t.d_leaf_tab.as<double>(), t.leaf_rows, c->stream)) != hipSuccess ||
         (e = hipStreamSynchronize(c->stream)) != hipSuccess)
-        return c->hip_fail(e, "pair_table_kernel");
+        return c->hip_fail(e, "combine_table_kernel");
     t.on = true;
     if (c->skip_allgap && t.d_op_meta.ptr) {   // the reduced program's all-gap messages, by the reduced program itself (like the full program's above)
         const size_t doubles = 2 * (static_cast<size_t>(ne) + 1) * 64;
@@ -254,7 +295,7 @@ int build_cherry_tables(pcsf_ctx* c, const pcsf::Vec prior[2])
             (e = hipMemsetAsync(t.d_gap_tab.ptr, 0, doubles * sizeof(double), c->stream)) != hipSuccess ||
             (e = hipMemsetAsync(d_gaps.ptr, 64, static_cast<size_t>(nl) * 64, c->stream)) != hipSuccess) {
             t.on = false;
-            return c->hip_fail(e, "pcsf_create (cherry tables: all-gap messages)");
+            return c->hip_fail(e, "pcsf_create (subtree tables: all-gap messages)");
         }
         int flag = 0;
         pcsf::PruneParams gp = pcsf::tracks_prune_params(c, &flag);
@@ -267,7 +308,7 @@ int build_cherry_tables(pcsf_ctx* c, const pcsf::Vec prior[2])
         if ((e = pcsf::launch_prune_fixed(gp, 256 | (t.schedule.stack_depth > pcsf::MAX_STACK_DEPTH ? 66 : 2), c->stream, 0)) != hipSuccess ||
             (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
             t.on = false;
-            return c->hip_fail(e, "pcsf_create (cherry tables: all-gap messages)");
+            return c->hip_fail(e, "pcsf_create (subtree tables: all-gap messages)");
         }
     }
     return PCSF_OK;
@@ -481,16 +522,18 @@ int pcsf_tracks_program_info(const pcsf_ctx* c, int64_t* out)
     out[1] = c->cherry.on ? static_cast<int64_t>(c->cherry.schedule.slot_node.size()) : out[0];
     out[2] = c->cherry.on ? static_cast<int64_t>(c->cherry.pairs.size()) : 0;
     out[3] = c->cherry.on ? static_cast<int64_t>(c->cherry.leaf_rows) : static_cast<int64_t>(c->n_leaves) * 65;
+    out[4] = c->cherry.on ? static_cast<int64_t>(c->cherry.triples.size()) : 0;
     return PCSF_OK;
 }
 
 int pcsf_debug_cherry_schedule(int32_t n_nodes, const int16_t* child1, const int16_t* child2, uint32_t* program, int32_t program_cap, int32_t* slot_node, int32_t* n_ops,
-                               int32_t* n_slots, int32_t* stack_depth, int32_t* pairs, int32_t* n_pairs)
+                               int32_t* n_slots, int32_t* stack_depth, int32_t* pairs, int32_t* n_pairs, int32_t* triples, int32_t* n_triples)
 {
     if (!child1 || !child2 || !program || !slot_node || !n_ops || !n_slots || !stack_depth || !pairs || !n_pairs) return PCSF_ERR_INVALID_ARG;
     try {
-        const pcsf::CherryReduction red = pcsf::reduce_cherries(pcsf::TreeView{n_nodes, child1, child2});
+        const pcsf::CherryReduction red = pcsf::reduce_cherries(pcsf::TreeView{n_nodes, child1, child2}, triples ? 3 : 2);
         *n_pairs = static_cast<int32_t>(red.pairs.size());
+        if (n_triples) *n_triples = static_cast<int32_t>(red.triples.size());
         if (!red.any()) return PCSF_OK;
         const pcsf::Schedule s = pcsf::build_reduced_schedule(red);
         if (static_cast<int32_t>(s.program.size()) > program_cap) return PCSF_ERR_INVALID_ARG;
@@ -501,6 +544,9 @@ int pcsf_debug_cherry_schedule(int32_t n_nodes, const int16_t* child1, const int
         *stack_depth = s.stack_depth;
         for (size_t p = 0; p < red.pairs.size(); ++p)
             for (int k = 0; k < 3; ++k) pairs[3 * p + k] = red.pairs[p][k];
+        if (triples)
+            for (size_t p = 0; p < red.triples.size(); ++p)
+                for (int k = 0; k < 3; ++k) triples[3 * p + k] = red.triples[p][k];
     } catch (const std::exception& ex) {
         g_create_error = std::string("pcsf_debug_cherry_schedule: ") + ex.what();
         return PCSF_ERR_INVALID_ARG;

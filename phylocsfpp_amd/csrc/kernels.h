@@ -51,12 +51,15 @@ struct PruneParams {
     int prio_mode;               // experiment (PCSF_PRIO_MODE): 1 = the wave in the odd hardware slot of its SIMD runs at priority 0,
                                  // the other at 3 (asymmetric: one work-group of a CU owns the matrix pipe, the other fills its gaps)
     uint32_t stagger_first_blocks;
-    // cherry tables (variants + 256, schedule.hpp reduce_cherries): `program` is the reduced tree's, an operand >= PAIR_OPERAND_BASE_DEV names a
-    // cherry, and every table set of leaf_tab is [n_leaves][65] rows followed by [n_pairs][65 * 65] rows (leaf_rows in all) of 64 doubles
-    const uint16_t* pair_leaves; // [n_pairs][2]: the two leaves of every cherry
-    int n_pairs;
+    // subtree tables (variants + 256, schedule.hpp reduce_cherries): `program` is the reduced tree's, an operand >= PAIR_OPERAND_BASE_DEV names a
+    // cherry, >= TRIPLE_OPERAND_BASE_DEV a node over a cherry and a leaf, and every table set of leaf_tab is [n_leaves][65] rows, then
+    // [n_pairs][65^2] rows, then [n_triples][65^3] rows (leaf_rows in all) of 64 doubles
+    const uint16_t* pair_leaves; // [n_pairs][2]: the two leaves of every cherry; the first n_free_pairs are operands of the program
+    const uint32_t* trip_info;   // [n_triples][3]: leaf A | leaf B << 16 (its cherry), leaf C, first row of the triple's table in a table set
+    int n_pairs, n_free_pairs, n_triples;
     uint32_t leaf_rows;
-    uint32_t pair_lds_offset;    // set by the launcher: where the work-group's pair codes start in its dynamic LDS
+    uint32_t pair_lds_offset;    // set by the launcher: where the work-group's pair codes (2 bytes per free pair and site), then its triples' rows
+                                 // (4 bytes per triple and site) start in its dynamic LDS
     const double* gap_tab;       // variants + 128: [n_passes][n_edges + 1][64] recorded messages of all-gap subtrees (lane order), see kernels.hip
     double* gap_dump;            // diagnostic variants (2, 66) only: where work-group 0 records them; else null
     unsigned long long* stamps;  // diagnostic variant only: [2][n_ops][4] s_memtime values, else null
@@ -73,11 +76,14 @@ struct PruneParams {
 // + 128 (variants 0, 32, also with + 64): all-gap subtrees of a work-group's columns are skipped (needs op_leaves / op_meta)
 // + 256 (variants 0, 2, 32, with + 64 / + 128): cherry tables -- the reduced tree's program, pair rows behind the leaves' rows
 hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t stream, size_t extra_lds = 0);
-constexpr uint32_t PAIR_OPERAND_BASE_DEV = 8192, PAIR_CODES_DEV = 65 * 65;   // schedule.hpp PAIR_OPERAND_BASE / PAIR_CODES
-// The pair rows of every cherry and both models, by the product the pruning kernel would run: row (a, b) of cherry p =
-// P_c (leaf row A[a] o leaf row B[b]) in leaf-row layout, written behind the leaves' rows of leaf_tab.  frag: [2][n_pairs][4096] the
-// cherry nodes' branch matrices in fragment order.
-hipError_t launch_pair_tables(const double* frag, double* leaf_tab, uint32_t leaf_rows, int n_leaves, int n_pairs, const uint16_t* pair_leaves, hipStream_t stream);
+constexpr uint32_t PAIR_OPERAND_BASE_DEV = 8192, TRIPLE_OPERAND_BASE_DEV = 12288, PAIR_CODES_DEV = 65 * 65;   // schedule.hpp PAIR_OPERAND_BASE / TRIPLE_OPERAND_BASE / PAIR_CODES
+// One table of a table set made from two others (a leaf's 65 rows count as one): row x * y_size + y of the output = P_v (row x of X o
+// row y of Y) in leaf-row layout, by the product the pruning kernel would run.  frag: index of P_v's fragment image in the launch's array.
+struct CombineTable {
+    uint32_t x_base, x_size, y_base, y_size, out_base, frag;
+};
+// frag: [2][n_frag][4096]; tables of one launch must not read each other's output (cherries first, then the triples over them)
+hipError_t launch_combine_tables(const CombineTable* d_tables, int n_tables, uint32_t max_rows, const double* frag, int n_frag, double* leaf_tab, uint32_t leaf_rows, hipStream_t stream);
 int prune_variant_count();
 
 }  // namespace pcsf

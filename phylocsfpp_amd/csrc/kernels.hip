@@ -35,6 +35,9 @@ struct LeafRow {
     double2_t v[8];
 };
 constexpr int ROW_PIECE_STRIDE = 4;  // in 16-byte units
+#ifndef PCSF_LEAF_ROW_Q0
+#define PCSF_LEAF_ROW_Q0 4            // MM_LEAF: the k-step whose slot 2 requests the first piece of the leaf row (A/B builds: tools/build_variant.sh)
+#endif
 
 __device__ __forceinline__ const double2_t* leaf_row_ptr(const double* __restrict__ leaf_tab, int leaf, uint32_t code, int g4)
 {
@@ -257,16 +260,24 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     for (int i = tid; i < p.n_ops; i += NW * 64) lprog[i] = p.program[i];
     const unsigned char* my_cod = lcod + wave * 16 + sl;  // + leaf*SITES
     __syncthreads();
-    // PAIRS: the pair code 65 a + b of every cherry and site
+    // PAIRS: the pair code 65 a + b of every cherry that is an operand, per site; behind them the ROW of every triple and site
     uint16_t* lpair = reinterpret_cast<uint16_t*>(lds_raw + p.pair_lds_offset);
     const uint16_t* my_pair = lpair + wave * 16 + sl;     // + pair*SITES
+    uint32_t* ltrip = reinterpret_cast<uint32_t*>(lds_raw + p.pair_lds_offset + ((static_cast<uint32_t>(PAIRS ? p.n_free_pairs : 0) * SITES * 2 + 15) & ~15u));
+    const uint32_t* my_trip = ltrip + wave * 16 + sl;     // + triple*SITES
     (void)my_pair;
+    (void)my_trip;
     if constexpr (PAIRS) {
         static_assert(!BLOCKS, "per-block table sets have no pair rows");
-        for (int idx = tid; idx < p.n_pairs * SITES; idx += NW * 64) {
+        for (int idx = tid; idx < p.n_free_pairs * SITES; idx += NW * 64) {
             const int pp = idx / SITES, s = idx - pp * SITES;
             const unsigned la = p.pair_leaves[2 * pp], lb = p.pair_leaves[2 * pp + 1];
             lpair[idx] = static_cast<uint16_t>(lcod[la * SITES + s] * 65u + lcod[lb * SITES + s]);
+        }
+        for (int idx = tid; idx < p.n_triples * SITES; idx += NW * 64) {
+            const int t = idx / SITES, s = idx - t * SITES;
+            const uint32_t ab = p.trip_info[3 * t], lc = p.trip_info[3 * t + 1], base = p.trip_info[3 * t + 2];
+            ltrip[idx] = base + (lcod[(ab & 0xffffu) * SITES + s] * 65u + lcod[(ab >> 16) * SITES + s]) * 65u + lcod[lc * SITES + s];
         }
         if constexpr (!SKIP) __syncthreads();   // (SKIP: its own barriers below come before the first use)
     }
@@ -276,8 +287,11 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
             return my_cod[x * SITES];
         } else {
             if (x < PAIR_OPERAND_BASE_DEV) return x * 65u + my_cod[x * SITES];
-            const uint32_t pp = x - PAIR_OPERAND_BASE_DEV;
-            return static_cast<uint32_t>(p.n_leaves) * 65u + pp * PAIR_CODES_DEV + my_pair[pp * SITES];
+            if (x < TRIPLE_OPERAND_BASE_DEV) {
+                const uint32_t pp = x - PAIR_OPERAND_BASE_DEV;
+                return static_cast<uint32_t>(p.n_leaves) * 65u + pp * PAIR_CODES_DEV + my_pair[pp * SITES];
+            }
+            return my_trip[(x - TRIPLE_OPERAND_BASE_DEV) * SITES];
         }
     };
     // SKIP: the work-group's own program (see above), built by wave 0 from the leaves that have a codon in any of its columns
@@ -654,7 +668,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
                         constexpr int q = decltype(qc)::value;
                         constexpr int j = decltype(jc)::value;
                         PCSF_STAGE_SLOT(q, j)
-                        if constexpr (j == 2 && q >= 4 && q < 12) ra.v[q - 4] = pa[(q - 4) * ROW_PIECE_STRIDE];  // one 16-byte piece per k-step
+                        if constexpr (j == 2 && q >= PCSF_LEAF_ROW_Q0 && q < PCSF_LEAF_ROW_Q0 + 8) ra.v[q - PCSF_LEAF_ROW_Q0] = pa[(q - PCSF_LEAF_ROW_Q0) * ROW_PIECE_STRIDE];  // one 16-byte piece per k-step
                     });
                     PCSF_DUMP(acc)
                     }
@@ -766,7 +780,9 @@ static hipError_t launch_impl(const PruneParams& p_in, hipStream_t stream, size_
 {
     PruneParams p = p_in;
     if (SKIP && (!p.op_leaves || !p.op_meta || p.n_ops > 128 || p.n_leaves > 128)) return hipErrorInvalidValue;
-    if (PAIRS && (!p.pair_leaves || p.n_pairs <= 0 || p.leaf_rows != static_cast<uint32_t>(p.n_leaves) * 65u + static_cast<uint32_t>(p.n_pairs) * PAIR_CODES_DEV)) return hipErrorInvalidValue;
+    if (PAIRS && (!p.pair_leaves || p.n_pairs <= 0 || p.n_triples < 0 || (p.n_triples > 0 && !p.trip_info) || p.n_free_pairs < 0 || p.n_free_pairs > p.n_pairs ||
+                  p.leaf_rows != static_cast<uint32_t>(p.n_leaves) * 65u + static_cast<uint32_t>(p.n_pairs) * PAIR_CODES_DEV + static_cast<uint32_t>(p.n_triples) * 65u * PAIR_CODES_DEV))
+        return hipErrorInvalidValue;
     const size_t sites_per_block = static_cast<size_t>(NW) * 16;
     const size_t blocks = BLOCKS ? p.n_wgs : (p.n_sites + sites_per_block - 1) / sites_per_block;
     if (blocks == 0) return hipSuccess;
@@ -781,7 +797,7 @@ static hipError_t launch_impl(const PruneParams& p_in, hipStream_t stream, size_
     if (PAIRS) {   // the work-group's pair codes: two bytes per cherry and site
         lds = (lds + 15) & ~size_t(15);
         p.pair_lds_offset = static_cast<uint32_t>(lds);
-        lds += static_cast<size_t>(p.n_pairs) * sites_per_block * 2;
+        lds += ((static_cast<size_t>(p.n_free_pairs) * sites_per_block * 2 + 15) & ~size_t(15)) + static_cast<size_t>(p.n_triples) * sites_per_block * 4;
     }
     lds += extra_lds;
     if (lds > 160 * 1024 - (SKIP ? 2048 : 0)) return hipErrorInvalidValue;   // SKIP: 1 KiB of static LDS beside the dynamic array
@@ -831,42 +847,47 @@ hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t str
     }
 }
 
-// The pair rows of the cherries (PAIRS): one work-group = 64 pair codes of one cherry and model; a lane multiplies the two leaf rows of
-// its pair like the CHERRY arm above does and runs product() -- the instruction sequence the full program runs on the cherry's edge,
-// so the row holds the bits the full program would compute -- and stores the result as a leaf row.
-__global__ __launch_bounds__(256) void pair_table_kernel(const double* __restrict__ frag, double* __restrict__ leaf_tab_all, uint32_t leaf_rows, int n_leaves, int n_pairs,
-                                                         const uint16_t* __restrict__ pair_leaves)
+// The rows of a subtree table (PAIRS): one work-group = 64 codes of one table and model; a lane multiplies the two operand rows of its
+// code like the CHERRY arm above does and runs product() -- the instruction sequence the full program runs on that edge, so the row
+// holds the bits the full program would compute -- and stores the result as a row of the table set.
+__global__ __launch_bounds__(256) void combine_table_kernel(const CombineTable* __restrict__ tables, const double* __restrict__ frag, int n_frag, double* __restrict__ leaf_tab_all,
+                                                            uint32_t leaf_rows)
 {
     __shared__ __attribute__((aligned(16))) double2_t lfrag[FRAG_DOUBLES_DEV / 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sl = lane & 15, g4 = lane >> 4;
-    const int model = blockIdx.z, pp = blockIdx.y;
-    const double2_t* src = reinterpret_cast<const double2_t*>(frag + (static_cast<size_t>(model) * n_pairs + pp) * FRAG_DOUBLES_DEV);
+    const int model = blockIdx.z;
+    const CombineTable t = tables[blockIdx.y];
+    const uint32_t n_codes = t.x_size * t.y_size;
+    if (blockIdx.x * 64u >= n_codes) return;   // (the launch is sized for its largest table)
+    const double2_t* src = reinterpret_cast<const double2_t*>(frag + (static_cast<size_t>(model) * n_frag + t.frag) * FRAG_DOUBLES_DEV);
     for (int i = tid; i < FRAG_DOUBLES_DEV / 2; i += 256) lfrag[i] = src[i];
     __syncthreads();
     const uint32_t code = blockIdx.x * 64u + wave * 16u + sl;
-    const bool valid = code < PAIR_CODES_DEV;
-    const uint32_t cc = valid ? code : 0u, ca = cc / 65u, cb = cc % 65u;
+    const bool valid = code < n_codes;
+    const uint32_t cc = valid ? code : 0u, cx = cc / t.y_size, cy = cc % t.y_size;
     double* leaf_tab = leaf_tab_all + static_cast<size_t>(model) * leaf_rows * 64;
-    const LeafRow ra = load_leaf_row(leaf_tab, pair_leaves[2 * pp], ca, g4), rb = load_leaf_row(leaf_tab, pair_leaves[2 * pp + 1], cb, g4);
+    const double2_t* px = operand_row_ptr<true>(leaf_tab, 0, t.x_base + cx, g4);
+    const double2_t* py = operand_row_ptr<true>(leaf_tab, 0, t.y_base + cy, g4);
     double cur[16];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        cur[2 * i] = ra.v[i].x * rb.v[i].x;
-        cur[2 * i + 1] = ra.v[i].y * rb.v[i].y;
+        const double2_t rx = px[i * ROW_PIECE_STRIDE], ry = py[i * ROW_PIECE_STRIDE];
+        cur[2 * i] = rx.x * ry.x;
+        cur[2 * i + 1] = rx.y * ry.y;
     }
     double4_t acc[4];
     product(lfrag, lane, cur, acc, [](auto, auto) {});
     if (valid) {
-        double2_t* dst = reinterpret_cast<double2_t*>(leaf_tab + (static_cast<size_t>(n_leaves) * 65 + static_cast<size_t>(pp) * PAIR_CODES_DEV + code) * 64) + g4;
+        double2_t* dst = reinterpret_cast<double2_t*>(leaf_tab + (static_cast<size_t>(t.out_base) + code) * 64) + g4;
 #pragma unroll
         for (int i = 0; i < 8; ++i) dst[i * ROW_PIECE_STRIDE] = double2_t{acc[(2 * i) >> 2][(2 * i) & 3], acc[(2 * i + 1) >> 2][(2 * i + 1) & 3]};
     }
 }
 
-hipError_t launch_pair_tables(const double* frag, double* leaf_tab, uint32_t leaf_rows, int n_leaves, int n_pairs, const uint16_t* pair_leaves, hipStream_t stream)
+hipError_t launch_combine_tables(const CombineTable* d_tables, int n_tables, uint32_t max_rows, const double* frag, int n_frag, double* leaf_tab, uint32_t leaf_rows, hipStream_t stream)
 {
-    if (n_pairs <= 0) return hipSuccess;
-    hipLaunchKernelGGL(pair_table_kernel, dim3((PAIR_CODES_DEV + 63) / 64, static_cast<unsigned>(n_pairs), 2), dim3(256), 0, stream, frag, leaf_tab, leaf_rows, n_leaves, n_pairs, pair_leaves);
+    if (n_tables <= 0 || max_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(combine_table_kernel, dim3((max_rows + 63) / 64, static_cast<unsigned>(n_tables), 2), dim3(256), 0, stream, d_tables, frag, n_frag, leaf_tab, leaf_rows);
     return hipGetLastError();
 }
 

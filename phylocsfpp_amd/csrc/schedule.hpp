@@ -208,55 +208,111 @@ struct ProgramFacts {
     std::vector<uint32_t> meta;     // [n_ops]: slot | depth << 14 | parking op << 18
 };
 
-// Cherry tables (round 6; tracks mode, the model's own branch lengths): a cherry -- an internal node whose two children are leaves --
+// Subtree tables (round 6; tracks mode, the model's own branch lengths).  A cherry -- an internal node whose two children are leaves --
 // sends its parent P_c (P_A[:, a] o P_B[:, b]), a vector that depends on the column only through the codon PAIR (a, b): 65 x 65 rows
-// of 64 doubles per cherry and model, made once per context by the product the kernel would run (kernels.hip pair_table_kernel:
+// of 64 doubles per cherry and model, made once per context by the product the kernel would run (kernels.hip combine_table_kernel:
 // the same multiplies, the same MFMA sequence, so the same bits).  The cherry then IS a leaf -- of a reduced tree whose program has
-// one product less per cherry (58mammals: 39 instead of 56 per model) -- with the pair code as its "codon".  An op-word operand
-// below PAIR_OPERAND_BASE is a leaf of the original tree, PAIR_OPERAND_BASE + p the p-th cherry.
-constexpr int PAIR_OPERAND_BASE = 8192;
-constexpr int PAIR_CODES = 65 * 65;
+// one product less per cherry -- with the pair code 65 a + b as its "codon".  One level up the same holds for a node over a cherry and
+// a leaf: its message is a row of a 65^3 table (code 65 (65 a + b) + c), made from the cherry's rows and the leaf's; two products less.
+// (58mammals: 56 products per model in the full program, 39 with the 17 cherries as leaves, 30 with the 9 triples too.)
+// An op-word operand below PAIR_OPERAND_BASE is a leaf of the original tree, PAIR_OPERAND_BASE + p the p-th pair, TRIPLE_OPERAND_BASE + t the
+// t-th triple.
+constexpr int PAIR_OPERAND_BASE = 8192, TRIPLE_OPERAND_BASE = 12288;
+constexpr int PAIR_CODES = 65 * 65, TRIPLE_CODES = 65 * 65 * 65;
 
 struct CherryReduction {
-    std::vector<std::array<int, 3>> pairs;   // leaf A (child1), leaf B (child2), the cherry node
-    std::vector<int16_t> child1, child2;     // the reduced tree, numbered like newick_flatten numbers a tree (leaves first, children before parents, root last)
-    std::vector<int> operand;                // [reduced leaf]: what the op words name
-    std::vector<int> node;                   // [reduced node] -> node of the original tree (its branch matrix; a pair leaf: the cherry node)
+    std::vector<std::array<int, 3>> pairs;     // leaf A (child1), leaf B (child2), the cherry node -- every cherry below the root: the first n_free_pairs
+                                               // are operands themselves, the others lie inside a triple (their rows are what the triple's are made from)
+    int n_free_pairs = 0;
+    std::vector<std::array<int, 3>> triples;   // pair index, the third leaf, the node over them
+    std::vector<int16_t> child1, child2;       // the reduced tree, numbered like newick_flatten numbers a tree (leaves first, children before parents, root last)
+    std::vector<int> operand;                  // [reduced leaf]: what the op words name
+    std::vector<int> node;                     // [reduced node] -> node of the original tree (its branch matrix; a table leaf: the subtree's root)
     bool any() const { return !pairs.empty(); }
+    // the leaves of the original tree behind an operand
+    std::vector<int> leaves_of(int operand_id) const
+    {
+        if (operand_id >= TRIPLE_OPERAND_BASE) {
+            const auto& t = triples[static_cast<size_t>(operand_id - TRIPLE_OPERAND_BASE)];
+            return {pairs[static_cast<size_t>(t[0])][0], pairs[static_cast<size_t>(t[0])][1], t[1]};
+        }
+        if (operand_id >= PAIR_OPERAND_BASE) return {pairs[static_cast<size_t>(operand_id - PAIR_OPERAND_BASE)][0], pairs[static_cast<size_t>(operand_id - PAIR_OPERAND_BASE)][1]};
+        return {operand_id};
+    }
 };
 
-inline CherryReduction reduce_cherries(const TreeView& t)
+// max_leaves: 2 = cherries only, 3 = also the nodes over a cherry and a leaf
+inline CherryReduction reduce_cherries(const TreeView& t, int max_leaves = 2)
 {
     validate_tree(t);
     CherryReduction r;
     const int n = t.n_nodes, nl = t.n_leaves();
-    std::vector<int> cherry_of(n, -1);   // leaf -> its cherry node
-    for (int v = nl; v < n - 1; ++v)     // (the root sends no message: a two-leaf tree keeps its cherry)
+    std::vector<int> pair_of(n, -1), table_root(n, -1);   // node -> its index in r.pairs; node or leaf -> the table leaf (node id) that absorbs it
+    for (int v = nl; v < n - 1; ++v)     // (the root sends no message: nothing is absorbed into it)
         if (t.child1[v] < nl && t.child2[v] < nl) {
-            cherry_of[t.child1[v]] = cherry_of[t.child2[v]] = v;
+            pair_of[v] = static_cast<int>(r.pairs.size());
             r.pairs.push_back({t.child1[v], t.child2[v], v});
         }
-    if (r.pairs.empty() || nl >= PAIR_OPERAND_BASE || static_cast<int>(r.pairs.size()) >= 16384 - PAIR_OPERAND_BASE) {
+    if (r.pairs.empty() || nl >= PAIR_OPERAND_BASE || static_cast<int>(r.pairs.size()) >= TRIPLE_OPERAND_BASE - PAIR_OPERAND_BASE) {
         r.pairs.clear();
         return r;
     }
+    std::vector<int> triple_of(n, -1);
+    if (max_leaves >= 3)
+        for (int v = nl; v < n - 1; ++v) {
+            const int a = t.child1[v], b = t.child2[v];
+            const int pr = (a >= nl && pair_of[a] >= 0 && b < nl) ? a : ((b >= nl && pair_of[b] >= 0 && a < nl) ? b : -1);
+            if (pr < 0 || static_cast<int>(r.triples.size()) >= 16383 - TRIPLE_OPERAND_BASE) continue;
+            triple_of[v] = static_cast<int>(r.triples.size());
+            r.triples.push_back({pair_of[pr], pr == a ? b : a, v});
+        }
+    {   // the cherries that stay operands first (the kernel stages codes for those only)
+        std::vector<char> inner(r.pairs.size(), 0);
+        for (const auto& tr : r.triples) inner[static_cast<size_t>(tr[0])] = 1;
+        std::vector<int> moved(r.pairs.size(), -1);
+        std::vector<std::array<int, 3>> ordered;
+        for (int pass = 0; pass < 2; ++pass)
+            for (size_t p = 0; p < r.pairs.size(); ++p)
+                if (inner[p] == pass) {
+                    moved[p] = static_cast<int>(ordered.size());
+                    ordered.push_back(r.pairs[p]);
+                }
+        r.n_free_pairs = static_cast<int>(r.pairs.size() - r.triples.size());
+        r.pairs.swap(ordered);
+        for (auto& tr : r.triples) tr[0] = moved[static_cast<size_t>(tr[0])];
+        for (int v = nl; v < n - 1; ++v)
+            if (pair_of[v] >= 0) pair_of[v] = moved[static_cast<size_t>(pair_of[v])];
+    }
+    // who absorbs whom: a triple its pair node and three leaves, a free-standing pair its two leaves
+    for (size_t k = 0; k < r.triples.size(); ++k) {
+        const int v = r.triples[k][2], p = r.triples[k][0];
+        table_root[v] = v;
+        table_root[r.pairs[static_cast<size_t>(p)][2]] = v;
+        table_root[r.pairs[static_cast<size_t>(p)][0]] = table_root[r.pairs[static_cast<size_t>(p)][1]] = table_root[r.triples[k][1]] = v;
+    }
+    for (size_t p = 0; p < r.pairs.size(); ++p) {
+        const int v = r.pairs[p][2];
+        if (table_root[v] >= 0) continue;
+        table_root[v] = table_root[r.pairs[p][0]] = table_root[r.pairs[p][1]] = v;
+    }
     std::vector<int> new_id(n, -1);
     for (int l = 0; l < nl; ++l)
-        if (cherry_of[l] < 0) {
+        if (table_root[l] < 0) {
             new_id[l] = static_cast<int>(r.node.size());
             r.operand.push_back(l);
             r.node.push_back(l);
         }
-    for (size_t p = 0; p < r.pairs.size(); ++p) {
-        new_id[r.pairs[p][2]] = static_cast<int>(r.node.size());
-        r.operand.push_back(PAIR_OPERAND_BASE + static_cast<int>(p));
-        r.node.push_back(r.pairs[p][2]);
+    for (int v = nl; v < n - 1; ++v) {
+        if (table_root[v] != v) continue;
+        new_id[v] = static_cast<int>(r.node.size());
+        r.operand.push_back(triple_of[v] >= 0 ? TRIPLE_OPERAND_BASE + triple_of[v] : PAIR_OPERAND_BASE + pair_of[v]);
+        r.node.push_back(v);
     }
     const size_t n_red_leaves = r.node.size();
     r.child1.assign(n_red_leaves, -1);
     r.child2.assign(n_red_leaves, -1);
     for (int v = nl; v < n; ++v) {
-        if (new_id[v] >= 0) continue;    // a cherry: already a leaf
+        if (table_root[v] >= 0) continue;    // inside a table leaf (or one itself)
         new_id[v] = static_cast<int>(r.node.size());
         r.node.push_back(v);
         r.child1.push_back(static_cast<int16_t>(new_id[t.child1[v]]));
@@ -279,8 +335,8 @@ inline Schedule build_reduced_schedule(const CherryReduction& r)
     return s;
 }
 
-// (pairs: the cherries behind operands >= PAIR_OPERAND_BASE of a reduced program; n_leaves: leaves of the ORIGINAL tree, which the sets are over)
-inline ProgramFacts program_facts(const Schedule& s, const std::vector<std::array<int, 3>>* pairs = nullptr, int n_leaves = -1)
+// (red: the table leaves behind operands >= PAIR_OPERAND_BASE of a reduced program; n_leaves: leaves of the ORIGINAL tree, which the sets are over)
+inline ProgramFacts program_facts(const Schedule& s, const CherryReduction* red = nullptr, int n_leaves = -1)
 {
     ProgramFacts f;
     const size_t n_ops = s.program.size();
@@ -288,12 +344,9 @@ inline ProgramFacts program_facts(const Schedule& s, const std::vector<std::arra
     f.leaves.assign(2 * n_ops, 0);
     f.meta.assign(n_ops, 0);
     struct Set { uint64_t w[2] = {0, 0}; };
-    auto with = [pairs](Set x, int leaf) {
-        if (leaf >= PAIR_OPERAND_BASE && pairs) {
-            for (int k = 0; k < 2; ++k) {
-                const int l = (*pairs)[static_cast<size_t>(leaf - PAIR_OPERAND_BASE)][k];
-                x.w[l >> 6] |= uint64_t(1) << (l & 63);
-            }
+    auto with = [red](Set x, int leaf) {
+        if (leaf >= PAIR_OPERAND_BASE && red) {
+            for (int l : red->leaves_of(leaf)) x.w[l >> 6] |= uint64_t(1) << (l & 63);
             return x;
         }
         x.w[leaf >> 6] |= uint64_t(1) << (leaf & 63);

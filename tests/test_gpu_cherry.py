@@ -1,7 +1,8 @@
-"""GPU: cherry tables (csrc/schedule.hpp reduce_cherries, kernels.hip PAIRS / pair_table_kernel).  Tracks mode runs the program of the tree
-whose cherries are leaves: a cherry's message to its parent is a row of a 65 x 65 table per cherry and model, made once per context by the
-product the full program would run.  The claim is BIT-IDENTITY with the full program (PCSF_CHERRY_TABLES=0), on every entry point that
-runs prune_fixed in tracks mode; parity with the oracle is what every other GPU test of the FIXED path already holds the default form to."""
+"""GPU: subtree tables (csrc/schedule.hpp reduce_cherries, kernels.hip PAIRS / combine_table_kernel).  Tracks mode runs the program of the
+tree whose cherries -- and the nodes over a cherry and a leaf -- are leaves: such a node's message to its parent is a row of a 65^2 (65^3)
+table per node and model, made once per context by the product the full program would run.  The claim is BIT-IDENTITY with the full
+program (PCSF_CHERRY_TABLES=0) and with the cherries-only form (PCSF_TABLE_LEAVES=2), on every entry point that runs prune_fixed in
+tracks mode; parity with the oracle is what every other GPU test of the FIXED path already holds the default form to."""
 import os
 
 import numpy as np
@@ -14,31 +15,41 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _two_contexts(name, monkeypatch, **kw):
+def _contexts(name, monkeypatch, **kw):
+    """the full program, cherries only, cherries + triples (the default)"""
     import phylocsfpp_amd as pa
     model = pa.load_model(name)
     monkeypatch.setenv("PCSF_CHERRY_TABLES", "0")
     full = model.context(device=0, **kw)
     monkeypatch.delenv("PCSF_CHERRY_TABLES")
+    monkeypatch.setenv("PCSF_TABLE_LEAVES", "2")
+    pairs = model.context(device=0, **kw)
+    monkeypatch.delenv("PCSF_TABLE_LEAVES")
     tab = model.context(device=0, **kw)
-    return model, full, tab
+    return model, full, pairs, tab
 
 
 @pytest.mark.parametrize("name", ["53birds", "58mammals", "100vertebrates", "7yeast", "12flies", "29mammals"])
 def test_cherry_tables_give_the_full_programs_bits(name, monkeypatch):
-    model, full, tab = _two_contexts(name, monkeypatch, with_bls=True)
+    model, full, pairs_only, tab = _contexts(name, monkeypatch, with_bls=True)
     try:
         assert model.nl >= 7
-        red = __import__("phylocsfpp_amd").build_cherry_schedule(model.child1, model.child2)
+        red = __import__("phylocsfpp_amd").build_cherry_schedule(model.child1, model.child2, triples=True)
         assert red is not None and len(red[3]) >= 1
+        fi, pi, ti = full.tracks_program_info(), pairs_only.tracks_program_info(), tab.tracks_program_info()
+        assert fi["cherries"] == 0 and fi["products_run"] == model.nl - 2
+        assert pi["cherries"] == len(red[3]) and pi["triples"] == 0 and pi["products_run"] == model.nl - 2 - len(red[3])
+        assert ti["cherries"] == len(red[3]) and ti["triples"] == len(red[4]) and ti["products_run"] == model.nl - 2 - len(red[3]) - len(red[4])
+        assert ti["rows_per_table_set"] == model.nl * 65 + len(red[3]) * 65 ** 2 + len(red[4]) * 65 ** 3
         cod = synth.synthetic_codon_columns(model.child1, model.child2, model.branch_len, model.S_c, model.pi_c, model.S_nc, model.pi_nc, 4000, seed=3)
         rng = np.random.default_rng(1)
         cod[:, 100:140] = 64                                   # all-gap columns
         cod[rng.integers(0, model.nl, 500), rng.integers(0, 4000, 500)] = 64
         cod[::2, 200:300] = 64                                 # one leaf of many cherries a gap
         cod[:, 300:400] = rng.integers(0, 65, size=(model.nl, 100))   # unrelated codons: every pair row is somebody's
-        a, b = full.score_sites_fixed(cod), tab.score_sites_fixed(cod)
+        a, b, b2 = full.score_sites_fixed(cod), tab.score_sites_fixed(cod), pairs_only.score_sites_fixed(cod)
         assert np.array_equal(a, b, equal_nan=True), np.abs(a - b).max()
+        assert np.array_equal(a, b2, equal_nan=True), np.abs(a - b2).max()
         assert np.isfinite(a[:100]).all()
         # the six-frame entry point (fused front end, all-gap subtrees skipped per work-group) and the branch-length scores beside it
         nuc = np.frombuffer(b"ACGTacgtN-", dtype=np.uint8)[rng.integers(0, 10, size=(model.nl, 3000))]
@@ -46,11 +57,12 @@ def test_cherry_tables_give_the_full_programs_bits(name, monkeypatch):
         nuc[:, 2000:2200] = ord("N")
         alns = [(0, 1700, 1001, 50000), (1700, 1300, 77, 90000)]
         ra, _, ba = full.score_alignments_6frames(nuc, alns, with_bls=True)
-        rb, _, bb = tab.score_alignments_6frames(nuc, alns, with_bls=True)
-        assert np.array_equal(ba, bb)
-        for k in range(2):
-            for f in range(6):
-                assert np.array_equal(ra[k][f], rb[k][f], equal_nan=True), (k, f)
+        for other in (tab, pairs_only):
+            rb, _, bb = other.score_alignments_6frames(nuc, alns, with_bls=True)
+            assert np.array_equal(ba, bb)
+            for k in range(2):
+                for f in range(6):
+                    assert np.array_equal(ra[k][f], rb[k][f], equal_nan=True), (k, f)
         # FIXED block scores run the same kernel
         off = np.array([0, 40, 41, 140, 1000, 4000], dtype=np.uint64)
         pa_, aa = full.score_blocks(1, cod, off, compute_anc=True)
@@ -58,6 +70,7 @@ def test_cherry_tables_give_the_full_programs_bits(name, monkeypatch):
         assert np.array_equal(pa_, pb_, equal_nan=True) and np.array_equal(aa, ab, equal_nan=True)
     finally:
         full.close()
+        pairs_only.close()
         tab.close()
 
 
@@ -83,7 +96,7 @@ def test_cherry_tables_on_a_tree_deeper_than_the_register_stack(monkeypatch):
     bl = rng.uniform(0.01, 0.3, size=2 * nl - 1).astype(np.float32)
     c1, c2 = np.array(c1, np.int16), np.array(c2, np.int16)
     prog, slots, depth, pairs = pa.build_cherry_schedule(c1, c2)
-    assert len(pairs) == 32 and pa.build_schedule(c1, c2)[2] == 5 and depth == 4
+    assert len(pairs) == 32 and pa.build_schedule(c1, c2)[2] == 5 and depth == 4      # (no node over a cherry and a leaf in a balanced tree)
     ctxs = []
     for env in ("0", None):
         if env is None:
@@ -100,3 +113,24 @@ def test_cherry_tables_on_a_tree_deeper_than_the_register_stack(monkeypatch):
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_a_table_budget_too_small_for_the_triples_keeps_the_cherries(monkeypatch):
+    """PCSF_TABLE_BYTES: the rows of both models must fit; 58mammals' triples need 2.6 GB, its cherries 77 MB"""
+    import phylocsfpp_amd as pa
+    model = pa.load_model("58mammals")
+    cod = synth.synthetic_codon_columns(model.child1, model.child2, model.branch_len, model.S_c, model.pi_c, model.S_nc, model.pi_nc, 500, seed=2)
+    got = {}
+    for budget, want in (("1000000000", (17, 0)), ("1000000", (0, 0)), (None, (17, 9))):
+        if budget is None:
+            monkeypatch.delenv("PCSF_TABLE_BYTES", raising=False)
+        else:
+            monkeypatch.setenv("PCSF_TABLE_BYTES", budget)
+        c = model.context(device=0)
+        try:
+            info = c.tracks_program_info()
+            assert (info["cherries"], info["triples"]) == want, (budget, info)
+            got[budget] = c.score_sites_fixed(cod)
+        finally:
+            c.close()
+    assert np.array_equal(got["1000000000"], got[None]) and np.array_equal(got["1000000"], got[None])

@@ -265,12 +265,12 @@ def test_eigen_solver_quad_form_seats_follow_the_same_schedule():
 
 
 # ---- cherry tables (csrc/schedule.hpp reduce_cherries; kernels.hip PAIRS): the program of the tree whose cherries are leaves ----
-PAIR_BASE = 8192
+PAIR_BASE, TRIPLE_BASE = 8192, 12288
 
 
-def interpret_with_pair_tables(prog, slots, pairs, P, prior, cod_col):
+def interpret_with_pair_tables(prog, slots, pairs, P, prior, cod_col, triples=()):
     """the reduced program in numpy: an operand >= 8192 is a cherry, whose message is P_c (leafmsg(A) o leafmsg(B)) -- what the context
-    keeps per codon pair"""
+    keeps per codon pair --, an operand >= 12288 a node over a cherry and a leaf: P_v (cherry message o leafmsg(C))"""
     def leafmsg(l):
         c = cod_col[l]
         return P[l][:, c] if c < 64 else np.array([P[l][a, :].sum() for a in range(64)])
@@ -278,6 +278,9 @@ def interpret_with_pair_tables(prog, slots, pairs, P, prior, cod_col):
     def operand(x):
         if x < PAIR_BASE:
             return leafmsg(x)
+        if x >= TRIPLE_BASE:
+            pr, lc, node = triples[x - TRIPLE_BASE]
+            return P[node] @ (operand(PAIR_BASE + pr) * leafmsg(lc))
         la, lb, node = pairs[x - PAIR_BASE]
         return P[node] @ (leafmsg(la) * leafmsg(lb))
     cur, stk, slot, z, products = None, {}, 0, None, 0
@@ -303,15 +306,24 @@ def interpret_with_pair_tables(prog, slots, pairs, P, prior, cod_col):
     return z, products
 
 
+@pytest.mark.parametrize("with_triples", [False, True])
 @pytest.mark.parametrize("model", ["53birds", "58mammals", "100vertebrates"])
-def test_cherry_table_program_reproduces_oracle(model, oracle_models):
+def test_cherry_table_program_reproduces_oracle(model, with_triples, oracle_models):
     m = oracle_models(model)
-    prog, slots, depth, pairs = pa.build_cherry_schedule(m.child1, m.child2)
+    red = pa.build_cherry_schedule(m.child1, m.child2, triples=with_triples)
+    prog, slots, depth, pairs = red[:4]
+    triples = red[4] if with_triples else np.zeros((0, 3), np.int32)
     full_prog, full_slots, full_depth = pa.build_schedule(m.child1, m.child2)
     cherries = [v for v in range(m.nl, m.n - 1) if m.child1[v] < m.nl and m.child2[v] < m.nl]
-    assert [int(p[2]) for p in pairs] == cherries and all(m.child1[p[2]] == p[0] and m.child2[p[2]] == p[1] for p in pairs)
-    assert len(slots) == len(full_slots) - len(pairs) and depth <= full_depth      # one product less per cherry
-    assert sorted(slots.tolist() + cherries) == sorted(full_slots.tolist())
+    assert sorted(int(p[2]) for p in pairs) == cherries and all(m.child1[p[2]] == p[0] and m.child2[p[2]] == p[1] for p in pairs)
+    if with_triples:
+        assert len(triples) == {"53birds": 7, "58mammals": 9, "100vertebrates": 15}[model]
+        for pr, lc, node in triples:
+            kids = {int(m.child1[node]), int(m.child2[node])}
+            assert kids == {int(pairs[pr][2]), int(lc)} and lc < m.nl
+    absorbed = cherries + [int(t[2]) for t in triples]
+    assert len(slots) == len(full_slots) - len(absorbed) and depth <= full_depth      # one product less per table node
+    assert sorted(slots.tolist() + absorbed) == sorted(full_slots.tolist())
     qd = m.qdiag(True)
     rc, P = m.all_P(qd, 1.0)
     assert rc == 0
@@ -324,8 +336,8 @@ def test_cherry_table_program_reproduces_oracle(model, oracle_models):
     ob.lib().po_lpr_leaves(C.byref(qd), C.byref(m.m.tree), 1.0, cod.ctypes.data_as(C.POINTER(C.c_uint8)), cod.shape[1],
                            cod.shape[1], 0, C.byref(lpr), C.byref(anc), per.ctypes.data_as(C.POINTER(C.c_double)))
     for s in range(cod.shape[1]):
-        z, products = interpret_with_pair_tables(prog, slots, pairs, P, prior, cod[:, s])
-        assert products == m.nl - 2 - len(pairs)
+        z, products = interpret_with_pair_tables(prog, slots, pairs, P, prior, cod[:, s], triples)
+        assert products == m.nl - 2 - len(pairs) - len(triples)
         assert abs(np.log(z) - per[s]) < 1e-11
 
 
@@ -335,18 +347,26 @@ def test_cherry_table_programs_of_random_trees_use_every_leaf_once():
     for _ in range(300):
         nl = int(rng.integers(2, 40))
         c1, c2 = _random_tree(nl, rng)
-        red = pa.build_cherry_schedule(c1, c2)
+        use_triples = bool(rng.integers(0, 2))
+        red = pa.build_cherry_schedule(c1, c2, triples=use_triples)
         n = 2 * nl - 1
         cherries = [v for v in range(nl, n - 1) if c1[v] < nl and c2[v] < nl]
         if not cherries:
             assert red is None
             continue
         with_cherries += 1
-        prog, slots, depth, pairs = red
-        assert [int(p[2]) for p in pairs] == cherries
+        prog, slots, depth, pairs = red[:4]
+        triples = red[4] if use_triples else []
+        assert sorted(int(p[2]) for p in pairs) == cherries
+        want_triples = [v for v in range(nl, n - 1) if (c1[v] in cherries and c2[v] < nl) or (c2[v] in cherries and c1[v] < nl)]
+        assert [int(t[2]) for t in triples] == (want_triples if use_triples else [])
+        cherries = [v for v in cherries] + [int(t[2]) for t in triples]      # every node whose product is in a table
         deep = depth > 3
 
         def leaves_of(x):
+            if x >= TRIPLE_BASE:
+                pr, lc, _ = triples[x - TRIPLE_BASE]
+                return {int(pairs[pr][0]), int(pairs[pr][1]), int(lc)}
             return {x} if x < PAIR_BASE else {int(pairs[x - PAIR_BASE][0]), int(pairs[x - PAIR_BASE][1])}
         used, slot, stk, cur, deep_stk = [], 0, {}, None, []
         for o in prog:
@@ -359,7 +379,7 @@ def test_cherry_table_programs_of_random_trees_use_every_leaf_once():
             else:
                 node = slots[slot]
                 slot += 1
-                assert c1[node] >= nl or c2[node] >= nl          # never a cherry: its product is in the table
+                assert node not in cherries                      # never a table node: its product is in the table
 
                 def below(v):
                     return {v} if v < nl else below(c1[v]) | below(c2[v])
