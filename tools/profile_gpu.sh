@@ -32,8 +32,8 @@ if "FETCH_SIZE" in summ and "WRITE_SIZE" in summ:   # per-launch memory-side byt
     f, w = summ["FETCH_SIZE"]["mean_per_dispatch"], summ["WRITE_SIZE"]["mean_per_dispatch"]
     json.dump({"sites_per_launch": 2000000, "hbm_bytes_per_launch": int(f * 1024 * 2 + w * 1024), "fetch_size_kb_raw": f, "write_size_kb_raw": w,
                "dispatches": summ["FETCH_SIZE"]["dispatches"], "source": "profiles/$TAG/pmc_summary.json",
-               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `python3 bench.py --steps 5 --warmup 1 --cpu-baseline-sites 0 --strong-steps 0 "
-                       "--other-models 0` (tools/profile_gpu.sh); means over the bench's own prune_fixed launches; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for "
+               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over the bench command of tools/profile_gpu.sh (python3 bench.py --steps 5 --warmup 1 "
+                       "--cpu-baseline-sites 0 --strong-steps 0 --other-models 0); means over the bench's own prune_fixed launches; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for "
                        "gfx950.  WRITE_SIZE is the 16 MB of scores.  FETCH_SIZE counts L2 misses including Infinity-Cache hits: re-reads of the branch-matrix fragments, "
                        "the leaves' rows and the subtree tables' rows by 31,250 work-groups; algorithmic HBM bytes are 132 MB."},
               open(out + "/traffic.json", "w"), indent=1)
