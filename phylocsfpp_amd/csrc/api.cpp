@@ -153,7 +153,7 @@ int launch_fixed(pcsf_ctx* c, const uint8_t* d_codons, size_t n_sites, size_t le
         p.dump_codons = fused->dump_codons;
         variant = 32;
     }
-    if (cherry_flag && variant != 0 && variant != 32) cherry_flag = 0, p = base_prune_params(c);   // (the 8-wave / stamped forms: the full program)
+    if (cherry_flag && variant != 0 && variant != 2 && variant != 32) cherry_flag = 0, p = base_prune_params(c);   // (the 8-wave form: the full program)
     if (stack_depth > pcsf::MAX_STACK_DEPTH) variant = (variant == 32 ? 32 : 0) | 64;  // parked tiles in scratch memory
     // All-gap subtrees of a work-group's 64 columns cost nothing (kernels.hip SKIP).  Default: on where the columns come from
     // alignments (the six-frame entry points: species missing from a block are missing for hundreds of columns; 1.7x on a MAF with
@@ -203,7 +203,13 @@ int build_cherry_tables(pcsf_ctx* c, const pcsf::Vec prior[2])
         }
         if (!red.any()) return PCSF_OK;
         leaf_rows = static_cast<size_t>(nl) * 65 + red.pairs.size() * pcsf::PAIR_CODES + red.triples.size() * pcsf::TRIPLE_CODES;
-        if (leaf_rows * 64 * sizeof(double) * 2 <= budget && leaf_rows < 0xffffffffull) break;
+        // LDS of a work-group of the table form at its largest (fused front end, all-gap skipping; kernels.hip launch_impl has the same sum):
+        // the codes it stages must neither pass the CU's 160 KiB nor cost the second work-group of a CU where the full program has one
+        const size_t lds_base = ((2 * 32768 + ((c->schedule.program.size() + 3) & ~size_t(3)) * 4 + static_cast<size_t>(nl) * 64 + 15) & ~size_t(15)) + 256 + 64 * 9 + 16;
+        const size_t lds_tab = ((lds_base + 15) & ~size_t(15)) + ((static_cast<size_t>(red.n_free_pairs) * 128 + 15) & ~size_t(15)) + red.triples.size() * 256;
+        const size_t two_per_cu = 160 * 1024 / 2 - 1560;   // (the skipping variants' static LDS beside the dynamic array)
+        const bool lds_ok = lds_tab <= 158 * 1024 && (lds_tab <= two_per_cu || lds_base > two_per_cu);
+        if (lds_ok && leaf_rows * 64 * sizeof(double) * 2 <= budget && leaf_rows < 0xffffffffull) break;
         if (red.triples.empty()) return PCSF_OK;   // not even the cherries fit
     }
     if (max_leaves < 2) return PCSF_OK;

@@ -269,15 +269,17 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     (void)my_trip;
     if constexpr (PAIRS) {
         static_assert(!BLOCKS, "per-block table sets have no pair rows");
-        for (int idx = tid; idx < p.n_free_pairs * SITES; idx += NW * 64) {
-            const int pp = idx / SITES, s = idx - pp * SITES;
-            const unsigned la = p.pair_leaves[2 * pp], lb = p.pair_leaves[2 * pp + 1];
-            lpair[idx] = static_cast<uint16_t>(lcod[la * SITES + s] * 65u + lcod[lb * SITES + s]);
+        // (SITES = the wave's 64 lanes: entry idx = tid + 256 k belongs to table wave + 4 k -- wave-uniform, so its leaves come by scalar loads)
+        static_assert(SITES == 64, "one table operand per wave and pass");
+        for (int pp = wave; pp < p.n_free_pairs; pp += NW) {
+            const int pu = __builtin_amdgcn_readfirstlane(pp);
+            const unsigned la = p.pair_leaves[2 * pu], lb = p.pair_leaves[2 * pu + 1];
+            lpair[pu * SITES + lane] = static_cast<uint16_t>(lcod[la * SITES + lane] * 65u + lcod[lb * SITES + lane]);
         }
-        for (int idx = tid; idx < p.n_triples * SITES; idx += NW * 64) {
-            const int t = idx / SITES, s = idx - t * SITES;
-            const uint32_t ab = p.trip_info[3 * t], lc = p.trip_info[3 * t + 1], base = p.trip_info[3 * t + 2];
-            ltrip[idx] = base + (lcod[(ab & 0xffffu) * SITES + s] * 65u + lcod[(ab >> 16) * SITES + s]) * 65u + lcod[lc * SITES + s];
+        for (int t = wave; t < p.n_triples; t += NW) {
+            const int tu = __builtin_amdgcn_readfirstlane(t);
+            const uint32_t ab = p.trip_info[3 * tu], lc = p.trip_info[3 * tu + 1], base = p.trip_info[3 * tu + 2];
+            ltrip[tu * SITES + lane] = base + (lcod[(ab & 0xffffu) * SITES + lane] * 65u + lcod[(ab >> 16) * SITES + lane]) * 65u + lcod[lc * SITES + lane];
         }
         if constexpr (!SKIP) __syncthreads();   // (SKIP: its own barriers below come before the first use)
     }
@@ -286,12 +288,20 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
         if constexpr (!PAIRS) {
             return my_cod[x * SITES];
         } else {
+#ifdef PCSF_OPERAND_BRANCHFREE
+            // all three look-ups issued, the operand's kind picks one: no scalar branch in the op loop (indices clamped into their arrays)
+            const uint32_t kind = x >> 12, li = x < PAIR_OPERAND_BASE_DEV ? x : 0u, pi = kind == 2u ? x - PAIR_OPERAND_BASE_DEV : 0u, ti = kind == 3u ? x - TRIPLE_OPERAND_BASE_DEV : 0u;
+            const uint32_t c8 = my_cod[li * SITES], c16 = my_pair[pi * SITES], c32 = my_trip[ti * SITES];
+            const uint32_t r_leaf = li * 65u + c8, r_pair = static_cast<uint32_t>(p.n_leaves) * 65u + pi * PAIR_CODES_DEV + c16;
+            return kind < 2u ? r_leaf : (kind == 2u ? r_pair : c32);
+#else
             if (x < PAIR_OPERAND_BASE_DEV) return x * 65u + my_cod[x * SITES];
             if (x < TRIPLE_OPERAND_BASE_DEV) {
                 const uint32_t pp = x - PAIR_OPERAND_BASE_DEV;
                 return static_cast<uint32_t>(p.n_leaves) * 65u + pp * PAIR_CODES_DEV + my_pair[pp * SITES];
             }
             return my_trip[(x - TRIPLE_OPERAND_BASE_DEV) * SITES];
+#endif
         }
     };
     // SKIP: the work-group's own program (see above), built by wave 0 from the leaves that have a codon in any of its columns
