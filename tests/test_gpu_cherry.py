@@ -134,3 +134,38 @@ def test_a_table_budget_too_small_for_the_triples_keeps_the_cherries(monkeypatch
         finally:
             c.close()
     assert np.array_equal(got["1000000000"], got[None]) and np.array_equal(got["1000000"], got[None])
+
+
+def test_tables_on_a_tree_of_300_species(monkeypatch):
+    """A random 300-leaf tree: more than 128 leaves (no all-gap skipping), a codon matrix that leaves one work-group per CU either way, ~100
+    cherries; its ~50 triples would take 14 GB and stay out under the default budget -- and come in under a larger one.  Same bits in all forms."""
+    import phylocsfpp_amd as pa
+    from test_schedule import _random_tree
+    m = pa.load_model("58mammals")
+    rng = np.random.default_rng(12)
+    nl = 300
+    c1, c2 = _random_tree(nl, rng)
+    bl = rng.uniform(0.005, 0.1, size=2 * nl - 1).astype(np.float32)
+    red = pa.build_cherry_schedule(c1, c2, triples=True)
+    n_pairs, n_triples = len(red[3]), len(red[4])
+    assert n_pairs > 60 and n_triples > 20
+    cod = synth.synthetic_codon_columns(c1, c2, bl, m.S_c, m.pi_c, m.S_nc, m.pi_nc, 700, seed=8)
+    cod[:, 10:20] = 64
+    cod[::3, 50:200] = 64
+    got = {}
+    for tag, env in (("full", {"PCSF_CHERRY_TABLES": "0"}), ("default", {}), ("roomy", {"PCSF_TABLE_BYTES": str(40 << 30)})):
+        for k in ("PCSF_CHERRY_TABLES", "PCSF_TABLE_BYTES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = pa.ScoringContext(c1, c2, bl, m.S_c, m.pi_c, m.S_nc, m.pi_nc, device=0)
+        try:
+            info = c.tracks_program_info()
+            got[tag] = (c.score_sites_fixed(cod), info)
+        finally:
+            c.close()
+    assert got["full"][1]["cherries"] == 0
+    assert got["default"][1]["cherries"] == n_pairs and got["default"][1]["triples"] == 0          # 2 x n_triples x 140 MB > 8 GiB
+    assert got["roomy"][1]["triples"] == n_triples and got["roomy"][1]["products_run"] == nl - 2 - n_pairs - n_triples
+    assert np.isfinite(got["full"][0]).all()
+    assert np.array_equal(got["full"][0], got["default"][0]) and np.array_equal(got["full"][0], got["roomy"][0])
