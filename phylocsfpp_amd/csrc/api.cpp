@@ -727,8 +727,14 @@ int pcsf_create(pcsf_ctx** out, const pcsf_model_desc* m, int device_id)
     {   // cherry tables (PCSF_CHERRY_TABLES=0: tracks mode runs the full program -- the A/B switch; same bits either way)
         const char* v = std::getenv("PCSF_CHERRY_TABLES");
         if (!(v && v[0] == '0') && (rc = build_cherry_tables(c.get(), prior)) != PCSF_OK) {
-            g_create_error = c->error;
-            return rc;
+            if (c->error.compare(0, 9, "hipMalloc") != 0) {
+                g_create_error = c->error;
+                return rc;
+            }
+            // no room for the rows on this device (other contexts, other processes): tracks mode runs the full program
+            (void)hipGetLastError();
+            c->cherry.reset();
+            c->error.clear();
         }
     }
     *out = c.release();

@@ -169,6 +169,15 @@ struct pcsf_ctx {
         int n_free_pairs = 0;               // pairs[0 .. n_free_pairs) are operands of the program, the others lie inside triples
         uint32_t leaf_rows = 0;             // per table set: n_leaves * 65 + pairs * 65^2 + triples * 65^3
         pcsf::DeviceBuffer d_program, d_op_leaves, d_op_meta, d_frag, d_leaf_tab, d_gap_tab, d_pair_leaves, d_trip_info;
+        void reset()
+        {
+            on = false;
+            pairs.clear();
+            triples.clear();
+            n_free_pairs = 0;
+            leaf_rows = 0;
+            for (pcsf::DeviceBuffer* b : {&d_program, &d_op_leaves, &d_op_meta, &d_frag, &d_leaf_tab, &d_gap_tab, &d_pair_leaves, &d_trip_info}) b->release();
+        }
     } cherry;
     // scratch for the host-pointer entry points
     pcsf::DeviceBuffer d_codons, d_out, d_lnz, d_anc, d_stamps, d_nucl, d_segments, d_wg_seg;
