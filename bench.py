@@ -753,7 +753,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "build-tracks fixed (run_tracks) on a synthetic 58-row alignment, 6 frames: %d codon-frames on this GPU "
-                                   "per step (%s), inputs resident in HBM"
+                                   "per step (%s), inputs resident in HBM; the kernel runs the context's default form (subtree tables: roofline.cherry_tables)"
                                    % (n_sites, "1 Mb per GPU, BASELINE.json configs[2]" if args.scaling == "weak" else
                                       "its contiguous share of %d = BASELINE.json configs[3]" % args.total_sites),
                        "model": MODEL, "n_leaves": int(m.nl), "sites_per_gpu": n_sites,
