@@ -434,6 +434,16 @@ def test_one_process_per_rank_writes_the_files_of_a_single_process(cli, tmp_path
     for n in names:
         a = open(outs[0] / n, "rb").read()
         assert a == open(outs[1] / n, "rb").read() and len(a) > 1000, n
+    # a packed alignment file cut into the ranks' ranges
+    packed = tmp_path / "syn.pcsfbin"
+    subprocess.check_call([cli, "pack-maf", model58, str(syn), str(packed)], stderr=subprocess.DEVNULL)
+    one = tmp_path / "one"
+    subprocess.check_call([cli, "build-tracks", "--output", str(one), model58, str(syn)], stderr=subprocess.DEVNULL, env=env)
+    out = tmp_path / "packed_r3"
+    subprocess.check_call([cli, "build-tracks", "--output", str(out), "--ranks", "3", "--batch-sites", "6000", "--window-bytes", "100000", model58, str(packed)],
+                          stderr=subprocess.DEVNULL, env=env)
+    for n in names:
+        assert open(out / n, "rb").read() == open(one / n, "rb").read(), n
 
 
 def test_a_failing_rank_ends_the_run(cli, tmp_path):
