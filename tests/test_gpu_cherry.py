@@ -169,3 +169,34 @@ def test_tables_on_a_tree_of_300_species(monkeypatch):
     assert got["roomy"][1]["triples"] == n_triples and got["roomy"][1]["products_run"] == nl - 2 - n_pairs - n_triples
     assert np.isfinite(got["full"][0]).all()
     assert np.array_equal(got["full"][0], got["default"][0]) and np.array_equal(got["full"][0], got["roomy"][0])
+
+
+def test_tables_on_the_smallest_trees(monkeypatch):
+    """Trees of 2 to 9 leaves, random shapes: a tree whose only internal nodes are table nodes and the root runs a program without any product
+    (three leaves: one cherry and a leaf under the root); two leaves: nothing to tabulate.  Same bits as the full program, finite scores."""
+    import phylocsfpp_amd as pa
+    from test_schedule import _random_tree
+    m = pa.load_model("58mammals")
+    rng = np.random.default_rng(21)
+    seen_zero_product = False
+    for nl in (2, 3, 3, 4, 4, 4, 5, 5, 6, 7, 9):
+        c1, c2 = _random_tree(nl, rng)
+        bl = rng.uniform(0.01, 0.2, size=2 * nl - 1).astype(np.float32)
+        cod = synth.synthetic_codon_columns(c1, c2, bl, m.S_c, m.pi_c, m.S_nc, m.pi_nc, 200, seed=nl)
+        cod[:, 5] = 64
+        cod[0, 10:30] = 64
+        res = []
+        for env in ("0", None):
+            if env is None:
+                monkeypatch.delenv("PCSF_CHERRY_TABLES", raising=False)
+            else:
+                monkeypatch.setenv("PCSF_CHERRY_TABLES", env)
+            c = pa.ScoringContext(c1, c2, bl, m.S_c, m.pi_c, m.S_nc, m.pi_nc, device=0)
+            try:
+                res.append((c.score_sites_fixed(cod), c.tracks_program_info()))
+            finally:
+                c.close()
+        assert np.array_equal(res[0][0], res[1][0]) and np.isfinite(res[0][0]).all(), nl
+        assert res[1][1]["products_run"] == nl - 2 - res[1][1]["cherries"] - res[1][1]["triples"]
+        seen_zero_product |= res[1][1]["products_run"] == 0 and res[1][1]["cherries"] > 0
+    assert seen_zero_product
