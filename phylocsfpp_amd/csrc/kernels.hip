@@ -35,6 +35,9 @@ struct LeafRow {
     double2_t v[8];
 };
 constexpr int ROW_PIECE_STRIDE = 4;  // in 16-byte units
+#ifndef PCSF_STAGE_Q0
+#define PCSF_STAGE_Q0 4               // the k-step whose slot 1 requests the first LDS-DMA piece of the next product's matrix (round 6: 4 instead of 0, +1 % on the table form; tools/cherry_ab.sh)
+#endif
 #ifndef PCSF_LEAF_ROW_Q0
 #define PCSF_LEAF_ROW_Q0 4            // MM_LEAF: the k-step whose slot 2 requests the first piece of the leaf row (A/B builds: tools/build_variant.sh)
 #endif
@@ -168,6 +171,38 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     const unsigned long long stamp_t0 = STAMP ? stamp_now() : 0ull;
     (void)stamp_t0;
 
+    // ---- fragment staging: 32 KiB per slot, moved by LDS-DMA in 1 KiB wave-instructions
+    constexpr int CHUNKS_PER_WAVE = 32 / NW;
+    const int total_slots = p.n_passes * p.n_edges;  // pass 0 slots, then pass 1 slots (consecutive table sets)
+    // each wave moves CHUNKS_PER_WAVE consecutive 1 KiB pieces; the instruction's immediate offset
+    // advances the global and the LDS address together, so one address register serves 4 pieces
+    const unsigned char* src_lane = reinterpret_cast<const unsigned char*>(p.frag) +
+                                    static_cast<size_t>(table0) * p.n_edges * (FRAG_DOUBLES_DEV * 8) + wave * (CHUNKS_PER_WAVE * 1024) + lane * 16;
+    // stage_piece<J>(slot): J-th of this wave's CHUNKS_PER_WAVE pieces of `slot`
+    auto stage_piece = [&](auto jc, int slot, int buffer) {
+        constexpr int J = decltype(jc)::value;
+        const unsigned char* src = src_lane + static_cast<size_t>(slot) * (FRAG_DOUBLES_DEV * 8) + (J / 4) * 4096;
+        unsigned char* dst = lds_raw + buffer * (FRAG_DOUBLES_DEV * 8) + wave * (CHUNKS_PER_WAVE * 1024) + (J / 4) * 4096;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, (J % 4) * 1024, 0);
+    };
+    auto stage_slot = [&](int slot) {
+        stage_piece(std::integral_constant<int, 0>{}, slot, slot & 1);
+        stage_piece(std::integral_constant<int, 1>{}, slot, slot & 1);
+        stage_piece(std::integral_constant<int, 2>{}, slot, slot & 1);
+        stage_piece(std::integral_constant<int, 3>{}, slot, slot & 1);
+        if constexpr (CHUNKS_PER_WAVE > 4) {
+            stage_piece(std::integral_constant<int, 4>{}, slot, slot & 1);
+            stage_piece(std::integral_constant<int, 5>{}, slot, slot & 1);
+            stage_piece(std::integral_constant<int, 6>{}, slot, slot & 1);
+            stage_piece(std::integral_constant<int, 7>{}, slot, slot & 1);
+        }
+    };
+    // (the first product's matrix is requested before anything else: its 32 KiB arrive while the codons are staged -- the skipping variants
+    // only know their first product after the compaction below)
+    if constexpr (!SKIP) {
+        if (total_slots > 0) stage_slot(0);
+    }
     // ---- stage this work-group's codon columns into LDS (clamped to 0..64; 64 beyond the end)
     // A full, 16-byte aligned window moves as one 16-byte load per thread (58 leaves x 64 sites = 232 pieces):
     // the byte-wise loop below costs ~15 dependent round trips per work-group while the CU's other group runs alone.
@@ -398,33 +433,6 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     const uint32_t* const prog = SKIP ? lprog2 : lprog;
     const int n_run = SKIP ? lcount2[0] : p.n_ops;
 
-    // ---- fragment staging: 32 KiB per slot, moved by LDS-DMA in 1 KiB wave-instructions
-    constexpr int CHUNKS_PER_WAVE = 32 / NW;
-    const int total_slots = p.n_passes * p.n_edges;  // pass 0 slots, then pass 1 slots (consecutive table sets)
-    // each wave moves CHUNKS_PER_WAVE consecutive 1 KiB pieces; the instruction's immediate offset
-    // advances the global and the LDS address together, so one address register serves 4 pieces
-    const unsigned char* src_lane = reinterpret_cast<const unsigned char*>(p.frag) +
-                                    static_cast<size_t>(table0) * p.n_edges * (FRAG_DOUBLES_DEV * 8) + wave * (CHUNKS_PER_WAVE * 1024) + lane * 16;
-    // stage_piece<J>(slot): J-th of this wave's CHUNKS_PER_WAVE pieces of `slot`
-    auto stage_piece = [&](auto jc, int slot, int buffer) {
-        constexpr int J = decltype(jc)::value;
-        const unsigned char* src = src_lane + static_cast<size_t>(slot) * (FRAG_DOUBLES_DEV * 8) + (J / 4) * 4096;
-        unsigned char* dst = lds_raw + buffer * (FRAG_DOUBLES_DEV * 8) + wave * (CHUNKS_PER_WAVE * 1024) + (J / 4) * 4096;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, (J % 4) * 1024, 0);
-    };
-    auto stage_slot = [&](int slot) {
-        stage_piece(std::integral_constant<int, 0>{}, slot, slot & 1);
-        stage_piece(std::integral_constant<int, 1>{}, slot, slot & 1);
-        stage_piece(std::integral_constant<int, 2>{}, slot, slot & 1);
-        stage_piece(std::integral_constant<int, 3>{}, slot, slot & 1);
-        if constexpr (CHUNKS_PER_WAVE > 4) {
-            stage_piece(std::integral_constant<int, 4>{}, slot, slot & 1);
-            stage_piece(std::integral_constant<int, 5>{}, slot, slot & 1);
-            stage_piece(std::integral_constant<int, 6>{}, slot, slot & 1);
-            stage_piece(std::integral_constant<int, 7>{}, slot, slot & 1);
-        }
-    };
     int slot = 0;   // products done so far: the LDS buffer a product reads is slot & 1 (SKIP: the table slot comes from lslot2)
     if constexpr (SKIP) {
         if (lcount2[1] >= 0 && total_slots > 0) {
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
             stage_piece(std::integral_constant<int, 6>{}, lcount2[1], 0);
             stage_piece(std::integral_constant<int, 7>{}, lcount2[1], 0);
         }
-    } else if (total_slots > 0) stage_slot(0);
+    }
     // Two work-groups share a CU (one wave each per SIMD), run the same program and start together,
     // so they would reach their matrix phases and their between-product gaps at the same time and
     // leave the pipe idle in every gap.  The first generation of work-groups is staggered by
@@ -587,8 +595,8 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     ++slot;
 // slot 1 of k-steps 0..CHUNKS_PER_WAVE-1: one LDS-DMA piece of the next slot each
 #define PCSF_STAGE_SLOT(q, j)                                                        \
-    if constexpr (j == 1 && q < CHUNKS_PER_WAVE) {                                   \
-        stage_piece(std::integral_constant<int, (q < CHUNKS_PER_WAVE ? q : 0)>{}, stage_next, (this_slot + 1) & 1); \
+    if constexpr (j == 1 && q >= PCSF_STAGE_Q0 && q < PCSF_STAGE_Q0 + CHUNKS_PER_WAVE) { \
+        stage_piece(std::integral_constant<int, (q >= PCSF_STAGE_Q0 && q < PCSF_STAGE_Q0 + CHUNKS_PER_WAVE ? q - PCSF_STAGE_Q0 : 0)>{}, stage_next, (this_slot + 1) & 1); \
     }                                                                                \
     if constexpr (j == 3 && q == 13) PCSF_FETCH_NEXT_OP()
 // Cherry rows: piece i of row a in k-step i slot 2, of row b in k-step i slot 3 (i = 0..7); multiplied after the
