@@ -18,6 +18,10 @@
 
 #include "ctx.hpp"
 
+namespace pcsf {
+void set_global_error(const std::string& msg);   // api.cpp: what pcsf_last_error(NULL) returns
+}
+
 namespace {
 
 struct Rccl {
@@ -108,10 +112,17 @@ int pcsf_comm_unique_id(void* id)
     if (!id) return PCSF_ERR_INVALID_ARG;
     std::string why;
     Rccl* api = rccl(&why);
-    if (!api) return PCSF_ERR_UNSUPPORTED;
+    if (!api) {
+        pcsf::set_global_error("pcsf_comm_unique_id: " + why);
+        return PCSF_ERR_UNSUPPORTED;
+    }
     ncclUniqueId u;
     static_assert(sizeof(u) == PCSF_COMM_ID_BYTES, "PCSF_COMM_ID_BYTES is ncclUniqueId's size");
-    if (api->GetUniqueId(&u) != ncclSuccess) return PCSF_ERR_HIP;
+    const ncclResult_t r = api->GetUniqueId(&u);
+    if (r != ncclSuccess) {
+        pcsf::set_global_error(std::string("ncclGetUniqueId: ") + api->GetErrorString(r));
+        return PCSF_ERR_HIP;
+    }
     memcpy(id, &u, sizeof u);
     return PCSF_OK;
 }
