@@ -65,26 +65,26 @@ CLI = os.path.join(ROOT, "phylocsfpp_amd", "host", "phylocsf-amd")
 ORACLE_CLI = os.path.join(ROOT, "oracle", "_build", "oracle_cli")
 
 
-def flop_per_site(nl, cherries=0, triples=0):
+def flop_per_site(nl, cherries=0, triples=0, quads=0):
     """both models; internal edges as 64x64 mat-vec, element-wise products, root dot.  cherries: cherries whose message
     comes from a pair table (kernels.hip PAIRS) -- one product and one element-wise product less each: the work of the algorithm the
     kernel runs (every MFMA it executes is in this count: the PMC's SQ_VALU_MFMA_BUSY_CYCLES / 64 x 2,048 agrees)."""
-    absorbed = cherries + triples   # table nodes: the nodes over a cherry and a leaf too (every cherry has a table, also those inside a triple)
+    absorbed = cherries + triples + quads   # table nodes: every one removes the product of its own edge (a cherry inside a triple has a table too)
     return 2 * ((nl - 2 - absorbed) * 2 * 64 * 64 + (nl - 1 - absorbed) * 64 + 2 * 64)
 
 
 def roofline_of(ctx_info, nl, n_sites, kernel_ms):
     """the roofline object of a prune_fixed launch: achieved on the work the kernel's algorithm does, and -- when cherry tables removed
     products -- what the same time means in SURVEY 8(d)'s count of the table-free algorithm"""
-    cherries, triples = ctx_info["cherries"], ctx_info.get("triples", 0)
-    fl, fl_full = flop_per_site(nl, cherries, triples), flop_per_site(nl)
+    cherries, triples, quads = ctx_info["cherries"], ctx_info.get("triples", 0), ctx_info.get("quads", 0)
+    fl, fl_full = flop_per_site(nl, cherries, triples, quads), flop_per_site(nl)
     tf = n_sites * fl / (kernel_ms * 1e-3) / 1e12
     r = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_MFMA_TFLOPS,
          "kernel": "pcsf::prune_fixed", "kernel_ms": kernel_ms, "flop_per_codon_frame": fl}
     if cherries:
         tf_full = n_sites * fl_full / (kernel_ms * 1e-3) / 1e12
-        assert ctx_info["products_run"] == nl - 2 - cherries - triples
-        r["cherry_tables"] = {"cherries": cherries, "triples": triples, "products_per_model": ctx_info["products_run"], "products_per_model_without_tables": ctx_info["products_full"],
+        assert ctx_info["products_run"] == nl - 2 - cherries - triples - quads, "table nodes and products do not add up"
+        r["cherry_tables"] = {"cherries": cherries, "triples": triples, "quads": quads, "products_per_model": ctx_info["products_run"], "products_per_model_without_tables": ctx_info["products_full"],
                               "table_rows_per_model": ctx_info["rows_per_table_set"], "table_bytes": ctx_info["rows_per_table_set"] * 512 * 2,
                               "survey_8d_flop_per_codon_frame": fl_full, "survey_8d_equivalent_tflops": tf_full,
                               "survey_8d_equivalent_frac": tf_full / PEAK_FP64_MFMA_TFLOPS,
@@ -568,6 +568,8 @@ def main():
     ap.add_argument("--end-to-end-runs", type=int, default=3, help="build-tracks CLI runs on the synthetic 1 Mb MAF (0 disables; N = 1 only)")
     ap.add_argument("--block-runs", type=int, default=2, help="score-msa --strategy mle / omega runs on the same MAF (0 disables; N = 1 only)")
     ap.add_argument("--other-models", type=int, default=1, help="1: also time prune_fixed on 53birds and 100vertebrates (three steps each; N = 1 only)")
+    ap.add_argument("--table-forms", type=int, default=1, help="1: also time the launch under the other forms of tracks mode (full program, cherries only, "
+                    "quads when the device has 150 GB free) and compare their bits with the default form's (N = 1 only)")
     ap.add_argument("--force-gather", type=int, default=0,
                     help="1: at N = 1, run the N > 1 code path anyway (a world-size-1 RCCL process group, the pipelined gather and its "
                          "gather_check) -- the one-GPU rehearsal of a SCALE run; changes what `value` times, so never the driver's line")
@@ -689,6 +691,49 @@ def main():
     kernel_ms = float(np.mean(durs))
     tracks_info = ctx.tracks_program_info()
     codons_host = codons[:, :min(n_sites, 1 << 20)].cpu().numpy() if rank == 0 else None
+
+    # The same launch under the other forms of tracks mode: the full program (rounds 1-5's kernel), cherries only, and -- opt-in
+    # in the library (PCSF_TABLE_LEAVES=4; 65^4 rows per node: 94 GB for 58mammals, seconds of context creation) -- the nodes over four leaves.
+    # Every form must give the default form's bits.  `value` above is the DEFAULT form's.
+    table_forms = None
+    if rank == 0 and world == 1 and args.table_forms:
+        table_forms = {}
+        saved = {k: os.environ.get(k) for k in ("PCSF_CHERRY_TABLES", "PCSF_TABLE_LEAVES", "PCSF_TABLE_BYTES")}
+        forms = [("full_program", {"PCSF_CHERRY_TABLES": "0"}), ("cherries_only", {"PCSF_TABLE_LEAVES": "2"})]
+        if torch.cuda.mem_get_info()[0] > (150 << 30):
+            forms.append(("quads_opt_in", {"PCSF_TABLE_LEAVES": "4", "PCSF_TABLE_BYTES": str(140 << 30)}))
+        for form, env in forms:
+            try:
+                for k in saved:
+                    os.environ.pop(k, None)
+                os.environ.update(env)
+                t_c = time.perf_counter()
+                cf = m.context(device=local_rank)
+                t_c = time.perf_counter() - t_c
+                out_f = torch.empty(n_sites, dtype=torch.float64, device=dev)
+                cf.score_sites_fixed_torch(codons, out=out_f)
+                cf.set_timing(True)
+                df = []
+                for _ in range(5):
+                    cf.score_sites_fixed_torch(codons, out=out_f)
+                    df.append(cf.last_kernel_ms())
+                cf.set_timing(False)
+                torch.cuda.synchronize()
+                info_f = cf.tracks_program_info()
+                rf = roofline_of(info_f, m.nl, n_sites, float(np.mean(df)))
+                table_forms[form] = {"environment": env, "codon_frames_per_s": n_sites / (float(np.mean(df)) * 1e-3), "kernel_ms": float(np.mean(df)),
+                                     "products_per_model": info_f["products_run"], "table_bytes": info_f["rows_per_table_set"] * 512 * 2 if info_f["cherries"] else 0,
+                                     "context_creation_seconds": t_c, "frac": rf["frac"],
+                                     "bit_identical_to_the_default_form": bool(torch.equal(out_f.view(torch.int64), scores.view(torch.int64)))}
+                cf.close()
+                del out_f
+            except Exception as ex:
+                table_forms[form] = {"error": str(ex)[-500:]}
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+        torch.cuda.empty_cache()
     del codons, scores
 
     # the same kernel on the other two models the reference ships and BASELINE.json's configs name (53birds: configs[1]; 100vertebrates:
@@ -767,6 +812,8 @@ def main():
             out["strong"] = strong
         if other_models:
             out["other_models"] = other_models
+        if table_forms:
+            out["table_forms"] = table_forms
         if world == 1 and args.cpu_baseline_sites != 0:
             budget = args.cpu_baseline_sites
             if budget < 0:

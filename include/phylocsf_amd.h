@@ -346,7 +346,8 @@ int pcsf_build_schedule(int32_t n_nodes, const int16_t *child1, const int16_t *c
                         int32_t *stack_depth);
 /* what this context's tracks-mode kernel runs: out[0] = products per site and model of the full program (internal non-root nodes), out[1] = of
  * the program it runs (subtree tables: one less per cherry, one more less per node over a cherry and a leaf), out[2] = cherries with a pair
- * table (0: the full program), out[3] = rows of 64 doubles per table set (leaves' rows + pair rows + triple rows), out[4] = triples */
+ * table (0: the full program), out[3] = rows of 64 doubles per table set (leaves' rows + pair rows + triple rows + quad rows), out[4] = triples,
+ * out[5] = quads (nodes over two cherries or over a triple and a leaf; PCSF_TABLE_LEAVES=4).  out needs 6 entries. */
 int pcsf_tracks_program_info(const pcsf_ctx *ctx, int64_t *out);
 /* host-only: the program tracks mode runs when the tree has cherries (csrc/schedule.hpp reduce_cherries: every cherry below the root is a
  * leaf whose "codon" is the pair of its leaves' codons; its message comes from a table of 65 x 65 rows made once per context; with
@@ -357,6 +358,11 @@ int pcsf_tracks_program_info(const pcsf_ctx *ctx, int64_t *out);
 int pcsf_debug_cherry_schedule(int32_t n_nodes, const int16_t *child1, const int16_t *child2, uint32_t *program,
                                int32_t program_cap, int32_t *slot_node, int32_t *n_ops, int32_t *n_slots,
                                int32_t *stack_depth, int32_t *pairs, int32_t *n_pairs, int32_t *triples, int32_t *n_triples);
+/* host-only: the same for any table depth (max_leaves 2, 3 or 4): operands[2 k], operands[2 k + 1] = an operand id >= 8192 that the program
+ * names and the node of the tree whose message to its parent that operand's table holds (operands needs n_nodes + 1 entries). */
+int pcsf_debug_table_schedule(int32_t n_nodes, const int16_t *child1, const int16_t *child2, int32_t max_leaves, uint32_t *program,
+                              int32_t program_cap, int32_t *slot_node, int32_t *n_ops, int32_t *n_slots, int32_t *stack_depth,
+                              int32_t *operands, int32_t *n_operands);
 /* host-only: runs the lock-step optimiser (fit_find_init + Brent, src/fixed_lik.hpp:469-544) on a
  * caller-supplied objective (to be MAXIMISED), mt19937 seeded with `seed` and advanced by
  * `skip_draws` 32-bit draws; returns the evaluation points in order and the value of the LAST one. */

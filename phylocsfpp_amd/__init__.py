@@ -230,6 +230,30 @@ def build_cherry_schedule(child1, child2, triples=False):
     return out + (trips[:3 * n_trips.value].reshape(-1, 3).copy(),) if triples else out
 
 
+def build_table_schedule(child1, child2, max_leaves=3):
+    """Host-only: the program tracks mode runs with subtree tables of up to max_leaves (2, 3 or 4) leaves.  Returns (program, slot_node -- nodes
+    of the ORIGINAL tree --, stack_depth, {operand id: node whose message to its parent the operand's table holds}), or None when the tree
+    has no cherry below the root."""
+    lib = load_library()
+    c1 = np.ascontiguousarray(child1, dtype=np.int16)
+    c2 = np.ascontiguousarray(child2, dtype=np.int16)
+    n = len(c1)
+    prog = np.zeros(4 * n + 8, dtype=np.uint32)
+    slots = np.zeros(n, dtype=np.int32)
+    ops = np.zeros(2 * (n + 1), dtype=np.int32)
+    n_ops, n_slots, depth, n_operands = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    i16, i32 = C.POINTER(C.c_int16), C.POINTER(C.c_int32)
+    lib.pcsf_debug_table_schedule.argtypes = [C.c_int32, i16, i16, C.c_int32, C.POINTER(C.c_uint32), C.c_int32, i32, i32, i32, i32, i32, i32]
+    rc = lib.pcsf_debug_table_schedule(n, c1.ctypes.data_as(i16), c2.ctypes.data_as(i16), int(max_leaves), prog.ctypes.data_as(C.POINTER(C.c_uint32)), len(prog),
+                                       slots.ctypes.data_as(i32), C.byref(n_ops), C.byref(n_slots), C.byref(depth), ops.ctypes.data_as(i32), C.byref(n_operands))
+    if rc:
+        raise PcsfError(rc, lib.pcsf_last_error(None).decode())
+    if n_operands.value == 0:
+        return None
+    return (prog[:n_ops.value].copy(), slots[:n_slots.value].copy(), depth.value,
+            {int(ops[2 * k]): int(ops[2 * k + 1]) for k in range(n_operands.value)})
+
+
 class ScoringContext:
     """One model resident on one GPU (replaces the per-call PhyloCSFModel_make of src/run.hpp:38-39).
 
@@ -283,10 +307,11 @@ class ScoringContext:
     def tracks_program_info(self):
         """what the tracks-mode kernel of this context runs: products per site and model of the full program and of the program it runs, cherries
         with a pair table (0: the full program), rows per table set"""
-        out = (C.c_int64 * 5)()
+        out = (C.c_int64 * 6)()
         self._lib.pcsf_tracks_program_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         self._check(self._lib.pcsf_tracks_program_info(self._h, out))
-        return {"products_full": int(out[0]), "products_run": int(out[1]), "cherries": int(out[2]), "rows_per_table_set": int(out[3]), "triples": int(out[4])}
+        return {"products_full": int(out[0]), "products_run": int(out[1]), "cherries": int(out[2]), "rows_per_table_set": int(out[3]), "triples": int(out[4]),
+                "quads": int(out[5])}
 
     def score_sites_fixed(self, codons):
         """codons: uint8 ndarray [n_leaves, n_sites] (host) -> float64 ndarray [n_sites] of

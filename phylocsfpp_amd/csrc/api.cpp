@@ -126,6 +126,9 @@ PruneParams tracks_prune_params(const pcsf_ctx* c, int* variant_flags)
     p.n_pairs = static_cast<int>(t.pairs.size());
     p.n_free_pairs = t.n_free_pairs;
     p.n_triples = static_cast<int>(t.triples.size());
+    p.n_free_triples = t.n_free_triples;
+    p.n_quads = t.n_quads;
+    p.quad_info = t.d_quad_info.as<uint32_t>();
     p.leaf_rows = t.leaf_rows;
     if (variant_flags) *variant_flags |= 256;
     return p;
@@ -184,7 +187,8 @@ namespace {
 // messages, recorded like the full program's.  Leaves the context without them (tracks mode then runs the full program) when the tree
 // has no cherry below the root.  PCSF_TABLE_BYTES bounds the rows of both models (default 8 GiB: every tree the reference ships gets its
 // triples -- 58mammals 2.6 GB, 100vertebrates 4.4 GB); a tree whose triples do not fit keeps its cherries, one whose cherries do not fit
-// runs the full program.
+// runs the full program.  PCSF_TABLE_LEAVES=4 with a budget to match (9.1 GB per node and model) adds the nodes over two cherries / over a triple
+// and a leaf.
 int build_cherry_tables(pcsf_ctx* c, const pcsf::Vec prior[2])
 {
     (void)prior;
@@ -202,18 +206,24 @@ int build_cherry_tables(pcsf_ctx* c, const pcsf::Vec prior[2])
             return PCSF_OK;
         }
         if (!red.any()) return PCSF_OK;
-        leaf_rows = static_cast<size_t>(nl) * 65 + red.pairs.size() * pcsf::PAIR_CODES + red.triples.size() * pcsf::TRIPLE_CODES;
+        leaf_rows = static_cast<size_t>(pcsf::table_set_rows(nl, static_cast<int>(red.pairs.size()), static_cast<int>(red.triples.size()), static_cast<int>(red.quads.size())));
         // LDS of a work-group of the table form at its largest (fused front end, all-gap skipping; kernels.hip launch_impl has the same sum):
         // the codes it stages must neither pass the CU's 160 KiB nor cost the second work-group of a CU where the full program has one
         const size_t lds_base = ((2 * 32768 + ((c->schedule.program.size() + 3) & ~size_t(3)) * 4 + static_cast<size_t>(nl) * 64 + 15) & ~size_t(15)) + 256 + 64 * 9 + 16;
-        const size_t lds_tab = ((lds_base + 15) & ~size_t(15)) + ((static_cast<size_t>(red.n_free_pairs) * 128 + 15) & ~size_t(15)) + red.triples.size() * 256;
+        const size_t lds_tab = ((lds_base + 15) & ~size_t(15)) + ((static_cast<size_t>(red.n_free_pairs) * 128 + 15) & ~size_t(15)) +
+                               (static_cast<size_t>(red.n_free_triples) + red.quads.size()) * 256;
         const size_t two_per_cu = 160 * 1024 / 2 - 1560;   // (the skipping variants' static LDS beside the dynamic array)
         const bool lds_ok = lds_tab <= 158 * 1024 && (lds_tab <= two_per_cu || lds_base > two_per_cu);
-        if (lds_ok && leaf_rows * 64 * sizeof(double) * 2 <= budget && leaf_rows < 0xffffffffull) break;
-        if (red.triples.empty()) return PCSF_OK;   // not even the cherries fit
+        if (lds_ok && leaf_rows * 64 * sizeof(double) * 2 <= budget && leaf_rows < 0xffffffffull) {
+            // the rows themselves: when the device has no room for them (other contexts, other processes) the next smaller form is tried
+            const hipError_t ea = c->cherry.d_leaf_tab.reserve_exact(leaf_rows * 64 * sizeof(double) * 2);
+            if (ea == hipSuccess) break;
+            (void)hipGetLastError();
+        }
+        if (red.triples.empty() && red.quads.empty()) return PCSF_OK;   // not even the cherries fit
     }
     if (max_leaves < 2) return PCSF_OK;
-    const size_t np = red.pairs.size(), nt = red.triples.size();
+    const size_t np = red.pairs.size(), nt = red.triples.size(), nq = red.quads.size();
     pcsf_ctx::CherryTables& t = c->cherry;
     try {
         t.schedule = pcsf::build_reduced_schedule(red);
@@ -223,6 +233,8 @@ int build_cherry_tables(pcsf_ctx* c, const pcsf::Vec prior[2])
     t.pairs = red.pairs;
     t.triples = red.triples;
     t.n_free_pairs = red.n_free_pairs;
+    t.n_free_triples = red.n_free_triples;
+    t.n_quads = static_cast<int>(nq);
     t.leaf_rows = static_cast<uint32_t>(leaf_rows);
     hipError_t e;
     const auto& prog = t.schedule.program;
@@ -239,7 +251,7 @@ int build_cherry_tables(pcsf_ctx* c, const pcsf::Vec prior[2])
             return c->hip_fail(e, "pcsf_create (subtree tables: program facts)");
     }
     // fragment images: the reduced program's slots, then (scratch) the table nodes' -- cherries, then triples -- for the table kernel
-    const size_t n_tab = np + nt;
+    const size_t n_tab = np + nt + nq;
     std::vector<double> frag(static_cast<size_t>(2) * std::max(ne, 1) * pcsf::FRAG_DOUBLES), cfrag(2 * n_tab * pcsf::FRAG_DOUBLES);
     std::vector<double> leaf(static_cast<size_t>(nl) * pcsf::LEAF_TABLE_DOUBLES);
     std::vector<uint16_t> pl(2 * np);
@@ -249,7 +261,22 @@ int build_cherry_tables(pcsf_ctx* c, const pcsf::Vec prior[2])
     }
     const uint32_t pair_row0 = static_cast<uint32_t>(nl) * 65u, trip_row0 = pair_row0 + static_cast<uint32_t>(np) * pcsf::PAIR_CODES;
     std::vector<uint32_t> ti(3 * std::max<size_t>(nt, 1), 0);
-    std::vector<pcsf::CombineTable> pair_tabs(np), trip_tabs(nt);
+    std::vector<pcsf::CombineTable> pair_tabs(np), trip_tabs(nt), quad_tabs(nq);
+    const uint32_t quad_row0 = trip_row0 + static_cast<uint32_t>(nt) * pcsf::TRIPLE_CODES;
+    std::vector<uint32_t> qi(3 * std::max<size_t>(nq, 1), 0);
+    for (size_t k = 0; k < nq; ++k) {
+        const pcsf::CherryReduction::Quad& q = red.quads[k];
+        const uint32_t base = quad_row0 + static_cast<uint32_t>(k * static_cast<size_t>(pcsf::QUAD_CODES));
+        qi[3 * k] = static_cast<uint32_t>(q.leaves[0]) | (static_cast<uint32_t>(q.leaves[1]) << 16);
+        qi[3 * k + 1] = static_cast<uint32_t>(q.leaves[2]) | (static_cast<uint32_t>(q.leaves[3]) << 16);
+        qi[3 * k + 2] = base;
+        if (q.x_triple >= 0)
+            quad_tabs[k] = pcsf::CombineTable{trip_row0 + static_cast<uint32_t>(q.x_triple) * pcsf::TRIPLE_CODES, static_cast<uint32_t>(pcsf::TRIPLE_CODES), static_cast<uint32_t>(q.y) * 65u, 65u, base,
+                                              static_cast<uint32_t>(np + nt + k)};
+        else
+            quad_tabs[k] = pcsf::CombineTable{pair_row0 + static_cast<uint32_t>(q.x_pair) * pcsf::PAIR_CODES, pcsf::PAIR_CODES, pair_row0 + static_cast<uint32_t>(q.y) * pcsf::PAIR_CODES, pcsf::PAIR_CODES,
+                                              base, static_cast<uint32_t>(np + nt + k)};
+    }
     for (size_t p = 0; p < np; ++p)
         pair_tabs[p] = pcsf::CombineTable{static_cast<uint32_t>(red.pairs[p][0]) * 65u, 65u, static_cast<uint32_t>(red.pairs[p][1]) * 65u, 65u,
                                           pair_row0 + static_cast<uint32_t>(p) * pcsf::PAIR_CODES, static_cast<uint32_t>(p)};
@@ -263,8 +290,9 @@ int build_cherry_tables(pcsf_ctx* c, const pcsf::Vec prior[2])
     }
     pcsf::DeviceBuffer d_cfrag, d_tabs;
     if ((e = t.d_frag.reserve(frag.size() * sizeof(double))) != hipSuccess || (e = d_cfrag.reserve(cfrag.size() * sizeof(double))) != hipSuccess ||
-        (e = t.d_leaf_tab.reserve(leaf_rows * 64 * sizeof(double) * 2)) != hipSuccess || (e = t.d_pair_leaves.reserve(pl.size() * sizeof(uint16_t))) != hipSuccess ||
-        (e = t.d_trip_info.reserve(ti.size() * sizeof(uint32_t))) != hipSuccess || (e = d_tabs.reserve(n_tab * sizeof(pcsf::CombineTable))) != hipSuccess)
+        (e = t.d_pair_leaves.reserve(pl.size() * sizeof(uint16_t))) != hipSuccess ||
+        (e = t.d_trip_info.reserve(ti.size() * sizeof(uint32_t))) != hipSuccess || (e = t.d_quad_info.reserve(qi.size() * sizeof(uint32_t))) != hipSuccess ||
+        (e = d_tabs.reserve(n_tab * sizeof(pcsf::CombineTable))) != hipSuccess)
         return c->hip_fail(e, "hipMalloc(subtree tables)");
     for (int m = 0; m < 2; ++m) {
         const double* Pm = c->host_P.data() + static_cast<size_t>(m) * (n - 1) * 4096;
@@ -274,6 +302,8 @@ int build_cherry_tables(pcsf_ctx* c, const pcsf::Vec prior[2])
             pcsf::to_fragment_order(Pm + static_cast<size_t>(red.pairs[p][2]) * 4096, cfrag.data() + (static_cast<size_t>(m) * n_tab + p) * pcsf::FRAG_DOUBLES);
         for (size_t k = 0; k < nt; ++k)
             pcsf::to_fragment_order(Pm + static_cast<size_t>(red.triples[k][2]) * 4096, cfrag.data() + (static_cast<size_t>(m) * n_tab + np + k) * pcsf::FRAG_DOUBLES);
+        for (size_t k = 0; k < nq; ++k)
+            pcsf::to_fragment_order(Pm + static_cast<size_t>(red.quads[k].node) * 4096, cfrag.data() + (static_cast<size_t>(m) * n_tab + np + nt + k) * pcsf::FRAG_DOUBLES);
         for (int l = 0; l < nl; ++l) pcsf::to_leaf_table(Pm + static_cast<size_t>(l) * 4096, leaf.data() + static_cast<size_t>(l) * pcsf::LEAF_TABLE_DOUBLES);
         // (a synchronous copy: `leaf` is filled again for the second model)
         if ((e = hipMemcpy(t.d_leaf_tab.as<double>() + static_cast<size_t>(m) * leaf_rows * 64, leaf.data(), leaf.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess)
@@ -283,6 +313,8 @@ int build_cherry_tables(pcsf_ctx* c, const pcsf::Vec prior[2])
         (e = hipMemcpy(d_cfrag.ptr, cfrag.data(), cfrag.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(t.d_pair_leaves.ptr, pl.data(), pl.size() * sizeof(uint16_t), hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(t.d_trip_info.ptr, ti.data(), ti.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(t.d_quad_info.ptr, qi.data(), qi.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess ||
+        (nq && (e = hipMemcpy(d_tabs.as<pcsf::CombineTable>() + np + nt, quad_tabs.data(), nq * sizeof(pcsf::CombineTable), hipMemcpyHostToDevice)) != hipSuccess) ||
         (e = hipMemcpy(d_tabs.ptr, pair_tabs.data(), np * sizeof(pcsf::CombineTable), hipMemcpyHostToDevice)) != hipSuccess ||
         (nt && (e = hipMemcpy(d_tabs.as<pcsf::CombineTable>() + np, trip_tabs.data(), nt * sizeof(pcsf::CombineTable), hipMemcpyHostToDevice)) != hipSuccess))
         return c->hip_fail(e, "hipMemcpy(subtree tables)");
@@ -290,6 +322,8 @@ int build_cherry_tables(pcsf_ctx* c, const pcsf::Vec prior[2])
     if ((e = pcsf::launch_combine_tables(d_tabs.as<pcsf::CombineTable>(), static_cast<int>(np), pcsf::PAIR_CODES, d_cfrag.as<double>(), static_cast<int>(n_tab), t.d_leaf_tab.as<double>(),
                                          t.leaf_rows, c->stream)) != hipSuccess ||
         (e = pcsf::launch_combine_tables(d_tabs.as<pcsf::CombineTable>() + np, static_cast<int>(nt), pcsf::TRIPLE_CODES, d_cfrag.as<double>(), static_cast<int>(n_tab),
+                                         t.d_leaf_tab.as<double>(), t.leaf_rows, c->stream)) != hipSuccess ||
+        (e = pcsf::launch_combine_tables(d_tabs.as<pcsf::CombineTable>() + np + nt, static_cast<int>(nq), static_cast<uint32_t>(pcsf::QUAD_CODES), d_cfrag.as<double>(), static_cast<int>(n_tab),
                                          t.d_leaf_tab.as<double>(), t.leaf_rows, c->stream)) != hipSuccess ||
         (e = hipStreamSynchronize(c->stream)) != hipSuccess)
         return c->hip_fail(e, "combine_table_kernel");
@@ -529,6 +563,7 @@ int pcsf_tracks_program_info(const pcsf_ctx* c, int64_t* out)
     out[2] = c->cherry.on ? static_cast<int64_t>(c->cherry.pairs.size()) : 0;
     out[3] = c->cherry.on ? static_cast<int64_t>(c->cherry.leaf_rows) : static_cast<int64_t>(c->n_leaves) * 65;
     out[4] = c->cherry.on ? static_cast<int64_t>(c->cherry.triples.size()) : 0;
+    out[5] = c->cherry.on ? static_cast<int64_t>(c->cherry.n_quads) : 0;
     return PCSF_OK;
 }
 
@@ -555,6 +590,36 @@ int pcsf_debug_cherry_schedule(int32_t n_nodes, const int16_t* child1, const int
                 for (int k = 0; k < 3; ++k) triples[3 * p + k] = red.triples[p][k];
     } catch (const std::exception& ex) {
         g_create_error = std::string("pcsf_debug_cherry_schedule: ") + ex.what();
+        return PCSF_ERR_INVALID_ARG;
+    }
+    return PCSF_OK;
+}
+
+int pcsf_debug_table_schedule(int32_t n_nodes, const int16_t* child1, const int16_t* child2, int32_t max_leaves, uint32_t* program, int32_t program_cap, int32_t* slot_node,
+                              int32_t* n_ops, int32_t* n_slots, int32_t* stack_depth, int32_t* operands, int32_t* n_operands)
+{
+    if (!child1 || !child2 || !program || !slot_node || !n_ops || !n_slots || !stack_depth || !operands || !n_operands || max_leaves < 2 || max_leaves > 4) return PCSF_ERR_INVALID_ARG;
+    try {
+        const pcsf::CherryReduction red = pcsf::reduce_cherries(pcsf::TreeView{n_nodes, child1, child2}, max_leaves);
+        *n_operands = 0;
+        if (!red.any()) return PCSF_OK;
+        const pcsf::Schedule s = pcsf::build_reduced_schedule(red);
+        if (static_cast<int32_t>(s.program.size()) > program_cap) return PCSF_ERR_INVALID_ARG;
+        std::copy(s.program.begin(), s.program.end(), program);
+        std::copy(s.slot_node.begin(), s.slot_node.end(), slot_node);
+        *n_ops = static_cast<int32_t>(s.program.size());
+        *n_slots = static_cast<int32_t>(s.slot_node.size());
+        *stack_depth = s.stack_depth;
+        int32_t k = 0;
+        for (size_t r = 0; r < red.operand.size(); ++r)
+            if (red.operand[r] >= pcsf::PAIR_OPERAND_BASE) {
+                operands[2 * k] = red.operand[r];
+                operands[2 * k + 1] = red.node[r];
+                ++k;
+            }
+        *n_operands = k;
+    } catch (const std::exception& ex) {
+        g_create_error = std::string("pcsf_debug_table_schedule: ") + ex.what();
         return PCSF_ERR_INVALID_ARG;
     }
     return PCSF_OK;

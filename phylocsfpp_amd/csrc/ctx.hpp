@@ -46,6 +46,16 @@ struct DeviceBuffer {
         if (e == hipSuccess) bytes = n;
         return e;
     }
+    // exactly n bytes (tables of many gigabytes: no head room)
+    hipError_t reserve_exact(size_t n)
+    {
+        if (n <= bytes) return hipSuccess;
+        release();
+        const hipError_t e = hipMalloc(&ptr, n);
+        if (e == hipSuccess) bytes = n;
+        else ptr = nullptr;
+        return e;
+    }
     // like reserve(), but the first `keep` bytes of the old contents survive a growth (device-to-device copy on
     // `stream`, which the caller's later work on that stream is ordered behind)
     hipError_t reserve_keep(size_t n, size_t keep, hipStream_t stream)
@@ -166,17 +176,18 @@ struct pcsf_ctx {
         bool on = false;
         pcsf::Schedule schedule;
         std::vector<std::array<int, 3>> pairs, triples;
-        int n_free_pairs = 0;               // pairs[0 .. n_free_pairs) are operands of the program, the others lie inside triples
+        int n_free_pairs = 0;               // pairs[0 .. n_free_pairs) are operands of the program, the others lie inside triples / quads
+        int n_free_triples = 0, n_quads = 0;
         uint32_t leaf_rows = 0;             // per table set: n_leaves * 65 + pairs * 65^2 + triples * 65^3
-        pcsf::DeviceBuffer d_program, d_op_leaves, d_op_meta, d_frag, d_leaf_tab, d_gap_tab, d_pair_leaves, d_trip_info;
+        pcsf::DeviceBuffer d_program, d_op_leaves, d_op_meta, d_frag, d_leaf_tab, d_gap_tab, d_pair_leaves, d_trip_info, d_quad_info;
         void reset()
         {
             on = false;
             pairs.clear();
             triples.clear();
-            n_free_pairs = 0;
+            n_free_pairs = n_free_triples = n_quads = 0;
             leaf_rows = 0;
-            for (pcsf::DeviceBuffer* b : {&d_program, &d_op_leaves, &d_op_meta, &d_frag, &d_leaf_tab, &d_gap_tab, &d_pair_leaves, &d_trip_info}) b->release();
+            for (pcsf::DeviceBuffer* b : {&d_program, &d_op_leaves, &d_op_meta, &d_frag, &d_leaf_tab, &d_gap_tab, &d_pair_leaves, &d_trip_info, &d_quad_info}) b->release();
         }
     } cherry;
     // scratch for the host-pointer entry points

@@ -55,8 +55,9 @@ struct PruneParams {
     // cherry, >= TRIPLE_OPERAND_BASE_DEV a node over a cherry and a leaf, and every table set of leaf_tab is [n_leaves][65] rows, then
     // [n_pairs][65^2] rows, then [n_triples][65^3] rows (leaf_rows in all) of 64 doubles
     const uint16_t* pair_leaves; // [n_pairs][2]: the two leaves of every cherry; the first n_free_pairs are operands of the program
-    const uint32_t* trip_info;   // [n_triples][3]: leaf A | leaf B << 16 (its cherry), leaf C, first row of the triple's table in a table set
-    int n_pairs, n_free_pairs, n_triples;
+    const uint32_t* trip_info;   // [n_free_triples][3]: leaf A | leaf B << 16 (its cherry), leaf C, first row of the triple's table in a table set
+    const uint32_t* quad_info;   // [n_quads][3]: leaf A | leaf B << 16, leaf C | leaf D << 16 (code order), first row of the quad's table
+    int n_pairs, n_free_pairs, n_triples, n_free_triples, n_quads;   // n_pairs / n_triples: tables in the set; n_free_*: operands of the program (the first ones)
     uint32_t leaf_rows;
     uint32_t pair_lds_offset;    // set by the launcher: where the work-group's pair codes (2 bytes per free pair and site), then its triples' rows
                                  // (4 bytes per triple and site) start in its dynamic LDS
@@ -76,7 +77,7 @@ struct PruneParams {
 // + 128 (variants 0, 32, also with + 64): all-gap subtrees of a work-group's columns are skipped (needs op_leaves / op_meta)
 // + 256 (variants 0, 2, 32, with + 64 / + 128): cherry tables -- the reduced tree's program, pair rows behind the leaves' rows
 hipError_t launch_prune_fixed(const PruneParams& p, int variant, hipStream_t stream, size_t extra_lds = 0);
-constexpr uint32_t PAIR_OPERAND_BASE_DEV = 8192, TRIPLE_OPERAND_BASE_DEV = 12288, PAIR_CODES_DEV = 65 * 65;   // schedule.hpp PAIR_OPERAND_BASE / TRIPLE_OPERAND_BASE / PAIR_CODES
+constexpr uint32_t PAIR_OPERAND_BASE_DEV = 8192, TRIPLE_OPERAND_BASE_DEV = 12288, QUAD_OPERAND_BASE_DEV = 14336, PAIR_CODES_DEV = 65 * 65;   // schedule.hpp
 // One table of a table set made from two others (a leaf's 65 rows count as one): row x * y_size + y of the output = P_v (row x of X o
 // row y of Y) in leaf-row layout, by the product the pruning kernel would run.  frag: index of P_v's fragment image in the launch's array.
 struct CombineTable {
@@ -84,6 +85,12 @@ struct CombineTable {
 };
 // frag: [2][n_frag][4096]; tables of one launch must not read each other's output (cherries first, then the triples over them)
 hipError_t launch_combine_tables(const CombineTable* d_tables, int n_tables, uint32_t max_rows, const double* frag, int n_frag, double* leaf_tab, uint32_t leaf_rows, hipStream_t stream);
+// rows of a table set for a tree's tables (leaves' rows first)
+inline uint64_t table_set_rows(int n_leaves, int n_pairs, int n_triples, int n_quads)
+{
+    return static_cast<uint64_t>(n_leaves) * 65u + static_cast<uint64_t>(n_pairs) * PAIR_CODES_DEV + static_cast<uint64_t>(n_triples) * 65u * PAIR_CODES_DEV +
+           static_cast<uint64_t>(n_quads) * PAIR_CODES_DEV * PAIR_CODES_DEV;
+}
 int prune_variant_count();
 
 }  // namespace pcsf

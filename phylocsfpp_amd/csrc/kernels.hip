@@ -299,7 +299,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
     uint16_t* lpair = reinterpret_cast<uint16_t*>(lds_raw + p.pair_lds_offset);
     const uint16_t* my_pair = lpair + wave * 16 + sl;     // + pair*SITES
     uint32_t* ltrip = reinterpret_cast<uint32_t*>(lds_raw + p.pair_lds_offset + ((static_cast<uint32_t>(PAIRS ? p.n_free_pairs : 0) * SITES * 2 + 15) & ~15u));
-    const uint32_t* my_trip = ltrip + wave * 16 + sl;     // + triple*SITES
+    const uint32_t* my_trip = ltrip + wave * 16 + sl;     // + triple*SITES; the quads' rows follow the free triples' (operand QUAD_BASE + q = entry n_free_triples + q)
     (void)my_pair;
     (void)my_trip;
     if constexpr (PAIRS) {
@@ -311,10 +311,16 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
             const unsigned la = p.pair_leaves[2 * pu], lb = p.pair_leaves[2 * pu + 1];
             lpair[pu * SITES + lane] = static_cast<uint16_t>(lcod[la * SITES + lane] * 65u + lcod[lb * SITES + lane]);
         }
-        for (int t = wave; t < p.n_triples; t += NW) {
+        for (int t = wave; t < p.n_free_triples; t += NW) {
             const int tu = __builtin_amdgcn_readfirstlane(t);
             const uint32_t ab = p.trip_info[3 * tu], lc = p.trip_info[3 * tu + 1], base = p.trip_info[3 * tu + 2];
             ltrip[tu * SITES + lane] = base + (lcod[(ab & 0xffffu) * SITES + lane] * 65u + lcod[(ab >> 16) * SITES + lane]) * 65u + lcod[lc * SITES + lane];
+        }
+        for (int q = wave; q < p.n_quads; q += NW) {
+            const int qu = __builtin_amdgcn_readfirstlane(q);
+            const uint32_t ab = p.quad_info[3 * qu], cd = p.quad_info[3 * qu + 1], base = p.quad_info[3 * qu + 2];
+            const uint32_t code = ((lcod[(ab & 0xffffu) * SITES + lane] * 65u + lcod[(ab >> 16) * SITES + lane]) * 65u + lcod[(cd & 0xffffu) * SITES + lane]) * 65u + lcod[(cd >> 16) * SITES + lane];
+            ltrip[(p.n_free_triples + qu) * SITES + lane] = base + code;
         }
         if constexpr (!SKIP) __syncthreads();   // (SKIP: its own barriers below come before the first use)
     }
@@ -325,7 +331,8 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
         } else {
 #ifdef PCSF_OPERAND_BRANCHFREE
             // all three look-ups issued, the operand's kind picks one: no scalar branch in the op loop (indices clamped into their arrays)
-            const uint32_t kind = x >> 12, li = x < PAIR_OPERAND_BASE_DEV ? x : 0u, pi = kind == 2u ? x - PAIR_OPERAND_BASE_DEV : 0u, ti = kind == 3u ? x - TRIPLE_OPERAND_BASE_DEV : 0u;
+            const uint32_t kind = x >> 12, li = x < PAIR_OPERAND_BASE_DEV ? x : 0u, pi = kind == 2u ? x - PAIR_OPERAND_BASE_DEV : 0u,
+                           ti = kind == 3u ? (x < QUAD_OPERAND_BASE_DEV ? x - TRIPLE_OPERAND_BASE_DEV : static_cast<uint32_t>(p.n_free_triples) + x - QUAD_OPERAND_BASE_DEV) : 0u;
             const uint32_t c8 = my_cod[li * SITES], c16 = my_pair[pi * SITES], c32 = my_trip[ti * SITES];
             const uint32_t r_leaf = li * 65u + c8, r_pair = static_cast<uint32_t>(p.n_leaves) * 65u + pi * PAIR_CODES_DEV + c16;
             return kind < 2u ? r_leaf : (kind == 2u ? r_pair : c32);
@@ -335,7 +342,8 @@ __global__ __launch_bounds__(NW * 64, 2) void prune_fixed(const PruneParams p)
                 const uint32_t pp = x - PAIR_OPERAND_BASE_DEV;
                 return static_cast<uint32_t>(p.n_leaves) * 65u + pp * PAIR_CODES_DEV + my_pair[pp * SITES];
             }
-            return my_trip[(x - TRIPLE_OPERAND_BASE_DEV) * SITES];
+            if (x < QUAD_OPERAND_BASE_DEV) return my_trip[(x - TRIPLE_OPERAND_BASE_DEV) * SITES];
+            return my_trip[(static_cast<uint32_t>(p.n_free_triples) + x - QUAD_OPERAND_BASE_DEV) * SITES];
 #endif
         }
     };
@@ -798,8 +806,9 @@ static hipError_t launch_impl(const PruneParams& p_in, hipStream_t stream, size_
 {
     PruneParams p = p_in;
     if (SKIP && (!p.op_leaves || !p.op_meta || p.n_ops > 128 || p.n_leaves > 128)) return hipErrorInvalidValue;
-    if (PAIRS && (!p.pair_leaves || p.n_pairs <= 0 || p.n_triples < 0 || (p.n_triples > 0 && !p.trip_info) || p.n_free_pairs < 0 || p.n_free_pairs > p.n_pairs ||
-                  p.leaf_rows != static_cast<uint32_t>(p.n_leaves) * 65u + static_cast<uint32_t>(p.n_pairs) * PAIR_CODES_DEV + static_cast<uint32_t>(p.n_triples) * 65u * PAIR_CODES_DEV))
+    if (PAIRS && (!p.pair_leaves || p.n_pairs <= 0 || p.n_triples < 0 || (p.n_free_triples > 0 && !p.trip_info) || p.n_free_pairs < 0 || p.n_free_pairs > p.n_pairs ||
+                  p.n_free_triples < 0 || p.n_free_triples > p.n_triples || p.n_quads < 0 || (p.n_quads > 0 && !p.quad_info) ||
+                  p.leaf_rows != table_set_rows(p.n_leaves, p.n_pairs, p.n_triples, p.n_quads)))
         return hipErrorInvalidValue;
     const size_t sites_per_block = static_cast<size_t>(NW) * 16;
     const size_t blocks = BLOCKS ? p.n_wgs : (p.n_sites + sites_per_block - 1) / sites_per_block;
@@ -815,7 +824,7 @@ static hipError_t launch_impl(const PruneParams& p_in, hipStream_t stream, size_
     if (PAIRS) {   // the work-group's pair codes: two bytes per cherry and site
         lds = (lds + 15) & ~size_t(15);
         p.pair_lds_offset = static_cast<uint32_t>(lds);
-        lds += ((static_cast<size_t>(p.n_free_pairs) * sites_per_block * 2 + 15) & ~size_t(15)) + static_cast<size_t>(p.n_triples) * sites_per_block * 4;
+        lds += ((static_cast<size_t>(p.n_free_pairs) * sites_per_block * 2 + 15) & ~size_t(15)) + static_cast<size_t>(p.n_free_triples + p.n_quads) * sites_per_block * 4;
     }
     lds += extra_lds;
     if (lds > 160 * 1024 - (SKIP ? 2048 : 0)) return hipErrorInvalidValue;   // SKIP: 1 KiB of static LDS beside the dynamic array

@@ -215,16 +215,26 @@ struct ProgramFacts {
 // one product less per cherry -- with the pair code 65 a + b as its "codon".  One level up the same holds for a node over a cherry and
 // a leaf: its message is a row of a 65^3 table (code 65 (65 a + b) + c), made from the cherry's rows and the leaf's; two products less.
 // (58mammals: 56 products per model in the full program, 39 with the 17 cherries as leaves, 30 with the 9 triples too.)
-// An op-word operand below PAIR_OPERAND_BASE is a leaf of the original tree, PAIR_OPERAND_BASE + p the p-th pair, TRIPLE_OPERAND_BASE + t the
-// t-th triple.
-constexpr int PAIR_OPERAND_BASE = 8192, TRIPLE_OPERAND_BASE = 12288;
+// One level further (PCSF_TABLE_LEAVES=4 and room for it: 65^4 rows = 9.1 GB per node and model) a node over two cherries, or over a triple and
+// a leaf.  An op-word operand below PAIR_OPERAND_BASE is a leaf of the original tree, PAIR_OPERAND_BASE + p the p-th pair, TRIPLE_OPERAND_BASE + t
+// the t-th triple, QUAD_OPERAND_BASE + q the q-th quad.
+constexpr int PAIR_OPERAND_BASE = 8192, TRIPLE_OPERAND_BASE = 12288, QUAD_OPERAND_BASE = 14336;
 constexpr int PAIR_CODES = 65 * 65, TRIPLE_CODES = 65 * 65 * 65;
+constexpr long long QUAD_CODES = 65LL * 65 * 65 * 65;
 
 struct CherryReduction {
-    std::vector<std::array<int, 3>> pairs;     // leaf A (child1), leaf B (child2), the cherry node -- every cherry below the root: the first n_free_pairs
-                                               // are operands themselves, the others lie inside a triple (their rows are what the triple's are made from)
+    // Tables are made bottom-up and only some are operands of the program: the FREE ones come first in their lists (the kernel stages codes for
+    // those only); the others lie inside a larger table, whose rows are made from theirs.
+    std::vector<std::array<int, 3>> pairs;     // leaf A (child1), leaf B (child2), the cherry node -- every cherry below the root
     int n_free_pairs = 0;
     std::vector<std::array<int, 3>> triples;   // pair index, the third leaf, the node over them
+    int n_free_triples = 0;
+    struct Quad {
+        int x_triple;       // >= 0: X is that triple and Y the leaf `y`; -1: X is pair `x_pair` and Y pair `y`
+        int x_pair, y, node;
+        int leaves[4];      // in code order: code = ((a 65 + b) 65 + c) 65 + d
+    };
+    std::vector<Quad> quads;                   // all free
     std::vector<int16_t> child1, child2;       // the reduced tree, numbered like newick_flatten numbers a tree (leaves first, children before parents, root last)
     std::vector<int> operand;                  // [reduced leaf]: what the op words name
     std::vector<int> node;                     // [reduced node] -> node of the original tree (its branch matrix; a table leaf: the subtree's root)
@@ -232,6 +242,10 @@ struct CherryReduction {
     // the leaves of the original tree behind an operand
     std::vector<int> leaves_of(int operand_id) const
     {
+        if (operand_id >= QUAD_OPERAND_BASE) {
+            const Quad& q = quads[static_cast<size_t>(operand_id - QUAD_OPERAND_BASE)];
+            return {q.leaves[0], q.leaves[1], q.leaves[2], q.leaves[3]};
+        }
         if (operand_id >= TRIPLE_OPERAND_BASE) {
             const auto& t = triples[static_cast<size_t>(operand_id - TRIPLE_OPERAND_BASE)];
             return {pairs[static_cast<size_t>(t[0])][0], pairs[static_cast<size_t>(t[0])][1], t[1]};
@@ -241,13 +255,13 @@ struct CherryReduction {
     }
 };
 
-// max_leaves: 2 = cherries only, 3 = also the nodes over a cherry and a leaf
+// max_leaves: 2 = cherries only, 3 = also the nodes over a cherry and a leaf, 4 = also the nodes over two cherries or over a triple and a leaf
 inline CherryReduction reduce_cherries(const TreeView& t, int max_leaves = 2)
 {
     validate_tree(t);
     CherryReduction r;
     const int n = t.n_nodes, nl = t.n_leaves();
-    std::vector<int> pair_of(n, -1), table_root(n, -1);   // node -> its index in r.pairs; node or leaf -> the table leaf (node id) that absorbs it
+    std::vector<int> pair_of(n, -1), triple_of(n, -1), quad_of(n, -1);
     for (int v = nl; v < n - 1; ++v)     // (the root sends no message: nothing is absorbed into it)
         if (t.child1[v] < nl && t.child2[v] < nl) {
             pair_of[v] = static_cast<int>(r.pairs.size());
@@ -257,44 +271,102 @@ inline CherryReduction reduce_cherries(const TreeView& t, int max_leaves = 2)
         r.pairs.clear();
         return r;
     }
-    std::vector<int> triple_of(n, -1);
     if (max_leaves >= 3)
         for (int v = nl; v < n - 1; ++v) {
             const int a = t.child1[v], b = t.child2[v];
             const int pr = (a >= nl && pair_of[a] >= 0 && b < nl) ? a : ((b >= nl && pair_of[b] >= 0 && a < nl) ? b : -1);
-            if (pr < 0 || static_cast<int>(r.triples.size()) >= 16383 - TRIPLE_OPERAND_BASE) continue;
+            if (pr < 0 || static_cast<int>(r.triples.size()) >= QUAD_OPERAND_BASE - TRIPLE_OPERAND_BASE) continue;
             triple_of[v] = static_cast<int>(r.triples.size());
             r.triples.push_back({pair_of[pr], pr == a ? b : a, v});
         }
-    {   // the cherries that stay operands first (the kernel stages codes for those only)
-        std::vector<char> inner(r.pairs.size(), 0);
-        for (const auto& tr : r.triples) inner[static_cast<size_t>(tr[0])] = 1;
-        std::vector<int> moved(r.pairs.size(), -1);
+    if (max_leaves >= 4)
+        for (int v = nl; v < n - 1; ++v) {
+            const int a = t.child1[v], b = t.child2[v];
+            if (static_cast<int>(r.quads.size()) >= 16383 - QUAD_OPERAND_BASE) break;
+            CherryReduction::Quad q{};
+            q.node = v;
+            if (a >= nl && b >= nl && pair_of[a] >= 0 && pair_of[b] >= 0) {
+                q.x_triple = -1;
+                q.x_pair = pair_of[a];
+                q.y = pair_of[b];
+            } else {
+                const int tr = (a >= nl && triple_of[a] >= 0 && b < nl) ? a : ((b >= nl && triple_of[b] >= 0 && a < nl) ? b : -1);
+                if (tr < 0) continue;
+                q.x_triple = triple_of[tr];
+                q.x_pair = -1;
+                q.y = tr == a ? b : a;
+            }
+            quad_of[v] = static_cast<int>(r.quads.size());
+            r.quads.push_back(q);
+        }
+    // which tables lie inside a larger one
+    std::vector<char> inner_pair(r.pairs.size(), 0), inner_triple(r.triples.size(), 0);
+    for (const auto& q : r.quads) {
+        if (q.x_triple >= 0) inner_triple[static_cast<size_t>(q.x_triple)] = 1;
+        else inner_pair[static_cast<size_t>(q.x_pair)] = inner_pair[static_cast<size_t>(q.y)] = 1;
+    }
+    for (const auto& tr : r.triples) inner_pair[static_cast<size_t>(tr[0])] = 1;
+    // the free ones first
+    auto reorder = [](std::vector<std::array<int, 3>>& list, const std::vector<char>& inner, int& n_free) {
+        std::vector<int> moved(list.size(), -1);
         std::vector<std::array<int, 3>> ordered;
+        n_free = 0;
         for (int pass = 0; pass < 2; ++pass)
-            for (size_t p = 0; p < r.pairs.size(); ++p)
-                if (inner[p] == pass) {
-                    moved[p] = static_cast<int>(ordered.size());
-                    ordered.push_back(r.pairs[p]);
+            for (size_t k = 0; k < list.size(); ++k)
+                if (inner[k] == pass) {
+                    moved[k] = static_cast<int>(ordered.size());
+                    ordered.push_back(list[k]);
+                    if (pass == 0) ++n_free;
                 }
-        r.n_free_pairs = static_cast<int>(r.pairs.size() - r.triples.size());
-        r.pairs.swap(ordered);
-        for (auto& tr : r.triples) tr[0] = moved[static_cast<size_t>(tr[0])];
-        for (int v = nl; v < n - 1; ++v)
-            if (pair_of[v] >= 0) pair_of[v] = moved[static_cast<size_t>(pair_of[v])];
+        list.swap(ordered);
+        return moved;
+    };
+    const std::vector<int> moved_pair = reorder(r.pairs, inner_pair, r.n_free_pairs);
+    const std::vector<int> moved_triple = reorder(r.triples, inner_triple, r.n_free_triples);
+    for (auto& tr : r.triples) tr[0] = moved_pair[static_cast<size_t>(tr[0])];
+    for (auto& q : r.quads) {
+        if (q.x_triple >= 0) q.x_triple = moved_triple[static_cast<size_t>(q.x_triple)];
+        else {
+            q.x_pair = moved_pair[static_cast<size_t>(q.x_pair)];
+            q.y = moved_pair[static_cast<size_t>(q.y)];
+        }
     }
-    // who absorbs whom: a triple its pair node and three leaves, a free-standing pair its two leaves
-    for (size_t k = 0; k < r.triples.size(); ++k) {
-        const int v = r.triples[k][2], p = r.triples[k][0];
-        table_root[v] = v;
-        table_root[r.pairs[static_cast<size_t>(p)][2]] = v;
-        table_root[r.pairs[static_cast<size_t>(p)][0]] = table_root[r.pairs[static_cast<size_t>(p)][1]] = table_root[r.triples[k][1]] = v;
+    for (int v = nl; v < n - 1; ++v) {
+        if (pair_of[v] >= 0) pair_of[v] = moved_pair[static_cast<size_t>(pair_of[v])];
+        if (triple_of[v] >= 0) triple_of[v] = moved_triple[static_cast<size_t>(triple_of[v])];
     }
-    for (size_t p = 0; p < r.pairs.size(); ++p) {
-        const int v = r.pairs[p][2];
-        if (table_root[v] >= 0) continue;
-        table_root[v] = table_root[r.pairs[p][0]] = table_root[r.pairs[p][1]] = v;
+    for (auto& q : r.quads) {   // the leaves in code order: X's, then Y's
+        if (q.x_triple >= 0) {
+            const auto& tr = r.triples[static_cast<size_t>(q.x_triple)];
+            q.leaves[0] = r.pairs[static_cast<size_t>(tr[0])][0];
+            q.leaves[1] = r.pairs[static_cast<size_t>(tr[0])][1];
+            q.leaves[2] = tr[1];
+            q.leaves[3] = q.y;
+        } else {
+            q.leaves[0] = r.pairs[static_cast<size_t>(q.x_pair)][0];
+            q.leaves[1] = r.pairs[static_cast<size_t>(q.x_pair)][1];
+            q.leaves[2] = r.pairs[static_cast<size_t>(q.y)][0];
+            q.leaves[3] = r.pairs[static_cast<size_t>(q.y)][1];
+        }
     }
+    // the operands: quads, free triples, free pairs -- each absorbs the whole subtree below its node
+    std::vector<int> table_root(n, -1), operand_of(n, -1);
+    auto absorb = [&](int root_node, int operand_id) {
+        operand_of[root_node] = operand_id;
+        std::vector<int> todo{root_node};
+        while (!todo.empty()) {
+            const int v = todo.back();
+            todo.pop_back();
+            table_root[v] = root_node;
+            if (v >= nl) {
+                todo.push_back(t.child1[v]);
+                todo.push_back(t.child2[v]);
+            }
+        }
+    };
+    for (size_t k = 0; k < r.quads.size(); ++k) absorb(r.quads[k].node, QUAD_OPERAND_BASE + static_cast<int>(k));
+    for (int k = 0; k < r.n_free_triples; ++k) absorb(r.triples[static_cast<size_t>(k)][2], TRIPLE_OPERAND_BASE + k);
+    for (int k = 0; k < r.n_free_pairs; ++k) absorb(r.pairs[static_cast<size_t>(k)][2], PAIR_OPERAND_BASE + k);
     std::vector<int> new_id(n, -1);
     for (int l = 0; l < nl; ++l)
         if (table_root[l] < 0) {
@@ -305,7 +377,7 @@ inline CherryReduction reduce_cherries(const TreeView& t, int max_leaves = 2)
     for (int v = nl; v < n - 1; ++v) {
         if (table_root[v] != v) continue;
         new_id[v] = static_cast<int>(r.node.size());
-        r.operand.push_back(triple_of[v] >= 0 ? TRIPLE_OPERAND_BASE + triple_of[v] : PAIR_OPERAND_BASE + pair_of[v]);
+        r.operand.push_back(operand_of[v]);
         r.node.push_back(v);
     }
     const size_t n_red_leaves = r.node.size();

@@ -200,3 +200,42 @@ def test_tables_on_the_smallest_trees(monkeypatch):
         assert res[1][1]["products_run"] == nl - 2 - res[1][1]["cherries"] - res[1][1]["triples"]
         seen_zero_product |= res[1][1]["products_run"] == 0 and res[1][1]["cherries"] > 0
     assert seen_zero_product
+
+
+def test_quad_tables_give_the_same_bits(monkeypatch):
+    """PCSF_TABLE_LEAVES=4 (opt-in: 65^4 rows = 9.1 GB per node and model): a node over two cherries, and a node over a triple and a leaf, as
+    leaves of the program.  Two small trees with one such node each (18 GB of rows per context), against the default form and the full program."""
+    import phylocsfpp_amd as pa
+    m = pa.load_model("58mammals")
+    rng = np.random.default_rng(31)
+    trees = {
+        # leaves 0..6; ((0,1),(2,3)) is a node over two cherries; the rest keeps it away from the root
+        "two cherries": ([-1] * 7 + [0, 2, 7, 4, 10, 11], [-1] * 7 + [1, 3, 8, 5, 9, 6]),
+        # (((0,1),2),3): a triple and a leaf
+        "triple and leaf": ([-1] * 7 + [0, 7, 8, 4, 10, 11], [-1] * 7 + [1, 2, 3, 5, 9, 6]),
+    }
+    for tag, (c1, c2) in trees.items():
+        c1, c2 = np.array(c1, np.int16), np.array(c2, np.int16)
+        nl = 7
+        red = pa.build_table_schedule(c1, c2, 4)
+        assert red is not None and any(x >= 14336 for x in red[3]), tag                  # a quad operand
+        bl = rng.uniform(0.01, 0.2, size=2 * nl - 1).astype(np.float32)
+        cod = synth.synthetic_codon_columns(c1, c2, bl, m.S_c, m.pi_c, m.S_nc, m.pi_nc, 3000, seed=3)
+        cod[:, 7] = 64
+        cod[1, 100:400] = 64
+        cod[:, 1000:1200] = rng.integers(0, 65, size=(nl, 200))                          # unrelated codons: cold rows of the big table
+        got = {}
+        for form, env in (("full", {"PCSF_CHERRY_TABLES": "0"}), ("default", {}), ("quads", {"PCSF_TABLE_LEAVES": "4", "PCSF_TABLE_BYTES": str(40 << 30)})):
+            for k in ("PCSF_CHERRY_TABLES", "PCSF_TABLE_LEAVES", "PCSF_TABLE_BYTES"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            c = pa.ScoringContext(c1, c2, bl, m.S_c, m.pi_c, m.S_nc, m.pi_nc, device=0)
+            try:
+                got[form] = (c.score_sites_fixed(cod), c.tracks_program_info())
+            finally:
+                c.close()
+        assert got["quads"][1]["quads"] == 1 and got["default"][1]["quads"] == 0, (tag, got["quads"][1])
+        assert got["quads"][1]["products_run"] == got["default"][1]["products_run"] - 1
+        assert np.isfinite(got["full"][0]).all()
+        assert np.array_equal(got["full"][0], got["default"][0]) and np.array_equal(got["full"][0], got["quads"][0]), tag

@@ -398,3 +398,99 @@ def test_cherry_table_programs_of_random_trees_use_every_leaf_once():
                     cur = cur | (deep_stk.pop() if deep else stk[code - F_POP0])
         assert sorted(used) == list(range(nl)) and slot == len(slots) == nl - 2 - len(cherries)
     assert with_cherries > 250
+
+
+def _interpret_tables(prog, slots, operand_node, c1, c2, nl, P, prior, cod_col):
+    """a reduced program in numpy for any table depth: an operand >= 8192 stands for the message the node `operand_node[x]` of the ORIGINAL
+    tree sends its parent, computed here by plain recursion (what the context keeps per code)"""
+    def leafmsg(l):
+        c = cod_col[l]
+        return P[l][:, c] if c < 64 else np.array([P[l][a, :].sum() for a in range(64)])
+
+    def message(v):
+        return leafmsg(v) if v < nl else P[v] @ (message(c1[v]) * message(c2[v]))
+
+    def operand(x):
+        return leafmsg(x) if x < PAIR_BASE else message(operand_node[x])
+    cur, stk, slot, z = None, {}, 0, None
+    for o in prog:
+        code, a, b = int(o >> 28), int((o >> 14) & 0x3fff), int(o & 0x3fff)
+        if code == F_CHERRY:
+            cur = operand(a) * operand(b)
+        elif code == F_ROOT:
+            z = float(prior @ cur)
+        else:
+            acc = P[slots[slot]] @ cur
+            slot += 1
+            if code == F_MM_LEAF:
+                cur = acc * operand(a)
+            elif F_PUSH0 <= code < F_POP0:
+                stk[code - F_PUSH0] = acc
+                cur = operand(a) * operand(b)
+            else:
+                cur = stk[code - F_POP0] * acc
+    assert slot == len(slots)
+    return z
+
+
+@pytest.mark.parametrize("max_leaves", [2, 3, 4])
+@pytest.mark.parametrize("model", ["53birds", "58mammals", "100vertebrates"])
+def test_table_programs_of_every_depth_reproduce_the_oracle(model, max_leaves, oracle_models):
+    m = oracle_models(model)
+    prog, slots, depth, operand_node = pa.build_table_schedule(m.child1, m.child2, max_leaves)
+    size = [1] * m.nl + [0] * (m.n - m.nl)
+    for v in range(m.nl, m.n):
+        size[v] = size[m.child1[v]] + size[m.child2[v]]
+    # the operands are exactly the maximal subtrees of at most max_leaves leaves that are chains of (table, leaf) or two cherries
+    assert all(2 <= size[v] <= max_leaves for v in operand_node.values())
+    absorbed = sum(size[v] - 1 for v in operand_node.values())
+    assert len(slots) == m.nl - 2 - absorbed
+    want = {2: {"53birds": 39, "58mammals": 39, "100vertebrates": 70}, 3: {"53birds": 32, "58mammals": 30, "100vertebrates": 55},
+            4: {"53birds": 28, "58mammals": 25, "100vertebrates": 47}}[max_leaves][model]
+    assert len(slots) == want
+    qd = m.qdiag(True)
+    rc, P = m.all_P(qd, 1.0)
+    assert rc == 0
+    prior = np.array(qd.prior)
+    cod = synth.synthetic_codon_columns(m.child1, m.child2, m.branch_len, m.S_c, m.pi_c, m.S_nc, m.pi_nc, 6, seed=9)
+    cod[::4, 1] = 64
+    lpr, anc = C.c_double(), C.c_double()
+    per = np.empty(cod.shape[1])
+    ob.lib().po_lpr_leaves(C.byref(qd), C.byref(m.m.tree), 1.0, cod.ctypes.data_as(C.POINTER(C.c_uint8)), cod.shape[1],
+                           cod.shape[1], 0, C.byref(lpr), C.byref(anc), per.ctypes.data_as(C.POINTER(C.c_double)))
+    for s in range(cod.shape[1]):
+        z = _interpret_tables(prog, slots, operand_node, m.child1, m.child2, m.nl, P, prior, cod[:, s])
+        assert abs(np.log(z) - per[s]) < 1e-11
+
+
+def test_table_programs_of_random_trees_cover_every_leaf_and_edge_once():
+    rng = np.random.default_rng(17)
+    for _ in range(300):
+        nl = int(rng.integers(3, 40))
+        c1, c2 = _random_tree(nl, rng)
+        max_leaves = int(rng.integers(2, 5))
+        red = pa.build_table_schedule(c1, c2, max_leaves)
+        if red is None:
+            continue
+        prog, slots, depth, operand_node = red
+
+        def below(v):
+            return {v} if v < nl else below(c1[v]) | below(c2[v])
+
+        def inner(v):
+            return set() if v < nl else {v} | inner(c1[v]) | inner(c2[v])
+        covered_leaves, covered_nodes = [], set(int(v) for v in slots)
+        for o in prog:
+            code, a, b = int(o >> 28), int((o >> 14) & 0x3fff), int(o & 0x3fff)
+            ops = [a, b] if code == F_CHERRY or F_PUSH0 <= code < F_POP0 else ([a] if code == F_MM_LEAF else [])
+            for x in ops:
+                if x < PAIR_BASE:
+                    covered_leaves.append(x)
+                else:
+                    v = operand_node[x]
+                    assert len(below(v)) <= max_leaves
+                    covered_leaves += sorted(below(v))
+                    assert not (inner(v) & covered_nodes)
+                    covered_nodes |= inner(v)
+        assert sorted(covered_leaves) == list(range(nl))
+        assert covered_nodes == set(range(nl, 2 * nl - 2))      # every internal node but the root: by a product or inside a table

@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
-BENCH="python3 bench.py --steps 5 --warmup 1 --cpu-baseline-sites 0 --strong-steps 0 --other-models 0"   # the 58mammals launches only: the statistics are per kernel NAME
+BENCH="python3 bench.py --steps 5 --warmup 1 --cpu-baseline-sites 0 --strong-steps 0 --other-models 0 --table-forms 0"   # the 58mammals launches only: the statistics are per kernel NAME
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $BENCH > $OUT/pmc_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
