@@ -33,7 +33,7 @@ inline int usage(const char* prog)
             "                  [--output-phylo 0|1] [--output-regions 0|1] [--genome-length N --coding-exons FILE | --hmm-params P]\n"
             "                  [--species A,B,...] [--mapping FILE] [--species-aliases FILE] [--device N | --devices N,M,...]\n"
             "                  [--threads N] [--window-bytes N] [--batch-sites N] [--contexts-per-device N] [--host-bls 0|1]\n"
-            "                  [--ranks N [--gather-root-text 0|1]]\n"
+            "                  [--ranks N [--gather-root-text 0|1]] [--table-leaves 2|3|4] [--table-bytes N]\n"
             "                  <model prefix> <alignment.maf>...\n"
             "  %s score-msa    [--strategy fixed|mle|omega|fixed_mean] [--comp-phylo 0|1] [--comp-anc 0|1] [--comp-bls 0|1]\n"
             "                  [--output DIR] [--species A,B,...] [--mapping FILE] [--species-aliases FILE] [--device N | --devices N,M,...]\n"
@@ -43,6 +43,8 @@ inline int usage(const char* prog)
             "                  (build-tracks also reads the packed file: same tracks, no text parsing)\n"
             "--hmm-params: coding prior, mean coding length (codons), 3 non-coding weights, 3 non-coding mean lengths (codons)\n"
             "--species reduces the model's tree to the named species (tree labels or their other names)\n"
+            "--table-leaves / --table-bytes: how far the scoring contexts' subtree tables go (default 3 leaves within 8 GiB; 4 leaves need ~9 GB per\n"
+            "           node and model -- 94 GB for 58mammals -- and pay from about a gigabase of input); the scores do not depend on it\n"
             "--ranks N: build-tracks as N processes, one per GPU (--devices lists them; default 0..N-1): rank r scores the r-th of N byte ranges\n"
             "           of every input, the ranks' text is gathered onto rank 0's GPU over RCCL and rank 0 writes the files\n"
             "<model prefix> names <prefix>_coding.ECM, <prefix>_noncoding.ECM and <prefix>.nh\n"
@@ -327,6 +329,8 @@ inline int cli_main(int argc, char** argv, const BackendFactory& make_backend, b
         else if (k == "--species") species = v;
         else if (k == "--mapping") mapping = v;
         else if (k == "--context-model") context_model = v;   // smooth-tracks: a model to make a scoring context with, for the device recurrences
+        else if (k == "--table-leaves") setenv("PCSF_TABLE_LEAVES", v.c_str(), 1);   // how far the scoring contexts' subtree tables go (2, 3 or 4 leaves; include/phylocsf_amd.h)
+        else if (k == "--table-bytes") setenv("PCSF_TABLE_BYTES", v.c_str(), 1);     // ... and the device memory their rows may take
         else if (k == "--ranks") n_ranks = atoi(v.c_str());
         else if (k == "--gather-root-text") bt.gather_root_text = parse_bool(v);   // rank 0's own text through the gather too (a rehearsal on one GPU)
         else if (k == "--device") { devices = {atoi(v.c_str())}; devices_given = true; }

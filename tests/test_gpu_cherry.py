@@ -239,3 +239,30 @@ def test_quad_tables_give_the_same_bits(monkeypatch):
         assert got["quads"][1]["products_run"] == got["default"][1]["products_run"] - 1
         assert np.isfinite(got["full"][0]).all()
         assert np.array_equal(got["full"][0], got["default"][0]) and np.array_equal(got["full"][0], got["quads"][0]), tag
+
+
+@pytest.mark.parametrize("form", ["full", "leaves2", "default"])
+def test_command_line_writes_the_golden_tracks_in_every_form(tmp_path, form):
+    """phylocsf-amd build-tracks on the reference's example MAF under --table-leaves 2, the default, and PCSF_CHERRY_TABLES=0: the reference's
+    golden files, byte for byte (six-frame entry point, fused front end, all-gap subtrees skipped, text formatted on the device)."""
+    import gzip
+    import shutil
+    import subprocess
+    gold = os.path.join(ROOT, "tests", "golden")
+    cli = os.path.join(ROOT, "phylocsfpp_amd", "host", "phylocsf-amd")
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(cli)])
+    maf = tmp_path / "galGal6.maf"
+    with gzip.open(os.path.join(gold, "build-tracks", "galGal6_chr22_25_28_each_30k_bases.maf.gz"), "rb") as fi, open(maf, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    out = tmp_path / "out"
+    env = dict(os.environ)
+    env.pop("PCSF_CHERRY_TABLES", None)
+    extra = []
+    if form == "full":
+        env["PCSF_CHERRY_TABLES"] = "0"
+    elif form == "leaves2":
+        extra = ["--table-leaves", "2"]
+    subprocess.check_call([cli, "build-tracks", "--output", str(out)] + extra + [os.path.join(gold, "models", "53birds"), str(maf)], env=env, stderr=subprocess.DEVNULL)
+    for n in ["PhyloCSFpower"] + ["PhyloCSFRaw%s%d" % (s, f) for s in "+-" for f in (1, 2, 3)]:
+        want = gzip.open(os.path.join(gold, "build-tracks", n + ".wig.gz"), "rb").read()
+        assert open(out / (n + ".wig"), "rb").read() == want, (form, n)
