@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Differential run of the host layer against the reference's own code (oracle/_ref/ref_harness; only where /root/reference
 exists): random corner-case MAFs (tests/golden/make_ref_vectors.py's generator with other seeds) through the reference's
-reader / power-track loop and through `oracle_cli dump-alignments` / `build-tracks`, compared byte for byte.
+reader / power-track loop and through `oracle_cli dump-alignments` / `build-tracks`, compared byte for byte; the smoothing pass on random
+tracks and parameters; and build-tracks --ranks 2 / 3 / 5 on the same MAFs against the single process.
 
   python tools/fuzz_against_reference.py [first_seed] [n_seeds]
 """
@@ -79,6 +80,26 @@ def main():
                 if open(os.path.join(dref, "PhyloCSF%s%s" % (t, e))).read() != open(os.path.join(dmine, "PhyloCSF%s%s" % (t, e))).read():
                     bad += 1
                     print("seed %d: PhyloCSF%s%s differs (%s)" % (seed, t, e, work), flush=True)
+    # one process per rank (build-tracks --ranks N, the test command line's file-based gather): the same corner-case MAFs cut into 2 / 3 / 5
+    # byte ranges -- break points, discontinuities and near-empty ranks included -- against the single process
+    env = dict(os.environ, PCSF_ORACLE_BACKEND_FAKE="1")
+    for seed in range(first, first + n):
+        rng = np.random.default_rng(seed)
+        style = dict(blocks=int(rng.integers(60, 400)), cols_max=int(rng.choice([2, 4, 30, 300, 3000])), skip_prob=float(rng.choice([0.0, 0.02, 0.25, 0.9])),
+                     absent_prob=float(rng.choice([0.2, 0.7, 0.97])), start=int(rng.choice([0, 5, 999_400, 999_990, 1_999_000, 2_999_999 - 4000])),
+                     chrom_len=int(rng.choice([4_000_000, 250_000_000, 2**31 - 1])), ref_only_prob=float(rng.choice([0.0, 0.5, 1.0])))
+        path = os.path.join(work, "r.maf")
+        open(path, "w").write(mk.corner_maf(rng, labels, True, **style))
+        subprocess.check_call([CLI, "build-tracks", "--output", os.path.join(work, "plain"), birds, path], stderr=subprocess.DEVNULL, env=env)
+        for ranks in (2, 3, 5):
+            out = os.path.join(work, "ranks%d" % ranks)
+            extra = ["--gather-root-text", "1"] if ranks == 3 else []
+            subprocess.check_call([CLI, "build-tracks", "--output", out, "--ranks", str(ranks), "--window-bytes", "70000", "--batch-sites", "3000"] + extra + [birds, path],
+                                  stderr=subprocess.DEVNULL, env=env)
+            for name in os.listdir(os.path.join(work, "plain")):
+                if open(os.path.join(work, "plain", name), "rb").read() != open(os.path.join(out, name), "rb").read():
+                    bad += 1
+                    print("seed %d, %d ranks: %s differs from the single process's" % (seed, ranks, name), flush=True)
     print("%d seeds, %d differences" % (n, bad))
     return 1 if bad else 0
 
