@@ -61,6 +61,7 @@ METRIC = "alignment codons/sec (build-tracks, 58mammals) at 1/2/4/8 MI355X"
 E2E_BASES = 1_000_000               # BASELINE.json configs[2]
 E2E_SEED = 20261002
 E2E_TILES = 10                      # steady-state leg: the segment tiled ten times (10 Mb, ~0.9 GB of text)
+CLI_TIMEOUT_S = 900                # a build-tracks child of the bench that takes longer than this is ended (with its process group)
 CLI = os.path.join(ROOT, "phylocsfpp_amd", "host", "phylocsf-amd")
 ORACLE_CLI = os.path.join(ROOT, "oracle", "_build", "oracle_cli")
 
@@ -172,8 +173,24 @@ def run_cli(binary, maf, out_dir, extra_args=(), env=None):
     os.makedirs(out_dir, exist_ok=True)
     cmd = [binary, "build-tracks", "--output", out_dir] + list(extra_args) + [MODEL_PREFIX, maf]
     t0 = time.perf_counter()
-    p = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    # in a session of its own: a run that hangs (a --ranks run whose ranks wait for each other) is ended as a whole -- the launcher and its ranks
+    # are one process group -- instead of holding up the bench
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    try:
+        out_text, err_text = proc.communicate(timeout=CLI_TIMEOUT_S)
+    except subprocess.TimeoutExpired:
+        import signal
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        out_text, err_text = proc.communicate()
+        raise RuntimeError("%s did not finish within %d s: %s" % (" ".join(cmd), CLI_TIMEOUT_S, err_text[-1500:]))
     wall = time.perf_counter() - t0
+
+    class _Done:
+        returncode, stdout, stderr = proc.returncode, out_text, err_text
+    p = _Done
     if p.returncode != 0:
         raise RuntimeError("%s failed (%d): %s" % (" ".join(cmd), p.returncode, p.stderr[-2000:]))
     a, s = STATS_RE.search(p.stderr), SECONDS_RE.search(p.stderr)
