@@ -92,7 +92,12 @@ const char *pcsf_model_label(const pcsf_model *model, int32_t node);
 int32_t pcsf_model_leaf_of(const pcsf_model *model, const char *species_name);
 
 /* Replaces PhyloCSFModel_make x2 (src/run.hpp:38-39): builds Q, its eigen-system and the
- * 2*(n-1) branch matrices once and keeps them resident in HBM.  device_id: HIP ordinal. */
+ * 2*(n-1) branch matrices once and keeps them resident in HBM.  device_id: HIP ordinal.
+ * Also made here, once: the subtree tables of tracks mode -- for every cherry of the tree (and every node over a cherry and a leaf) the
+ * message it sends its parent, per codon pair (triple), computed by the pruning kernel's own product: per-codon scoring then runs one
+ * matrix product less per such node and model with the same bits (58mammals: 30 instead of 56; 2.6 GB of device memory).  Environment,
+ * read here: PCSF_CHERRY_TABLES=0 (none), PCSF_TABLE_LEAVES=2|3|4 (default 3), PCSF_TABLE_BYTES (default 8 GiB); pcsf_tracks_program_info
+ * reports what a context uses. */
 int pcsf_create(pcsf_ctx **out, const pcsf_model_desc *model, int device_id);
 void pcsf_destroy(pcsf_ctx *ctx);
 /* message of the last failure on this context (or of the last failed pcsf_create if ctx==NULL) */
