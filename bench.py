@@ -62,6 +62,7 @@ E2E_BASES = 1_000_000               # BASELINE.json configs[2]
 E2E_SEED = 20261002
 E2E_TILES = 10                      # steady-state leg: the segment tiled ten times (10 Mb, ~0.9 GB of text)
 CLI_TIMEOUT_S = 900                # a build-tracks child of the bench that takes longer than this is ended (with its process group)
+RANKS_TIMEOUT_S = 240              # ... and the --ranks legs (seconds of work): a communicator that never forms must not cost the bench its time limit
 CLI = os.path.join(ROOT, "phylocsfpp_amd", "host", "phylocsf-amd")
 ORACLE_CLI = os.path.join(ROOT, "oracle", "_build", "oracle_cli")
 
@@ -168,7 +169,7 @@ RANK_RE = re.compile(r"\[rank (\d+) of (\d+), device (\d+)\] gather ([\d.]+) s(?
 STARTUP_RE = re.compile(r"start-up seconds: options \+ model files ([\d.]+), first scoring context ([\d.]+)")
 
 
-def run_cli(binary, maf, out_dir, extra_args=(), env=None):
+def run_cli(binary, maf, out_dir, extra_args=(), env=None, timeout_s=None):
     """One build-tracks run in a child process; returns the driver's own statistics and the process wall time."""
     os.makedirs(out_dir, exist_ok=True)
     cmd = [binary, "build-tracks", "--output", out_dir] + list(extra_args) + [MODEL_PREFIX, maf]
@@ -176,8 +177,9 @@ def run_cli(binary, maf, out_dir, extra_args=(), env=None):
     # in a session of its own: a run that hangs (a --ranks run whose ranks wait for each other) is ended as a whole -- the launcher and its ranks
     # are one process group -- instead of holding up the bench
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    timeout_s = timeout_s or CLI_TIMEOUT_S
     try:
-        out_text, err_text = proc.communicate(timeout=CLI_TIMEOUT_S)
+        out_text, err_text = proc.communicate(timeout=timeout_s)
     except subprocess.TimeoutExpired:
         import signal
         try:
@@ -185,7 +187,7 @@ def run_cli(binary, maf, out_dir, extra_args=(), env=None):
         except OSError:
             pass
         out_text, err_text = proc.communicate()
-        raise RuntimeError("%s did not finish within %d s: %s" % (" ".join(cmd), CLI_TIMEOUT_S, err_text[-1500:]))
+        raise RuntimeError("%s did not finish within %d s: %s" % (" ".join(cmd), timeout_s, err_text[-1500:]))
     wall = time.perf_counter() - t0
 
     class _Done:
@@ -318,7 +320,8 @@ def end_to_end(device, runs, cpu_rate_all_cores, work_dir):
         # per GPU (--ranks 1), every batch's text kept on the device, one grouped RCCL send / receive (the root's text to itself), the files
         # written from what came back -- against the plain run's files
         try:
-            rk = min([run_cli(CLI, big, os.path.join(work_dir, "gpu_big_ranks"), ["--devices", str(device), "--ranks", "1", "--gather-root-text", "1"]) for _ in range(2)],
+            rk = min([run_cli(CLI, big, os.path.join(work_dir, "gpu_big_ranks"), ["--devices", str(device), "--ranks", "1", "--gather-root-text", "1"],
+                                  timeout_s=RANKS_TIMEOUT_S) for _ in range(2)],
                      key=lambda r: r["process_wall_seconds"])
             e2e["steady_state"]["ranks_rehearsal"] = {
                 "command": "phylocsf-amd build-tracks --ranks 1 --gather-root-text 1 58mammals <maf>", "ranks": rk["ranks"], "seconds": rk["seconds"],
@@ -382,7 +385,8 @@ def end_to_end_multi(n_gpus, work_dir):
                                # one PROCESS per GPU, the ranks' wig text gathered onto rank 0's GPU over RCCL (csrc/comm.cpp): north_star's form
                                ("ranks_rccl", all_devs, ["--ranks", str(n_gpus)])):
         try:
-            runs = [run_cli(CLI, big, os.path.join(work_dir, "gpu_multi_" + label), ["--devices", devs] + extra) for _ in range(2)]
+            runs = [run_cli(CLI, big, os.path.join(work_dir, "gpu_multi_" + label), ["--devices", devs] + extra,
+                            timeout_s=RANKS_TIMEOUT_S if label == "ranks_rccl" else None) for _ in range(2)]
         except Exception as ex:
             if label != "ranks_rccl":
                 raise
